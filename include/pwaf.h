@@ -1,0 +1,264 @@
+/*
+ * pwaf.h — C ABI of the MI355X batched WAF rule-matching engine (libpwaf.so).
+ *
+ * This is the drop-in boundary for ONE hot path of pingooio/pingoo: the per-request
+ * rule evaluation that the reference runs inline in its hyper request closure.
+ * The reference has no FFI/plugin seam for this path, so every entry
+ * point below cites the reference code it replaces. All citations are relative to
+ * the reference tree.
+ *
+ *   reference construct                                        replaced by
+ *   ---------------------------------------------------------  ---------------------------
+ *   rules::compile_expression        rules/rules.rs:45-53      pwaf_compile_expression
+ *   rules::validate_expression       rules/rules.rs:55-77      pwaf_validate_expression
+ *   Vec<Rule> + lists + GeoipDB      pingoo/server.rs:40-47,76 pwaf_engine_create
+ *   rule loop + gates                http_listener.rs:196-264  pwaf_evaluate_batch / _one
+ *   Rule::match_request              pingoo/rules.rs:37-51     (inside the batch evaluation)
+ *   GeoipDB::lookup                  pingoo/geoip.rs:73-91     (device trie, or caller-supplied asn/country)
+ *   get_host / get_path / UA derive  http_listener.rs:140-165,284-296; http_utils.rs:114-116
+ *                                                              pwaf_derive_host / _path / _user_agent
+ *
+ * Plain pointers and sizes only; no C++/torch types. Never aborts across the ABI:
+ * every failure is an int status (<0) plus pwaf_last_error().
+ */
+#ifndef PWAF_H
+#define PWAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWAF_ABI_VERSION 1u
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define PWAF_OK 0
+#define PWAF_E_INVALID_ARG (-1)  /* NULL pointer, bad struct_size, bad enum value            */
+#define PWAF_E_SYNTAX (-2)       /* == rules::Error::ExpressionIsNotValid (rules/rules.rs:41) */
+#define PWAF_E_UNSUPPORTED (-3)  /* valid expression outside the device-compilable subset     */
+#define PWAF_E_LIST (-4)         /* list item does not parse (pingoo/lists.rs:93-108)         */
+#define PWAF_E_DEVICE (-5)       /* HIP error / no GPU: host may fail open                    */
+#define PWAF_E_BATCH (-6)        /* malformed batch (offsets not monotone, bad country, ...)  */
+#define PWAF_E_NOMEM (-7)
+
+/* ---- verdict vocabulary (rules::Action, rules/rules.rs:30-35) ------------------------ */
+#define PWAF_ACTION_ALLOW 0u   /* no rule fired: proceed to routing (http_listener.rs:266)   */
+#define PWAF_ACTION_BLOCK 1u   /* Action::Block {}   -> 403 (http_listener.rs:255)           */
+#define PWAF_ACTION_CAPTCHA 2u /* Action::Captcha {} -> captcha page (http_listener.rs:256)  */
+#define PWAF_ACTION_BYPASS 3u  /* path under /__pingoo/captcha: rules skipped (:200-204)     */
+
+#define PWAF_RULE_NONE 0xFFFFFFFFu             /* verdict not caused by a rule (Allow)       */
+#define PWAF_RULE_UA_GATE 0xFFFFFFFEu          /* UA empty or >=256 B (http_listener.rs:196) */
+#define PWAF_RULE_CAPTCHA_ENDPOINT 0xFFFFFFFDu /* http_listener.rs:200                        */
+
+/* action kinds inside a rule description (serde tag "action": block | captcha) */
+#define PWAF_RULE_ACTION_BLOCK 1u
+#define PWAF_RULE_ACTION_CAPTCHA 2u
+
+typedef struct pwaf_engine pwaf_engine;   /* compiled rules + device tables (immutable, thread-safe) */
+typedef struct pwaf_program pwaf_program; /* host-side compiled form only (no GPU needed)            */
+
+/* One rule == pingoo::rules::Rule {name, expression: Option<Program>, actions} (pingoo/rules.rs:9-14).
+ * Array order == evaluation order (first match wins, http_listener.rs:251-264). */
+typedef struct pwaf_rule_desc {
+    const char *name;       /* NUL-terminated, for diagnostics                         */
+    const char *expression; /* NUL-terminated; NULL == match-all (pingoo/rules.rs:48-50) */
+    const uint8_t *actions; /* PWAF_RULE_ACTION_*, in order                            */
+    uint32_t n_actions;
+    uint32_t reserved;
+} pwaf_rule_desc;
+
+/* One list == pingoo/lists.rs:11-15. Items are the raw CSV column-0 strings; the engine trims
+ * them and parses Int / IpNetwork exactly where the reference does (lists.rs:90-108). */
+#define PWAF_LIST_STRING 0u
+#define PWAF_LIST_INT 1u
+#define PWAF_LIST_IP 2u
+typedef struct pwaf_list_desc {
+    const char *name;
+    uint32_t type;
+    uint32_t n_items;
+    const char *const *items;
+} pwaf_list_desc;
+
+/* GeoIP prefix table: the decoded content of a MaxMind DB as the reference consumes it
+ * (pingoo/geoip.rs:17-23: asn u32, country 2 x 'A'..'Z'). Longest prefix wins. */
+typedef struct pwaf_geoip_entry {
+    uint8_t addr[16];  /* v4: first 4 bytes, network order; v6: all 16 */
+    uint8_t prefix_len;
+    uint8_t is_v6;
+    uint8_t country[2];
+    uint32_t asn;
+} pwaf_geoip_entry;
+typedef struct pwaf_geoip_table {
+    const pwaf_geoip_entry *entries;
+    size_t n_entries;
+} pwaf_geoip_table;
+
+#define PWAF_OPT_NO_UA_GATE 1u        /* skip gate A (http_listener.rs:196-198)             */
+#define PWAF_OPT_NO_CAPTCHA_BYPASS 2u /* skip gate B (http_listener.rs:200-204)             */
+typedef struct pwaf_options {
+    uint32_t struct_size; /* sizeof(pwaf_options) */
+    uint32_t flags;
+    int32_t device;            /* HIP device ordinal, -1 = current device                 */
+    uint32_t lds_table_budget; /* bytes of LDS one DFA table may use; 0 = default         */
+    uint32_t max_dfa_states;   /* per DFA group; 0 = default (derived from the LDS budget) */
+    uint32_t reserved[3];
+} pwaf_options;
+
+/* Per-rule diagnostics of engine creation. */
+typedef struct pwaf_compile_error {
+    int32_t code;        /* PWAF_E_* */
+    uint32_t rule_index; /* offending rule, or 0xFFFFFFFF */
+    char message[248];
+} pwaf_compile_error;
+
+/* ---- the batch: struct-of-arrays, one request per index --------------------------------
+ * String field i of request r is data[offsets[r] .. offsets[r+1]). offsets has n+1 entries and is
+ * non-decreasing, so each field's bytes are contiguous in request order (field-major arena).
+ * `data` must be readable for 16 bytes past offsets[n] (PWAF_ARENA_PAD) when memory == DEVICE.
+ * Field meaning == RequestData / ClientData (pingoo/rules.rs:16-34) AFTER the reference's own
+ * derivation (pwaf_derive_* below). */
+#define PWAF_FIELD_HOST 0
+#define PWAF_FIELD_URL 1
+#define PWAF_FIELD_PATH 2
+#define PWAF_FIELD_METHOD 3
+#define PWAF_FIELD_USER_AGENT 4
+#define PWAF_N_FIELDS 5
+#define PWAF_ARENA_PAD 16u
+
+#define PWAF_MEM_HOST 0u
+#define PWAF_MEM_DEVICE 1u
+
+#define PWAF_FLAG_CAPTCHA_VERIFIED 1u /* http_listener.rs:222-236, decided on the host (JWT) */
+
+typedef struct pwaf_strcol {
+    const uint8_t *data;
+    const uint32_t *offsets; /* n+1 */
+} pwaf_strcol;
+
+typedef struct pwaf_batch {
+    uint32_t struct_size; /* sizeof(pwaf_batch) */
+    uint32_t n;
+    uint32_t memory; /* PWAF_MEM_HOST | PWAF_MEM_DEVICE: where EVERY pointer below lives */
+    uint32_t reserved;
+    pwaf_strcol field[PWAF_N_FIELDS];
+    const uint8_t *ip;       /* n x 16; IPv4 in bytes 0..3 (network order), rest ignored  */
+    const uint8_t *ip_is_v6; /* n                                                        */
+    const uint16_t *port;    /* n; client.remote_port                                    */
+    const uint8_t *flags;    /* n; PWAF_FLAG_*                                           */
+    /* Optional pre-computed GeoIP (both or neither). When NULL the engine looks the ip up in its
+     * own table on the device, or uses {0,"XX"} if it has none (geoip.rs:111-118). */
+    const uint32_t *asn;     /* n */
+    const uint16_t *country; /* n; two bytes 'A'..'Z' in memory order */
+} pwaf_batch;
+
+typedef struct pwaf_verdict {
+    uint8_t action; /* PWAF_ACTION_* */
+    uint8_t pad[3];
+    uint32_t rule_idx; /* index into the rule array, or PWAF_RULE_* */
+} pwaf_verdict;
+
+typedef struct pwaf_counts {
+    uint64_t by_action[4]; /* indexed by PWAF_ACTION_* */
+} pwaf_counts;
+
+/* One request, for the evaluate(Request)->Action convenience wrapper. */
+typedef struct pwaf_request {
+    const char *host, *url, *path, *method, *user_agent; /* not NUL-terminated */
+    uint32_t host_len, url_len, path_len, method_len, user_agent_len;
+    uint8_t ip[16];
+    uint8_t ip_is_v6;
+    uint8_t flags;
+    uint16_t port;
+    uint8_t has_geoip; /* 1: asn/country below are valid */
+    uint8_t country[2];
+    uint8_t pad;
+    uint32_t asn;
+} pwaf_request;
+
+/* ---- expression front-end (no GPU needed) ------------------------------------------------ */
+/* rules::compile_expression (rules/rules.rs:45-53): syntax only. 0 or PWAF_E_SYNTAX. */
+int pwaf_compile_expression(const char *expression, char *errbuf, size_t errbuf_len);
+/* rules::validate_expression (rules/rules.rs:55-77): also rejects "" and the `in` operator. */
+int pwaf_validate_expression(const char *expression, char *errbuf, size_t errbuf_len);
+
+/* ---- host-side compilation only (used by engine_create; exported for inspection/tests) ---- */
+int pwaf_program_compile(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_list_desc *lists,
+                         size_t n_lists, const pwaf_geoip_table *geoip, const pwaf_options *opts,
+                         pwaf_program **out, pwaf_compile_error *err);
+void pwaf_program_destroy(pwaf_program *);
+/* Serialises the compiled tables as a self-describing little-endian blob;
+ * returns the byte size; copies at most `cap` bytes into `buf` (buf may be NULL to query). */
+size_t pwaf_program_dump(const pwaf_program *, uint8_t *buf, size_t cap);
+/* Number of per-rule warnings (statically-erroring expressions that can never match,
+ * pingoo/rules.rs:41-45) and their text. */
+size_t pwaf_program_warning_count(const pwaf_program *);
+const char *pwaf_program_warning(const pwaf_program *, size_t i);
+
+/* ---- engine ------------------------------------------------------------------------------ */
+int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_list_desc *lists,
+                       size_t n_lists, const pwaf_geoip_table *geoip /* nullable */,
+                       const pwaf_options *opts /* nullable */, pwaf_engine **out,
+                       pwaf_compile_error *err /* nullable */);
+void pwaf_engine_destroy(pwaf_engine *);
+const pwaf_program *pwaf_engine_program(const pwaf_engine *);
+
+/* Synchronous batch evaluation. HOST batches are copied to the device, evaluated, and verdicts are
+ * copied back into `out` (host, n entries). DEVICE batches are evaluated in place and `out`/`counts`
+ * must be device pointers too. `counts` is nullable. Callable concurrently from several threads. */
+int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts);
+
+/* Asynchronous device-resident evaluation on a caller-supplied HIP stream (hipStream_t as void*;
+ * NULL = the engine's own stream). All pointers (batch columns, out, counts, match_idx, n_matches)
+ * are device pointers. `match_idx`/`n_matches` (nullable) receive the compacted indices of
+ * non-Allow requests (wavefront ballot + prefix-sum compaction; order unspecified).
+ * `counts` and `n_matches` are ACCUMULATED into (caller zeroes them). */
+int pwaf_evaluate_device(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts,
+                         uint32_t *match_idx, uint32_t *n_matches, void *stream);
+
+/* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
+int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+typedef struct pwaf_kernel_time {
+    char name[48];
+    float ms;            /* HIP-event duration of the last profiled evaluate call */
+    uint64_t alg_bytes;  /* algorithmic bytes this launch is credited with */
+} pwaf_kernel_time;
+/* When on, pwaf_evaluate_device brackets each kernel with hipEvents on the launch stream. */
+int pwaf_engine_set_profiling(pwaf_engine *, int on);
+/* Blocks until the last profiled call finished; fills up to cap entries; returns the count. */
+int pwaf_engine_kernel_times(pwaf_engine *, pwaf_kernel_time *out, int cap);
+
+typedef struct pwaf_stats {
+    uint32_t n_rules, n_atoms, n_scan_atoms, n_numeric_atoms;
+    uint32_t n_dfa_groups, n_dfa_states_total, max_dfa_states, dfa_table_bytes_total;
+    uint32_t n_ip_lists, ipset_trie_nodes, geo_trie_nodes, n_dnf_literals;
+    uint32_t n_warnings, reserved[3];
+} pwaf_stats;
+int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
+int pwaf_program_stats(const pwaf_program *, pwaf_stats *out);
+
+/* ---- host-side field derivation (what the reference does before building RequestData) ------ */
+/* get_path: uri.path().trim_end_matches('/') (http_utils.rs:114-116). Returns the kept length. */
+size_t pwaf_derive_path(const uint8_t *uri_path, size_t len);
+/* User-Agent (http_listener.rs:159-165): header bytes -> to_str() (fails -> "" unless every byte is
+ * visible ASCII 0x20..0x7E or TAB) -> trim -> heapless::String<256> (len > 256 -> ""). Writes the
+ * start offset and length of the kept slice. `present` = 0 when the header is absent. */
+void pwaf_derive_user_agent(const uint8_t *hdr, size_t len, int present, size_t *out_start, size_t *out_len);
+/* get_host (http_listener.rs:284-296): uri.host() if any (trim), else Host header to_str() (trim);
+ * longer than 256 -> "". Same output convention. */
+void pwaf_derive_host(const uint8_t *uri_host, size_t uri_host_len, int uri_host_present,
+                      const uint8_t *host_hdr, size_t host_hdr_len, int host_hdr_present,
+                      int *out_from_header, size_t *out_start, size_t *out_len);
+
+/* Thread-local message of the last failing call on this thread. Never NULL. */
+const char *pwaf_last_error(void);
+uint32_t pwaf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWAF_H */
