@@ -1,0 +1,72 @@
+"""Builds libpwaf.so (host compiler + gfx950 kernels + C ABI) in-tree with hipcc.
+
+`python -m pingoo_amd.build` or `pingoo_amd.build.build()`. The .so is git-ignored but travels to the
+GPU box with the repo snapshot. hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpwaf.so")
+SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "compile.cpp", "engine.cpp", "kernels.hip"]
+HEADERS = ["frontend.h", "program.h", "kernels.h", os.path.join("..", "..", "include", "pwaf.h")]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needed to build pingoo_amd/libpwaf.so)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    objs = []
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(HERE, "..", "include")]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), *(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)):
+            continue
+        cmd = [cc, *common, "-c", path, "-o", obj]
+        if src.endswith(".hip") or src == "engine.cpp":
+            cmd[1:1] = ["-x", "hip", "--offload-arch=gfx950"]
+        else:
+            # host-only translation units (no HIP headers): plain C++
+            cmd[1:1] = ["-x", "c++"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

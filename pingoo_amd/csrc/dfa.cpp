@@ -1,0 +1,465 @@
+// dfa.cpp — multi-pattern DFA construction for one (field, group): the table the scan kernel walks.
+//
+// All string predicates of the rule language over one request field — contains / starts_with /
+// ends_with / == / matches(regex) / membership in a string list — become patterns of one joint
+// automaton, so the field's bytes are read ONCE regardless of how many rules mention it
+// ("each input byte is counted once regardless of rule count").
+//
+// Construction: Thompson NFA per pattern (continuation-passing, no patch lists) -> subset
+// construction over "core sets" with zero-width assertions resolved at byte boundaries:
+//   state  D = (core C, prev-kind pk, delayed emits Ed)
+//   entry  eager closure from C ∪ {pattern starts} under pk: EPS and the assertions decidable from the
+//          previous byte alone (\A, (?m)^) are taken; assertions needing the NEXT byte ($, \z, \b, \B,
+//          (?m)$) park as pending. Accepts reached here are emitted on entering D.
+//   step   on byte class cl (kind nk): pending assertions that hold under (pk, nk) are released,
+//          closure continues; accepts reached now become the successor's delayed emits; the successor
+//          core is move(live BYTE states, cl).
+//   end    pending assertions are released with next = END; accepts reached are D's end-emits.
+// For literal-only pattern sets no assertion needs the next byte, Ed is always empty and the result is
+// exactly the Aho-Corasick DFA of the literals.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "program.h"
+
+namespace pwaf {
+
+namespace {
+
+enum : uint8_t { N_EPS, N_BYTE, N_ASSERT, N_ACCEPT };
+struct NState {
+    uint8_t type;
+    AssertKind ak;
+    int out = -1, out2 = -1;
+    int cls = -1;   // N_BYTE: distinct class-set id
+    int atom = -1;  // N_ACCEPT: local atom id
+};
+
+enum : uint8_t { K_EDGE = 0 /* START as prev, END as next */, K_OTHER = 1, K_WORD = 2, K_NEWLINE = 3 };
+
+struct Nfa {
+    std::vector<NState> st;
+    std::vector<ByteSet> sets;
+    std::map<std::string, int> set_ids;
+    std::vector<int> entries;  // per-pattern entry states
+    bool uses_word = false, uses_line = false;
+    size_t cap = 0;
+    bool overflow = false;
+
+    int add(NState s) {
+        if (st.size() >= cap) { overflow = true; return 0; }
+        st.push_back(s);
+        return (int)st.size() - 1;
+    }
+    int set_id(const ByteSet &b) {
+        std::string k = b.to_string();
+        auto it = set_ids.find(k);
+        if (it != set_ids.end()) return it->second;
+        int id = (int)sets.size();
+        sets.push_back(b);
+        set_ids.emplace(std::move(k), id);
+        return id;
+    }
+    // compile `n` so that a match continues at state `next`; returns the entry state
+    int build(const RNode &n, int next) {
+        if (overflow) return next;
+        switch (n.k) {
+            case RNode::EMPTY: return next;
+            case RNode::CLASS: {
+                NState s{N_BYTE, A_TEXT_START};
+                s.cls = set_id(n.cls);
+                s.out = next;
+                return add(s);
+            }
+            case RNode::CAT: {
+                int cur = next;
+                for (size_t k = n.kids.size(); k-- > 0;) cur = build(*n.kids[k], cur);
+                return cur;
+            }
+            case RNode::ALT: {
+                int cur = build(*n.kids.back(), next);
+                for (size_t k = n.kids.size() - 1; k-- > 0;) {
+                    NState s{N_EPS, A_TEXT_START};
+                    s.out = build(*n.kids[k], next);
+                    s.out2 = cur;
+                    cur = add(s);
+                }
+                return cur;
+            }
+            case RNode::REPEAT: {
+                const RNode &k = *n.kids[0];
+                int cur;
+                if (n.rmax < 0) {
+                    NState loop{N_EPS, A_TEXT_START};
+                    int L = add(loop);
+                    int body = build(k, L);
+                    st[L].out = body;
+                    st[L].out2 = next;
+                    if (n.rmin == 0) cur = L;
+                    else {
+                        cur = body;  // x+ : enter through the body, loop state decides
+                        for (int c = 1; c < n.rmin; c++) cur = build(k, cur);
+                    }
+                } else {
+                    cur = next;
+                    for (int c = n.rmin; c < n.rmax; c++) {
+                        NState opt{N_EPS, A_TEXT_START};
+                        opt.out = build(k, cur);
+                        opt.out2 = next;
+                        cur = add(opt);
+                    }
+                    for (int c = 0; c < n.rmin; c++) cur = build(k, cur);
+                }
+                return cur;
+            }
+            case RNode::ASSERT: {
+                NState s{N_ASSERT, n.ak};
+                s.out = next;
+                if (n.ak == A_WORD_B || n.ak == A_NOT_WORD_B) uses_word = true;
+                if (n.ak == A_LINE_START || n.ak == A_LINE_END) uses_line = true;
+                return add(s);
+            }
+        }
+        return next;
+    }
+};
+
+static inline bool needs_next(AssertKind a) { return a == A_TEXT_END || a == A_LINE_END || a == A_WORD_B || a == A_NOT_WORD_B; }
+static inline bool holds(AssertKind a, uint8_t pk, uint8_t nk) {
+    // pk: K_EDGE = start of text; nk: K_EDGE = end of text
+    switch (a) {
+        case A_TEXT_START: return pk == K_EDGE;
+        case A_TEXT_END: return nk == K_EDGE;
+        case A_LINE_START: return pk == K_EDGE || pk == K_NEWLINE;
+        case A_LINE_END: return nk == K_EDGE || nk == K_NEWLINE;
+        case A_WORD_B: return (pk == K_WORD) != (nk == K_WORD);
+        case A_NOT_WORD_B: return (pk == K_WORD) == (nk == K_WORD);
+    }
+    return false;
+}
+
+struct DKey {
+    std::vector<int> core;
+    std::vector<uint16_t> delayed;
+    uint8_t pk;
+    bool operator<(const DKey &o) const {
+        if (pk != o.pk) return pk < o.pk;
+        if (core != o.core) return core < o.core;
+        return delayed < o.delayed;
+    }
+};
+
+struct Builder {
+    const Nfa &nfa;
+    std::vector<uint32_t> mark;
+    uint32_t stamp = 0;
+    std::vector<int> stack;  // also used directly by build_dfa's filtered phase-A walk
+
+    explicit Builder(const Nfa &n) : nfa(n), mark(n.st.size(), 0) {}
+
+    // Closure from `seeds` (already-unvisited check by stamp). When nk_known is false, assertions that need
+    // the next byte are parked in `pending`; otherwise every assertion is decided under (pk, nk).
+    void closure(const std::vector<int> &seeds, uint8_t pk, bool nk_known, uint8_t nk, std::vector<int> &live, std::vector<uint16_t> &accepts,
+                 std::vector<int> *pending) {
+        stack.clear();
+        for (int s : seeds) stack.push_back(s);
+        while (!stack.empty()) {
+            int s = stack.back();
+            stack.pop_back();
+            if (mark[s] == stamp) continue;
+            mark[s] = stamp;
+            const NState &n = nfa.st[s];
+            switch (n.type) {
+                case N_EPS:
+                    if (n.out2 >= 0) stack.push_back(n.out2);
+                    if (n.out >= 0) stack.push_back(n.out);
+                    break;
+                case N_BYTE: live.push_back(s); break;
+                case N_ACCEPT: accepts.push_back((uint16_t)n.atom); break;
+                case N_ASSERT:
+                    if (!nk_known && needs_next(n.ak)) { pending->push_back(s); break; }
+                    if (holds(n.ak, pk, nk)) stack.push_back(n.out);
+                    break;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32_t max_table_bytes, DfaGroup &out, std::string &err) {
+    Nfa nfa;
+    nfa.cap = 400000;
+    for (size_t k = 0; k < pats.size(); k++) {
+        NState acc{N_ACCEPT, A_TEXT_START};
+        acc.atom = (int)k;
+        int a = nfa.add(acc);
+        size_t before = nfa.st.size();
+        nfa.entries.push_back(nfa.build(*pats[k].rx, a));
+        if (nfa.overflow || nfa.st.size() - before > 20000) {
+            err = "pattern too large (more than 20000 NFA states)";
+            return false;
+        }
+    }
+    // ---- byte classes: bytes are equivalent when no class set and no assertion kind tells them apart ----
+    auto kind_of = [&](int b) -> uint8_t {
+        bool w = (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_';
+        if (nfa.uses_word && w) return K_WORD;
+        if (nfa.uses_line && b == '\n') return K_NEWLINE;
+        return K_OTHER;
+    };
+    std::vector<int> cls_of(256);
+    int n_cls = 0;
+    {
+        std::map<int, int> first;
+        for (int b = 0; b < 256; b++) {
+            int k = kind_of(b);
+            auto it = first.find(k);
+            if (it == first.end()) it = first.emplace(k, n_cls++).first;
+            cls_of[b] = it->second;
+        }
+        for (const ByteSet &s : nfa.sets) {
+            std::map<std::pair<int, bool>, int> split;
+            int next_id = 0;
+            std::vector<int> nc(256);
+            for (int b = 0; b < 256; b++) {
+                auto key = std::make_pair(cls_of[b], (bool)s[b]);
+                auto it = split.find(key);
+                if (it == split.end()) it = split.emplace(key, next_id++).first;
+                nc[b] = it->second;
+            }
+            cls_of = nc;
+            n_cls = next_id;
+        }
+    }
+    std::vector<int> rep(n_cls, -1);  // representative byte per class
+    for (int b = 0; b < 256; b++) if (rep[cls_of[b]] < 0) rep[cls_of[b]] = b;
+    // set membership per class
+    std::vector<std::vector<uint8_t>> set_has(nfa.sets.size(), std::vector<uint8_t>(n_cls));
+    for (size_t s = 0; s < nfa.sets.size(); s++)
+        for (int c = 0; c < n_cls; c++) set_has[s][c] = nfa.sets[s][rep[c]];
+    std::vector<uint8_t> cls_kind(n_cls);
+    for (int c = 0; c < n_cls; c++) cls_kind[c] = kind_of(rep[c]);
+
+    if ((uint64_t)n_cls * 2 > max_table_bytes) { err = "LDS table budget too small"; return false; }
+    uint32_t state_cap = std::min<uint64_t>(max_states, (uint64_t)max_table_bytes / (2ull * n_cls));
+    state_cap = std::min<uint32_t>(state_cap, 65535);
+
+    // ---- subset construction ----
+    // The pattern entry states are seeds of EVERY state's closure (unanchored search restarts at each
+    // boundary), so their closure ("root") is computed once per prev-kind and shared.
+    Builder bl(nfa);
+    struct Root {
+        std::vector<uint8_t> in;  // visited in phase A
+        std::vector<int> liveA, pending;
+        std::vector<uint16_t> accA;
+        std::vector<int> liveB[4];      // extra live states released under next-kind nk
+        std::vector<uint16_t> accB[4];  // accepts released under nk
+        std::vector<std::vector<int>> move;  // per class: sorted targets of liveA ∪ liveB[kind(c)]
+        bool ready = false;
+    };
+    Root roots[4];
+    auto get_root = [&](uint8_t pk) -> Root & {
+        Root &r = roots[pk];
+        if (r.ready) return r;
+        r.ready = true;
+        r.in.assign(nfa.st.size(), 0);
+        bl.stamp++;
+        bl.closure(nfa.entries, pk, false, 0, r.liveA, r.accA, &r.pending);
+        for (size_t s = 0; s < nfa.st.size(); s++) r.in[s] = bl.mark[s] == bl.stamp;
+        for (uint8_t nk = 0; nk < 4; nk++) {
+            std::vector<int> rel;
+            for (int s : r.pending)
+                if (holds(nfa.st[s].ak, pk, nk)) rel.push_back(nfa.st[s].out);
+            if (rel.empty()) continue;
+            bl.stamp++;
+            for (int s : r.liveA) bl.mark[s] = bl.stamp;
+            bl.closure(rel, pk, true, nk, r.liveB[nk], r.accB[nk], nullptr);
+        }
+        r.move.assign(n_cls, {});
+        for (int c = 0; c < n_cls; c++) {
+            std::vector<int> &m = r.move[c];
+            for (int s : r.liveA) if (set_has[nfa.st[s].cls][c]) m.push_back(nfa.st[s].out);
+            for (int s : r.liveB[cls_kind[c]]) if (set_has[nfa.st[s].cls][c]) m.push_back(nfa.st[s].out);
+            std::sort(m.begin(), m.end());
+            m.erase(std::unique(m.begin(), m.end()), m.end());
+        }
+        return r;
+    };
+
+    struct DState {
+        DKey key;
+        std::vector<uint16_t> emits;      // eager accepts ∪ delayed
+        std::vector<uint16_t> end_emits;  // accepts released at END
+        std::vector<int> next;            // per class
+    };
+    std::vector<DState> ds;
+    std::map<DKey, int> index;
+    auto intern = [&](DKey &&k) -> int {
+        auto it = index.find(k);
+        if (it != index.end()) return it->second;
+        int id = (int)ds.size();
+        ds.emplace_back();
+        ds.back().key = k;
+        index.emplace(std::move(k), id);
+        return id;
+    };
+    auto uniq16 = [](std::vector<uint16_t> &v) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    };
+    DKey k0;
+    k0.pk = K_EDGE;
+    intern(std::move(k0));
+    std::vector<int> liveA, liveB, pending, rel;
+    std::vector<uint16_t> accA, accB, entry_emits;
+    for (size_t d = 0; d < ds.size(); d++) {
+        if (ds.size() > state_cap) {
+            err = "DFA state limit exceeded";
+            return false;
+        }
+        DKey key = ds[d].key;  // copy: ds may reallocate
+        Root &root = get_root(key.pk);
+        // phase A over the core seeds only (root part is shared); skip what the root closure covers
+        liveA.clear(); accA.clear(); pending.clear();
+        bl.stamp++;
+        uint32_t stampA = bl.stamp;
+        {
+            std::vector<int> seeds;
+            for (int s : key.core) if (!root.in[s]) seeds.push_back(s);
+            // closure() does not know about root.in: pre-mark nothing, filter on the fly instead
+            bl.stack.clear();
+            for (int s : seeds) bl.stack.push_back(s);
+            while (!bl.stack.empty()) {
+                int s = bl.stack.back();
+                bl.stack.pop_back();
+                if (bl.mark[s] == stampA || root.in[s]) continue;
+                bl.mark[s] = stampA;
+                const NState &n = nfa.st[s];
+                switch (n.type) {
+                    case N_EPS:
+                        if (n.out2 >= 0) bl.stack.push_back(n.out2);
+                        if (n.out >= 0) bl.stack.push_back(n.out);
+                        break;
+                    case N_BYTE: liveA.push_back(s); break;
+                    case N_ACCEPT: accA.push_back((uint16_t)n.atom); break;
+                    case N_ASSERT:
+                        if (needs_next(n.ak)) { pending.push_back(s); break; }
+                        if (holds(n.ak, key.pk, 0)) bl.stack.push_back(n.out);
+                        break;
+                }
+            }
+        }
+        entry_emits = accA;
+        entry_emits.insert(entry_emits.end(), root.accA.begin(), root.accA.end());
+        entry_emits.insert(entry_emits.end(), key.delayed.begin(), key.delayed.end());
+        uniq16(entry_emits);
+        ds[d].emits = entry_emits;
+        ds[d].next.assign(n_cls, 0);
+        // phase B for next-kind nk: release this state's own pending assertions (the root's are precomputed)
+        auto phaseB = [&](uint8_t nk) {
+            liveB.clear();
+            accB.clear();
+            rel.clear();
+            for (int s : pending)
+                if (holds(nfa.st[s].ak, key.pk, nk)) rel.push_back(nfa.st[s].out);
+            if (!rel.empty()) {
+                // keep phase-A marks (same stamp): only NEW states are entered. States of the root closure may be
+                // re-entered here; duplicates are removed when targets/accepts are sorted.
+                std::vector<int> extra;
+                bl.closure(rel, key.pk, true, nk, extra, accB, nullptr);
+                liveB = extra;
+            }
+            accB.insert(accB.end(), root.accB[nk].begin(), root.accB[nk].end());
+            uniq16(accB);
+            std::vector<uint16_t> diff;
+            std::set_difference(accB.begin(), accB.end(), entry_emits.begin(), entry_emits.end(), std::back_inserter(diff));
+            accB.swap(diff);
+        };
+        phaseB(K_EDGE);
+        ds[d].end_emits = accB;
+        for (uint8_t nk : {K_OTHER, K_WORD, K_NEWLINE}) {
+            bool used = false;
+            for (int c = 0; c < n_cls; c++) if (cls_kind[c] == nk) used = true;
+            if (!used) continue;
+            // phase B marks must not leak between next-kinds: restart from the phase-A marks
+            bl.stamp++;
+            for (int s : liveA) bl.mark[s] = bl.stamp;
+            phaseB(nk);
+            for (int c = 0; c < n_cls; c++) {
+                if (cls_kind[c] != nk) continue;
+                DKey nkey;
+                nkey.pk = nk;
+                nkey.delayed = accB;
+                nkey.core = root.move[c];
+                for (int s : liveA) if (set_has[nfa.st[s].cls][c]) nkey.core.push_back(nfa.st[s].out);
+                for (int s : liveB) if (set_has[nfa.st[s].cls][c]) nkey.core.push_back(nfa.st[s].out);
+                std::sort(nkey.core.begin(), nkey.core.end());
+                nkey.core.erase(std::unique(nkey.core.begin(), nkey.core.end()), nkey.core.end());
+                int t = intern(std::move(nkey));
+                ds[d].next[c] = t;
+            }
+        }
+    }
+    if (ds.size() > state_cap) {
+        err = "DFA state limit exceeded";
+        return false;
+    }
+
+    // ---- renumber: start first, non-emitting states, then emitting states ----
+    uint32_t S = (uint32_t)ds.size();
+    std::vector<uint32_t> order, newid(S);
+    bool start_emits = !ds[0].emits.empty();
+    if (!start_emits) order.push_back(0);
+    for (uint32_t s = 0; s < S; s++) if (ds[s].emits.empty() && s != 0) order.push_back(s);
+    uint32_t first_emit = (uint32_t)order.size();
+    if (start_emits) order.push_back(0);
+    for (uint32_t s = 0; s < S; s++) if (!ds[s].emits.empty() && s != 0) order.push_back(s);
+    for (uint32_t k = 0; k < S; k++) newid[order[k]] = k;
+
+    out.n_states = S;
+    out.n_classes = (uint32_t)n_cls;
+    out.first_emit = first_emit;
+    for (int b = 0; b < 256; b++) out.classmap[b] = (uint8_t)cls_of[b];
+    out.trans.assign((size_t)S * n_cls, 0);
+    out.emit_off.assign(1, 0);
+    out.emit_list.clear();
+    out.end_off.assign(1, 0);
+    out.end_list.clear();
+    out.end_flag.assign((S + 31) / 32, 0);
+    for (uint32_t k = 0; k < S; k++) {
+        const DState &d = ds[order[k]];
+        for (int c = 0; c < n_cls; c++) out.trans[(size_t)k * n_cls + c] = (uint16_t)newid[d.next[c]];
+        if (k >= first_emit) {
+            out.emit_list.insert(out.emit_list.end(), d.emits.begin(), d.emits.end());
+            out.emit_off.push_back((uint32_t)out.emit_list.size());
+        }
+        out.end_list.insert(out.end_list.end(), d.end_emits.begin(), d.end_emits.end());
+        out.end_off.push_back((uint32_t)out.end_list.size());
+        if (!d.end_emits.empty()) out.end_flag[k >> 5] |= 1u << (k & 31);
+    }
+    out.start = newid[0];
+    out.atoms.clear();
+    for (auto &p : pats) out.atoms.push_back(p.atom);
+    return true;
+}
+
+void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms) {
+    uint32_t s = g.start;
+    auto emit = [&](uint32_t st) {
+        if (st >= g.first_emit)
+            for (uint32_t k = g.emit_off[st - g.first_emit]; k < g.emit_off[st - g.first_emit + 1]; k++) out_atoms.push_back(g.emit_list[k]);
+    };
+    emit(s);
+    for (size_t i = 0; i < n; i++) {
+        s = g.trans[(size_t)s * g.n_classes + g.classmap[bytes[i]]];
+        emit(s);
+    }
+    for (uint32_t k = g.end_off[s]; k < g.end_off[s + 1]; k++) out_atoms.push_back(g.end_list[k]);
+    std::sort(out_atoms.begin(), out_atoms.end());
+    out_atoms.erase(std::unique(out_atoms.begin(), out_atoms.end()), out_atoms.end());
+}
+
+}  // namespace pwaf

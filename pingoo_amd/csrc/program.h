@@ -1,0 +1,194 @@
+// program.h — the compiled form of a rule set: what the host compiler produces and the device consumes.
+//
+// Pipeline:  expression text --front-end--> typed boolean DAG over ATOMS
+//   --DNF--> per-rule literal lists;  string atoms --regex/literal patterns--> per-field DFA groups
+//   (LDS-resident transition tables);  ip-list atoms --> one multibit radix trie (membership-set ids);
+//   GeoIP prefixes --> one multibit radix trie (record ids).
+#pragma once
+#include <array>
+#include <bitset>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pwaf.h"
+
+namespace pwaf {
+
+// ---- regex / literal patterns ------------------------------------------------------------------
+using ByteSet = std::bitset<256>;
+
+enum AssertKind : uint8_t { A_TEXT_START, A_TEXT_END, A_LINE_START, A_LINE_END, A_WORD_B, A_NOT_WORD_B };
+
+struct RNode;
+using RNodeP = std::shared_ptr<RNode>;
+struct RNode {
+    enum K : uint8_t { EMPTY, CLASS, CAT, ALT, REPEAT, ASSERT } k = EMPTY;
+    ByteSet cls;
+    std::vector<RNodeP> kids;
+    int rmin = 0, rmax = -1;  // REPEAT; rmax < 0 = unbounded
+    AssertKind ak = A_TEXT_START;
+};
+RNodeP rx_empty();
+RNodeP rx_class(const ByteSet &s);
+RNodeP rx_byte(uint8_t c);
+RNodeP rx_literal(const std::string &bytes);
+RNodeP rx_cat(std::vector<RNodeP> kids);
+RNodeP rx_alt(std::vector<RNodeP> kids);
+RNodeP rx_assert(AssertKind k);
+std::string rx_key(const RNode &n);  // canonical text (atom de-duplication)
+
+// Parses the supported Rust-regex subset. status: 0 ok, 1 invalid pattern
+// (a run-time error in the reference => the rule can never match), 2 valid-but-unsupported.
+RNodeP regex_parse(const std::string &pattern, int &status, std::string &err);
+
+// ---- atoms ---------------------------------------------------------------------------------------
+enum AtomKind : uint8_t {
+    ATOM_TRUE = 0,   // column of all ones
+    ATOM_SCAN,       // string field matched by a pattern (DFA)           -> scan kernels
+    ATOM_LEN,        // byte length of a string field  <op> constant       -> verdict kernel
+    ATOM_INT,        // client.remote_port / client.asn <op> constant
+    ATOM_INTSET,     // client.remote_port / client.asn in sorted set
+    ATOM_IPSET,      // client.ip contained in CIDR list L
+    ATOM_COUNTRY,    // client.country in 676-bit table
+};
+enum CmpOp : uint8_t { OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE };
+enum IntVar : uint8_t { VAR_PORT = 0, VAR_ASN = 1 };
+
+struct Atom {
+    AtomKind kind = ATOM_TRUE;
+    uint8_t field = 0;  // SCAN/LEN: PWAF_FIELD_*; INT/INTSET: IntVar
+    CmpOp op = OP_EQ;
+    int64_t c = 0;             // LEN / INT constant
+    RNodeP pattern;            // SCAN
+    uint32_t ref = 0;          // INTSET: index into int_sets; IPSET: ip list index; COUNTRY: lut index
+    uint32_t id = 0;           // device column id (assigned at layout time)
+    std::string key;           // canonical form for de-duplication
+};
+
+// ---- DFA groups ----------------------------------------------------------------------------------
+struct DfaGroup {
+    uint8_t field = 0;
+    uint32_t n_states = 0, n_classes = 0;
+    uint32_t first_emit = 0;             // states >= first_emit carry mid-stream emits
+    uint32_t start = 0;                  // start state (0, or first_emit when the start state itself emits)
+    uint8_t classmap[256] = {0};
+    std::vector<uint16_t> trans;         // n_states * n_classes, row-major; state 0 = start
+    std::vector<uint32_t> emit_off;      // (n_states - first_emit) + 1 offsets into emit_list
+    std::vector<uint16_t> emit_list;     // LOCAL atom ids (column = atom_base + local)
+    std::vector<uint32_t> end_off;       // n_states + 1
+    std::vector<uint16_t> end_list;      // LOCAL atom ids true if the field ends in this state
+    std::vector<uint32_t> end_flag;      // bitset over states: end_off[s+1] > end_off[s]
+    uint32_t atom_base = 0;              // first device column of this group (multiple of 64)
+    uint32_t n_local = 0;                // columns owned by this group (multiple of 64)
+    std::vector<uint32_t> atoms;         // indices into Program::atoms, local id order
+};
+
+// ---- radix tries ----------------------------------------------------------------------------------
+// Entry: bit31 set => leaf, low 31 bits = value; else child node index (node n occupies nodes[n*256 ..]).
+struct IpTrie {
+    std::vector<uint32_t> root4, root6;  // 65536 entries each (empty vector when the family has no prefixes)
+    std::vector<uint32_t> nodes;         // 256-entry nodes, shared by both families
+    uint32_t n_nodes() const { return (uint32_t)(nodes.size() / 256); }
+};
+static constexpr uint32_t TRIE_LEAF = 0x80000000u;
+
+struct GeoRec {
+    uint32_t asn;
+    uint16_t country;  // two bytes in memory order
+    uint16_t pad;
+};
+
+// ---- per-rule device records -----------------------------------------------------------------------
+struct DevRule {
+    uint32_t lit_off, lit_cnt;  // into Program::lits
+    uint32_t public_idx;        // index in the caller's rule array, or PWAF_RULE_* pseudo index
+    uint8_t eff_unverified;     // PWAF_ACTION_* applied when this rule matches and the client is not captcha-verified
+    uint8_t eff_verified;       //   ... and when it is (ALLOW here means "no effect: keep going")
+    uint8_t pad[2];
+};
+// literal encoding in Program::lits
+static constexpr uint32_t LIT_NEG = 1u << 30;       // negated atom
+static constexpr uint32_t LIT_TERM_END = 1u << 31;  // last literal of its conjunction
+static constexpr uint32_t LIT_ATOM_MASK = (1u << 24) - 1;
+
+struct NumAtomDev {  // numeric atom descriptor consumed by the verdict kernel
+    uint32_t col;    // device column
+    uint8_t kind, var, op, pad;
+    uint32_t ref, ref2;  // INTSET: [begin,end) into int_pool; IPSET: list bit; COUNTRY: lut index
+    int64_t c;
+};
+
+struct Program {
+    // source-level
+    std::vector<Atom> atoms;                     // atoms[0] = TRUE
+    std::vector<std::vector<int64_t>> int_sets;  // sorted, unique
+    std::vector<std::bitset<704>> country_luts;  // index = (c0-'A')*26 + (c1-'A')
+    std::vector<std::string> warnings;
+
+    // device-level
+    uint32_t n_cols = 0;          // total columns (TRUE + scan blocks + numeric), multiple of 64
+    uint32_t n_scan_cols = 0;     // columns [64, 64 + n_scan_cols) belong to scan groups (multiple of 64)
+    std::vector<DfaGroup> groups;
+    std::vector<NumAtomDev> num_atoms;
+    std::vector<int64_t> int_pool;
+    std::vector<uint32_t> country_lut_words;  // 22 words per lut
+    std::vector<DevRule> rules;               // pseudo rules first, then the caller's rules with an effect
+    std::vector<uint32_t> lits;
+    uint32_t n_user_rules = 0;
+
+    // ip lists -> membership sets
+    uint32_t n_ip_lists = 0;
+    uint32_t set_words = 0;                // 32-bit words per membership set
+    std::vector<uint32_t> set_masks;       // n_sets * set_words ; set 0 = empty
+    IpTrie ipset_trie;
+    bool has_geo = false;
+    IpTrie geo_trie;
+    std::vector<GeoRec> geo_recs;          // rec 0 = default {0,"XX"}
+
+    uint32_t flags = 0;
+    pwaf_stats stats{};
+};
+
+struct CompileInput {
+    const pwaf_rule_desc *rules;
+    size_t n_rules;
+    const pwaf_list_desc *lists;
+    size_t n_lists;
+    const pwaf_geoip_table *geoip;
+    pwaf_options opts;
+};
+
+// Returns PWAF_OK or an error code; fills err (rule index + message) on failure.
+int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_compile_error &err);
+
+// Little-endian self-describing dump used by tests to inspect compiler output.
+std::vector<uint8_t> dump_program(const Program &p);
+
+// ---- pieces (exposed for unit tests through the dump) -------------------------------------------------
+struct ScanPattern {
+    RNodeP rx;
+    uint32_t atom;  // index into Program::atoms
+};
+// Builds one DFA for `pats` (local ids = positions in pats). Returns false when the state limit is exceeded.
+bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32_t max_table_bytes, DfaGroup &out, std::string &err);
+// Runs a DFA on the host over `bytes`, returning local atom ids that hold. COMPILE-TIME USE ONLY
+// (folding predicates over the 676 possible country codes into a lookup table).
+void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms);
+
+struct PrefixEntry {
+    uint8_t addr[16];
+    uint8_t len;
+    bool v6;
+    uint32_t payload;  // list index (sets) or record id (LPM)
+};
+// mode 0: membership sets (payload = list bit, result value = set id into set_masks)
+// mode 1: longest-prefix match (result value = payload of the most specific prefix; later duplicates win)
+void build_ip_trie(const std::vector<PrefixEntry> &prefixes, int mode, uint32_t n_lists, IpTrie &trie, std::vector<uint32_t> &set_masks, uint32_t &set_words);
+
+bool parse_ipnet_text(const std::string &s, PrefixEntry &out, std::string &err);
+bool parse_i64_text(const std::string &s, int64_t &out);
+
+}  // namespace pwaf

@@ -1,0 +1,362 @@
+"""Host-side mirror of the reference's rule interface, over the C ABI of libpwaf.so.
+
+Names follow the reference so call sites read the same:
+
+    rules::Action {Block, Captcha}        rules/rules.rs:30-35      -> Action
+    rules::compile_expression             rules/rules.rs:45-53      -> compile_expression
+    rules::validate_expression            rules/rules.rs:55-77      -> validate_expression
+    pingoo::rules::Rule {name, expression: Option<_>, actions}      -> Rule
+    Rule::match_request / the rule loop   http_listener.rs:251-264  -> RuleEngine.evaluate(...)
+    Error::ExpressionIsNotValid           rules/rules.rs:41-42      -> ExpressionIsNotValid
+
+Every evaluation runs on the GPU through libpwaf.so; there is no Python or CPU evaluation path.
+If the library (or a HIP device) is missing the calls raise — loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .batch import VERDICT_DTYPE, Request, RequestBatch
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpwaf.so")
+
+
+class PwafError(RuntimeError):
+    def __init__(self, code: int, message: str, rule_index: Optional[int] = None):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+        self.rule_index = rule_index
+
+
+class ExpressionIsNotValid(PwafError):
+    """rules::Error::ExpressionIsNotValid (rules/rules.rs:41-42)."""
+
+
+class UnsupportedExpression(PwafError):
+    """A valid expression outside the device-compilable subset."""
+
+
+class DeviceError(PwafError):
+    """No usable HIP device / a HIP call failed. The caller decides whether to fail open."""
+
+
+def lib():
+    """Loads libpwaf.so. Raises if it has not been built — the product path never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: build it with `python -m pingoo_amd.build` (hipcc, gfx950). "
+                          "pingoo_amd has no CPU fallback.")
+    L = C.CDLL(_LIB_PATH)
+    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    L.pwaf_abi_version.restype = C.c_uint32
+    L.pwaf_last_error.restype = C.c_char_p
+    L.pwaf_compile_expression.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.pwaf_validate_expression.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    create_args = [C.POINTER(_abi.RuleDesc), C.c_size_t, C.POINTER(_abi.ListDesc), C.c_size_t, C.POINTER(_abi.GeoipTable), C.POINTER(_abi.Options)]
+    L.pwaf_program_compile.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
+    L.pwaf_program_destroy.argtypes = [vp]
+    L.pwaf_program_destroy.restype = None
+    L.pwaf_program_dump.argtypes = [vp, vp, C.c_size_t]
+    L.pwaf_program_dump.restype = C.c_size_t
+    L.pwaf_program_warning_count.argtypes = [vp]
+    L.pwaf_program_warning_count.restype = C.c_size_t
+    L.pwaf_program_warning.argtypes = [vp, C.c_size_t]
+    L.pwaf_program_warning.restype = C.c_char_p
+    L.pwaf_program_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+    L.pwaf_engine_create.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
+    L.pwaf_engine_destroy.argtypes = [vp]
+    L.pwaf_engine_destroy.restype = None
+    L.pwaf_engine_program.argtypes = [vp]
+    L.pwaf_engine_program.restype = vp
+    L.pwaf_engine_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+    L.pwaf_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
+    L.pwaf_evaluate_device.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp, vp, vp, vp]
+    L.pwaf_evaluate_one.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
+    L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
+    L.pwaf_engine_kernel_times.argtypes = [vp, C.POINTER(_abi.KernelTime), C.c_int]
+    L.pwaf_derive_path.argtypes = [C.c_char_p, C.c_size_t]
+    L.pwaf_derive_path.restype = C.c_size_t
+    L.pwaf_derive_user_agent.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.pwaf_derive_user_agent.restype = None
+    L.pwaf_derive_host.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.pwaf_derive_host.restype = None
+    if L.pwaf_abi_version() != _abi.ABI_VERSION:
+        raise ImportError("libpwaf.so ABI version mismatch: rebuild with `python -m pingoo_amd.build --force`")
+    _LIB = L
+    return L
+
+
+def _raise(code: int, message: str, rule_index: Optional[int] = None):
+    cls = {_abi.E_SYNTAX: ExpressionIsNotValid, _abi.E_UNSUPPORTED: UnsupportedExpression, _abi.E_DEVICE: DeviceError}.get(code, PwafError)
+    raise cls(code, message, rule_index)
+
+
+class Action(enum.IntEnum):
+    """rules::Action (rules/rules.rs:30-35). Values are the PWAF_RULE_ACTION_* codes."""
+
+    Block = _abi.RULE_ACTION_BLOCK
+    Captcha = _abi.RULE_ACTION_CAPTCHA
+
+
+class Decision(enum.IntEnum):
+    """What the listener does with the request (http_listener.rs:196-264)."""
+
+    Allow = _abi.ACTION_ALLOW
+    Block = _abi.ACTION_BLOCK
+    Captcha = _abi.ACTION_CAPTCHA
+    Bypass = _abi.ACTION_BYPASS  # /__pingoo/captcha endpoints: rules are skipped
+
+
+@dataclass
+class Rule:
+    """pingoo::rules::Rule (pingoo/rules.rs:9-14). expression None == match all."""
+
+    name: str
+    expression: Optional[str]
+    actions: Sequence[Action] = field(default_factory=list)
+
+    def as_tuple(self) -> Tuple[str, Optional[str], List[int]]:
+        return (self.name, self.expression, [int(a) for a in self.actions])
+
+
+@dataclass
+class Verdict:
+    decision: Decision
+    rule_idx: Optional[int]  # index of the deciding rule; None for Allow / the built-in gates
+    gate: Optional[str] = None  # "user_agent" | "captcha_endpoint" when a built-in gate decided
+
+
+def compile_expression(expression: str) -> None:
+    """rules::compile_expression: raises ExpressionIsNotValid on a syntax error."""
+    buf = C.create_string_buffer(512)
+    rc = lib().pwaf_compile_expression(expression.encode(), buf, 512)
+    if rc != 0:
+        _raise(rc, buf.value.decode(errors="replace"))
+
+
+def validate_expression(expression: str) -> None:
+    """rules::validate_expression: additionally rejects "" and the `in` operator."""
+    buf = C.create_string_buffer(512)
+    rc = lib().pwaf_validate_expression(expression.encode(), buf, 512)
+    if rc != 0:
+        _raise(rc, buf.value.decode(errors="replace"))
+
+
+def get_path(uri_path: bytes) -> bytes:
+    """get_path (http_utils.rs:114-116)."""
+    return uri_path[: lib().pwaf_derive_path(uri_path, len(uri_path))]
+
+
+def get_user_agent(header: Optional[bytes]) -> bytes:
+    """The User-Agent derivation of http_listener.rs:159-165."""
+    s, l = C.c_size_t(), C.c_size_t()
+    h = header or b""
+    lib().pwaf_derive_user_agent(h, len(h), int(header is not None), C.byref(s), C.byref(l))
+    return h[s.value:s.value + l.value]
+
+
+def get_host(uri_host: Optional[bytes], host_header: Optional[bytes]) -> bytes:
+    """get_host (http_listener.rs:284-296)."""
+    s, l, fh = C.c_size_t(), C.c_size_t(), C.c_int()
+    a, b = uri_host or b"", host_header or b""
+    lib().pwaf_derive_host(a, len(a), int(uri_host is not None), b, len(b), int(host_header is not None), C.byref(fh), C.byref(s), C.byref(l))
+    src = b if fh.value else a
+    return src[s.value:s.value + l.value]
+
+
+def _options(flags=0, device=-1, lds_table_budget=0, max_dfa_states=0) -> _abi.Options:
+    o = _abi.Options()
+    o.struct_size = C.sizeof(_abi.Options)
+    o.flags = flags
+    o.device = device
+    o.lds_table_budget = lds_table_budget
+    o.max_dfa_states = max_dfa_states
+    return o
+
+
+def _norm_rules(rules) -> List[Tuple[str, Optional[str], List[int]]]:
+    return [r.as_tuple() if isinstance(r, Rule) else (r[0], r[1], [int(a) for a in r[2]]) for r in rules]
+
+
+class CompiledProgram:
+    """Host-side compilation only (no GPU): stats, warnings and the table dump used by the tests."""
+
+    def __init__(self, rules, lists: Optional[Dict[str, Tuple[int, Sequence[str]]]] = None, geoip: Optional[np.ndarray] = None, **opts):
+        L = lib()
+        m = _abi.Marshalled()
+        r, nr = _abi.marshal_rules(_norm_rules(rules), m)
+        l, nl = _abi.marshal_lists(lists, m)
+        g = _abi.marshal_geoip(geoip, m)
+        o = _options(**opts)
+        h = C.c_void_p()
+        err = _abi.CompileError()
+        rc = L.pwaf_program_compile(r, nr, l, nl, g, C.byref(o), C.byref(h), C.byref(err))
+        if rc != 0:
+            _raise(rc, err.message.decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self._h = h
+        self._owned = True
+
+    @classmethod
+    def _borrow(cls, handle) -> "CompiledProgram":
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        return self
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self._h:
+            lib().pwaf_program_destroy(self._h)
+            self._h = None
+
+    def dump(self) -> bytes:
+        n = lib().pwaf_program_dump(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        lib().pwaf_program_dump(self._h, buf, n)
+        return buf.raw
+
+    def warnings(self) -> List[str]:
+        return [lib().pwaf_program_warning(self._h, i).decode(errors="replace") for i in range(lib().pwaf_program_warning_count(self._h))]
+
+    def stats(self) -> dict:
+        s = _abi.Stats()
+        lib().pwaf_program_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k != "reserved"}
+
+
+class RuleEngine:
+    """The engine handle that replaces `(Arc<Vec<Rule>>, lists, geoip)` (pingoo/server.rs:40-47,76).
+
+    rules: ordered [Rule | (name, expression|None, [actions])]
+    lists: {name: (LIST_STRING|LIST_INT|LIST_IP, [csv column-0 strings])}
+    geoip: GEOIP_DTYPE array (see pingoo_amd.batch.geoip_entries) or None
+    """
+
+    def __init__(self, rules, lists: Optional[Dict[str, Tuple[int, Sequence[str]]]] = None, geoip: Optional[np.ndarray] = None, **opts):
+        L = lib()
+        m = _abi.Marshalled()
+        self.rules = _norm_rules(rules)
+        r, nr = _abi.marshal_rules(self.rules, m)
+        l, nl = _abi.marshal_lists(lists, m)
+        g = _abi.marshal_geoip(geoip, m)
+        o = _options(**opts)
+        h = C.c_void_p()
+        err = _abi.CompileError()
+        rc = L.pwaf_engine_create(r, nr, l, nl, g, C.byref(o), C.byref(h), C.byref(err))
+        if rc != 0:
+            _raise(rc, err.message.decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pwaf_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def program(self) -> CompiledProgram:
+        return CompiledProgram._borrow(lib().pwaf_engine_program(self._h))
+
+    def stats(self) -> dict:
+        s = _abi.Stats()
+        lib().pwaf_engine_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k != "reserved"}
+
+    # ---- evaluation -------------------------------------------------------------------------------
+    def evaluate_batch(self, batch: RequestBatch, with_counts: bool = False):
+        """Host batch in, numpy VERDICT_DTYPE array out (and the 4 action counters when asked)."""
+        out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
+        counts = _abi.Counts()
+        st = batch.as_struct()
+        rc = lib().pwaf_evaluate_batch(self._h, C.byref(st), out.ctypes.data, C.addressof(counts))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        if with_counts:
+            return out, np.array(list(counts.by_action), dtype=np.uint64)
+        return out
+
+    def evaluate(self, request: Request) -> Verdict:
+        """RuleEngine::evaluate(Request) -> Action: a batch of one through the same device path."""
+        v = self.evaluate_batch(RequestBatch.from_requests([request]))[0]
+        return verdict_from_record(v)
+
+    def evaluate_device(self, dbatch: "DeviceBatch", out=None, counts=None, match_idx=None, n_matches=None, stream=None):
+        """Device-resident evaluation on torch's current stream (or `stream`). Tensors stay on the GPU."""
+        import torch
+
+        if out is None:
+            out = torch.empty((dbatch.n, 2), dtype=torch.int32, device=dbatch.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(dbatch.device).cuda_stream
+        st = dbatch.as_struct()
+        rc = lib().pwaf_evaluate_device(self._h, C.byref(st), out.data_ptr(), counts.data_ptr() if counts is not None else None,
+                                        match_idx.data_ptr() if match_idx is not None else None, n_matches.data_ptr() if n_matches is not None else None,
+                                        C.c_void_p(stream))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return out
+
+    def set_profiling(self, on: bool):
+        lib().pwaf_engine_set_profiling(self._h, int(on))
+
+    def kernel_times(self) -> List[Tuple[str, float, int]]:
+        arr = (_abi.KernelTime * 64)()
+        n = lib().pwaf_engine_kernel_times(self._h, arr, 64)
+        if n < 0:
+            _raise(n, lib().pwaf_last_error().decode(errors="replace"))
+        return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
+
+
+def verdict_from_record(v) -> Verdict:
+    ridx = int(v["rule_idx"])
+    gate = {_abi.RULE_UA_GATE: "user_agent", _abi.RULE_CAPTCHA_ENDPOINT: "captcha_endpoint"}.get(ridx)
+    return Verdict(Decision(int(v["action"])), None if ridx >= _abi.RULE_CAPTCHA_ENDPOINT else ridx, gate)
+
+
+class DeviceBatch:
+    """A RequestBatch uploaded to HBM as torch tensors (PyTorch is only the allocator/stream owner here)."""
+
+    def __init__(self, batch: RequestBatch, device="cuda:0"):
+        import torch
+
+        self.device = torch.device(device)
+        self.n = batch.n
+        self.algorithmic_bytes = batch.algorithmic_bytes()
+        self.field_bytes = [int(o[-1]) - int(o[0]) for o in batch.offsets]
+        t = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)  # noqa: E731
+        self.data = [t(d) for d in batch.data]
+        self.offsets = [t(o.view(np.int32)) for o in batch.offsets]
+        self.ip = t(batch.ip)
+        self.ip_is_v6 = t(batch.ip_is_v6)
+        self.port = t(batch.port.view(np.int16))
+        self.flags = t(batch.flags)
+        self.asn = None if batch.asn is None else t(batch.asn.view(np.int32))
+        self.country = None if batch.country is None else t(batch.country.view(np.int16))
+
+    def as_struct(self) -> _abi.Batch:
+        b = _abi.Batch()
+        b.struct_size = C.sizeof(_abi.Batch)
+        b.n = self.n
+        b.memory = _abi.MEM_DEVICE
+        for f in range(_abi.N_FIELDS):
+            b.field[f].data = self.data[f].data_ptr()
+            b.field[f].offsets = self.offsets[f].data_ptr()
+        b.ip = self.ip.data_ptr()
+        b.ip_is_v6 = self.ip_is_v6.data_ptr()
+        b.port = self.port.data_ptr()
+        b.flags = self.flags.data_ptr()
+        b.asn = None if self.asn is None else self.asn.data_ptr()
+        b.country = None if self.country is None else self.country.data_ptr()
+        return b

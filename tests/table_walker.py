@@ -1,0 +1,179 @@
+"""TEST-ONLY interpreter of the compiled tables that `pwaf_program_dump` exports.
+
+It re-implements, in plain Python and one request at a time, what the HIP kernels do with the
+tables (DFA walk with emit/end lists, numeric atoms, trie lookups, DNF rule evaluation, first match
+wins). It exists so that the HOST COMPILER (parser, typing, DFA construction, trie construction,
+DNF) can be checked against the oracle on CPU-only machines. It is test infrastructure: the product
+never imports it, and it is far too slow to be anyone's fallback.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from pingoo_amd import _abi
+
+LIT_NEG = 1 << 30
+LIT_TERM_END = 1 << 31
+LIT_ATOM_MASK = (1 << 24) - 1
+TRIE_LEAF = 0x80000000
+ATOM_LEN, ATOM_INT, ATOM_INTSET, ATOM_IPSET, ATOM_COUNTRY = 2, 3, 4, 5, 6
+OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE = range(6)
+
+NUMA_DTYPE = np.dtype([("col", "<u4"), ("kind", "u1"), ("var", "u1"), ("op", "u1"), ("pad", "u1"), ("ref", "<u4"), ("ref2", "<u4"), ("c", "<i8")])
+RULE_DTYPE = np.dtype([("lit_off", "<u4"), ("lit_cnt", "<u4"), ("public_idx", "<u4"), ("eff_u", "u1"), ("eff_v", "u1"), ("pad", "u1", (2,))])
+GREC_DTYPE = np.dtype([("asn", "<u4"), ("country", "<u2"), ("pad", "<u2")])
+assert NUMA_DTYPE.itemsize == 24 and RULE_DTYPE.itemsize == 16 and GREC_DTYPE.itemsize == 8
+
+
+def parse_dump(blob: bytes):
+    assert blob[:8] == b"PWAFPRG1", "bad dump magic"
+    pos = 8
+    sections = []
+    while pos < len(blob):
+        tag = blob[pos:pos + 4].decode()
+        count, = struct.unpack_from("<I", blob, pos + 4)
+        length, = struct.unpack_from("<Q", blob, pos + 8)
+        payload = blob[pos + 16:pos + 16 + length]
+        pos += 16 + length
+        pos = (pos + 7) // 8 * 8
+        sections.append((tag, count, payload))
+    return sections
+
+
+class Tables:
+    def __init__(self, blob: bytes):
+        self.groups = []
+        cur = None
+        for tag, count, pl in parse_dump(blob):
+            if tag == "HEAD":
+                (self.n_cols, self.n_scan_cols, self.n_groups, self.n_rules, self.n_ip_lists, self.set_words, self.has_geo, self.flags) = struct.unpack("<8I", pl)
+            elif tag == "GHDR":
+                f, ns, nc, fe, st, ab, nl, na = struct.unpack("<8I", pl)
+                cur = dict(field=f, n_states=ns, n_classes=nc, first_emit=fe, start=st, atom_base=ab, n_local=nl, n_atoms=na)
+                self.groups.append(cur)
+            elif tag == "GCLS":
+                cur["classmap"] = np.frombuffer(pl, dtype=np.uint8)
+            elif tag == "GTRN":
+                cur["trans"] = np.frombuffer(pl, dtype="<u2").reshape(cur["n_states"], cur["n_classes"])
+            elif tag == "GEMO":
+                cur["emit_off"] = np.frombuffer(pl, dtype="<u4")
+            elif tag == "GEML":
+                cur["emit_list"] = np.frombuffer(pl, dtype="<u2")
+            elif tag == "GENO":
+                cur["end_off"] = np.frombuffer(pl, dtype="<u4")
+            elif tag == "GENL":
+                cur["end_list"] = np.frombuffer(pl, dtype="<u2")
+            elif tag == "NUMA":
+                self.num_atoms = np.frombuffer(pl, dtype=NUMA_DTYPE)
+            elif tag == "INTP":
+                self.int_pool = np.frombuffer(pl, dtype="<i8")
+            elif tag == "CLUT":
+                self.country_luts = np.frombuffer(pl, dtype="<u4")
+            elif tag == "RULE":
+                self.rules = np.frombuffer(pl, dtype=RULE_DTYPE)
+            elif tag == "LITS":
+                self.lits = np.frombuffer(pl, dtype="<u4")
+            elif tag == "SETM":
+                self.set_masks = np.frombuffer(pl, dtype="<u4")
+            elif tag in ("IR4 ", "IR6 ", "INOD", "GR4 ", "GR6 ", "GNOD"):
+                setattr(self, tag.strip().lower(), np.frombuffer(pl, dtype="<u4"))
+            elif tag == "GREC":
+                self.geo_recs = np.frombuffer(pl, dtype=GREC_DTYPE)
+
+    # --- pieces ---
+    def scan_field(self, g: dict, data: bytes, cols: set):
+        """Walks one field through group g's DFA, adding the device column ids that hold."""
+        st = g["start"]
+        fe = g["first_emit"]
+
+        def emit(s):
+            if s >= fe:
+                k = s - fe
+                for a in g["emit_list"][g["emit_off"][k]:g["emit_off"][k + 1]]:
+                    cols.add(g["atom_base"] + int(a))
+        emit(st)
+        cm, tr = g["classmap"], g["trans"]
+        for b in data:
+            st = int(tr[st, cm[b]])
+            emit(st)
+        for a in g["end_list"][g["end_off"][st]:g["end_off"][st + 1]]:
+            cols.add(g["atom_base"] + int(a))
+
+    @staticmethod
+    def trie_lookup(root, nodes, ip: bytes) -> int:
+        if root is None or len(root) == 0:
+            return 0
+        e = int(root[(ip[0] << 8) | ip[1]])
+        k = 2
+        while not (e & TRIE_LEAF):
+            e = int(nodes[e * 256 + ip[k]])
+            k += 1
+        return e & ~TRIE_LEAF
+
+    def geo(self, ip: bytes, v6: bool):
+        asn, country = 0, b"XX"
+        if not self.has_geo:
+            return asn, country
+        if not v6:
+            if ip[0] == 127 or (ip[0] & 0xF0) == 0xE0:
+                return asn, country
+        else:
+            if ip[:15] == b"\0" * 15 and ip[15] == 1:
+                return asn, country
+            if ip[0] == 0xFF:
+                return asn, country
+        rec = self.trie_lookup(self.gr6 if v6 else self.gr4, self.gnod, ip)
+        r = self.geo_recs[rec]
+        return int(r["asn"]), int(r["country"]).to_bytes(2, "little")
+
+    def evaluate(self, batch, i: int):
+        """Returns (action, rule_idx) for request i of a RequestBatch, exactly as the device pipeline would."""
+        cols = {0}
+        fields = [batch.field_bytes(f, i) for f in range(5)]
+        for g in self.groups:
+            self.scan_field(g, fields[g["field"]], cols)
+        ip = batch.ip[i].tobytes()
+        v6 = bool(batch.ip_is_v6[i])
+        port = int(batch.port[i])
+        verified = bool(batch.flags[i] & _abi.FLAG_CAPTCHA_VERIFIED)
+        if batch.asn is not None:
+            asn, country = int(batch.asn[i]), int(batch.country[i]).to_bytes(2, "little")
+        else:
+            asn, country = self.geo(ip, v6)
+        c0, c1 = country[0] - 65, country[1] - 65
+        cidx = c0 * 26 + c1 if 0 <= c0 < 26 and 0 <= c1 < 26 else 23 * 26 + 23
+        set_id = self.trie_lookup(self.ir6 if v6 else self.ir4, self.inod, ip) if self.n_ip_lists else 0
+        for d in self.num_atoms:
+            kind, var, op, c = int(d["kind"]), int(d["var"]), int(d["op"]), int(d["c"])
+            t = False
+            if kind in (ATOM_LEN, ATOM_INT):
+                v = len(fields[var]) if kind == ATOM_LEN else (port if var == 0 else asn)
+                t = {OP_EQ: v == c, OP_LT: v < c, OP_LE: v <= c}[op]
+            elif kind == ATOM_INTSET:
+                v = port if var == 0 else asn
+                t = v in set(int(x) for x in self.int_pool[int(d["ref"]):int(d["ref2"])])
+            elif kind == ATOM_IPSET:
+                r = int(d["ref"])
+                t = bool((int(self.set_masks[set_id * self.set_words + (r >> 5)]) >> (r & 31)) & 1)
+            elif kind == ATOM_COUNTRY:
+                t = bool((int(self.country_luts[int(d["ref"]) * 22 + (cidx >> 5)]) >> (cidx & 31)) & 1)
+            if t:
+                cols.add(int(d["col"]))
+        for r in self.rules:
+            acc_or, acc_and = False, True
+            for k in range(int(r["lit_off"]), int(r["lit_off"]) + int(r["lit_cnt"])):
+                lit = int(self.lits[k])
+                v = (lit & LIT_ATOM_MASK) in cols
+                if lit & LIT_NEG:
+                    v = not v
+                acc_and = acc_and and v
+                if lit & LIT_TERM_END:
+                    acc_or = acc_or or acc_and
+                    acc_and = True
+            if acc_or:
+                eff = int(r["eff_v"] if verified else r["eff_u"])
+                if eff:
+                    return eff, int(r["public_idx"])
+        return _abi.ACTION_ALLOW, _abi.RULE_NONE
