@@ -1,0 +1,58 @@
+"""Multi-GPU sharding of request batches: one process per GPU, no data-path collective.
+
+Requests are independent and the compiled tables are immutable (pingoo/server.rs:40-47,76: rules, lists and
+GeoIP are loaded once and shared read-only), so every rank holds a full replica of the tables and evaluates a
+contiguous slab of the request stream. The only exchange is the all-reduce of the four action counters
+(RCCL over xGMI through torch.distributed's "nccl" backend on GPUs; "gloo" in CPU tests). Verdict arrays are
+NOT gathered: each shard's verdicts go back to its own host buffers.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+GROUP = 64  # requests per bit-column word on the device: slabs are aligned to it so no group straddles two ranks
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slab [lo, hi) of rank `rank` out of `world`: balanced to within one 64-request group."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    groups = (n + GROUP - 1) // GROUP
+    lo_g = groups * rank // world
+    hi_g = groups * (rank + 1) // world
+    return min(n, lo_g * GROUP), min(n, hi_g * GROUP)
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment; (0, 1, 0) when absent."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend: str | None = None):
+    """Initialises torch.distributed from the env when WORLD_SIZE > 1. nccl == RCCL on ROCm."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world, local = env_rank()
+    if world == 1 or dist.is_initialized():
+        return rank, world, local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_counts(counts):
+    """Sums the per-rank action counters (int64 tensor [4] on the rank's device) in place across ranks."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts

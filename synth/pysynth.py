@@ -1,0 +1,95 @@
+"""ctypes wrapper of the synthetic workload generator (synth/synth.cpp): test & bench infrastructure."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pingoo_amd import _abi
+from pingoo_amd.batch import GEOIP_DTYPE, RequestBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpwaf_synth.so")
+_lib = None
+DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "synth.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB_PATH, src, "-lpthread"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.synth_create.argtypes = [C.c_int, C.c_uint64]
+        L.synth_create.restype = C.c_void_p
+        L.synth_destroy.argtypes = [C.c_void_p]
+        L.synth_destroy.restype = None
+        for f in ("synth_rules_text", "synth_lists_text"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_char_p
+        L.synth_geoip_count.argtypes = [C.c_void_p]
+        L.synth_geoip_count.restype = C.c_size_t
+        L.synth_geoip_fill.argtypes = [C.c_void_p, C.c_void_p]
+        L.synth_geoip_fill.restype = None
+        L.synth_sizes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+        L.synth_sizes.restype = None
+        L.synth_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.synth_fill.restype = None
+        _lib = L
+    return _lib
+
+
+_ACTIONS = {"block": _abi.RULE_ACTION_BLOCK, "captcha": _abi.RULE_ACTION_CAPTCHA}
+
+
+class Workload:
+    """config_id: 1..3, 5 = BASELINE.json configs[0..2], [4]; 0 = tiny mixed config for unit tests."""
+
+    def __init__(self, config_id: int, seed: int = 0):
+        self.config_id = config_id
+        self._h = C.c_void_p(lib().synth_create(config_id, seed))
+        self.rules = []
+        for line in lib().synth_rules_text(self._h).decode().splitlines():
+            name, acts, expr = line.split("\t", 2)
+            self.rules.append((name, expr, [_ACTIONS[a] for a in acts.split(",")]))
+        lists = {}
+        for line in lib().synth_lists_text(self._h).decode().splitlines():
+            name, item = line.split("\t", 1)
+            lists.setdefault(name, []).append(item)
+        self.lists = {k: (_abi.LIST_INT if k.startswith("asn") else _abi.LIST_IP, v) for k, v in lists.items()}
+        n = lib().synth_geoip_count(self._h)
+        self.geoip = None
+        if n:
+            self.geoip = np.zeros(n, dtype=GEOIP_DTYPE)
+            lib().synth_geoip_fill(self._h, self.geoip.ctypes.data)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().synth_destroy(self._h)
+            self._h = None
+
+    def batch(self, start: int, n: int, threads: int = DEFAULT_THREADS) -> RequestBatch:
+        sizes = (C.c_uint64 * 5)()
+        lib().synth_sizes(self._h, start, n, sizes, threads)
+        for s in sizes:
+            if s + _abi.ARENA_PAD >= 2 ** 32:
+                raise ValueError("a field arena would exceed the 32-bit offset range: split the batch")
+        data = [np.zeros(int(s) + _abi.ARENA_PAD, dtype=np.uint8) for s in sizes]
+        offs = [np.zeros(n + 1, dtype=np.uint32) for _ in range(5)]
+        ip = np.zeros((n, 16), dtype=np.uint8)
+        v6 = np.zeros(n, dtype=np.uint8)
+        port = np.zeros(n, dtype=np.uint16)
+        flags = np.zeros(n, dtype=np.uint8)
+        dp = (C.c_void_p * 5)(*[d.ctypes.data for d in data])
+        op = (C.c_void_p * 5)(*[o.ctypes.data for o in offs])
+        lib().synth_fill(self._h, start, n, dp, op, ip.ctypes.data, v6.ctypes.data, port.ctypes.data, flags.ctypes.data, threads)
+        return RequestBatch(data, offs, ip, v6, port, flags)

@@ -1,0 +1,496 @@
+// synth.cpp — deterministic synthetic workload generator for tests and bench (NOT product code, NOT oracle).
+//
+// Implements the synthetic request / rule / list / GeoIP model of SURVEY.md §8(d): the reference ships no
+// request corpus, rule corpus or .mmdb fixture, so both the CPU oracle and the GPU engine are
+// fed from this one generator. Everything is a pure function of (config id, seed, request index):
+// any request range can be regenerated independently (parallel fill, CPU-baseline samples, shards of a
+// multi-GPU run) and yields identical bytes.
+//
+// PRNG: SplitMix64 (seeding / per-request streams) + xoshiro256**. seed = 0x50494E47 ^ config_id by default.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct SplitMix {
+    uint64_t s;
+    explicit SplitMix(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+};
+struct Rng {
+    uint64_t s[4];
+    explicit Rng(uint64_t seed) {
+        SplitMix sm(seed);
+        for (auto &x : s) x = sm.next();
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return r;
+    }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+    double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    bool chance(double p) { return unit() < p; }
+    uint32_t range(uint32_t lo, uint32_t hi) { return lo + below(hi - lo + 1); }  // inclusive
+};
+
+static const char *kAttackTokens[] = {
+    "/.env", "/.git", "/wp-admin", "../", "<script", "union select", "/etc/passwd", "/phpmyadmin", "/.aws/credentials", "/cgi-bin/", "cmd.exe",
+    "/wp-login.php", "/xmlrpc.php", "/.svn/entries", "/actuator/env", "/server-status", "${jndi:", "/vendor/phpunit", "/.DS_Store", "/config.json",
+    "/backup.sql", "/id_rsa", "base64_decode(", "/solr/admin", "/manager/html", "/console/login", "/.htpasswd", "/web.config", "/debug/pprof", "sleep(5)",
+};
+static const int kNAttack = sizeof(kAttackTokens) / sizeof(kAttackTokens[0]);
+static const char *kMethods[] = {"GET", "POST", "HEAD", "PUT", "DELETE"};
+static const int kMethodW[] = {80, 95, 97, 99, 100};
+static const char *kTlds[] = {"com", "net", "org", "io", "dev", "app", "co.uk", "de", "fr", "jp"};
+
+struct Config {
+    int id;
+    uint64_t seed;
+    std::vector<std::string> words;      // 5000 common words (paths, query keys)
+    std::vector<std::string> rare;       // 4000 rare words: each appears in ~1e-5 of requests; literal rules target them
+    std::vector<std::string> hosts;      // 1000 host names, Zipf(1.1)
+    std::vector<double> host_cdf;
+    std::vector<std::string> uas;        // 200 user-agent templates
+    std::vector<std::string> rare_uas;   // 64 rare bot agents
+    // generated rule set
+    std::string rules_text, lists_text;
+    struct Geo { uint8_t addr[16]; uint8_t len, v6; char cc[2]; uint32_t asn; };
+    std::vector<Geo> geo;
+    int n_headers = 0;
+};
+
+static std::string make_word(Rng &r, int minl, int maxl) {
+    static const char *cons = "bcdfghjklmnprstvwz", *vow = "aeiou";
+    int len = (int)r.range((uint32_t)minl, (uint32_t)maxl);
+    std::string w;
+    for (int k = 0; k < len; k++) w += (k & 1) ? vow[r.below(5)] : cons[r.below(18)];
+    return w;
+}
+
+static void build_pools(Config &c) {
+    Rng r(c.seed ^ 0xA11CE);
+    std::vector<std::string> seen;
+    for (int k = 0; k < 5000; k++) c.words.push_back(make_word(r, 3, 10));
+    // rare words carry a digit/marker so they can never collide with a common word or a substring of one
+    for (int k = 0; k < 4000; k++) c.rare.push_back(make_word(r, 3, 7) + std::to_string(r.range(10, 99)) + make_word(r, 2, 4));
+    for (int k = 0; k < 1000; k++) {
+        std::string h = make_word(r, 3, 12);
+        if (r.chance(0.5)) h = make_word(r, 3, 8) + "." + h;
+        if (r.chance(0.2)) h = "www." + h;
+        h += ".";
+        h += kTlds[r.below(10)];
+        if (r.chance(0.7)) h = make_word(r, 4, 10) + "-" + make_word(r, 3, 9) + "." + h;
+        if (r.chance(0.5)) h = make_word(r, 2, 6) + std::to_string(r.below(100)) + "." + h;
+        if (h.size() < 8) h = "api-" + h;
+        if (h.size() > 64) h.resize(64);
+        c.hosts.push_back(h);
+    }
+    double tot = 0;
+    for (int k = 0; k < 1000; k++) { tot += 1.0 / std::pow(k + 1.0, 1.1); c.host_cdf.push_back(tot); }
+    for (auto &x : c.host_cdf) x /= tot;
+    for (int k = 0; k < 200; k++) {
+        char buf[320];
+        int fam = (int)r.below(100);
+        if (fam < 45) snprintf(buf, sizeof buf, "Mozilla/5.0 (Windows NT 10.0; Win64; x64) AppleWebKit/537.36 (KHTML, like Gecko) Chrome/%u.0.%u.%u Safari/537.36", r.range(90, 131), r.range(1000, 6999), r.range(10, 250));
+        else if (fam < 60) snprintf(buf, sizeof buf, "Mozilla/5.0 (Macintosh; Intel Mac OS X 10_15_%u) AppleWebKit/605.1.15 (KHTML, like Gecko) Version/%u.%u Safari/605.1.15", r.range(1, 7), r.range(13, 18), r.range(0, 6));
+        else if (fam < 72) snprintf(buf, sizeof buf, "Mozilla/5.0 (X11; Linux x86_64; rv:%u.0) Gecko/20100101 Firefox/%u.0", r.range(90, 133), r.range(90, 133));
+        else if (fam < 80) snprintf(buf, sizeof buf, "Mozilla/5.0 (iPhone; CPU iPhone OS %u_%u like Mac OS X) AppleWebKit/605.1.15 (KHTML, like Gecko) Version/%u.0 Mobile/15E148 Safari/604.1", r.range(14, 18), r.range(0, 7), r.range(14, 18));
+        else if (fam < 86) snprintf(buf, sizeof buf, "curl/%u.%u.%u", r.range(7, 8), r.range(0, 12), r.range(0, 9));
+        else if (fam < 91) snprintf(buf, sizeof buf, "python-requests/2.%u.%u", r.range(20, 32), r.range(0, 5));
+        else if (fam < 94) snprintf(buf, sizeof buf, "Go-http-client/%u.%u", r.range(1, 2), r.range(0, 1));
+        else if (fam < 96) snprintf(buf, sizeof buf, "Mozilla/5.0 (compatible; Googlebot/2.1; +http://www.google.com/bot.html)");
+        else if (fam < 98) snprintf(buf, sizeof buf, "Mozilla/5.0 (compatible; bingbot/2.0; +http://www.bing.com/bingbot.htm)");
+        else snprintf(buf, sizeof buf, "okhttp/%u.%u.%u", r.range(3, 4), r.range(0, 12), r.range(0, 9));
+        c.uas.push_back(buf);
+    }
+    for (int k = 0; k < 64; k++) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "%sBot/%u.%u (+http://%s.example/bot)", c.rare[(size_t)(3000 + k)].c_str(), r.range(1, 9), r.range(0, 9), make_word(r, 4, 9).c_str());
+        c.rare_uas.push_back(buf);
+    }
+}
+
+// ---- one request ------------------------------------------------------------------------------------------
+struct Req {
+    std::string host, url, path, method, ua;
+    uint8_t ip[16];
+    uint8_t v6;
+    uint16_t port;
+    uint8_t flags;
+};
+
+static void gen_request(const Config &c, uint64_t idx, Req &q) {
+    Rng r(c.seed ^ (0xD1B54A32D192ED03ull * (idx + 1)));
+    // host
+    double u = r.unit();
+    size_t hi = (size_t)(std::lower_bound(c.host_cdf.begin(), c.host_cdf.end(), u) - c.host_cdf.begin());
+    q.host = c.hosts[std::min(hi, c.hosts.size() - 1)];
+    // path
+    q.path.clear();
+    int segs = (int)r.range(2, 8);
+    if (r.chance(0.6)) segs += (int)r.range(2, 6);  // long tail towards the 128-byte cap
+    for (int s = 0; s < segs; s++) {
+        q.path += '/';
+        q.path += c.words[r.below(5000)];
+    }
+    if (r.chance(0.3)) { static const char *ext[] = {".html", ".js", ".css", ".png", ".json"}; q.path += ext[r.below(5)]; }
+    if (r.chance(0.02)) {
+        // attack token (2 % of requests)
+        std::string tok = kAttackTokens[r.below((uint32_t)kNAttack)];
+        if (tok[0] == '/' && r.chance(0.5)) q.path = tok + q.path;            // at the start (prefix rules)
+        else if (tok[0] == '/') q.path += tok;
+        else q.path += "/" + tok;
+    }
+    if (r.chance(0.01)) {
+        // a rare word somewhere in the path
+        q.path += '/';
+        q.path += c.rare[r.below(3000)];
+    }
+    if (q.path.size() > 128) q.path.resize(128);
+    // url = path (before the trailing-slash trim) + query
+    bool trailing = r.chance(0.05);
+    q.url = q.path;
+    if (trailing) q.url += '/';
+    while (!q.path.empty() && q.path.back() == '/') q.path.pop_back();  // get_path (http_utils.rs:114-116)
+    int nq = (int)r.below(6);
+    for (int k = 0; k < nq; k++) {
+        q.url += k ? '&' : '?';
+        q.url += c.words[r.below(5000)];
+        q.url += '=';
+        if (r.chance(0.004)) q.url += c.rare[r.below(3000)];
+        else if (r.chance(0.5)) q.url += std::to_string(r.below(100000));
+        else q.url += c.words[r.below(5000)];
+    }
+    // method
+    uint32_t m = r.below(100);
+    int mi = 0;
+    while (m >= (uint32_t)kMethodW[mi]) mi++;
+    q.method = kMethods[mi];
+    // user agent
+    double ur = r.unit();
+    if (ur < 0.001) q.ua.clear();
+    else if (ur < 0.002) q.ua = std::string(256 + r.below(40), 'A');
+    else if (ur < 0.004) q.ua = c.rare_uas[r.below(64)];
+    else q.ua = c.uas[r.below(200)];
+    // client
+    memset(q.ip, 0, 16);
+    if (r.chance(0.9)) {
+        q.v6 = 0;
+        q.ip[0] = (uint8_t)r.range(1, 223);
+        q.ip[1] = (uint8_t)r.below(256);
+        q.ip[2] = (uint8_t)r.below(256);
+        q.ip[3] = (uint8_t)r.below(256);
+    } else {
+        q.v6 = 1;
+        uint64_t a = r.next(), b = r.next();
+        for (int k = 0; k < 8; k++) { q.ip[k] = (uint8_t)(a >> (56 - 8 * k)); q.ip[8 + k] = (uint8_t)(b >> (56 - 8 * k)); }
+        q.ip[0] = (uint8_t)(0x20 | (q.ip[0] & 0x1F));  // 2000::/3
+    }
+    q.port = (uint16_t)r.range(1024, 65535);
+    q.flags = r.chance(0.05) ? 1 : 0;
+}
+
+// ---- rules / lists / geoip ----------------------------------------------------------------------------------
+static std::string quote(const std::string &s) {
+    std::string o = "\"";
+    for (char ch : s) {
+        if (ch == '"' || ch == '\\') o += '\\';
+        o += ch;
+    }
+    return o + "\"";
+}
+static std::string v4str(uint32_t a) {
+    char b[32];
+    snprintf(b, sizeof b, "%u.%u.%u.%u", a >> 24, (a >> 16) & 255, (a >> 8) & 255, a & 255);
+    return b;
+}
+
+static const char *kFields[5] = {"host", "url", "path", "method", "user_agent"};
+
+static std::string literal_pred(Config &c, Rng &r, int &rare_cursor) {
+    // one atomic string predicate that fires rarely
+    int kind = (int)r.below(100);
+    if (kind < 12) {
+        std::string tok = kAttackTokens[r.below((uint32_t)kNAttack)];
+        return std::string("http_request.") + (r.chance(0.5) ? "path" : "url") + ".contains(" + quote(tok) + ")";
+    }
+    if (kind < 18) {
+        std::string tok = kAttackTokens[r.below((uint32_t)kNAttack)];
+        if (tok[0] == '/') return "http_request.path.starts_with(" + quote(tok) + ")";
+        return "http_request.url.contains(" + quote(tok) + ")";
+    }
+    const std::string &w = c.rare[(size_t)(rare_cursor++ % 3000)];
+    if (kind < 50) return "http_request.path.contains(" + quote("/" + w) + ")";
+    if (kind < 65) return "http_request.url.contains(" + quote("=" + w) + ")";
+    if (kind < 75) return "http_request.path.ends_with(" + quote(w) + ")";
+    if (kind < 82) return "http_request.user_agent.contains(" + quote(c.rare[(size_t)(3000 + r.below(64))] + "Bot/") + ")";
+    if (kind < 88) return "http_request.user_agent.starts_with(" + quote(c.rare[(size_t)(3000 + r.below(64))]) + ")";
+    if (kind < 94) return "http_request.host == " + quote(w + ".example.org");
+    if (kind < 97) return "http_request.host.ends_with(" + quote("." + w + ".internal") + ")";
+    return "http_request.path == " + quote("/" + w + "/" + c.rare[r.below(3000)]);
+}
+
+static std::string regex_pred(Config &c, Rng &r, int &rare_cursor) {
+    const std::string &w = c.rare[(size_t)(rare_cursor++ % 3000)], &w2 = c.rare[(size_t)(rare_cursor++ % 3000)];
+    int kind = (int)r.below(12);
+    std::string f, p;
+    switch (kind) {
+        case 0: f = "url"; p = "(?i)union\\s+select"; if (r.chance(0.7)) p = "(?i)" + w + "\\s+select"; break;
+        case 1: f = "path"; p = "\\.(" + w + "|" + w2 + "|php5)$"; break;
+        case 2: f = "path"; p = "^/api/v[0-9]+/" + w; break;
+        case 3: f = "url"; p = "(?i)<script[^>]*>" + w; break;
+        case 4: f = "url"; p = w + "=[0-9]{3,6}(&|$)"; break;
+        case 5: f = "user_agent"; p = "^" + w + "[A-Za-z]*/[0-9]+\\.[0-9]+"; break;
+        case 6: f = "path"; p = "/" + w + "/(\\.\\./)+"; break;
+        case 7: f = "url"; p = "(?i)(select|insert|delete)\\s.*\\s" + w; break;
+        case 8: f = "host"; p = "^([a-z0-9-]+\\.)*" + w + "\\.(com|net|org)$"; break;
+        case 9: f = "path"; p = "^/wp-(admin|login|content)/.*" + w + "\\.php$"; break;
+        case 10: f = "url"; p = "\\b" + w + "\\b.*\\b" + w2 + "\\b"; break;
+        default: f = "user_agent"; p = "(?i)(" + w + "|" + w2 + ")(bot|spider|crawl)"; break;
+    }
+    return "http_request." + f + ".matches(" + quote(p) + ")";
+}
+
+static void gen_cidr_list(Rng &r, int n, int minlen4, std::string &out, const char *name) {
+    // pingoo/lists.rs CSV: one network per line
+    for (int k = 0; k < n; k++) {
+        out += name;
+        out += '\t';
+        if (r.chance(0.85)) {
+            int len = (int)r.range((uint32_t)minlen4, 32);
+            uint32_t a = ((uint32_t)r.range(1, 223) << 24) | (uint32_t)(r.next() & 0xFFFFFF);
+            if (len < 32) a &= ~((1u << (32 - len)) - 1);
+            out += v4str(a);
+            if (len < 32 || r.chance(0.5)) out += "/" + std::to_string(len);
+        } else {
+            int len = (int)r.range(40, 64);
+            uint64_t hi = (r.next() & 0x1FFFFFFFFFFFFFFFull) | 0x2000000000000000ull;
+            hi &= ~((1ull << (64 - len)) - 1);
+            char b[64];
+            snprintf(b, sizeof b, "%x:%x:%x:%x::/%d", (unsigned)(hi >> 48), (unsigned)((hi >> 32) & 0xFFFF), (unsigned)((hi >> 16) & 0xFFFF), (unsigned)(hi & 0xFFFF), len);
+            out += b;
+        }
+        out += '\n';
+    }
+}
+
+static void build_rules(Config &c, int n_literal_rules, int n_regex, int n_cidr, int n_geo, int cidrs_per_list, bool combos) {
+    Rng r(c.seed ^ 0xB0B);
+    int rare_cursor = 0;
+    struct R { std::string name, acts, expr; };
+    std::vector<R> rules;
+    auto action = [&]() { double u = r.unit(); return u < 0.78 ? "block" : u < 0.97 ? "captcha" : "captcha,block"; };
+    for (int k = 0; k < n_literal_rules; k++) {
+        std::string e = literal_pred(c, r, rare_cursor);
+        if (combos) {
+            int shape = (int)r.below(10);
+            if (shape == 0) e = e + " || " + literal_pred(c, r, rare_cursor);
+            else if (shape == 1) e = e + " && http_request.method == " + quote(kMethods[r.below(5)]);
+            else if (shape == 2) e = "(" + e + " || " + literal_pred(c, r, rare_cursor) + ") && !http_request.user_agent.starts_with(\"Mozilla/\")";
+            else if (shape == 3) e = e + " && http_request.path.length() > " + std::to_string(r.range(8, 40));
+            else if (shape == 4) e = "!(" + e + ") ? false : client.remote_port >= 1024";
+        }
+        rules.push_back({"lit_" + std::to_string(k), action(), e});
+    }
+    for (int k = 0; k < n_regex; k++) rules.push_back({"re_" + std::to_string(k), action(), regex_pred(c, r, rare_cursor)});
+    for (int k = 0; k < n_cidr; k++) {
+        std::string ln = "l" + std::to_string(k);
+        gen_cidr_list(r, cidrs_per_list, 20, c.lists_text, ln.c_str());
+        rules.push_back({"cidr_" + std::to_string(k), action(), "lists[" + quote(ln) + "].contains(client.ip)"});
+    }
+    if (n_geo > 0) {
+        // GeoIP prefixes: 500k v4 + 100k v6 at full scale; scaled with the config
+        size_t n4 = c.id >= 3 ? 500000 : 20000, n6 = c.id >= 3 ? 100000 : 4000;
+        Rng g(c.seed ^ 0x6E0);
+        // Zipf-ish country popularity: a few big countries, a long tail the rules target
+        auto cc = [&](Rng &x, char out[2]) {
+            double u = x.unit();
+            int ci = (int)(676.0 * u * u * u * u * u * u);
+            out[0] = (char)('A' + ci / 26);
+            out[1] = (char)('A' + ci % 26);
+        };
+        for (size_t k = 0; k < n4; k++) {
+            Config::Geo e{};
+            int len = (int)g.range(12, 24);
+            uint32_t a = ((uint32_t)g.range(1, 223) << 24) | (uint32_t)(g.next() & 0xFFFFFF);
+            a &= ~((1u << (32 - len)) - 1);
+            e.addr[0] = (uint8_t)(a >> 24); e.addr[1] = (uint8_t)(a >> 16); e.addr[2] = (uint8_t)(a >> 8); e.addr[3] = (uint8_t)a;
+            e.len = (uint8_t)len;
+            cc(g, e.cc);
+            e.asn = g.chance(0.02) ? 0 : (uint32_t)g.range(1, 70000);
+            if (g.chance(0.0005)) e.cc[0] = 'x';  // a record that fails CountryCode validation (geoip.rs:128-142)
+            c.geo.push_back(e);
+        }
+        for (size_t k = 0; k < n6; k++) {
+            Config::Geo e{};
+            int len = (int)g.range(24, 48);
+            uint64_t hi = (g.next() & 0x1FFFFFFFFFFFFFFFull) | 0x2000000000000000ull;
+            hi &= ~((1ull << (64 - len)) - 1);
+            for (int b = 0; b < 8; b++) e.addr[b] = (uint8_t)(hi >> (56 - 8 * b));
+            e.len = (uint8_t)len;
+            e.v6 = 1;
+            cc(g, e.cc);
+            e.asn = (uint32_t)g.range(1, 70000);
+            c.geo.push_back(e);
+        }
+        for (int k = 0; k < n_geo; k++) {
+            int shape = (int)r.below(4);
+            std::string e;
+            auto rare_cc = [&]() {
+                int ci = 600 + (int)r.below(76);
+                if (ci == 23 * 26 + 23) ci++;  // never "XX": that is the default record of unmatched addresses (geoip.rs:111-118)
+                std::string s; s += (char)('A' + ci / 26); s += (char)('A' + ci % 26); return s; };
+            if (shape == 0) e = "client.country == " + quote(rare_cc());
+            else if (shape == 1) e = "[" + quote(rare_cc()) + ", " + quote(rare_cc()) + ", " + quote(rare_cc()) + "].contains(client.country)";
+            else if (shape == 2) e = "client.asn == " + std::to_string(r.range(1, 70000));
+            else {
+                std::string ln = "asn" + std::to_string(k);
+                for (int j = 0; j < 16; j++) c.lists_text += ln + "\t" + std::to_string(r.range(1, 70000)) + "\n";
+                e = "lists[" + quote(ln) + "].contains(client.asn)";
+            }
+            rules.push_back({"geo_" + std::to_string(k), action(), e});
+        }
+    }
+    // deterministic shuffle so rule kinds interleave (first-match-wins order matters)
+    for (size_t k = rules.size(); k > 1; k--) std::swap(rules[k - 1], rules[r.below((uint32_t)k)]);
+    for (auto &x : rules) c.rules_text += x.name + "\t" + x.acts + "\t" + x.expr + "\n";
+}
+
+static Config *make_config(int id, uint64_t seed) {
+    auto *c = new Config();
+    c->id = id;
+    c->seed = seed ? seed : (0x50494E47ull ^ (uint64_t)id);
+    build_pools(*c);
+    switch (id) {
+        case 1: {  // 16 literal-substring rules (plumbing)
+            Rng r(c->seed ^ 0xB0B);
+            int cur = 0;
+            for (int k = 0; k < 16; k++) {
+                static const char *f[] = {"path", "url", "user_agent", "host"};
+                std::string lit = k < 6 ? std::string(kAttackTokens[k]) : c->rare[(size_t)(cur++)];
+                if (k >= 12) lit = c->words[(size_t)(k * 37)];  // a few literals that hit ~1e-3 of requests
+                c->rules_text += "lit_" + std::to_string(k) + "\tblock\thttp_request." + f[k < 6 ? (k & 1) : (k % 3 == 2 ? 2 : k & 1)] + ".contains(" + quote(lit) + ")\n";
+            }
+            break;
+        }
+        case 2: build_rules(*c, 192, 0, 64, 0, 1024, true); break;
+        case 3: build_rules(*c, 600, 200, 124, 100, 1024, true); break;
+        case 5: build_rules(*c, 2800, 700, 396, 200, 512, true); break;  // 4096 rules (header fields: see DESIGN.md)
+        default: build_rules(*c, 24, 8, 4, 4, 64, true); break;           // tiny mixed config for unit tests
+    }
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+void *synth_create(int config_id, uint64_t seed) { return make_config(config_id, seed); }
+void synth_destroy(void *h) { delete (Config *)h; }
+const char *synth_rules_text(void *h) { return ((Config *)h)->rules_text.c_str(); }
+const char *synth_lists_text(void *h) { return ((Config *)h)->lists_text.c_str(); }
+size_t synth_geoip_count(void *h) { return ((Config *)h)->geo.size(); }
+// entries: 24-byte pwaf_geoip_entry layout
+void synth_geoip_fill(void *h, uint8_t *out) {
+    Config *c = (Config *)h;
+    for (size_t k = 0; k < c->geo.size(); k++) {
+        uint8_t *e = out + 24 * k;
+        memcpy(e, c->geo[k].addr, 16);
+        e[16] = c->geo[k].len;
+        e[17] = c->geo[k].v6;
+        e[18] = (uint8_t)c->geo[k].cc[0];
+        e[19] = (uint8_t)c->geo[k].cc[1];
+        memcpy(e + 20, &c->geo[k].asn, 4);
+    }
+}
+
+// total bytes per string field for requests [start, start + n)
+void synth_sizes(void *h, uint64_t start, uint64_t n, uint64_t out_bytes[5], int n_threads) {
+    const Config &c = *(Config *)h;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::vector<uint64_t>> part((size_t)n_threads, std::vector<uint64_t>(5, 0));
+    auto work = [&](int t) {
+        Req q;
+        uint64_t lo = start + n * (uint64_t)t / (uint64_t)n_threads, hi = start + n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        for (uint64_t i = lo; i < hi; i++) {
+            gen_request(c, i, q);
+            part[(size_t)t][0] += q.host.size(); part[(size_t)t][1] += q.url.size(); part[(size_t)t][2] += q.path.size();
+            part[(size_t)t][3] += q.method.size(); part[(size_t)t][4] += q.ua.size();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    for (int f = 0; f < 5; f++) { out_bytes[f] = 0; for (int t = 0; t < n_threads; t++) out_bytes[f] += part[(size_t)t][(size_t)f]; }
+}
+
+// fills SoA arrays for requests [start, start + n). data[f] must hold the byte totals from synth_sizes (+ pad),
+// offsets[f] n + 1 entries. Chunked two-pass so threads write disjoint ranges.
+void synth_fill(void *h, uint64_t start, uint64_t n, uint8_t *const data[5], uint32_t *const offsets[5], uint8_t *ip, uint8_t *v6, uint16_t *port,
+                uint8_t *flags, int n_threads) {
+    const Config &c = *(Config *)h;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::vector<uint64_t>> part((size_t)n_threads, std::vector<uint64_t>(5, 0));
+    auto bounds = [&](int t, uint64_t &lo, uint64_t &hi) { lo = n * (uint64_t)t / (uint64_t)n_threads; hi = n * (uint64_t)(t + 1) / (uint64_t)n_threads; };
+    auto pass1 = [&](int t) {
+        Req q;
+        uint64_t lo, hi;
+        bounds(t, lo, hi);
+        for (uint64_t i = lo; i < hi; i++) {
+            gen_request(c, start + i, q);
+            part[(size_t)t][0] += q.host.size(); part[(size_t)t][1] += q.url.size(); part[(size_t)t][2] += q.path.size();
+            part[(size_t)t][3] += q.method.size(); part[(size_t)t][4] += q.ua.size();
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(pass1, t);
+        for (auto &t : th) t.join();
+    }
+    std::vector<std::vector<uint64_t>> base((size_t)n_threads, std::vector<uint64_t>(5, 0));
+    for (int f = 0; f < 5; f++) {
+        uint64_t acc = 0;
+        for (int t = 0; t < n_threads; t++) { base[(size_t)t][(size_t)f] = acc; acc += part[(size_t)t][(size_t)f]; }
+        offsets[f][n] = (uint32_t)acc;
+    }
+    auto pass2 = [&](int t) {
+        Req q;
+        uint64_t lo, hi;
+        bounds(t, lo, hi);
+        uint64_t pos[5];
+        for (int f = 0; f < 5; f++) pos[f] = base[(size_t)t][(size_t)f];
+        for (uint64_t i = lo; i < hi; i++) {
+            gen_request(c, start + i, q);
+            const std::string *s[5] = {&q.host, &q.url, &q.path, &q.method, &q.ua};
+            for (int f = 0; f < 5; f++) {
+                offsets[f][i] = (uint32_t)pos[f];
+                memcpy(data[f] + pos[f], s[f]->data(), s[f]->size());
+                pos[f] += s[f]->size();
+            }
+            memcpy(ip + 16 * i, q.ip, 16);
+            v6[i] = q.v6;
+            port[i] = q.port;
+            flags[i] = q.flags;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(pass2, t);
+    for (auto &t : th) t.join();
+}
+
+}  // extern "C"

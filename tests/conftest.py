@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # build everything once per session: libpwaf.so (hipcc cross-compiles without a GPU), the oracle, the generator
+    import __graft_entry__
+
+    __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def kat():
+    from helpers import load_kat
+
+    return load_kat()

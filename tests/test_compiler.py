@@ -1,0 +1,162 @@
+"""Host compiler (no GPU): front-end accept/reject parity with the oracle, and the compiled tables —
+interpreted by the test-only walker in tests/table_walker.py — against the oracle's verdicts."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi
+from pingoo_amd.engine import CompiledProgram, ExpressionIsNotValid, PwafError, UnsupportedExpression, compile_expression, validate_expression
+from table_walker import Tables
+
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+
+
+def walk(program: CompiledProgram, batch: RequestBatch):
+    t = Tables(program.dump())
+    out = np.zeros(batch.n, dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    for i in range(batch.n):
+        out[i] = t.evaluate(batch, i)
+    return out
+
+
+def test_golden_vectors_through_compiled_tables(kat):
+    for c in kat["cases"]:
+        rules, lists, batch, expect = H.kat_case_inputs(c)
+        got = walk(CompiledProgram(rules, lists), batch)
+        assert [(int(v["action"]), int(v["rule_idx"])) for v in got] == [tuple(e) for e in expect.tolist()], c["name"]
+
+
+def test_syntax_accept_reject_parity_with_oracle():
+    """Two independently written parsers (recursive descent vs Pratt) must agree on every input."""
+    rng = random.Random(2024)
+    toks = ["a", "http_request", ".", "path", "(", ")", "[", "]", "{", "}", ",", ":", "?", "!", "-", "+", "*", "/", "%", "==", "!=", "<", "<=", ">", ">=", "&&", "||", "in", "true",
+            "null", "1", "2.5", "0x1f", '"s"', "'t'", 'r"\\d"', " ", "contains", "9223372036854775808", "1u", '"\\q"', "//c\n", "\n", ".5", "1e3", "e", "_x1", "@", '"', "-9223372036854775808"]
+    n_ok = n_bad = 0
+    for _ in range(6000):
+        e = "".join(rng.choice(toks) + rng.choice(["", "", " "]) for _ in range(rng.randint(1, 9)))
+        try:
+            pyoracle.compile_expression(e)
+            o_ok = True
+        except pyoracle.OracleError:
+            o_ok = False
+        try:
+            compile_expression(e)
+            p_ok = True
+        except ExpressionIsNotValid:
+            p_ok = False
+        assert o_ok == p_ok, repr(e)
+        try:
+            pyoracle.validate_expression(e)
+            ov = True
+        except pyoracle.OracleError:
+            ov = False
+        try:
+            validate_expression(e)
+            pv = True
+        except ExpressionIsNotValid:
+            pv = False
+        assert ov == pv, repr(e)
+        n_ok += o_ok
+        n_bad += not o_ok
+    assert n_ok > 300 and n_bad > 300, (n_ok, n_bad)
+    for e in [H.rexpr(rng, {}) for _ in range(300)]:
+        pyoracle.compile_expression(e)
+        compile_expression(e)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_compiled_tables_match_oracle(seed):
+    rng = random.Random(1000 + seed)
+    lists = H.fuzz_lists(rng)
+    geo = H.fuzz_geoip(rng) if rng.random() < 0.7 else None
+    with_geo = rng.random() < 0.3
+    rules = []
+    for k in range(rng.randint(1, 12)):
+        e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
+        acts = H.fuzz_actions(rng)
+        try:
+            CompiledProgram([("r", e, acts)], lists)
+        except UnsupportedExpression:
+            continue
+        rules.append((f"r{k}", e, acts))
+    flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
+    prog = CompiledProgram(rules, lists, geo, flags=flags, lds_table_budget=rng.choice([0, 0, 2048, 4096]))
+    batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
+    want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
+    H.assert_verdicts_equal(walk(prog, batch), want, batch, f"seed {seed}")
+
+
+def test_synthetic_workload_tables_match_oracle():
+    from synth import pysynth
+
+    for cid, n in ((0, 1500), (2, 400)):
+        w = pysynth.Workload(cid)
+        prog = CompiledProgram(w.rules, w.lists, w.geoip)
+        assert not prog.warnings(), prog.warnings()
+        # take the requests that do NOT end up Allow plus a slice of ordinary ones, so rule paths are exercised
+        big = w.batch(0, 40000)
+        ov = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(big, threads=4)
+        idx = np.concatenate([np.nonzero(ov["action"] != 0)[0][: n // 2], np.arange(n // 2)])
+        reqs = RequestBatch(
+            [np.concatenate([big.data[f][big.offsets[f][i]:big.offsets[f][i + 1]] for i in idx] + [np.zeros(16, np.uint8)]) for f in range(5)],
+            [np.concatenate([[0], np.cumsum([int(big.offsets[f][i + 1]) - int(big.offsets[f][i]) for i in idx])]).astype(np.uint32) for f in range(5)],
+            big.ip[idx], big.ip_is_v6[idx], big.port[idx], big.flags[idx])
+        want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(reqs)
+        assert (want["action"] != 0).sum() >= min(n // 2, 50)
+        H.assert_verdicts_equal(walk(prog, reqs), want, reqs, f"workload {cid}")
+
+
+def test_static_errors_become_warnings_not_failures():
+    p = CompiledProgram([("a", "http_request.nope == 1", [B]), ("b", "http_request.path", [B]), ("c", 'http_request.path.matches("(")', [B]),
+                         ("d", 'lists["missing"].contains(client.ip)', [B]), ("e", "undefined(1)", [B]), ("ok", 'http_request.path == "/x"', [B])])
+    w = p.warnings()
+    assert len(w) == 5 and all("never match" in x for x in w), w
+    assert p.stats()["n_rules"] == 3  # UA gate, captcha endpoint, and the one live rule
+
+
+def test_unsupported_constructs_are_rejected_with_the_rule_index():
+    cases = ['http_request.host == http_request.path', "client.remote_port + 1 == 81", 'http_request.path < "m"', 'http_request.path.matches(http_request.host)',
+             '(http_request.method == "GET" ? http_request.path : http_request.url) == "/"', 'http_request.url.matches("\\\\p{L}")', 'http_request.path + "x" == "/x"',
+             "[http_request.method].contains(\"GET\")", 'http_request.path.matches("(?x)a b")']
+    for e in cases:
+        pyoracle.compile_expression(e)  # valid language, just outside the device subset
+        with pytest.raises(UnsupportedExpression) as ei:
+            CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])])
+        assert ei.value.rule_index == 1 and "bad" in ei.value.message, e
+    with pytest.raises(ExpressionIsNotValid) as ei:
+        CompiledProgram([("x", "a ==", [B])])
+    assert ei.value.rule_index == 0
+    with pytest.raises(PwafError) as ei:
+        CompiledProgram([("x", None, [7])])
+    assert ei.value.code == _abi.E_INVALID_ARG
+    with pytest.raises(PwafError) as ei:
+        CompiledProgram([("x", None, [B])], {"l": (_abi.LIST_IP, ["1.2.3"])})
+    assert ei.value.code == _abi.E_LIST and "line 1" in ei.value.message
+
+
+def test_dfa_grouping_respects_the_lds_budget_and_keeps_results():
+    rng = random.Random(7)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(3, 7))) for _ in range(120)]
+    rules = [(f"r{k}", f'http_request.path.contains("{w}")', [B]) for k, w in enumerate(words)]
+    big = CompiledProgram(rules)
+    small = CompiledProgram(rules, lds_table_budget=4096)
+    assert big.stats()["n_dfa_groups"] == 1 + 0 or big.stats()["n_dfa_groups"] >= 1
+    assert small.stats()["n_dfa_groups"] > big.stats()["n_dfa_groups"]
+    t = Tables(small.dump())
+    for g in t.groups:
+        assert g["n_states"] * g["n_classes"] * 2 <= 4096
+    reqs = [Request(path="/" + "".join(rng.choice(words + ["zz", "/"]) for _ in range(rng.randint(0, 3)))) for _ in range(200)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(walk(big, batch), want, batch, "one group")
+    H.assert_verdicts_equal(walk(small, batch), want, batch, "split groups")
+
+
+def test_atoms_are_shared_across_rules():
+    rules = [(f"r{k}", 'http_request.path.contains("/admin") && client.remote_port == %d' % k, [B]) for k in range(50)]
+    s = CompiledProgram(rules).stats()
+    assert s["n_scan_atoms"] == 2  # "/admin" once + the captcha-endpoint prefix
+    assert s["n_numeric_atoms"] == 50 + 2  # 50 ports + the two UA-length gate atoms

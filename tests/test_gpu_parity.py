@@ -1,0 +1,176 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libpwaf.so), against the CPU oracle on identical
+inputs — bit-exact (actions and deciding rule index are integers). Needs a real MI355X: `pytest -m gpu`."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi
+from pingoo_amd.engine import Decision, DeviceBatch, RuleEngine, UnsupportedExpression
+
+pytestmark = pytest.mark.gpu
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+
+
+def test_golden_vectors_on_the_gpu(kat):
+    for c in kat["cases"]:
+        rules, lists, batch, expect = H.kat_case_inputs(c)
+        eng = RuleEngine(rules, lists)
+        got = eng.evaluate_batch(batch)
+        assert [(int(v["action"]), int(v["rule_idx"])) for v in got] == [tuple(e) for e in expect.tolist()], c["name"]
+        # evaluate(Request) -> Action façade == batch of one
+        for i, r in enumerate(c["requests"]):
+            v = eng.evaluate(Request(**r))
+            assert int(v.decision) == expect[i][0], (c["name"], i)
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_gpu_matches_oracle(seed):
+    rng = random.Random(5000 + seed)
+    lists = H.fuzz_lists(rng)
+    geo = H.fuzz_geoip(rng) if rng.random() < 0.7 else None
+    with_geo = rng.random() < 0.3
+    rules = []
+    for k in range(rng.randint(1, 14)):
+        e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
+        acts = H.fuzz_actions(rng)
+        try:
+            from pingoo_amd.engine import CompiledProgram
+            CompiledProgram([("r", e, acts)], lists)
+        except UnsupportedExpression:
+            continue
+        rules.append((f"r{k}", e, acts))
+    flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS])
+    eng = RuleEngine(rules, lists, geo, flags=flags, lds_table_budget=rng.choice([0, 0, 2048, 8192]))
+    n = rng.choice([1, 63, 64, 65, 200, 777])
+    batch = RequestBatch.from_requests(H.fuzz_requests(rng, n, with_geo))
+    want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, f"seed {seed}")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    eng.close()
+
+
+@pytest.mark.parametrize("cid,n", [(0, 20000), (1, 10000), (2, 20000), (3, 6000)])
+def test_synthetic_configs_match_oracle(cid, n):
+    """BASELINE.json configs at sizes the oracle finishes in seconds (config 1 at its full 10k x 16)."""
+    from synth import pysynth
+
+    w = pysynth.Workload(cid)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    batch = w.batch(0, n)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=8)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, f"config {cid}")
+    hist = np.bincount(want["action"], minlength=4)
+    assert counts.tolist() == hist.tolist()
+    assert hist[1] > 0 and hist[0] > hist[1]  # some blocks, mostly allows
+    eng.close()
+
+
+def test_edge_cases_empty_ragged_and_maximum_lengths():
+    rules = [("long", "http_request.url.length() >= 4000", [B]), ("tail", 'http_request.url.ends_with("zz")', [CAP]), ("h", 'http_request.host == ""', [B]),
+             ("p", 'http_request.path.matches("^(/[a-z]+)*$") && http_request.path.length() > 30', [B])]
+    eng = RuleEngine(rules)
+    orc = pyoracle.Oracle(rules)
+    # empty batch
+    empty = RequestBatch.from_requests([])
+    assert len(eng.evaluate_batch(empty)) == 0
+    reqs = [Request(host="", url="", path="", method="", user_agent="x"),                      # every field empty (UA must not be, or the gate fires)
+            Request(url="/" + "a" * 8000 + "zz", host="h"), Request(url="/" + "a" * 3997 + "zz", host="h"),  # far beyond any 16-byte chunk
+            Request(url="zz", host="h"), Request(url="z", host="h"), Request(host="h" * 256), Request(user_agent="u" * 255, host="h"),
+            Request(path="/abc/def/ghi/jkl/mno/pqr/stu/vwx/yz", host="h"), Request(path="/abc/def/ghi/jkl/mno/pqr/stu/vwx/y1", host="h")]
+    for k in range(1, 40):  # ragged lengths around the chunk size, ending on every alignment
+        reqs.append(Request(url="q" * k + "zz", host="h"))
+        reqs.append(Request(url="q" * k + "z", host="h"))
+    for n in (1, 2, 63, 64, 65, len(reqs)):
+        batch = RequestBatch.from_requests(reqs[:n])
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), orc.evaluate(batch), batch, f"n={n}")
+    eng.close()
+
+
+def test_device_resident_api_counts_and_match_compaction():
+    import torch
+    from synth import pysynth
+
+    w = pysynth.Workload(2)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    batch = w.batch(100000, 30000)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=8)
+    db = DeviceBatch(batch)
+    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    midx = torch.full((batch.n,), -1, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = eng.evaluate_device(db, counts=counts, match_idx=midx, n_matches=nm)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got[:, 0] == want["action"]).all() and (got[:, 1] == want["rule_idx"]).all()
+    assert counts.cpu().tolist() == np.bincount(want["action"], minlength=4).tolist()
+    k = int(nm.item())
+    hits = np.sort(midx[:k].cpu().numpy())
+    assert hits.tolist() == np.nonzero(want["action"] != 0)[0].tolist()  # compaction lists exactly the non-Allow requests
+    # idempotence: a second evaluation over the same resident batch gives the same bytes (scratch is fully rewritten)
+    out2 = eng.evaluate_device(db)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    eng.close()
+
+
+def test_full_size_config2_properties():
+    """1M requests x 256 rules (BASELINE.json configs[1]) — too big for the oracle to check exhaustively in seconds, so:
+    (1) a random 8k sample is checked bit-exactly, (2) counters == histogram of the verdict array (checksum of checksums),
+    (3) evaluating slabs separately and concatenating equals evaluating the whole (requests are independent: shard invariance),
+    (4) a permuted batch gives permuted verdicts."""
+    import torch
+    from synth import pysynth
+
+    w = pysynth.Workload(2)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    n = 1_000_000
+    batch = w.batch(0, n)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    assert counts.tolist() == np.bincount(got["action"], minlength=4).tolist() and int(counts.sum()) == n
+    frac = counts / n
+    assert 0.90 < frac[0] < 0.99 and 0.005 < frac[1] < 0.08, frac
+    # (1) sample
+    rng = np.random.default_rng(3)
+    lo = int(rng.integers(0, n - 8192))
+    sub = batch.slice(lo, lo + 8192)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(sub, threads=8)
+    H.assert_verdicts_equal(got[lo:lo + 8192], want, sub, "1M sample")
+    # (3) shard invariance at non-aligned cut points
+    cuts = [0, 333_333, 333_334 + 64 * 1000 + 7, n]
+    parts = [eng.evaluate_batch(batch.slice(a, b)) for a, b in zip(cuts, cuts[1:])]
+    cat = np.concatenate(parts)
+    assert (cat["action"] == got["action"]).all() and (cat["rule_idx"] == got["rule_idx"]).all()
+    # (4) permutation on a 50k slab
+    slab = batch.slice(0, 50_000)
+    perm = rng.permutation(slab.n)
+    reqs_perm = RequestBatch(
+        [np.concatenate([slab.data[f][slab.offsets[f][i]:slab.offsets[f][i + 1]] for i in perm] + [np.zeros(16, np.uint8)]) for f in range(5)],
+        [np.concatenate([[0], np.cumsum(np.diff(slab.offsets[f].astype(np.int64))[perm])]).astype(np.uint32) for f in range(5)],
+        slab.ip[perm], slab.ip_is_v6[perm], slab.port[perm], slab.flags[perm])
+    gp = eng.evaluate_batch(reqs_perm)
+    assert (gp["action"] == got["action"][:50_000][perm]).all() and (gp["rule_idx"] == got["rule_idx"][:50_000][perm]).all()
+    eng.close()
+
+
+def test_missing_library_or_device_is_loud(monkeypatch):
+    """The product path has no fallback: a bad batch or a missing device is an error code, never a silent CPU answer."""
+    eng = RuleEngine([("r", None, [B])])
+    b = RequestBatch.from_requests([Request()])
+    st = b.as_struct()
+    st.struct_size = 1
+    import ctypes as C
+    from pingoo_amd import engine as E
+    out = np.zeros(1, dtype=[("a", np.uint32), ("r", np.uint32)])
+    assert E.lib().pwaf_evaluate_batch(eng._h, C.byref(st), out.ctypes.data, None) == _abi.E_INVALID_ARG
+    bad = RequestBatch.from_requests([Request(asn=1, country="FR")])
+    bad.country[0] = 0x3131
+    with pytest.raises(E.PwafError) as ei:
+        eng.evaluate_batch(bad)
+    assert ei.value.code == _abi.E_BATCH
+    eng.close()

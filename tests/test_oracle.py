@@ -1,0 +1,247 @@
+"""Pins the CPU oracle: golden vectors derived from the reference's docs/call sites, and independent
+third-party implementations (CPython `re`, `ipaddress`) for the parts whose algorithm lives in
+un-vendored dependencies of the reference (regex 1.12.2, ipnetwork 0.21.1, maxminddb 0.24.0)."""
+import ipaddress
+import random
+import re
+
+import numpy as np
+import pytest
+
+from helpers import assert_verdicts_equal, kat_case_inputs
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi, geoip_entries
+
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+
+
+def test_golden_vectors(kat):
+    for c in kat["cases"]:
+        rules, lists, batch, expect = kat_case_inputs(c)
+        got = pyoracle.Oracle(rules, lists).evaluate(batch)
+        assert [(int(v["action"]), int(v["rule_idx"])) for v in got] == [tuple(e) for e in expect.tolist()], c["name"]
+
+
+def test_compile_and_validate_accept_reject():
+    ok = ['http_request.path == "/x"', "a.b.c", "x in [1, 2,]", "!(!a)", "--1 == 1", 'r"\\d" == "\\\\d"', "a ? b : c ? d : e", "{'k': 1}.k == 1", "-9223372036854775808 < 0",
+          "1.5e3 > .5", "0x1F == 31", "a // comment\n && b", '"\\u00e9\\x41\\101" != ""']
+    bad = ["", "a ==", "a &&& b", "(a", "a b", "1 +", "a.b(", "[1, 2", '"unterminated', "9223372036854775808", "a ? b", "1u", 'b"x"', "a.", "!-a", "a ? b : ", "@", '"""x"""',
+           "Foo{a: 1}", "a[1", "in", "a in", ".a"]
+    for e in ok:
+        pyoracle.compile_expression(e)
+    for e in bad:
+        with pytest.raises(pyoracle.OracleError):
+            pyoracle.compile_expression(e)
+    # validate_expression = compile + non-empty + no `in` (rules/rules.rs:55-77)
+    pyoracle.validate_expression("a == 1")
+    for e in ["", "x in [1]", "a ==", "[x in y]"]:
+        with pytest.raises(pyoracle.OracleError):
+            pyoracle.validate_expression(e)
+
+
+def _exec(expr, req=None, lists=None):
+    o = pyoracle.Oracle([("r", expr, [B])], lists, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    return o.execute_rule(0, RequestBatch.from_requests([req or Request()]), 0)
+
+
+def test_language_semantics_decisions():
+    """One line per documented decision of DESIGN.md §3.3 (1 true, 0 false, 2 non-Bool, 3 error)."""
+    R = Request(host="h.example", url="/a/b?x=1", path="/a/b", method="POST", user_agent="UA", ip="1.2.3.4", remote_port=8080, asn=64512, country="FR")
+    cases = {
+        # D3 member access == index
+        'http_request["path"] == http_request.path': 1,
+        # D4 equality across types is false, numeric Int/Float compare by value
+        'http_request.path == 5': 0, 'client.remote_port == "8080"': 0, "1 == 1.0": 1, "client.remote_port == 8080.0": 1, "null == null": 1, "[1, 2] == [1, 2.0]": 1,
+        'client.ip == "1.2.3.4"': 0,
+        # D5 ordering only Int/Float/String
+        '"a" < "b"': 1, "1 < 2.5": 1, 'client.remote_port < "9"': 3, "true < false": 3, "client.remote_port >= 8080": 1,
+        # D6 && || left-to-right short circuit, Bool operands only, errors propagate when evaluated
+        "true || http_request.nope": 1, "http_request.nope || true": 3, "false && http_request.nope": 0, "http_request.nope && false": 3,
+        'http_request.path && true': 3, "false || 1": 3, "true || 1": 1,
+        # D7 ! only on Bool
+        "!true": 0, "!1": 3, "!!(1 == 1)": 1,
+        # D8 arithmetic: checked Int, String concatenation
+        "1 + 2 * 3 == 7": 1, "7 / 2 == 3": 1, "-7 % 3 == -1": 1, "1 / 0 == 1": 3, "9223372036854775807 + 1 > 0": 3, '"a" + "b" == "ab"': 1, "client.remote_port + 1 == 8081": 1,
+        "1 + 1.5 == 2.5": 1, '1 + "a" == 1': 3,
+        # D9 conditional evaluates only the chosen branch
+        "true ? true : http_request.nope": 1, "false ? http_request.nope : true": 1, "1 ? true : false": 3,
+        # D10 in
+        "2 in [1, 2]": 1, '"k" in {"k": 1}': 1, "client.asn in [64512]": 1, '1 in "abc"': 3,
+        # D11 functions and strict typing
+        'http_request.path.contains("a/")': 1, "http_request.path.contains(1)": 3, 'http_request.path.starts_with("/a")': 1, 'http_request.path.ends_with("/b")': 1,
+        "http_request.path.length() == 4": 1, "[1, 2, 3].length() == 3": 1, 'http_request.path.bogus()': 3, "length(http_request.path) == 4": 3, '"abc".contains("")': 1,
+        '{"a": 1}.contains("a")': 1, 'http_request.contains("path")': 1, "[[1], [2]].contains([2])": 1,
+        # D13 length counts bytes
+        '"é".length() == 2': 1,
+        # D14 matches
+        'http_request.method.matches("^P(OS|U)T$")': 1, 'http_request.method.matches("(")': 3, 'http_request.url.matches("x=[0-9]+$")': 1,
+        # non-Bool results never match (pingoo/rules.rs:47)
+        "http_request.path": 2, "client.remote_port": 2, "null": 2, "[1]": 2,
+        # unknown names are execution errors, not compile errors (rules/rules.rs:75 "validate variables TODO")
+        "nope": 3, "client.nope": 3, 'lists["nope"]': 3, "http_request.path.nope": 3,
+        # country and asn surface (pingoo/rules.rs:27-34)
+        'client.country == "FR"': 1, "client.asn == 64512": 1, 'client.country.length() == 2': 1,
+    }
+    for expr, want in cases.items():
+        assert _exec(expr, R) == want, expr
+
+
+# ---- regex: the oracle's Pike VM against CPython's backtracking engine on the shared syntax -------------------
+def _rand_regex(rng, depth=0):
+    k = rng.randint(0, 12 if depth < 3 else 3)
+    if k <= 1:
+        return rng.choice(["a", "b", "c", "/", "\\.", "-", "ab", "\\n", "\\x41", "\\/"])
+    if k == 2:
+        return rng.choice(["[ab]", "[^a]", "[a-c/]", "\\w", "\\W", "\\d", "\\D", "\\s", "\\S", "[^/.]", "[\\w/]", "[a\\-c]", "[]a]", "[^]a]", "[a-]", "."])
+    if k == 3:
+        return rng.choice(["^", "$", "\\b", "\\B", "\\A"])
+    if k == 4:
+        return _rand_regex(rng, depth + 1) + _rand_regex(rng, depth + 1)
+    if k == 5:
+        return "(" + _rand_regex(rng, depth + 1) + "|" + _rand_regex(rng, depth + 1) + ")"
+    if k == 6:
+        return "(?:" + _rand_regex(rng, depth + 1) + ")" + rng.choice(["*", "+", "?", "{2}", "{1,3}", "{2,}", "*?", "+?", "??", "{0,2}?"])
+    if k == 7:
+        return _rand_regex(rng, depth + 1) + rng.choice(["a*", "b+", "/?", ".*", ".+", "[ab]{0,2}", "c{2}"])
+    if k == 8:
+        return "(?i:" + rng.choice(["A", "aB", "[A-B]c", "\\w"]) + ")" + _rand_regex(rng, depth + 1)
+    if k == 9:
+        return "(" + _rand_regex(rng, depth + 1) + ")" + _rand_regex(rng, depth + 1)
+    if k == 10:
+        return rng.choice(["a|", "|b", "(a|)", "()", "(?:)", "(?P<n>a)", "(?s:a.b)", "(?m:^a)", "(?m:b$)"])
+    return _rand_regex(rng, depth + 1) + "|" + _rand_regex(rng, depth + 1)
+
+
+def _to_python(pat: str) -> bytes:
+    # Rust `$` (no multi-line) matches only at the very end; Python's also matches before a trailing '\n'
+    out, i, in_class, ml = "", 0, False, 0
+    while i < len(pat):
+        ch = pat[i]
+        if ch == "\\":
+            out += pat[i:i + 2]
+            i += 2
+            continue
+        if in_class:
+            if ch == "]" and out[-1] not in "[^" :
+                in_class = False
+            out += ch
+        elif ch == "[":
+            in_class = True
+            out += ch
+            if pat[i + 1:i + 2] == "^":
+                out += "^"
+                i += 1
+            if pat[i + 1:i + 2] == "]":
+                out += "\\]"
+                i += 1
+        elif pat.startswith("(?m:", i):
+            ml += 1
+            out += "(?m:"
+            i += 3
+        elif ch == "$" and "(?m:" not in pat:
+            out += "\\Z"
+        else:
+            out += ch
+        i += 1
+    return out.encode()
+
+
+def test_regex_matches_cpython_re():
+    rng = random.Random(1234)
+    n_checked = 0
+    for _ in range(1500):
+        pat = _rand_regex(rng)
+        if "(?m:" in pat and "$" in pat.replace("(?m:b$)", ""):
+            continue  # mixed multi-line and plain `$` cannot be expressed with one translation rule
+        try:
+            pyre = re.compile(_to_python(pat))
+        except re.error:
+            continue
+        for _ in range(12):
+            hay = "".join(rng.choice("abc/.-A\n _1") for _ in range(rng.randint(0, 9))).encode()
+            if hay == b"" and "\\B" in pat:
+                continue  # CPython quirk (fixed in 3.14): \B never matches the empty string; the regex crate's does
+            want = pyre.search(hay) is not None
+            got = pyoracle.regex_is_match(pat, hay)
+            assert got == want, (pat, hay, got, want)
+            n_checked += 1
+    assert n_checked > 10000
+
+
+def test_regex_syntax_errors_and_unsupported():
+    for pat in ["(", ")", "a{2", "a{,3}", "*a", "a**b{", "[a", "\\", "\\q", "(?z)", "(?P<>a)", "a{3,2}", "[b-a]", "(?=a)", "(?<!a)", "\\1", "\\p{L}", "[[:bogus:]]", "(?x)a b", "[a&&b]", "\\xZZ",
+                "\\x{110000}"]:
+        with pytest.raises(pyoracle.OracleError):
+            pyoracle.regex_is_match(pat, b"a")
+    assert pyoracle.regex_is_match("[[:alpha:]]+[[:digit:]]", b"..ab1")
+    assert pyoracle.regex_is_match("(?i)union\\s+select", b"x UnIoN \t SELECT y")
+    assert not pyoracle.regex_is_match("^$", b"a") and pyoracle.regex_is_match("^$", b"") and pyoracle.regex_is_match("a*", b"")
+    assert pyoracle.regex_is_match("a$", b"a") and not pyoracle.regex_is_match("a$", b"a\n")  # Rust `$` is not Perl's
+    assert pyoracle.regex_is_match("(?m)a$", b"a\nb") and pyoracle.regex_is_match("(?m)^b", b"a\nb")
+    assert pyoracle.regex_is_match("a.b", b"a\xffb") and not pyoracle.regex_is_match("a.b", b"a\nb") and pyoracle.regex_is_match("(?s)a.b", b"a\nb")
+
+
+# ---- ip parsing / containment against the stdlib -------------------------------------------------------------------
+def test_ip_parse_and_cidr_containment_match_ipaddress():
+    rng = random.Random(99)
+    texts = ["1.2.3.4", "01.2.3.4", "1.2.3", "1.2.3.4.5", "256.1.1.1", "1.2.3.04", "", " 1.2.3.4", "::", "::1", "1::", "2001:db8::1", "2001:db8:0:0:0:0:0:1", "1:2:3:4:5:6:7:8",
+             "1:2:3:4:5:6:7:8:9", "::ffff:1.2.3.4", "1:2:3:4:5:6:1.2.3.4", "1::2::3", ":1", "1:", "12345::", "g::", "::1.2.3", "1:2:3:4:5:6:7::", "::2:3:4:5:6:7:8", "1:2:3:4:5:6:7::8"]
+    for t in texts:
+        fam, raw = pyoracle.parse_ip(t)
+        try:
+            a = ipaddress.ip_address(t)
+            assert fam == a.version, t
+            assert raw[: len(a.packed)] == a.packed, t
+        except ValueError:
+            assert fam == 0, t
+    for _ in range(4000):
+        if rng.random() < 0.6:
+            addr = ipaddress.IPv4Address(rng.getrandbits(32))
+            plen = rng.randint(0, 32)
+        else:
+            addr = ipaddress.IPv6Address(rng.getrandbits(128))
+            plen = rng.randint(0, 128)
+        net = ipaddress.ip_network(f"{addr}/{plen}", strict=False)
+        # ipnetwork keeps host bits in the text; containment masks both sides
+        probe_int = int(net.network_address) + rng.getrandbits(net.max_prefixlen - plen) if (plen < net.max_prefixlen and rng.random() < 0.5) else rng.getrandbits(net.max_prefixlen)
+        probe = type(addr)(probe_int)
+        raw = probe.packed + b"\0" * (16 - len(probe.packed))
+        assert pyoracle.ipnet_contains(f"{addr}/{plen}", raw, probe.version == 6) == (probe in net)
+        other = ipaddress.IPv6Address(1) if addr.version == 4 else ipaddress.IPv4Address(1)
+        assert not pyoracle.ipnet_contains(f"{addr}/{plen}", other.packed + b"\0" * (16 - len(other.packed)), other.version == 6)
+    assert pyoracle.ipnet_contains("10.0.0.0/255.0.0.0", bytes([10, 9, 8, 7]) + b"\0" * 12, False)
+    for bad in ["10.0.0.0/33", "10.0.0.0/255.0.255.0", "::/129", "1.2.3.4/", "1.2.3.4/a", "x/8", "1.2.3.4/-1"]:
+        with pytest.raises(pyoracle.OracleError):
+            pyoracle.ipnet_contains(bad, b"\0" * 16, False)
+
+
+def test_geoip_longest_prefix_and_defaults():
+    rows = [("1.0.0.0/8", 10, "AU"), ("1.2.0.0/16", 20, "CN"), ("1.2.3.0/24", 30, "FR"), ("1.2.3.0/24", 31, "DE"), ("5.0.0.0/8", 40, "q1"), ("5.5.0.0/16", 50, "US"),
+            ("127.0.0.0/8", 60, "US"), ("224.0.0.0/4", 61, "US"), ("2001:db8::/32", 70, "JP"), ("::/0", 71, "BR"), ("0.0.0.0/0", 5, "ZZ")]
+    o = pyoracle.Oracle([("r", None, [B])], None, geoip_entries(rows))
+
+    def look(ip):
+        a = ipaddress.ip_address(ip)
+        return o.geoip_lookup(a.packed + b"\0" * (16 - len(a.packed)), a.version == 6)
+
+    assert look("1.9.9.9") == (10, b"AU") and look("1.2.9.9") == (20, b"CN")
+    assert look("1.2.3.4") == (31, b"DE")  # the later duplicate wins
+    assert look("5.1.1.1") == (0, b"XX")   # record with an invalid country fails to decode -> default (geoip.rs:128-142, http_listener.rs:148-153)
+    assert look("5.5.1.1") == (50, b"US")
+    assert look("127.0.0.1") == (0, b"XX") and look("224.0.0.9") == (0, b"XX")  # loopback / multicast are never looked up (geoip.rs:74-76)
+    assert look("::1") == (0, b"XX") and look("ff02::1") == (0, b"XX")
+    assert look("2001:db8::5") == (70, b"JP") and look("2001:db9::5") == (71, b"BR") and look("9.9.9.9") == (5, b"ZZ")
+    no_db = pyoracle.Oracle([("r", None, [B])])
+    assert no_db.geoip_lookup(bytes([1, 2, 3, 4]) + b"\0" * 12, False) == (0, b"XX")
+
+
+def test_list_loading_errors_and_trimming():
+    o = pyoracle.Oracle([("r", 'lists["a"].contains(client.asn) && lists["s"].contains(http_request.method) && lists["n"].contains(client.ip)', [B])],
+                        {"a": (_abi.LIST_INT, [" 7 ", "-3", "+5"]), "s": (_abi.LIST_STRING, ["  GET\t", ""]), "n": (_abi.LIST_IP, [" 9.9.9.9 "])})
+    b = RequestBatch.from_requests([Request(method="GET", ip="9.9.9.9", asn=7, country="FR"), Request(method="GET ", ip="9.9.9.9", asn=7, country="FR")])
+    assert [int(v["action"]) for v in o.evaluate(b)] == [1, 0]
+    for lists in [{"a": (_abi.LIST_INT, ["x"])}, {"a": (_abi.LIST_INT, ["1.5"])}, {"a": (_abi.LIST_INT, [""])}, {"a": (_abi.LIST_INT, ["9223372036854775808"])},
+                  {"n": (_abi.LIST_IP, ["1.2.3"])}, {"n": (_abi.LIST_IP, ["1.2.3.4/40"])}]:
+        with pytest.raises(pyoracle.OracleError) as ei:
+            pyoracle.Oracle([("r", None, [B])], lists)
+        assert ei.value.code == _abi.E_LIST

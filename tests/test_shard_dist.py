@@ -1,0 +1,73 @@
+"""N>1 path on CPU: two gloo ranks shard one synthetic batch, evaluate their slabs with the CPU oracle (the
+checker — the GPU engine is exercised by the -m gpu tests) and all-reduce the action counters."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pingoo_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition_every_batch_size():
+    for n in [0, 1, 63, 64, 65, 127, 128, 1000, 4096, 100001]:
+        for world in [1, 2, 3, 4, 8]:
+            edges = [shard.shard_bounds(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            for (a, b), (c, d) in zip(edges, edges[1:]):
+                assert b == c and a <= b
+            for lo, hi in edges:
+                assert lo % 64 == 0 or lo == n
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 64 or n < 64 * world
+    with pytest.raises(ValueError):
+        shard.shard_bounds(10, 2, 2)
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import pyoracle
+    from synth import pysynth
+
+    r, w, _ = shard.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    wl = pysynth.Workload(0)
+    lo, hi = shard.shard_bounds(n, rank, world)
+    batch = wl.batch(lo, hi - lo, threads=1)  # each rank generates only its own slab of the global request stream
+    v = pyoracle.Oracle(wl.rules, wl.lists, wl.geoip).evaluate(batch)
+    counts = torch.from_numpy(np.bincount(v["action"], minlength=4).astype(np.int64))
+    local = counts.clone()
+    shard.allreduce_counts(counts)
+    dist.barrier()
+    q.put((rank, lo, hi, local.tolist(), counts.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_counter_allreduce_matches_single_process():
+    from oracle import pyoracle
+    from synth import pysynth
+
+    n, world = 3000, 2
+    wl = pysynth.Workload(0)
+    whole = pyoracle.Oracle(wl.rules, wl.lists, wl.geoip).evaluate(wl.batch(0, n, threads=1))
+    want = np.bincount(whole["action"], minlength=4).tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n
+    assert [a + b for a, b in zip(res[0][3], res[1][3])] == want
+    assert res[0][4] == want and res[1][4] == want
+    assert want[0] > 0 and sum(want[1:]) > 0
