@@ -57,8 +57,16 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} is missing: build it with `python -m pingoo_amd.build` (hipcc, gfx950). "
                           "pingoo_amd has no CPU fallback.")
+    # ONE HIP runtime per process. libpwaf.so needs "libamdhip64.so.7"; PyTorch-ROCm bundles its own copy with that
+    # very soname (plus its own libhsa-runtime64). Whichever is mapped first serves both users — two HSA runtimes in
+    # one process do not work (the second sees no GPU). bench.py and the tests use torch for device buffers, streams
+    # and torch.distributed, so when torch is installed its runtime is mapped first and libpwaf.so binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB_PATH)
-    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    vp = C.c_void_p
     L.pwaf_abi_version.restype = C.c_uint32
     L.pwaf_last_error.restype = C.c_char_p
     L.pwaf_compile_expression.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
