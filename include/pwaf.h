@@ -204,14 +204,15 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                        pwaf_compile_error *err /* nullable */);
 void pwaf_engine_destroy(pwaf_engine *);
 const pwaf_program *pwaf_engine_program(const pwaf_engine *);
+void *pwaf_engine_stream(const pwaf_engine *); /* hipStream_t the synchronous entry points run on */
 
 /* Synchronous batch evaluation. HOST batches are copied to the device, evaluated, and verdicts are
  * copied back into `out` (host, n entries). DEVICE batches are evaluated in place and `out`/`counts`
  * must be device pointers too. `counts` is nullable. Callable concurrently from several threads. */
 int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts);
 
-/* Asynchronous device-resident evaluation on a caller-supplied HIP stream (hipStream_t as void*;
- * NULL = the engine's own stream). All pointers (batch columns, out, counts, match_idx, n_matches)
+/* Asynchronous device-resident evaluation on a caller-supplied HIP stream (hipStream_t as void*, passed through
+ * unchanged: NULL is HIP's default stream; pwaf_engine_stream() returns the engine's own non-blocking stream). All pointers (batch columns, out, counts, match_idx, n_matches)
  * are device pointers. `match_idx`/`n_matches` (nullable) receive the compacted indices of
  * non-Allow requests (wavefront ballot + prefix-sum compaction; order unspecified).
  * `counts` and `n_matches` are ACCUMULATED into (caller zeroes them). */
@@ -227,9 +228,11 @@ typedef struct pwaf_kernel_time {
     float ms;            /* HIP-event duration of the last profiled evaluate call */
     uint64_t alg_bytes;  /* algorithmic bytes this launch is credited with */
 } pwaf_kernel_time;
-/* When on, pwaf_evaluate_device brackets each kernel with hipEvents on the launch stream. */
+/* When on, every evaluate call brackets each kernel with hipEvents on the launch stream. Calling it (on or off)
+ * starts a new measurement window. */
 int pwaf_engine_set_profiling(pwaf_engine *, int on);
-/* Blocks until the last profiled call finished; fills up to cap entries; returns the count. */
+/* Blocks until the last profiled launch finished; fills up to cap entries, one per kernel launch since the window
+ * started (in launch order); returns the count. */
 int pwaf_engine_kernel_times(pwaf_engine *, pwaf_kernel_time *out, int cap);
 
 typedef struct pwaf_stats {

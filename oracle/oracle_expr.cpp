@@ -726,11 +726,24 @@ bool compile(std::string_view src, Program &out, std::string &err) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Scratch storage for values created during one execution (string concatenation, list/map literals with
+// computed items). Created lazily: the common predicates allocate nothing.
+template <class T>
+struct Lazy {
+    std::unique_ptr<std::deque<T>> d;
+    template <class... A>
+    T &emplace_back(A &&...a) {
+        if (!d) d = std::make_unique<std::deque<T>>();
+        d->emplace_back(std::forward<A>(a)...);
+        return d->back();
+    }
+    T &back() { return d->back(); }
+};
 struct Exec {
     const Context &ctx;
-    std::deque<std::string> strs;
-    std::deque<ListVal> lists;
-    std::deque<MapVal> maps;
+    Lazy<std::string> strs;
+    Lazy<ListVal> lists;
+    Lazy<MapVal> maps;
 };
 
 static bool val_eq(const Val &a, const Val &b);
@@ -793,7 +806,15 @@ static Val eval_call(const Node &n, Exec &ex) {
     if (!n.has_receiver) return Val::err("undeclared function");
     Val recv = eval(*n.kids[0], ex);
     if (recv.k == Val::Error) return recv;
-    std::vector<Val> args;
+    struct Args {  // calls in this language take 0..1 arguments; keep the common case off the heap
+        Val inl[2];
+        std::vector<Val> more;
+        size_t n = 0;
+        void push_back(const Val &v) { if (n < 2) inl[n] = v; else more.push_back(v); n++; }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        const Val &operator[](size_t k) const { return k < 2 ? inl[k] : more[k - 2]; }
+    } args;
     for (size_t k = 1; k < n.kids.size(); k++) {
         Val a = eval(*n.kids[k], ex);
         if (a.k == Val::Error) return a;
@@ -1016,7 +1037,7 @@ static Val eval(const Node &n, Exec &ex) {
 }  // namespace
 
 Val execute(const Program &p, const Context &ctx) {
-    Exec ex{ctx, {}, {}, {}};
+    Exec ex{ctx, {}, {}, {}};  // no allocation until a value needs scratch storage
     Val v = eval(*p.root, ex);
     // values backed by Exec storage die here; only scalars / context-backed values may escape.
     if (v.k == Val::String || v.k == Val::List || v.k == Val::Map) {

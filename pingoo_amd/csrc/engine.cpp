@@ -177,7 +177,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     if ((rc = e->S.reserve((size_t)n_groups * std::max(1u, scan_words) * 8))) return rc;
     if ((rc = e->M.reserve((size_t)n_groups * std::max(64u, P.n_scan_cols) * 8))) return rc;
 
-    size_t ev_i = 0;
+    size_t ev_i = e->profiling ? e->n_timed : 0;
     auto mark = [&](const char *name, uint64_t alg_bytes) -> int {
         if (!e->profiling) return PWAF_OK;
         if (e->ev.size() < ev_i + 1) {
@@ -195,8 +195,6 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         ev_i++;
         return PWAF_OK;
     };
-    if (e->profiling) e->times.clear();
-
     // per-field byte counts are not known on the host for DEVICE batches; alg_bytes for scans are filled by the
     // caller-visible formula in bench.py from the offsets it owns. Here: fixed-width part only.
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
@@ -428,6 +426,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
 }
 
 const pwaf_program *pwaf_engine_program(const pwaf_engine *e) { return e ? &e->prog : nullptr; }
+void *pwaf_engine_stream(const pwaf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
     if (!e || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
@@ -443,7 +442,7 @@ int pwaf_evaluate_device(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out
     if ((match_idx == nullptr) != (n_matches == nullptr)) return fail(PWAF_E_INVALID_ARG, "match_idx and n_matches must be given together");
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    return run_pipeline(e, *in, out, counts, match_idx, n_matches, stream ? (hipStream_t)stream : e->stream);
+    return run_pipeline(e, *in, out, counts, match_idx, n_matches, (hipStream_t)stream);
 }
 
 int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts) {
@@ -559,6 +558,8 @@ int pwaf_engine_set_profiling(pwaf_engine *e, int on) {
     if (!e) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(e->mu);
     e->profiling = on != 0;
+    e->times.clear();  // (re)starting a measurement window: kernel_times() reports every launch since this call
+    e->n_timed = 0;
     return PWAF_OK;
 }
 

@@ -88,6 +88,8 @@ def lib():
     L.pwaf_engine_program.argtypes = [vp]
     L.pwaf_engine_program.restype = vp
     L.pwaf_engine_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+    L.pwaf_engine_stream.argtypes = [vp]
+    L.pwaf_engine_stream.restype = vp
     L.pwaf_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
     L.pwaf_evaluate_device.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp, vp, vp, vp]
     L.pwaf_evaluate_one.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
@@ -320,8 +322,8 @@ class RuleEngine:
         lib().pwaf_engine_set_profiling(self._h, int(on))
 
     def kernel_times(self) -> List[Tuple[str, float, int]]:
-        arr = (_abi.KernelTime * 64)()
-        n = lib().pwaf_engine_kernel_times(self._h, arr, 64)
+        arr = (_abi.KernelTime * 8192)()
+        n = lib().pwaf_engine_kernel_times(self._h, arr, 8192)
         if n < 0:
             _raise(n, lib().pwaf_last_error().decode(errors="replace"))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
