@@ -102,9 +102,10 @@ typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;
     int32_t device;            /* HIP device ordinal, -1 = current device                 */
-    uint32_t lds_table_budget; /* bytes of LDS one DFA table may use; 0 = default         */
-    uint32_t max_dfa_states;   /* per DFA group; 0 = default (derived from the LDS budget) */
-    uint32_t reserved[3];
+    uint32_t lds_table_budget; /* LDS bytes for the hot rows of one DFA table; 0 = default (64 KiB) */
+    uint32_t max_dfa_states;   /* per DFA group, <= 32767; 0 = default (32767)                       */
+    uint32_t max_table_bytes;  /* per DFA group (L2-resident transition table); 0 = default (3 MiB)  */
+    uint32_t reserved[2];
 } pwaf_options;
 
 /* Per-rule diagnostics of engine creation. */
@@ -218,6 +219,10 @@ int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, 
  * `counts` and `n_matches` are ACCUMULATED into (caller zeroes them). */
 int pwaf_evaluate_device(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts,
                          uint32_t *match_idx, uint32_t *n_matches, void *stream);
+
+/* After pwaf_evaluate_device: waits for the device and returns PWAF_OK, or PWAF_E_NOMEM when the last batch ran out of
+ * scan scratch (verdicts incomplete; cannot happen below 8 overflowing hits per request on average). */
+int pwaf_engine_device_status(pwaf_engine *);
 
 /* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
 int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);

@@ -71,7 +71,8 @@ class Options(C.Structure):
         ("device", C.c_int32),
         ("lds_table_budget", C.c_uint32),
         ("max_dfa_states", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("max_table_bytes", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
     ]
 
 

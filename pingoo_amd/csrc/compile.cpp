@@ -946,9 +946,15 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     Program &P = *prog;
     P.flags = in.opts.flags;
     uint32_t lds_budget = in.opts.lds_table_budget ? in.opts.lds_table_budget : 64 * 1024;
-    uint32_t max_states = in.opts.max_dfa_states ? in.opts.max_dfa_states : 65535;
+    uint32_t max_states = in.opts.max_dfa_states ? std::min(in.opts.max_dfa_states, kMaxDfaStates) : kMaxDfaStates;
+    uint32_t max_table_bytes = in.opts.max_table_bytes ? in.opts.max_table_bytes : 3u << 20;  // L2-resident: 4 MiB per XCD
     if (lds_budget < 1024 || lds_budget > 150 * 1024) {
         set_err(err, PWAF_E_INVALID_ARG, 0xFFFFFFFFu, "lds_table_budget must be within 1 KiB .. 150 KiB");
+        return PWAF_E_INVALID_ARG;
+    }
+    P.lds_hot_budget = lds_budget;
+    if (max_table_bytes < 1024) {
+        set_err(err, PWAF_E_INVALID_ARG, 0xFFFFFFFFu, "max_table_bytes must be at least 1 KiB");
         return PWAF_E_INVALID_ARG;
     }
 
@@ -1093,7 +1099,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     used[0] = 1;
     for (auto &terms : rule_terms) for (auto &t : terms) for (uint32_t l : t) used[l >> 1] = 1;
 
-    // ---- column layout: [0] TRUE, numeric atoms, pad to 64, then one 64-aligned block range per DFA group ----
+    // ---- column layout: [0] TRUE, numeric atoms, then each DFA group's atoms (group-local id = column - atom_base) ----
     uint32_t col = 1;
     for (size_t a = 1; a < P.atoms.size(); a++) {
         Atom &at = P.atoms[a];
@@ -1101,43 +1107,54 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         at.id = col++;
     }
     uint32_t n_numeric = col - 1;
-    uint32_t scan_base = (col + 63) / 64 * 64;
-    // DFA groups per field
+    const uint32_t scan_base = col;
     uint32_t next_col = scan_base;
+    // DFA groups per field: ideally ONE table per field (the field's bytes are then read once). The state budget is what
+    // an L2-resident table allows (hot rows are cached in LDS by the kernel), not what fits LDS. Patterns with an
+    // unbounded wide-class repetition in the middle (".*") multiply states with each other, so when the joint DFA
+    // explodes they are isolated into small groups of their own.
     for (int f = 0; f < PWAF_N_FIELDS; f++) {
         std::vector<ScanPattern> pats;
         for (size_t a = 1; a < P.atoms.size(); a++)
             if (used[a] && P.atoms[a].kind == ATOM_SCAN && P.atoms[a].field == f) pats.push_back({P.atoms[a].pattern, (uint32_t)a});
         if (pats.empty()) continue;
-        // greedy: try everything in one table; on overflow split the pattern list in halves
         std::vector<std::vector<ScanPattern>> work{pats};
         while (!work.empty()) {
             std::vector<ScanPattern> cur = std::move(work.back());
             work.pop_back();
             DfaGroup g;
             std::string derr;
-            if (build_dfa(cur, max_states, lds_budget, g, derr)) {
+            if (cur.size() <= kMaxLocalAtoms && build_dfa(cur, max_states, max_table_bytes, g, derr)) {
                 g.field = (uint8_t)f;
                 g.atom_base = next_col;
-                g.n_local = (uint32_t)((cur.size() + 63) / 64 * 64);
                 for (size_t k = 0; k < cur.size(); k++) P.atoms[cur[k].atom].id = next_col + (uint32_t)k;
                 next_col += g.n_local;
                 P.groups.push_back(std::move(g));
                 continue;
             }
             if (cur.size() == 1) {
-                uint32_t ridx = 0xFFFFFFFFu;
-                set_err(err, PWAF_E_UNSUPPORTED, ridx, std::string("a pattern on http_request.") + kFieldNames[f] + " needs a DFA larger than the LDS table budget: " + derr);
+                set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, std::string("a pattern on http_request.") + kFieldNames[f] + " needs a DFA beyond the state/table budget: " + derr);
                 return PWAF_E_UNSUPPORTED;
             }
-            size_t half = cur.size() / 2;
-            work.emplace_back(cur.begin() + (long)half, cur.end());
-            work.emplace_back(cur.begin(), cur.begin() + (long)half);
+            std::vector<ScanPattern> gap, plain;
+            for (auto &p : cur) (has_wide_gap(*p.rx) ? gap : plain).push_back(p);
+            if (!gap.empty() && !plain.empty()) {
+                // chunks of gap patterns, then the plain rest (LIFO work list: push in reverse)
+                work.push_back(plain);
+                for (size_t k = 0; k < gap.size(); k += 8) work.emplace_back(gap.begin() + (long)k, gap.begin() + (long)std::min(gap.size(), k + 8));
+            } else {
+                size_t half = cur.size() / 2;
+                work.emplace_back(cur.begin() + (long)half, cur.end());
+                work.emplace_back(cur.begin(), cur.begin() + (long)half);
+            }
         }
     }
     P.n_scan_cols = next_col - scan_base;
-    P.n_cols = next_col == scan_base ? scan_base : next_col;
-    if (P.n_cols < 64) P.n_cols = 64;
+    P.n_cols = next_col;
+    if (P.groups.size() > 64) {
+        set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "the rule set needs more than 64 scan passes");
+        return PWAF_E_UNSUPPORTED;
+    }
     if (P.n_cols >= LIT_ATOM_MASK) {
         set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "too many distinct predicates");
         return PWAF_E_UNSUPPORTED;
@@ -1282,7 +1299,7 @@ std::vector<uint8_t> dump_program(const Program &p) {
     w.section("HEAD", 8, head, sizeof head);
     for (size_t gi = 0; gi < p.groups.size(); gi++) {
         const DfaGroup &g = p.groups[gi];
-        uint32_t gh[8] = {g.field, g.n_states, g.n_classes, g.first_emit, g.start, g.atom_base, g.n_local, (uint32_t)g.atoms.size()};
+        uint32_t gh[8] = {g.field, g.n_states, g.n_classes, 0, 0, g.atom_base, g.n_local, (uint32_t)g.atoms.size()};
         w.section("GHDR", (uint32_t)gi, gh, sizeof gh);
         w.section("GCLS", (uint32_t)gi, g.classmap, 256);
         w.section("GTRN", (uint32_t)gi, g.trans.data(), g.trans.size() * 2);

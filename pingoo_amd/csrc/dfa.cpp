@@ -245,7 +245,7 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
 
     if ((uint64_t)n_cls * 2 > max_table_bytes) { err = "LDS table budget too small"; return false; }
     uint32_t state_cap = std::min<uint64_t>(max_states, (uint64_t)max_table_bytes / (2ull * n_cls));
-    state_cap = std::min<uint32_t>(state_cap, 65535);
+    state_cap = std::min<uint32_t>(state_cap, kMaxDfaStates);
 
     // ---- subset construction ----
     // The pattern entry states are seeds of EVERY state's closure (unanchored search restarts at each
@@ -408,49 +408,40 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         return false;
     }
 
-    // ---- renumber: start first, non-emitting states, then emitting states ----
+    // ---- output: states keep their BFS discovery order (start = 0) ----
     uint32_t S = (uint32_t)ds.size();
-    std::vector<uint32_t> order, newid(S);
-    bool start_emits = !ds[0].emits.empty();
-    if (!start_emits) order.push_back(0);
-    for (uint32_t s = 0; s < S; s++) if (ds[s].emits.empty() && s != 0) order.push_back(s);
-    uint32_t first_emit = (uint32_t)order.size();
-    if (start_emits) order.push_back(0);
-    for (uint32_t s = 0; s < S; s++) if (!ds[s].emits.empty() && s != 0) order.push_back(s);
-    for (uint32_t k = 0; k < S; k++) newid[order[k]] = k;
-
     out.n_states = S;
     out.n_classes = (uint32_t)n_cls;
-    out.first_emit = first_emit;
     for (int b = 0; b < 256; b++) out.classmap[b] = (uint8_t)cls_of[b];
     out.trans.assign((size_t)S * n_cls, 0);
     out.emit_off.assign(1, 0);
     out.emit_list.clear();
     out.end_off.assign(1, 0);
     out.end_list.clear();
-    out.end_flag.assign((S + 31) / 32, 0);
     for (uint32_t k = 0; k < S; k++) {
-        const DState &d = ds[order[k]];
-        for (int c = 0; c < n_cls; c++) out.trans[(size_t)k * n_cls + c] = (uint16_t)newid[d.next[c]];
-        if (k >= first_emit) {
-            out.emit_list.insert(out.emit_list.end(), d.emits.begin(), d.emits.end());
-            out.emit_off.push_back((uint32_t)out.emit_list.size());
-        }
+        const DState &d = ds[k];
+        for (int c = 0; c < n_cls; c++) out.trans[(size_t)k * n_cls + c] = (uint16_t)d.next[c];
+        out.emit_list.insert(out.emit_list.end(), d.emits.begin(), d.emits.end());
+        out.emit_off.push_back((uint32_t)out.emit_list.size());
         out.end_list.insert(out.end_list.end(), d.end_emits.begin(), d.end_emits.end());
         out.end_off.push_back((uint32_t)out.end_list.size());
-        if (!d.end_emits.empty()) out.end_flag[k >> 5] |= 1u << (k & 31);
     }
-    out.start = newid[0];
     out.atoms.clear();
     for (auto &p : pats) out.atoms.push_back(p.atom);
+    out.n_local = (uint32_t)pats.size();
     return true;
 }
 
+bool has_wide_gap(const RNode &n) {
+    if (n.k == RNode::REPEAT && n.rmax < 0 && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64) return true;
+    for (auto &k : n.kids) if (has_wide_gap(*k)) return true;
+    return false;
+}
+
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms) {
-    uint32_t s = g.start;
+    uint32_t s = 0;
     auto emit = [&](uint32_t st) {
-        if (st >= g.first_emit)
-            for (uint32_t k = g.emit_off[st - g.first_emit]; k < g.emit_off[st - g.first_emit + 1]; k++) out_atoms.push_back(g.emit_list[k]);
+        for (uint32_t k = g.emit_off[st]; k < g.emit_off[st + 1]; k++) out_atoms.push_back(g.emit_list[k]);
     };
     emit(s);
     for (size_t i = 0; i < n; i++) {

@@ -72,7 +72,7 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 
 struct DevGroup {
     DevBuf tab, classmap, list_off, list;
-    uint32_t n_states, stride, n_classes, first_emit_pm, start_pm, n_local, col_rel;
+    uint32_t n_states, stride, n_classes, n_hot, atom_base;
     uint8_t field;
 };
 
@@ -85,10 +85,9 @@ struct pwaf_engine {
     std::vector<DevGroup> groups;
     DevBuf num_atoms, int_pool, country_luts, rules, lits, set_masks;
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
-    uint32_t scan_base = 0;
     // per-call scratch (guarded by mu)
     std::mutex mu;
-    DevBuf S, M;
+    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word */, pass_base;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // profiling
@@ -115,24 +114,26 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
     g_last_error = src.message;
 }
 
-// table rows: [next * stride ...] [1 + end list id] [1 + emit list id]; lists shared
-int build_device_group(const DfaGroup &g, uint32_t scan_base, DevGroup &d) {
+// table rows: [next | 0x8000 if next emits ...] [1 + end list id] [1 + emit list id]; lists shared
+int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) {
     const uint32_t C = g.n_classes, stride = C + 2;
-    if ((uint64_t)g.n_states * stride > 65535) return fail(PWAF_E_UNSUPPORTED, "DFA table exceeds the 16-bit pre-multiplied index range");
+    if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
     std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
     std::vector<uint32_t> list_off{0};
     std::vector<uint16_t> list;
     for (uint32_t s = 0; s < g.n_states; s++) {
-        for (uint32_t c = 0; c < C; c++) tab[(size_t)s * stride + c] = (uint16_t)(g.trans[(size_t)s * C + c] * stride);
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t t = g.trans[(size_t)s * C + c];
+            tab[(size_t)s * stride + c] = (uint16_t)(t | (g.emit_off[t + 1] > g.emit_off[t] ? 0x8000u : 0u));
+        }
         if (g.end_off[s + 1] > g.end_off[s]) {
             list.insert(list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[s + 1]);
             list_off.push_back((uint32_t)list.size());
             if (list_off.size() - 1 > 65534) return fail(PWAF_E_UNSUPPORTED, "too many emit lists in one DFA group");
             tab[(size_t)s * stride + C] = (uint16_t)(list_off.size() - 1);
         }
-        if (s >= g.first_emit) {
-            uint32_t k = s - g.first_emit;
-            list.insert(list.end(), g.emit_list.begin() + g.emit_off[k], g.emit_list.begin() + g.emit_off[k + 1]);
+        if (g.emit_off[s + 1] > g.emit_off[s]) {
+            list.insert(list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[s + 1]);
             list_off.push_back((uint32_t)list.size());
             if (list_off.size() - 1 > 65534) return fail(PWAF_E_UNSUPPORTED, "too many emit lists in one DFA group");
             tab[(size_t)s * stride + C + 1] = (uint16_t)(list_off.size() - 1);
@@ -141,10 +142,9 @@ int build_device_group(const DfaGroup &g, uint32_t scan_base, DevGroup &d) {
     d.n_states = g.n_states;
     d.stride = stride;
     d.n_classes = C;
-    d.first_emit_pm = g.first_emit * stride;
-    d.start_pm = g.start * stride;
-    d.n_local = g.n_local;
-    d.col_rel = g.atom_base - scan_base;
+    d.n_hot = std::min<uint32_t>(g.n_states, lds_hot_budget / (stride * 2));
+    if (d.n_hot == 0) d.n_hot = 1;
+    d.atom_base = g.atom_base;
     d.field = g.field;
     int rc;
     if ((rc = upload(d.tab, tab, 16))) return rc;
@@ -172,10 +172,16 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
-    const uint32_t scan_words = P.n_scan_cols / 64;
+    const uint32_t n_passes = (uint32_t)e->groups.size();
     int rc;
-    if ((rc = e->S.reserve((size_t)n_groups * std::max(1u, scan_words) * 8))) return rc;
-    if ((rc = e->M.reserve((size_t)n_groups * std::max(64u, P.n_scan_cols) * 8))) return rc;
+    // scratch sized for the worst case the 288 GB part can afford: one 4-byte hit record per (pass, request) and an overflow
+    // pool of 8 entries per request (exhaustion is reported through the status word, never silently)
+    const uint64_t pool_cap64 = std::max<uint64_t>(1u << 20, (uint64_t)n * 8);
+    const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
+    if ((rc = e->rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
+    if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
+    if ((rc = e->ctrl.reserve(16))) return rc;
+    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 16, stream));
 
     size_t ev_i = e->profiling ? e->n_timed : 0;
     auto mark = [&](const char *name, uint64_t alg_bytes) -> int {
@@ -195,15 +201,13 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         ev_i++;
         return PWAF_OK;
     };
-    // per-field byte counts are not known on the host for DEVICE batches; alg_bytes for scans are filled by the
-    // caller-visible formula in bench.py from the offsets it owns. Here: fixed-width part only.
+
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
         DevGroup &d = e->groups[gi];
         ScanArgs a{};
         a.data = db.field[d.field].data;
         a.off = db.field[d.field].offsets;
         a.n = n;
-        a.n_groups = n_groups;
         a.tab = (const uint16_t *)d.tab.p;
         a.classmap = (const uint8_t *)d.classmap.p;
         a.list_off = (const uint32_t *)d.list_off.p;
@@ -211,14 +215,12 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.n_states = d.n_states;
         a.stride = d.stride;
         a.n_classes = d.n_classes;
-        a.first_emit_pm = d.first_emit_pm;
-        a.start_pm = d.start_pm;
-        a.n_local = d.n_local;
-        a.col_rel = d.col_rel;
-        a.scan_cols = P.n_scan_cols;
-        a.scan_words = scan_words;
-        a.S = (uint64_t *)e->S.p;
-        a.M = (uint64_t *)e->M.p;
+        a.n_hot = d.n_hot;
+        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
+        a.pool = (PoolEntry *)e->pool.p;
+        a.pool_count = (uint32_t *)e->ctrl.p;
+        a.pool_cap = pool_cap;
+        a.status = (uint32_t *)e->ctrl.p + 1;
         char nm[48];
         static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
         snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
@@ -238,11 +240,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.asn = db.asn;
     v.country = db.country;
     v.n_cols = P.n_cols;
-    v.scan_base = e->scan_base;
-    v.scan_cols = P.n_scan_cols;
-    v.scan_words = scan_words;
-    v.S = (const uint64_t *)e->S.p;
-    v.M = (const uint64_t *)e->M.p;
+    v.n_passes = n_passes;
+    v.rec = (const uint32_t *)e->rec.p;
+    v.pass_base = (const uint32_t *)e->pass_base.p;
+    v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
     v.n_num_atoms = (uint32_t)P.num_atoms.size();
     v.int_pool = (const int64_t *)e->int_pool.p;
@@ -386,11 +387,13 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     }
     e->device = dev;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { fail(PWAF_E_DEVICE, "hipStreamCreate failed"); return dev_fail(PWAF_E_DEVICE); }
-    e->scan_base = P.groups.empty() ? P.n_cols : P.groups[0].atom_base;
-    for (auto &g : P.groups) e->scan_base = std::min(e->scan_base, g.atom_base);
     e->groups.resize(P.groups.size());
-    for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], e->scan_base, e->groups[k]))) return dev_fail(rc);
+    std::vector<uint32_t> pass_base;
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k]))) return dev_fail(rc);
+        pass_base.push_back(P.groups[k].atom_base);
+    }
+    if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
 #define UP(buf, vec)                                     \
     if ((rc = upload(e->buf, vec))) return dev_fail(rc);
     UP(num_atoms, P.num_atoms)
@@ -416,7 +419,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.list_off.release(); g.list.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->int_pool, &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->S, &e->M, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
@@ -459,7 +462,10 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         if (counts) HIP_TRY(hipMemsetAsync(counts, 0, sizeof *counts, e->stream));
         rc = run_pipeline(e, *in, out, counts, nullptr, nullptr, e->stream);
         if (rc) return rc;
+        uint32_t status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
         return PWAF_OK;
     }
     // HOST batch: validate what a device cannot report, stage, run, copy back
@@ -515,7 +521,22 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, e->stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
     if (counts) HIP_TRY(hipMemcpyAsync(counts, e->stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
+    return PWAF_OK;
+}
+
+int pwaf_engine_device_status(pwaf_engine *e) {
+    if (!e) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!e->ctrl.p) return PWAF_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpy(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost));
+    if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of the last batch are incomplete");
     return PWAF_OK;
 }
 

@@ -6,27 +6,35 @@
 
 namespace pwaf {
 
-// Device copy of one DFA group's tables.
-// tab: n_states rows of (n_classes + 2) uint16: [0, n_classes) = next state PRE-MULTIPLIED by the row
-// stride, [n_classes] = 1 + end-list id (0 = none), [n_classes + 1] = 1 + emit-list id (0 = none).
+static constexpr int kMaxPasses = 64;
+
+// Hit record of one (scan pass, request): what the request's field matched in that pass's DFA.
+//   bit 31 = 0: bits [14:0] = first local atom + 1 (0 = none), bits [29:15] = second local atom + 1 (0 = none)
+//   bit 31 = 1: bits [30:0] = head of a chain in the overflow pool holding ALL atoms of the request for this pass
+static constexpr uint32_t REC_OVERFLOW = 0x80000000u;
+struct PoolEntry {
+    uint32_t atom;  // local atom id
+    uint32_t next;  // 0xFFFFFFFF = end of chain
+};
+
+// Device table of one DFA group: n_states rows of stride = n_classes + 2 uint16:
+//   [0, n_classes)  next state id | 0x8000 when the next state has an emit list
+//   [n_classes]     1 + end-list id (0 = none)        [n_classes + 1]  1 + emit-list id (0 = none)
+// Rows [0, n_hot) are staged into LDS by every workgroup; colder rows are read from this (L2-resident) copy.
 struct ScanArgs {
     const uint8_t *data;      // field arena
     const uint32_t *off;      // n + 1 offsets
     uint32_t n;
-    uint32_t n_groups;        // ceil(n / 64): one group = 64 consecutive requests = one bit column word
-    const uint16_t *tab;      // global copy of the table (staged into LDS by every block)
+    const uint16_t *tab;
     const uint8_t *classmap;  // 256 bytes
     const uint32_t *list_off; // shared by end- and emit-lists
     const uint16_t *list;     // local atom ids
-    uint32_t n_states, stride /* n_classes + 2 */, n_classes;
-    uint32_t first_emit_pm;   // first_emit * stride
-    uint32_t start_pm;        // start * stride
-    uint32_t n_local;         // columns owned by this group (multiple of 64)
-    uint32_t col_rel;         // atom_base - scan_base (multiple of 64)
-    uint32_t scan_cols;       // total scan columns (row length of M)
-    uint32_t scan_words;      // scan_cols / 64 (row length of S)
-    uint64_t *S;              // [n_groups][scan_words]  bit a%64 of word a/64: column a has a hit in this group
-    uint64_t *M;              // [n_groups][scan_cols]   64-request hit masks; valid only where S says so
+    uint32_t n_states, stride, n_classes, n_hot;
+    uint32_t *rec;            // n hit records of this pass
+    PoolEntry *pool;
+    uint32_t *pool_count;     // atomic allocator
+    uint32_t pool_cap;
+    uint32_t *status;         // device status word: bit 0 = overflow pool exhausted
 };
 
 struct VerdictArgs {
@@ -38,10 +46,13 @@ struct VerdictArgs {
     const uint8_t *flags;
     const uint32_t *asn;      // nullable
     const uint16_t *country;  // nullable
+    // scan results
+    uint32_t n_passes;
+    const uint32_t *rec;        // [n_passes][n]
+    const uint32_t *pass_base;  // first column of each pass
+    const PoolEntry *pool;
     // compiled program
-    uint32_t n_cols, scan_base, scan_cols, scan_words;
-    const uint64_t *S;
-    const uint64_t *M;
+    uint32_t n_cols;
     const NumAtomDev *num_atoms;
     uint32_t n_num_atoms;
     const int64_t *int_pool;
@@ -67,8 +78,7 @@ struct VerdictArgs {
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
 int launch_scan(const ScanArgs &a, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
-// LDS bytes the scan kernel needs for a group with these dimensions (table + classmap + wave matrices)
-uint32_t scan_lds_bytes(uint32_t n_states, uint32_t stride, uint32_t n_local);
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
 uint32_t verdict_lds_bytes(uint32_t n_cols);
 
 }  // namespace pwaf

@@ -1,19 +1,21 @@
 // kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the WAF batch matcher.
 //
-// Data model: requests are processed in GROUPS of 64 consecutive requests. Every
-// predicate ("atom") of the compiled rule set is a COLUMN; for one group a column is one 64-bit word
-// whose bit r says "atom holds for request 64*g + r". Rule evaluation is then bit-parallel over 64
-// requests per ALU op, with one lane per RULE (verdict_kernel), instead of one interpreter walk per
-// rule per request (pingoo/rules.rs:37-51, http_listener.rs:251-264).
+// Data model: every predicate ("atom") of the compiled rule set is a COLUMN. The verdict kernel
+// handles requests in GROUPS of 64 (one wavefront); for a group a column is one 64-bit word whose bit r says
+// "atom holds for request 64*g + r", so rule evaluation is bit-parallel over 64 requests per ALU op with one
+// lane per RULE — instead of one interpreter walk per rule per request (pingoo/rules.rs:37-51,
+// http_listener.rs:251-264).
 //
-//   scan_kernel     one launch per (field, DFA group). Streams the field's byte arena once; each lane
-//                   walks one request through the LDS-resident DFA; hits are OR-ed into the wave's
-//                   LDS column words and flushed sparsely (S = which columns are non-zero, M = words).
-//   verdict_kernel  per group: gathers the sparse scan columns, derives the numeric columns (lengths,
-//                   port, ASN, country table, ip-list membership via the radix trie, GeoIP via the
-//                   LPM trie) with wave ballots, evaluates every rule's DNF with one lane per rule,
-//                   resolves first-match-wins, writes verdicts, action counters and the compacted
-//                   index list of non-Allow requests (ballot + prefix popcount).
+//   scan_kernel     one launch per DFA group (ideally one per request field). Every lane walks ONE request's field
+//                   through the multi-pattern DFA and PULLS the next request of its wave's slab when it is done
+//                   (ballot + prefix popcount), so ragged field lengths do not idle lanes. Transition rows of
+//                   the shallow ("hot") states live in LDS; rows of deep states are read from the L2-resident
+//                   table. What a request matched is written as one 4-byte hit record (two atoms inline, more
+//                   through an overflow chain): lanes never share state, no atomics on the common path.
+//   verdict_kernel  per group: turns the hit records into LDS column words, derives the numeric columns (lengths,
+//                   port, ASN, country table, ip-list membership via the radix trie, GeoIP via the LPM trie) with
+//                   wave ballots, evaluates every rule's DNF with one lane per rule, resolves first-match-wins,
+//                   writes verdicts, action counters and the compacted index list of non-Allow requests.
 //
 // No MFMA: this is byte/integer work bounded by LDS lookups per input byte and HBM streaming.
 #include <hip/hip_runtime.h>
@@ -26,103 +28,168 @@ static constexpr int kScanThreads = 512;
 static constexpr int kScanWaves = kScanThreads / 64;
 static constexpr int kVerdictThreads = 256;
 static constexpr int kVerdictWaves = kVerdictThreads / 64;
+static constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-uint32_t scan_lds_bytes(uint32_t n_states, uint32_t stride, uint32_t n_local) {
-    uint32_t tab = (n_states * stride * 2 + 15) & ~15u;
-    return tab + 256 + kScanWaves * n_local * 8;
-}
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return ((n_hot * stride * 2 + 15) & ~15u) + 256; }
 uint32_t verdict_lds_bytes(uint32_t n_cols) { return kVerdictWaves * n_cols * 8; }
-
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // -------------------------------------------------------------------------------------------------
 // scan
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit_list(const ScanArgs &a, uint32_t id, unsigned long long *col, unsigned long long bit) {
-    uint32_t b = a.list_off[id], e = a.list_off[id + 1];
-    for (uint32_t k = b; k < e; k++) atomicOr(&col[a.list[k]], bit);
+struct Hits {
+    uint32_t a0, a1;  // local atom + 1, 0 = empty
+    uint32_t ovf;     // head of the overflow chain, kNone = not overflowed
+};
+
+__device__ __noinline__ void pool_push(const ScanArgs &a, uint32_t atom, Hits &h) {
+    const uint32_t idx = atomicAdd(a.pool_count, 1u);
+    if (idx >= a.pool_cap) {
+        atomicOr(a.status, 1u);
+        return;
+    }
+    a.pool[idx].atom = atom;
+    a.pool[idx].next = h.ovf;
+    h.ovf = idx;
+}
+
+__device__ __noinline__ void record_atom(const ScanArgs &a, uint32_t atom, Hits &h) {
+    if (h.ovf == kNone) {
+        if (h.a0 == atom + 1 || h.a1 == atom + 1) return;
+        if (h.a0 == 0) { h.a0 = atom + 1; return; }
+        if (h.a1 == 0) { h.a1 = atom + 1; return; }
+        pool_push(a, h.a0 - 1, h);
+        pool_push(a, h.a1 - 1, h);
+        pool_push(a, atom, h);
+        return;
+    }
+    // overflowed: the chain holds every atom of this request; de-duplicate against it (this lane is its only writer)
+    for (uint32_t i = h.ovf; i != kNone;) {
+        const uint32_t at = __hip_atomic_load(&a.pool[i].atom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at == atom) return;
+        i = __hip_atomic_load(&a.pool[i].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pool_push(a, atom, h);
+}
+
+__device__ __forceinline__ void emit_list(const ScanArgs &a, uint32_t id, Hits &h) {
+    const uint32_t b = a.list_off[id], e = a.list_off[id + 1];
+    for (uint32_t k = b; k < e; k++) record_atom(a, a.list[k], h);
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t tab_bytes = (a.n_states * a.stride * 2 + 15) & ~15u;
-    const uint16_t *tab = reinterpret_cast<const uint16_t *>(lds);
-    const uint8_t *cls = lds + tab_bytes;
+    const uint32_t hot_bytes = (a.n_hot * a.stride * 2 + 15) & ~15u;
+    const uint16_t *ltab = reinterpret_cast<const uint16_t *>(lds);
+    const uint8_t *cls = lds + hot_bytes;
+    const uint16_t *gtab = a.tab;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned long long *col = reinterpret_cast<unsigned long long *>(lds + tab_bytes + 256) + (size_t)wave * a.n_local;
 
-    // stage the transition table and the byte-class map into LDS (coalesced 16 B per lane)
-    for (uint32_t i = tid * 16; i < tab_bytes; i += kScanThreads * 16)
-        *reinterpret_cast<uint4 *>(lds + i) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.tab) + i);
-    if (tid < 64) reinterpret_cast<uint32_t *>(lds + tab_bytes)[tid] = reinterpret_cast<const uint32_t *>(a.classmap)[tid];
-    for (uint32_t k = lane; k < a.n_local; k += 64) col[k] = 0;
+    // stage the hot rows and the byte-class map into LDS (coalesced 16 B per lane; the global table is padded)
+    for (uint32_t i = tid * 16; i < hot_bytes; i += kScanThreads * 16)
+        *reinterpret_cast<uint4 *>(lds + i) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(gtab) + i);
+    if (tid < 64) reinterpret_cast<uint32_t *>(lds + hot_bytes)[tid] = reinterpret_cast<const uint32_t *>(a.classmap)[tid];
     __syncthreads();
 
-    const unsigned long long mybit = 1ull << lane;
-    const uint32_t ncls = a.n_classes, first_emit = a.first_emit_pm;
-    const bool start_emits = a.start_pm >= first_emit;
+    const uint32_t stride = a.stride, ncls = a.n_classes, n_hot = a.n_hot;
+    // this wave's slab of requests: contiguous, 64-aligned so offset blocks are whole
+    const uint32_t total_waves = gridDim.x * kScanWaves;
+    const uint32_t per_wave = (((a.n + total_waves - 1) / total_waves) + 63) & ~63u;
+    const uint32_t gw = blockIdx.x * kScanWaves + wave;
+    const uint32_t w0 = min(a.n, gw * per_wave), w1 = min(a.n, w0 + per_wave);
+    if (w0 >= w1) return;
 
-    for (uint32_t g = blockIdx.x * kScanWaves + wave; g < a.n_groups; g += gridDim.x * kScanWaves) {
-        const uint32_t i = g * 64 + lane;
-        const bool valid = i < a.n;
-        uint32_t p = 0, end = 0;
-        if (valid) {
-            p = a.off[i];
-            end = a.off[i + 1];
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    const uint32_t start_emit = gtab[ncls + 1];  // emit-list id + 1 of state 0 (wave-uniform)
+
+    uint32_t next = w0, blk = w0;
+    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi) {
+        const uint32_t i = min(base + lane, a.n - 1);  // base + lane < n + 63; clamp keeps the load in bounds
+        lo = a.off[i];
+        hi = a.off[i + 1];
+    };
+    uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0;
+    load_off(blk, o_lo, o_hi);
+    if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi);
+
+    uint32_t r = kNone, p = 0, end = 0, st = 0;
+    Hits h{0, 0, kNone};
+
+    for (;;) {
+        // ---- refill idle lanes from the slab (ballot + prefix popcount) ----
+        const unsigned long long idle = __ballot(r == kNone);
+        if (idle != 0 && next < w1) {
+            const uint32_t avail = min(w1 - next, blk + 64 - next);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(idle & lt_mask);
+            const bool take = r == kNone && rank < avail;
+            const uint32_t j = take ? next + rank - blk : 0;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_lo);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_hi);
+            if (take) {
+                r = next + rank;
+                p = lo;
+                end = hi;
+                st = 0;
+                h = Hits{0, 0, kNone};
+                if (start_emit) emit_list(a, start_emit - 1, h);
+            }
+            next += min((uint32_t)__builtin_popcountll(idle), avail);
+            if (next == blk + 64 && next < w1) {
+                blk += 64;
+                o_lo = n_lo;
+                o_hi = n_hi;
+                if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi);
+            }
         }
-        uint32_t st = a.start_pm;
-        if (start_emits && valid) emit_list(a, (uint32_t)tab[st + ncls + 1] - 1, col, mybit);
+        if (__ballot(r != kNone) == 0) break;
 
-        while (__ballot(p < end) != 0) {
-            const bool act = p < end;
-            const uint32_t cnt = act ? min(16u, end - p) : 0u;
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (act) __builtin_memcpy(w, a.data + p, 16);  // unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack
+        // ---- 16 bytes of every active lane's field ----
+        const bool act = r != kNone && p < end;
+        const uint32_t cnt = act ? min(16u, end - p) : 0u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (act) __builtin_memcpy(w, a.data + p, 16);  // unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t byte = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const uint32_t ns = tab[st + cls[byte]];
-                const bool use = (uint32_t)k < cnt;
-                st = use ? ns : st;
-                if (use && ns >= first_emit) emit_list(a, (uint32_t)tab[ns + ncls + 1] - 1, col, mybit);
+        for (int k = 0; k < 16; k++) {
+            const uint32_t byte = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            const bool use = (uint32_t)k < cnt;
+            const uint32_t idx = st * stride + cls[byte];
+            const bool hot = st < n_hot;
+            uint32_t e = ltab[hot ? idx : 0u];
+            if (use && !hot) e = gtab[idx];  // deep state: row comes from L2
+            if (use) {
+                st = e & 0x7FFFu;
+                if (e & 0x8000u) {
+                    const uint32_t id = st < n_hot ? ltab[st * stride + ncls + 1] : gtab[st * stride + ncls + 1];
+                    emit_list(a, id - 1, h);
+                }
             }
-            p += cnt;
         }
-        if (valid) {
-            const uint32_t e = tab[st + ncls];
-            if (e) emit_list(a, e - 1, col, mybit);
+        p += cnt;
+
+        // ---- finished requests: end-of-field matches, then the hit record ----
+        if (r != kNone && p >= end) {
+            const uint32_t e = st < n_hot ? ltab[st * stride + ncls] : gtab[st * stride + ncls];
+            if (e) emit_list(a, e - 1, h);
+            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+            r = kNone;
         }
-        // LDS atomics of this wave are complete before its own later LDS reads (in-order per wave);
-        // keep the compiler from reordering across the flush
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // sparse flush: one S word per 64 columns, M words only where non-zero
-        unsigned long long *Mrow = reinterpret_cast<unsigned long long *>(a.M) + (size_t)g * a.scan_cols + a.col_rel;
-        unsigned long long *Srow = reinterpret_cast<unsigned long long *>(a.S) + (size_t)g * a.scan_words + (a.col_rel >> 6);
-        for (uint32_t b = 0; b < a.n_local; b += 64) {
-            const unsigned long long v = col[b + lane];
-            const bool nz = v != 0;
-            const unsigned long long mask = __ballot(nz);
-            if (nz) {
-                Mrow[b + lane] = v;
-                col[b + lane] = 0;
-            }
-            if (lane == 0) Srow[b >> 6] = mask;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
 int launch_scan(const ScanArgs &a, void *stream) {
-    uint32_t lds = scan_lds_bytes(a.n_states, a.stride, a.n_local);
+    uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
     static thread_local uint32_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = lds;
     }
-    uint32_t blocks = (a.n_groups + kScanWaves - 1) / kScanWaves;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks == 0) return 0;
+    if (a.n == 0) return 0;
+    // enough waves to fill 256 CUs several times over, but each with a few hundred requests so that work-pulling
+    // has something to balance (a slab is >= 64 requests)
+    uint32_t waves = (a.n + 255) / 256;
+    uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
@@ -169,16 +236,22 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
 
-        // 2. gather the sparse scan columns
-        {
-            const unsigned long long *Srow = reinterpret_cast<const unsigned long long *>(a.S) + (size_t)g * a.scan_words;
-            const unsigned long long *Mrow = reinterpret_cast<const unsigned long long *>(a.M) + (size_t)g * a.scan_cols;
-            for (uint32_t wd = lane; wd < a.scan_words; wd += 64) {
-                unsigned long long s = Srow[wd];
-                while (s) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(s);
-                    s &= s - 1;
-                    col[a.scan_base + wd * 64 + b] = Mrow[wd * 64 + b];
+        // 2. scan results: each lane ORs its request's bit into the columns its hit records name
+        if (valid) {
+            for (uint32_t ps = 0; ps < a.n_passes; ps++) {
+                const uint32_t rv = a.rec[(size_t)ps * a.n + i];
+                if (rv == 0) continue;
+                const uint32_t base = a.pass_base[ps];
+                if (rv & REC_OVERFLOW) {
+                    for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
+                        const PoolEntry pe = a.pool[k];
+                        atomicOr(&col[base + pe.atom], mybit);
+                        k = pe.next;
+                    }
+                } else {
+                    const uint32_t x0 = rv & 0x7FFFu, x1 = (rv >> 15) & 0x7FFFu;
+                    if (x0) atomicOr(&col[base + x0 - 1], mybit);
+                    if (x1) atomicOr(&col[base + x1 - 1], mybit);
                 }
             }
         }

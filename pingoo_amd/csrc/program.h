@@ -69,22 +69,24 @@ struct Atom {
 };
 
 // ---- DFA groups ----------------------------------------------------------------------------------
+// One multi-pattern DFA = one scan pass over one field. States are numbered in BFS order from the start
+// state (id 0), so low ids are the shallow, frequently visited states: the device keeps rows [0, n_hot)
+// in LDS and reads colder rows from the L2-resident global copy.
 struct DfaGroup {
     uint8_t field = 0;
     uint32_t n_states = 0, n_classes = 0;
-    uint32_t first_emit = 0;             // states >= first_emit carry mid-stream emits
-    uint32_t start = 0;                  // start state (0, or first_emit when the start state itself emits)
     uint8_t classmap[256] = {0};
     std::vector<uint16_t> trans;         // n_states * n_classes, row-major; state 0 = start
-    std::vector<uint32_t> emit_off;      // (n_states - first_emit) + 1 offsets into emit_list
+    std::vector<uint32_t> emit_off;      // n_states + 1 offsets into emit_list (columns set on ENTERING the state)
     std::vector<uint16_t> emit_list;     // LOCAL atom ids (column = atom_base + local)
     std::vector<uint32_t> end_off;       // n_states + 1
     std::vector<uint16_t> end_list;      // LOCAL atom ids true if the field ends in this state
-    std::vector<uint32_t> end_flag;      // bitset over states: end_off[s+1] > end_off[s]
-    uint32_t atom_base = 0;              // first device column of this group (multiple of 64)
-    uint32_t n_local = 0;                // columns owned by this group (multiple of 64)
+    uint32_t atom_base = 0;              // first device column of this group
+    uint32_t n_local = 0;                // columns owned by this group (= atoms.size())
     std::vector<uint32_t> atoms;         // indices into Program::atoms, local id order
 };
+static constexpr uint32_t kMaxDfaStates = 32767;   // 15-bit state ids: bit 15 of a table entry flags "target state emits"
+static constexpr uint32_t kMaxLocalAtoms = 32766;  // 15-bit (+1) atom slots in a hit record
 
 // ---- radix tries ----------------------------------------------------------------------------------
 // Entry: bit31 set => leaf, low 31 bits = value; else child node index (node n occupies nodes[n*256 ..]).
@@ -129,8 +131,8 @@ struct Program {
     std::vector<std::string> warnings;
 
     // device-level
-    uint32_t n_cols = 0;          // total columns (TRUE + scan blocks + numeric), multiple of 64
-    uint32_t n_scan_cols = 0;     // columns [64, 64 + n_scan_cols) belong to scan groups (multiple of 64)
+    uint32_t n_cols = 0;          // total columns: [0] TRUE, numeric atoms, then each DFA group's atoms
+    uint32_t n_scan_cols = 0;     // columns owned by DFA groups
     std::vector<DfaGroup> groups;
     std::vector<NumAtomDev> num_atoms;
     std::vector<int64_t> int_pool;
@@ -149,6 +151,7 @@ struct Program {
     std::vector<GeoRec> geo_recs;          // rec 0 = default {0,"XX"}
 
     uint32_t flags = 0;
+    uint32_t lds_hot_budget = 64 * 1024;  // LDS bytes the scan kernel may use for the hot rows of one table
     pwaf_stats stats{};
 };
 
@@ -174,6 +177,9 @@ struct ScanPattern {
 };
 // Builds one DFA for `pats` (local ids = positions in pats). Returns false when the state limit is exceeded.
 bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32_t max_table_bytes, DfaGroup &out, std::string &err);
+// true when the pattern has an unbounded repetition of a wide byte class (".*", "[^x]*", ...): such patterns multiply DFA
+// states with each other (each adds an independent "prefix seen" bit), so the grouping heuristic isolates them.
+bool has_wide_gap(const RNode &n);
 // Runs a DFA on the host over `bytes`, returning local atom ids that hold. COMPILE-TIME USE ONLY
 // (folding predicates over the 676 possible country codes into a lookup table).
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms);

@@ -93,6 +93,7 @@ def lib():
     L.pwaf_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
     L.pwaf_evaluate_device.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp, vp, vp, vp]
     L.pwaf_evaluate_one.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
+    L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
     L.pwaf_engine_kernel_times.argtypes = [vp, C.POINTER(_abi.KernelTime), C.c_int]
     L.pwaf_derive_path.argtypes = [C.c_char_p, C.c_size_t]
@@ -185,13 +186,14 @@ def get_host(uri_host: Optional[bytes], host_header: Optional[bytes]) -> bytes:
     return src[s.value:s.value + l.value]
 
 
-def _options(flags=0, device=-1, lds_table_budget=0, max_dfa_states=0) -> _abi.Options:
+def _options(flags=0, device=-1, lds_table_budget=0, max_dfa_states=0, max_table_bytes=0) -> _abi.Options:
     o = _abi.Options()
     o.struct_size = C.sizeof(_abi.Options)
     o.flags = flags
     o.device = device
     o.lds_table_budget = lds_table_budget
     o.max_dfa_states = max_dfa_states
+    o.max_table_bytes = max_table_bytes
     return o
 
 
@@ -317,6 +319,12 @@ class RuleEngine:
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
         return out
+
+    def device_status(self) -> None:
+        """Synchronises and raises if the last device-resident batch ran out of scan scratch."""
+        rc = lib().pwaf_engine_device_status(self._h)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
 
     def set_profiling(self, on: bool):
         lib().pwaf_engine_set_profiling(self._h, int(on))

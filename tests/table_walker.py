@@ -50,8 +50,8 @@ class Tables:
             if tag == "HEAD":
                 (self.n_cols, self.n_scan_cols, self.n_groups, self.n_rules, self.n_ip_lists, self.set_words, self.has_geo, self.flags) = struct.unpack("<8I", pl)
             elif tag == "GHDR":
-                f, ns, nc, fe, st, ab, nl, na = struct.unpack("<8I", pl)
-                cur = dict(field=f, n_states=ns, n_classes=nc, first_emit=fe, start=st, atom_base=ab, n_local=nl, n_atoms=na)
+                f, ns, nc, _, _, ab, nl, na = struct.unpack("<8I", pl)
+                cur = dict(field=f, n_states=ns, n_classes=nc, atom_base=ab, n_local=nl, n_atoms=na)
                 self.groups.append(cur)
             elif tag == "GCLS":
                 cur["classmap"] = np.frombuffer(pl, dtype=np.uint8)
@@ -85,14 +85,11 @@ class Tables:
     # --- pieces ---
     def scan_field(self, g: dict, data: bytes, cols: set):
         """Walks one field through group g's DFA, adding the device column ids that hold."""
-        st = g["start"]
-        fe = g["first_emit"]
+        st = 0  # states are in BFS order from the start state
 
         def emit(s):
-            if s >= fe:
-                k = s - fe
-                for a in g["emit_list"][g["emit_off"][k]:g["emit_off"][k + 1]]:
-                    cols.add(g["atom_base"] + int(a))
+            for a in g["emit_list"][g["emit_off"][s]:g["emit_off"][s + 1]]:
+                cols.add(g["atom_base"] + int(a))
         emit(st)
         cm, tr = g["classmap"], g["trans"]
         for b in data:

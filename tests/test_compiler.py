@@ -83,7 +83,7 @@ def test_fuzz_compiled_tables_match_oracle(seed):
             continue
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
-    prog = CompiledProgram(rules, lists, geo, flags=flags, lds_table_budget=rng.choice([0, 0, 2048, 4096]))
+    prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
     H.assert_verdicts_equal(walk(prog, batch), want, batch, f"seed {seed}")
@@ -142,8 +142,8 @@ def test_dfa_grouping_respects_the_lds_budget_and_keeps_results():
     words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(3, 7))) for _ in range(120)]
     rules = [(f"r{k}", f'http_request.path.contains("{w}")', [B]) for k, w in enumerate(words)]
     big = CompiledProgram(rules)
-    small = CompiledProgram(rules, lds_table_budget=4096)
-    assert big.stats()["n_dfa_groups"] == 1 + 0 or big.stats()["n_dfa_groups"] >= 1
+    small = CompiledProgram(rules, max_table_bytes=4096)
+    assert big.stats()["n_dfa_groups"] == 1  # one table per field: the literals and the captcha-endpoint prefix share the path table
     assert small.stats()["n_dfa_groups"] > big.stats()["n_dfa_groups"]
     t = Tables(small.dump())
     for g in t.groups:

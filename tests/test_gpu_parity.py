@@ -44,7 +44,7 @@ def test_fuzz_gpu_matches_oracle(seed):
             continue
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS])
-    eng = RuleEngine(rules, lists, geo, flags=flags, lds_table_budget=rng.choice([0, 0, 2048, 8192]))
+    eng = RuleEngine(rules, lists, geo, flags=flags, lds_table_budget=rng.choice([0, 0, 1024, 2048]), max_table_bytes=rng.choice([0, 0, 4096]), max_dfa_states=rng.choice([0, 0, 60]))
     n = rng.choice([1, 63, 64, 65, 200, 777])
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, n, with_geo))
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
