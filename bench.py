@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -143,6 +144,15 @@ def main():
             elif name == "verdict":
                 verdict_ms += ms
         n_scan_launches = sum(1 for k in ktimes if k[0].startswith("scan_"))
+        if args.verbose:
+            per = {}
+            for name, ms, tag in ktimes:
+                per.setdefault(name, []).append(ms)
+            for name, v in per.items():
+                fb = field_bytes[int(name.split("_g")[0].split("_", 1)[1] == "user_agent" and 4 or ["host", "url", "path", "method"].index(name.split("_g")[0].split("_", 1)[1]))] if name.startswith("scan_") else 0
+                avg = sum(v) / len(v)
+                print(f"  {name:<24} avg {avg:8.3f} ms  x{len(v)}" + (f"  {fb / avg / 1e6:8.1f} GB/s of field bytes" if fb else ""), file=sys.stderr)
+            print("  " + json.dumps(stats), file=sys.stderr)
         # algorithmic bytes: every byte of a scanned field ONCE per step (however many DFA groups re-read it)
         # + its n+1 offsets; the verdict kernel is credited with the fixed-width columns.
         scan_alg = sum(field_bytes[f] + 4 * (n + 1) for f in fields_scanned) * args.steps

@@ -1118,14 +1118,19 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         for (size_t a = 1; a < P.atoms.size(); a++)
             if (used[a] && P.atoms[a].kind == ATOM_SCAN && P.atoms[a].field == f) pats.push_back({P.atoms[a].pattern, (uint32_t)a});
         if (pats.empty()) continue;
-        std::vector<std::vector<ScanPattern>> work{pats};
+        struct WorkItem { std::vector<ScanPattern> pats; std::vector<uint32_t> filter; };
+        struct PendingGate { std::vector<ScanPattern> pats; std::vector<uint32_t> factors; };
+        std::vector<WorkItem> work;
+        work.push_back({pats, {}});
         while (!work.empty()) {
-            std::vector<ScanPattern> cur = std::move(work.back());
+            std::vector<ScanPattern> cur = std::move(work.back().pats);
+            std::vector<uint32_t> cur_filter = std::move(work.back().filter);
             work.pop_back();
             DfaGroup g;
             std::string derr;
             if (cur.size() <= kMaxLocalAtoms && build_dfa(cur, max_states, max_table_bytes, g, derr)) {
                 g.field = (uint8_t)f;
+                g.filter_atoms = cur_filter;
                 g.atom_base = next_col;
                 for (size_t k = 0; k < cur.size(); k++) P.atoms[cur[k].atom].id = next_col + (uint32_t)k;
                 next_col += g.n_local;
@@ -1138,17 +1143,46 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             }
             std::vector<ScanPattern> gap, plain;
             for (auto &p : cur) (has_wide_gap(*p.rx) ? gap : plain).push_back(p);
-            if (!gap.empty() && !plain.empty()) {
-                // chunks of gap patterns, then the plain rest (LIFO work list: push in reverse)
-                work.push_back(plain);
-                for (size_t k = 0; k < gap.size(); k += 8) work.emplace_back(gap.begin() + (long)k, gap.begin() + (long)std::min(gap.size(), k + 8));
+            if (!gap.empty() && (!plain.empty() || gap.size() > 8)) {
+                // Isolate the gap patterns in chunks of 8. Each chunk whose patterns all have a necessary prefix factor is
+                // GATED: the factors join the plain patterns (as hidden atoms) and the chunk's pass only visits requests where
+                // one of them fired. LIFO work list: push the plain rest first so that it is built last, with the factors.
+                std::vector<PendingGate> gates;
+                for (size_t k = 0; k < gap.size(); k += 8) {
+                    std::vector<ScanPattern> chunk(gap.begin() + (long)k, gap.begin() + (long)std::min(gap.size(), k + 8));
+                    std::vector<uint32_t> factors;
+                    bool all = true;
+                    for (auto &p : chunk) {
+                        RNodeP x = gap_prefilter(p.rx);
+                        if (!x) { all = false; break; }
+                        Atom fa;
+                        fa.kind = ATOM_SCAN;
+                        fa.field = (uint8_t)f;
+                        fa.pattern = x;
+                        fa.key = "S" + std::to_string(f) + ":" + rx_key(*x);
+                        uint32_t idx = (uint32_t)rc.intern_atom(std::move(fa));
+                        if (idx >= used.size()) used.resize(idx + 1, 0);
+                        if (!used[idx]) {
+                            used[idx] = 1;
+                            plain.push_back({P.atoms[idx].pattern, idx});  // hidden atom: scanned with the plain patterns
+                        }
+                        factors.push_back(idx);
+                    }
+                    gates.push_back({chunk, all ? factors : std::vector<uint32_t>()});
+                }
+                if (!plain.empty()) work.push_back({plain, {}});
+                for (auto &g : gates) work.push_back({g.pats, g.factors});
             } else {
                 size_t half = cur.size() / 2;
-                work.emplace_back(cur.begin() + (long)half, cur.end());
-                work.emplace_back(cur.begin(), cur.begin() + (long)half);
+                work.push_back({std::vector<ScanPattern>(cur.begin() + (long)half, cur.end()), cur_filter});
+                work.push_back({std::vector<ScanPattern>(cur.begin(), cur.begin() + (long)half), cur_filter});
             }
         }
     }
+    // gated groups run after every ungated one (their factors must have been scanned), and resolve factor columns
+    std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty(); });
+    for (auto &g : P.groups)
+        for (uint32_t fa : g.filter_atoms) g.filter_cols.push_back(P.atoms[fa].id);
     P.n_scan_cols = next_col - scan_base;
     P.n_cols = next_col;
     if (P.groups.size() > 64) {
@@ -1307,6 +1341,7 @@ std::vector<uint8_t> dump_program(const Program &p) {
         w.section("GEML", (uint32_t)gi, g.emit_list.data(), g.emit_list.size() * 2);
         w.section("GENO", (uint32_t)gi, g.end_off.data(), g.end_off.size() * 4);
         w.section("GENL", (uint32_t)gi, g.end_list.data(), g.end_list.size() * 2);
+        w.section("GFLT", (uint32_t)gi, g.filter_cols.data(), g.filter_cols.size() * 4);
     }
     w.section("NUMA", (uint32_t)p.num_atoms.size(), p.num_atoms.data(), p.num_atoms.size() * sizeof(NumAtomDev));
     w.section("INTP", (uint32_t)p.int_pool.size(), p.int_pool.data(), p.int_pool.size() * 8);

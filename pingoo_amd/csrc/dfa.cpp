@@ -438,6 +438,33 @@ bool has_wide_gap(const RNode &n) {
     return false;
 }
 
+static bool rx_nullable(const RNode &n) {
+    switch (n.k) {
+        case RNode::EMPTY: case RNode::ASSERT: return true;
+        case RNode::CLASS: return false;
+        case RNode::CAT: for (auto &k : n.kids) if (!rx_nullable(*k)) return false; return true;
+        case RNode::ALT: for (auto &k : n.kids) if (rx_nullable(*k)) return true; return false;
+        case RNode::REPEAT: return n.rmin == 0 || rx_nullable(*n.kids[0]);
+    }
+    return true;
+}
+
+RNodeP gap_prefilter(const RNodeP &rx) {
+    if (!rx || rx->k != RNode::CAT) return nullptr;
+    auto is_gap = [](const RNode &n) { return n.k == RNode::REPEAT && n.rmax < 0 && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64; };
+    size_t g = 0;
+    while (g < rx->kids.size() && !is_gap(*rx->kids[g])) {
+        if (has_wide_gap(*rx->kids[g])) return nullptr;  // a gap nested deeper comes first: no clean prefix
+        g++;
+    }
+    if (g == rx->kids.size()) return nullptr;
+    std::vector<RNodeP> pre(rx->kids.begin(), rx->kids.begin() + (long)g);
+    while (!pre.empty() && pre.back()->k == RNode::ASSERT) pre.pop_back();  // trailing look-arounds only strengthen X
+    RNodeP x = rx_cat(pre);
+    if (pre.empty() || rx_nullable(*x)) return nullptr;  // would fire everywhere: useless as a filter
+    return x;
+}
+
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms) {
     uint32_t s = 0;
     auto emit = [&](uint32_t st) {

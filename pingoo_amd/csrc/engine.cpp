@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -71,9 +72,10 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 }
 
 struct DevGroup {
-    DevBuf tab, classmap, list_off, list;
-    uint32_t n_states, stride, n_classes, n_hot, atom_base;
+    DevBuf tab, classmap, special, list_off, list;
+    uint32_t n_states, stride, n_classes, n_hot, start_emit, atom_base;
     uint8_t field;
+    int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
 };
 
 }  // namespace
@@ -83,11 +85,16 @@ struct pwaf_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<DevGroup> groups;
-    DevBuf num_atoms, int_pool, country_luts, rules, lits, set_masks;
+    DevBuf num_atoms, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
+    uint32_t cc_words = 1;
+    DevBuf iu_vals[2], iu_masks[2];
+    uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
     // per-call scratch (guarded by mu)
     std::mutex mu;
-    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word */, pass_base;
+    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
+    DevBuf colmask, gate_lists;
+    uint32_t n_ungated = 0, n_gated = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // profiling
@@ -114,42 +121,62 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
     g_last_error = src.message;
 }
 
-// table rows: [next | 0x8000 if next emits ...] [1 + end list id] [1 + emit list id]; lists shared
+// Builds the device form of one DFA group: see the cell encoding in kernels.h.
 int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) {
-    const uint32_t C = g.n_classes, stride = C + 2;
+    const uint32_t C = g.n_classes, stride = C + 2, stride2 = stride * 2;
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
+    // hot rows + the sentinel row must stay below 64 KiB so that a row's byte offset fits an even uint16
+    const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 65534u);
+    uint32_t n_hot = budget > 2 * stride2 ? (budget - stride2) / stride2 : 1;
+    n_hot = std::max(1u, std::min(n_hot, g.n_states));
     std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
     std::vector<uint32_t> list_off{0};
     std::vector<uint16_t> list;
+    auto add_list = [&](const std::vector<uint16_t> &src, uint32_t b, uint32_t e) -> uint32_t {
+        list.insert(list.end(), src.begin() + b, src.begin() + e);
+        list_off.push_back((uint32_t)list.size());
+        return (uint32_t)list_off.size() - 1;  // 1 + id
+    };
+    std::vector<uint32_t> emit_id(g.n_states, 0), special_of(g.n_states, 0xFFFFFFFFu);
+    for (uint32_t s = 0; s < g.n_states; s++)
+        if (g.emit_off[s + 1] > g.emit_off[s]) emit_id[s] = add_list(g.emit_list, g.emit_off[s], g.emit_off[s + 1]);
+    std::vector<SpecialCell> special;
     for (uint32_t s = 0; s < g.n_states; s++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t t = g.trans[(size_t)s * C + c];
-            tab[(size_t)s * stride + c] = (uint16_t)(t | (g.emit_off[t + 1] > g.emit_off[t] ? 0x8000u : 0u));
+            uint16_t cell;
+            if (t < n_hot && !emit_id[t]) {
+                cell = (uint16_t)(t * stride2);
+            } else {
+                if (special_of[t] == 0xFFFFFFFFu) {
+                    special_of[t] = (uint32_t)special.size();
+                    special.push_back({t * stride2, emit_id[t]});
+                }
+                if (special_of[t] > 32767) return fail(PWAF_E_UNSUPPORTED, "too many cold/emitting states in one DFA group");
+                cell = (uint16_t)((special_of[t] << 1) | 1u);
+            }
+            tab[(size_t)s * stride + c] = cell;
         }
+        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride2) : (uint16_t)1;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
-            list.insert(list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[s + 1]);
-            list_off.push_back((uint32_t)list.size());
-            if (list_off.size() - 1 > 65534) return fail(PWAF_E_UNSUPPORTED, "too many emit lists in one DFA group");
-            tab[(size_t)s * stride + C] = (uint16_t)(list_off.size() - 1);
-        }
-        if (g.emit_off[s + 1] > g.emit_off[s]) {
-            list.insert(list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[s + 1]);
-            list_off.push_back((uint32_t)list.size());
-            if (list_off.size() - 1 > 65534) return fail(PWAF_E_UNSUPPORTED, "too many emit lists in one DFA group");
-            tab[(size_t)s * stride + C + 1] = (uint16_t)(list_off.size() - 1);
+            uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
+            if (id1 > 65535) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
+            tab[(size_t)s * stride + C + 1] = (uint16_t)id1;
         }
     }
+    if (special.empty()) special.push_back({0, 0});
     d.n_states = g.n_states;
     d.stride = stride;
     d.n_classes = C;
-    d.n_hot = std::min<uint32_t>(g.n_states, lds_hot_budget / (stride * 2));
-    if (d.n_hot == 0) d.n_hot = 1;
+    d.n_hot = n_hot;
+    d.start_emit = emit_id[0];
     d.atom_base = g.atom_base;
     d.field = g.field;
     int rc;
     if ((rc = upload(d.tab, tab, 16))) return rc;
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     if ((rc = upload(d.classmap, cm))) return rc;
+    if ((rc = upload(d.special, special))) return rc;
     if ((rc = upload(d.list_off, list_off))) return rc;
     if ((rc = upload(d.list, list))) return rc;
     return PWAF_OK;
@@ -180,8 +207,9 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
     if ((rc = e->rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
     if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
-    if ((rc = e->ctrl.reserve(16))) return rc;
-    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 16, stream));
+    if ((rc = e->ctrl.reserve(4 * 34))) return rc;
+    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
+    if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
 
     size_t ev_i = e->profiling ? e->n_timed : 0;
     auto mark = [&](const char *name, uint64_t alg_bytes) -> int {
@@ -202,16 +230,43 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         return PWAF_OK;
     };
 
+    bool selected = false;
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
         DevGroup &d = e->groups[gi];
+        if (d.gate >= 0 && !selected) {
+            // all ungated passes are enqueued: find the requests the gated passes have to visit
+            SelectArgs sa{};
+            sa.n = n;
+            sa.n_passes = e->n_ungated;
+            sa.n_gated = e->n_gated;
+            sa.rec = (const uint32_t *)e->rec.p;
+            sa.pass_base = (const uint32_t *)e->pass_base.p;
+            sa.pool = (const PoolEntry *)e->pool.p;
+            sa.colmask = (const uint32_t *)e->colmask.p;
+            sa.lists = (uint32_t *)e->gate_lists.p;
+            sa.list_count = (uint32_t *)e->ctrl.p + 2;
+            if ((rc = mark(nullptr, 0))) return rc;
+            int he = launch_select(sa, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("select kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark("select", 0xFEu))) return rc;
+            selected = true;
+        }
         ScanArgs a{};
+        if (d.gate >= 0) {
+            // records of requests the pass does not visit must read "nothing matched"
+            HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + gi * (size_t)n, 0, (size_t)n * 4, stream));
+            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
+            a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
+        }
         a.data = db.field[d.field].data;
         a.off = db.field[d.field].offsets;
         a.n = n;
         a.tab = (const uint16_t *)d.tab.p;
         a.classmap = (const uint8_t *)d.classmap.p;
+        a.special = (const SpecialCell *)d.special.p;
         a.list_off = (const uint32_t *)d.list_off.p;
         a.list = (const uint16_t *)d.list.p;
+        a.start_emit = d.start_emit;
         a.n_states = d.n_states;
         a.stride = d.stride;
         a.n_classes = d.n_classes;
@@ -223,7 +278,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.status = (uint32_t *)e->ctrl.p + 1;
         char nm[48];
         static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
-        snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
+        snprintf(nm, sizeof nm, "%s_%s_g%zu", d.gate >= 0 ? "gscan" : "scan", fn[d.field], gi);
         if ((rc = mark(nullptr, 0))) return rc;
         int he = launch_scan(a, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
@@ -246,8 +301,14 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
     v.n_num_atoms = (uint32_t)P.num_atoms.size();
-    v.int_pool = (const int64_t *)e->int_pool.p;
-    v.country_luts = (const uint32_t *)e->country_luts.p;
+    for (int var = 0; var < 2; var++) {
+        v.iu_vals[var] = (const int64_t *)e->iu_vals[var].p;
+        v.iu_masks[var] = (const uint32_t *)e->iu_masks[var].p;
+        v.iu_n[var] = e->iu_n[var];
+        v.iu_words[var] = e->iu_words[var];
+    }
+    v.country_masks = (const uint32_t *)e->country_luts.p;
+    v.cc_words = e->cc_words;
     v.rules = (const DevRule *)e->rules.p;
     v.n_rules = (uint32_t)P.rules.size();
     v.lits = (const uint32_t *)e->lits.p;
@@ -394,11 +455,61 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         pass_base.push_back(P.groups[k].atom_base);
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
+    {
+        // gated passes (compile.cpp orders them after every ungated pass): column -> bitmask of the gated passes it triggers
+        std::vector<uint32_t> colmask(P.n_cols, 0);
+        for (size_t k = 0; k < P.groups.size(); k++) {
+            if (P.groups[k].filter_cols.empty() || e->n_gated >= 32) {
+                if (e->n_gated == 0) e->n_ungated = (uint32_t)k + 1;
+                continue;  // (beyond 32 gated passes the rest simply run ungated)
+            }
+            e->groups[k].gate = (int)e->n_gated;
+            for (uint32_t c : P.groups[k].filter_cols) colmask[c] |= 1u << e->n_gated;
+            e->n_gated++;
+        }
+        if (e->n_gated == 0) e->n_ungated = (uint32_t)P.groups.size();
+        if ((rc = upload(e->colmask, colmask))) return dev_fail(rc);
+    }
 #define UP(buf, vec)                                     \
     if ((rc = upload(e->buf, vec))) return dev_fail(rc);
-    UP(num_atoms, P.num_atoms)
-    UP(int_pool, P.int_pool)
-    UP(country_luts, P.country_lut_words)
+    {
+        // integer-set atoms: merge all sets tested against one variable into a sorted union with membership rows, so the
+        // device does one binary search per request and variable instead of one per predicate
+        std::vector<NumAtomDev> atoms = P.num_atoms;
+        for (int var = 0; var < 2; var++) {
+            std::map<int64_t, std::vector<uint32_t>> member;
+            uint32_t n_sets = 0;
+            for (auto &d : atoms) {
+                if (d.kind != ATOM_INTSET || d.var != var) continue;
+                for (uint32_t k = d.ref; k < d.ref2; k++) member[P.int_pool[k]].push_back(n_sets);
+                d.ref = n_sets++;  // from now on: bit index in the variable's membership row
+            }
+            if (n_sets > 128) { fail(PWAF_E_UNSUPPORTED, "more than 128 integer-set predicates on one client variable"); return dev_fail(PWAF_E_UNSUPPORTED); }
+            e->iu_words[var] = std::max(1u, (n_sets + 31) / 32);
+            e->iu_n[var] = (uint32_t)member.size();
+            std::vector<int64_t> vals;
+            std::vector<uint32_t> masks(e->iu_words[var], 0);  // row 0: the value is in no set
+            for (auto &kv : member) {
+                vals.push_back(kv.first);
+                std::vector<uint32_t> row(e->iu_words[var], 0);
+                for (uint32_t b : kv.second) row[b >> 5] |= 1u << (b & 31);
+                masks.insert(masks.end(), row.begin(), row.end());
+            }
+            UP(iu_vals[var], vals)
+            UP(iu_masks[var], masks)
+        }
+        UP(num_atoms, atoms)
+    }
+    {
+        // transpose the per-predicate 676-bit country tables into per-country membership words (one gather per request)
+        const uint32_t n_luts = (uint32_t)P.country_luts.size();
+        e->cc_words = std::max(1u, (n_luts + 31) / 32);
+        std::vector<uint32_t> masks((size_t)676 * e->cc_words, 0);
+        for (uint32_t t = 0; t < n_luts; t++)
+            for (uint32_t c = 0; c < 676; c++)
+                if (P.country_luts[t][c]) masks[(size_t)c * e->cc_words + (t >> 5)] |= 1u << (t & 31);
+        UP(country_luts, masks)
+    }
     UP(rules, P.rules)
     UP(lits, P.lits)
     UP(set_masks, P.set_masks)
@@ -417,9 +528,9 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.list_off.release(); g.list.release(); }
-    for (DevBuf *b : {&e->num_atoms, &e->int_pool, &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
+    for (DevBuf *b : {&e->num_atoms, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }

@@ -17,24 +17,49 @@ struct PoolEntry {
     uint32_t next;  // 0xFFFFFFFF = end of chain
 };
 
-// Device table of one DFA group: n_states rows of stride = n_classes + 2 uint16:
-//   [0, n_classes)  next state id | 0x8000 when the next state has an emit list
-//   [n_classes]     1 + end-list id (0 = none)        [n_classes + 1]  1 + emit-list id (0 = none)
-// Rows [0, n_hot) are staged into LDS by every workgroup; colder rows are read from this (L2-resident) copy.
+// Device table of one DFA group. n_states rows of stride = n_classes + 2 uint16, row r at byte offset
+// r * stride * 2 (rows are in BFS order; rows [0, n_hot) are copied into LDS, followed by one SENTINEL row of all-ones):
+//   [0, n_classes)   transition cell        [n_classes]  STAY cell (= own row, used for lanes past their last byte)
+//   [n_classes + 1]  1 + end-list id (0 = none)
+// A transition cell is EVEN  -> byte offset of the next row, which is hot and has nothing to emit  (the common case:
+//                               next lookup address = cell + class offset, no multiply, no compare)
+//                      ODD   -> (index << 1) | 1 into `special`: the target row is cold and/or has an emit list.
+// A lane whose current row is cold parks on the sentinel row, whose cells are all odd, so the same bit-0 test routes it
+// to the slow path that reads the real row from the L2-resident table.
+struct SpecialCell {
+    uint32_t next_off;  // byte offset of the target row in the full table
+    uint32_t emit;      // 1 + emit-list id, 0 = none
+};
 struct ScanArgs {
     const uint8_t *data;      // field arena
     const uint32_t *off;      // n + 1 offsets
     uint32_t n;
-    const uint16_t *tab;
+    const uint16_t *tab;      // full table (all rows), padded to 16 bytes
     const uint8_t *classmap;  // 256 bytes
+    const SpecialCell *special;
     const uint32_t *list_off; // shared by end- and emit-lists
     const uint16_t *list;     // local atom ids
     uint32_t n_states, stride, n_classes, n_hot;
+    uint32_t start_emit;      // 1 + emit-list id of the start state
     uint32_t *rec;            // n hit records of this pass
     PoolEntry *pool;
     uint32_t *pool_count;     // atomic allocator
     uint32_t pool_cap;
     uint32_t *status;         // device status word: bit 0 = overflow pool exhausted
+    // gated pass only (else null): the requests to visit and, on the device, how many
+    const uint32_t *req_list;
+    const uint32_t *n_list;
+};
+
+// select_kernel: builds the request lists of the gated passes from the ungated passes' hit records
+struct SelectArgs {
+    uint32_t n, n_passes /* ungated */, n_gated;
+    const uint32_t *rec;        // [n_passes][n]
+    const uint32_t *pass_base;
+    const PoolEntry *pool;
+    const uint32_t *colmask;    // per column: bit g set = gated pass g must visit a request that has this column
+    uint32_t *lists;            // [n_gated][n]
+    uint32_t *list_count;       // [n_gated], zeroed by the host per batch
 };
 
 struct VerdictArgs {
@@ -55,8 +80,12 @@ struct VerdictArgs {
     uint32_t n_cols;
     const NumAtomDev *num_atoms;
     uint32_t n_num_atoms;
-    const int64_t *int_pool;
-    const uint32_t *country_luts;  // 22 words per lut
+    // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
+    const int64_t *iu_vals[2];
+    const uint32_t *iu_masks[2];
+    uint32_t iu_n[2], iu_words[2];
+    const uint32_t *country_masks;  // [676][cc_words]: bit t of row c = country table t contains country code c
+    uint32_t cc_words;
     const DevRule *rules;
     uint32_t n_rules;
     const uint32_t *lits;
@@ -77,6 +106,7 @@ struct VerdictArgs {
 
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
 int launch_scan(const ScanArgs &a, void *stream);
+int launch_select(const SelectArgs &a, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
 uint32_t verdict_lds_bytes(uint32_t n_cols);

@@ -24,13 +24,21 @@
 
 namespace pwaf {
 
-static constexpr int kScanThreads = 512;
+static constexpr int kScanThreads = 1024;
 static constexpr int kScanWaves = kScanThreads / 64;
 static constexpr int kVerdictThreads = 256;
 static constexpr int kVerdictWaves = kVerdictThreads / 64;
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return ((n_hot * stride * 2 + 15) & ~15u) + 256; }
+// Explicit address spaces: a generic pointer that may be LDS or global makes the compiler emit FLAT loads for the table
+// lookups (one flat_load per input byte through the texture path instead of ds_read_u16 — measured 5x slower).
+#define PWAF_LDS __attribute__((address_space(3)))
+#define PWAF_GLOBAL __attribute__((address_space(1)))
+typedef const PWAF_LDS uint16_t *lds_u16_ptr;
+typedef const PWAF_GLOBAL uint16_t *glb_u16_ptr;
+typedef const PWAF_LDS uint32_t *lds_u32_ptr;
+
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + 1024; }
 uint32_t verdict_lds_bytes(uint32_t n_cols) { return kVerdictWaves * n_cols * 8; }
 
 // -------------------------------------------------------------------------------------------------
@@ -76,121 +84,230 @@ __device__ __forceinline__ void emit_list(const ScanArgs &a, uint32_t id, Hits &
     for (uint32_t k = b; k < e; k++) record_atom(a, a.list[k], h);
 }
 
+template <bool INDIRECT>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t hot_bytes = (a.n_hot * a.stride * 2 + 15) & ~15u;
-    const uint16_t *ltab = reinterpret_cast<const uint16_t *>(lds);
-    const uint8_t *cls = lds + hot_bytes;
-    const uint16_t *gtab = a.tab;
+    const uint32_t stride2 = a.stride * 2;
+    const uint32_t hot_bytes = a.n_hot * stride2;            // sentinel row starts here
+    const uint32_t tab_bytes = (hot_bytes + stride2 + 15) & ~15u;
+    const PWAF_LDS unsigned char *ltab = (const PWAF_LDS unsigned char *)lds;
+    // 256 x uint32: 2 * byte class (a byte offset inside a row). One dword per byte value: bytes that differ by less than
+    // 32 never share an LDS bank, so lower-case text (the bulk of URLs) reads it conflict-free.
+    lds_u32_ptr cls2 = (lds_u32_ptr)(lds + tab_bytes);
+    const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
-    // stage the hot rows and the byte-class map into LDS (coalesced 16 B per lane; the global table is padded)
-    for (uint32_t i = tid * 16; i < hot_bytes; i += kScanThreads * 16)
-        *reinterpret_cast<uint4 *>(lds + i) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(gtab) + i);
-    if (tid < 64) reinterpret_cast<uint32_t *>(lds + hot_bytes)[tid] = reinterpret_cast<const uint32_t *>(a.classmap)[tid];
+    // stage the hot rows, the sentinel row and the byte-class map into LDS (coalesced 16 B per lane)
+    for (uint32_t i = tid * 16; i < tab_bytes; i += kScanThreads * 16) {
+        uint4 v = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);  // sentinel cells: odd
+        if (i + 16 <= hot_bytes) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.tab) + i);
+        *reinterpret_cast<uint4 *>(lds + i) = v;
+    }
+    __syncthreads();
+    if (hot_bytes & 15) {  // the last, partially covered 16-byte slot of the hot rows
+        const uint32_t base = hot_bytes & ~15u;
+        if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + base)[tid] = a.tab[base / 2 + tid];
+    }
+    if (tid < 256) reinterpret_cast<uint32_t *>(lds + tab_bytes)[tid] = 2u * a.classmap[tid];
     __syncthreads();
 
-    const uint32_t stride = a.stride, ncls = a.n_classes, n_hot = a.n_hot;
-    // this wave's slab of requests: contiguous, 64-aligned so offset blocks are whole
+    const uint32_t stay2 = a.n_classes * 2, end_col2 = a.n_classes * 2 + 2;
+    // this wave's slab of work items: contiguous, 64-aligned so offset blocks are whole. A work item is request i, or —
+    // for a gated pass — entry i of the list of requests whose prefilter fired (its length lives on the device).
+    const uint32_t n_items = INDIRECT ? min(*a.n_list, a.n) : a.n;
     const uint32_t total_waves = gridDim.x * kScanWaves;
-    const uint32_t per_wave = (((a.n + total_waves - 1) / total_waves) + 63) & ~63u;
+    const uint32_t per_wave = (((n_items + total_waves - 1) / total_waves) + 63) & ~63u;
     const uint32_t gw = blockIdx.x * kScanWaves + wave;
-    const uint32_t w0 = min(a.n, gw * per_wave), w1 = min(a.n, w0 + per_wave);
+    const uint32_t w0 = min(n_items, gw * per_wave), w1 = min(n_items, w0 + per_wave);
     if (w0 >= w1) return;
 
     const unsigned long long lt_mask = (1ull << lane) - 1;
-    const uint32_t start_emit = gtab[ncls + 1];  // emit-list id + 1 of state 0 (wave-uniform)
+    const uint32_t start_emit = a.start_emit;
 
     uint32_t next = w0, blk = w0;
-    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi) {
-        const uint32_t i = min(base + lane, a.n - 1);  // base + lane < n + 63; clamp keeps the load in bounds
+    uint32_t o_id = 0, n_id = 0;  // INDIRECT: request index of each block entry
+    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi, uint32_t &id) {
+        uint32_t i = min(base + lane, n_items - 1);  // base + lane < n_items + 63; clamp keeps the load in bounds
+        if (INDIRECT) i = a.req_list[i];
+        id = i;
         lo = a.off[i];
         hi = a.off[i + 1];
     };
     uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0;
-    load_off(blk, o_lo, o_hi);
-    if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi);
+    load_off(blk, o_lo, o_hi, o_id);
+    if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi, n_id);
 
-    uint32_t r = kNone, p = 0, end = 0, st = 0;
+    // Software pipeline: while a lane chews on the 16 bytes in `w`, the 16 bytes it will need in the NEXT iteration are
+    // already in flight in `wn` — either the next chunk of the same field or, when this is the field's last chunk, the
+    // first chunk of the request the lane has just pulled (r2/p2/end2). HBM/L2 latency hides behind 16 DFA steps.
+    uint32_t r = kNone, p = 0, end = 0;           // current request
+    uint32_t row = 0;                             // LDS byte offset of the current row (== hot_bytes: parked, row is cold)
+    uint32_t crow = 0;                            // byte offset of the current row in the full table while cold
+    uint32_t r2 = kNone, p2 = 0, end2 = 0;        // request pulled ahead
     Hits h{0, 0, kNone};
+    uint4 w = make_uint4(0, 0, 0, 0), wn = make_uint4(0, 0, 0, 0);
 
     for (;;) {
-        // ---- refill idle lanes from the slab (ballot + prefix popcount) ----
-        const unsigned long long idle = __ballot(r == kNone);
-        if (idle != 0 && next < w1) {
+        // ---- 1. pull ahead: lanes on their last chunk (or idle) take the next request of the slab ----
+        const bool last = r == kNone || p + 16 >= end;
+        const unsigned long long want = __ballot(last && r2 == kNone);
+        if (want != 0 && next < w1) {
             const uint32_t avail = min(w1 - next, blk + 64 - next);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(idle & lt_mask);
-            const bool take = r == kNone && rank < avail;
+            const uint32_t rank = (uint32_t)__builtin_popcountll(want & lt_mask);
+            const bool take = last && r2 == kNone && rank < avail;
             const uint32_t j = take ? next + rank - blk : 0;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_lo);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_hi);
+            uint32_t rid = next + rank;
+            if (INDIRECT) rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_id);
             if (take) {
-                r = next + rank;
-                p = lo;
-                end = hi;
-                st = 0;
-                h = Hits{0, 0, kNone};
-                if (start_emit) emit_list(a, start_emit - 1, h);
+                r2 = rid;
+                p2 = lo;
+                end2 = hi;
             }
-            next += min((uint32_t)__builtin_popcountll(idle), avail);
+            next += min((uint32_t)__builtin_popcountll(want), avail);
             if (next == blk + 64 && next < w1) {
                 blk += 64;
                 o_lo = n_lo;
                 o_hi = n_hi;
-                if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi);
+                o_id = n_id;
+                if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi, n_id);
             }
         }
-        if (__ballot(r != kNone) == 0) break;
+        if (__ballot(r != kNone || r2 != kNone) == 0) break;
+        {
+            const uint32_t np = last ? p2 : p + 16;
+            const bool have = last ? (r2 != kNone && p2 < end2) : true;
+            if (have) __builtin_memcpy(&wn, a.data + np, 16);  // unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack
+        }
 
-        // ---- 16 bytes of every active lane's field ----
+        // ---- 2. 16 bytes of every active lane's field ----
         const bool act = r != kNone && p < end;
         const uint32_t cnt = act ? min(16u, end - p) : 0u;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (act) __builtin_memcpy(w, a.data + p, 16);  // unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack
+        const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+        uint32_t c2[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint32_t byte = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            const bool use = (uint32_t)k < cnt;
-            const uint32_t idx = st * stride + cls[byte];
-            const bool hot = st < n_hot;
-            uint32_t e = ltab[hot ? idx : 0u];
-            if (use && !hot) e = gtab[idx];  // deep state: row comes from L2
-            if (use) {
-                st = e & 0x7FFFu;
-                if (e & 0x8000u) {
-                    const uint32_t id = st < n_hot ? ltab[st * stride + ncls + 1] : gtab[st * stride + ncls + 1];
-                    emit_list(a, id - 1, h);
+            const uint32_t c = cls2[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];  // byte classes do not depend on the state
+            c2[k] = (uint32_t)k < cnt ? c : stay2;                            // past the end: the STAY column
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t prev = row;
+            row = *reinterpret_cast<lds_u16_ptr>(ltab + prev + c2[k]);  // even: the next row's LDS offset — done
+            if (row & 1u) {
+                // rare: the target row is cold and/or emits, or this lane is parked on the sentinel row (current row cold)
+                uint32_t cell = row;
+                row = prev;
+                if ((uint32_t)k < cnt) {
+                    if (prev == hot_bytes) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
+                    if (cell & 1u) {
+                        const SpecialCell sp = a.special[cell >> 1];
+                        if (sp.next_off < hot_bytes) row = sp.next_off;
+                        else { row = hot_bytes; crow = sp.next_off; }
+                        if (sp.emit) emit_list(a, sp.emit - 1, h);
+                    } else {
+                        row = cell;
+                    }
                 }
             }
         }
         p += cnt;
 
-        // ---- finished requests: end-of-field matches, then the hit record ----
+        // ---- 3. finished requests: end-of-field matches, the hit record, then switch to the pulled-ahead request ----
         if (r != kNone && p >= end) {
-            const uint32_t e = st < n_hot ? ltab[st * stride + ncls] : gtab[st * stride + ncls];
+            const uint32_t e = row == hot_bytes ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + end_col2)
+                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + row + end_col2);
             if (e) emit_list(a, e - 1, h);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             r = kNone;
         }
+        if (r == kNone && r2 != kNone) {
+            r = r2;
+            p = p2;
+            end = end2;
+            r2 = kNone;
+            row = 0;
+            h = Hits{0, 0, kNone};
+            if (start_emit) emit_list(a, start_emit - 1, h);
+        }
+        w = wn;
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// select: which requests must the gated passes visit?
+// -------------------------------------------------------------------------------------------------
+// One lane per request: looks at the hit records of the ungated passes; every recorded column that is a prefilter factor
+// names (through colmask) the gated passes that have to scan this request. Requests are appended to those passes' lists with
+// a wave ballot + prefix popcount and one atomic per (wave, pass).
+__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < a.n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + lane;
+        uint32_t need = 0;
+        if (i < a.n) {
+            for (uint32_t ps = 0; ps < a.n_passes; ps++) {
+                const uint32_t rv = a.rec[(size_t)ps * a.n + i];
+                if (rv == 0) continue;
+                const uint32_t cb = a.pass_base[ps];
+                if (rv & REC_OVERFLOW) {
+                    for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
+                        const PoolEntry pe = a.pool[k];
+                        need |= a.colmask[cb + pe.atom];
+                        k = pe.next;
+                    }
+                } else {
+                    const uint32_t x0 = rv & 0x7FFFu, x1 = (rv >> 15) & 0x7FFFu;
+                    if (x0) need |= a.colmask[cb + x0 - 1];
+                    if (x1) need |= a.colmask[cb + x1 - 1];
+                }
+            }
+        }
+        for (uint32_t gte = 0; gte < a.n_gated; gte++) {
+            const unsigned long long m = __ballot((need >> gte) & 1u);
+            if (m == 0) continue;
+            uint32_t basei = 0;
+            if (lane == 0) basei = atomicAdd(&a.list_count[gte], (uint32_t)__builtin_popcountll(m));
+            basei = __builtin_amdgcn_readfirstlane(basei);
+            if ((need >> gte) & 1u) a.lists[(size_t)gte * a.n + basei + (uint32_t)__builtin_popcountll(m & lt_mask)] = i;
+        }
+    }
+}
+
+int launch_select(const SelectArgs &a, void *stream) {
+    if (a.n == 0 || a.n_gated == 0) return 0;
+    uint32_t blocks = (a.n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 
 int launch_scan(const ScanArgs &a, void *stream) {
     uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
-    static thread_local uint32_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static thread_local uint32_t configured[2] = {0, 0};
+    const int variant = a.req_list != nullptr;
+    if (lds > configured[variant]) {
+        const void *fn = variant ? reinterpret_cast<const void *>(scan_kernel<true>) : reinterpret_cast<const void *>(scan_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        configured = lds;
+        configured[variant] = lds;
     }
     if (a.n == 0) return 0;
-    // enough waves to fill 256 CUs several times over, but each with a few hundred requests so that work-pulling
-    // has something to balance (a slab is >= 64 requests)
+    if (variant) {
+        // gated pass: the list length is only known on the device; lists are short (the prefilter is rare), so a modest
+        // fixed grid is enough and idle workgroups exit at once
+        hipLaunchKernelGGL(scan_kernel<true>, dim3(64), dim3(kScanThreads), lds, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
+    // at least 256 requests per wave so that work-pulling has something to balance; at most two rounds of one
+    // workgroup per CU: long slabs keep the pull queue busy until the very end
     uint32_t waves = (a.n + 255) / 256;
     uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
@@ -299,30 +416,84 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         }
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
 
-        for (uint32_t k = 0; k < a.n_num_atoms; k++) {
-            const NumAtomDev d = a.num_atoms[k];  // wave-uniform
-            bool t = false;
-            switch (d.kind) {
-                case ATOM_LEN: t = cmp_i64((long long)len[d.var < PWAF_N_FIELDS ? d.var : 0], d.op, d.c); break;
-                case ATOM_INT: t = cmp_i64(d.var == VAR_PORT ? (long long)port : (long long)asn, d.op, d.c); break;
-                case ATOM_INTSET: {
-                    const long long v = d.var == VAR_PORT ? (long long)port : (long long)asn;
-                    uint32_t lo = d.ref, hi = d.ref2;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        const long long m = a.int_pool[mid];
-                        if (m < v) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    t = lo < d.ref2 && a.int_pool[lo] == v;
-                    break;
+        // Per-lane membership words, loaded once per request: which ip lists contain the address, which country tables
+        // contain the country. Every IPSET / COUNTRY atom is then a register bit test + one ballot, no memory access.
+        uint32_t ipm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ccm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t ism[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // integer-set membership of remote_port / asn
+        const bool ip_in_regs = a.set_words <= 8, cc_in_regs = a.cc_words <= 8;
+        if (valid) {
+#pragma unroll
+            for (int var = 0; var < 2; var++) {
+                if (a.iu_n[var] == 0) continue;
+                // ONE binary search per request over the union of every set tested against this variable; the hit's row
+                // says which sets contain the value (the reference scans each list per rule: pingoo/lists.rs:119-121)
+                const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
+                uint32_t lo = 0, hi = a.iu_n[var];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.iu_vals[var][mid] < v) lo = mid + 1;
+                    else hi = mid;
                 }
-                case ATOM_IPSET: t = (a.set_masks[(size_t)set_id * a.set_words + (d.ref >> 5)] >> (d.ref & 31)) & 1u; break;
-                case ATOM_COUNTRY: t = (a.country_luts[(size_t)d.ref * 22 + (cidx >> 5)] >> (cidx & 31)) & 1u; break;
-                default: break;
+                const uint32_t row = (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) ? lo + 1 : 0;
+                for (uint32_t wv = 0; wv < a.iu_words[var]; wv++) ism[var][wv] = a.iu_masks[var][(size_t)row * a.iu_words[var] + wv];
             }
-            const unsigned long long m = __ballot(t && valid);
-            if (lane == 0) col[d.col] = m;
+            if (ip_in_regs && a.n_ip_lists)
+                for (uint32_t wv = 0; wv < a.set_words; wv++) ipm[wv] = a.set_masks[(size_t)set_id * a.set_words + wv];
+            if (cc_in_regs)
+                for (uint32_t wv = 0; wv < a.cc_words; wv++) ccm[wv] = a.country_masks[(size_t)cidx * a.cc_words + wv];
+        }
+        // Atom descriptors are fetched 64 at a time (one per lane, coalesced) and broadcast with v_readlane: the
+        // per-atom loop touches no memory besides the LDS column store.
+        for (uint32_t base = 0; base < a.n_num_atoms; base += 64) {
+            uint32_t m_col = 0, m_meta = 0, m_ref = 0, m_clo = 0, m_chi = 0;
+            if (base + lane < a.n_num_atoms) {
+                const NumAtomDev d = a.num_atoms[base + lane];
+                m_col = d.col;
+                m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
+                m_ref = d.ref;
+                m_clo = (uint32_t)(unsigned long long)d.c;
+                m_chi = (uint32_t)((unsigned long long)d.c >> 32);
+            }
+            const uint32_t cntd = min(64u, a.n_num_atoms - base);
+            for (uint32_t j = 0; j < cntd; j++) {
+                const uint32_t meta = __builtin_amdgcn_readlane(m_meta, j), ref = __builtin_amdgcn_readlane(m_ref, j);
+                const uint32_t kind = meta & 0xFFu, var = (meta >> 8) & 0xFFu, op = meta >> 16;
+                bool t = false;
+                if (kind == ATOM_IPSET) {
+                    if (ip_in_regs) {
+                        const uint32_t wsel = ref >> 5;
+                        const uint32_t word = wsel < 4 ? (wsel < 2 ? (wsel == 0 ? ipm[0] : ipm[1]) : (wsel == 2 ? ipm[2] : ipm[3]))
+                                                       : (wsel < 6 ? (wsel == 4 ? ipm[4] : ipm[5]) : (wsel == 6 ? ipm[6] : ipm[7]));
+                        t = (word >> (ref & 31)) & 1u;
+                    } else if (valid) {
+                        t = (a.set_masks[(size_t)set_id * a.set_words + (ref >> 5)] >> (ref & 31)) & 1u;
+                    }
+                } else if (kind == ATOM_COUNTRY) {
+                    if (cc_in_regs) {
+                        const uint32_t wsel = ref >> 5;
+                        const uint32_t word = wsel < 4 ? (wsel < 2 ? (wsel == 0 ? ccm[0] : ccm[1]) : (wsel == 2 ? ccm[2] : ccm[3]))
+                                                       : (wsel < 6 ? (wsel == 4 ? ccm[4] : ccm[5]) : (wsel == 6 ? ccm[6] : ccm[7]));
+                        t = (word >> (ref & 31)) & 1u;
+                    } else if (valid) {
+                        t = (a.country_masks[(size_t)cidx * a.cc_words + (ref >> 5)] >> (ref & 31)) & 1u;
+                    }
+                } else {
+                    const long long c = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_chi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(m_clo, j));
+                    if (kind == ATOM_LEN) {
+                        const uint32_t l = var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4];
+                        t = cmp_i64((long long)l, op, c);
+                    } else if (kind == ATOM_INT) {
+                        t = cmp_i64(var == VAR_PORT ? (long long)port : (long long)asn, op, c);
+                    } else if (kind == ATOM_INTSET) {
+                        const uint32_t wsel = ref >> 5;
+                        const uint32_t w0 = wsel < 2 ? (wsel == 0 ? ism[0][0] : ism[0][1]) : (wsel == 2 ? ism[0][2] : ism[0][3]);
+                        const uint32_t w1 = wsel < 2 ? (wsel == 0 ? ism[1][0] : ism[1][1]) : (wsel == 2 ? ism[1][2] : ism[1][3]);
+                        t = ((var == VAR_PORT ? w0 : w1) >> (ref & 31)) & 1u;
+                    }
+                }
+                const unsigned long long m = __ballot(t && valid);
+                if (lane == 0) col[__builtin_amdgcn_readlane(m_col, j)] = m;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 

@@ -84,6 +84,11 @@ struct DfaGroup {
     uint32_t atom_base = 0;              // first device column of this group
     uint32_t n_local = 0;                // columns owned by this group (= atoms.size())
     std::vector<uint32_t> atoms;         // indices into Program::atoms, local id order
+    // Prefilter gating: when non-empty, a request's field can only match a pattern of this group if at
+    // least one of these columns (owned by EARLIER, ungated groups of the same field) is set, so the pass only needs to
+    // visit those requests.
+    std::vector<uint32_t> filter_atoms;  // indices into Program::atoms
+    std::vector<uint32_t> filter_cols;   // their device columns (filled at layout time)
 };
 static constexpr uint32_t kMaxDfaStates = 32767;   // 15-bit state ids: bit 15 of a table entry flags "target state emits"
 static constexpr uint32_t kMaxLocalAtoms = 32766;  // 15-bit (+1) atom slots in a hit record
@@ -180,6 +185,10 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
 // true when the pattern has an unbounded repetition of a wide byte class (".*", "[^x]*", ...): such patterns multiply DFA
 // states with each other (each adds an independent "prefix seen" bit), so the grouping heuristic isolates them.
 bool has_wide_gap(const RNode &n);
+// For a pattern that is a top-level concatenation X · gap · REST (gap = unbounded repetition of a wide class): returns X
+// without trailing zero-width assertions — every match of the pattern contains a match of X — or null when no useful
+// (non-nullable) prefix exists.
+RNodeP gap_prefilter(const RNodeP &rx);
 // Runs a DFA on the host over `bytes`, returning local atom ids that hold. COMPILE-TIME USE ONLY
 // (folding predicates over the 676 possible country codes into a lookup table).
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms);
