@@ -102,7 +102,7 @@ typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;
     int32_t device;            /* HIP device ordinal, -1 = current device                 */
-    uint32_t lds_table_budget; /* LDS bytes for the hot rows of one DFA table; 0 = default (64 KiB) */
+    uint32_t lds_table_budget; /* LDS bytes for the hot rows of one DFA table; 0 = default (128 KiB) */
     uint32_t max_dfa_states;   /* per DFA group, <= 32767; 0 = default (32767)                       */
     uint32_t max_table_bytes;  /* per DFA group (L2-resident transition table); 0 = default (3 MiB)  */
     uint32_t reserved[2];

@@ -945,7 +945,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     auto prog = std::make_unique<Program>();
     Program &P = *prog;
     P.flags = in.opts.flags;
-    uint32_t lds_budget = in.opts.lds_table_budget ? in.opts.lds_table_budget : 64 * 1024;
+    uint32_t lds_budget = in.opts.lds_table_budget ? in.opts.lds_table_budget : 128 * 1024;
     uint32_t max_states = in.opts.max_dfa_states ? std::min(in.opts.max_dfa_states, kMaxDfaStates) : kMaxDfaStates;
     uint32_t max_table_bytes = in.opts.max_table_bytes ? in.opts.max_table_bytes : 3u << 20;  // L2-resident: 4 MiB per XCD
     if (lds_budget < 1024 || lds_budget > 150 * 1024) {

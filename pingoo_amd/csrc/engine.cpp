@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -85,8 +86,8 @@ struct pwaf_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<DevGroup> groups;
-    DevBuf num_atoms, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
-    uint32_t cc_words = 1;
+    DevBuf num_atoms, bit_atoms, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
+    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0;
     DevBuf iu_vals[2], iu_masks[2];
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
@@ -95,6 +96,7 @@ struct pwaf_engine {
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
     DevBuf colmask, gate_lists;
     uint32_t n_ungated = 0, n_gated = 0;
+    unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // profiling
@@ -123,10 +125,11 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
 
 // Builds the device form of one DFA group: see the cell encoding in kernels.h.
 int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) {
-    const uint32_t C = g.n_classes, stride = C + 2, stride2 = stride * 2;
+    // rows are 4-byte aligned (even number of uint16 cells) so that a row's uint16 index is even: bit 0 of a cell is the
+    // "special" flag and 15 bits of index reach 128 KiB of LDS
+    const uint32_t C = g.n_classes, stride = (C + 2 + 1) & ~1u, stride2 = stride * 2;
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
-    // hot rows + the sentinel row must stay below 64 KiB so that a row's byte offset fits an even uint16
-    const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 65534u);
+    const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 131068u);
     uint32_t n_hot = budget > 2 * stride2 ? (budget - stride2) / stride2 : 1;
     n_hot = std::max(1u, std::min(n_hot, g.n_states));
     std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
@@ -146,7 +149,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
             const uint32_t t = g.trans[(size_t)s * C + c];
             uint16_t cell;
             if (t < n_hot && !emit_id[t]) {
-                cell = (uint16_t)(t * stride2);
+                cell = (uint16_t)(t * stride);  // the row's uint16 index (even)
             } else {
                 if (special_of[t] == 0xFFFFFFFFu) {
                     special_of[t] = (uint32_t)special.size();
@@ -157,7 +160,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
             }
             tab[(size_t)s * stride + c] = cell;
         }
-        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride2) : (uint16_t)1;  // STAY
+        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride) : (uint16_t)1;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
             uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
             if (id1 > 65535) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
@@ -239,6 +242,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             sa.n = n;
             sa.n_passes = e->n_ungated;
             sa.n_gated = e->n_gated;
+            sa.pass_mask = e->select_pass_mask;
             sa.rec = (const uint32_t *)e->rec.p;
             sa.pass_base = (const uint32_t *)e->pass_base.p;
             sa.pool = (const PoolEntry *)e->pool.p;
@@ -300,7 +304,9 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.pass_base = (const uint32_t *)e->pass_base.p;
     v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
-    v.n_num_atoms = (uint32_t)P.num_atoms.size();
+    v.n_num_atoms = e->n_cmp_atoms;
+    v.bit_atoms = (const uint32_t *)e->bit_atoms.p;
+    v.n_bit_atoms = e->n_bit_atoms;
     for (int var = 0; var < 2; var++) {
         v.iu_vals[var] = (const int64_t *)e->iu_vals[var].p;
         v.iu_masks[var] = (const uint32_t *)e->iu_masks[var].p;
@@ -468,6 +474,9 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             e->n_gated++;
         }
         if (e->n_gated == 0) e->n_ungated = (uint32_t)P.groups.size();
+        for (size_t k = 0; k < P.groups.size() && k < 64; k++)
+            for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
+                if (colmask[c]) e->select_pass_mask |= 1ull << k;
         if ((rc = upload(e->colmask, colmask))) return dev_fail(rc);
     }
 #define UP(buf, vec)                                     \
@@ -498,7 +507,25 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             UP(iu_vals[var], vals)
             UP(iu_masks[var], masks)
         }
-        UP(num_atoms, atoms)
+        // split: membership atoms become register bit tests (source word, bit); the rest are comparisons
+        std::vector<NumAtomDev> cmp_atoms;
+        std::vector<uint32_t> bit_atoms;
+        if (P.n_cols >= (1u << 20)) { fail(PWAF_E_UNSUPPORTED, "more than 2^20 predicate columns"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        if (P.set_words > 8) { fail(PWAF_E_UNSUPPORTED, "more than 256 ip lists"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        if (P.country_luts.size() > 256) { fail(PWAF_E_UNSUPPORTED, "more than 256 distinct client.country predicates"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        for (auto &d : atoms) {
+            uint32_t src;
+            if (d.kind == ATOM_IPSET) src = d.ref >> 5;
+            else if (d.kind == ATOM_COUNTRY) src = 8 + (d.ref >> 5);
+            else if (d.kind == ATOM_INTSET) src = 16 + 4 * d.var + (d.ref >> 5);
+            else { cmp_atoms.push_back(d); continue; }
+            bit_atoms.push_back(d.col | ((d.ref & 31u) << 20) | (src << 25));
+        }
+        std::sort(bit_atoms.begin(), bit_atoms.end(), [](uint32_t x, uint32_t y) { return (x >> 25) != (y >> 25) ? (x >> 25) < (y >> 25) : x < y; });
+        e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
+        e->n_bit_atoms = (uint32_t)bit_atoms.size();
+        UP(num_atoms, cmp_atoms)
+        UP(bit_atoms, bit_atoms)
     }
     {
         // transpose the per-predicate 676-bit country tables into per-country membership words (one gather per request)
@@ -529,7 +556,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
-    for (DevBuf *b : {&e->num_atoms, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
+    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
                       &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();

@@ -54,6 +54,7 @@ struct ScanArgs {
 // select_kernel: builds the request lists of the gated passes from the ungated passes' hit records
 struct SelectArgs {
     uint32_t n, n_passes /* ungated */, n_gated;
+    unsigned long long pass_mask;  // ungated passes that own at least one prefilter factor column
     const uint32_t *rec;        // [n_passes][n]
     const uint32_t *pass_base;
     const PoolEntry *pool;
@@ -78,8 +79,10 @@ struct VerdictArgs {
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;
-    const NumAtomDev *num_atoms;
+    const NumAtomDev *num_atoms;  // comparison atoms only (LEN / INT)
     uint32_t n_num_atoms;
+    const uint32_t *bit_atoms;    // column | bit << 20 | source word << 25, sorted by source word
+    uint32_t n_bit_atoms;
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
     const uint32_t *iu_masks[2];

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t stride2 = a.stride * 2;
     const uint32_t hot_bytes = a.n_hot * stride2;            // sentinel row starts here
+    const uint32_t hot_elems = hot_bytes >> 1;
     const uint32_t tab_bytes = (hot_bytes + stride2 + 15) & ~15u;
     const PWAF_LDS unsigned char *ltab = (const PWAF_LDS unsigned char *)lds;
     // 256 x uint32: 2 * byte class (a byte offset inside a row). One dword per byte value: bytes that differ by less than
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     // already in flight in `wn` — either the next chunk of the same field or, when this is the field's last chunk, the
     // first chunk of the request the lane has just pulled (r2/p2/end2). HBM/L2 latency hides behind 16 DFA steps.
     uint32_t r = kNone, p = 0, end = 0;           // current request
-    uint32_t row = 0;                             // LDS byte offset of the current row (== hot_bytes: parked, row is cold)
+    uint32_t row = 0;                             // current row as a CELL value: its uint16 index in LDS, always even
+                                                  // (== hot_elems: parked on the sentinel row, the real row is cold)
     uint32_t crow = 0;                            // byte offset of the current row in the full table while cold
     uint32_t r2 = kNone, p2 = 0, end2 = 0;        // request pulled ahead
     Hits h{0, 0, kNone};
@@ -194,17 +196,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t prev = row;
-            row = *reinterpret_cast<lds_u16_ptr>(ltab + prev + c2[k]);  // even: the next row's LDS offset — done
+            row = *reinterpret_cast<lds_u16_ptr>(ltab + ((prev << 1) + c2[k]));  // even: the next row's cell — done
             if (row & 1u) {
                 // rare: the target row is cold and/or emits, or this lane is parked on the sentinel row (current row cold)
                 uint32_t cell = row;
                 row = prev;
                 if ((uint32_t)k < cnt) {
-                    if (prev == hot_bytes) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
+                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
                     if (cell & 1u) {
                         const SpecialCell sp = a.special[cell >> 1];
-                        if (sp.next_off < hot_bytes) row = sp.next_off;
-                        else { row = hot_bytes; crow = sp.next_off; }
+                        if (sp.next_off < hot_bytes) row = sp.next_off >> 1;
+                        else { row = hot_elems; crow = sp.next_off; }
                         if (sp.emit) emit_list(a, sp.emit - 1, h);
                     } else {
                         row = cell;
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
 
         // ---- 3. finished requests: end-of-field matches, the hit record, then switch to the pulled-ahead request ----
         if (r != kNone && p >= end) {
-            const uint32_t e = row == hot_bytes ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + end_col2)
-                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + row + end_col2);
+            const uint32_t e = row == hot_elems ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + end_col2)
+                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + ((row << 1) + end_col2));
             if (e) emit_list(a, e - 1, h);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             r = kNone;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         uint32_t need = 0;
         if (i < a.n) {
             for (uint32_t ps = 0; ps < a.n_passes; ps++) {
+                if (!((a.pass_mask >> ps) & 1ull)) continue;  // this pass owns no prefilter factor
                 const uint32_t rv = a.rec[(size_t)ps * a.n + i];
                 if (rv == 0) continue;
                 const uint32_t cb = a.pass_base[ps];
@@ -416,11 +419,12 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         }
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
 
-        // Per-lane membership words, loaded once per request: which ip lists contain the address, which country tables
-        // contain the country. Every IPSET / COUNTRY atom is then a register bit test + one ballot, no memory access.
-        uint32_t ipm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ccm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t ism[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // integer-set membership of remote_port / asn
-        const bool ip_in_regs = a.set_words <= 8, cc_in_regs = a.cc_words <= 8;
+        // Per-lane membership words, loaded once per request: which ip lists contain the address (srcw[0..8)), which country
+        // tables contain the country (srcw[8..16)), which integer sets contain remote_port / asn (srcw[16..20) / [20..24)).
+        // Every IPSET / COUNTRY / INTSET atom is then a register bit test + one ballot — no memory access per atom.
+        uint32_t srcw[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) srcw[k] = 0;
         if (valid) {
 #pragma unroll
             for (int var = 0; var < 2; var++) {
@@ -435,65 +439,65 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                     else hi = mid;
                 }
                 const uint32_t row = (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) ? lo + 1 : 0;
-                for (uint32_t wv = 0; wv < a.iu_words[var]; wv++) ism[var][wv] = a.iu_masks[var][(size_t)row * a.iu_words[var] + wv];
+#pragma unroll
+                for (int wv = 0; wv < 4; wv++)
+                    if ((uint32_t)wv < a.iu_words[var]) srcw[16 + 4 * var + wv] = a.iu_masks[var][(size_t)row * a.iu_words[var] + wv];
             }
-            if (ip_in_regs && a.n_ip_lists)
-                for (uint32_t wv = 0; wv < a.set_words; wv++) ipm[wv] = a.set_masks[(size_t)set_id * a.set_words + wv];
-            if (cc_in_regs)
-                for (uint32_t wv = 0; wv < a.cc_words; wv++) ccm[wv] = a.country_masks[(size_t)cidx * a.cc_words + wv];
+#pragma unroll
+            for (int wv = 0; wv < 8; wv++) {
+                if ((uint32_t)wv < a.set_words && a.n_ip_lists) srcw[wv] = a.set_masks[(size_t)set_id * a.set_words + wv];
+                if ((uint32_t)wv < a.cc_words) srcw[8 + wv] = a.country_masks[(size_t)cidx * a.cc_words + wv];
+            }
         }
-        // Atom descriptors are fetched 64 at a time (one per lane, coalesced) and broadcast with v_readlane: the
-        // per-atom loop touches no memory besides the LDS column store.
+        // 3a. bit atoms. Descriptors (column | bit << 20 | source word << 25, sorted by source word) are fetched 64 at a time,
+        // one per lane, and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, so the
+        // 64 column words of a chunk leave in ONE ds_write_b64.
+        {
+            uint32_t cur_src = 0xFFFFFFFFu, curw = 0;
+            for (uint32_t base = 0; base < a.n_bit_atoms; base += 64) {
+                const uint32_t mine = base + lane < a.n_bit_atoms ? a.bit_atoms[base + lane] : 0u;
+                const uint32_t cntd = min(64u, a.n_bit_atoms - base);
+                uint32_t acc_lo = 0, acc_hi = 0;
+                for (uint32_t j = 0; j < cntd; j++) {
+                    const uint32_t d = __builtin_amdgcn_readlane(mine, j);
+                    const uint32_t src = d >> 25;
+                    if (src != cur_src) {  // wave-uniform, taken once per run of atoms on the same source word
+                        cur_src = src;
+                        curw = 0;
+#pragma unroll
+                        for (int k = 0; k < 24; k++) curw = src == (uint32_t)k ? srcw[k] : curw;
+                    }
+                    const unsigned long long m = __ballot((curw >> ((d >> 20) & 31u)) & 1u);
+                    acc_lo = lane == j ? (uint32_t)m : acc_lo;  // park atom j's ballot in lane j
+                    acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
+                }
+                if (lane < cntd) col[mine & 0xFFFFFu] = ((unsigned long long)acc_hi << 32) | acc_lo;
+            }
+        }
+        // 3b. comparison atoms (lengths, port, asn against constants): few; same descriptor broadcast
         for (uint32_t base = 0; base < a.n_num_atoms; base += 64) {
-            uint32_t m_col = 0, m_meta = 0, m_ref = 0, m_clo = 0, m_chi = 0;
+            uint32_t m_col = 0, m_meta = 0, m_clo = 0, m_chi = 0;
             if (base + lane < a.n_num_atoms) {
                 const NumAtomDev d = a.num_atoms[base + lane];
                 m_col = d.col;
                 m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
-                m_ref = d.ref;
                 m_clo = (uint32_t)(unsigned long long)d.c;
                 m_chi = (uint32_t)((unsigned long long)d.c >> 32);
             }
             const uint32_t cntd = min(64u, a.n_num_atoms - base);
+            uint32_t acc_lo = 0, acc_hi = 0;
             for (uint32_t j = 0; j < cntd; j++) {
-                const uint32_t meta = __builtin_amdgcn_readlane(m_meta, j), ref = __builtin_amdgcn_readlane(m_ref, j);
+                const uint32_t meta = __builtin_amdgcn_readlane(m_meta, j);
                 const uint32_t kind = meta & 0xFFu, var = (meta >> 8) & 0xFFu, op = meta >> 16;
-                bool t = false;
-                if (kind == ATOM_IPSET) {
-                    if (ip_in_regs) {
-                        const uint32_t wsel = ref >> 5;
-                        const uint32_t word = wsel < 4 ? (wsel < 2 ? (wsel == 0 ? ipm[0] : ipm[1]) : (wsel == 2 ? ipm[2] : ipm[3]))
-                                                       : (wsel < 6 ? (wsel == 4 ? ipm[4] : ipm[5]) : (wsel == 6 ? ipm[6] : ipm[7]));
-                        t = (word >> (ref & 31)) & 1u;
-                    } else if (valid) {
-                        t = (a.set_masks[(size_t)set_id * a.set_words + (ref >> 5)] >> (ref & 31)) & 1u;
-                    }
-                } else if (kind == ATOM_COUNTRY) {
-                    if (cc_in_regs) {
-                        const uint32_t wsel = ref >> 5;
-                        const uint32_t word = wsel < 4 ? (wsel < 2 ? (wsel == 0 ? ccm[0] : ccm[1]) : (wsel == 2 ? ccm[2] : ccm[3]))
-                                                       : (wsel < 6 ? (wsel == 4 ? ccm[4] : ccm[5]) : (wsel == 6 ? ccm[6] : ccm[7]));
-                        t = (word >> (ref & 31)) & 1u;
-                    } else if (valid) {
-                        t = (a.country_masks[(size_t)cidx * a.cc_words + (ref >> 5)] >> (ref & 31)) & 1u;
-                    }
-                } else {
-                    const long long c = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_chi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(m_clo, j));
-                    if (kind == ATOM_LEN) {
-                        const uint32_t l = var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4];
-                        t = cmp_i64((long long)l, op, c);
-                    } else if (kind == ATOM_INT) {
-                        t = cmp_i64(var == VAR_PORT ? (long long)port : (long long)asn, op, c);
-                    } else if (kind == ATOM_INTSET) {
-                        const uint32_t wsel = ref >> 5;
-                        const uint32_t w0 = wsel < 2 ? (wsel == 0 ? ism[0][0] : ism[0][1]) : (wsel == 2 ? ism[0][2] : ism[0][3]);
-                        const uint32_t w1 = wsel < 2 ? (wsel == 0 ? ism[1][0] : ism[1][1]) : (wsel == 2 ? ism[1][2] : ism[1][3]);
-                        t = ((var == VAR_PORT ? w0 : w1) >> (ref & 31)) & 1u;
-                    }
-                }
-                const unsigned long long m = __ballot(t && valid);
-                if (lane == 0) col[__builtin_amdgcn_readlane(m_col, j)] = m;
+                const long long c = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_chi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(m_clo, j));
+                long long v;
+                if (kind == ATOM_LEN) v = (long long)(var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4]);
+                else v = var == VAR_PORT ? (long long)port : (long long)asn;
+                const unsigned long long m = __ballot(cmp_i64(v, op, c) && valid);
+                acc_lo = lane == j ? (uint32_t)m : acc_lo;
+                acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
             }
+            if (lane < cntd) col[m_col] = ((unsigned long long)acc_hi << 32) | acc_lo;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
