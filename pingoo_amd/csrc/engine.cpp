@@ -74,7 +74,7 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 
 struct DevGroup {
     DevBuf tab, classmap, special, list_off, list;
-    uint32_t n_states, stride, n_classes, n_hot, start_emit, atom_base;
+    uint32_t n_states, stride, n_classes, n_hot, start_emit, special_base, atom_base;
     uint8_t field;
     int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
 };
@@ -125,14 +125,8 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
 
 // Builds the device form of one DFA group: see the cell encoding in kernels.h.
 int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) {
-    // rows are 4-byte aligned (even number of uint16 cells) so that a row's uint16 index is even: bit 0 of a cell is the
-    // "special" flag and 15 bits of index reach 128 KiB of LDS
-    const uint32_t C = g.n_classes, stride = (C + 2 + 1) & ~1u, stride2 = stride * 2;
+    const uint32_t C = g.n_classes, stride = C + 2, stride2 = stride * 2;
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
-    const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 131068u);
-    uint32_t n_hot = budget > 2 * stride2 ? (budget - stride2) / stride2 : 1;
-    n_hot = std::max(1u, std::min(n_hot, g.n_states));
-    std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
     std::vector<uint32_t> list_off{0};
     std::vector<uint16_t> list;
     auto add_list = [&](const std::vector<uint16_t> &src, uint32_t b, uint32_t e) -> uint32_t {
@@ -140,27 +134,40 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
         list_off.push_back((uint32_t)list.size());
         return (uint32_t)list_off.size() - 1;  // 1 + id
     };
-    std::vector<uint32_t> emit_id(g.n_states, 0), special_of(g.n_states, 0xFFFFFFFFu);
+    std::vector<uint32_t> emit_id(g.n_states, 0);
     for (uint32_t s = 0; s < g.n_states; s++)
         if (g.emit_off[s + 1] > g.emit_off[s]) emit_id[s] = add_list(g.emit_list, g.emit_off[s], g.emit_off[s + 1]);
+    // Cell value space (uint16): [0, (n_hot+1)*stride) addresses hot rows + the sentinel row, the rest indexes `special` (one
+    // entry per target state that is cold or emits). Shrink the hot set until both fit.
+    const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 131070u);
+    uint32_t n_hot = budget > 2 * stride2 ? (budget - stride2) / stride2 : 1;
+    n_hot = std::max(1u, std::min(n_hot, g.n_states));
+    std::vector<uint32_t> special_of;
     std::vector<SpecialCell> special;
+    for (;;) {
+        special_of.assign(g.n_states, 0xFFFFFFFFu);
+        special.clear();
+        for (uint32_t t = 0; t < g.n_states; t++) {
+            if (t < n_hot && !emit_id[t]) continue;
+            special_of[t] = (uint32_t)special.size();  // (targets nobody points to cost a slot each: negligible)
+            special.push_back({t * stride2, emit_id[t]});
+        }
+        const uint64_t need = (uint64_t)(n_hot + 1) * stride + special.size();
+        if (need <= 65535 || n_hot == 1) {
+            if (need > 65535) return fail(PWAF_E_UNSUPPORTED, "DFA too large for the 16-bit cell space");
+            break;
+        }
+        const uint32_t over = (uint32_t)(need - 65535);
+        n_hot = std::max(1u, n_hot - std::max(1u, over / stride + 1));  // every evicted row frees `stride` cells and may add one special
+    }
+    const uint32_t special_base = (n_hot + 1) * stride;
+    std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
     for (uint32_t s = 0; s < g.n_states; s++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t t = g.trans[(size_t)s * C + c];
-            uint16_t cell;
-            if (t < n_hot && !emit_id[t]) {
-                cell = (uint16_t)(t * stride);  // the row's uint16 index (even)
-            } else {
-                if (special_of[t] == 0xFFFFFFFFu) {
-                    special_of[t] = (uint32_t)special.size();
-                    special.push_back({t * stride2, emit_id[t]});
-                }
-                if (special_of[t] > 32767) return fail(PWAF_E_UNSUPPORTED, "too many cold/emitting states in one DFA group");
-                cell = (uint16_t)((special_of[t] << 1) | 1u);
-            }
-            tab[(size_t)s * stride + c] = cell;
+            tab[(size_t)s * stride + c] = special_of[t] == 0xFFFFFFFFu ? (uint16_t)(t * stride) : (uint16_t)(special_base + special_of[t]);
         }
-        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride) : (uint16_t)1;  // STAY
+        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride) : (uint16_t)0xFFFF;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
             uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
             if (id1 > 65535) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
@@ -173,6 +180,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
     d.n_classes = C;
     d.n_hot = n_hot;
     d.start_emit = emit_id[0];
+    d.special_base = special_base;
     d.atom_base = g.atom_base;
     d.field = g.field;
     int rc;
@@ -271,6 +279,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.list_off = (const uint32_t *)d.list_off.p;
         a.list = (const uint16_t *)d.list.p;
         a.start_emit = d.start_emit;
+        a.special_base = d.special_base;
         a.n_states = d.n_states;
         a.stride = d.stride;
         a.n_classes = d.n_classes;

@@ -17,15 +17,16 @@ struct PoolEntry {
     uint32_t next;  // 0xFFFFFFFF = end of chain
 };
 
-// Device table of one DFA group. n_states rows of stride = n_classes + 2 uint16, row r at byte offset
-// r * stride * 2 (rows are in BFS order; rows [0, n_hot) are copied into LDS, followed by one SENTINEL row of all-ones):
+// Device table of one DFA group. n_states rows of `stride` uint16 cells, row r starting at cell index
+// r * stride (rows are in BFS order; rows [0, n_hot) are copied into LDS, followed by one SENTINEL row of 0xFFFF cells):
 //   [0, n_classes)   transition cell        [n_classes]  STAY cell (= own row, used for lanes past their last byte)
 //   [n_classes + 1]  1 + end-list id (0 = none)
-// A transition cell is EVEN  -> byte offset of the next row, which is hot and has nothing to emit  (the common case:
-//                               next lookup address = cell + class offset, no multiply, no compare)
-//                      ODD   -> (index << 1) | 1 into `special`: the target row is cold and/or has an emit list.
-// A lane whose current row is cold parks on the sentinel row, whose cells are all odd, so the same bit-0 test routes it
-// to the slow path that reads the real row from the L2-resident table.
+// A transition cell c <  special_base -> cell index of the next row, which is hot and has nothing to emit (the common case:
+//                                        next lookup address = (c + class) * 2: one add-shift, one compare)
+//                   c >= special_base -> index c - special_base into `special`: the target row is cold and/or has an emit
+//                                        list. special_base = (n_hot + 1) * stride, just past the sentinel row.
+// A lane whose current row is cold parks on the sentinel row, whose cells are all 0xFFFF, so the same compare routes it to
+// the slow path that reads the real row from the L2-resident table.
 struct SpecialCell {
     uint32_t next_off;  // byte offset of the target row in the full table
     uint32_t emit;      // 1 + emit-list id, 0 = none
@@ -41,6 +42,7 @@ struct ScanArgs {
     const uint16_t *list;     // local atom ids
     uint32_t n_states, stride, n_classes, n_hot;
     uint32_t start_emit;      // 1 + emit-list id of the start state
+    uint32_t special_base;
     uint32_t *rec;            // n hit records of this pass
     PoolEntry *pool;
     uint32_t *pool_count;     // atomic allocator

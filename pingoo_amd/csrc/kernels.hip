@@ -37,6 +37,8 @@ static constexpr uint32_t kNone = 0xFFFFFFFFu;
 typedef const PWAF_LDS uint16_t *lds_u16_ptr;
 typedef const PWAF_GLOBAL uint16_t *glb_u16_ptr;
 typedef const PWAF_LDS uint32_t *lds_u32_ptr;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // 16 bytes at any byte address (gfx950 global loads need no alignment)
 
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + 1024; }
 uint32_t verdict_lds_bytes(uint32_t n_cols) { return kVerdictWaves * n_cols * 8; }
@@ -49,40 +51,57 @@ struct Hits {
     uint32_t ovf;     // head of the overflow chain, kNone = not overflowed
 };
 
-__device__ __noinline__ void pool_push(const ScanArgs &a, uint32_t atom, Hits &h) {
-    const uint32_t idx = atomicAdd(a.pool_count, 1u);
-    if (idx >= a.pool_cap) {
-        atomicOr(a.status, 1u);
-        return;
+// The slow path is ONE out-of-line function that takes and returns the per-request hit state BY VALUE: passing `Hits` or the
+// kernel arguments by reference would pin them in scratch memory, and every scratch access in the main loop is a vector
+// memory operation whose s_waitcnt vmcnt(0) also drains the prefetched chunk (measured: 5 us per iteration).
+struct SlowCtx {
+    const uint32_t *list_off;
+    const uint16_t *list;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t *status;
+    uint32_t pool_cap;
+};
+
+__device__ __forceinline__ Hits pool_push(const SlowCtx &c, uint32_t atom, Hits h) {
+    const uint32_t idx = atomicAdd(c.pool_count, 1u);
+    if (idx >= c.pool_cap) {
+        atomicOr(c.status, 1u);
+        return h;
     }
-    a.pool[idx].atom = atom;
-    a.pool[idx].next = h.ovf;
+    c.pool[idx].atom = atom;
+    c.pool[idx].next = h.ovf;
     h.ovf = idx;
+    return h;
 }
 
-__device__ __noinline__ void record_atom(const ScanArgs &a, uint32_t atom, Hits &h) {
+__device__ __forceinline__ Hits record_atom(const SlowCtx &c, uint32_t atom, Hits h) {
     if (h.ovf == kNone) {
-        if (h.a0 == atom + 1 || h.a1 == atom + 1) return;
-        if (h.a0 == 0) { h.a0 = atom + 1; return; }
-        if (h.a1 == 0) { h.a1 = atom + 1; return; }
-        pool_push(a, h.a0 - 1, h);
-        pool_push(a, h.a1 - 1, h);
-        pool_push(a, atom, h);
-        return;
+        if (h.a0 == atom + 1 || h.a1 == atom + 1) return h;
+        if (h.a0 == 0) { h.a0 = atom + 1; return h; }
+        if (h.a1 == 0) { h.a1 = atom + 1; return h; }
+        const uint32_t x0 = h.a0 - 1, x1 = h.a1 - 1;
+        h = pool_push(c, x0, h);
+        h = pool_push(c, x1, h);
+        return pool_push(c, atom, h);
     }
     // overflowed: the chain holds every atom of this request; de-duplicate against it (this lane is its only writer)
     for (uint32_t i = h.ovf; i != kNone;) {
-        const uint32_t at = __hip_atomic_load(&a.pool[i].atom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (at == atom) return;
-        i = __hip_atomic_load(&a.pool[i].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t at = __hip_atomic_load(&c.pool[i].atom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at == atom) return h;
+        i = __hip_atomic_load(&c.pool[i].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    pool_push(a, atom, h);
+    return pool_push(c, atom, h);
 }
 
-__device__ __forceinline__ void emit_list(const ScanArgs &a, uint32_t id, Hits &h) {
-    const uint32_t b = a.list_off[id], e = a.list_off[id + 1];
-    for (uint32_t k = b; k < e; k++) record_atom(a, a.list[k], h);
+__device__ __noinline__ Hits emit_list(const uint32_t *list_off, const uint16_t *list, PoolEntry *pool, uint32_t *pool_count, uint32_t *status,
+                                       uint32_t pool_cap, uint32_t id, Hits h) {
+    const SlowCtx c{list_off, list, pool, pool_count, status, pool_cap};
+    const uint32_t b = list_off[id], e = list_off[id + 1];
+    for (uint32_t k = b; k < e; k++) h = record_atom(c, list[k], h);
+    return h;
 }
+#define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
 
 template <bool INDIRECT>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
@@ -92,15 +111,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     const uint32_t hot_elems = hot_bytes >> 1;
     const uint32_t tab_bytes = (hot_bytes + stride2 + 15) & ~15u;
     const PWAF_LDS unsigned char *ltab = (const PWAF_LDS unsigned char *)lds;
-    // 256 x uint32: 2 * byte class (a byte offset inside a row). One dword per byte value: bytes that differ by less than
+    // 256 x uint32: byte class (the cell index inside a row). One dword per byte value: bytes that differ by less than
     // 32 never share an LDS bank, so lower-case text (the bulk of URLs) reads it conflict-free.
     lds_u32_ptr cls2 = (lds_u32_ptr)(lds + tab_bytes);
     const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
+    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
+    const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     // stage the hot rows, the sentinel row and the byte-class map into LDS (coalesced 16 B per lane)
     for (uint32_t i = tid * 16; i < tab_bytes; i += kScanThreads * 16) {
-        uint4 v = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);  // sentinel cells: odd
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // sentinel cells: "special"
         if (i + 16 <= hot_bytes) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.tab) + i);
         *reinterpret_cast<uint4 *>(lds + i) = v;
     }
@@ -109,10 +130,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         const uint32_t base = hot_bytes & ~15u;
         if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + base)[tid] = a.tab[base / 2 + tid];
     }
-    if (tid < 256) reinterpret_cast<uint32_t *>(lds + tab_bytes)[tid] = 2u * a.classmap[tid];
+    if (tid < 256) reinterpret_cast<uint32_t *>(lds + tab_bytes)[tid] = a.classmap[tid];
     __syncthreads();
 
-    const uint32_t stay2 = a.n_classes * 2, end_col2 = a.n_classes * 2 + 2;
+    const uint32_t stay_col = a.n_classes, end_col = a.n_classes + 1;
+    const uint32_t special_base = a.special_base;  // cells >= special_base index the special table
     // this wave's slab of work items: contiguous, 64-aligned so offset blocks are whole. A work item is request i, or —
     // for a gated pass — entry i of the list of requests whose prefilter fired (its length lives on the device).
     const uint32_t n_items = INDIRECT ? min(*a.n_list, a.n) : a.n;
@@ -131,8 +153,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         uint32_t i = min(base + lane, n_items - 1);  // base + lane < n_items + 63; clamp keeps the load in bounds
         if (INDIRECT) i = a.req_list[i];
         id = i;
-        lo = a.off[i];
-        hi = a.off[i + 1];
+        lo = goff[i];
+        hi = goff[i + 1];
     };
     uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0;
     load_off(blk, o_lo, o_hi, o_id);
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     uint32_t crow = 0;                            // byte offset of the current row in the full table while cold
     uint32_t r2 = kNone, p2 = 0, end2 = 0;        // request pulled ahead
     Hits h{0, 0, kNone};
-    uint4 w = make_uint4(0, 0, 0, 0), wn = make_uint4(0, 0, 0, 0);
+    u32x4 w = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
 
     for (;;) {
         // ---- 1. pull ahead: lanes on their last chunk (or idle) take the next request of the slab ----
@@ -178,9 +200,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         }
         if (__ballot(r != kNone || r2 != kNone) == 0) break;
         {
-            const uint32_t np = last ? p2 : p + 16;
+            // Unconditional (no branch, so no wait is forced here): lanes with nothing to fetch read the arena's first bytes.
+            // Unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack.
             const bool have = last ? (r2 != kNone && p2 < end2) : true;
-            if (have) __builtin_memcpy(&wn, a.data + np, 16);  // unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack
+            const uint32_t np = have ? (last ? p2 : p + 16) : 0u;
+            wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + np);
         }
 
         // ---- 2. 16 bytes of every active lane's field ----
@@ -191,23 +215,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t c = cls2[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];  // byte classes do not depend on the state
-            c2[k] = (uint32_t)k < cnt ? c : stay2;                            // past the end: the STAY column
+            c2[k] = (uint32_t)k < cnt ? c : stay_col;                         // past the end: the STAY column
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t prev = row;
-            row = *reinterpret_cast<lds_u16_ptr>(ltab + ((prev << 1) + c2[k]));  // even: the next row's cell — done
-            if (row & 1u) {
+            row = *reinterpret_cast<lds_u16_ptr>(ltab + ((prev + c2[k]) << 1));  // below special_base: the next row's cell — done
+            if (row >= special_base) {
                 // rare: the target row is cold and/or emits, or this lane is parked on the sentinel row (current row cold)
                 uint32_t cell = row;
                 row = prev;
                 if ((uint32_t)k < cnt) {
-                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
-                    if (cell & 1u) {
-                        const SpecialCell sp = a.special[cell >> 1];
+                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + (c2[k] << 1));  // the real row, from L2
+                    if (cell >= special_base) {
+                        const SpecialCell sp = a.special[cell - special_base];
                         if (sp.next_off < hot_bytes) row = sp.next_off >> 1;
                         else { row = hot_elems; crow = sp.next_off; }
-                        if (sp.emit) emit_list(a, sp.emit - 1, h);
+                        if (sp.emit) PWAF_EMIT(sp.emit - 1);
                     } else {
                         row = cell;
                     }
@@ -218,9 +242,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
 
         // ---- 3. finished requests: end-of-field matches, the hit record, then switch to the pulled-ahead request ----
         if (r != kNone && p >= end) {
-            const uint32_t e = row == hot_elems ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + end_col2)
-                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + ((row << 1) + end_col2));
-            if (e) emit_list(a, e - 1, h);
+            const uint32_t e = row == hot_elems ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + (end_col << 1))
+                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + ((row + end_col) << 1));
+            if (e) PWAF_EMIT(e - 1);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             r = kNone;
         }
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
             r2 = kNone;
             row = 0;
             h = Hits{0, 0, kNone};
-            if (start_emit) emit_list(a, start_emit - 1, h);
+            if (start_emit) PWAF_EMIT(start_emit - 1);
         }
         w = wn;
     }
