@@ -241,34 +241,20 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         return PWAF_OK;
     };
 
-    bool selected = false;
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
         DevGroup &d = e->groups[gi];
-        if (d.gate >= 0 && !selected) {
-            // all ungated passes are enqueued: find the requests the gated passes have to visit
-            SelectArgs sa{};
-            sa.n = n;
-            sa.n_passes = e->n_ungated;
-            sa.n_gated = e->n_gated;
-            sa.pass_mask = e->select_pass_mask;
-            sa.rec = (const uint32_t *)e->rec.p;
-            sa.pass_base = (const uint32_t *)e->pass_base.p;
-            sa.pool = (const PoolEntry *)e->pool.p;
-            sa.colmask = (const uint32_t *)e->colmask.p;
-            sa.lists = (uint32_t *)e->gate_lists.p;
-            sa.list_count = (uint32_t *)e->ctrl.p + 2;
-            if ((rc = mark(nullptr, 0))) return rc;
-            int he = launch_select(sa, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("select kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc = mark("select", 0xFEu))) return rc;
-            selected = true;
-        }
         ScanArgs a{};
         if (d.gate >= 0) {
             // records of requests the pass does not visit must read "nothing matched"
             HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + gi * (size_t)n, 0, (size_t)n * 4, stream));
             a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
             a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
+        }
+        if (d.gate < 0 && e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+            // this pass owns prefilter factors: it feeds the gated passes' request lists as requests finish
+            a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
+            a.gate_lists = (uint32_t *)e->gate_lists.p;
+            a.gate_count = (uint32_t *)e->ctrl.p + 2;
         }
         a.data = db.field[d.field].data;
         a.off = db.field[d.field].offsets;

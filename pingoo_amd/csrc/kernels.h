@@ -48,6 +48,10 @@ struct ScanArgs {
     uint32_t *pool_count;     // atomic allocator
     uint32_t pool_cap;
     uint32_t *status;         // device status word: bit 0 = overflow pool exhausted
+    // a pass that owns prefilter factors (else null): per local atom, the bitmask of gated passes it triggers, and their lists
+    const uint32_t *colmask_local;
+    uint32_t *gate_lists;     // [n_gated][n]
+    uint32_t *gate_count;     // [n_gated], zeroed by the host per batch
     // gated pass only (else null): the requests to visit and, on the device, how many
     const uint32_t *req_list;
     const uint32_t *n_list;

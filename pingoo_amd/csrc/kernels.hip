@@ -101,6 +101,27 @@ __device__ __noinline__ Hits emit_list(const uint32_t *list_off, const uint16_t 
     for (uint32_t k = b; k < e; k++) h = record_atom(c, list[k], h);
     return h;
 }
+// A finished request whose hits include prefilter factors is appended to the lists of the gated passes those factors guard
+// (rare: one atomic per request and gated pass).
+__device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const PoolEntry *pool, uint32_t *gate_lists, uint32_t *gate_count, uint32_t n,
+                                           uint32_t r, Hits h) {
+    uint32_t need = 0;
+    if (h.ovf != kNone) {
+        for (uint32_t i = h.ovf; i != kNone;) {
+            need |= colmask_local[__hip_atomic_load(&pool[i].atom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+            i = __hip_atomic_load(&pool[i].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (h.a0) need |= colmask_local[h.a0 - 1];
+        if (h.a1) need |= colmask_local[h.a1 - 1];
+    }
+    while (need) {
+        const uint32_t g = (uint32_t)__builtin_ctz(need);
+        need &= need - 1;
+        gate_lists[(size_t)g * n + atomicAdd(&gate_count[g], 1u)] = r;
+    }
+}
+
 #define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
 
 template <bool INDIRECT>
@@ -156,10 +177,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         lo = goff[i];
         hi = goff[i + 1];
     };
-    uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0;
+    uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0, n_base = kNone;
     load_off(blk, o_lo, o_hi, o_id);
-    if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi, n_id);
-
     // Software pipeline: while a lane chews on the 16 bytes in `w`, the 16 bytes it will need in the NEXT iteration are
     // already in flight in `wn` — either the next chunk of the same field or, when this is the field's last chunk, the
     // first chunk of the request the lane has just pulled (r2/p2/end2). HBM/L2 latency hides behind 16 DFA steps.
@@ -172,6 +191,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     u32x4 w = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
 
     for (;;) {
+        // offsets of the NEXT block of 64 work items: re-requested every iteration (L1 hits) instead of once per block inside a
+        // branch, because a load whose result crosses a branch merge forces an immediate s_waitcnt vmcnt(0) — which would
+        // also drain the chunk prefetch
+        uint32_t f_lo, f_hi, f_id;
+        const uint32_t f_base = blk + 64;
+        load_off(f_base, f_lo, f_hi, f_id);
         // ---- 1. pull ahead: lanes on their last chunk (or idle) take the next request of the slab ----
         const bool last = r == kNone || p + 16 >= end;
         const unsigned long long want = __ballot(last && r2 == kNone);
@@ -192,10 +217,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
             next += min((uint32_t)__builtin_popcountll(want), avail);
             if (next == blk + 64 && next < w1) {
                 blk += 64;
-                o_lo = n_lo;
-                o_hi = n_hi;
-                o_id = n_id;
-                if (blk + 64 < w1) load_off(blk + 64, n_lo, n_hi, n_id);
+                if (n_base == blk) {  // requested during an earlier iteration for this very block
+                    o_lo = n_lo;
+                    o_hi = n_hi;
+                    o_id = n_id;
+                } else {              // two block switches in consecutive iterations (very short fields): fetch now
+                    load_off(blk, o_lo, o_hi, o_id);
+                }
             }
         }
         if (__ballot(r != kNone || r2 != kNone) == 0) break;
@@ -246,6 +274,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
                                                 : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + ((row + end_col) << 1));
             if (e) PWAF_EMIT(e - 1);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+            if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) enqueue_gated(a.colmask_local, a.pool, a.gate_lists, a.gate_count, a.n, r, h);
             r = kNone;
         }
         if (r == kNone && r2 != kNone) {
@@ -258,6 +287,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
             if (start_emit) PWAF_EMIT(start_emit - 1);
         }
         w = wn;
+        n_lo = f_lo;
+        n_hi = f_hi;
+        n_id = f_id;
+        n_base = f_base;
     }
 }
 
