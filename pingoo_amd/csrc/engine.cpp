@@ -86,8 +86,10 @@ struct pwaf_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<DevGroup> groups;
-    DevBuf num_atoms, bit_atoms, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
-    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0;
+    DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
+    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, geo_row_words = 2;
+    std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
+    std::vector<int64_t> host_iu_vals1;
     DevBuf iu_vals[2], iu_masks[2];
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
@@ -300,8 +302,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
     v.n_num_atoms = e->n_cmp_atoms;
-    v.bit_atoms = (const uint32_t *)e->bit_atoms.p;
-    v.n_bit_atoms = e->n_bit_atoms;
+    v.bit_col = (const uint32_t *)e->bit_atoms.p;
+    v.trig_off = (const uint32_t *)e->trig_off.p;
+    v.trig_rules = (const uint16_t *)e->trig_rules.p;
+    v.always_rules = (const uint32_t *)e->always_rules.p;
     for (int var = 0; var < 2; var++) {
         v.iu_vals[var] = (const int64_t *)e->iu_vals[var].p;
         v.iu_masks[var] = (const uint32_t *)e->iu_masks[var].p;
@@ -322,7 +326,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.geo_root4 = P.geo_trie.root4.empty() ? nullptr : (const uint32_t *)e->geo_root4.p;
     v.geo_root6 = P.geo_trie.root6.empty() ? nullptr : (const uint32_t *)e->geo_root6.p;
     v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
-    v.geo_recs = (const GeoRec *)e->geo_recs.p;
+    v.geo_rows = (const uint32_t *)e->geo_recs.p;
+    v.geo_row_words = e->geo_row_words;
     v.has_geo = P.has_geo ? 1u : 0u;
     v.out = d_out;
     v.counts = (unsigned long long *)d_counts;
@@ -499,6 +504,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                 for (uint32_t b : kv.second) row[b >> 5] |= 1u << (b & 31);
                 masks.insert(masks.end(), row.begin(), row.end());
             }
+            if (var == 1) { e->host_iu_vals1 = vals; e->host_iu_masks1 = masks; }
             UP(iu_vals[var], vals)
             UP(iu_masks[var], masks)
         }
@@ -516,11 +522,49 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             else { cmp_atoms.push_back(d); continue; }
             bit_atoms.push_back(d.col | ((d.ref & 31u) << 20) | (src << 25));
         }
-        std::sort(bit_atoms.begin(), bit_atoms.end(), [](uint32_t x, uint32_t y) { return (x >> 25) != (y >> 25) ? (x >> 25) < (y >> 25) : x < y; });
+        // (source word, bit) -> column
+        std::vector<uint32_t> bit_col(24 * 32, 0);
+        for (uint32_t d : bit_atoms) bit_col[(d >> 25) * 32 + ((d >> 20) & 31u)] = d & 0xFFFFFu;
         e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
-        e->n_bit_atoms = (uint32_t)bit_atoms.size();
         UP(num_atoms, cmp_atoms)
-        UP(bit_atoms, bit_atoms)
+        UP(bit_atoms, bit_col)
+        // Trigger lists: a rule can match only if one of its DNF terms is true; a term with a positive literal needs that
+        // column to be non-zero. Per term pick the positive literal least likely to be set (scan < membership < comparison <
+        // TRUE) and file the rule under that column; terms made of negations only make the rule an unconditional candidate.
+        if (P.rules.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 effective rules"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        std::vector<uint8_t> rank(P.n_cols, 0);  // 0 = scan atom
+        rank[0] = 3;
+        for (auto &d : cmp_atoms) rank[d.col] = 2;
+        for (uint32_t d : bit_atoms) rank[d & 0xFFFFFu] = 1;
+        std::vector<std::vector<uint16_t>> by_col(P.n_cols);
+        std::vector<uint32_t> always((P.rules.size() + 31) / 32 + 1, 0);
+        for (size_t r = 0; r < P.rules.size(); r++) {
+            const DevRule &dr = P.rules[r];
+            int best = -1;
+            bool term_open = false;
+            for (uint32_t k = dr.lit_off; k < dr.lit_off + dr.lit_cnt; k++) {
+                const uint32_t lit = P.lits[k];
+                if (!term_open) { best = -1; term_open = true; }
+                if (!(lit & LIT_NEG)) {
+                    const int c = (int)(lit & LIT_ATOM_MASK);
+                    if (best < 0 || rank[c] < rank[best]) best = c;
+                }
+                if (lit & LIT_TERM_END) {
+                    if (best < 0) always[r >> 5] |= 1u << (r & 31);
+                    else if (by_col[best].empty() || by_col[best].back() != (uint16_t)r) by_col[best].push_back((uint16_t)r);
+                    term_open = false;
+                }
+            }
+        }
+        std::vector<uint32_t> trig_off(1, 0);
+        std::vector<uint16_t> trig_rules;
+        for (uint32_t c = 0; c < P.n_cols; c++) {
+            trig_rules.insert(trig_rules.end(), by_col[c].begin(), by_col[c].end());
+            trig_off.push_back((uint32_t)trig_rules.size());
+        }
+        UP(trig_off, trig_off)
+        UP(trig_rules, trig_rules)
+        UP(always_rules, always)
     }
     {
         // transpose the per-predicate 676-bit country tables into per-country membership words (one gather per request)
@@ -530,6 +574,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         for (uint32_t t = 0; t < n_luts; t++)
             for (uint32_t c = 0; c < 676; c++)
                 if (P.country_luts[t][c]) masks[(size_t)c * e->cc_words + (t >> 5)] |= 1u << (t & 31);
+        e->host_cc_masks = masks;
         UP(country_luts, masks)
     }
     UP(rules, P.rules)
@@ -541,7 +586,23 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     UP(geo_root4, P.geo_trie.root4)
     UP(geo_root6, P.geo_trie.root6)
     UP(geo_nodes, P.geo_trie.nodes)
-    UP(geo_recs, P.geo_recs)
+    {
+        // per GeoIP record: everything that is a function of (asn, country), so the device gathers one row per request
+        e->geo_row_words = 2 + e->cc_words + e->iu_words[1];
+        std::vector<uint32_t> rows((size_t)P.geo_recs.size() * e->geo_row_words, 0);
+        for (size_t r = 0; r < P.geo_recs.size(); r++) {
+            uint32_t *row = &rows[r * e->geo_row_words];
+            row[0] = P.geo_recs[r].asn;
+            row[1] = P.geo_recs[r].country;
+            const uint32_t c0 = (P.geo_recs[r].country & 0xFFu) - 'A', c1 = (P.geo_recs[r].country >> 8) - 'A';
+            const uint32_t cidx = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;
+            for (uint32_t w = 0; w < e->cc_words; w++) row[2 + w] = e->host_cc_masks[(size_t)cidx * e->cc_words + w];
+            auto it = std::lower_bound(e->host_iu_vals1.begin(), e->host_iu_vals1.end(), (int64_t)P.geo_recs[r].asn);
+            const size_t mrow = (it != e->host_iu_vals1.end() && *it == (int64_t)P.geo_recs[r].asn) ? (size_t)(it - e->host_iu_vals1.begin()) + 1 : 0;
+            for (uint32_t w = 0; w < e->iu_words[1]; w++) row[2 + e->cc_words + w] = e->host_iu_masks1[mrow * e->iu_words[1] + w];
+        }
+        UP(geo_recs, rows)
+    }
 #undef UP
     if (hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "device synchronize failed after table upload"); return dev_fail(PWAF_E_DEVICE); }
     *out = e.release();
@@ -551,7 +612,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
-    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
+    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
                       &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();

@@ -57,18 +57,6 @@ struct ScanArgs {
     const uint32_t *n_list;
 };
 
-// select_kernel: builds the request lists of the gated passes from the ungated passes' hit records
-struct SelectArgs {
-    uint32_t n, n_passes /* ungated */, n_gated;
-    unsigned long long pass_mask;  // ungated passes that own at least one prefilter factor column
-    const uint32_t *rec;        // [n_passes][n]
-    const uint32_t *pass_base;
-    const PoolEntry *pool;
-    const uint32_t *colmask;    // per column: bit g set = gated pass g must visit a request that has this column
-    uint32_t *lists;            // [n_gated][n]
-    uint32_t *list_count;       // [n_gated], zeroed by the host per batch
-};
-
 struct VerdictArgs {
     uint32_t n, n_groups;
     const uint32_t *off[PWAF_N_FIELDS];
@@ -87,8 +75,7 @@ struct VerdictArgs {
     uint32_t n_cols;
     const NumAtomDev *num_atoms;  // comparison atoms only (LEN / INT)
     uint32_t n_num_atoms;
-    const uint32_t *bit_atoms;    // column | bit << 20 | source word << 25, sorted by source word
-    uint32_t n_bit_atoms;
+    const uint32_t *bit_col;      // [24 source words][32 bits] -> column of the membership atom, 0 = none
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
     const uint32_t *iu_masks[2];
@@ -98,13 +85,17 @@ struct VerdictArgs {
     const DevRule *rules;
     uint32_t n_rules;
     const uint32_t *lits;
+    const uint32_t *trig_off;     // [n_cols + 1]: rules triggered by a non-zero column (one positive literal per term)
+    const uint16_t *trig_rules;
+    const uint32_t *always_rules; // bitmap over rules with a term made of negations only
     // tries
     const uint32_t *ip_root4, *ip_root6, *ip_nodes;  // membership sets (null roots => set 0)
     const uint32_t *set_masks;
     uint32_t set_words;
     uint32_t n_ip_lists;
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
-    const GeoRec *geo_recs;
+    const uint32_t *geo_rows;   // per GeoIP record: asn, country, country-table words, asn-set words (row 0 = default {0,"XX"})
+    uint32_t geo_row_words;
     uint32_t has_geo;
     // outputs
     pwaf_verdict *out;
@@ -115,9 +106,8 @@ struct VerdictArgs {
 
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
 int launch_scan(const ScanArgs &a, void *stream);
-int launch_select(const SelectArgs &a, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
-uint32_t verdict_lds_bytes(uint32_t n_cols);
+uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules);
 
 }  // namespace pwaf

@@ -41,7 +41,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // 16 bytes at any byte address (gfx950 global loads need no alignment)
 
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + 1024; }
-uint32_t verdict_lds_bytes(uint32_t n_cols) { return kVerdictWaves * n_cols * 8; }
+
 
 // -------------------------------------------------------------------------------------------------
 // scan
@@ -294,56 +294,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// select: which requests must the gated passes visit?
-// -------------------------------------------------------------------------------------------------
-// One lane per request: looks at the hit records of the ungated passes; every recorded column that is a prefilter factor
-// names (through colmask) the gated passes that have to scan this request. Requests are appended to those passes' lists with
-// a wave ballot + prefix popcount and one atomic per (wave, pass).
-__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1;
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < a.n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + lane;
-        uint32_t need = 0;
-        if (i < a.n) {
-            for (uint32_t ps = 0; ps < a.n_passes; ps++) {
-                if (!((a.pass_mask >> ps) & 1ull)) continue;  // this pass owns no prefilter factor
-                const uint32_t rv = a.rec[(size_t)ps * a.n + i];
-                if (rv == 0) continue;
-                const uint32_t cb = a.pass_base[ps];
-                if (rv & REC_OVERFLOW) {
-                    for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
-                        const PoolEntry pe = a.pool[k];
-                        need |= a.colmask[cb + pe.atom];
-                        k = pe.next;
-                    }
-                } else {
-                    const uint32_t x0 = rv & 0x7FFFu, x1 = (rv >> 15) & 0x7FFFu;
-                    if (x0) need |= a.colmask[cb + x0 - 1];
-                    if (x1) need |= a.colmask[cb + x1 - 1];
-                }
-            }
-        }
-        for (uint32_t gte = 0; gte < a.n_gated; gte++) {
-            const unsigned long long m = __ballot((need >> gte) & 1u);
-            if (m == 0) continue;
-            uint32_t basei = 0;
-            if (lane == 0) basei = atomicAdd(&a.list_count[gte], (uint32_t)__builtin_popcountll(m));
-            basei = __builtin_amdgcn_readfirstlane(basei);
-            if ((need >> gte) & 1u) a.lists[(size_t)gte * a.n + basei + (uint32_t)__builtin_popcountll(m & lt_mask)] = i;
-        }
-    }
-}
-
-int launch_select(const SelectArgs &a, void *stream) {
-    if (a.n == 0 || a.n_gated == 0) return 0;
-    uint32_t blocks = (a.n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-}
-
 int launch_scan(const ScanArgs &a, void *stream) {
     uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
     static thread_local uint32_t configured[2] = {0, 0};
@@ -396,49 +346,78 @@ __device__ __forceinline__ bool cmp_i64(long long v, uint32_t op, long long c) {
     return op == OP_EQ ? v == c : op == OP_LT ? v < c : v <= c;  // the compiler only emits EQ / LT / LE
 }
 
+// LDS per wave: the column file (one 64-request word per atom), a bitmap of non-zero columns, a bitmap of candidate rules
+// and the ordered candidate list.
+__host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
+    const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
+    return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;
+}
+
 __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned long long *col = reinterpret_cast<unsigned long long *>(lds) + (size_t)wave * a.n_cols;
+    const uint32_t colw = (a.n_cols + 31) / 32, rulew = (a.n_rules + 31) / 32;
+    unsigned char *mine = lds + (size_t)wave * verdict_wave_lds(a.n_cols, a.n_rules);
+    unsigned long long *col = reinterpret_cast<unsigned long long *>(mine);
+    uint32_t *colnz = reinterpret_cast<uint32_t *>(mine + (size_t)a.n_cols * 8);
+    uint32_t *rulebm = colnz + colw;
+    uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
     const unsigned long long mybit = 1ull << lane;
+    const unsigned long long lt_mask = mybit - 1;
     unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;  // wave-uniform tallies
+
+    // a lane marks "atom c holds for my request": its bit in the column word, and the column in the non-zero bitmap
+    auto set_col = [&](uint32_t c) {
+        atomicOr(&col[c], mybit);
+        atomicOr(&colnz[c >> 5], 1u << (c & 31));
+    };
 
     for (uint32_t g = blockIdx.x * kVerdictWaves + wave; g < a.n_groups; g += gridDim.x * kVerdictWaves) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
         const unsigned long long valid_mask = __ballot(valid);
 
-        // 1. clear the column file; column 0 is the constant TRUE
+        // 1. clear the column file and the bitmaps; column 0 is the constant TRUE; rules that can match with every column
+        //    zero (a term made of negations only) are always candidates
         for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;
+        for (uint32_t k = lane; k < colw; k += 64) colnz[k] = k == 0 ? 1u : 0u;
+        for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = a.always_rules[k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
 
-        // 2. scan results: each lane ORs its request's bit into the columns its hit records name
-        if (valid) {
-            for (uint32_t ps = 0; ps < a.n_passes; ps++) {
-                const uint32_t rv = a.rec[(size_t)ps * a.n + i];
-                if (rv == 0) continue;
-                const uint32_t base = a.pass_base[ps];
-                if (rv & REC_OVERFLOW) {
-                    for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
+        // 2. scan results: each lane marks the columns its hit records name. The records of 8 passes are requested together
+        //    (independent loads, one wait) before any of them is examined.
+        for (uint32_t pb = 0; pb < a.n_passes; pb += 8) {
+            uint32_t rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
+                rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (pb + (uint32_t)q >= a.n_passes || rv[q] == 0) continue;
+                const uint32_t base = a.pass_base[pb + q];
+                if (rv[q] & REC_OVERFLOW) {
+                    for (uint32_t k = rv[q] & ~REC_OVERFLOW; k != kNone;) {
                         const PoolEntry pe = a.pool[k];
-                        atomicOr(&col[base + pe.atom], mybit);
+                        set_col(base + pe.atom);
                         k = pe.next;
                     }
                 } else {
-                    const uint32_t x0 = rv & 0x7FFFu, x1 = (rv >> 15) & 0x7FFFu;
-                    if (x0) atomicOr(&col[base + x0 - 1], mybit);
-                    if (x1) atomicOr(&col[base + x1 - 1], mybit);
+                    const uint32_t x0 = rv[q] & 0x7FFFu, x1 = (rv[q] >> 15) & 0x7FFFu;
+                    if (x0) set_col(base + x0 - 1);
+                    if (x1) set_col(base + x1 - 1);
                 }
             }
         }
 
-        // 3. this lane's request: lengths and numeric columns
+        // 3. this lane's request: lengths, address, port, GeoIP record, ip-list membership
         uint32_t len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};
         uint32_t ipw[4] = {0, 0, 0, 0};
         bool v6 = false;
         uint32_t port = 0, flags = 0, asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
-        uint32_t set_id = 0;
+        uint32_t set_id = 0, geo_rec = 0;
         if (valid) {
 #pragma unroll
             for (int f = 0; f < PWAF_N_FIELDS; f++) len[f] = a.off[f][i + 1] - a.off[f][i];
@@ -447,45 +426,67 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
             v6 = a.ip_is_v6[i] != 0;
             port = a.port[i];
             flags = a.flags[i];
+            // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
+            // dependent loads overlap instead of queueing behind each other.
+            bool geo_walk = false;
             if (a.asn != nullptr) {
                 asn = a.asn[i];
                 country = a.country[i];
             } else if (a.has_geo) {
                 // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
-                bool skip;
                 if (!v6) {
                     const uint32_t b0 = ipw[0] & 0xFFu;
-                    skip = b0 == 127u || (b0 & 0xF0u) == 0xE0u;
+                    geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
                 } else {
                     const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
-                    skip = loopback || (ipw[0] & 0xFFu) == 0xFFu;
-                }
-                if (!skip) {
-                    const uint32_t rec = trie_lookup(a.geo_root4, a.geo_root6, a.geo_nodes, ipw, v6);
-                    const GeoRec r = a.geo_recs[rec];
-                    asn = r.asn;
-                    country = r.country;
+                    geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
                 }
             }
-            if (a.n_ip_lists) set_id = trie_lookup(a.ip_root4, a.ip_root6, a.ip_nodes, ipw, v6);
-        }
-        uint32_t cidx;
-        {
-            const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
-            cidx = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
+            const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
+            const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
+            uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
+            if (geo_walk && groot != nullptr) eg = groot[top];
+            if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
+            for (uint32_t k = 2; !((eg & ei) & TRIE_LEAF); k++) {
+                const uint32_t byte = ip_byte(ipw, k);
+                const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
+                const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
+                eg = ng;
+                ei = ni;
+            }
+            geo_rec = eg & ~TRIE_LEAF;
+            set_id = ei & ~TRIE_LEAF;
         }
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
 
-        // Per-lane membership words, loaded once per request: which ip lists contain the address (srcw[0..8)), which country
-        // tables contain the country (srcw[8..16)), which integer sets contain remote_port / asn (srcw[16..20) / [20..24)).
-        // Every IPSET / COUNTRY / INTSET atom is then a register bit test + one ballot — no memory access per atom.
-        uint32_t srcw[24];
-#pragma unroll
-        for (int k = 0; k < 24; k++) srcw[k] = 0;
+        // 3a. membership atoms (ip lists, country tables, integer sets). The request's membership words are gathered once;
+        //     each SET BIT is one atom that holds for this request, translated to its column through bit_col. Work is
+        //     proportional to the number of memberships (rare), not to the number of lists / predicates.
         if (valid) {
+            const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
+            auto mark_word = [&](uint32_t src, uint32_t word) {
+                while (word) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(word);
+                    word &= word - 1;
+                    const uint32_t c = a.bit_col[src * 32 + bit];
+                    if (c) set_col(c);
+                }
+            };
+            if (from_row) {
+                // per GeoIP record the engine has precomputed everything that depends on (asn, country)
+                const uint32_t *row = a.geo_rows + (size_t)geo_rec * a.geo_row_words;
+                asn = row[0];
+                country = row[1];
+                for (uint32_t wv = 0; wv < a.cc_words; wv++) mark_word(8 + wv, row[2 + wv]);
+                for (uint32_t wv = 0; wv < a.iu_words[1]; wv++) mark_word(20 + wv, row[2 + a.cc_words + wv]);
+            } else {
+                const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
+                const uint32_t cidx = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
+                for (uint32_t wv = 0; wv < a.cc_words; wv++) mark_word(8 + wv, a.country_masks[(size_t)cidx * a.cc_words + wv]);
+            }
 #pragma unroll
             for (int var = 0; var < 2; var++) {
-                if (a.iu_n[var] == 0) continue;
+                if (a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
                 // ONE binary search per request over the union of every set tested against this variable; the hit's row
                 // says which sets contain the value (the reference scans each list per rule: pingoo/lists.rs:119-121)
                 const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
@@ -495,43 +496,14 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                     if (a.iu_vals[var][mid] < v) lo = mid + 1;
                     else hi = mid;
                 }
-                const uint32_t row = (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) ? lo + 1 : 0;
-#pragma unroll
-                for (int wv = 0; wv < 4; wv++)
-                    if ((uint32_t)wv < a.iu_words[var]) srcw[16 + 4 * var + wv] = a.iu_masks[var][(size_t)row * a.iu_words[var] + wv];
+                if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v)
+                    for (uint32_t wv = 0; wv < a.iu_words[var]; wv++) mark_word(16 + 4 * var + wv, a.iu_masks[var][(size_t)(lo + 1) * a.iu_words[var] + wv]);
             }
-#pragma unroll
-            for (int wv = 0; wv < 8; wv++) {
-                if ((uint32_t)wv < a.set_words && a.n_ip_lists) srcw[wv] = a.set_masks[(size_t)set_id * a.set_words + wv];
-                if ((uint32_t)wv < a.cc_words) srcw[8 + wv] = a.country_masks[(size_t)cidx * a.cc_words + wv];
-            }
+            if (a.n_ip_lists && set_id)
+                for (uint32_t wv = 0; wv < a.set_words; wv++) mark_word(wv, a.set_masks[(size_t)set_id * a.set_words + wv]);
         }
-        // 3a. bit atoms. Descriptors (column | bit << 20 | source word << 25, sorted by source word) are fetched 64 at a time,
-        // one per lane, and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, so the
-        // 64 column words of a chunk leave in ONE ds_write_b64.
-        {
-            uint32_t cur_src = 0xFFFFFFFFu, curw = 0;
-            for (uint32_t base = 0; base < a.n_bit_atoms; base += 64) {
-                const uint32_t mine = base + lane < a.n_bit_atoms ? a.bit_atoms[base + lane] : 0u;
-                const uint32_t cntd = min(64u, a.n_bit_atoms - base);
-                uint32_t acc_lo = 0, acc_hi = 0;
-                for (uint32_t j = 0; j < cntd; j++) {
-                    const uint32_t d = __builtin_amdgcn_readlane(mine, j);
-                    const uint32_t src = d >> 25;
-                    if (src != cur_src) {  // wave-uniform, taken once per run of atoms on the same source word
-                        cur_src = src;
-                        curw = 0;
-#pragma unroll
-                        for (int k = 0; k < 24; k++) curw = src == (uint32_t)k ? srcw[k] : curw;
-                    }
-                    const unsigned long long m = __ballot((curw >> ((d >> 20) & 31u)) & 1u);
-                    acc_lo = lane == j ? (uint32_t)m : acc_lo;  // park atom j's ballot in lane j
-                    acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
-                }
-                if (lane < cntd) col[mine & 0xFFFFFu] = ((unsigned long long)acc_hi << 32) | acc_lo;
-            }
-        }
-        // 3b. comparison atoms (lengths, port, asn against constants): few; same descriptor broadcast
+        // 3b. comparison atoms (lengths, port, asn against constants): few. Descriptors are fetched 64 at a time, one per lane,
+        //     and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, one ds_write_b64 per chunk.
         for (uint32_t base = 0; base < a.n_num_atoms; base += 64) {
             uint32_t m_col = 0, m_meta = 0, m_clo = 0, m_chi = 0;
             if (base + lane < a.n_num_atoms) {
@@ -554,19 +526,54 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                 acc_lo = lane == j ? (uint32_t)m : acc_lo;
                 acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
             }
-            if (lane < cntd) col[m_col] = ((unsigned long long)acc_hi << 32) | acc_lo;
+            if (lane < cntd && (acc_lo | acc_hi)) {
+                col[m_col] = ((unsigned long long)acc_hi << 32) | acc_lo;
+                atomicOr(&colnz[m_col >> 5], 1u << (m_col & 31));
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-        // 4. rules: one lane per rule, 64 requests per ALU op; first match (lowest rule index) wins
+        // 4. candidate rules: a rule can only match some request of this group if one of its terms has a non-zero positive
+        //    column (trigger lists, one chosen literal per term) or consists of negations only (always_rules).
+        for (uint32_t wv = lane; wv < colw; wv += 64) {
+            uint32_t nz = colnz[wv];
+            while (nz) {
+                const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
+                nz &= nz - 1;
+                for (uint32_t k = a.trig_off[c]; k < a.trig_off[c + 1]; k++) {
+                    const uint32_t r = a.trig_rules[k];
+                    atomicOr(&rulebm[r >> 5], 1u << (r & 31));
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ordered compaction of the rule bitmap into the candidate list (ascending rule index = evaluation order)
+        uint32_t n_cand = 0;
+        for (uint32_t wb = 0; wb < rulew; wb += 64) {
+            const uint32_t word = wb + lane < rulew ? rulebm[wb + lane] : 0u;
+            uint32_t pc = (uint32_t)__builtin_popcount(word), incl = pc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            uint32_t pos = n_cand + incl - pc, wrd = word;
+            while (wrd) {
+                cand[pos++] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(wrd));
+                wrd &= wrd - 1;
+            }
+            n_cand += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        // 5. evaluate candidates: one lane per rule, 64 requests per ALU op; first match (lowest rule index) wins
         unsigned long long pending = valid_mask;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
-        for (uint32_t base = 0; base < a.n_rules && pending != 0; base += 64) {
-            const uint32_t r = base + lane;
+        for (uint32_t base = 0; base < n_cand && pending != 0; base += 64) {
             unsigned long long fire = 0;
             uint32_t eff_u = 0, eff_v = 0, pub = 0;
-            if (r < a.n_rules) {
-                const DevRule dr = a.rules[r];
+            if (base + lane < n_cand) {
+                const DevRule dr = a.rules[cand[base + lane]];
                 eff_u = dr.eff_unverified;
                 eff_v = dr.eff_verified;
                 pub = dr.public_idx;
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
             }
         }
 
-        // 5. outputs
+        // 6. outputs
         if (valid) {
             uint2 v;
             v.x = my_action;  // action in byte 0, pad bytes zero
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                 uint32_t basei = 0;
                 if (lane == 0) basei = atomicAdd(a.n_matches, (uint32_t)__builtin_popcountll(hit));
                 basei = __builtin_amdgcn_readfirstlane(basei);
-                if (hit & mybit) a.match_idx[basei + (uint32_t)__builtin_popcountll(hit & (mybit - 1))] = i;
+                if (hit & mybit) a.match_idx[basei + (uint32_t)__builtin_popcountll(hit & lt_mask)] = i;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -635,8 +642,10 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
     }
 }
 
+uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules) { return kVerdictWaves * verdict_wave_lds(n_cols, n_rules); }
+
 int launch_verdict(const VerdictArgs &a, void *stream) {
-    uint32_t lds = verdict_lds_bytes(a.n_cols);
+    uint32_t lds = verdict_lds_bytes(a.n_cols, a.n_rules);
     static thread_local uint32_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(verdict_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
