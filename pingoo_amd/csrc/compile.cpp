@@ -170,6 +170,7 @@ public:
             a.kind = ATOM_SCAN;
             a.field = (uint8_t)target.field;
             a.pattern = rx;
+            a.min_len = rx_min_len(*rx);
             a.key = "S" + std::to_string(target.field) + ":" + rx_key(*rx);
             return atom_tf(intern_atom(std::move(a)));
         }
@@ -1159,6 +1160,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                         fa.kind = ATOM_SCAN;
                         fa.field = (uint8_t)f;
                         fa.pattern = x;
+                        fa.min_len = rx_min_len(*x);
                         fa.key = "S" + std::to_string(f) + ":" + rx_key(*x);
                         uint32_t idx = (uint32_t)rc.intern_atom(std::move(fa));
                         if (idx >= used.size()) used.resize(idx + 1, 0);

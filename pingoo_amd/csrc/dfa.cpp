@@ -449,6 +449,17 @@ static bool rx_nullable(const RNode &n) {
     return true;
 }
 
+uint32_t rx_min_len(const RNode &n) {
+    switch (n.k) {
+        case RNode::EMPTY: case RNode::ASSERT: return 0;
+        case RNode::CLASS: return 1;
+        case RNode::CAT: { uint32_t s = 0; for (auto &k : n.kids) s += rx_min_len(*k); return s; }
+        case RNode::ALT: { uint32_t m = 0xFFFFFFFFu; for (auto &k : n.kids) m = std::min(m, rx_min_len(*k)); return m == 0xFFFFFFFFu ? 0 : m; }
+        case RNode::REPEAT: return (uint32_t)n.rmin * rx_min_len(*n.kids[0]);
+    }
+    return 0;
+}
+
 RNodeP gap_prefilter(const RNodeP &rx) {
     if (!rx || rx->k != RNode::CAT) return nullptr;
     auto is_gap = [](const RNode &n) { return n.k == RNode::REPEAT && n.rmax < 0 && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64; };

@@ -288,6 +288,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     VerdictArgs v{};
     v.n = n;
     v.n_groups = n_groups;
+    {
+        static const uint32_t skip = getenv("PWAF_DEBUG_SKIP") ? (uint32_t)strtoul(getenv("PWAF_DEBUG_SKIP"), nullptr, 0) : 0u;
+        v.debug_skip = skip;  // timing experiments only: results are wrong when non-zero
+    }
     for (int f = 0; f < PWAF_N_FIELDS; f++) v.off[f] = db.field[f].offsets;
     v.ip = db.ip;
     v.ip_is_v6 = db.ip_is_v6;
@@ -298,7 +302,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_cols = P.n_cols;
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)e->rec.p;
-    v.pass_base = (const uint32_t *)e->pass_base.p;
+    for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) v.pass_base_v[k] = e->groups[k].atom_base;
     v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
     v.n_num_atoms = e->n_cmp_atoms;
@@ -519,7 +523,16 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             if (d.kind == ATOM_IPSET) src = d.ref >> 5;
             else if (d.kind == ATOM_COUNTRY) src = 8 + (d.ref >> 5);
             else if (d.kind == ATOM_INTSET) src = 16 + 4 * d.var + (d.ref >> 5);
-            else { cmp_atoms.push_back(d); continue; }
+            else {
+                // lengths, ports and ASNs are 32-bit unsigned: fold constants beyond 2^32 so the device compares in 32 bits
+                NumAtomDev c = d;
+                if (d.c > 0xFFFFFFFFll) {
+                    if (d.op == OP_EQ) { c.op = OP_LT; c.c = 0; }         // never true
+                    else { c.op = OP_LE; c.c = 0xFFFFFFFFll; }            // always true
+                }
+                cmp_atoms.push_back(c);
+                continue;
+            }
             bit_atoms.push_back(d.col | ((d.ref & 31u) << 20) | (src << 25));
         }
         // (source word, bit) -> column
@@ -532,10 +545,14 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         // column to be non-zero. Per term pick the positive literal least likely to be set (scan < membership < comparison <
         // TRUE) and file the rule under that column; terms made of negations only make the rule an unconditional candidate.
         if (P.rules.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 effective rules"); return dev_fail(PWAF_E_UNSUPPORTED); }
-        std::vector<uint8_t> rank(P.n_cols, 0);  // 0 = scan atom
-        rank[0] = 3;
-        for (auto &d : cmp_atoms) rank[d.col] = 2;
-        for (uint32_t d : bit_atoms) rank[d & 0xFFFFFu] = 1;
+        // lower = rarer: scan atoms by how specific their pattern is (shortest possible match), then memberships, then
+        // comparisons (often true for most requests), then the constant TRUE column
+        std::vector<uint32_t> rank(P.n_cols, 100);
+        for (auto &at : P.atoms)
+            if (at.kind == ATOM_SCAN && at.id < P.n_cols) rank[at.id] = 64 - std::min<uint32_t>(at.min_len, 64);
+        rank[0] = 300;
+        for (auto &d : cmp_atoms) rank[d.col] = 200;
+        for (uint32_t d : bit_atoms) rank[d & 0xFFFFFu] = 60;
         std::vector<std::vector<uint16_t>> by_col(P.n_cols);
         std::vector<uint32_t> always((P.rules.size() + 31) / 32 + 1, 0);
         for (size_t r = 0; r < P.rules.size(); r++) {

@@ -59,6 +59,7 @@ struct ScanArgs {
 
 struct VerdictArgs {
     uint32_t n, n_groups;
+    uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
     const uint32_t *off[PWAF_N_FIELDS];
     const uint8_t *ip;
     const uint8_t *ip_is_v6;
@@ -69,7 +70,7 @@ struct VerdictArgs {
     // scan results
     uint32_t n_passes;
     const uint32_t *rec;        // [n_passes][n]
-    const uint32_t *pass_base;  // first column of each pass
+    uint32_t pass_base_v[kMaxPasses + 1];  // first column of each pass (in the kernel-argument block: scalar loads)
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;

@@ -342,8 +342,8 @@ __device__ __forceinline__ uint32_t trie_lookup(const uint32_t *root4, const uin
     return e & ~TRIE_LEAF;
 }
 
-__device__ __forceinline__ bool cmp_i64(long long v, uint32_t op, long long c) {
-    return op == OP_EQ ? v == c : op == OP_LT ? v < c : v <= c;  // the compiler only emits EQ / LT / LE
+__device__ __forceinline__ bool cmp_u32(uint32_t v, uint32_t op, uint32_t c) {
+    return op == OP_EQ ? v == c : op == OP_LT ? v < c : v <= c;  // only EQ / LT / LE reach the device; operands fit 32 bits
 }
 
 // LDS per wave: the column file (one 64-request word per atom), a bitmap of non-zero columns, a bitmap of candidate rules
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
 
         // 2. scan results: each lane marks the columns its hit records name. The records of 8 passes are requested together
         //    (independent loads, one wait) before any of them is examined.
-        for (uint32_t pb = 0; pb < a.n_passes; pb += 8) {
+        for (uint32_t pb = 0; pb < a.n_passes && !(a.debug_skip & 1u); pb += 8) {
             uint32_t rv[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -396,18 +396,33 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                if (pb + (uint32_t)q >= a.n_passes || rv[q] == 0) continue;
-                const uint32_t base = a.pass_base[pb + q];
+                if (pb + (uint32_t)q >= a.n_passes) break;
+                if (__ballot(rv[q] != 0) == 0) continue;  // nobody in the group matched anything in this pass
+                const uint32_t base = a.pass_base_v[pb + q];  // kernel argument: no memory round trip
                 if (rv[q] & REC_OVERFLOW) {
                     for (uint32_t k = rv[q] & ~REC_OVERFLOW; k != kNone;) {
                         const PoolEntry pe = a.pool[k];
                         set_col(base + pe.atom);
                         k = pe.next;
                     }
-                } else {
-                    const uint32_t x0 = rv[q] & 0x7FFFu, x1 = (rv[q] >> 15) & 0x7FFFu;
-                    if (x0) set_col(base + x0 - 1);
-                    if (x1) set_col(base + x1 - 1);
+                }
+                // inline atoms: lanes that name the SAME atom (frequent atoms such as a browser User-Agent prefix are named by
+                // most of the 64 requests) are folded into one column update instead of 64 serialised LDS atomics
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const uint32_t x = (rv[q] & REC_OVERFLOW) ? 0u : (half == 0 ? rv[q] & 0x7FFFu : (rv[q] >> 15) & 0x7FFFu);
+                    unsigned long long todo = __ballot(x != 0);
+                    while (todo) {
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                        const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)__builtin_amdgcn_readfirstlane(leader));
+                        const unsigned long long same = __ballot(x == xa);
+                        todo &= ~same;
+                        if (lane == leader) {
+                            const uint32_t c = base + xa - 1;
+                            atomicOr(&col[c], same);
+                            atomicOr(&colnz[c >> 5], 1u << (c & 31));
+                        }
+                    }
                 }
             }
         }
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         bool v6 = false;
         uint32_t port = 0, flags = 0, asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
         uint32_t set_id = 0, geo_rec = 0;
-        if (valid) {
+        if (valid && !(a.debug_skip & 2u)) {
 #pragma unroll
             for (int f = 0; f < PWAF_N_FIELDS; f++) len[f] = a.off[f][i + 1] - a.off[f][i];
             const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         // 3a. membership atoms (ip lists, country tables, integer sets). The request's membership words are gathered once;
         //     each SET BIT is one atom that holds for this request, translated to its column through bit_col. Work is
         //     proportional to the number of memberships (rare), not to the number of lists / predicates.
-        if (valid) {
+        if (valid && !(a.debug_skip & 2u)) {
             const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
             auto mark_word = [&](uint32_t src, uint32_t word) {
                 while (word) {
@@ -504,25 +519,24 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         }
         // 3b. comparison atoms (lengths, port, asn against constants): few. Descriptors are fetched 64 at a time, one per lane,
         //     and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, one ds_write_b64 per chunk.
-        for (uint32_t base = 0; base < a.n_num_atoms; base += 64) {
-            uint32_t m_col = 0, m_meta = 0, m_clo = 0, m_chi = 0;
+        for (uint32_t base = 0; base < a.n_num_atoms && !(a.debug_skip & 4u); base += 64) {
+            uint32_t m_col = 0, m_meta = 0, m_clo = 0;
             if (base + lane < a.n_num_atoms) {
                 const NumAtomDev d = a.num_atoms[base + lane];
                 m_col = d.col;
                 m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
-                m_clo = (uint32_t)(unsigned long long)d.c;
-                m_chi = (uint32_t)((unsigned long long)d.c >> 32);
+                m_clo = (uint32_t)(unsigned long long)d.c;  // the engine folds constants outside [0, 2^32) away
             }
             const uint32_t cntd = min(64u, a.n_num_atoms - base);
             uint32_t acc_lo = 0, acc_hi = 0;
             for (uint32_t j = 0; j < cntd; j++) {
                 const uint32_t meta = __builtin_amdgcn_readlane(m_meta, j);
                 const uint32_t kind = meta & 0xFFu, var = (meta >> 8) & 0xFFu, op = meta >> 16;
-                const long long c = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_chi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(m_clo, j));
-                long long v;
-                if (kind == ATOM_LEN) v = (long long)(var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4]);
-                else v = var == VAR_PORT ? (long long)port : (long long)asn;
-                const unsigned long long m = __ballot(cmp_i64(v, op, c) && valid);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(m_clo, j);
+                uint32_t v;
+                if (kind == ATOM_LEN) v = var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4];
+                else v = var == VAR_PORT ? port : asn;
+                const unsigned long long m = __ballot(cmp_u32(v, op, c) && valid);
                 acc_lo = lane == j ? (uint32_t)m : acc_lo;
                 acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
             }
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
 
         // 4. candidate rules: a rule can only match some request of this group if one of its terms has a non-zero positive
         //    column (trigger lists, one chosen literal per term) or consists of negations only (always_rules).
-        for (uint32_t wv = lane; wv < colw; wv += 64) {
+        for (uint32_t wv = lane; wv < colw && !(a.debug_skip & 8u); wv += 64) {
             uint32_t nz = colnz[wv];
             while (nz) {
                 const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // ordered compaction of the rule bitmap into the candidate list (ascending rule index = evaluation order)
         uint32_t n_cand = 0;
-        for (uint32_t wb = 0; wb < rulew; wb += 64) {
+        for (uint32_t wb = 0; wb < rulew && !(a.debug_skip & 16u); wb += 64) {
             const uint32_t word = wb + lane < rulew ? rulebm[wb + lane] : 0u;
             uint32_t pc = (uint32_t)__builtin_popcount(word), incl = pc;
 #pragma unroll
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         // 5. evaluate candidates: one lane per rule, 64 requests per ALU op; first match (lowest rule index) wins
         unsigned long long pending = valid_mask;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
-        for (uint32_t base = 0; base < n_cand && pending != 0; base += 64) {
+        for (uint32_t base = 0; base < n_cand && pending != 0 && !(a.debug_skip & 32u); base += 64) {
             unsigned long long fire = 0;
             uint32_t eff_u = 0, eff_v = 0, pub = 0;
             if (base + lane < n_cand) {

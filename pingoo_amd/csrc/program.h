@@ -65,6 +65,7 @@ struct Atom {
     RNodeP pattern;            // SCAN
     uint32_t ref = 0;          // INTSET: index into int_sets; IPSET: ip list index; COUNTRY: lut index
     uint32_t id = 0;           // device column id (assigned at layout time)
+    uint32_t min_len = 0;      // SCAN: length of the shortest string the pattern matches (a proxy for how rare a hit is)
     std::string key;           // canonical form for de-duplication
 };
 
@@ -189,6 +190,7 @@ bool has_wide_gap(const RNode &n);
 // without trailing zero-width assertions — every match of the pattern contains a match of X — or null when no useful
 // (non-nullable) prefix exists.
 RNodeP gap_prefilter(const RNodeP &rx);
+uint32_t rx_min_len(const RNode &n);
 // Runs a DFA on the host over `bytes`, returning local atom ids that hold. COMPILE-TIME USE ONLY
 // (folding predicates over the 676 possible country codes into a lookup table).
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms);
