@@ -74,6 +74,9 @@ def main():
     t_compile = time.time() - t0
     stats = eng.stats()
     dbatch = DeviceBatch(batch, dev)
+    if os.environ.get("PWAF_BENCH_FILL"):  # diagnostic only: constant field bytes => no DFA ever leaves its root (pure hot-loop time)
+        for d in dbatch.data:
+            d.fill_(int(os.environ["PWAF_BENCH_FILL"]))
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     counts = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev)

@@ -73,7 +73,8 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 }
 
 struct DevGroup {
-    DevBuf tab, classmap, special, list_off, list;
+    DevBuf tab, classmap, special, lsp, list_off, list;
+    uint32_t n_lsp = 0;
     uint32_t n_states, stride, n_classes, n_hot, start_emit, special_base, atom_base;
     uint8_t field;
     int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
@@ -96,7 +97,7 @@ struct pwaf_engine {
     // per-call scratch (guarded by mu)
     std::mutex mu;
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
-    DevBuf colmask, gate_lists;
+    DevBuf colmask, gate_lists, attr;
     uint32_t n_ungated = 0, n_gated = 0;
     unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
@@ -106,6 +107,8 @@ struct pwaf_engine {
     std::vector<hipEvent_t> ev;
     std::vector<pwaf_kernel_time> times;
     size_t n_timed = 0;
+    hipStream_t side = nullptr;  // attribute kernel runs here, beside the scans
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -176,6 +179,25 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
             tab[(size_t)s * stride + C + 1] = (uint16_t)id1;
         }
     }
+    // LDS-resident prefix of the special table: the hot targets that emit come first (state order), as long as their match
+    // fits the packed form and LDS (160 KiB per workgroup) has room after the class map and the hot rows
+    std::vector<uint32_t> lsp;
+    {
+        const uint32_t used = 1024 + (((n_hot + 1) * stride2 + 15) & ~15u);
+        const uint32_t room = used < 163840u ? (163840u - used) / 4 : 0;
+        for (size_t k = 0; k < special.size() && lsp.size() < room; k++) {
+            const SpecialCell &sp = special[k];
+            if (sp.next_off >= n_hot * stride2 || sp.emit == 0) break;
+            const uint32_t b = list_off[sp.emit - 1], en = list_off[sp.emit];
+            uint32_t code;
+            if (en - b == 1 && list[b] < 0x8000u) code = 0x8000u | list[b];
+            else if (sp.emit < 0x8000u) code = sp.emit;
+            else break;
+            lsp.push_back((sp.next_off >> 1) | (code << 16));
+        }
+    }
+    d.n_lsp = (uint32_t)lsp.size();
+    if (lsp.empty()) lsp.push_back(0);
     if (special.empty()) special.push_back({0, 0});
     d.n_states = g.n_states;
     d.stride = stride;
@@ -190,6 +212,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     if ((rc = upload(d.classmap, cm))) return rc;
     if ((rc = upload(d.special, special))) return rc;
+    if ((rc = upload(d.lsp, lsp))) return rc;
     if ((rc = upload(d.list_off, list_off))) return rc;
     if ((rc = upload(d.list, list))) return rc;
     return PWAF_OK;
@@ -219,20 +242,21 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     const uint64_t pool_cap64 = std::max<uint64_t>(1u << 20, (uint64_t)n * 8);
     const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
     if ((rc = e->rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
+    if ((rc = e->attr.reserve((size_t)n * 16))) return rc;  // the attribute kernel's four row-index columns
     if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     if ((rc = e->ctrl.reserve(4 * 34))) return rc;
     HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
     if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
 
     size_t ev_i = e->profiling ? e->n_timed : 0;
-    auto mark = [&](const char *name, uint64_t alg_bytes) -> int {
+    auto mark = [&](const char *name, uint64_t alg_bytes, hipStream_t on = nullptr) -> int {
         if (!e->profiling) return PWAF_OK;
         if (e->ev.size() < ev_i + 1) {
             hipEvent_t x;
             HIP_TRY(hipEventCreate(&x));
             e->ev.push_back(x);
         }
-        HIP_TRY(hipEventRecord(e->ev[ev_i], stream));
+        HIP_TRY(hipEventRecord(e->ev[ev_i], on ? on : stream));
         if (name) {
             pwaf_kernel_time t{};
             snprintf(t.name, sizeof t.name, "%s", name);
@@ -243,48 +267,6 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         return PWAF_OK;
     };
 
-    for (size_t gi = 0; gi < e->groups.size(); gi++) {
-        DevGroup &d = e->groups[gi];
-        ScanArgs a{};
-        if (d.gate >= 0) {
-            // records of requests the pass does not visit must read "nothing matched"
-            HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + gi * (size_t)n, 0, (size_t)n * 4, stream));
-            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
-            a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
-        }
-        if (d.gate < 0 && e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
-            // this pass owns prefilter factors: it feeds the gated passes' request lists as requests finish
-            a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
-            a.gate_lists = (uint32_t *)e->gate_lists.p;
-            a.gate_count = (uint32_t *)e->ctrl.p + 2;
-        }
-        a.data = db.field[d.field].data;
-        a.off = db.field[d.field].offsets;
-        a.n = n;
-        a.tab = (const uint16_t *)d.tab.p;
-        a.classmap = (const uint8_t *)d.classmap.p;
-        a.special = (const SpecialCell *)d.special.p;
-        a.list_off = (const uint32_t *)d.list_off.p;
-        a.list = (const uint16_t *)d.list.p;
-        a.start_emit = d.start_emit;
-        a.special_base = d.special_base;
-        a.n_states = d.n_states;
-        a.stride = d.stride;
-        a.n_classes = d.n_classes;
-        a.n_hot = d.n_hot;
-        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
-        a.pool = (PoolEntry *)e->pool.p;
-        a.pool_count = (uint32_t *)e->ctrl.p;
-        a.pool_cap = pool_cap;
-        a.status = (uint32_t *)e->ctrl.p + 1;
-        char nm[48];
-        static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
-        snprintf(nm, sizeof nm, "%s_%s_g%zu", d.gate >= 0 ? "gscan" : "scan", fn[d.field], gi);
-        if ((rc = mark(nullptr, 0))) return rc;
-        int he = launch_scan(a, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        if ((rc = mark(nm, (uint64_t)d.field))) return rc;  // alg_bytes slot carries the field id; bench.py supplies bytes
-    }
     VerdictArgs v{};
     v.n = n;
     v.n_groups = n_groups;
@@ -303,6 +285,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)e->rec.p;
     for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) v.pass_base_v[k] = e->groups[k].atom_base;
+    v.attr_out = (uint32_t *)e->attr.p;
+    v.attr = (const uint32_t *)e->attr.p;
     v.pool = (const PoolEntry *)e->pool.p;
     v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
     v.n_num_atoms = e->n_cmp_atoms;
@@ -337,6 +321,88 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.counts = (unsigned long long *)d_counts;
     v.match_idx = d_match_idx;
     v.n_matches = d_n_matches;
+    // The attribute kernel (GeoIP / ip-list / integer-set lookups: dependent gathers, latency-bound) does not depend on the scans
+    // (LDS / issue-bound), so it runs beside them on the engine's side stream and joins before the verdict kernel.
+    HIP_TRY(hipEventRecord(e->ev_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    if ((rc = mark(nullptr, 0, e->side))) return rc;
+    {
+        int he = launch_attr(v, e->side);
+        if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+    }
+    if ((rc = mark("attr", 0xFEu, e->side))) return rc;
+    HIP_TRY(hipEventRecord(e->ev_join, e->side));
+
+    GatedArgs gb{};
+    auto flush_gated = [&]() -> int {
+        if (gb.count == 0) return PWAF_OK;
+        int rc2;
+        if ((rc2 = mark(nullptr, 0))) return rc2;
+        int he = launch_scan_gated(gb, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        char nm[48];
+        snprintf(nm, sizeof nm, "gscan_x%u", gb.count);
+        if ((rc2 = mark(nm, 0xFDu))) return rc2;
+        gb.count = 0;
+        return PWAF_OK;
+    };
+    bool gated_cleared = false;
+    for (size_t gi = 0; gi < e->groups.size(); gi++) {
+        DevGroup &d = e->groups[gi];
+        ScanArgs a{};
+        if (d.gate >= 0) {
+            if (!gated_cleared) {
+                // records of requests a gated pass does not visit must read "nothing matched"; the gated passes are
+                // consecutive (compile.cpp orders them after the ungated ones), so one memset covers them all
+                HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + gi * (size_t)n, 0, (size_t)e->n_gated * n * 4, stream));
+                gated_cleared = true;
+            }
+            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
+            a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
+        }
+        if (d.gate < 0 && e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+            // this pass owns prefilter factors: it feeds the gated passes' request lists as requests finish
+            a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
+            a.gate_lists = (uint32_t *)e->gate_lists.p;
+            a.gate_count = (uint32_t *)e->ctrl.p + 2;
+        }
+        a.data = db.field[d.field].data;
+        a.off = db.field[d.field].offsets;
+        a.n = n;
+        a.tab = (const uint16_t *)d.tab.p;
+        a.classmap = (const uint8_t *)d.classmap.p;
+        a.special = (const SpecialCell *)d.special.p;
+        a.lsp = (const uint32_t *)d.lsp.p;
+        a.n_lsp = d.n_lsp;
+        a.list_off = (const uint32_t *)d.list_off.p;
+        a.list = (const uint16_t *)d.list.p;
+        a.start_emit = d.start_emit;
+        a.special_base = d.special_base;
+        a.n_states = d.n_states;
+        a.stride = d.stride;
+        a.n_classes = d.n_classes;
+        a.n_hot = d.n_hot;
+        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
+        a.pool = (PoolEntry *)e->pool.p;
+        a.pool_count = (uint32_t *)e->ctrl.p;
+        a.pool_cap = pool_cap;
+        a.status = (uint32_t *)e->ctrl.p + 1;
+        if (d.gate >= 0) {
+            gb.g[gb.count++] = a;
+            if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
+            continue;
+        }
+        if ((rc = flush_gated())) return rc;  // (only when ungated passes follow gated ones: more than 32 gated passes)
+        char nm[48];
+        static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
+        snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
+        if ((rc = mark(nullptr, 0))) return rc;
+        int he = launch_scan(a, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc = mark(nm, (uint64_t)d.field))) return rc;  // alg_bytes slot carries the field id; bench.py supplies bytes
+    }
+    if ((rc = flush_gated())) return rc;
+    HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
     if (he) return fail(PWAF_E_DEVICE, std::string("verdict kernel launch failed: ") + hipGetErrorString((hipError_t)he));
@@ -457,7 +523,11 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         return dev_fail(PWAF_E_DEVICE);
     }
     e->device = dev;
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { fail(PWAF_E_DEVICE, "hipStreamCreate failed"); return dev_fail(PWAF_E_DEVICE); }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
+        return dev_fail(PWAF_E_DEVICE);
+    }
     e->groups.resize(P.groups.size());
     std::vector<uint32_t> pass_base;
     for (size_t k = 0; k < P.groups.size(); k++) {
@@ -628,14 +698,17 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
+    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.lsp.release(); g.list_off.release(); g.list.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     delete e;
 }
 

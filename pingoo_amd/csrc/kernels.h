@@ -38,6 +38,8 @@ struct ScanArgs {
     const uint16_t *tab;      // full table (all rows), padded to 16 bytes
     const uint8_t *classmap;  // 256 bytes
     const SpecialCell *special;
+    const uint32_t *lsp;      // LDS-resident prefix of `special` (hot targets that emit): next cell | code << 16, code = 0x8000 | atom or 1 + list id
+    uint32_t n_lsp;
     const uint32_t *list_off; // shared by end- and emit-lists
     const uint16_t *list;     // local atom ids
     uint32_t n_states, stride, n_classes, n_hot;
@@ -98,6 +100,9 @@ struct VerdictArgs {
     const uint32_t *geo_rows;   // per GeoIP record: asn, country, country-table words, asn-set words (row 0 = default {0,"XX"})
     uint32_t geo_row_words;
     uint32_t has_geo;
+    // attribute kernel (runs before the verdict kernel): per request the row indices of its membership rows
+    uint32_t *attr_out;      // [4][n]: GeoIP record (or country index), ip-list set, port-set row, asn-set row
+    const uint32_t *attr;    // the same, as the verdict kernel reads it
     // outputs
     pwaf_verdict *out;
     unsigned long long *counts;  // 4, accumulated (nullable)
@@ -106,9 +111,16 @@ struct VerdictArgs {
 };
 
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
+static constexpr uint32_t kGatedPerLaunch = 8;
+struct GatedArgs {
+    ScanArgs g[kGatedPerLaunch];
+    uint32_t count;
+};
 int launch_scan(const ScanArgs &a, void *stream);
+int launch_scan_gated(const GatedArgs &b, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
+int launch_attr(const VerdictArgs &a, void *stream);
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_lsp);
 uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules);
 
 }  // namespace pwaf

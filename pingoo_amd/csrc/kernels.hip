@@ -37,10 +37,12 @@ static constexpr uint32_t kNone = 0xFFFFFFFFu;
 typedef const PWAF_LDS uint16_t *lds_u16_ptr;
 typedef const PWAF_GLOBAL uint16_t *glb_u16_ptr;
 typedef const PWAF_LDS uint32_t *lds_u32_ptr;
+typedef const PWAF_LDS uint8_t *lds_u8_ptr;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // 16 bytes at any byte address (gfx950 global loads need no alignment)
 
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + 1024; }
+static constexpr uint32_t kClsBytes = 1024;  // byte-class map at LDS offset 0: 256 x uint32
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_lsp) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + kClsBytes + n_lsp * 4; }
 
 
 // -------------------------------------------------------------------------------------------------
@@ -101,6 +103,10 @@ __device__ __noinline__ Hits emit_list(const uint32_t *list_off, const uint16_t 
     for (uint32_t k = b; k < e; k++) h = record_atom(c, list[k], h);
     return h;
 }
+__device__ __noinline__ Hits emit_atom(PoolEntry *pool, uint32_t *pool_count, uint32_t *status, uint32_t pool_cap, uint32_t atom, Hits h) {
+    const SlowCtx c{nullptr, nullptr, pool, pool_count, status, pool_cap};
+    return record_atom(c, atom, h);
+}
 // A finished request whose hits include prefilter factors is appended to the lists of the gated passes those factors guard
 // (rare: one atomic per request and gated pass).
 __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const PoolEntry *pool, uint32_t *gate_lists, uint32_t *gate_count, uint32_t n,
@@ -125,16 +131,17 @@ __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const 
 #define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
 
 template <bool INDIRECT>
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
+__device__ __forceinline__ void scan_body(const ScanArgs &a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t stride2 = a.stride * 2;
     const uint32_t hot_bytes = a.n_hot * stride2;            // sentinel row starts here
     const uint32_t hot_elems = hot_bytes >> 1;
     const uint32_t tab_bytes = (hot_bytes + stride2 + 15) & ~15u;
-    const PWAF_LDS unsigned char *ltab = (const PWAF_LDS unsigned char *)lds;
-    // 256 x uint32: byte class (the cell index inside a row). One dword per byte value: bytes that differ by less than
-    // 32 never share an LDS bank, so lower-case text (the bulk of URLs) reads it conflict-free.
-    lds_u32_ptr cls2 = (lds_u32_ptr)(lds + tab_bytes);
+    // LDS: [0, kClsBytes) byte -> BYTE offset of its class cell inside a row (class * 2; one dword per byte value: a plain 32-bit load needs no masking), then the
+    // hot rows + sentinel row. The kernel has no static LDS, so the dynamic segment starts at LDS address 0 (checked below) and
+    // lookups use plain integer addresses: the region bases fold into the ds_read offset fields, a class lookup is one SDWA
+    // shift + ds_read_b32, a DFA step is v_lshl_add (cell * 2 + class offset) + ds_read_u16.
+    if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
     const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
@@ -144,17 +151,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     for (uint32_t i = tid * 16; i < tab_bytes; i += kScanThreads * 16) {
         uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // sentinel cells: "special"
         if (i + 16 <= hot_bytes) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.tab) + i);
-        *reinterpret_cast<uint4 *>(lds + i) = v;
+        *reinterpret_cast<uint4 *>(lds + kClsBytes + i) = v;
     }
     __syncthreads();
     if (hot_bytes & 15) {  // the last, partially covered 16-byte slot of the hot rows
         const uint32_t base = hot_bytes & ~15u;
-        if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + base)[tid] = a.tab[base / 2 + tid];
+        if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + kClsBytes + base)[tid] = a.tab[base / 2 + tid];
     }
-    if (tid < 256) reinterpret_cast<uint32_t *>(lds + tab_bytes)[tid] = a.classmap[tid];
+    if (tid < 256) reinterpret_cast<uint32_t *>(lds)[tid] = a.classmap[tid] * 2u;
+    const uint32_t lsp_base = kClsBytes + tab_bytes, n_lsp = a.n_lsp;
+    for (uint32_t i = tid; i < n_lsp; i += kScanThreads) reinterpret_cast<uint32_t *>(lds + lsp_base)[i] = a.lsp[i];
     __syncthreads();
 
-    const uint32_t stay_col = a.n_classes, end_col = a.n_classes + 1;
+    const uint32_t end_col = a.n_classes + 1;
+    // the STAY cell's byte offset, pinned in a vector register: as a scalar it would be re-materialised (v_mov) before every
+    // one of the 16 selects, because v_cndmask cannot read a second scalar next to VCC
+    uint32_t stay2;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stay2) : "s"(a.n_classes * 2u));
     const uint32_t special_base = a.special_base;  // cells >= special_base index the special table
     // this wave's slab of work items: contiguous, 64-aligned so offset blocks are whole. A work item is request i, or —
     // for a gated pass — entry i of the list of requests whose prefilter fired (its length lives on the device).
@@ -242,24 +255,48 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         uint32_t c2[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint32_t c = cls2[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];  // byte classes do not depend on the state
-            c2[k] = (uint32_t)k < cnt ? c : stay_col;                         // past the end: the STAY column
+            const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            // byte classes do not depend on the state: all 16 lookups are issued before the dependent chain starts
+            const uint32_t c = *reinterpret_cast<lds_u32_ptr>((uintptr_t)(byte << 2));
+            c2[k] = (uint32_t)k < cnt ? c : stay2;  // past the end: the STAY cell
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t prev = row;
-            row = *reinterpret_cast<lds_u16_ptr>(ltab + ((prev + c2[k]) << 1));  // below special_base: the next row's cell — done
+            row = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((prev << 1) + c2[k] + kClsBytes));  // below special_base: the next row's cell — done
             if (row >= special_base) {
                 // rare: the target row is cold and/or emits, or this lane is parked on the sentinel row (current row cold)
                 uint32_t cell = row;
                 row = prev;
                 if ((uint32_t)k < cnt) {
-                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + (c2[k] << 1));  // the real row, from L2
+                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
                     if (cell >= special_base) {
-                        const SpecialCell sp = a.special[cell - special_base];
-                        if (sp.next_off < hot_bytes) row = sp.next_off >> 1;
-                        else { row = hot_elems; crow = sp.next_off; }
-                        if (sp.emit) PWAF_EMIT(sp.emit - 1);
+                        const uint32_t si = cell - special_base;
+                        if (si < n_lsp) {
+                            // the usual special: a HOT row that emits. Target cell and match come from LDS, and a match that is
+                            // already in the request's record (or fits an empty slot) never leaves the registers.
+                            const uint32_t e = *reinterpret_cast<lds_u32_ptr>((uintptr_t)(lsp_base + si * 4));
+                            row = e & 0xFFFFu;
+                            const uint32_t code = e >> 16;
+                            if (code & 0x8000u) {
+                                const uint32_t x = (code & 0x7FFFu) + 1;
+                                if (h.ovf == kNone && (h.a0 == x || h.a1 == x)) {
+                                } else if (h.ovf == kNone && h.a0 == 0) {
+                                    h.a0 = x;
+                                } else if (h.ovf == kNone && h.a1 == 0) {
+                                    h.a1 = x;
+                                } else {
+                                    h = emit_atom(a.pool, a.pool_count, a.status, a.pool_cap, x - 1, h);
+                                }
+                            } else {
+                                PWAF_EMIT(code - 1);
+                            }
+                        } else {
+                            const SpecialCell sp = a.special[si];
+                            if (sp.next_off < hot_bytes) row = sp.next_off >> 1;
+                            else { row = hot_elems; crow = sp.next_off; }
+                            if (sp.emit) PWAF_EMIT(sp.emit - 1);
+                        }
                     } else {
                         row = cell;
                     }
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
         // ---- 3. finished requests: end-of-field matches, the hit record, then switch to the pulled-ahead request ----
         if (r != kNone && p >= end) {
             const uint32_t e = row == hot_elems ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + (end_col << 1))
-                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>(ltab + ((row + end_col) << 1));
+                                                : (uint32_t)*reinterpret_cast<lds_u16_ptr>((uintptr_t)(((row + end_col) << 1) + kClsBytes));
             if (e) PWAF_EMIT(e - 1);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) enqueue_gated(a.colmask_local, a.pool, a.gate_lists, a.gate_count, a.n, r, h);
@@ -294,30 +331,47 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) {
     }
 }
 
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false>(a); }
+
+// Every gated pass of the program in ONE launch (blockIdx.y = pass): their request lists are short, so separate launches were
+// dominated by launch latency and table staging.
+__global__ __launch_bounds__(kScanThreads) void gscan_kernel(GatedArgs b) {
+    const ScanArgs a = b.g[blockIdx.y];
+    scan_body<true>(a);
+}
+
+static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
+    if (lds <= configured) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = lds;
+    return 0;
+}
+
 int launch_scan(const ScanArgs &a, void *stream) {
-    uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
-    static thread_local uint32_t configured[2] = {0, 0};
-    const int variant = a.req_list != nullptr;
-    if (lds > configured[variant]) {
-        const void *fn = variant ? reinterpret_cast<const void *>(scan_kernel<true>) : reinterpret_cast<const void *>(scan_kernel<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured[variant] = lds;
-    }
+    const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.n_lsp);
+    static thread_local uint32_t configured = 0;
+    if (int e = configure_lds(reinterpret_cast<const void *>(scan_kernel), lds, configured)) return e;
     if (a.n == 0) return 0;
-    if (variant) {
-        // gated pass: the list length is only known on the device; lists are short (the prefilter is rare), so a modest
-        // fixed grid is enough and idle workgroups exit at once
-        hipLaunchKernelGGL(scan_kernel<true>, dim3(64), dim3(kScanThreads), lds, (hipStream_t)stream, a);
-        return (int)hipGetLastError();
-    }
     // at least 256 requests per wave so that work-pulling has something to balance; at most two rounds of one
     // workgroup per CU: long slabs keep the pull queue busy until the very end
     uint32_t waves = (a.n + 255) / 256;
     uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
     if (blocks > 512) blocks = 512;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_scan_gated(const GatedArgs &b, void *stream) {
+    uint32_t lds = 0;
+    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, b.g[k].n_lsp));
+    static thread_local uint32_t configured = 0;
+    if (int e = configure_lds(reinterpret_cast<const void *>(gscan_kernel), lds, configured)) return e;
+    if (b.count == 0 || b.g[0].n == 0) return 0;
+    // the list lengths are only known on the device; lists are short (the prefilters are rare), so a modest fixed grid per
+    // pass is enough and idle workgroups exit at once
+    hipLaunchKernelGGL(gscan_kernel, dim3(64, b.count), dim3(kScanThreads), lds, (hipStream_t)stream, b);
     return (int)hipGetLastError();
 }
 
@@ -348,6 +402,21 @@ __device__ __forceinline__ bool cmp_u32(uint32_t v, uint32_t op, uint32_t c) {
 
 // LDS per wave: the column file (one 64-request word per atom), a bitmap of non-zero columns, a bitmap of candidate rules
 // and the ordered candidate list.
+// Bitwise OR over the 64 lanes, in the vector ALU (DPP row shifts + the two cross-row broadcasts): no LDS, no memory.
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+#define PWAF_DPP_OR(ctrl, rows) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (ctrl), (rows), 0xF, true)
+    PWAF_DPP_OR(0x111, 0xF);  // row_shr:1
+    PWAF_DPP_OR(0x112, 0xF);  // row_shr:2
+    PWAF_DPP_OR(0x114, 0xF);  // row_shr:4
+    PWAF_DPP_OR(0x118, 0xF);  // row_shr:8   -> lane 15 of each row holds its row
+    PWAF_DPP_OR(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
+    PWAF_DPP_OR(0x143, 0xC);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+#undef PWAF_DPP_OR
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+static constexpr uint32_t kBitColEntries = 24 * 32;  // (source word, bit) -> column table, shared by the block in LDS
+
 __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
     const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
     return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;
@@ -362,6 +431,9 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
     uint32_t *colnz = reinterpret_cast<uint32_t *>(mine + (size_t)a.n_cols * 8);
     uint32_t *rulebm = colnz + colw;
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
+    uint32_t *bitcol = reinterpret_cast<uint32_t *>(lds + (size_t)kVerdictWaves * verdict_wave_lds(a.n_cols, a.n_rules));
+    for (uint32_t k = tid; k < kBitColEntries; k += kVerdictThreads) bitcol[k] = a.bit_col[k];
+    __syncthreads();
     const unsigned long long mybit = 1ull << lane;
     const unsigned long long lt_mask = mybit - 1;
     unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;  // wave-uniform tallies
@@ -372,6 +444,17 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         atomicOr(&colnz[c >> 5], 1u << (c & 31));
     };
 
+    // group-invariant tables, fetched once per wave: the comparison-atom descriptors (lane j keeps atom j) and this lane's
+    // word of the always-candidate bitmap
+    uint32_t h_col = 0, h_meta = 0, h_c = 0;
+    if (lane < a.n_num_atoms) {
+        const NumAtomDev d = a.num_atoms[lane];
+        h_col = d.col;
+        h_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
+        h_c = (uint32_t)(unsigned long long)d.c;  // the engine folds constants outside [0, 2^32) away
+    }
+    const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
+
     for (uint32_t g = blockIdx.x * kVerdictWaves + wave; g < a.n_groups; g += gridDim.x * kVerdictWaves) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
@@ -381,9 +464,26 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         //    zero (a term made of negations only) are always candidates
         for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;
         for (uint32_t k = lane; k < colw; k += 64) colnz[k] = k == 0 ? 1u : 0u;
-        for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = a.always_rules[k];
+        for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = k < 64 ? h_always : a.always_rules[k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
+
+        // this lane's request columns: requested now, consumed after the hit records (their latency overlaps section 2)
+        uint32_t len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};
+        uint32_t port = 0, flags = 0, r_geo = 0, r_set = 0, r_port = 0, r_asn = 0, asn = 0;
+        if (valid) {
+#pragma unroll
+            for (int f = 0; f < PWAF_N_FIELDS; f++) len[f] = a.off[f][i + 1] - a.off[f][i];
+            port = a.port[i];
+            flags = a.flags[i];
+            r_geo = a.attr[i];
+            r_set = a.attr[(size_t)a.n + i];
+            r_port = a.attr[2 * (size_t)a.n + i];
+            if (a.asn != nullptr) {
+                r_asn = a.attr[3 * (size_t)a.n + i];
+                asn = a.asn[i];
+            }
+        }
 
         // 2. scan results: each lane marks the columns its hit records name. The records of 8 passes are requested together
         //    (independent loads, one wait) before any of them is examined.
@@ -427,105 +527,65 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
             }
         }
 
-        // 3. this lane's request: lengths, address, port, GeoIP record, ip-list membership
-        uint32_t len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};
-        uint32_t ipw[4] = {0, 0, 0, 0};
-        bool v6 = false;
-        uint32_t port = 0, flags = 0, asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
-        uint32_t set_id = 0, geo_rec = 0;
-        if (valid && !(a.debug_skip & 2u)) {
-#pragma unroll
-            for (int f = 0; f < PWAF_N_FIELDS; f++) len[f] = a.off[f][i + 1] - a.off[f][i];
-            const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
-            ipw[0] = raw.x; ipw[1] = raw.y; ipw[2] = raw.z; ipw[3] = raw.w;
-            v6 = a.ip_is_v6[i] != 0;
-            port = a.port[i];
-            flags = a.flags[i];
-            // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
-            // dependent loads overlap instead of queueing behind each other.
-            bool geo_walk = false;
-            if (a.asn != nullptr) {
-                asn = a.asn[i];
-                country = a.country[i];
-            } else if (a.has_geo) {
-                // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
-                if (!v6) {
-                    const uint32_t b0 = ipw[0] & 0xFFu;
-                    geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
-                } else {
-                    const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
-                    geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
-                }
-            }
-            const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
-            const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
-            uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
-            if (geo_walk && groot != nullptr) eg = groot[top];
-            if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
-            for (uint32_t k = 2; !((eg & ei) & TRIE_LEAF); k++) {
-                const uint32_t byte = ip_byte(ipw, k);
-                const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
-                const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
-                eg = ng;
-                ei = ni;
-            }
-            geo_rec = eg & ~TRIE_LEAF;
-            set_id = ei & ~TRIE_LEAF;
-        }
+        // 3. membership atoms (ip lists, country tables, integer sets). The attribute kernel has resolved every dependent
+        //    lookup to a row index; the rows are gathered together (independent loads, one wait) and each SET BIT is one atom
+        //    that holds for this request, translated to its column through bit_col. Work is proportional to the number of
+        //    memberships, not to the number of lists / predicates.
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
-
-        // 3a. membership atoms (ip lists, country tables, integer sets). The request's membership words are gathered once;
-        //     each SET BIT is one atom that holds for this request, translated to its column through bit_col. Work is
-        //     proportional to the number of memberships (rare), not to the number of lists / predicates.
-        if (valid && !(a.debug_skip & 2u)) {
-            const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
-            auto mark_word = [&](uint32_t src, uint32_t word) {
-                while (word) {
-                    const uint32_t bit = (uint32_t)__builtin_ctz(word);
-                    word &= word - 1;
-                    const uint32_t c = a.bit_col[src * 32 + bit];
-                    if (c) set_col(c);
-                }
-            };
-            if (from_row) {
-                // per GeoIP record the engine has precomputed everything that depends on (asn, country)
-                const uint32_t *row = a.geo_rows + (size_t)geo_rec * a.geo_row_words;
-                asn = row[0];
-                country = row[1];
-                for (uint32_t wv = 0; wv < a.cc_words; wv++) mark_word(8 + wv, row[2 + wv]);
-                for (uint32_t wv = 0; wv < a.iu_words[1]; wv++) mark_word(20 + wv, row[2 + a.cc_words + wv]);
-            } else {
-                const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
-                const uint32_t cidx = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
-                for (uint32_t wv = 0; wv < a.cc_words; wv++) mark_word(8 + wv, a.country_masks[(size_t)cidx * a.cc_words + wv]);
-            }
+        if (!(a.debug_skip & 2u)) {
+            const bool from_row = a.asn == nullptr;
+            // per GeoIP record the engine has precomputed everything that depends on (asn, country); a batch that brings its own
+            // asn / country columns uses the per-country rows and the asn-set rows instead
+            const uint32_t *grow = from_row ? a.geo_rows + (size_t)r_geo * a.geo_row_words + 2 : a.country_masks + (size_t)r_geo * a.cc_words;
+            const uint32_t *arow = from_row ? grow + a.cc_words : a.iu_masks[1] + (size_t)r_asn * a.iu_words[1];
+            const uint32_t *prow = a.iu_masks[0] + (size_t)r_port * a.iu_words[0];
+            const uint32_t *srow = a.set_masks + (size_t)r_set * a.set_words;
+            uint32_t mw[24];  // this lane's membership words, by source word: 0-7 ip lists, 8-15 country tables, 16-19 port sets, 20-23 asn sets
 #pragma unroll
-            for (int var = 0; var < 2; var++) {
-                if (a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
-                // ONE binary search per request over the union of every set tested against this variable; the hit's row
-                // says which sets contain the value (the reference scans each list per rule: pingoo/lists.rs:119-121)
-                const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
-                uint32_t lo = 0, hi = a.iu_n[var];
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (a.iu_vals[var][mid] < v) lo = mid + 1;
-                    else hi = mid;
+            for (uint32_t wv = 0; wv < 8; wv++) mw[wv] = (valid && wv < a.set_words && r_set) ? srow[wv] : 0u;
+#pragma unroll
+            for (uint32_t wv = 0; wv < 8; wv++) mw[8 + wv] = (valid && wv < a.cc_words) ? grow[wv] : 0u;
+#pragma unroll
+            for (uint32_t wv = 0; wv < 4; wv++) mw[16 + wv] = (valid && wv < a.iu_words[0] && r_port) ? prow[wv] : 0u;
+#pragma unroll
+            for (uint32_t wv = 0; wv < 4; wv++) mw[20 + wv] = (valid && wv < a.iu_words[1] && (from_row || r_asn)) ? arow[wv] : 0u;
+            if (valid && from_row) asn = grow[-2];
+            // A membership word is transposed in registers: one ballot per bit that ANY of the 64 requests has set (wave-wide OR
+            // first, so absent bits cost nothing); lane b keeps bit b's request mask and stores it to that atom's column.
+#pragma unroll
+            for (uint32_t src = 0; src < 24; src++) {
+                const uint32_t lim = src < 8 ? a.set_words : src < 16 ? a.cc_words + 8 : src < 20 ? a.iu_words[0] + 16 : a.iu_words[1] + 20;
+                if (src >= lim) continue;
+                const uint32_t w = mw[src];
+                const uint32_t orw0 = wave_or(w);
+                if (orw0 == 0) continue;
+                unsigned long long mine_m = 0;
+                for (uint32_t orw = orw0; orw; orw &= orw - 1) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(orw);
+                    const unsigned long long m = __ballot((w >> b) & 1u);
+                    if (lane == b) mine_m = m;
                 }
-                if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v)
-                    for (uint32_t wv = 0; wv < a.iu_words[var]; wv++) mark_word(16 + 4 * var + wv, a.iu_masks[var][(size_t)(lo + 1) * a.iu_words[var] + wv]);
+                if (lane < 32 && ((orw0 >> lane) & 1u)) {
+                    const uint32_t c = bitcol[src * 32 + lane];
+                    if (c) {
+                        atomicOr(&col[c], mine_m);
+                        atomicOr(&colnz[c >> 5], 1u << (c & 31));
+                    }
+                }
             }
-            if (a.n_ip_lists && set_id)
-                for (uint32_t wv = 0; wv < a.set_words; wv++) mark_word(wv, a.set_masks[(size_t)set_id * a.set_words + wv]);
         }
         // 3b. comparison atoms (lengths, port, asn against constants): few. Descriptors are fetched 64 at a time, one per lane,
         //     and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, one ds_write_b64 per chunk.
         for (uint32_t base = 0; base < a.n_num_atoms && !(a.debug_skip & 4u); base += 64) {
-            uint32_t m_col = 0, m_meta = 0, m_clo = 0;
-            if (base + lane < a.n_num_atoms) {
-                const NumAtomDev d = a.num_atoms[base + lane];
-                m_col = d.col;
-                m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
-                m_clo = (uint32_t)(unsigned long long)d.c;  // the engine folds constants outside [0, 2^32) away
+            uint32_t m_col = h_col, m_meta = h_meta, m_clo = h_c;
+            if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
+                m_col = m_meta = m_clo = 0;
+                if (base + lane < a.n_num_atoms) {
+                    const NumAtomDev d = a.num_atoms[base + lane];
+                    m_col = d.col;
+                    m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
+                    m_clo = (uint32_t)(unsigned long long)d.c;
+                }
             }
             const uint32_t cntd = min(64u, a.n_num_atoms - base);
             uint32_t acc_lo = 0, acc_hi = 0;
@@ -656,7 +716,86 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
     }
 }
 
-uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules) { return kVerdictWaves * verdict_wave_lds(n_cols, n_rules); }
+uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules) { return kVerdictWaves * verdict_wave_lds(n_cols, n_rules) + kBitColEntries * 4; }
+
+// -------------------------------------------------------------------------------------------------
+// attributes: GeoIP record, ip-list membership, country / integer-set membership — one thread per request
+// -------------------------------------------------------------------------------------------------
+// Everything here is a chain of dependent gathers (trie levels, membership rows). Running it one thread per request at full
+// occupancy (no LDS, few registers) hides that latency behind thousands of other requests; inside the verdict kernel, whose
+// LDS column file caps it at a few waves per CU, the same chains cost ~0.5 ms per 10M requests. The memberships found are
+// written as one more hit-record pass whose "local atoms" are column numbers (pass base 0).
+__global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
+    const uint32_t ipw[4] = {raw.x, raw.y, raw.z, raw.w};
+    const bool v6 = a.ip_is_v6[i] != 0;
+    uint32_t asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
+    // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
+    // dependent loads overlap instead of queueing behind each other.
+    bool geo_walk = false;
+    if (a.asn != nullptr) {
+        asn = a.asn[i];
+        country = a.country[i];
+    } else if (a.has_geo) {
+        // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
+        if (!v6) {
+            const uint32_t b0 = ipw[0] & 0xFFu;
+            geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
+        } else {
+            const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
+            geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
+        }
+    }
+    const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
+    const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
+    uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
+    if (geo_walk && groot != nullptr) eg = groot[top];
+    if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
+    for (uint32_t k = 2; !((eg & ei) & TRIE_LEAF); k++) {
+        const uint32_t byte = ip_byte(ipw, k);
+        const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
+        const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
+        eg = ng;
+        ei = ni;
+    }
+    const uint32_t geo_rec = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
+
+    // Row indices the verdict kernel turns into membership columns with one independent gather each.
+    const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
+    uint32_t r_geo = geo_rec;
+    if (!from_row) {
+        const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
+        r_geo = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
+    }
+    uint32_t r_int[2] = {0, 0};
+    const uint32_t port = a.port[i];
+#pragma unroll
+    for (int var = 0; var < 2; var++) {
+        if (a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
+        // ONE binary search per request over the union of every set tested against this variable; the hit's row
+        // says which sets contain the value (the reference scans each list per rule: pingoo/lists.rs:119-121)
+        const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
+        uint32_t lo = 0, hi = a.iu_n[var];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.iu_vals[var][mid] < v) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) r_int[var] = lo + 1;
+    }
+    a.attr_out[i] = r_geo;
+    a.attr_out[(size_t)a.n + i] = set_id;
+    a.attr_out[2 * (size_t)a.n + i] = r_int[0];
+    if (!from_row) a.attr_out[3 * (size_t)a.n + i] = r_int[1];
+}
+
+int launch_attr(const VerdictArgs &a, void *stream) {
+    if (a.n == 0) return 0;
+    hipLaunchKernelGGL(attr_kernel, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
 
 int launch_verdict(const VerdictArgs &a, void *stream) {
     uint32_t lds = verdict_lds_bytes(a.n_cols, a.n_rules);
