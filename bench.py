@@ -71,6 +71,11 @@ def main():
     t0 = time.time()
     opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
     eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
+    # profile-guided LDS residency: the DFA rows kept in LDS are chosen from a traffic sample DISJOINT from the timed batch
+    # (a deployment would sample live traffic); verdicts do not depend on it
+    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 8192
+    if tune_n:
+        eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
     t_compile = time.time() - t0
     stats = eng.stats()
     dbatch = DeviceBatch(batch, dev)
@@ -131,6 +136,7 @@ def main():
                         f"{0 if wl.geoip is None else len(wl.geoip)} GeoIP prefixes), seed 0x50494E47^{args.config}",
             "requests_per_gpu": n,
             "rules": len(wl.rules),
+            "hot_rows": f"tuned on {tune_n} sample requests disjoint from the timed batch" if tune_n else "BFS order (untuned)",
             "parallelism": f"requests sharded over {world} GPU(s), tables replicated, RCCL all-reduce of 4 counters",
             "action_counts_allow_block_captcha_bypass": final_counts,
         },

@@ -224,6 +224,13 @@ int pwaf_evaluate_device(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out,
  * scan scratch (verdicts incomplete; cannot happen below 8 overflowing hits per request on average). */
 int pwaf_engine_device_status(pwaf_engine *);
 
+/* Optional tuning from a traffic sample (HOST memory; at most the first 65536 requests are used). Each DFA pass keeps its most
+ * visited states in LDS; without a profile those are the shallowest states (BFS order), with one they are the states the sample
+ * actually visits. Only speed depends on this: verdicts are identical with any profile. Synchronises the device, then rebuilds
+ * and re-uploads the scan tables. No reference counterpart (the reference interprets each rule per request:
+ * pingoo/rules.rs:37-51); the closest analogue is warming its caches. */
+int pwaf_engine_tune(pwaf_engine *, const pwaf_batch *sample);
+
 /* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
 int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);
 

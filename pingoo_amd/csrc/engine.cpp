@@ -73,9 +73,8 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 }
 
 struct DevGroup {
-    DevBuf tab, classmap, special, lsp, list_off, list;
-    uint32_t n_lsp = 0;
-    uint32_t n_states, stride, n_classes, n_hot, start_emit, special_base, atom_base;
+    DevBuf tab, classmap, special, list_off, list;
+    uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base;
     uint8_t field;
     int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
 };
@@ -88,7 +87,8 @@ struct pwaf_engine {
     hipStream_t stream = nullptr;
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
-    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, geo_row_words = 2;
+    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, geo_row_words = 2, n_trig = 0;
+    uint16_t cmp_seg[15] = {0};
     std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
     std::vector<int64_t> host_iu_vals1;
     DevBuf iu_vals[2], iu_masks[2];
@@ -128,9 +128,11 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
     g_last_error = src.message;
 }
 
-// Builds the device form of one DFA group: see the cell encoding in kernels.h.
-int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) {
-    const uint32_t C = g.n_classes, stride = C + 2, stride2 = stride * 2;
+// Builds the device form of one DFA group: see the cell encoding in kernels.h. `visits` (optional, one count per state) is a
+// traffic profile from pwaf_engine_tune: the LDS-resident ("hot") rows are then the most visited states instead of the
+// shallowest ones. The result of a scan never depends on which rows are hot.
+int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, const std::vector<uint64_t> *visits = nullptr) {
+    const uint32_t C = g.n_classes, stride = C + 3, stride2 = stride * 2;
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
     std::vector<uint32_t> list_off{0};
     std::vector<uint16_t> list;
@@ -142,68 +144,66 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
     std::vector<uint32_t> emit_id(g.n_states, 0);
     for (uint32_t s = 0; s < g.n_states; s++)
         if (g.emit_off[s + 1] > g.emit_off[s]) emit_id[s] = add_list(g.emit_list, g.emit_off[s], g.emit_off[s + 1]);
-    // Cell value space (uint16): [0, (n_hot+1)*stride) addresses hot rows + the sentinel row, the rest indexes `special` (one
-    // entry per target state that is cold or emits). Shrink the hot set until both fit.
+    // what entering the start state emits is recorded when a request starts (start_emit); re-entering it adds nothing
+    const uint32_t start_emit = emit_id[0];
+    emit_id[0] = 0;
+
+    // Row order: the start state, then by visit count (profile) or BFS depth (the DFA builder's state order).
+    std::vector<uint32_t> order(g.n_states);
+    for (uint32_t s = 0; s < g.n_states; s++) order[s] = s;
+    if (visits && visits->size() == g.n_states)
+        std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
+
+    // Cell value space (uint16): [0, emit_base) plain hot rows, [emit_base, (n_hot+1)*stride) hot rows that emit + the sentinel
+    // row, the rest indexes `special` (one entry per cold state). Shrink the hot set until everything fits.
     const uint32_t budget = std::min<uint32_t>(lds_hot_budget, 131070u);
     uint32_t n_hot = budget > 2 * stride2 ? (budget - stride2) / stride2 : 1;
     n_hot = std::max(1u, std::min(n_hot, g.n_states));
-    std::vector<uint32_t> special_of;
-    std::vector<SpecialCell> special;
     for (;;) {
-        special_of.assign(g.n_states, 0xFFFFFFFFu);
-        special.clear();
-        for (uint32_t t = 0; t < g.n_states; t++) {
-            if (t < n_hot && !emit_id[t]) continue;
-            special_of[t] = (uint32_t)special.size();  // (targets nobody points to cost a slot each: negligible)
-            special.push_back({t * stride2, emit_id[t]});
-        }
-        const uint64_t need = (uint64_t)(n_hot + 1) * stride + special.size();
-        if (need <= 65535 || n_hot == 1) {
-            if (need > 65535) return fail(PWAF_E_UNSUPPORTED, "DFA too large for the 16-bit cell space");
-            break;
-        }
+        const uint64_t need = (uint64_t)(n_hot + 1) * stride + (g.n_states - n_hot);
+        if (need <= 65535) break;
+        if (n_hot == 1) return fail(PWAF_E_UNSUPPORTED, "DFA too large for the 16-bit cell space");
         const uint32_t over = (uint32_t)(need - 65535);
-        n_hot = std::max(1u, n_hot - std::max(1u, over / stride + 1));  // every evicted row frees `stride` cells and may add one special
+        n_hot = std::max(1u, n_hot - std::max(1u, over / (stride - 1) + 1));  // an evicted row frees `stride` cells and adds one special
     }
-    const uint32_t special_base = (n_hot + 1) * stride;
+    // hot rows: plain ones first, then the emitting ones (one compare against emit_base finds both "emits" and "special")
+    std::stable_partition(order.begin() + 1, order.begin() + n_hot, [&](uint32_t s) { return emit_id[s] == 0; });
+    uint32_t n_plain = n_hot;
+    for (uint32_t q = 0; q < n_hot; q++)
+        if (emit_id[order[q]]) { n_plain = q; break; }
+    std::vector<uint32_t> pos(g.n_states);
+    for (uint32_t q = 0; q < g.n_states; q++) pos[order[q]] = q;
+    const uint32_t emit_base = n_plain * stride, special_base = (n_hot + 1) * stride;
+    std::vector<SpecialCell> special;
+    for (uint32_t q = n_hot; q < g.n_states; q++) special.push_back({q * stride2, emit_id[order[q]]});
+    auto cell_of = [&](uint32_t t) -> uint16_t { return pos[t] < n_hot ? (uint16_t)(pos[t] * stride) : (uint16_t)(special_base + (pos[t] - n_hot)); };
+
     std::vector<uint16_t> tab((size_t)g.n_states * stride, 0);
-    for (uint32_t s = 0; s < g.n_states; s++) {
-        for (uint32_t c = 0; c < C; c++) {
-            const uint32_t t = g.trans[(size_t)s * C + c];
-            tab[(size_t)s * stride + c] = special_of[t] == 0xFFFFFFFFu ? (uint16_t)(t * stride) : (uint16_t)(special_base + special_of[t]);
-        }
-        tab[(size_t)s * stride + C] = s < n_hot ? (uint16_t)(s * stride) : (uint16_t)0xFFFF;  // STAY
+    for (uint32_t q = 0; q < g.n_states; q++) {
+        const uint32_t s = order[q];
+        uint16_t *row = &tab[(size_t)q * stride];
+        for (uint32_t c = 0; c < C; c++) row[c] = cell_of(g.trans[(size_t)s * C + c]);
+        row[C] = q < n_hot ? (uint16_t)(q * stride) : (uint16_t)0xFFFF;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
-            uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
+            const uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
             if (id1 > 65535) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
-            tab[(size_t)s * stride + C + 1] = (uint16_t)id1;
+            row[C + 1] = (uint16_t)id1;
+        }
+        if (emit_id[s]) {
+            // EMIT cell of a hot row: 0x8000 | atom for a single match, else 1 + list id
+            const uint32_t b = list_off[emit_id[s] - 1], en = list_off[emit_id[s]];
+            if (en - b == 1 && list[b] < 0x8000u) row[C + 2] = (uint16_t)(0x8000u | list[b]);
+            else if (emit_id[s] < 0x8000u) row[C + 2] = (uint16_t)emit_id[s];
+            else return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
         }
     }
-    // LDS-resident prefix of the special table: the hot targets that emit come first (state order), as long as their match
-    // fits the packed form and LDS (160 KiB per workgroup) has room after the class map and the hot rows
-    std::vector<uint32_t> lsp;
-    {
-        const uint32_t used = 1024 + (((n_hot + 1) * stride2 + 15) & ~15u);
-        const uint32_t room = used < 163840u ? (163840u - used) / 4 : 0;
-        for (size_t k = 0; k < special.size() && lsp.size() < room; k++) {
-            const SpecialCell &sp = special[k];
-            if (sp.next_off >= n_hot * stride2 || sp.emit == 0) break;
-            const uint32_t b = list_off[sp.emit - 1], en = list_off[sp.emit];
-            uint32_t code;
-            if (en - b == 1 && list[b] < 0x8000u) code = 0x8000u | list[b];
-            else if (sp.emit < 0x8000u) code = sp.emit;
-            else break;
-            lsp.push_back((sp.next_off >> 1) | (code << 16));
-        }
-    }
-    d.n_lsp = (uint32_t)lsp.size();
-    if (lsp.empty()) lsp.push_back(0);
     if (special.empty()) special.push_back({0, 0});
     d.n_states = g.n_states;
     d.stride = stride;
     d.n_classes = C;
     d.n_hot = n_hot;
-    d.start_emit = emit_id[0];
+    d.start_emit = start_emit;
+    d.emit_base = emit_base;
     d.special_base = special_base;
     d.atom_base = g.atom_base;
     d.field = g.field;
@@ -212,7 +212,6 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d) 
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     if ((rc = upload(d.classmap, cm))) return rc;
     if ((rc = upload(d.special, special))) return rc;
-    if ((rc = upload(d.lsp, lsp))) return rc;
     if ((rc = upload(d.list_off, list_off))) return rc;
     if ((rc = upload(d.list, list))) return rc;
     return PWAF_OK;
@@ -288,8 +287,11 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.attr_out = (uint32_t *)e->attr.p;
     v.attr = (const uint32_t *)e->attr.p;
     v.pool = (const PoolEntry *)e->pool.p;
-    v.num_atoms = (const NumAtomDev *)e->num_atoms.p;
-    v.n_num_atoms = e->n_cmp_atoms;
+    v.cmp = (const CmpAtomDev *)e->num_atoms.p;
+    v.n_cmp = e->n_cmp_atoms;
+    for (int k = 0; k < 15; k++) v.cmp_seg[k] = e->cmp_seg[k];
+    v.n_trig = e->n_trig;
+    v.n_lits = (uint32_t)P.lits.size();
     v.bit_col = (const uint32_t *)e->bit_atoms.p;
     v.trig_off = (const uint32_t *)e->trig_off.p;
     v.trig_rules = (const uint16_t *)e->trig_rules.p;
@@ -372,11 +374,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.tab = (const uint16_t *)d.tab.p;
         a.classmap = (const uint8_t *)d.classmap.p;
         a.special = (const SpecialCell *)d.special.p;
-        a.lsp = (const uint32_t *)d.lsp.p;
-        a.n_lsp = d.n_lsp;
         a.list_off = (const uint32_t *)d.list_off.p;
         a.list = (const uint16_t *)d.list.p;
         a.start_emit = d.start_emit;
+        a.emit_base = d.emit_base;
         a.special_base = d.special_base;
         a.n_states = d.n_states;
         a.stride = d.stride;
@@ -583,7 +584,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             UP(iu_masks[var], masks)
         }
         // split: membership atoms become register bit tests (source word, bit); the rest are comparisons
-        std::vector<NumAtomDev> cmp_atoms;
+        std::vector<NumAtomDev> cmp_src;
         std::vector<uint32_t> bit_atoms;
         if (P.n_cols >= (1u << 20)) { fail(PWAF_E_UNSUPPORTED, "more than 2^20 predicate columns"); return dev_fail(PWAF_E_UNSUPPORTED); }
         if (P.set_words > 8) { fail(PWAF_E_UNSUPPORTED, "more than 256 ip lists"); return dev_fail(PWAF_E_UNSUPPORTED); }
@@ -594,13 +595,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             else if (d.kind == ATOM_COUNTRY) src = 8 + (d.ref >> 5);
             else if (d.kind == ATOM_INTSET) src = 16 + 4 * d.var + (d.ref >> 5);
             else {
-                // lengths, ports and ASNs are 32-bit unsigned: fold constants beyond 2^32 so the device compares in 32 bits
-                NumAtomDev c = d;
-                if (d.c > 0xFFFFFFFFll) {
-                    if (d.op == OP_EQ) { c.op = OP_LT; c.c = 0; }         // never true
-                    else { c.op = OP_LE; c.c = 0xFFFFFFFFll; }            // always true
-                }
-                cmp_atoms.push_back(c);
+                cmp_src.push_back(d);
                 continue;
             }
             bit_atoms.push_back(d.col | ((d.ref & 31u) << 20) | (src << 25));
@@ -608,6 +603,38 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         // (source word, bit) -> column
         std::vector<uint32_t> bit_col(24 * 32, 0);
         for (uint32_t d : bit_atoms) bit_col[(d >> 25) * 32 + ((d >> 20) & 31u)] = d & 0xFFFFFu;
+        // Comparison atoms in the canonical form the kernel evaluates: variable (0-4 field lengths, 5 remote_port, 6 asn) against
+        // a 32-bit constant with == or <=. Lengths, ports and ASNs are unsigned 32-bit, so constants outside [0, 2^32) fold to
+        // "never" (the atom is dropped: its column stays zero) or "always" (<= 0xFFFFFFFF); `v < c` becomes `v <= c - 1`.
+        struct Canon { uint32_t vi, op, col, c; };
+        std::vector<Canon> canon;
+        for (const NumAtomDev &d : cmp_src) {
+            const uint32_t vi = d.kind == ATOM_LEN ? d.var : 5u + d.var;
+            if (vi > 6 || (d.kind == ATOM_LEN && d.var > 4)) { fail(PWAF_E_UNSUPPORTED, "comparison atom on an unknown variable"); return dev_fail(PWAF_E_UNSUPPORTED); }
+            int64_t c = d.c;
+            uint32_t op;  // 0: ==, 1: <=
+            if (d.op == OP_EQ) {
+                if (c < 0 || c > 0xFFFFFFFFll) continue;
+                op = 0;
+            } else {
+                if (d.op == OP_LT) {
+                    if (c <= 0) continue;  // v < c with c <= 0: never
+                    c -= 1;
+                }
+                if (c < 0) continue;
+                if (c > 0xFFFFFFFFll) c = 0xFFFFFFFFll;
+                op = 1;
+            }
+            canon.push_back({vi, op, d.col, (uint32_t)c});
+        }
+        std::stable_sort(canon.begin(), canon.end(), [](const Canon &x, const Canon &y) { return x.vi != y.vi ? x.vi < y.vi : x.op < y.op; });
+        if (canon.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 comparison predicates"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        std::vector<CmpAtomDev> cmp_atoms;
+        for (int k = 0; k < 15; k++) e->cmp_seg[k] = 0;
+        for (const Canon &cn : canon) {
+            cmp_atoms.push_back({cn.col, cn.c});
+            for (uint32_t k = 2 * cn.vi + cn.op + 1; k < 15; k++) e->cmp_seg[k]++;  // seg[k] = number of atoms in segments before k
+        }
         e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
         UP(num_atoms, cmp_atoms)
         UP(bit_atoms, bit_col)
@@ -621,7 +648,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         for (auto &at : P.atoms)
             if (at.kind == ATOM_SCAN && at.id < P.n_cols) rank[at.id] = 64 - std::min<uint32_t>(at.min_len, 64);
         rank[0] = 300;
-        for (auto &d : cmp_atoms) rank[d.col] = 200;
+        for (auto &d : cmp_src) rank[d.col] = 200;
         for (uint32_t d : bit_atoms) rank[d & 0xFFFFFu] = 60;
         std::vector<std::vector<uint16_t>> by_col(P.n_cols);
         std::vector<uint32_t> always((P.rules.size() + 31) / 32 + 1, 0);
@@ -649,9 +676,14 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             trig_rules.insert(trig_rules.end(), by_col[c].begin(), by_col[c].end());
             trig_off.push_back((uint32_t)trig_rules.size());
         }
+        e->n_trig = (uint32_t)trig_rules.size();
         UP(trig_off, trig_off)
         UP(trig_rules, trig_rules)
         UP(always_rules, always)
+        if (verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size()).waves == 0) {
+            fail(PWAF_E_UNSUPPORTED, "too many distinct predicates for one LDS column file (160 KiB)");
+            return dev_fail(PWAF_E_UNSUPPORTED);
+        }
     }
     {
         // transpose the per-predicate 676-bit country tables into per-country membership words (one gather per request)
@@ -698,7 +730,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.lsp.release(); g.list_off.release(); g.list.release(); }
+    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
                       &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
@@ -809,6 +841,39 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     HIP_TRY(hipMemcpyAsync(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
+    return PWAF_OK;
+}
+
+int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
+    if (!e) return fail(PWAF_E_INVALID_ARG, "engine is NULL");
+    int rc = validate_batch_header(sample);
+    if (rc) return rc;
+    if (sample->memory != PWAF_MEM_HOST) return fail(PWAF_E_INVALID_ARG, "pwaf_engine_tune needs a HOST-memory sample");
+    std::lock_guard<std::mutex> lock(e->mu);
+    const Program &P = *e->prog.p;
+    const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
+    if (n == 0) return PWAF_OK;
+    // host walk of every pass over the sample: how often each DFA state is the current state
+    std::vector<std::vector<uint64_t>> visits(P.groups.size());
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        const DfaGroup &g = P.groups[k];
+        std::vector<uint64_t> &v = visits[k];
+        v.assign(g.n_states, 0);
+        const uint8_t *data = sample->field[g.field].data;
+        const uint32_t *off = sample->field[g.field].offsets;
+        for (uint32_t i = 0; i < n; i++) {
+            if (off[i + 1] < off[i]) return fail(PWAF_E_BATCH, "sample offsets are not monotonic");
+            uint32_t s = 0;
+            for (uint32_t p = off[i]; p < off[i + 1]; p++) {
+                s = g.trans[(size_t)s * g.n_classes + g.classmap[data[p]]];
+                v[s]++;
+            }
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
+    for (size_t k = 0; k < P.groups.size(); k++)
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k]))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;
 }
 

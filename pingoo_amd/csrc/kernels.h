@@ -17,16 +17,19 @@ struct PoolEntry {
     uint32_t next;  // 0xFFFFFFFF = end of chain
 };
 
-// Device table of one DFA group. n_states rows of `stride` uint16 cells, row r starting at cell index
-// r * stride (rows are in BFS order; rows [0, n_hot) are copied into LDS, followed by one SENTINEL row of 0xFFFF cells):
-//   [0, n_classes)   transition cell        [n_classes]  STAY cell (= own row, used for lanes past their last byte)
-//   [n_classes + 1]  1 + end-list id (0 = none)
-// A transition cell c <  special_base -> cell index of the next row, which is hot and has nothing to emit (the common case:
-//                                        next lookup address = (c + class) * 2: one add-shift, one compare)
-//                   c >= special_base -> index c - special_base into `special`: the target row is cold and/or has an emit
-//                                        list. special_base = (n_hot + 1) * stride, just past the sentinel row.
-// A lane whose current row is cold parks on the sentinel row, whose cells are all 0xFFFF, so the same compare routes it to
-// the slow path that reads the real row from the L2-resident table.
+// Device table of one DFA group. n_states rows of `stride` = n_classes + 3 uint16 cells, row r starting at
+// cell index r * stride. Row 0 is the start state; rows [0, n_hot) are copied into LDS ("hot": the most visited states when
+// the engine was tuned on a traffic sample, else the shallowest), followed by one SENTINEL row of 0xFFFF cells. Among the hot
+// rows the ones that emit matches come last: rows [n_plain, n_hot).
+//   [0, n_classes)   transition cell        [n_classes]      STAY cell (= own row; used for lanes past their last byte)
+//   [n_classes + 1]  1 + end-list id (0 = none)   [n_classes + 2]  EMIT cell: 0x8000 | atom, or 1 + emit-list id (0 = none)
+// A transition cell c <  emit_base    -> cell index of the next row: hot, nothing to emit (next lookup address = c * 2 + class
+//                                        offset: one v_lshl_add)
+//                   c <  special_base -> same, and entering that row emits what its EMIT cell says
+//                   c >= special_base -> index c - special_base into `special`: the target row is cold.
+// emit_base = n_plain * stride, special_base = (n_hot + 1) * stride (just past the sentinel row). A lane whose current row is
+// cold parks on the sentinel row, whose cells are all 0xFFFF, so the same single compare (c >= emit_base) routes it to the
+// careful path that reads the real row from the L2-resident table.
 struct SpecialCell {
     uint32_t next_off;  // byte offset of the target row in the full table
     uint32_t emit;      // 1 + emit-list id, 0 = none
@@ -38,13 +41,11 @@ struct ScanArgs {
     const uint16_t *tab;      // full table (all rows), padded to 16 bytes
     const uint8_t *classmap;  // 256 bytes
     const SpecialCell *special;
-    const uint32_t *lsp;      // LDS-resident prefix of `special` (hot targets that emit): next cell | code << 16, code = 0x8000 | atom or 1 + list id
-    uint32_t n_lsp;
     const uint32_t *list_off; // shared by end- and emit-lists
     const uint16_t *list;     // local atom ids
     uint32_t n_states, stride, n_classes, n_hot;
     uint32_t start_emit;      // 1 + emit-list id of the start state
-    uint32_t special_base;
+    uint32_t emit_base, special_base;
     uint32_t *rec;            // n hit records of this pass
     PoolEntry *pool;
     uint32_t *pool_count;     // atomic allocator
@@ -59,6 +60,9 @@ struct ScanArgs {
     const uint32_t *n_list;
 };
 
+struct CmpAtomDev {
+    uint32_t col, c;
+};
 struct VerdictArgs {
     uint32_t n, n_groups;
     uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
@@ -76,8 +80,9 @@ struct VerdictArgs {
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;
-    const NumAtomDev *num_atoms;  // comparison atoms only (LEN / INT)
-    uint32_t n_num_atoms;
+    const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant), sorted by variable and operator
+    uint32_t n_cmp;
+    uint16_t cmp_seg[15];         // variable vi (0-4 field lengths, 5 port, 6 asn): atoms [seg[2vi], seg[2vi+1]) test ==, [seg[2vi+1], seg[2vi+2]) test <=
     const uint32_t *bit_col;      // [24 source words][32 bits] -> column of the membership atom, 0 = none
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
@@ -88,6 +93,7 @@ struct VerdictArgs {
     const DevRule *rules;
     uint32_t n_rules;
     const uint32_t *lits;
+    uint32_t n_lits, n_trig;
     const uint32_t *trig_off;     // [n_cols + 1]: rules triggered by a non-zero column (one positive literal per term)
     const uint16_t *trig_rules;
     const uint32_t *always_rules; // bitmap over rules with a term made of negations only
@@ -120,7 +126,10 @@ int launch_scan(const ScanArgs &a, void *stream);
 int launch_scan_gated(const GatedArgs &b, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 int launch_attr(const VerdictArgs &a, void *stream);
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_lsp);
-uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules);
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
+struct VerdictShape {
+    uint32_t waves, lds_bytes, lds_tables;
+};
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits);
 
 }  // namespace pwaf

@@ -26,8 +26,6 @@ namespace pwaf {
 
 static constexpr int kScanThreads = 1024;
 static constexpr int kScanWaves = kScanThreads / 64;
-static constexpr int kVerdictThreads = 256;
-static constexpr int kVerdictWaves = kVerdictThreads / 64;
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // Explicit address spaces: a generic pointer that may be LDS or global makes the compiler emit FLAT loads for the table
@@ -42,7 +40,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // 16 bytes at any byte address (gfx950 global loads need no alignment)
 
 static constexpr uint32_t kClsBytes = 1024;  // byte-class map at LDS offset 0: 256 x uint32
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_lsp) { return (((n_hot + 1) * stride * 2 + 15) & ~15u) + kClsBytes + n_lsp * 4; }
+// The walk is speculative (see scan_body): a lane that has just read a special cell keeps using it as an address until the
+// group of 4 steps is checked, so every address a 16-bit cell can form — (0xFFFF << 1) + a class offset — must stay inside the
+// allocation.
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) {
+    const uint32_t need = (((n_hot + 1) * stride * 2 + 15) & ~15u) + kClsBytes;
+    const uint32_t reach = ((0xFFFFu << 1) + stride * 2 + kClsBytes + 15) & ~15u;
+    return need > reach ? need : reach;
+}
 
 
 // -------------------------------------------------------------------------------------------------
@@ -103,9 +108,44 @@ __device__ __noinline__ Hits emit_list(const uint32_t *list_off, const uint16_t 
     for (uint32_t k = b; k < e; k++) h = record_atom(c, list[k], h);
     return h;
 }
-__device__ __noinline__ Hits emit_atom(PoolEntry *pool, uint32_t *pool_count, uint32_t *status, uint32_t pool_cap, uint32_t atom, Hits h) {
-    const SlowCtx c{nullptr, nullptr, pool, pool_count, status, pool_cap};
-    return record_atom(c, atom, h);
+// One careful DFA step of one lane (out of line, by value): used when the speculative group walk met an emitting row, a cold
+// row or a parked lane. `t` is the cell the lane read from LDS for this step.
+struct Walk {
+    uint32_t row, crow;
+    Hits h;
+};
+// (Arguments are kept few and scalar: beyond the register budget of the calling convention the compiler passes `Hits` through
+// scratch memory.)
+__device__ __noinline__ Walk careful_step(const PWAF_GLOBAL unsigned char *gtab, const SpecialCell *special, const uint32_t *list_off, const uint16_t *list,
+                                          PoolEntry *pool, uint32_t *ctrl /* [0] pool allocator, [1] status */, uint32_t pool_cap, uint32_t hot_emit /* hot_elems | emit_base << 16 */,
+                                          uint32_t special_col /* special_base | emit_col2 << 16 */, uint32_t prev, uint32_t crow, uint32_t c2k, uint32_t t, uint32_t a0,
+                                          uint32_t a1, uint32_t ovf) {
+    const SlowCtx c{list_off, list, pool, ctrl, ctrl + 1, pool_cap};
+    const uint32_t hot_elems = hot_emit & 0xFFFFu, emit_base = hot_emit >> 16, special_base = special_col & 0xFFFFu, emit_col2 = special_col >> 16;
+    const Hits h{a0, a1, ovf};
+    uint32_t cell = t;
+    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2k);  // parked: the real (cold) row, from L2
+    Walk w{cell, crow, h};
+    if (cell >= special_base) {
+        // the target row is cold: park on the sentinel row and remember where the real row lives
+        const SpecialCell sp = special[cell - special_base];
+        w.row = hot_elems;
+        w.crow = sp.next_off;
+        if (sp.emit) {
+            const uint32_t b = list_off[sp.emit - 1], e = list_off[sp.emit];
+            for (uint32_t k = b; k < e; k++) w.h = record_atom(c, list[k], w.h);
+        }
+    } else if (cell >= emit_base) {
+        // a hot row that emits: its EMIT cell (LDS) names the match
+        const uint32_t code = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((cell << 1) + emit_col2 + kClsBytes));
+        if (code & 0x8000u) {
+            w.h = record_atom(c, code & 0x7FFFu, w.h);
+        } else {
+            const uint32_t b = list_off[code - 1], e = list_off[code];
+            for (uint32_t k = b; k < e; k++) w.h = record_atom(c, list[k], w.h);
+        }
+    }
+    return w;
 }
 // A finished request whose hits include prefilter factors is appended to the lists of the gated passes those factors guard
 // (rare: one atomic per request and gated pass).
@@ -159,8 +199,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + kClsBytes + base)[tid] = a.tab[base / 2 + tid];
     }
     if (tid < 256) reinterpret_cast<uint32_t *>(lds)[tid] = a.classmap[tid] * 2u;
-    const uint32_t lsp_base = kClsBytes + tab_bytes, n_lsp = a.n_lsp;
-    for (uint32_t i = tid; i < n_lsp; i += kScanThreads) reinterpret_cast<uint32_t *>(lds + lsp_base)[i] = a.lsp[i];
     __syncthreads();
 
     const uint32_t end_col = a.n_classes + 1;
@@ -168,7 +206,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     // one of the 16 selects, because v_cndmask cannot read a second scalar next to VCC
     uint32_t stay2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(stay2) : "s"(a.n_classes * 2u));
+    const uint32_t emit_base = a.emit_base;        // cells >= emit_base: the row emits, or (>= special_base) is cold
     const uint32_t special_base = a.special_base;  // cells >= special_base index the special table
+    const uint32_t emit_col2 = (a.n_classes + 2) * 2u;
     // this wave's slab of work items: contiguous, 64-aligned so offset blocks are whole. A work item is request i, or —
     // for a gated pass — entry i of the list of requests whose prefilter fired (its length lives on the device).
     const uint32_t n_items = INDIRECT ? min(*a.n_list, a.n) : a.n;
@@ -260,47 +300,56 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             const uint32_t c = *reinterpret_cast<lds_u32_ptr>((uintptr_t)(byte << 2));
             c2[k] = (uint32_t)k < cnt ? c : stay2;  // past the end: the STAY cell
         }
+        // The 16 steps run in groups of 4 with ONE check per group: inside a group every lane chains lookup to lookup
+        // (v_lshl_add + ds_read_u16, nothing else on the dependent path), treating whatever it reads as the next row. Only if
+        // some lane read a cell >= emit_base (it entered an emitting row, left the hot set, or is parked on a cold row) are
+        // the group's 4 steps re-walked carefully by the lanes concerned; all other lanes keep their speculative result.
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t prev = row;
-            row = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((prev << 1) + c2[k] + kClsBytes));  // below special_base: the next row's cell — done
-            if (row >= special_base) {
-                // rare: the target row is cold and/or emits, or this lane is parked on the sentinel row (current row cold)
-                uint32_t cell = row;
-                row = prev;
-                if ((uint32_t)k < cnt) {
-                    if (prev == hot_elems) cell = *reinterpret_cast<glb_u16_ptr>(gtab + crow + c2[k]);  // the real row, from L2
-                    if (cell >= special_base) {
-                        const uint32_t si = cell - special_base;
-                        if (si < n_lsp) {
-                            // the usual special: a HOT row that emits. Target cell and match come from LDS, and a match that is
-                            // already in the request's record (or fits an empty slot) never leaves the registers.
-                            const uint32_t e = *reinterpret_cast<lds_u32_ptr>((uintptr_t)(lsp_base + si * 4));
-                            row = e & 0xFFFFu;
-                            const uint32_t code = e >> 16;
-                            if (code & 0x8000u) {
-                                const uint32_t x = (code & 0x7FFFu) + 1;
-                                if (h.ovf == kNone && (h.a0 == x || h.a1 == x)) {
-                                } else if (h.ovf == kNone && h.a0 == 0) {
-                                    h.a0 = x;
-                                } else if (h.ovf == kNone && h.a1 == 0) {
-                                    h.a1 = x;
-                                } else {
-                                    h = emit_atom(a.pool, a.pool_count, a.status, a.pool_cap, x - 1, h);
-                                }
-                            } else {
-                                PWAF_EMIT(code - 1);
-                            }
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            const uint32_t t1 = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((row << 1) + c2[k0] + kClsBytes));
+            const uint32_t t2 = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((t1 << 1) + c2[k0 + 1] + kClsBytes));
+            const uint32_t t3 = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((t2 << 1) + c2[k0 + 2] + kClsBytes));
+            const uint32_t t4 = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((t3 << 1) + c2[k0 + 3] + kClsBytes));
+            if (max(max(t1, t2), max(t3, t4)) >= emit_base) {
+                // Entering a hot row that emits does not break the chain (its cell is a real row), so the speculative cells stay
+                // usable until the lane meets a special cell; the usual case — a match that is already in the request's record, or
+                // fits a free slot — is settled from LDS and registers alone.
+                uint32_t cur = row;
+                bool chain = true;
+                auto redo = [&](const uint32_t ts, const uint32_t cls, const bool in_range) {
+                    const uint32_t t = chain ? ts : (uint32_t)*reinterpret_cast<lds_u16_ptr>((uintptr_t)((cur << 1) + cls + kClsBytes));
+                    if (in_range) {  // (past the end the row does not change)
+                        bool slow = t >= special_base;
+                        if (!slow && t >= emit_base) {
+                            const uint32_t code = *reinterpret_cast<lds_u16_ptr>((uintptr_t)((t << 1) + emit_col2 + kClsBytes));
+                            const uint32_t x = (code & 0x7FFFu) + 1;
+                            if (!(code & 0x8000u) || h.ovf != kNone) slow = true;  // a list of matches, or the record has overflowed
+                            else if (h.a0 == x || h.a1 == x) {}
+                            else if (h.a0 == 0) h.a0 = x;
+                            else if (h.a1 == 0) h.a1 = x;
+                            else slow = true;
+                        }
+                        if (slow) {
+                            const Walk wk = careful_step(gtab, a.special, a.list_off, a.list, a.pool, a.pool_count, a.pool_cap, hot_elems | (emit_base << 16),
+                                                         special_base | (emit_col2 << 16), cur, crow, cls, t, h.a0, h.a1, h.ovf);
+                            chain = chain && wk.row == t;  // still on a real hot row: the cells read after it remain valid
+                            cur = wk.row;
+                            crow = wk.crow;
+                            h = wk.h;
                         } else {
-                            const SpecialCell sp = a.special[si];
-                            if (sp.next_off < hot_bytes) row = sp.next_off >> 1;
-                            else { row = hot_elems; crow = sp.next_off; }
-                            if (sp.emit) PWAF_EMIT(sp.emit - 1);
+                            cur = t;
                         }
                     } else {
-                        row = cell;
+                        chain = chain && t < special_base;  // (a parked lane past its end reads the sentinel: nothing to reuse)
                     }
-                }
+                };
+                redo(t1, c2[k0], (uint32_t)k0 < cnt);
+                redo(t2, c2[k0 + 1], (uint32_t)(k0 + 1) < cnt);
+                redo(t3, c2[k0 + 2], (uint32_t)(k0 + 2) < cnt);
+                redo(t4, c2[k0 + 3], (uint32_t)(k0 + 3) < cnt);
+                row = cur;
+            } else {
+                row = t4;
             }
         }
         p += cnt;
@@ -349,7 +398,7 @@ static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
 }
 
 int launch_scan(const ScanArgs &a, void *stream) {
-    const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.n_lsp);
+    const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
     static thread_local uint32_t configured = 0;
     if (int e = configure_lds(reinterpret_cast<const void *>(scan_kernel), lds, configured)) return e;
     if (a.n == 0) return 0;
@@ -365,7 +414,7 @@ int launch_scan(const ScanArgs &a, void *stream) {
 
 int launch_scan_gated(const GatedArgs &b, void *stream) {
     uint32_t lds = 0;
-    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, b.g[k].n_lsp));
+    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride));
     static thread_local uint32_t configured = 0;
     if (int e = configure_lds(reinterpret_cast<const void *>(gscan_kernel), lds, configured)) return e;
     if (b.count == 0 || b.g[0].n == 0) return 0;
@@ -422,21 +471,64 @@ __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uin
     return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;
 }
 
-__global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a) {
+// LDS-resident copies of the small read-mostly program tables (LT = true): trigger lists, rule headers and DNF literals are
+// gathered several times per 64-request group, and each gather from L2 is a ~1 us round trip that the few waves a CU can hold
+// (the column files fill LDS) cannot hide.
+struct VerdictTables {
+    uint32_t bitcol, trig_off, trig_rules, rules, lits, end;  // byte offsets from the start of the table region
+};
+__host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool lt) {
+    VerdictTables t;
+    t.bitcol = 0;
+    t.trig_off = kBitColEntries * 4;
+    t.trig_rules = t.trig_off + (lt ? ((n_cols + 1) * 2 + 3) & ~3u : 0u);
+    t.rules = t.trig_rules + (lt ? (n_trig * 2 + 7) & ~7u : 0u);
+    t.lits = t.rules + (lt ? n_rules * 8 : 0u);
+    t.end = t.lits + (lt ? n_lits * 4 : 0u);
+    return t;
+}
+
+template <bool LT>
+__global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const uint32_t colw = (a.n_cols + 31) / 32, rulew = (a.n_rules + 31) / 32;
-    unsigned char *mine = lds + (size_t)wave * verdict_wave_lds(a.n_cols, a.n_rules);
+    const uint32_t wave_bytes = verdict_wave_lds(a.n_cols, a.n_rules);
+    unsigned char *mine = lds + (size_t)wave * wave_bytes;
     unsigned long long *col = reinterpret_cast<unsigned long long *>(mine);
     uint32_t *colnz = reinterpret_cast<uint32_t *>(mine + (size_t)a.n_cols * 8);
     uint32_t *rulebm = colnz + colw;
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
-    uint32_t *bitcol = reinterpret_cast<uint32_t *>(lds + (size_t)kVerdictWaves * verdict_wave_lds(a.n_cols, a.n_rules));
-    for (uint32_t k = tid; k < kBitColEntries; k += kVerdictThreads) bitcol[k] = a.bit_col[k];
+    unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
+    const VerdictTables vt = verdict_tables(a.n_cols, a.n_rules, a.n_trig, a.n_lits, LT);
+    uint32_t *bitcol = reinterpret_cast<uint32_t *>(tables + vt.bitcol);
+    uint16_t *l_trig_off = reinterpret_cast<uint16_t *>(tables + vt.trig_off);
+    uint16_t *l_trig_rules = reinterpret_cast<uint16_t *>(tables + vt.trig_rules);
+    uint2 *l_rules = reinterpret_cast<uint2 *>(tables + vt.rules);
+    uint32_t *l_lits = reinterpret_cast<uint32_t *>(tables + vt.lits);
+    for (uint32_t k = tid; k < kBitColEntries; k += blockDim.x) bitcol[k] = a.bit_col[k];
+    if (LT) {
+        for (uint32_t k = tid; k <= a.n_cols; k += blockDim.x) l_trig_off[k] = (uint16_t)a.trig_off[k];
+        for (uint32_t k = tid; k < a.n_trig; k += blockDim.x) l_trig_rules[k] = a.trig_rules[k];
+        for (uint32_t k = tid; k < a.n_rules; k += blockDim.x) {
+            const DevRule dr = a.rules[k];  // header without the public index (only read when the rule decides a request)
+            l_rules[k] = make_uint2(dr.lit_off, dr.lit_cnt | ((uint32_t)dr.eff_unverified << 16) | ((uint32_t)dr.eff_verified << 24));
+        }
+        for (uint32_t k = tid; k < a.n_lits; k += blockDim.x) l_lits[k] = a.lits[k];
+    }
     __syncthreads();
     const unsigned long long mybit = 1ull << lane;
     const unsigned long long lt_mask = mybit - 1;
     unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;  // wave-uniform tallies
+
+    // group-invariant tables, fetched once per wave: the comparison atoms (lane j keeps atom j of the first 64) and this
+    // lane's word of the always-candidate bitmap
+    uint32_t h_col = 0, h_c = 0;
+    if (lane < a.n_cmp) {
+        h_col = a.cmp[lane].col;
+        h_c = a.cmp[lane].c;
+    }
+    const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
 
     // a lane marks "atom c holds for my request": its bit in the column word, and the column in the non-zero bitmap
     auto set_col = [&](uint32_t c) {
@@ -444,18 +536,7 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         atomicOr(&colnz[c >> 5], 1u << (c & 31));
     };
 
-    // group-invariant tables, fetched once per wave: the comparison-atom descriptors (lane j keeps atom j) and this lane's
-    // word of the always-candidate bitmap
-    uint32_t h_col = 0, h_meta = 0, h_c = 0;
-    if (lane < a.n_num_atoms) {
-        const NumAtomDev d = a.num_atoms[lane];
-        h_col = d.col;
-        h_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
-        h_c = (uint32_t)(unsigned long long)d.c;  // the engine folds constants outside [0, 2^32) away
-    }
-    const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
-
-    for (uint32_t g = blockIdx.x * kVerdictWaves + wave; g < a.n_groups; g += gridDim.x * kVerdictWaves) {
+    for (uint32_t g = blockIdx.x * n_waves + wave; g < a.n_groups; g += gridDim.x * n_waves) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
         const unsigned long long valid_mask = __ballot(valid);
@@ -469,11 +550,14 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         if (lane == 0) col[0] = ~0ull;
 
         // this lane's request columns: requested now, consumed after the hit records (their latency overlaps section 2)
-        uint32_t len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};
+        uint32_t len0 = 0, len1 = 0, len2 = 0, len3 = 0, len4 = 0;
         uint32_t port = 0, flags = 0, r_geo = 0, r_set = 0, r_port = 0, r_asn = 0, asn = 0;
         if (valid) {
-#pragma unroll
-            for (int f = 0; f < PWAF_N_FIELDS; f++) len[f] = a.off[f][i + 1] - a.off[f][i];
+            len0 = a.off[0][i + 1] - a.off[0][i];
+            len1 = a.off[1][i + 1] - a.off[1][i];
+            len2 = a.off[2][i + 1] - a.off[2][i];
+            len3 = a.off[3][i + 1] - a.off[3][i];
+            len4 = a.off[4][i + 1] - a.off[4][i];
             port = a.port[i];
             flags = a.flags[i];
             r_geo = a.attr[i];
@@ -574,33 +658,39 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                 }
             }
         }
-        // 3b. comparison atoms (lengths, port, asn against constants): few. Descriptors are fetched 64 at a time, one per lane,
-        //     and broadcast with v_readlane; atom j's 64-request ballot is parked in lane j, one ds_write_b64 per chunk.
-        for (uint32_t base = 0; base < a.n_num_atoms && !(a.debug_skip & 4u); base += 64) {
-            uint32_t m_col = h_col, m_meta = h_meta, m_clo = h_c;
+        // 3b. comparison atoms (lengths, port, asn against constants): few. The engine has reduced them to `v == c` / `v <= c` and
+        //     sorted them by variable and operator (cmp_seg), so each one is a scalar broadcast of its constant, one vector
+        //     compare whose 64-request ballot is parked in the atom's lane, and one LDS store per 64 atoms.
+        for (uint32_t base = 0; base < a.n_cmp && !(a.debug_skip & 4u); base += 64) {
+            uint32_t m_col = h_col, m_c = h_c;
             if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
-                m_col = m_meta = m_clo = 0;
-                if (base + lane < a.n_num_atoms) {
-                    const NumAtomDev d = a.num_atoms[base + lane];
-                    m_col = d.col;
-                    m_meta = (uint32_t)d.kind | ((uint32_t)d.var << 8) | ((uint32_t)d.op << 16);
-                    m_clo = (uint32_t)(unsigned long long)d.c;
+                m_col = m_c = 0;
+                if (base + lane < a.n_cmp) {
+                    m_col = a.cmp[base + lane].col;
+                    m_c = a.cmp[base + lane].c;
                 }
             }
-            const uint32_t cntd = min(64u, a.n_num_atoms - base);
             uint32_t acc_lo = 0, acc_hi = 0;
-            for (uint32_t j = 0; j < cntd; j++) {
-                const uint32_t meta = __builtin_amdgcn_readlane(m_meta, j);
-                const uint32_t kind = meta & 0xFFu, var = (meta >> 8) & 0xFFu, op = meta >> 16;
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(m_clo, j);
-                uint32_t v;
-                if (kind == ATOM_LEN) v = var == 0 ? len[0] : var == 1 ? len[1] : var == 2 ? len[2] : var == 3 ? len[3] : len[4];
-                else v = var == VAR_PORT ? port : asn;
-                const unsigned long long m = __ballot(cmp_u32(v, op, c) && valid);
-                acc_lo = lane == j ? (uint32_t)m : acc_lo;
-                acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
-            }
-            if (lane < cntd && (acc_lo | acc_hi)) {
+            auto cmp_var = [&](const uint32_t v, const int vi) {
+#pragma unroll
+                for (int op = 0; op < 2; op++) {
+                    const uint32_t lo = max((uint32_t)a.cmp_seg[2 * vi + op], base), hi = min((uint32_t)a.cmp_seg[2 * vi + op + 1], base + 64);
+                    for (uint32_t j = lo; j < hi; j++) {
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m_c, (int)(j - base));
+                        const unsigned long long m = __ballot(op == 0 ? v == c : v <= c) & valid_mask;
+                        acc_lo = lane == j - base ? (uint32_t)m : acc_lo;
+                        acc_hi = lane == j - base ? (uint32_t)(m >> 32) : acc_hi;
+                    }
+                }
+            };
+            cmp_var(len0, 0);
+            cmp_var(len1, 1);
+            cmp_var(len2, 2);
+            cmp_var(len3, 3);
+            cmp_var(len4, 4);
+            cmp_var(port, 5);
+            cmp_var(asn, 6);
+            if (base + lane < a.n_cmp && (acc_lo | acc_hi)) {
                 col[m_col] = ((unsigned long long)acc_hi << 32) | acc_lo;
                 atomicOr(&colnz[m_col >> 5], 1u << (m_col & 31));
             }
@@ -614,8 +704,9 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
             while (nz) {
                 const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
                 nz &= nz - 1;
-                for (uint32_t k = a.trig_off[c]; k < a.trig_off[c + 1]; k++) {
-                    const uint32_t r = a.trig_rules[k];
+                const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
+                for (uint32_t k = kb; k < ke; k++) {
+                    const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
                     atomicOr(&rulebm[r >> 5], 1u << (r & 31));
                 }
             }
@@ -645,15 +736,26 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
         for (uint32_t base = 0; base < n_cand && pending != 0 && !(a.debug_skip & 32u); base += 64) {
             unsigned long long fire = 0;
-            uint32_t eff_u = 0, eff_v = 0, pub = 0;
+            uint32_t eff_u = 0, eff_v = 0, my_cand = 0;
             if (base + lane < n_cand) {
-                const DevRule dr = a.rules[cand[base + lane]];
-                eff_u = dr.eff_unverified;
-                eff_v = dr.eff_verified;
-                pub = dr.public_idx;
+                my_cand = cand[base + lane];
+                uint32_t lit_off, lit_cnt;
+                if (LT) {
+                    const uint2 hdr = l_rules[my_cand];
+                    lit_off = hdr.x;
+                    lit_cnt = hdr.y & 0xFFFFu;
+                    eff_u = (hdr.y >> 16) & 0xFFu;
+                    eff_v = hdr.y >> 24;
+                } else {
+                    const DevRule dr = a.rules[my_cand];
+                    lit_off = dr.lit_off;
+                    lit_cnt = dr.lit_cnt;
+                    eff_u = dr.eff_unverified;
+                    eff_v = dr.eff_verified;
+                }
                 unsigned long long acc_or = 0, acc_and = ~0ull;
-                for (uint32_t k = dr.lit_off; k < dr.lit_off + dr.lit_cnt; k++) {
-                    const uint32_t lit = a.lits[k];
+                for (uint32_t k = lit_off; k < lit_off + lit_cnt; k++) {
+                    const uint32_t lit = LT ? l_lits[k] : a.lits[k];
                     unsigned long long c = col[lit & LIT_ATOM_MASK];
                     if (lit & LIT_NEG) c = ~c;
                     acc_and &= c;
@@ -674,10 +776,10 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
                 const unsigned long long newly = (((unsigned long long)fhi << 32) | flo) & pending;
                 pending &= ~newly;
                 const uint32_t ju = __builtin_amdgcn_readlane(eff_u, j), jv = __builtin_amdgcn_readlane(eff_v, j);
-                const uint32_t jp = __builtin_amdgcn_readlane(pub, j);
+                const uint32_t jc = __builtin_amdgcn_readlane(my_cand, j);
                 if (newly & mybit) {
                     my_action = (verified_mask & mybit) ? jv : ju;
-                    my_rule = jp;
+                    my_rule = a.rules[jc].public_idx;  // rare (a request that is not allowed): one gather
                 }
             }
         }
@@ -716,7 +818,6 @@ __global__ __launch_bounds__(kVerdictThreads) void verdict_kernel(VerdictArgs a)
     }
 }
 
-uint32_t verdict_lds_bytes(uint32_t n_cols, uint32_t n_rules) { return kVerdictWaves * verdict_wave_lds(n_cols, n_rules) + kBitColEntries * 4; }
 
 // -------------------------------------------------------------------------------------------------
 // attributes: GeoIP record, ip-list membership, country / integer-set membership — one thread per request
@@ -797,19 +898,36 @@ int launch_attr(const VerdictArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
+// Workgroup shape of the verdict kernel: as many waves as LDS (160 KiB) holds column files for, next to one copy of the program
+// tables; if the tables do not leave room for at least 4 column files they stay in global memory (LT = false).
+static constexpr uint32_t kLdsPerGroup = 160u * 1024u;
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits) {
+    VerdictShape s{};
+    const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
+    const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
+    const bool fits = n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
+    s.lds_tables = fits ? 1 : 0;
+    const uint32_t tables = fits ? t_lds : t_glb;
+    uint32_t w = tables + wave <= kLdsPerGroup ? (kLdsPerGroup - tables) / wave : 0;
+    if (!fits) w = std::min(w, 4u);  // small workgroups: several share a CU
+    s.waves = std::min(w, 16u);
+    s.lds_bytes = tables + s.waves * wave;
+    return s;
+}
+
 int launch_verdict(const VerdictArgs &a, void *stream) {
-    uint32_t lds = verdict_lds_bytes(a.n_cols, a.n_rules);
-    static thread_local uint32_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(verdict_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = lds;
-    }
-    uint32_t blocks = (a.n_groups + kVerdictWaves - 1) / kVerdictWaves;
-    if (blocks > 2048) blocks = 2048;
+    const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits);
+    if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
+    const void *fn = sh.lds_tables ? reinterpret_cast<const void *>(verdict_kernel<true>) : reinterpret_cast<const void *>(verdict_kernel<false>);
+    static thread_local uint32_t configured[2] = {0, 0};
+    if (int e = configure_lds(fn, sh.lds_bytes, configured[sh.lds_tables])) return e;
+    uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
+    const uint32_t cap = sh.lds_tables ? 1024u : 2048u;  // a few rounds per CU: the tail stays short, table staging stays negligible
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(verdict_kernel, dim3(blocks), dim3(kVerdictThreads), lds, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    void *args[] = {const_cast<VerdictArgs *>(&a)};
+    hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(sh.waves * 64), args, sh.lds_bytes, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
 }  // namespace pwaf

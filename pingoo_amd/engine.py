@@ -95,6 +95,7 @@ def lib():
     L.pwaf_evaluate_one.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
+    L.pwaf_engine_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
     L.pwaf_engine_kernel_times.argtypes = [vp, C.POINTER(_abi.KernelTime), C.c_int]
     L.pwaf_derive_path.argtypes = [C.c_char_p, C.c_size_t]
     L.pwaf_derive_path.restype = C.c_size_t
@@ -323,6 +324,13 @@ class RuleEngine:
     def device_status(self) -> None:
         """Synchronises and raises if the last device-resident batch ran out of scan scratch."""
         rc = lib().pwaf_engine_device_status(self._h)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+
+    def tune(self, sample: RequestBatch) -> None:
+        """Re-selects the LDS-resident DFA rows from a host traffic sample (speed only; verdicts never change)."""
+        st = sample.as_struct()
+        rc = lib().pwaf_engine_tune(self._h, C.byref(st))
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
 

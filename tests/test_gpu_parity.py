@@ -119,6 +119,24 @@ def test_device_resident_api_counts_and_match_compaction():
     eng.close()
 
 
+def test_tuning_changes_speed_only_never_verdicts():
+    """pwaf_engine_tune re-selects the LDS-resident DFA rows from a traffic sample; tiny LDS budgets force most rows cold, so
+    the cold / emitting / parked paths of the scan kernel are all exercised before and after tuning."""
+    from synth import pysynth
+
+    w = pysynth.Workload(2)
+    batch = w.batch(0, 20000)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=8)
+    for budget in (0, 4096, 1024):
+        eng = RuleEngine(w.rules, w.lists, w.geoip, lds_table_budget=budget)
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"untuned, budget {budget}")
+        eng.tune(w.batch(500000, 3000))
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"tuned, budget {budget}")
+        eng.tune(RequestBatch.from_requests([Request(path="/zzzz", url="/zzzz?" + "q" * 50)]))  # a useless profile is still correct
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"mis-tuned, budget {budget}")
+        eng.close()
+
+
 def test_full_size_config2_properties():
     """1M requests x 256 rules (BASELINE.json configs[1]) — too big for the oracle to check exhaustively in seconds, so:
     (1) a random 8k sample is checked bit-exactly, (2) counters == histogram of the verdict array (checksum of checksums),
