@@ -97,7 +97,7 @@ struct pwaf_engine {
     // per-call scratch (guarded by mu)
     std::mutex mu;
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
-    DevBuf colmask, gate_lists, attr;
+    DevBuf colmask, gate_lists, attr, dir24;
     uint32_t n_ungated = 0, n_gated = 0;
     unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
@@ -229,6 +229,22 @@ int validate_batch_header(const pwaf_batch *b) {
     return PWAF_OK;
 }
 
+// the trie part of the kernel arguments (shared by the per-batch pipeline and the one-off DIR-24 table build)
+void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
+    const Program &P = *e->prog.p;
+    v.ip_root4 = P.ipset_trie.root4.empty() ? nullptr : (const uint32_t *)e->ip_root4.p;
+    v.ip_root6 = P.ipset_trie.root6.empty() ? nullptr : (const uint32_t *)e->ip_root6.p;
+    v.ip_nodes = (const uint32_t *)e->ip_nodes.p;
+    v.set_masks = (const uint32_t *)e->set_masks.p;
+    v.set_words = P.set_words;
+    v.n_ip_lists = P.n_ip_lists;
+    v.geo_root4 = P.geo_trie.root4.empty() ? nullptr : (const uint32_t *)e->geo_root4.p;
+    v.geo_root6 = P.geo_trie.root6.empty() ? nullptr : (const uint32_t *)e->geo_root6.p;
+    v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
+    v.has_geo = P.has_geo ? 1u : 0u;
+    v.dir24 = (const uint64_t *)e->dir24.p;
+}
+
 int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
                  uint32_t *d_n_matches, hipStream_t stream) {
     const Program &P = *e->prog.p;
@@ -307,15 +323,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.rules = (const DevRule *)e->rules.p;
     v.n_rules = (uint32_t)P.rules.size();
     v.lits = (const uint32_t *)e->lits.p;
-    v.ip_root4 = P.ipset_trie.root4.empty() ? nullptr : (const uint32_t *)e->ip_root4.p;
-    v.ip_root6 = P.ipset_trie.root6.empty() ? nullptr : (const uint32_t *)e->ip_root6.p;
-    v.ip_nodes = (const uint32_t *)e->ip_nodes.p;
-    v.set_masks = (const uint32_t *)e->set_masks.p;
-    v.set_words = P.set_words;
-    v.n_ip_lists = P.n_ip_lists;
-    v.geo_root4 = P.geo_trie.root4.empty() ? nullptr : (const uint32_t *)e->geo_root4.p;
-    v.geo_root6 = P.geo_trie.root6.empty() ? nullptr : (const uint32_t *)e->geo_root6.p;
-    v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
+    set_trie_args(e, v);
     v.geo_rows = (const uint32_t *)e->geo_recs.p;
     v.geo_row_words = e->geo_row_words;
     v.has_geo = P.has_geo ? 1u : 0u;
@@ -723,6 +731,18 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         UP(geo_recs, rows)
     }
 #undef UP
+    if ((P.has_geo && !P.geo_trie.root4.empty()) || (P.n_ip_lists && !P.ipset_trie.root4.empty())) {
+        // DIR-24-8: one 128 MiB table (2^24 x 8 B) so that an IPv4 address resolves its GeoIP record AND its ip-list membership set
+        // with a single gather; built on the device from the two tries that were just uploaded
+        if ((rc = e->dir24.reserve((size_t)8 << 24))) return dev_fail(rc);
+        VerdictArgs tv{};
+        const void *table = e->dir24.p;
+        e->dir24.p = nullptr;  // (the builder itself must walk from the roots)
+        set_trie_args(e.get(), tv);
+        e->dir24.p = const_cast<void *>(table);
+        int he = launch_dir24(tv, e->dir24.p, nullptr);
+        if (he || hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
+    }
     if (hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "device synchronize failed after table upload"); return dev_fail(PWAF_E_DEVICE); }
     *out = e.release();
     return PWAF_OK;
@@ -732,7 +752,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }

@@ -103,6 +103,7 @@ struct VerdictArgs {
     uint32_t set_words;
     uint32_t n_ip_lists;
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
+    const uint64_t *dir24;        // IPv4: first 24 bits of both tries flattened, geo entry | ip-list entry << 32 (null = walk from the roots)
     const uint32_t *geo_rows;   // per GeoIP record: asn, country, country-table words, asn-set words (row 0 = default {0,"XX"})
     uint32_t geo_row_words;
     uint32_t has_geo;
@@ -126,6 +127,7 @@ int launch_scan(const ScanArgs &a, void *stream);
 int launch_scan_gated(const GatedArgs &b, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 int launch_attr(const VerdictArgs &a, void *stream);
+int launch_dir24(const VerdictArgs &a, void *out, void *stream);  // out: 2^24 x uint64
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;

@@ -827,8 +827,9 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 // LDS column file caps it at a few waves per CU, the same chains cost ~0.5 ms per 10M requests. The memberships found are
 // written as one more hit-record pass whose "local atoms" are column numbers (pass base 0).
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
+  // A small persistent grid (grid-stride loop): the kernel is meant to run BESIDE the scan kernels, whose workgroups need 16 free
+  // wave slots and most of a CU's LDS at once; a few resident waves per CU leave them that room for the whole scan phase.
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
     const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
     const uint32_t ipw[4] = {raw.x, raw.y, raw.z, raw.w};
     const bool v6 = a.ip_is_v6[i] != 0;
@@ -849,12 +850,22 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
         }
     }
-    const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
-    const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
     uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
-    if (geo_walk && groot != nullptr) eg = groot[top];
-    if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
-    for (uint32_t k = 2; !((eg & ei) & TRIE_LEAF); k++) {
+    uint32_t k = 2;
+    if (!v6 && a.dir24 != nullptr) {
+        // IPv4: ONE gather into the 2^24-entry table that flattens the first three levels of BOTH tries (DIR-24-8: sized for
+        // HBM, not for a cache). Prefixes longer than /24 leave a node index and continue below.
+        const unsigned long long e = a.dir24[(ip_byte(ipw, 0) << 16) | (ip_byte(ipw, 1) << 8) | ip_byte(ipw, 2)];
+        if (geo_walk) eg = (uint32_t)e;
+        ei = (uint32_t)(e >> 32);
+        k = 3;
+    } else {
+        const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
+        const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
+        if (geo_walk && groot != nullptr) eg = groot[top];
+        if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
+    }
+    for (; !((eg & ei) & TRIE_LEAF); k++) {
         const uint32_t byte = ip_byte(ipw, k);
         const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
         const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
@@ -890,11 +901,35 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
     a.attr_out[(size_t)a.n + i] = set_id;
     a.attr_out[2 * (size_t)a.n + i] = r_int[0];
     if (!from_row) a.attr_out[3 * (size_t)a.n + i] = r_int[1];
+  }
+}
+
+// Flattens the first 24 bits of the GeoIP trie and the ip-list trie (IPv4 family) into one table of {geo entry, set entry}: an
+// entry is a leaf (TRIE_LEAF | value) or, for prefixes longer than /24, the index of the node that continues the walk.
+__global__ __launch_bounds__(256) void dir24_kernel(VerdictArgs a, unsigned long long *out) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;  // the top 24 address bits
+    if (x >= (1u << 24)) return;
+    uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;
+    if (a.has_geo && a.geo_root4 != nullptr) {
+        eg = a.geo_root4[x >> 8];
+        if (!(eg & TRIE_LEAF)) eg = a.geo_nodes[(size_t)eg * 256 + (x & 0xFFu)];
+    }
+    if (a.n_ip_lists && a.ip_root4 != nullptr) {
+        ei = a.ip_root4[x >> 8];
+        if (!(ei & TRIE_LEAF)) ei = a.ip_nodes[(size_t)ei * 256 + (x & 0xFFu)];
+    }
+    out[x] = (unsigned long long)eg | ((unsigned long long)ei << 32);
+}
+
+int launch_dir24(const VerdictArgs &a, void *out, void *stream) {
+    hipLaunchKernelGGL(dir24_kernel, dim3((1u << 24) / 256), dim3(256), 0, (hipStream_t)stream, a, (unsigned long long *)out);
+    return (int)hipGetLastError();
 }
 
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    hipLaunchKernelGGL(attr_kernel, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, 1024u);  // ~4 workgroups = 16 waves per CU
+    hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
