@@ -88,7 +88,6 @@ struct pwaf_engine {
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
     uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, geo_row_words = 2, n_trig = 0;
-    uint16_t cmp_seg[15] = {0};
     std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
     std::vector<int64_t> host_iu_vals1;
     DevBuf iu_vals[2], iu_masks[2];
@@ -257,7 +256,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     const uint64_t pool_cap64 = std::max<uint64_t>(1u << 20, (uint64_t)n * 8);
     const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
     if ((rc = e->rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
-    if ((rc = e->attr.reserve((size_t)n * 16))) return rc;  // the attribute kernel's four row-index columns
+    // the attribute kernel's output: per group a header and room for EVERY non-scan atom (worst case: no overflow path), plus 64
+    // pairs of slack so the verdict kernel may read a full wave's worth unconditionally
+    const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms);
+    if ((rc = e->attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     if ((rc = e->ctrl.reserve(4 * 34))) return rc;
     HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
@@ -300,12 +302,12 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)e->rec.p;
     for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) v.pass_base_v[k] = e->groups[k].atom_base;
-    v.attr_out = (uint32_t *)e->attr.p;
-    v.attr = (const uint32_t *)e->attr.p;
+    v.gpairs = (uint4 *)e->attr.p;
+    v.ghdr = (uint32_t *)((char *)e->attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
+    v.pair_stride = pair_stride;
     v.pool = (const PoolEntry *)e->pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
-    for (int k = 0; k < 15; k++) v.cmp_seg[k] = e->cmp_seg[k];
     v.n_trig = e->n_trig;
     v.n_lits = (uint32_t)P.lits.size();
     v.bit_col = (const uint32_t *)e->bit_atoms.p;
@@ -608,6 +610,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             }
             bit_atoms.push_back(d.col | ((d.ref & 31u) << 20) | (src << 25));
         }
+        e->n_bit_atoms = (uint32_t)bit_atoms.size();
         // (source word, bit) -> column
         std::vector<uint32_t> bit_col(24 * 32, 0);
         for (uint32_t d : bit_atoms) bit_col[(d >> 25) * 32 + ((d >> 20) & 31u)] = d & 0xFFFFFu;
@@ -638,10 +641,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         std::stable_sort(canon.begin(), canon.end(), [](const Canon &x, const Canon &y) { return x.vi != y.vi ? x.vi < y.vi : x.op < y.op; });
         if (canon.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 comparison predicates"); return dev_fail(PWAF_E_UNSUPPORTED); }
         std::vector<CmpAtomDev> cmp_atoms;
-        for (int k = 0; k < 15; k++) e->cmp_seg[k] = 0;
         for (const Canon &cn : canon) {
-            cmp_atoms.push_back({cn.col, cn.c});
-            for (uint32_t k = 2 * cn.vi + cn.op + 1; k < 15; k++) e->cmp_seg[k]++;  // seg[k] = number of atoms in segments before k
+            cmp_atoms.push_back({cn.col | ((2 * cn.vi + cn.op) << 24), cn.c});
         }
         e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
         UP(num_atoms, cmp_atoms)

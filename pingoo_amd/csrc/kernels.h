@@ -80,9 +80,9 @@ struct VerdictArgs {
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;
-    const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant), sorted by variable and operator
+    const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant): col = column | code << 24 with
+                                  // code = 2 * variable (0-4 field lengths, 5 port, 6 asn) + operator (0: ==, 1: <=)
     uint32_t n_cmp;
-    uint16_t cmp_seg[15];         // variable vi (0-4 field lengths, 5 port, 6 asn): atoms [seg[2vi], seg[2vi+1]) test ==, [seg[2vi+1], seg[2vi+2]) test <=
     const uint32_t *bit_col;      // [24 source words][32 bits] -> column of the membership atom, 0 = none
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
@@ -107,9 +107,11 @@ struct VerdictArgs {
     const uint32_t *geo_rows;   // per GeoIP record: asn, country, country-table words, asn-set words (row 0 = default {0,"XX"})
     uint32_t geo_row_words;
     uint32_t has_geo;
-    // attribute kernel (runs before the verdict kernel): per request the row indices of its membership rows
-    uint32_t *attr_out;      // [4][n]: GeoIP record (or country index), ip-list set, port-set row, asn-set row
-    const uint32_t *attr;    // the same, as the verdict kernel reads it
+    // attribute kernel -> verdict kernel: per 64-request group the (column, mask) pairs of every non-scan atom that holds for
+    // some request of the group. gpairs[g * pair_stride + k] = {column, 0, mask lo, mask hi}, ghdr[g] = number of pairs
+    uint4 *gpairs;
+    uint32_t *ghdr;
+    uint32_t pair_stride;
     // outputs
     pwaf_verdict *out;
     unsigned long long *counts;  // 4, accumulated (nullable)

@@ -464,6 +464,19 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// Inclusive prefix sum over the 64 lanes, same DPP network (no LDS round trips, unlike __shfl_up).
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+#define PWAF_DPP_ADD(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (ctrl), (rows), 0xF, true)
+    PWAF_DPP_ADD(0x111, 0xF);  // row_shr:1
+    PWAF_DPP_ADD(0x112, 0xF);  // row_shr:2
+    PWAF_DPP_ADD(0x114, 0xF);  // row_shr:4
+    PWAF_DPP_ADD(0x118, 0xF);  // row_shr:8   -> inclusive scan inside each row of 16
+    PWAF_DPP_ADD(0x142, 0xA);  // row_bcast:15: rows 1 and 3 add the total of the row before
+    PWAF_DPP_ADD(0x143, 0xC);  // row_bcast:31: rows 2 and 3 add the total of rows 0-1
+#undef PWAF_DPP_ADD
+    return x;
+}
+
 static constexpr uint32_t kBitColEntries = 24 * 32;  // (source word, bit) -> column table, shared by the block in LDS
 
 __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
@@ -521,13 +534,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     const unsigned long long lt_mask = mybit - 1;
     unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;  // wave-uniform tallies
 
-    // group-invariant tables, fetched once per wave: the comparison atoms (lane j keeps atom j of the first 64) and this
-    // lane's word of the always-candidate bitmap
-    uint32_t h_col = 0, h_c = 0;
-    if (lane < a.n_cmp) {
-        h_col = a.cmp[lane].col;
-        h_c = a.cmp[lane].c;
-    }
+    // group-invariant, fetched once per wave: this lane's word of the always-candidate bitmap
     const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
 
     // a lane marks "atom c holds for my request": its bit in the column word, and the column in the non-zero bitmap
@@ -549,25 +556,12 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
 
-        // this lane's request columns: requested now, consumed after the hit records (their latency overlaps section 2)
-        uint32_t len0 = 0, len1 = 0, len2 = 0, len3 = 0, len4 = 0;
-        uint32_t port = 0, flags = 0, r_geo = 0, r_set = 0, r_port = 0, r_asn = 0, asn = 0;
-        if (valid) {
-            len0 = a.off[0][i + 1] - a.off[0][i];
-            len1 = a.off[1][i + 1] - a.off[1][i];
-            len2 = a.off[2][i + 1] - a.off[2][i];
-            len3 = a.off[3][i + 1] - a.off[3][i];
-            len4 = a.off[4][i + 1] - a.off[4][i];
-            port = a.port[i];
-            flags = a.flags[i];
-            r_geo = a.attr[i];
-            r_set = a.attr[(size_t)a.n + i];
-            r_port = a.attr[2 * (size_t)a.n + i];
-            if (a.asn != nullptr) {
-                r_asn = a.attr[3 * (size_t)a.n + i];
-                asn = a.asn[i];
-            }
-        }
+        // requested now, consumed after the hit records (their latency overlaps section 2): the captcha flag and the group's
+        // (column, mask) pairs from the attribute kernel
+        const uint32_t flags = valid ? (uint32_t)a.flags[i] : 0u;
+        const uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
+        const uint32_t n_pairs = a.ghdr[g];
+        const uint4 pair0 = pairs[lane];  // (the buffer is padded: reading past the group's count is harmless)
 
         // 2. scan results: each lane marks the columns its hit records name. The records of 8 passes are requested together
         //    (independent loads, one wait) before any of them is examined.
@@ -611,88 +605,14 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
             }
         }
 
-        // 3. membership atoms (ip lists, country tables, integer sets). The attribute kernel has resolved every dependent
-        //    lookup to a row index; the rows are gathered together (independent loads, one wait) and each SET BIT is one atom
-        //    that holds for this request, translated to its column through bit_col. Work is proportional to the number of
-        //    memberships, not to the number of lists / predicates.
+        // 3. everything that is not a string scan (memberships, comparisons) arrives from the attribute kernel as ready-made
+        //    column words: one lane per pair, a plain LDS store each
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
         if (!(a.debug_skip & 2u)) {
-            const bool from_row = a.asn == nullptr;
-            // per GeoIP record the engine has precomputed everything that depends on (asn, country); a batch that brings its own
-            // asn / country columns uses the per-country rows and the asn-set rows instead
-            const uint32_t *grow = from_row ? a.geo_rows + (size_t)r_geo * a.geo_row_words + 2 : a.country_masks + (size_t)r_geo * a.cc_words;
-            const uint32_t *arow = from_row ? grow + a.cc_words : a.iu_masks[1] + (size_t)r_asn * a.iu_words[1];
-            const uint32_t *prow = a.iu_masks[0] + (size_t)r_port * a.iu_words[0];
-            const uint32_t *srow = a.set_masks + (size_t)r_set * a.set_words;
-            uint32_t mw[24];  // this lane's membership words, by source word: 0-7 ip lists, 8-15 country tables, 16-19 port sets, 20-23 asn sets
-#pragma unroll
-            for (uint32_t wv = 0; wv < 8; wv++) mw[wv] = (valid && wv < a.set_words && r_set) ? srow[wv] : 0u;
-#pragma unroll
-            for (uint32_t wv = 0; wv < 8; wv++) mw[8 + wv] = (valid && wv < a.cc_words) ? grow[wv] : 0u;
-#pragma unroll
-            for (uint32_t wv = 0; wv < 4; wv++) mw[16 + wv] = (valid && wv < a.iu_words[0] && r_port) ? prow[wv] : 0u;
-#pragma unroll
-            for (uint32_t wv = 0; wv < 4; wv++) mw[20 + wv] = (valid && wv < a.iu_words[1] && (from_row || r_asn)) ? arow[wv] : 0u;
-            if (valid && from_row) asn = grow[-2];
-            // A membership word is transposed in registers: one ballot per bit that ANY of the 64 requests has set (wave-wide OR
-            // first, so absent bits cost nothing); lane b keeps bit b's request mask and stores it to that atom's column.
-#pragma unroll
-            for (uint32_t src = 0; src < 24; src++) {
-                const uint32_t lim = src < 8 ? a.set_words : src < 16 ? a.cc_words + 8 : src < 20 ? a.iu_words[0] + 16 : a.iu_words[1] + 20;
-                if (src >= lim) continue;
-                const uint32_t w = mw[src];
-                const uint32_t orw0 = wave_or(w);
-                if (orw0 == 0) continue;
-                unsigned long long mine_m = 0;
-                for (uint32_t orw = orw0; orw; orw &= orw - 1) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(orw);
-                    const unsigned long long m = __ballot((w >> b) & 1u);
-                    if (lane == b) mine_m = m;
-                }
-                if (lane < 32 && ((orw0 >> lane) & 1u)) {
-                    const uint32_t c = bitcol[src * 32 + lane];
-                    if (c) {
-                        atomicOr(&col[c], mine_m);
-                        atomicOr(&colnz[c >> 5], 1u << (c & 31));
-                    }
-                }
-            }
-        }
-        // 3b. comparison atoms (lengths, port, asn against constants): few. The engine has reduced them to `v == c` / `v <= c` and
-        //     sorted them by variable and operator (cmp_seg), so each one is a scalar broadcast of its constant, one vector
-        //     compare whose 64-request ballot is parked in the atom's lane, and one LDS store per 64 atoms.
-        for (uint32_t base = 0; base < a.n_cmp && !(a.debug_skip & 4u); base += 64) {
-            uint32_t m_col = h_col, m_c = h_c;
-            if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
-                m_col = m_c = 0;
-                if (base + lane < a.n_cmp) {
-                    m_col = a.cmp[base + lane].col;
-                    m_c = a.cmp[base + lane].c;
-                }
-            }
-            uint32_t acc_lo = 0, acc_hi = 0;
-            auto cmp_var = [&](const uint32_t v, const int vi) {
-#pragma unroll
-                for (int op = 0; op < 2; op++) {
-                    const uint32_t lo = max((uint32_t)a.cmp_seg[2 * vi + op], base), hi = min((uint32_t)a.cmp_seg[2 * vi + op + 1], base + 64);
-                    for (uint32_t j = lo; j < hi; j++) {
-                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m_c, (int)(j - base));
-                        const unsigned long long m = __ballot(op == 0 ? v == c : v <= c) & valid_mask;
-                        acc_lo = lane == j - base ? (uint32_t)m : acc_lo;
-                        acc_hi = lane == j - base ? (uint32_t)(m >> 32) : acc_hi;
-                    }
-                }
-            };
-            cmp_var(len0, 0);
-            cmp_var(len1, 1);
-            cmp_var(len2, 2);
-            cmp_var(len3, 3);
-            cmp_var(len4, 4);
-            cmp_var(port, 5);
-            cmp_var(asn, 6);
-            if (base + lane < a.n_cmp && (acc_lo | acc_hi)) {
-                col[m_col] = ((unsigned long long)acc_hi << 32) | acc_lo;
-                atomicOr(&colnz[m_col >> 5], 1u << (m_col & 31));
+            for (uint32_t p = lane; p < n_pairs; p += 64) {
+                const uint4 pr = p < 64 ? pair0 : pairs[p];
+                atomicOr(&col[pr.x], ((unsigned long long)pr.w << 32) | pr.z);
+                atomicOr(&colnz[pr.x >> 5], 1u << (pr.x & 31));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -716,12 +636,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         uint32_t n_cand = 0;
         for (uint32_t wb = 0; wb < rulew && !(a.debug_skip & 16u); wb += 64) {
             const uint32_t word = wb + lane < rulew ? rulebm[wb + lane] : 0u;
-            uint32_t pc = (uint32_t)__builtin_popcount(word), incl = pc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-                if (lane >= (uint32_t)d) incl += up;
-            }
+            const uint32_t pc = (uint32_t)__builtin_popcount(word), incl = wave_scan_add(pc);
             uint32_t pos = n_cand + incl - pc, wrd = word;
             while (wrd) {
                 cand[pos++] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(wrd));
@@ -820,88 +735,184 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
 
 // -------------------------------------------------------------------------------------------------
-// attributes: GeoIP record, ip-list membership, country / integer-set membership — one thread per request
+// attributes: everything about a request that is NOT a string scan — GeoIP record, ip-list membership, country / integer-set
+// membership, length / port / asn comparisons — reduced per 64-request group to a list of (column, 64-request mask) pairs
 // -------------------------------------------------------------------------------------------------
-// Everything here is a chain of dependent gathers (trie levels, membership rows). Running it one thread per request at full
-// occupancy (no LDS, few registers) hides that latency behind thousands of other requests; inside the verdict kernel, whose
-// LDS column file caps it at a few waves per CU, the same chains cost ~0.5 ms per 10M requests. The memberships found are
-// written as one more hit-record pass whose "local atoms" are column numbers (pass base 0).
+// The lookups are chains of dependent gathers (DIR-24 / trie levels, membership rows, binary searches); inside the verdict kernel,
+// whose LDS column file caps it at ~9 waves per CU, they cost more than a third of its time. This kernel needs no LDS and does
+// not depend on the scans, so it runs BESIDE them on the engine's side stream (a small persistent grid: the scan workgroups need
+// 16 free wave slots and most of a CU's LDS at once) and is off the critical path. One wave = one group; the verdict kernel
+// only copies the group's pairs into its column file.
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
-  // A small persistent grid (grid-stride loop): the kernel is meant to run BESIDE the scan kernels, whose workgroups need 16 free
-  // wave slots and most of a CU's LDS at once; a few resident waves per CU leave them that room for the whole scan phase.
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
-    const uint32_t ipw[4] = {raw.x, raw.y, raw.z, raw.w};
-    const bool v6 = a.ip_is_v6[i] != 0;
-    uint32_t asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
-    // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
-    // dependent loads overlap instead of queueing behind each other.
-    bool geo_walk = false;
-    if (a.asn != nullptr) {
-        asn = a.asn[i];
-        country = a.country[i];
-    } else if (a.has_geo) {
-        // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
-        if (!v6) {
-            const uint32_t b0 = ipw[0] & 0xFFu;
-            geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
-        } else {
-            const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
-            geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
-        }
-    }
-    uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
-    uint32_t k = 2;
-    if (!v6 && a.dir24 != nullptr) {
-        // IPv4: ONE gather into the 2^24-entry table that flattens the first three levels of BOTH tries (DIR-24-8: sized for
-        // HBM, not for a cache). Prefixes longer than /24 leave a node index and continue below.
-        const unsigned long long e = a.dir24[(ip_byte(ipw, 0) << 16) | (ip_byte(ipw, 1) << 8) | ip_byte(ipw, 2)];
-        if (geo_walk) eg = (uint32_t)e;
-        ei = (uint32_t)(e >> 32);
-        k = 3;
-    } else {
-        const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
-        const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
-        if (geo_walk && groot != nullptr) eg = groot[top];
-        if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
-    }
-    for (; !((eg & ei) & TRIE_LEAF); k++) {
-        const uint32_t byte = ip_byte(ipw, k);
-        const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
-        const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
-        eg = ng;
-        ei = ni;
-    }
-    const uint32_t geo_rec = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
-
-    // Row indices the verdict kernel turns into membership columns with one independent gather each.
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
     const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
-    uint32_t r_geo = geo_rec;
-    if (!from_row) {
-        const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
-        r_geo = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
+    // group-invariant: the first 64 comparison atoms, one per lane (col | code << 24, constant)
+    uint32_t h_col = 0, h_c = 0;
+    if (lane < a.n_cmp) {
+        h_col = a.cmp[lane].col;
+        h_c = a.cmp[lane].c;
     }
-    uint32_t r_int[2] = {0, 0};
-    const uint32_t port = a.port[i];
-#pragma unroll
-    for (int var = 0; var < 2; var++) {
-        if (a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
-        // ONE binary search per request over the union of every set tested against this variable; the hit's row
-        // says which sets contain the value (the reference scans each list per rule: pingoo/lists.rs:119-121)
-        const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
-        uint32_t lo = 0, hi = a.iu_n[var];
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a.iu_vals[var][mid] < v) lo = mid + 1;
-            else hi = mid;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < a.n_groups; g += gridDim.x * 4) {
+        const uint32_t i = g * 64 + lane;
+        const bool valid = i < a.n;
+        const unsigned long long valid_mask = __ballot(valid);
+        uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
+        uint32_t n_pairs = 0;  // wave-uniform
+        // lane-private (column, mask) -> the group's pair list, in lane order
+        auto emit_pairs = [&](const bool has, const uint32_t c, const uint32_t lo, const uint32_t hi) {
+            const unsigned long long em = __ballot(has);
+            if (has) pairs[n_pairs + (uint32_t)__builtin_popcountll(em & lt_mask)] = make_uint4(c, 0u, lo, hi);
+            n_pairs += (uint32_t)__builtin_popcountll(em);
+        };
+
+        uint32_t ipw[4] = {0, 0, 0, 0};
+        bool v6 = false;
+        uint32_t port = 0, asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
+        uint32_t len0 = 0, len1 = 0, len2 = 0, len3 = 0, len4 = 0;
+        if (valid) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
+            ipw[0] = raw.x; ipw[1] = raw.y; ipw[2] = raw.z; ipw[3] = raw.w;
+            v6 = a.ip_is_v6[i] != 0;
+            port = a.port[i];
+            len0 = a.off[0][i + 1] - a.off[0][i];
+            len1 = a.off[1][i + 1] - a.off[1][i];
+            len2 = a.off[2][i + 1] - a.off[2][i];
+            len3 = a.off[3][i + 1] - a.off[3][i];
+            len4 = a.off[4][i + 1] - a.off[4][i];
         }
-        if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) r_int[var] = lo + 1;
+        // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
+        // dependent loads overlap instead of queueing behind each other.
+        bool geo_walk = false;
+        if (valid && !from_row) {
+            asn = a.asn[i];
+            country = a.country[i];
+        } else if (valid && a.has_geo) {
+            // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
+            if (!v6) {
+                const uint32_t b0 = ipw[0] & 0xFFu;
+                geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
+            } else {
+                const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
+                geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
+            }
+        }
+        uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
+        if (valid) {
+            uint32_t k = 2;
+            if (!v6 && a.dir24 != nullptr) {
+                // IPv4: ONE gather into the 2^24-entry table that flattens the first three levels of BOTH tries (DIR-24-8: sized
+                // for HBM, not for a cache). Prefixes longer than /24 leave a node index and continue below.
+                const unsigned long long e = a.dir24[(ip_byte(ipw, 0) << 16) | (ip_byte(ipw, 1) << 8) | ip_byte(ipw, 2)];
+                if (geo_walk) eg = (uint32_t)e;
+                ei = (uint32_t)(e >> 32);
+                k = 3;
+            } else {
+                const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
+                const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
+                if (geo_walk && groot != nullptr) eg = groot[top];
+                if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
+            }
+            for (; !((eg & ei) & TRIE_LEAF); k++) {
+                const uint32_t byte = ip_byte(ipw, k);
+                const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
+                const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
+                eg = ng;
+                ei = ni;
+            }
+        }
+        const uint32_t geo_rec = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
+
+        // Membership rows: per GeoIP record the engine has precomputed everything that depends on (asn, country); a batch that
+        // brings its own asn / country columns uses the per-country rows and the asn-set rows instead. Integer sets: ONE binary
+        // search per request over the union of every set tested against the variable; the hit's row says which sets contain
+        // the value (the reference scans each list per rule: pingoo/lists.rs:119-121).
+        uint32_t r_geo = geo_rec;
+        if (!from_row) {
+            const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
+            r_geo = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
+        }
+        const uint32_t *grow = from_row ? a.geo_rows + (size_t)r_geo * a.geo_row_words + 2 : a.country_masks + (size_t)r_geo * a.cc_words;
+        if (valid && from_row) asn = grow[-2];
+        uint32_t r_int[2] = {0, 0};
+#pragma unroll
+        for (int var = 0; var < 2; var++) {
+            if (!valid || a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
+            const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
+            uint32_t lo = 0, hi = a.iu_n[var];
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.iu_vals[var][mid] < v) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) r_int[var] = lo + 1;
+        }
+        const uint32_t *arow = from_row ? grow + a.cc_words : a.iu_masks[1] + (size_t)r_int[1] * a.iu_words[1];
+        const uint32_t *prow = a.iu_masks[0] + (size_t)r_int[0] * a.iu_words[0];
+        const uint32_t *srow = a.set_masks + (size_t)set_id * a.set_words;
+
+        // A membership word is transposed in registers: one ballot per bit that ANY of the 64 requests has set (wave-wide OR
+        // first, so absent bits cost nothing); lane b keeps bit b's request mask and owns that atom's pair.
+        auto member_words = [&](const uint32_t *row, const bool have, const uint32_t words, const uint32_t src0) {
+            for (uint32_t wv = 0; wv < words; wv++) {
+                const uint32_t w = have ? row[wv] : 0u;
+                const uint32_t orw0 = wave_or(w);
+                if (orw0 == 0) continue;
+                unsigned long long mine_m = 0;
+                for (uint32_t orw = orw0; orw; orw &= orw - 1) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(orw);
+                    const unsigned long long m = __ballot((w >> b) & 1u);
+                    if (lane == b) mine_m = m;
+                }
+                const bool owner = lane < 32 && ((orw0 >> lane) & 1u);
+                const uint32_t c = owner ? a.bit_col[(src0 + wv) * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
+                emit_pairs(c != 0, c, (uint32_t)mine_m, (uint32_t)(mine_m >> 32));
+            }
+        };
+        member_words(srow, valid && a.n_ip_lists && set_id, a.set_words, 0);
+        member_words(grow, valid, a.cc_words, 8);
+        member_words(prow, valid && r_int[0], a.iu_words[0], 16);
+        member_words(arow, valid && (from_row || r_int[1]), a.iu_words[1], 20);
+
+        // Comparison atoms (lengths, port, asn against constants): the engine has reduced them to `v == c` / `v <= c` on 32-bit
+        // values and tagged each with code = 2 * variable + operator; an atom is a scalar broadcast of its constant, one
+        // vector compare and a ballot parked in the atom's lane.
+        for (uint32_t base = 0; base < a.n_cmp; base += 64) {
+            uint32_t m_col = h_col, m_c = h_c;
+            if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
+                m_col = m_c = 0;
+                if (base + lane < a.n_cmp) {
+                    m_col = a.cmp[base + lane].col;
+                    m_c = a.cmp[base + lane].c;
+                }
+            }
+            const uint32_t my_code = base + lane < a.n_cmp ? m_col >> 24 : 0xFFu;
+            uint32_t acc_lo = 0, acc_hi = 0;
+            auto cmp_var = [&](const uint32_t v, const int vi) {
+#pragma unroll
+                for (int op = 0; op < 2; op++) {
+                    unsigned long long todo = __ballot(my_code == (uint32_t)(2 * vi + op));
+                    while (todo) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m_c, (int)j);
+                        const unsigned long long m = __ballot(op == 0 ? v == c : v <= c) & valid_mask;
+                        acc_lo = lane == j ? (uint32_t)m : acc_lo;
+                        acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
+                    }
+                }
+            };
+            cmp_var(len0, 0);
+            cmp_var(len1, 1);
+            cmp_var(len2, 2);
+            cmp_var(len3, 3);
+            cmp_var(len4, 4);
+            cmp_var(port, 5);
+            cmp_var(asn, 6);
+            emit_pairs((acc_lo | acc_hi) != 0, m_col & 0xFFFFFFu, acc_lo, acc_hi);
+        }
+        if (lane == 0) a.ghdr[g] = n_pairs;
     }
-    a.attr_out[i] = r_geo;
-    a.attr_out[(size_t)a.n + i] = set_id;
-    a.attr_out[2 * (size_t)a.n + i] = r_int[0];
-    if (!from_row) a.attr_out[3 * (size_t)a.n + i] = r_int[1];
-  }
 }
 
 // Flattens the first 24 bits of the GeoIP trie and the ip-list trie (IPv4 family) into one table of {geo entry, set entry}: an
@@ -928,7 +939,7 @@ int launch_dir24(const VerdictArgs &a, void *out, void *stream) {
 
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, 1024u);  // ~4 workgroups = 16 waves per CU
+    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, 1024u);  // ~4 workgroups = 16 waves per CU
     hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
