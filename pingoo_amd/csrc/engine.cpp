@@ -76,6 +76,7 @@ struct DevGroup {
     DevBuf tab, classmap, special, list_off, list;
     uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base;
     uint8_t field;
+    uint32_t chunks = 1;  // 16-byte chunks per scan iteration (2 for fields whose sampled mean length is >= 48 bytes)
     int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
 };
 
@@ -388,6 +389,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.list = (const uint16_t *)d.list.p;
         a.start_emit = d.start_emit;
         a.emit_base = d.emit_base;
+        a.chunks = d.gate >= 0 ? 1u : d.chunks;
         a.special_base = d.special_base;
         a.n_states = d.n_states;
         a.stride = d.stride;
@@ -890,6 +892,10 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
                 v[s]++;
             }
         }
+    }
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        const uint32_t *off = sample->field[P.groups[k].field].offsets;
+        e->groups[k].chunks = (uint64_t)(off[n] - off[0]) >= (uint64_t)48 * n ? 2u : 1u;
     }
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)

@@ -170,7 +170,10 @@ __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const 
 
 #define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
 
-template <bool INDIRECT>
+// CH = 16-byte chunks a lane walks per loop iteration. 2 halves the per-byte cost of the pull / finish logic (a third of the
+// vector instructions at CH = 1) but idles a finished lane for up to 31 bytes instead of 15: it pays for long fields (URL,
+// User-Agent), not for short ones (host, method). The engine picks it per pass from the tuning sample's mean field length.
+template <bool INDIRECT, int CH>
 __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t stride2 = a.stride * 2;
@@ -241,7 +244,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     uint32_t crow = 0;                            // byte offset of the current row in the full table while cold
     uint32_t r2 = kNone, p2 = 0, end2 = 0;        // request pulled ahead
     Hits h{0, 0, kNone};
-    u32x4 w = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
+    u32x4 w[CH], wn[CH];
+#pragma unroll
+    for (int q = 0; q < CH; q++) w[q] = wn[q] = u32x4{0, 0, 0, 0};
+    constexpr uint32_t kStep = 16u * CH;  // bytes per iteration
 
     for (;;) {
         // offsets of the NEXT block of 64 work items: re-requested every iteration (L1 hits) instead of once per block inside a
@@ -251,7 +257,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         const uint32_t f_base = blk + 64;
         load_off(f_base, f_lo, f_hi, f_id);
         // ---- 1. pull ahead: lanes on their last chunk (or idle) take the next request of the slab ----
-        const bool last = r == kNone || p + 16 >= end;
+        const bool last = r == kNone || p + kStep >= end;
         const unsigned long long want = __ballot(last && r2 == kNone);
         if (want != 0 && next < w1) {
             const uint32_t avail = min(w1 - next, blk + 64 - next);
@@ -284,14 +290,23 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             // Unconditional (no branch, so no wait is forced here): lanes with nothing to fetch read the arena's first bytes.
             // Unaligned 16-byte load; arenas carry PWAF_ARENA_PAD slack.
             const bool have = last ? (r2 != kNone && p2 < end2) : true;
-            const uint32_t np = have ? (last ? p2 : p + 16) : 0u;
-            wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + np);
+            const uint32_t np = have ? (last ? p2 : p + kStep) : 0u;
+            const uint32_t nend = last ? end2 : end;  // end of the field the next iteration works on
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                // a further chunk is fetched only if the field reaches it: reads never go more than PWAF_ARENA_PAD past a field's end
+                const uint32_t at = (q == 0 || (have && np + 16u * q < nend)) ? np + 16u * q : 0u;
+                wn[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
+            }
         }
 
-        // ---- 2. 16 bytes of every active lane's field ----
+        // ---- 2. 16 * CH bytes of every active lane's field ----
         const bool act = r != kNone && p < end;
-        const uint32_t cnt = act ? min(16u, end - p) : 0u;
-        const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t cnt_all = act ? min(kStep, end - p) : 0u;
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+        const uint32_t cnt = cnt_all > 16u * q ? min(16u, cnt_all - 16u * q) : 0u;  // valid bytes of this chunk
+        const uint32_t wd[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
         uint32_t c2[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -352,7 +367,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
                 row = t4;
             }
         }
-        p += cnt;
+        }  // chunks
+        p += cnt_all;
 
         // ---- 3. finished requests: end-of-field matches, the hit record, then switch to the pulled-ahead request ----
         if (r != kNone && p >= end) {
@@ -372,7 +388,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             h = Hits{0, 0, kNone};
             if (start_emit) PWAF_EMIT(start_emit - 1);
         }
-        w = wn;
+#pragma unroll
+        for (int q = 0; q < CH; q++) w[q] = wn[q];
         n_lo = f_lo;
         n_hi = f_hi;
         n_id = f_id;
@@ -380,13 +397,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     }
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false>(a); }
+template <int CH>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false, CH>(a); }
 
 // Every gated pass of the program in ONE launch (blockIdx.y = pass): their request lists are short, so separate launches were
 // dominated by launch latency and table staging.
 __global__ __launch_bounds__(kScanThreads) void gscan_kernel(GatedArgs b) {
     const ScanArgs a = b.g[blockIdx.y];
-    scan_body<true>(a);
+    scan_body<true, 1>(a);
 }
 
 static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
@@ -399,8 +417,10 @@ static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
 
 int launch_scan(const ScanArgs &a, void *stream) {
     const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
-    static thread_local uint32_t configured = 0;
-    if (int e = configure_lds(reinterpret_cast<const void *>(scan_kernel), lds, configured)) return e;
+    static thread_local uint32_t configured[2] = {0, 0};
+    const int v = a.chunks == 2 ? 1 : 0;
+    const void *fn = v ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
+    if (int e = configure_lds(fn, lds, configured[v])) return e;
     if (a.n == 0) return 0;
     // at least 256 requests per wave so that work-pulling has something to balance; at most two rounds of one
     // workgroup per CU: long slabs keep the pull queue busy until the very end
@@ -408,8 +428,9 @@ int launch_scan(const ScanArgs &a, void *stream) {
     uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
     if (blocks > 512) blocks = 512;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(kScanThreads), lds, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    void *args[] = {const_cast<ScanArgs *>(&a)};
+    hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kScanThreads), args, lds, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
 int launch_scan_gated(const GatedArgs &b, void *stream) {
