@@ -108,6 +108,7 @@ struct pwaf_engine {
     std::vector<pwaf_kernel_time> times;
     size_t n_timed = 0;
     hipStream_t side = nullptr;  // attribute kernel runs here, beside the scans
+    uint32_t n_cus = 256;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -306,6 +307,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.gpairs = (uint4 *)e->attr.p;
     v.ghdr = (uint32_t *)((char *)e->attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
     v.pair_stride = pair_stride;
+    v.attr_blocks = e->n_cus;
     v.pool = (const PoolEntry *)e->pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
@@ -536,6 +538,10 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         return dev_fail(PWAF_E_DEVICE);
     }
     e->device = dev;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = (uint32_t)cus;
+    }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
         fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");

@@ -113,6 +113,7 @@ struct VerdictArgs {
     uint4 *gpairs;
     uint32_t *ghdr;
     uint32_t pair_stride;
+    uint32_t attr_blocks;  // grid of the attribute kernel (the device's CU count)
     // outputs
     pwaf_verdict *out;
     unsigned long long *counts;  // 4, accumulated (nullable)

@@ -20,6 +20,8 @@
 // No MFMA: this is byte/integer work bounded by LDS lookups per input byte and HBM streaming.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace pwaf {
@@ -960,7 +962,11 @@ int launch_dir24(const VerdictArgs &a, void *out, void *stream) {
 
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, 1024u);  // ~4 workgroups = 16 waves per CU
+    // One workgroup (4 waves) per CU: measured best on MI355X. The scan kernels leave ~25 % of the vector issue
+    // slots idle; one attribute wave per SIMD soaks those up over the whole scan phase, whereas a big grid competes with the scans
+    // for issue slots and merely moves time from one kernel to the other.
+    static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;  // profiling only
+    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : std::max(1u, a.attr_blocks));
     hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
