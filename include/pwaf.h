@@ -96,6 +96,20 @@ typedef struct pwaf_geoip_table {
     size_t n_entries;
 } pwaf_geoip_table;
 
+/* ---- data-file readers (the callers' data formats on either side of the path) ----------------------------- */
+/* Flattens a MaxMind DB (the uncompressed content of geoip.mmdb; the reference also accepts .zst, which this library does not
+ * decompress) into the prefix table above: one entry per network of the search tree, IPv4 networks of an IPv6 database (those
+ * below ::/96) emitted as IPv4 entries as well. Records are read the way the reference deserialises them (pingoo/geoip.rs:17-23,
+ * serde_utils.rs:1-9): {"asn": "AS<digits>" string, "country": two upper-case letters}; a record that would make the
+ * reference's lookup fail yields the default {0, "XX"} for its network (http_listener.rs:143-157). Replaces
+ * maxminddb::Reader::from_source + lookup (geoip.rs:57,73-91). *entries_out is malloc'ed: release with pwaf_geoip_free. */
+int pwaf_geoip_from_mmdb(const uint8_t *mmdb, size_t len, pwaf_geoip_entry **entries_out, size_t *n_out);
+void pwaf_geoip_free(pwaf_geoip_entry *entries);
+/* The list-file format of pingoo/lists.rs:62-117: CSV without header, 1 or 2 columns, the first column trimmed is the item.
+ * Returns the items as malloc'ed NUL-terminated strings for pwaf_list_desc.items: release with pwaf_list_free. */
+int pwaf_list_parse_csv(const char *text, size_t len, char ***items_out, size_t *n_out);
+void pwaf_list_free(char **items, size_t n);
+
 #define PWAF_OPT_NO_UA_GATE 1u        /* skip gate A (http_listener.rs:196-198)             */
 #define PWAF_OPT_NO_CAPTCHA_BYPASS 2u /* skip gate B (http_listener.rs:200-204)             */
 typedef struct pwaf_options {

@@ -28,13 +28,16 @@ struct pwaf_program {
 };
 
 namespace {
-
 thread_local std::string g_last_error = "";
-
-int fail(int code, const std::string &msg) {
+}
+namespace pwaf {
+int fail(int code, const std::string &msg) {  // also used by loaders.cpp
     g_last_error = msg;
     return code;
 }
+}  // namespace pwaf
+using pwaf::fail;
+namespace {
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
         hipError_t _e = (expr);                                                                                \

@@ -96,6 +96,12 @@ def lib():
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
     L.pwaf_engine_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
+    L.pwaf_geoip_from_mmdb.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(_abi.GeoipEntry)), C.POINTER(C.c_size_t)]
+    L.pwaf_geoip_free.argtypes = [C.POINTER(_abi.GeoipEntry)]
+    L.pwaf_geoip_free.restype = None
+    L.pwaf_list_parse_csv.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_size_t)]
+    L.pwaf_list_free.argtypes = [C.POINTER(C.c_char_p), C.c_size_t]
+    L.pwaf_list_free.restype = None
     L.pwaf_engine_kernel_times.argtypes = [vp, C.POINTER(_abi.KernelTime), C.c_int]
     L.pwaf_derive_path.argtypes = [C.c_char_p, C.c_size_t]
     L.pwaf_derive_path.restype = C.c_size_t
@@ -343,6 +349,36 @@ class RuleEngine:
         if n < 0:
             _raise(n, lib().pwaf_last_error().decode(errors="replace"))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
+
+
+def geoip_from_mmdb(content: bytes) -> np.ndarray:
+    """MaxMind DB file content -> GEOIP_DTYPE prefix table for RuleEngine(..., geoip=...) (pingoo/geoip.rs:43-91)."""
+    from .batch import GEOIP_DTYPE
+
+    ptr, n = C.POINTER(_abi.GeoipEntry)(), C.c_size_t(0)
+    rc = lib().pwaf_geoip_from_mmdb(content, len(content), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+    try:
+        out = np.zeros(n.value, dtype=GEOIP_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, ptr, n.value * GEOIP_DTYPE.itemsize)
+    finally:
+        lib().pwaf_geoip_free(ptr)
+    return out
+
+
+def parse_list_csv(text) -> List[str]:
+    """List file content -> items (pingoo/lists.rs:62-117: CSV, no header, 1-2 columns, first column trimmed)."""
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    items, n = C.POINTER(C.c_char_p)(), C.c_size_t(0)
+    rc = lib().pwaf_list_parse_csv(raw, len(raw), C.byref(items), C.byref(n))
+    if rc != 0:
+        _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+    try:
+        return [items[k].decode(errors="surrogateescape") for k in range(n.value)]
+    finally:
+        lib().pwaf_list_free(items, n.value)
 
 
 def verdict_from_record(v) -> Verdict:
