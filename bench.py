@@ -99,7 +99,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    eng.set_profiling(True)  # HIP events around every kernel launch, on the launch stream, during the timed steps
+    eng.set_profiling(not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream, during the timed steps
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

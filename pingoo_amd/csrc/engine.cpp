@@ -77,7 +77,7 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 
 struct DevGroup {
     DevBuf tab, classmap, special, list_off, list;
-    uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base;
+    uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base, n_local;
     uint8_t field;
     uint32_t chunks = 1;  // 16-byte chunks per scan iteration (2 for fields whose sampled mean length is >= 48 bytes)
     int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
@@ -109,6 +109,7 @@ struct pwaf_engine {
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<pwaf_kernel_time> times;
+    std::vector<std::pair<size_t, size_t>> time_ev;  // (begin, end) event index of each entry of `times`
     size_t n_timed = 0;
     hipStream_t side = nullptr;  // attribute kernel runs here, beside the scans
     uint32_t n_cus = 256;
@@ -210,6 +211,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     d.emit_base = emit_base;
     d.special_base = special_base;
     d.atom_base = g.atom_base;
+    d.n_local = g.n_local;
     d.field = g.field;
     int rc;
     if ((rc = upload(d.tab, tab, 16))) return rc;
@@ -270,22 +272,38 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
     if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
 
+    // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
+    // (half the events; the few microseconds of launch gap or memset in between are charged to the later kernel).
     size_t ev_i = e->profiling ? e->n_timed : 0;
-    auto mark = [&](const char *name, uint64_t alg_bytes, hipStream_t on = nullptr) -> int {
-        if (!e->profiling) return PWAF_OK;
+    long last_main = -1;  // index of the last event recorded on `stream` during this call
+    auto record = [&](hipStream_t on) -> int {
         if (e->ev.size() < ev_i + 1) {
             hipEvent_t x;
             HIP_TRY(hipEventCreate(&x));
             e->ev.push_back(x);
         }
-        HIP_TRY(hipEventRecord(e->ev[ev_i], on ? on : stream));
-        if (name) {
-            pwaf_kernel_time t{};
-            snprintf(t.name, sizeof t.name, "%s", name);
-            t.alg_bytes = alg_bytes;
-            e->times.push_back(t);
-        }
+        HIP_TRY(hipEventRecord(e->ev[ev_i], on));
         ev_i++;
+        return PWAF_OK;
+    };
+    long open_begin = -1;
+    auto mark = [&](const char *name, uint64_t alg_bytes, hipStream_t on = nullptr) -> int {
+        if (!e->profiling) return PWAF_OK;
+        int rc2;
+        if (!name) {  // begin
+            if (!on && last_main >= 0) { open_begin = last_main; return PWAF_OK; }
+            if ((rc2 = record(on ? on : stream))) return rc2;
+            open_begin = (long)ev_i - 1;
+            if (!on) last_main = open_begin;
+            return PWAF_OK;
+        }
+        if ((rc2 = record(on ? on : stream))) return rc2;
+        if (!on) last_main = (long)ev_i - 1;
+        pwaf_kernel_time t{};
+        snprintf(t.name, sizeof t.name, "%s", name);
+        t.alg_bytes = alg_bytes;
+        e->times.push_back(t);
+        e->time_ev.push_back({(size_t)open_begin, ev_i - 1});
         return PWAF_OK;
     };
 
@@ -381,6 +399,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         if (d.gate < 0 && e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
             // this pass owns prefilter factors: it feeds the gated passes' request lists as requests finish
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
+            a.n_local = d.n_local;
             a.gate_lists = (uint32_t *)e->gate_lists.p;
             a.gate_count = (uint32_t *)e->ctrl.p + 2;
         }
@@ -965,6 +984,7 @@ int pwaf_engine_set_profiling(pwaf_engine *e, int on) {
     std::lock_guard<std::mutex> lock(e->mu);
     e->profiling = on != 0;
     e->times.clear();  // (re)starting a measurement window: kernel_times() reports every launch since this call
+    e->time_ev.clear();
     e->n_timed = 0;
     return PWAF_OK;
 }
@@ -972,13 +992,13 @@ int pwaf_engine_set_profiling(pwaf_engine *e, int on) {
 int pwaf_engine_kernel_times(pwaf_engine *e, pwaf_kernel_time *out, int cap) {
     if (!e || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(e->mu);
-    if (e->n_timed < 2) return 0;
-    HIP_TRY(hipEventSynchronize(e->ev[e->n_timed - 1]));
+    if (e->n_timed < 2 || e->times.empty()) return 0;
     int n = 0;
-    for (size_t k = 0; k + 1 < e->n_timed && (size_t)n < e->times.size() && n < cap; k += 2, n++) {
+    for (size_t k = 0; k < e->times.size() && k < e->time_ev.size() && n < cap; k++, n++) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]));
-        out[n] = e->times[(size_t)n];
+        HIP_TRY(hipEventSynchronize(e->ev[e->time_ev[k].second]));
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[e->time_ev[k].first], e->ev[e->time_ev[k].second]));
+        out[n] = e->times[k];
         out[n].ms = ms;
     }
     return n;

@@ -54,6 +54,7 @@ struct ScanArgs {
     uint32_t *status;         // device status word: bit 0 = overflow pool exhausted
     // a pass that owns prefilter factors (else null): per local atom, the bitmask of gated passes it triggers, and their lists
     const uint32_t *colmask_local;
+    uint32_t n_local;         // atoms of this pass (entries of colmask_local)
     uint32_t *gate_lists;     // [n_gated][n]
     uint32_t *gate_count;     // [n_gated], zeroed by the host per batch
     // gated pass only (else null): the requests to visit and, on the device, how many
@@ -132,7 +133,7 @@ int launch_scan_gated(const GatedArgs &b, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 int launch_attr(const VerdictArgs &a, void *stream);
 int launch_dir24(const VerdictArgs &a, void *out, void *stream);  // out: 2^24 x uint64
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride);
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;
 };

@@ -45,8 +45,8 @@ static constexpr uint32_t kClsBytes = 1024;  // byte-class map at LDS offset 0: 
 // The walk is speculative (see scan_body): a lane that has just read a special cell keeps using it as an address until the
 // group of 4 steps is checked, so every address a 16-bit cell can form — (0xFFFF << 1) + a class offset — must stay inside the
 // allocation.
-uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride) {
-    const uint32_t need = (((n_hot + 1) * stride * 2 + 15) & ~15u) + kClsBytes;
+uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms) {
+    const uint32_t need = (((n_hot + 1) * stride * 2 + 15) & ~15u) + kClsBytes + n_gate_atoms * 4;
     const uint32_t reach = ((0xFFFFu << 1) + stride * 2 + kClsBytes + 15) & ~15u;
     return need > reach ? need : reach;
 }
@@ -204,6 +204,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + kClsBytes + base)[tid] = a.tab[base / 2 + tid];
     }
     if (tid < 256) reinterpret_cast<uint32_t *>(lds)[tid] = a.classmap[tid] * 2u;
+    // a pass that owns prefilter factors keeps its atom -> gated-pass bitmask map in LDS too (one lookup per hit of a finished request)
+    const uint32_t gate_base = kClsBytes + tab_bytes;
+    if (a.colmask_local != nullptr)
+        for (uint32_t i = tid; i < a.n_local; i += kScanThreads) reinterpret_cast<uint32_t *>(lds + gate_base)[i] = a.colmask_local[i];
     __syncthreads();
 
     const uint32_t end_col = a.n_classes + 1;
@@ -378,7 +382,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
                                                 : (uint32_t)*reinterpret_cast<lds_u16_ptr>((uintptr_t)(((row + end_col) << 1) + kClsBytes));
             if (e) PWAF_EMIT(e - 1);
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-            if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) enqueue_gated(a.colmask_local, a.pool, a.gate_lists, a.gate_count, a.n, r, h);
+            if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) {
+                // does any hit of this request gate a later pass? (LDS lookups; the enqueue itself is rare and out of line)
+                uint32_t need = 1;  // overflowed record: let the slow path walk the chain
+                if (h.ovf == kNone) {
+                    need = *reinterpret_cast<lds_u32_ptr>((uintptr_t)(gate_base + (h.a0 - 1) * 4));
+                    if (h.a1) need |= *reinterpret_cast<lds_u32_ptr>((uintptr_t)(gate_base + (h.a1 - 1) * 4));
+                }
+                if (need) enqueue_gated(a.colmask_local, a.pool, a.gate_lists, a.gate_count, a.n, r, h);
+            }
             r = kNone;
         }
         if (r == kNone && r2 != kNone) {
@@ -418,7 +430,7 @@ static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
 }
 
 int launch_scan(const ScanArgs &a, void *stream) {
-    const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride);
+    const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.colmask_local ? a.n_local : 0u);
     static thread_local uint32_t configured[2] = {0, 0};
     const int v = a.chunks == 2 ? 1 : 0;
     const void *fn = v ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
@@ -437,7 +449,7 @@ int launch_scan(const ScanArgs &a, void *stream) {
 
 int launch_scan_gated(const GatedArgs &b, void *stream) {
     uint32_t lds = 0;
-    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride));
+    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, 0u));
     static thread_local uint32_t configured = 0;
     if (int e = configure_lds(reinterpret_cast<const void *>(gscan_kernel), lds, configured)) return e;
     if (b.count == 0 || b.g[0].n == 0) return 0;
