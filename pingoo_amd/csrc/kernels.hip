@@ -578,10 +578,37 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         atomicOr(&colnz[c >> 5], 1u << (c & 31));
     };
 
-    for (uint32_t g = blockIdx.x * n_waves + wave; g < a.n_groups; g += gridDim.x * n_waves) {
+    // A group's inputs — up to kPre hit records per request, the captcha flag, the attribute kernel's pair count and first 64
+    // pairs — are requested ONE GROUP AHEAD: with ~9 waves per CU nothing else hides the ~2 us those first-touch loads take.
+    constexpr int kPre = 12;
+    struct Inputs {
+        uint32_t rv[kPre];
+        uint32_t flags, n_pairs;
+        uint4 pair0;
+    };
+    auto request_inputs = [&](const uint32_t g, Inputs &in) {
+        const uint32_t i = g * 64 + lane;
+        const bool valid = g < a.n_groups && i < a.n;
+#pragma unroll
+        for (int q = 0; q < kPre; q++) {
+            const uint32_t ps = min((uint32_t)q, a.n_passes - 1);
+            in.rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+        }
+        in.flags = valid ? (uint32_t)a.flags[i] : 0u;
+        const uint32_t gg = min(g, a.n_groups - 1);
+        in.n_pairs = a.ghdr[gg];
+        in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];  // (the buffer is padded: reading past the group's count is harmless)
+    };
+    const uint32_t g_stride = gridDim.x * n_waves;
+    Inputs cur;
+    request_inputs(blockIdx.x * n_waves + wave, cur);
+
+    for (uint32_t g = blockIdx.x * n_waves + wave; g < a.n_groups; g += g_stride) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
         const unsigned long long valid_mask = __ballot(valid);
+        Inputs nxt;
+        request_inputs(g + g_stride, nxt);
 
         // 1. clear the column file and the bitmaps; column 0 is the constant TRUE; rules that can match with every column
         //    zero (a term made of negations only) are always candidates
@@ -591,24 +618,26 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
 
-        // requested now, consumed after the hit records (their latency overlaps section 2): the captcha flag and the group's
-        // (column, mask) pairs from the attribute kernel
-        const uint32_t flags = valid ? (uint32_t)a.flags[i] : 0u;
+        const uint32_t flags = cur.flags;
         const uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
-        const uint32_t n_pairs = a.ghdr[g];
-        const uint4 pair0 = pairs[lane];  // (the buffer is padded: reading past the group's count is harmless)
+        const uint32_t n_pairs = cur.n_pairs;
+        const uint4 pair0 = cur.pair0;
 
-        // 2. scan results: each lane marks the columns its hit records name. The records of 8 passes are requested together
-        //    (independent loads, one wait) before any of them is examined.
-        for (uint32_t pb = 0; pb < a.n_passes && !(a.debug_skip & 1u); pb += 8) {
-            uint32_t rv[8];
+        // 2. scan results: each lane marks the columns its hit records name (passes beyond the prefetched kPre are fetched here,
+        //    kPre at a time: independent loads, one wait)
+        for (uint32_t pb = 0; pb < a.n_passes && !(a.debug_skip & 1u); pb += kPre) {
+            uint32_t rv[kPre];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
-                rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+            for (int q = 0; q < kPre; q++) {
+                if (pb == 0) {
+                    rv[q] = cur.rv[q];
+                } else {
+                    const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
+                    rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < kPre; q++) {
                 if (pb + (uint32_t)q >= a.n_passes) break;
                 if (__ballot(rv[q] != 0) == 0) continue;  // nobody in the group matched anything in this pass
                 const uint32_t base = a.pass_base_v[pb + q];  // kernel argument: no memory round trip
@@ -759,6 +788,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cur = nxt;
     }
     if (a.counts != nullptr && lane == 0) {
         if (cnt_allow) atomicAdd(&a.counts[PWAF_ACTION_ALLOW], cnt_allow);
