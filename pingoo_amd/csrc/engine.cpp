@@ -136,8 +136,23 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
 // Builds the device form of one DFA group: see the cell encoding in kernels.h. `visits` (optional, one count per state) is a
 // traffic profile from pwaf_engine_tune: the LDS-resident ("hot") rows are then the most visited states instead of the
 // shallowest ones. The result of a scan never depends on which rows are hot.
-int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, const std::vector<uint64_t> *visits = nullptr) {
+int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, const std::vector<uint64_t> *visits = nullptr,
+                       const std::vector<uint64_t> *class_freq = nullptr) {
     const uint32_t C = g.n_classes, stride = C + 3, stride2 = stride * 2;
+    // Class numbering = cell position inside a row. An LDS lookup conflicts when two lanes hit different dwords of one bank
+    // (32 banks x 4 B = 128 B: DESIGN.md §6); lanes that sit in the SAME row — the usual case, most walks hover around the
+    // start state — conflict exactly when their classes are 64 cells apart. With more than 64 classes the positions
+    // [C - 64, 64) have no alias inside the row: given a traffic profile, the most frequent classes get those.
+    std::vector<uint32_t> cpos(C);
+    for (uint32_t c = 0; c < C; c++) cpos[c] = c;
+    if (class_freq && class_freq->size() >= C && C > 64) {
+        std::vector<uint32_t> by_freq(C), slots;
+        for (uint32_t c = 0; c < C; c++) by_freq[c] = c;
+        std::stable_sort(by_freq.begin(), by_freq.end(), [&](uint32_t x, uint32_t y) { return (*class_freq)[x] > (*class_freq)[y]; });
+        for (uint32_t p = C - 64; p < 64; p++) slots.push_back(p);       // alias-free positions first
+        for (uint32_t p = 0; p < C - 64; p++) { slots.push_back(p + 64); slots.push_back(p); }  // then the aliasing pairs
+        for (uint32_t k = 0; k < C; k++) cpos[by_freq[k]] = slots[k];
+    }
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");
     std::vector<uint32_t> list_off{0};
     std::vector<uint16_t> list;
@@ -187,7 +202,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     for (uint32_t q = 0; q < g.n_states; q++) {
         const uint32_t s = order[q];
         uint16_t *row = &tab[(size_t)q * stride];
-        for (uint32_t c = 0; c < C; c++) row[c] = cell_of(g.trans[(size_t)s * C + c]);
+        for (uint32_t c = 0; c < C; c++) row[cpos[c]] = cell_of(g.trans[(size_t)s * C + c]);
         row[C] = q < n_hot ? (uint16_t)(q * stride) : (uint16_t)0xFFFF;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
             const uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
@@ -215,7 +230,8 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     d.field = g.field;
     int rc;
     if ((rc = upload(d.tab, tab, 16))) return rc;
-    std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
+    std::vector<uint8_t> cm(256);
+    for (int b = 0; b < 256; b++) cm[b] = (uint8_t)cpos[g.classmap[b]];
     if ((rc = upload(d.classmap, cm))) return rc;
     if ((rc = upload(d.special, special))) return rc;
     if ((rc = upload(d.list_off, list_off))) return rc;
@@ -905,29 +921,35 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
     if (n == 0) return PWAF_OK;
     // host walk of every pass over the sample: how often each DFA state is the current state
-    std::vector<std::vector<uint64_t>> visits(P.groups.size());
+    std::vector<std::vector<uint64_t>> visits(P.groups.size()), class_freq(P.groups.size());
     for (size_t k = 0; k < P.groups.size(); k++) {
         const DfaGroup &g = P.groups[k];
         std::vector<uint64_t> &v = visits[k];
         v.assign(g.n_states, 0);
+        std::vector<uint64_t> &cf = class_freq[k];
+        cf.assign(256, 0);
         const uint8_t *data = sample->field[g.field].data;
         const uint32_t *off = sample->field[g.field].offsets;
         for (uint32_t i = 0; i < n; i++) {
             if (off[i + 1] < off[i]) return fail(PWAF_E_BATCH, "sample offsets are not monotonic");
             uint32_t s = 0;
             for (uint32_t p = off[i]; p < off[i + 1]; p++) {
-                s = g.trans[(size_t)s * g.n_classes + g.classmap[data[p]]];
+                const uint32_t cl = g.classmap[data[p]];
+                cf[cl]++;
+                s = g.trans[(size_t)s * g.n_classes + cl];
                 v[s]++;
             }
         }
     }
     for (size_t k = 0; k < P.groups.size(); k++) {
         const uint32_t *off = sample->field[P.groups[k].field].offsets;
-        e->groups[k].chunks = (uint64_t)(off[n] - off[0]) >= (uint64_t)48 * n ? 2u : 1u;
+        const uint64_t total = (uint64_t)(off[n] - off[0]);
+        static const uint32_t t4 = getenv("PWAF_CH4_AT") ? (uint32_t)atoi(getenv("PWAF_CH4_AT")) : 80u;  // (profiling knob)
+        e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)48 * n ? 2u : 1u;
     }
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k]))) return rc;
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k], &class_freq[k]))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;
 }

@@ -431,9 +431,9 @@ static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
 
 int launch_scan(const ScanArgs &a, void *stream) {
     const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.colmask_local ? a.n_local : 0u);
-    static thread_local uint32_t configured[2] = {0, 0};
-    const int v = a.chunks == 2 ? 1 : 0;
-    const void *fn = v ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
+    static thread_local uint32_t configured[3] = {0, 0, 0};
+    const int v = a.chunks == 4 ? 2 : a.chunks == 2 ? 1 : 0;
+    const void *fn = v == 2 ? reinterpret_cast<const void *>(scan_kernel<4>) : v == 1 ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
     if (int e = configure_lds(fn, lds, configured[v])) return e;
     if (a.n == 0) return 0;
     // at least 256 requests per wave so that work-pulling has something to balance; at most two rounds of one

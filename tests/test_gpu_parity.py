@@ -68,6 +68,9 @@ def test_synthetic_configs_match_oracle(cid, n):
     hist = np.bincount(want["action"], minlength=4)
     assert counts.tolist() == hist.tolist()
     assert hist[1] > 0 and hist[0] > hist[1]  # some blocks, mostly allows
+    # profile-guided table layout (hot rows, class placement, chunks per iteration) never changes a verdict
+    eng.tune(w.batch(2_000_000, 3000))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"config {cid}, tuned")
     eng.close()
 
 
