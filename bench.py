@@ -175,8 +175,8 @@ def main():
         if args.config == 3 and n == 10_000_000 and os.path.exists(tpath):
             try:
                 tk = json.load(open(tpath))["kernels"]
-                sk = next(v for k, v in tk.items() if "scan_kernel" in k)
-                traffic = (sum(sk["fetch_bytes"]) + sum(sk["write_bytes"])) // max(1, sk["launches"])
+                sk = [v for k, v in tk.items() if "::scan_kernel" in k]  # one entry per template instantiation (chunks per iteration)
+                traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
                 traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
             except Exception:  # a malformed profile file must not break the bench line
                 traffic, traffic_src = None, None

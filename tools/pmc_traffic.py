@@ -16,12 +16,12 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(path)):
             if "pwaf::" in r["Kernel_Name"] and r["Counter_Name"] == cname:
                 per[r["Kernel_Name"].split("(")[0].replace("void ", "")][cname].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-out = {"unit": "bytes per launch", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)", "kernels": {}}
+out = {"unit": "bytes per launch, last pipeline pass of the trace", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)", "kernels": {}}
+passes = max(1, max((len(d["FETCH_SIZE"]) for k, d in per.items() if "verdict" in k), default=1))  # pipeline passes in the trace
 for k, d in per.items():
-    # the LAST pipeline pass in the trace (the timed step): take the final occurrences
     f = [v for _, v in sorted(d["FETCH_SIZE"])]
     w = [v for _, v in sorted(d["WRITE_SIZE"])]
-    n = {"scan_kernel": 5}.get(k.split("::")[-1].split("<")[0], 1)
+    n = max(1, len(f) // passes) if len(f) >= passes else len(f)
     f, w = f[-n:], w[-n:]
     out["kernels"][k] = {"launches": len(f), "fetch_bytes": [int(x * 1024 * 2) for x in f], "write_bytes": [int(x * 1024) for x in w]}
 print(json.dumps(out, indent=1))
