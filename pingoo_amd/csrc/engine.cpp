@@ -205,9 +205,15 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
         for (uint32_t c = 0; c < C; c++) row[cpos[c]] = cell_of(g.trans[(size_t)s * C + c]);
         row[C] = q < n_hot ? (uint16_t)(q * stride) : (uint16_t)0xFFFF;  // STAY
         if (g.end_off[s + 1] > g.end_off[s]) {
-            const uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
-            if (id1 > 65535) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
-            row[C + 1] = (uint16_t)id1;
+            // END cell: like the EMIT cell — 0x8000 | atom for a single match (whole-string equality, the usual case: no list
+            // walk, no memory access when a request finishes), else 1 + list id
+            if (g.end_off[s + 1] - g.end_off[s] == 1 && g.end_list[g.end_off[s]] < 0x8000u) {
+                row[C + 1] = (uint16_t)(0x8000u | g.end_list[g.end_off[s]]);
+            } else {
+                const uint32_t id1 = add_list(g.end_list, g.end_off[s], g.end_off[s + 1]);
+                if (id1 >= 0x8000u) return fail(PWAF_E_UNSUPPORTED, "too many match lists in one DFA group");
+                row[C + 1] = (uint16_t)id1;
+            }
         }
         if (emit_id[s]) {
             // EMIT cell of a hot row: 0x8000 | atom for a single match, else 1 + list id

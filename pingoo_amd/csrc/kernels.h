@@ -22,7 +22,7 @@ struct PoolEntry {
 // the engine was tuned on a traffic sample, else the shallowest), followed by one SENTINEL row of 0xFFFF cells. Among the hot
 // rows the ones that emit matches come last: rows [n_plain, n_hot).
 //   [0, n_classes)   transition cell        [n_classes]      STAY cell (= own row; used for lanes past their last byte)
-//   [n_classes + 1]  1 + end-list id (0 = none)   [n_classes + 2]  EMIT cell: 0x8000 | atom, or 1 + emit-list id (0 = none)
+//   [n_classes + 1]  END cell, [n_classes + 2]  EMIT cell: 0x8000 | atom for a single match, or 1 + list id (0 = none)
 // A transition cell c <  emit_base    -> cell index of the next row: hot, nothing to emit (next lookup address = c * 2 + class
 //                                        offset: one v_lshl_add)
 //                   c <  special_base -> same, and entering that row emits what its EMIT cell says

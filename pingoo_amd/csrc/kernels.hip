@@ -380,7 +380,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         if (r != kNone && p >= end) {
             const uint32_t e = row == hot_elems ? (uint32_t)*reinterpret_cast<glb_u16_ptr>(gtab + crow + (end_col << 1))
                                                 : (uint32_t)*reinterpret_cast<lds_u16_ptr>((uintptr_t)(((row + end_col) << 1) + kClsBytes));
-            if (e) PWAF_EMIT(e - 1);
+            if (e & 0x8000u) {  // a single end-of-field match: settled in registers unless the record is full
+                const uint32_t x = (e & 0x7FFFu) + 1;
+                if (h.ovf == kNone && (h.a0 == x || h.a1 == x)) {
+                } else if (h.ovf == kNone && h.a0 == 0) {
+                    h.a0 = x;
+                } else if (h.ovf == kNone && h.a1 == 0) {
+                    h.a1 = x;
+                } else {
+                    const SlowCtx sc{a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap};
+                    h = record_atom(sc, x - 1, h);
+                }
+            } else if (e) {
+                PWAF_EMIT(e - 1);
+            }
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) {
                 // does any hit of this request gate a later pass? (LDS lookups; the enqueue itself is rare and out of line)
