@@ -702,7 +702,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         // Trigger lists: a rule can match only if one of its DNF terms is true; a term with a positive literal needs that
         // column to be non-zero. Per term pick the positive literal least likely to be set (scan < membership < comparison <
         // TRUE) and file the rule under that column; terms made of negations only make the rule an unconditional candidate.
-        if (P.rules.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 effective rules"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        // (rule indices travel as 16-bit values inside the verdict kernel; 0xFFF0.. is kept for the pseudo rules of the two gates)
+        if (P.rules.size() > 65519 || n_rules > 65519) { fail(PWAF_E_UNSUPPORTED, "more than 65519 rules"); return dev_fail(PWAF_E_UNSUPPORTED); }
         // lower = rarer: scan atoms by how specific their pattern is (shortest possible match), then memberships, then
         // comparisons (often true for most requests), then the constant TRUE column
         std::vector<uint32_t> rank(P.n_cols, 100);

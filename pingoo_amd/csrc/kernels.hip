@@ -529,14 +529,14 @@ static constexpr uint32_t kBitColEntries = 24 * 32;  // (source word, bit) -> co
 
 __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
     const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
-    return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;
+    return ((n_cols * 8 + 64 * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;  // columns, fire words, bitmaps, candidates
 }
 
 // LDS-resident copies of the small read-mostly program tables (LT = true): trigger lists, rule headers and DNF literals are
 // gathered several times per 64-request group, and each gather from L2 is a ~1 us round trip that the few waves a CU can hold
 // (the column files fill LDS) cannot hide.
 struct VerdictTables {
-    uint32_t bitcol, trig_off, trig_rules, rules, lits, end;  // byte offsets from the start of the table region
+    uint32_t bitcol, trig_off, trig_rules, rules, lits, pub, end;  // byte offsets from the start of the table region
 };
 __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool lt) {
     VerdictTables t;
@@ -545,7 +545,8 @@ __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, 
     t.trig_rules = t.trig_off + (lt ? ((n_cols + 1) * 2 + 3) & ~3u : 0u);
     t.rules = t.trig_rules + (lt ? (n_trig * 2 + 7) & ~7u : 0u);
     t.lits = t.rules + (lt ? n_rules * 8 : 0u);
-    t.end = t.lits + (lt ? n_lits * 4 : 0u);
+    t.pub = t.lits + (lt ? n_lits * 4 : 0u);
+    t.end = t.pub + (lt ? (n_rules * 2 + 3) & ~3u : 0u);
     return t;
 }
 
@@ -557,7 +558,8 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     const uint32_t wave_bytes = verdict_wave_lds(a.n_cols, a.n_rules);
     unsigned char *mine = lds + (size_t)wave * wave_bytes;
     unsigned long long *col = reinterpret_cast<unsigned long long *>(mine);
-    uint32_t *colnz = reinterpret_cast<uint32_t *>(mine + (size_t)a.n_cols * 8);
+    unsigned long long *fbuf = col + a.n_cols;  // per round: candidate j's 64-request match word
+    uint32_t *colnz = reinterpret_cast<uint32_t *>(fbuf + 64);
     uint32_t *rulebm = colnz + colw;
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
     unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     uint16_t *l_trig_rules = reinterpret_cast<uint16_t *>(tables + vt.trig_rules);
     uint2 *l_rules = reinterpret_cast<uint2 *>(tables + vt.rules);
     uint32_t *l_lits = reinterpret_cast<uint32_t *>(tables + vt.lits);
+    uint16_t *l_pub = reinterpret_cast<uint16_t *>(tables + vt.pub);  // public rule index, 16 bits (the pseudo rules' 0xFFFFFFFx ids keep their low half)
     for (uint32_t k = tid; k < kBitColEntries; k += blockDim.x) bitcol[k] = a.bit_col[k];
     if (LT) {
         for (uint32_t k = tid; k <= a.n_cols; k += blockDim.x) l_trig_off[k] = (uint16_t)a.trig_off[k];
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         for (uint32_t k = tid; k < a.n_rules; k += blockDim.x) {
             const DevRule dr = a.rules[k];  // header without the public index (only read when the rule decides a request)
             l_rules[k] = make_uint2(dr.lit_off, dr.lit_cnt | ((uint32_t)dr.eff_unverified << 16) | ((uint32_t)dr.eff_verified << 24));
+            l_pub[k] = (uint16_t)dr.public_idx;
         }
         for (uint32_t k = tid; k < a.n_lits; k += blockDim.x) l_lits[k] = a.lits[k];
     }
@@ -612,6 +616,8 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         in.n_pairs = a.ghdr[gg];
         in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];  // (the buffer is padded: reading past the group's count is harmless)
     };
+    for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;  // the column file starts clean; afterwards groups clean up after themselves
+    for (uint32_t k = lane; k < colw; k += 64) colnz[k] = 0;
     const uint32_t g_stride = gridDim.x * n_waves;
     Inputs cur;
     request_inputs(blockIdx.x * n_waves + wave, cur);
@@ -625,8 +631,15 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
         // 1. clear the column file and the bitmaps; column 0 is the constant TRUE; rules that can match with every column
         //    zero (a term made of negations only) are always candidates
-        for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;
-        for (uint32_t k = lane; k < colw; k += 64) colnz[k] = k == 0 ? 1u : 0u;
+        //    (only the columns the previous group dirtied are cleared: the non-zero bitmap names them)
+        for (uint32_t wv = lane; wv < colw; wv += 64) {
+            uint32_t nz = colnz[wv];
+            colnz[wv] = wv == 0 ? 1u : 0u;
+            while (nz) {
+                col[wv * 32 + (uint32_t)__builtin_ctz(nz)] = 0;
+                nz &= nz - 1;
+            }
+        }
         for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = k < 64 ? h_always : a.always_rules[k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) col[0] = ~0ull;
@@ -723,15 +736,17 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-        // 5. evaluate candidates: one lane per rule, 64 requests per ALU op; first match (lowest rule index) wins
+        // 5. evaluate candidates: one lane per rule, 64 requests per ALU op. Each candidate's 64-request match word goes to LDS;
+        //    then every REQUEST lane scans the words in rule order for its own bit (broadcast reads), so first-match-wins needs
+        //    no lane-to-lane traffic
         unsigned long long pending = valid_mask;
+        bool undecided = valid;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
         for (uint32_t base = 0; base < n_cand && pending != 0 && !(a.debug_skip & 32u); base += 64) {
             unsigned long long fire = 0;
-            uint32_t eff_u = 0, eff_v = 0, my_cand = 0;
             if (base + lane < n_cand) {
-                my_cand = cand[base + lane];
-                uint32_t lit_off, lit_cnt;
+                const uint32_t my_cand = cand[base + lane];
+                uint32_t lit_off, lit_cnt, eff_u, eff_v;
                 if (LT) {
                     const uint2 hdr = l_rules[my_cand];
                     lit_off = hdr.x;
@@ -746,36 +761,66 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                     eff_v = dr.eff_verified;
                 }
                 unsigned long long acc_or = 0, acc_and = ~0ull;
-                for (uint32_t k = lit_off; k < lit_off + lit_cnt; k++) {
-                    const uint32_t lit = LT ? l_lits[k] : a.lits[k];
-                    unsigned long long c = col[lit & LIT_ATOM_MASK];
-                    if (lit & LIT_NEG) c = ~c;
-                    acc_and &= c;
-                    if (lit & LIT_TERM_END) {
-                        acc_or |= acc_and;
-                        acc_and = ~0ull;
+                // literals four at a time: the four literal words are requested together, then the four column words — two
+                // LDS round trips per four literals instead of eight dependent ones (a padding literal is column 0 = TRUE)
+                for (uint32_t k = lit_off; k < lit_off + lit_cnt; k += 4) {
+                    uint32_t lit[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) lit[q] = k + q < lit_off + lit_cnt ? (LT ? l_lits[k + q] : a.lits[k + q]) : 0u;
+                    unsigned long long cw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cw[q] = col[lit[q] & LIT_ATOM_MASK];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc_and &= (lit[q] & LIT_NEG) ? ~cw[q] : cw[q];
+                        if (lit[q] & LIT_TERM_END) {
+                            acc_or |= acc_and;
+                            acc_and = ~0ull;
+                        }
                     }
                 }
                 // a match only decides when the rule's action list yields an effect for that client
-                fire = acc_or & pending & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
+                fire = acc_or & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
             }
-            unsigned long long firing_lanes = __ballot(fire != 0);
-            while (firing_lanes) {
-                const uint32_t j = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(firing_lanes));
-                firing_lanes &= firing_lanes - 1;
-                const uint32_t flo = __builtin_amdgcn_readlane((uint32_t)fire, j);
-                const uint32_t fhi = __builtin_amdgcn_readlane((uint32_t)(fire >> 32), j);
-                const unsigned long long newly = (((unsigned long long)fhi << 32) | flo) & pending;
-                pending &= ~newly;
-                const uint32_t ju = __builtin_amdgcn_readlane(eff_u, j), jv = __builtin_amdgcn_readlane(eff_v, j);
-                const uint32_t jc = __builtin_amdgcn_readlane(my_cand, j);
-                if (newly & mybit) {
-                    my_action = (verified_mask & mybit) ? jv : ju;
-                    my_rule = a.rules[jc].public_idx;  // rare (a request that is not allowed): one gather
+            if (a.debug_skip & 256u) fire = 0;
+            fbuf[lane] = fire;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (__ballot(fire != 0) != 0 && !(a.debug_skip & 128u)) {
+                const uint32_t cnt = min(64u, n_cand - base);
+                uint32_t first = kNone;
+                for (uint32_t j = 0; j < cnt; j += 4) {
+                    unsigned long long w4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w4[q] = fbuf[min(j + (uint32_t)q, 63u)];  // same address in every lane: a broadcast read
+#pragma unroll
+                    for (int q = 3; q >= 0; q--)
+                        if (j + (uint32_t)q < cnt && (w4[q] & mybit)) first = first < j + (uint32_t)q ? first : j + (uint32_t)q;
+                    if (__ballot(undecided && first == kNone) == 0) break;  // every open request of the group has met its rule
                 }
+                if (undecided && first != kNone) {
+                    undecided = false;
+                    const uint32_t jc = cand[base + first];
+                    uint32_t eff_u, eff_v;
+                    if (LT) {
+                        const uint32_t y = l_rules[jc].y;
+                        eff_u = (y >> 16) & 0xFFu;
+                        eff_v = y >> 24;
+                        const uint32_t pi = l_pub[jc];
+                        my_rule = pi >= 0xFFF0u ? 0xFFFF0000u | pi : pi;
+                    } else {
+                        const DevRule dr = a.rules[jc];
+                        eff_u = dr.eff_unverified;
+                        eff_v = dr.eff_verified;
+                        my_rule = dr.public_idx;
+                    }
+                    my_action = (verified_mask & mybit) ? eff_v : eff_u;
+                }
+                pending = __ballot(undecided);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
 
+        if (a.debug_skip & 64u) my_rule = n_cand;  // profiling aid: report the candidate count instead of the deciding rule
         // 6. outputs
         if (valid) {
             uint2 v;
@@ -803,14 +848,23 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         cur = nxt;
     }
-    if (a.counts != nullptr && lane == 0) {
-        if (cnt_allow) atomicAdd(&a.counts[PWAF_ACTION_ALLOW], cnt_allow);
-        if (cnt_block) atomicAdd(&a.counts[PWAF_ACTION_BLOCK], cnt_block);
-        if (cnt_captcha) atomicAdd(&a.counts[PWAF_ACTION_CAPTCHA], cnt_captcha);
-        if (cnt_bypass) atomicAdd(&a.counts[PWAF_ACTION_BYPASS], cnt_bypass);
+    // Action counters: one atomic per counter and WORKGROUP. (One per wave was measured at 0.25 ms of a 0.6 ms kernel: at the end of
+    // every round of workgroups thousands of same-address atomics queue up at the L2.)
+    __syncthreads();  // every wave is done with its column file: the start of LDS can hold the tallies
+    unsigned long long *tally = reinterpret_cast<unsigned long long *>(lds);
+    if (lane == 0) {
+        tally[wave * 4 + PWAF_ACTION_ALLOW] = cnt_allow;
+        tally[wave * 4 + PWAF_ACTION_BLOCK] = cnt_block;
+        tally[wave * 4 + PWAF_ACTION_CAPTCHA] = cnt_captcha;
+        tally[wave * 4 + PWAF_ACTION_BYPASS] = cnt_bypass;
+    }
+    __syncthreads();
+    if (a.counts != nullptr && tid < 4) {
+        unsigned long long sum = 0;
+        for (uint32_t wv = 0; wv < n_waves; wv++) sum += tally[wv * 4 + tid];
+        if (sum) atomicAdd(&a.counts[tid], sum);
     }
 }
-
 
 // -------------------------------------------------------------------------------------------------
 // attributes: everything about a request that is NOT a string scan — GeoIP record, ip-list membership, country / integer-set
