@@ -952,7 +952,8 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         const uint32_t *off = sample->field[P.groups[k].field].offsets;
         const uint64_t total = (uint64_t)(off[n] - off[0]);
         static const uint32_t t4 = getenv("PWAF_CH4_AT") ? (uint32_t)atoi(getenv("PWAF_CH4_AT")) : 80u;  // (profiling knob)
-        e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)48 * n ? 2u : 1u;
+        static const uint32_t t2 = getenv("PWAF_CH2_AT") ? (uint32_t)atoi(getenv("PWAF_CH2_AT")) : 48u;  // (profiling knob)
+        e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)t2 * n ? 2u : 1u;
     }
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)

@@ -187,6 +187,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     // lookups use plain integer addresses: the region bases fold into the ds_read offset fields, a class lookup is one SDWA
     // shift + ds_read_b32, a DFA step is v_lshl_add (cell * 2 + class offset) + ds_read_u16.
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
+    if (INDIRECT) {
+        // gated pass: most workgroups of the fixed grid have nothing to do (the request lists are short) — leave before paying
+        // for the table staging
+        const uint32_t n_l = min(*a.n_list, a.n), tw = gridDim.x * kScanWaves;
+        const uint32_t pw = (((n_l + tw - 1) / tw) + 63) & ~63u;
+        if ((uint64_t)blockIdx.x * kScanWaves * pw >= n_l) return;
+    }
     const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
