@@ -248,6 +248,17 @@ int pwaf_engine_tune(pwaf_engine *, const pwaf_batch *sample);
 /* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
 int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);
 
+/* ---- deadline micro-batcher ------------------------------------------------------ */
+/* The reference evaluates rules once per request on the tokio worker that owns the connection (http_listener.rs:196-264); a
+ * drop-in RuleEngine::evaluate(Request) -> Action keeps that call shape. The batcher gathers concurrent callers: each call blocks
+ * until its batch — closed when it holds max_batch requests or its oldest request has waited max_delay_us — has gone through
+ * pwaf_evaluate_batch. Thread-safe; one dispatcher thread per batcher. Destroy it before the engine. */
+typedef struct pwaf_batcher pwaf_batcher;
+int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_delay_us, pwaf_batcher **out);
+int pwaf_batcher_evaluate(pwaf_batcher *, const pwaf_request *req, pwaf_verdict *out);
+int pwaf_batcher_stats(pwaf_batcher *, uint64_t *n_batches, uint64_t *n_requests);
+void pwaf_batcher_destroy(pwaf_batcher *);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct pwaf_kernel_time {
     char name[48];

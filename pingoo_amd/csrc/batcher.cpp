@@ -1,0 +1,201 @@
+// batcher.cpp — deadline micro-batcher: the piece that lets a per-request caller use a batch engine.
+//
+// The reference evaluates rules inline, once per request, on whichever tokio worker owns the connection
+// (pingoo/listeners/http_listener.rs:196-264). A drop-in `RuleEngine::evaluate(Request) -> Action` keeps that call shape, so
+// concurrent callers have to be gathered into batches somewhere: here. Callers block in pwaf_batcher_evaluate; a dispatcher
+// thread closes a batch when it is full or when its oldest request has waited max_delay_us, runs it through
+// pwaf_evaluate_batch (the same kernels as everything else) and wakes the callers with their verdicts.
+// Plain C++17 on top of the public C ABI: no device code, no access to engine internals.
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pwaf.h"
+
+namespace pwaf {
+int fail(int code, const std::string &msg);
+}
+using pwaf::fail;
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+struct Generation {  // one batch: the callers that joined it share this
+    std::vector<pwaf_verdict> verdicts;
+    int status = PWAF_OK;
+    std::string error;
+    bool done = false;
+};
+
+struct Slot {  // a batch being filled (struct of arrays, exactly the pwaf_batch layout)
+    std::vector<uint8_t> data[PWAF_N_FIELDS];
+    std::vector<uint32_t> offs[PWAF_N_FIELDS];
+    std::vector<uint8_t> ip, v6, flags;
+    std::vector<uint16_t> port, country;
+    std::vector<uint32_t> asn;
+    uint32_t n = 0;
+    Clock::time_point deadline;
+    std::shared_ptr<Generation> gen = std::make_shared<Generation>();
+    void reset() {
+        for (int f = 0; f < PWAF_N_FIELDS; f++) {
+            data[f].clear();
+            offs[f].assign(1, 0u);
+        }
+        ip.clear(); v6.clear(); flags.clear(); port.clear(); country.clear(); asn.clear();
+        n = 0;
+        gen = std::make_shared<Generation>();
+    }
+};
+
+}  // namespace
+
+struct pwaf_batcher {
+    pwaf_engine *engine = nullptr;
+    uint32_t max_batch = 0;
+    std::chrono::microseconds max_delay{0};
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    Slot slot[2];  // [0]: requests without GeoIP columns, [1]: requests that bring asn / country (a batch has them for all or none)
+    bool stop = false;
+    uint64_t n_batches = 0, n_requests = 0;
+    std::thread worker;
+
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            // which slot is due?
+            int due = -1;
+            Clock::time_point wake = Clock::time_point::max();
+            const auto now = Clock::now();
+            for (int s = 0; s < 2; s++) {
+                if (slot[s].n == 0) continue;
+                if (slot[s].n >= max_batch || slot[s].deadline <= now || stop) { due = s; break; }
+                if (slot[s].deadline < wake) wake = slot[s].deadline;
+            }
+            if (due < 0) {
+                if (stop) return;
+                if (wake == Clock::time_point::max()) cv_work.wait(lk);
+                else cv_work.wait_until(lk, wake);
+                continue;
+            }
+            Slot b = std::move(slot[due]);
+            slot[due] = Slot();
+            slot[due].reset();
+            lk.unlock();
+            // evaluate outside the lock: callers keep filling the next batch meanwhile
+            pwaf_batch pb{};
+            pb.struct_size = sizeof pb;
+            pb.n = b.n;
+            pb.memory = PWAF_MEM_HOST;
+            for (int f = 0; f < PWAF_N_FIELDS; f++) {
+                b.data[f].resize(b.data[f].size() + PWAF_ARENA_PAD, 0);
+                pb.field[f].data = b.data[f].data();
+                pb.field[f].offsets = b.offs[f].data();
+            }
+            pb.ip = b.ip.data();
+            pb.ip_is_v6 = b.v6.data();
+            pb.port = b.port.data();
+            pb.flags = b.flags.data();
+            if (due == 1) {
+                pb.asn = b.asn.data();
+                pb.country = b.country.data();
+            }
+            std::vector<pwaf_verdict> out(b.n);
+            const int rc = pwaf_evaluate_batch(engine, &pb, out.data(), nullptr);
+            const std::string err = rc ? pwaf_last_error() : "";
+            lk.lock();
+            b.gen->verdicts = std::move(out);
+            b.gen->status = rc;
+            b.gen->error = err;
+            b.gen->done = true;
+            n_batches++;
+            n_requests += b.n;
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_delay_us, pwaf_batcher **out) {
+    if (!engine || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    if (max_batch == 0) return fail(PWAF_E_INVALID_ARG, "max_batch must be at least 1");
+    auto *b = new pwaf_batcher();
+    b->engine = engine;
+    b->max_batch = max_batch;
+    b->max_delay = std::chrono::microseconds(max_delay_us);
+    b->slot[0].reset();
+    b->slot[1].reset();
+    b->worker = std::thread([b] { b->run(); });
+    *out = b;
+    return PWAF_OK;
+}
+
+int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *out) {
+    if (!b || !r || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    const char *ptr[PWAF_N_FIELDS] = {r->host, r->url, r->path, r->method, r->user_agent};
+    const uint32_t len[PWAF_N_FIELDS] = {r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
+    for (int f = 0; f < PWAF_N_FIELDS; f++)
+        if (len[f] && !ptr[f]) return fail(PWAF_E_INVALID_ARG, "NULL field with non-zero length");
+    std::shared_ptr<Generation> gen;
+    uint32_t idx;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        if (b->stop) return fail(PWAF_E_INVALID_ARG, "batcher is shutting down");
+        Slot &s = b->slot[r->has_geoip ? 1 : 0];
+        // a full slot the dispatcher has not picked up yet: wait for it to be taken
+        while (s.n >= b->max_batch && !b->stop) {
+            b->cv_work.notify_one();
+            b->cv_done.wait_for(lk, std::chrono::microseconds(50));
+        }
+        Slot &t = b->slot[r->has_geoip ? 1 : 0];
+        for (int f = 0; f < PWAF_N_FIELDS; f++) {
+            if ((uint64_t)t.data[f].size() + len[f] > 0xFFFFFFF0ull) return fail(PWAF_E_BATCH, "batch field arena would exceed 4 GiB");
+            t.data[f].insert(t.data[f].end(), (const uint8_t *)ptr[f], (const uint8_t *)ptr[f] + len[f]);
+            t.offs[f].push_back((uint32_t)t.data[f].size());
+        }
+        t.ip.insert(t.ip.end(), r->ip, r->ip + 16);
+        t.v6.push_back(r->ip_is_v6);
+        t.flags.push_back(r->flags);
+        t.port.push_back(r->port);
+        if (r->has_geoip) {
+            t.asn.push_back(r->asn);
+            t.country.push_back((uint16_t)(r->country[0] | (r->country[1] << 8)));
+        }
+        idx = t.n++;
+        gen = t.gen;
+        if (idx == 0) t.deadline = Clock::now() + b->max_delay;
+        if (idx == 0 || t.n >= b->max_batch) b->cv_work.notify_one();
+        b->cv_done.wait(lk, [&] { return gen->done; });
+    }
+    if (gen->status != PWAF_OK) return fail(gen->status, gen->error);
+    *out = gen->verdicts[idx];
+    return PWAF_OK;
+}
+
+int pwaf_batcher_stats(pwaf_batcher *b, uint64_t *n_batches, uint64_t *n_requests) {
+    if (!b) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (n_batches) *n_batches = b->n_batches;
+    if (n_requests) *n_requests = b->n_requests;
+    return PWAF_OK;
+}
+
+void pwaf_batcher_destroy(pwaf_batcher *b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;  // pending requests are still evaluated (the dispatcher drains both slots before it returns)
+    }
+    b->cv_work.notify_all();
+    if (b->worker.joinable()) b->worker.join();
+    delete b;
+}
+
+}  // extern "C"

@@ -96,6 +96,11 @@ def lib():
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
     L.pwaf_engine_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
+    L.pwaf_batcher_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.pwaf_batcher_evaluate.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
+    L.pwaf_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pwaf_batcher_destroy.argtypes = [vp]
+    L.pwaf_batcher_destroy.restype = None
     L.pwaf_geoip_from_mmdb.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(_abi.GeoipEntry)), C.POINTER(C.c_size_t)]
     L.pwaf_geoip_free.argtypes = [C.POINTER(_abi.GeoipEntry)]
     L.pwaf_geoip_free.restype = None
@@ -349,6 +354,65 @@ class RuleEngine:
         if n < 0:
             _raise(n, lib().pwaf_last_error().decode(errors="replace"))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
+
+
+def _request_struct(r: Request):
+    """pwaf_request for one Request; returns (struct, keepalive) — the byte strings must outlive the call."""
+    from .batch import ip_to_bytes16
+
+    fields = [x.encode() if isinstance(x, str) else bytes(x) for x in (r.host, r.url, r.path, r.method, r.user_agent)]
+    st = _abi.Request()
+    for name, b in zip(("host", "url", "path", "method", "user_agent"), fields):
+        setattr(st, name, b)
+        setattr(st, name + "_len", len(b))
+    ip, v6 = ip_to_bytes16(r.ip)
+    C.memmove(st.ip, ip, 16)
+    st.ip_is_v6 = int(v6)
+    st.flags = _abi.FLAG_CAPTCHA_VERIFIED if r.captcha_verified else 0
+    st.port = r.remote_port
+    if r.asn is not None and r.country is not None:
+        st.has_geoip = 1
+        cc = r.country.encode() if isinstance(r.country, str) else bytes(r.country)
+        st.country[0], st.country[1] = cc[0], cc[1]
+        st.asn = r.asn
+    return st, fields
+
+
+class MicroBatcher:
+    """Deadline micro-batcher over a RuleEngine (pwaf_batcher_*): `evaluate(Request)` blocks until the request's batch — closed at
+    `max_batch` requests or after `max_delay_us` — has been evaluated on the GPU. Safe to call from many threads (ctypes drops the GIL)."""
+
+    def __init__(self, engine: "RuleEngine", max_batch: int = 4096, max_delay_us: int = 200):
+        self._engine = engine  # keeps the engine alive
+        h = C.c_void_p()
+        rc = lib().pwaf_batcher_create(engine._h, max_batch, max_delay_us, C.byref(h))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        self._h = h
+
+    def evaluate(self, request: Request) -> Verdict:
+        st, _keep = _request_struct(request)
+        out = _abi.Verdict()
+        rc = lib().pwaf_batcher_evaluate(self._h, C.byref(st), C.byref(out))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return verdict_from_record({"action": out.action, "rule_idx": out.rule_idx})
+
+    def stats(self) -> Tuple[int, int]:
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        lib().pwaf_batcher_stats(self._h, C.byref(nb), C.byref(nr))
+        return nb.value, nr.value
+
+    def close(self):
+        if self._h:
+            lib().pwaf_batcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def geoip_from_mmdb(content: bytes) -> np.ndarray:

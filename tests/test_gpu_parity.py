@@ -140,6 +140,44 @@ def test_tuning_changes_speed_only_never_verdicts():
         eng.close()
 
 
+def test_micro_batcher_serves_concurrent_single_request_callers():
+    """RuleEngine::evaluate(Request) -> Action from many threads at once: the deadline micro-batcher gathers them into GPU batches."""
+    import threading
+    from pingoo_amd.engine import MicroBatcher
+
+    rng = random.Random(11)
+    lists = {"bad": (_abi.LIST_IP, ["10.0.0.0/8", "2001:db8::/32"])}
+    geo = H.fuzz_geoip(rng)
+    rules = [("ip", 'lists["bad"].contains(client.ip)', [B]), ("ua", 'http_request.user_agent.contains("sqlmap")', [B]),
+             ("adm", 'http_request.path.starts_with("/admin") && client.country != "FR"', [CAP, B]), ("asn", "client.asn == 64500", [B])]
+    eng = RuleEngine(rules, lists, geo)
+    reqs = H.fuzz_requests(rng, 1200, False) + H.fuzz_requests(rng, 400, True)  # engine-side GeoIP and caller-supplied asn/country, mixed
+    rng.shuffle(reqs)
+    want = []
+    for r in reqs:
+        v = pyoracle.Oracle(rules, lists, geo).evaluate(RequestBatch.from_requests([r]))[0]
+        want.append((int(v["action"]), int(v["rule_idx"])))
+    mb = MicroBatcher(eng, max_batch=256, max_delay_us=500)
+    got = [None] * len(reqs)
+
+    def work(lo, hi):
+        for k in range(lo, hi):
+            got[k] = mb.evaluate(reqs[k])
+    threads = [threading.Thread(target=work, args=(k * 50, (k + 1) * 50)) for k in range(len(reqs) // 50)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for k, v in enumerate(got):
+        assert int(v.decision) == want[k][0], k
+        if want[k][1] < _abi.RULE_CAPTCHA_ENDPOINT:
+            assert v.rule_idx == want[k][1], k
+    n_batches, n_requests = mb.stats()
+    assert n_requests == len(reqs) and n_batches < n_requests / 2, (n_batches, n_requests)  # callers really were batched
+    mb.close()
+    eng.close()
+
+
 def test_full_size_config2_properties():
     """1M requests x 256 rules (BASELINE.json configs[1]) — too big for the oracle to check exhaustively in seconds, so:
     (1) a random 8k sample is checked bit-exactly, (2) counters == histogram of the verdict array (checksum of checksums),
