@@ -114,7 +114,7 @@ struct VerdictArgs {
     uint4 *gpairs;
     uint32_t *ghdr;
     uint32_t pair_stride;
-    uint32_t attr_blocks;  // grid of the attribute kernel (the device's CU count)
+    uint32_t attr_blocks;  // the device's CU count: grid of the attribute kernel and of the LDS-table verdict kernel
     // outputs
     pwaf_verdict *out;
     unsigned long long *counts;  // 4, accumulated (nullable)

@@ -1113,7 +1113,10 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
     static thread_local uint32_t configured[2] = {0, 0};
     if (int e = configure_lds(fn, sh.lds_bytes, configured[sh.lds_tables])) return e;
     uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
-    const uint32_t cap = sh.lds_tables ? 1024u : 2048u;  // a few rounds per CU: the tail stays short, table staging stays negligible
+    static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;  // profiling only
+    // with LDS tables a workgroup fills a CU: one persistent workgroup per CU (measured: 0.331 ms vs 0.346 at 4 per CU — every
+    // workgroup stages 25 KiB of tables and clears its column files once); small workgroups: a few rounds per CU
+    const uint32_t cap = forced_cap ? forced_cap : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return 0;
     void *args[] = {const_cast<VerdictArgs *>(&a)};
