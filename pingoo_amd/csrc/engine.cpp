@@ -435,6 +435,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.list = (const uint16_t *)d.list.p;
         a.start_emit = d.start_emit;
         a.emit_base = d.emit_base;
+        a.n_cus = e->n_cus;
         a.chunks = d.gate >= 0 ? 1u : d.chunks;
         a.special_base = d.special_base;
         a.n_states = d.n_states;

@@ -46,6 +46,7 @@ struct ScanArgs {
     uint32_t n_states, stride, n_classes, n_hot;
     uint32_t start_emit;      // 1 + emit-list id of the start state
     uint32_t emit_base, special_base;
+    uint32_t n_cus;           // CUs of the device (grid cap of a full pass)
     uint32_t chunks;          // 16-byte chunks per loop iteration: 1 or 2 (ungated passes; chosen from the tuning sample)
     uint32_t *rec;            // n hit records of this pass
     PoolEntry *pool;

@@ -187,6 +187,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     // lookups use plain integer addresses: the region bases fold into the ds_read offset fields, a class lookup is one SDWA
     // shift + ds_read_b32, a DFA step is v_lshl_add (cell * 2 + class offset) + ds_read_u16.
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
+    // the attribute kernel shares the CUs: scan waves issue first, its waves take the slots they leave (default priority 0)
+    __builtin_amdgcn_s_setprio(3);
     if (INDIRECT) {
         // gated pass: most workgroups of the fixed grid have nothing to do (the request lists are short) — leave before paying
         // for the table staging
@@ -458,11 +460,12 @@ int launch_scan(const ScanArgs &a, void *stream) {
     const void *fn = v == 2 ? reinterpret_cast<const void *>(scan_kernel<4>) : v == 1 ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
     if (int e = configure_lds(fn, lds, configured[v])) return e;
     if (a.n == 0) return 0;
-    // at least 256 requests per wave so that work-pulling has something to balance; at most two rounds of one
-    // workgroup per CU: long slabs keep the pull queue busy until the very end
+    // at least 256 requests per wave so that work-pulling has something to balance
     uint32_t waves = (a.n + 255) / 256;
     uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
-    if (blocks > 512) blocks = 512;
+    static const uint32_t forced_cap = getenv("PWAF_SCAN_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_SCAN_BLOCKS")) : 0u;  // profiling only
+    const uint32_t cap = forced_cap ? forced_cap : std::max(1u, a.n_cus);  // one persistent workgroup per CU: the table is staged once
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     void *args[] = {const_cast<ScanArgs *>(&a)};
     hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kScanThreads), args, lds, (hipStream_t)stream);
@@ -1080,11 +1083,12 @@ int launch_dir24(const VerdictArgs &a, void *out, void *stream) {
 
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    // One workgroup (4 waves) per CU: measured best on MI355X. The scan kernels leave ~25 % of the vector issue
-    // slots idle; one attribute wave per SIMD soaks those up over the whole scan phase, whereas a big grid competes with the scans
-    // for issue slots and merely moves time from one kernel to the other.
+    // Two workgroups (8 waves) per CU, at the default wave priority 0 while the scan waves raise theirs to 3: the attribute waves
+    // take the issue slots the scans leave idle (~25 %) instead of competing for them, and 2 of them per SIMD are what still fits
+    // the register file next to a 4-chunk scan workgroup (measured on MI355X, DESIGN.md §6.1: 256/384/512/768 workgroups ->
+    // 2.71/2.49/2.47/2.76 ms per step).
     static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;  // profiling only
-    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : std::max(1u, a.attr_blocks));
+    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : 2 * std::max(1u, a.attr_blocks));
     hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
