@@ -141,16 +141,20 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     const uint32_t C = g.n_classes, stride = C + 3, stride2 = stride * 2;
     // Class numbering = cell position inside a row. An LDS lookup conflicts when two lanes hit different dwords of one bank
     // (32 banks x 4 B = 128 B: DESIGN.md §6); lanes that sit in the SAME row — the usual case, most walks hover around the
-    // start state — conflict exactly when their classes are 64 cells apart. With more than 64 classes the positions
-    // [C - 64, 64) have no alias inside the row: given a traffic profile, the most frequent classes get those.
+    // start state — conflict exactly when their classes are a multiple of 64 cells apart. With more than 64 classes some
+    // positions have no alias inside the row: given a traffic profile, the most frequent classes get those.
     std::vector<uint32_t> cpos(C);
     for (uint32_t c = 0; c < C; c++) cpos[c] = c;
     if (class_freq && class_freq->size() >= C && C > 64) {
         std::vector<uint32_t> by_freq(C), slots;
         for (uint32_t c = 0; c < C; c++) by_freq[c] = c;
         std::stable_sort(by_freq.begin(), by_freq.end(), [&](uint32_t x, uint32_t y) { return (*class_freq)[x] > (*class_freq)[y]; });
-        for (uint32_t p = C - 64; p < 64; p++) slots.push_back(p);       // alias-free positions first
-        for (uint32_t p = 0; p < C - 64; p++) { slots.push_back(p + 64); slots.push_back(p); }  // then the aliasing pairs
+        // positions ordered by how many positions of the row share their bank (p mod 64): alone first, then pairs, then triples
+        for (uint32_t share = 1; share <= 5; share++)
+            for (uint32_t p = 0; p < C; p++) {
+                const uint32_t r = p % 64, n_share = (C - 1 - r) / 64 + 1;
+                if (n_share == share) slots.push_back(p);
+            }
         for (uint32_t k = 0; k < C; k++) cpos[by_freq[k]] = slots[k];
     }
     if (g.n_states > kMaxDfaStates) return fail(PWAF_E_UNSUPPORTED, "DFA has more than 32767 states");

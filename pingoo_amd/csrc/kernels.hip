@@ -6,16 +6,19 @@
 // lane per RULE — instead of one interpreter walk per rule per request (pingoo/rules.rs:37-51,
 // http_listener.rs:251-264).
 //
-//   scan_kernel     one launch per DFA group (ideally one per request field). Every lane walks ONE request's field
-//                   through the multi-pattern DFA and PULLS the next request of its wave's slab when it is done
-//                   (ballot + prefix popcount), so ragged field lengths do not idle lanes. Transition rows of
-//                   the shallow ("hot") states live in LDS; rows of deep states are read from the L2-resident
-//                   table. What a request matched is written as one 4-byte hit record (two atoms inline, more
-//                   through an overflow chain): lanes never share state, no atomics on the common path.
-//   verdict_kernel  per group: turns the hit records into LDS column words, derives the numeric columns (lengths,
-//                   port, ASN, country table, ip-list membership via the radix trie, GeoIP via the LPM trie) with
-//                   wave ballots, evaluates every rule's DNF with one lane per rule, resolves first-match-wins,
-//                   writes verdicts, action counters and the compacted index list of non-Allow requests.
+//   scan_kernel<CH>  one launch per DFA pass (ideally one per request field), one persistent workgroup per CU. Every lane walks
+//                    ONE request's field through the multi-pattern DFA, CH 16-byte chunks per iteration, and PULLS the next request of
+//                    its wave's slab when it is done (ballot + prefix popcount), so ragged field lengths do not idle lanes. The most
+//                    visited transition rows live in LDS; the others are read from the L2-resident table. What a request matched is
+//                    written as one 4-byte hit record (two atoms inline, more through an overflow chain): lanes never share state, no
+//                    atomics on the common path.
+//   gscan_kernel     every gated pass (patterns with wide gaps, visited only by requests whose prefilter factor matched) in one launch.
+//   attr_kernel      beside the scans, on a side stream at lower wave priority: everything that is not a string scan — GeoIP record and
+//                    ip-list membership (DIR-24-8 table + radix tries), country / integer-set membership, length / port / asn
+//                    comparisons — reduced per 64-request group to (column, 64-request mask) pairs with wave ballots.
+//   verdict_kernel   per group: turns hit records and pairs into LDS column words, finds the candidate rules through trigger lists,
+//                    evaluates each candidate's DNF with one lane per rule, resolves first-match-wins, writes verdicts, action
+//                    counters and the compacted index list of non-Allow requests.
 //
 // No MFMA: this is byte/integer work bounded by LDS lookups per input byte and HBM streaming.
 #include <hip/hip_runtime.h>
@@ -175,7 +178,9 @@ __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const 
 // CH = 16-byte chunks a lane walks per loop iteration. 2 halves the per-byte cost of the pull / finish logic (a third of the
 // vector instructions at CH = 1) but idles a finished lane for up to 31 bytes instead of 15: it pays for long fields (URL,
 // User-Agent), not for short ones (host, method). The engine picks it per pass from the tuning sample's mean field length.
-template <bool INDIRECT, int CH>
+// WIDE: a row has more than 127 byte classes, so a class's byte offset inside a row (class * 2) no longer fits the 256 x u8 class
+// table; the table is then 256 x u32 (rare: it takes patterns that tell ~128 byte values apart).
+template <bool INDIRECT, int CH, bool WIDE>
 __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t stride2 = a.stride * 2;
@@ -212,7 +217,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         const uint32_t base = hot_bytes & ~15u;
         if (tid < (hot_bytes & 15) / 2) reinterpret_cast<uint16_t *>(lds + kClsBytes + base)[tid] = a.tab[base / 2 + tid];
     }
-    if (tid < 256) lds[tid] = (unsigned char)(a.classmap[tid] * 2u);
+    if (tid < 256) {
+        if (WIDE) reinterpret_cast<uint32_t *>(lds)[tid] = a.classmap[tid] * 2u;
+        else lds[tid] = (unsigned char)(a.classmap[tid] * 2u);
+    }
     // a pass that owns prefilter factors keeps its atom -> gated-pass bitmask map in LDS too (one lookup per hit of a finished request)
     const uint32_t gate_base = kClsBytes + tab_bytes;
     if (a.colmask_local != nullptr)
@@ -329,7 +337,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         for (int k = 0; k < 16; k++) {
             const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
             // byte classes do not depend on the state: all 16 lookups are issued before the dependent chain starts
-            uint32_t c = *reinterpret_cast<lds_u8_ptr>((uintptr_t)byte);
+            const uint32_t c = WIDE ? *reinterpret_cast<lds_u32_ptr>((uintptr_t)(byte << 2)) : (uint32_t)*reinterpret_cast<lds_u8_ptr>((uintptr_t)byte);
             c2[k] = (uint32_t)k < cnt ? c : stay2;  // past the end: the STAY cell
         }
         // The 16 steps run in groups of 4 with ONE check per group: inside a group every lane chains lookup to lookup
@@ -435,14 +443,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     }
 }
 
-template <int CH>
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false, CH>(a); }
+template <int CH, bool WIDE>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false, CH, WIDE>(a); }
 
 // Every gated pass of the program in ONE launch (blockIdx.y = pass): their request lists are short, so separate launches were
 // dominated by launch latency and table staging.
+template <bool WIDE>
 __global__ __launch_bounds__(kScanThreads) void gscan_kernel(GatedArgs b) {
     const ScanArgs a = b.g[blockIdx.y];
-    scan_body<true, 1>(a);
+    scan_body<true, 1, WIDE>(a);
 }
 
 static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
@@ -455,9 +464,13 @@ static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
 
 int launch_scan(const ScanArgs &a, void *stream) {
     const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.colmask_local ? a.n_local : 0u);
-    static thread_local uint32_t configured[3] = {0, 0, 0};
-    const int v = a.chunks == 4 ? 2 : a.chunks == 2 ? 1 : 0;
-    const void *fn = v == 2 ? reinterpret_cast<const void *>(scan_kernel<4>) : v == 1 ? reinterpret_cast<const void *>(scan_kernel<2>) : reinterpret_cast<const void *>(scan_kernel<1>);
+    static thread_local uint32_t configured[6] = {0, 0, 0, 0, 0, 0};
+    const bool wide = a.n_classes > 127;
+    const int v = (a.chunks == 4 ? 2 : a.chunks == 2 ? 1 : 0) + (wide ? 3 : 0);
+    const void *fns[6] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
+                          reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
+                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>)};
+    const void *fn = fns[v];
     if (int e = configure_lds(fn, lds, configured[v])) return e;
     if (a.n == 0) return 0;
     // at least 256 requests per wave so that work-pulling has something to balance
@@ -474,14 +487,20 @@ int launch_scan(const ScanArgs &a, void *stream) {
 
 int launch_scan_gated(const GatedArgs &b, void *stream) {
     uint32_t lds = 0;
-    for (uint32_t k = 0; k < b.count; k++) lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, 0u));
-    static thread_local uint32_t configured = 0;
-    if (int e = configure_lds(reinterpret_cast<const void *>(gscan_kernel), lds, configured)) return e;
+    bool wide = false;
+    for (uint32_t k = 0; k < b.count; k++) {
+        lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, 0u));
+        wide = wide || b.g[k].n_classes > 127;  // (the u32 class table serves narrow passes too: one variant per launch)
+    }
+    static thread_local uint32_t configured[2] = {0, 0};
+    const void *fn = wide ? reinterpret_cast<const void *>(gscan_kernel<true>) : reinterpret_cast<const void *>(gscan_kernel<false>);
+    if (int e = configure_lds(fn, lds, configured[wide ? 1 : 0])) return e;
     if (b.count == 0 || b.g[0].n == 0) return 0;
     // the list lengths are only known on the device; lists are short (the prefilters are rare), so a modest fixed grid per
     // pass is enough and idle workgroups exit at once
-    hipLaunchKernelGGL(gscan_kernel, dim3(64, b.count), dim3(kScanThreads), lds, (hipStream_t)stream, b);
-    return (int)hipGetLastError();
+    void *args[] = {const_cast<GatedArgs *>(&b)};
+    hipError_t e = hipLaunchKernel(fn, dim3(64, b.count), dim3(kScanThreads), args, lds, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -493,22 +512,6 @@ __device__ __forceinline__ uint32_t ip_byte(const uint32_t w[4], uint32_t k) {
 }
 
 // 16-bit root, then 8-bit strides. Returns the leaf value (0 when the family has no table).
-__device__ __forceinline__ uint32_t trie_lookup(const uint32_t *root4, const uint32_t *root6, const uint32_t *nodes, const uint32_t w[4], bool v6) {
-    const uint32_t *root = v6 ? root6 : root4;
-    if (root == nullptr) return 0;
-    uint32_t e = root[(ip_byte(w, 0) << 8) | ip_byte(w, 1)];
-    uint32_t k = 2;
-    while (!(e & TRIE_LEAF)) {
-        e = nodes[(size_t)e * 256 + ip_byte(w, k)];
-        k++;
-    }
-    return e & ~TRIE_LEAF;
-}
-
-__device__ __forceinline__ bool cmp_u32(uint32_t v, uint32_t op, uint32_t c) {
-    return op == OP_EQ ? v == c : op == OP_LT ? v < c : v <= c;  // only EQ / LT / LE reach the device; operands fit 32 bits
-}
-
 // LDS per wave: the column file (one 64-request word per atom), a bitmap of non-zero columns, a bitmap of candidate rules
 // and the ordered candidate list.
 // Bitwise OR over the 64 lanes, in the vector ALU (DPP row shifts + the two cross-row broadcasts): no LDS, no memory.

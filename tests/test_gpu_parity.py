@@ -140,6 +140,25 @@ def test_tuning_changes_speed_only_never_verdicts():
         eng.close()
 
 
+def test_more_than_127_byte_classes():
+    """A DFA that tells > 127 byte values apart uses the wide (u32) class table of the scan kernel; plain and tuned."""
+    rng = random.Random(5)
+    chars = [chr(c) for c in range(0x21, 0x7F) if chr(c) not in '"\\abcxyzq/'] + [chr(c) for c in range(0xA1, 0x100)] + [chr(c) for c in range(0x391, 0x3CA)] + [chr(c) for c in range(0x410, 0x450)]
+    rules = [(f"r{k}", f'http_request.path.contains("{ch}")', [B if k % 3 else CAP]) for k, ch in enumerate(chars)]
+    rules += [("two", 'http_request.url.contains("\u03b1\u03b2") || http_request.url.ends_with("\u044f")', [B])]
+    eng = RuleEngine(rules)
+    pool = chars + ["zz", "/", "\u03b1\u03b2", "\u044f"]
+    reqs = [Request(path="/" + "".join(rng.choice(pool) if rng.random() < 0.1 else rng.choice("abcxyz/") for _ in range(rng.randint(0, 60))),
+                    url="/" + "".join(rng.choice(pool) if rng.random() < 0.3 else "q" for _ in range(rng.randint(0, 90)))) for _ in range(3000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch, threads=8)
+    assert len(set(want["rule_idx"].tolist())) > 50  # many different characters decide
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "wide classes")
+    eng.tune(batch.slice(0, 1000))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "wide classes, tuned")
+    eng.close()
+
+
 def test_micro_batcher_serves_concurrent_single_request_callers():
     """RuleEngine::evaluate(Request) -> Action from many threads at once: the deadline micro-batcher gathers them into GPU batches."""
     import threading
