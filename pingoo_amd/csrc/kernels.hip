@@ -1103,7 +1103,8 @@ VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, u
     VerdictShape s{};
     const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
     const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
-    const bool fits = n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
+    static const bool force_global = getenv("PWAF_FORCE_GLOBAL_TABLES") != nullptr;  // testing knob: exercise the LT = false variant
+    const bool fits = !force_global && n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
     s.lds_tables = fits ? 1 : 0;
     const uint32_t tables = fits ? t_lds : t_glb;
     uint32_t w = tables + wave <= kLdsPerGroup ? (kLdsPerGroup - tables) / wave : 0;

@@ -1,0 +1,108 @@
+"""Targeted GPU parity cases for device-code paths the random fuzzers reach rarely: many comparison atoms (> 64: chunked), many scan
+passes (> 12: beyond the verdict kernel's prefetched records), hit-record overflow chains, prefixes longer than /24 behind the DIR-24
+table, and the verdict kernel variant that keeps the program tables in global memory."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi, geoip_entries
+from pingoo_amd.engine import RuleEngine
+
+pytestmark = pytest.mark.gpu
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def check(rules, lists, geo, reqs, label, **opts):
+    eng = RuleEngine(rules, lists, geo, **opts)
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, lists, geo).evaluate(batch, threads=8)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, label)
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    stats = eng.stats()
+    eng.close()
+    return want, stats
+
+
+def test_more_than_64_comparison_atoms():
+    rng = random.Random(1)
+    rules = [(f"p{k}", f"client.remote_port == {1000 + 7 * k}", [B]) for k in range(90)]
+    rules += [(f"l{k}", f"http_request.url.length() > {300 - k} && client.remote_port < {2000 + k}", [CAP]) for k in range(40)]
+    rules += [("neg", "client.remote_port < -5 || client.remote_port == 4294967296 || http_request.path.length() <= -1", [B]), ("all", "client.remote_port <= 4294967296", [CAP])]
+    reqs = [Request(remote_port=rng.choice([1000 + 7 * rng.randrange(95), rng.randrange(65536)]), url="/" + "u" * rng.randrange(400), captcha_verified=rng.random() < 0.3) for _ in range(2000)]
+    want, stats = check(rules, {}, None, reqs, "many comparisons")
+    assert stats["n_numeric_atoms"] > 130 and len(set(want["rule_idx"].tolist())) > 60
+
+
+def test_more_than_12_scan_passes_and_overflowing_hit_records():
+    rng = random.Random(2)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(3, 6))) for _ in range(260)]
+    rules = [(f"w{k}", f'http_request.path.contains("{w}")', [B]) for k, w in enumerate(words[:200])]
+    # rules that need SEVERAL atoms of the same pass: the request's hit record overflows into the pool chain
+    rules += [(f"m{k}", " && ".join(f'http_request.url.contains("{w}")' for w in words[200 + 6 * k:206 + 6 * k]), [CAP, B]) for k in range(10)]
+    reqs = []
+    for _ in range(3000):
+        p = "/" + "/".join(rng.choice(words + ["zzz"] * 300) for _ in range(rng.randint(0, 4)))
+        k = rng.randrange(10)
+        u = "/" + "-".join(rng.sample(words[200 + 6 * k:206 + 6 * k], rng.choice([6, 6, 5, 3, 0]))) + rng.choice(["", "?x=" + rng.choice(words)])
+        reqs.append(Request(path=p, url=u, captcha_verified=rng.random() < 0.5))
+    want, stats = check(rules, {}, None, reqs, "many passes", max_table_bytes=1024)
+    assert stats["n_dfa_groups"] > 12, stats
+    assert (want["action"] == _abi.ACTION_CAPTCHA).sum() > 50 and (want["action"] == _abi.ACTION_BLOCK).sum() > 50
+
+
+def test_prefixes_longer_than_24_bits_and_ipv6_depth():
+    rng = random.Random(3)
+    geo_rows = [("10.0.0.0/8", 100, "AA"), ("10.1.2.0/24", 200, "BB"), ("10.1.2.128/25", 300, "CC"), ("10.1.2.200/30", 400, "DD"), ("10.1.2.201/32", 500, "EE"),
+                ("2001:db8::/32", 600, "FF"), ("2001:db8:1:2::/64", 700, "GG"), ("2001:db8:1:2:3:4:5:0/112", 800, "HH"), ("2001:db8:1:2:3:4:5:6/128", 900, "II")]
+    lists = {"v4": (_abi.LIST_IP, ["10.1.2.202/31", "10.1.2.129", "192.168.0.0/16", "192.168.7.7/32"]), "v6": (_abi.LIST_IP, ["2001:db8:1:2:3:4:5:6", "2001:db8:1:2:3::/80", "fe80::/10"])}
+    rules = [(c, f'client.country == "{c}"', [B]) for _, _, c in geo_rows[::2]] + [("asn", "client.asn >= 300 && client.asn < 800", [CAP]), ("l4", 'lists["v4"].contains(client.ip)', [B]),
+                                                                                    ("l6", 'lists["v6"].contains(client.ip)', [B]), ("xx", 'client.country == "XX"', [CAP])]
+    v4 = ["10.1.2.%d" % k for k in range(120, 256)] + ["10.1.3.1", "10.9.9.9", "11.0.0.1", "192.168.7.7", "192.168.7.8", "127.0.0.1", "224.1.1.1"]
+    v6 = ["2001:db8:1:2:3:4:5:%x" % k for k in range(0, 12)] + ["2001:db8:1:2:3:4:6:1", "2001:db8:1:2:3:5::1", "2001:db8:1:3::1", "2001:db9::1", "fe80::1", "::1", "ff02::1", "::10.1.2.201"]
+    reqs = [Request(ip=rng.choice(v4 + v6), captcha_verified=rng.random() < 0.3) for _ in range(2000)]
+    want, _ = check(rules, lists, geoip_entries(geo_rows), reqs, "deep prefixes")
+    assert len(set(want["rule_idx"].tolist())) >= 8
+
+
+def test_verdict_kernel_with_program_tables_in_global_memory():
+    """The LT = false variant (programs whose tables do not fit LDS) on the fuzz cases, in a subprocess with the testing knob set."""
+    code = """
+import random, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import RequestBatch, _abi
+from pingoo_amd.engine import RuleEngine, CompiledProgram, UnsupportedExpression
+for seed in range(12):
+    rng = random.Random(9000 + seed)
+    lists = H.fuzz_lists(rng)
+    geo = H.fuzz_geoip(rng)
+    rules = []
+    for k in range(rng.randint(3, 14)):
+        e = H.rexpr(rng, lists)
+        try:
+            CompiledProgram([("r", e, [1])], lists)
+        except UnsupportedExpression:
+            continue
+        rules.append((f"r{k}", e, H.fuzz_actions(rng)))
+    eng = RuleEngine(rules, lists, geo)
+    batch = RequestBatch.from_requests(H.fuzz_requests(rng, 500, seed %% 3 == 0))
+    want = pyoracle.Oracle(rules, lists, geo).evaluate(batch)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, f"global tables, seed {seed}")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    eng.close()
+print("GLOBAL-TABLES-OK")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, PWAF_FORCE_GLOBAL_TABLES="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GLOBAL-TABLES-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
