@@ -202,6 +202,39 @@ def main():
                 "verdict_ms_per_step": verdict_ms / args.steps,
             },
         }
+        # ---- SURVEY §8(d) extras: the part's measured copy bandwidth, bytes per clock and CU, and the PCIe-inclusive rate ----
+        try:
+            src = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            copy_gbs = 8 * 2 * src.numel() / (e0.elapsed_time(e1) / 1e3) / 1e9  # read + write traffic of a device-to-device copy
+            del src, dst
+            props = torch.cuda.get_device_properties(dev)
+            result["roofline"]["peak_measured_copy_gbs"] = copy_gbs
+            result["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            # (2.4 GHz: the MI355X peak engine clock of MI355X_MICROARCH.md; torch does not expose the running clock)
+            result["roofline"]["bytes_per_clk_per_cu_at_2p4ghz"] = achieved * 1e9 / (props.multi_processor_count * 2.4e9)
+        except Exception as exc:  # informational only
+            result["roofline"]["peak_measured_copy_gbs"] = None
+            print(f"copy-bandwidth probe failed: {exc}", file=sys.stderr)
+        if world == 1:
+            # host batch in, verdicts out through pwaf_evaluate_batch: H2D + kernels + D2H, on a bounded slice of the same batch
+            m = min(n, 1_000_000)
+            hb = batch.slice(0, m) if m < n else batch
+            eng.evaluate_batch(hb)
+            t0 = time.perf_counter()
+            hv = eng.evaluate_batch(hb)
+            dt = time.perf_counter() - t0
+            gv = out[:m].cpu().numpy().view(np.uint32)
+            result["pcie_inclusive"] = {"value": m / dt, "unit": "requests/s", "sample": f"{m} requests from host memory, synchronous pwaf_evaluate_batch (H2D of ~324 B/request, kernels, D2H of 8 B/request)",
+                                        "verdicts_match_device_resident_run": bool((hv["action"] == gv[:, 0]).all() and (hv["rule_idx"] == gv[:, 1]).all())}
         # ---- CPU baseline: the oracle (port of the reference's per-request interpreter loop) on host cores ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle
