@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie-inclusive", action="store_true", help="also time a 1M-request HOST batch through pwaf_evaluate_batch (extra launches: keep it out of profiled runs)")
     ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -224,7 +225,7 @@ def main():
         except Exception as exc:  # informational only
             result["roofline"]["peak_measured_copy_gbs"] = None
             print(f"copy-bandwidth probe failed: {exc}", file=sys.stderr)
-        if world == 1:
+        if world == 1 and args.pcie_inclusive:
             # host batch in, verdicts out through pwaf_evaluate_batch: H2D + kernels + D2H, on a bounded slice of the same batch
             m = min(n, 1_000_000)
             hb = batch.slice(0, m) if m < n else batch
