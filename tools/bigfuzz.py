@@ -1,0 +1,44 @@
+"""Extended CPU fuzz: compiled tables (interpreted by tests/table_walker.py) against the oracle on random rule sets.
+usage: python tools/bigfuzz.py <first seed> <last seed>   (about 30 seeds per second and core; no GPU involved)"""
+import sys, random, time
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import RequestBatch, _abi
+from pingoo_amd.engine import CompiledProgram, UnsupportedExpression
+from table_walker import Tables
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+t0=time.time()
+for seed in range(lo, hi):
+    rng = random.Random(seed)
+    lists = H.fuzz_lists(rng)
+    geo = H.fuzz_geoip(rng) if rng.random() < 0.7 else None
+    with_geo = rng.random() < 0.3
+    rules = []
+    for k in range(rng.randint(1, 12)):
+        e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
+        acts = H.fuzz_actions(rng)
+        try:
+            CompiledProgram([("r", e, acts)], lists)
+        except UnsupportedExpression:
+            continue
+        rules.append((f"r{k}", e, acts))
+    flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
+    try:
+        prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
+    except UnsupportedExpression:
+        continue
+    batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
+    want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
+    t = Tables(prog.dump())
+    got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    try:
+        H.assert_verdicts_equal(got, want, batch, f"seed {seed}")
+    except AssertionError as ex:
+        bad += 1
+        print("MISMATCH seed", seed, str(ex)[:300], flush=True)
+print("done", lo, hi, "mismatches", bad, "time", round(time.time()-t0,1), flush=True)
