@@ -356,6 +356,25 @@ class RuleEngine:
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
 
 
+class ServiceRouter:
+    """Service selection on the same engine: the reference walks `services` in order and hands the request to the
+    first one whose `route:` expression is true — or has none (http_listener.rs:266-271, http_proxy_service.rs:84-95: same language,
+    same context, error / non-bool = no match). That is first-match-wins over one expression per service, i.e. a rule set whose rule
+    k 'blocks' with rule index k: no new device code, just an engine without the two request gates.
+    `route_batch` -> int32 array: index of the selected service, -1 = none (the reference answers 404)."""
+
+    def __init__(self, routes: Sequence[Tuple[str, Optional[str]]], lists=None, geoip=None, **opts):
+        rules = [(name, expr, [_abi.RULE_ACTION_BLOCK]) for name, expr in routes]
+        self._engine = RuleEngine(rules, lists or {}, geoip, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS, **opts)
+
+    def route_batch(self, batch: RequestBatch) -> np.ndarray:
+        v = self._engine.evaluate_batch(batch)
+        return np.where(v["action"] == _abi.ACTION_BLOCK, v["rule_idx"].astype(np.int64), -1).astype(np.int32)
+
+    def close(self):
+        self._engine.close()
+
+
 def _request_struct(r: Request):
     """pwaf_request for one Request; returns (struct, keepalive) — the byte strings must outlive the call."""
     from .batch import ip_to_bytes16

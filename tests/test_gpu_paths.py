@@ -106,3 +106,31 @@ print("GLOBAL-TABLES-OK")
     env = dict(os.environ, PWAF_FORCE_GLOBAL_TABLES="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GLOBAL-TABLES-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_service_routing_is_first_match_over_route_expressions():
+    """http_listener.rs:266-271: the first service whose route matches (or that has no route) takes the request; none -> 404."""
+    from pingoo_amd.engine import ServiceRouter
+
+    rng = random.Random(4)
+    routes = [("api", 'http_request.host.starts_with("api.")'), ("static", 'http_request.path.starts_with("/static/") || http_request.path.ends_with(".css")'),
+              ("admin", 'http_request.host == "admin.example.com" && lists["office"].contains(client.ip)'), ("broken", "http_request.path"), ("v2", 'http_request.url.matches("^/v2/[0-9]+")')]
+    lists = {"office": (_abi.LIST_IP, ["10.0.0.0/8"])}
+    hosts = ["api.example.com", "www.example.com", "admin.example.com", "api", ""]
+    paths = ["/static/a.js", "/x/y.css", "/v2/123/items", "/v2/abc", "", "/index.html"]
+    reqs = [Request(host=rng.choice(hosts), path=(p := rng.choice(paths)), url=p or "/", ip=rng.choice(["10.1.1.1", "8.8.8.8"]), user_agent="") for _ in range(800)]
+    batch = RequestBatch.from_requests(reqs)
+    rules = [(n, e, [B]) for n, e in routes]
+    flags = _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS
+    want = pyoracle.Oracle(rules, lists, None, flags=flags).evaluate(batch)
+    expect = np.where(want["action"] == _abi.ACTION_BLOCK, want["rule_idx"].astype(np.int64), -1)
+    router = ServiceRouter(routes, lists)
+    got = router.route_batch(batch)
+    assert (got == expect).all()
+    assert set(got.tolist()) == {-1, 0, 1, 2, 4}  # "broken" (a non-bool route) never matches; an empty User-Agent is not gated here
+    # with a catch-all service at the end nothing is unrouted
+    r2 = ServiceRouter(routes + [("default", None)], lists)
+    got2 = r2.route_batch(batch)
+    assert (got2[got >= 0] == got[got >= 0]).all() and (got2[got < 0] == len(routes)).all()
+    router.close()
+    r2.close()
