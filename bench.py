@@ -133,7 +133,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE.json configs[{args.config - 1}]: {n} requests/GPU x {len(wl.rules)} rules "
-                        f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} LDS-resident DFA tables, {stats['n_ip_lists']} CIDR lists, "
+                        f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} DFA passes, {stats['n_filtered_groups']} of them behind a bigram prefilter, {stats['n_ip_lists']} CIDR lists, "
                         f"{0 if wl.geoip is None else len(wl.geoip)} GeoIP prefixes), seed 0x50494E47^{args.config}",
             "requests_per_gpu": n,
             "rules": len(wl.rules),
@@ -146,45 +146,58 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (scan_kernel: the launches that stream the request bytes) ----
         field_bytes = dbatch.field_bytes
-        scan_ms, verdict_ms, fields_scanned = 0.0, 0.0, set()
+        # Launches that stream request bytes: filter_kernel (every pass behind a bigram prefilter, all fields in ONE launch) and
+        # scan_kernel (passes whose DFA walks every request). Algorithmic bytes: every byte of a streamed field ONCE per launch
+        # + its n+1 offsets. The roofline object describes whichever of the two takes more time per step.
+        kinds = {"filter_kernel": [0.0, 0, 0], "scan_kernel": [0.0, 0, 0]}  # ms, launches, algorithmic bytes
+        verdict_ms, attr_ms, other_ms = 0.0, 0.0, {}
+        fnames = ["host", "url", "path", "method", "user_agent"]
         for name, ms, tag in ktimes:
-            if name.startswith("scan_"):
-                scan_ms += ms
-                fields_scanned.add(tag)
+            if name == "filter":
+                k = kinds["filter_kernel"]
+                k[0] += ms
+                k[1] += 1
+                k[2] += sum(field_bytes[f] + 4 * (n + 1) for f in range(5) if (tag >> f) & 1)
+            elif name.startswith("scan_"):
+                k = kinds["scan_kernel"]
+                k[0] += ms
+                k[1] += 1
+                k[2] += field_bytes[tag] + 4 * (n + 1)
             elif name == "verdict":
                 verdict_ms += ms
-        n_scan_launches = sum(1 for k in ktimes if k[0].startswith("scan_"))
+            elif name == "attr":
+                attr_ms += ms  # side stream, beside the scans
+            else:
+                other_ms[name.split("_x")[0]] = other_ms.get(name.split("_x")[0], 0.0) + ms
+        dom = max(kinds, key=lambda kk: kinds[kk][0])
+        scan_ms, n_scan_launches, scan_alg = kinds[dom]
+        stream_ms = sum(v[0] for v in kinds.values())
         if args.verbose:
             per = {}
             for name, ms, tag in ktimes:
                 per.setdefault(name, []).append(ms)
             for name, v in per.items():
-                fb = field_bytes[int(name.split("_g")[0].split("_", 1)[1] == "user_agent" and 4 or ["host", "url", "path", "method"].index(name.split("_g")[0].split("_", 1)[1]))] if name.startswith("scan_") else 0
-                avg = sum(v) / len(v)
-                print(f"  {name:<24} avg {avg:8.3f} ms  x{len(v)}" + (f"  {fb / avg / 1e6:8.1f} GB/s of field bytes" if fb else ""), file=sys.stderr)
+                print(f"  {name:<24} avg {sum(v) / len(v):8.3f} ms  x{len(v)}", file=sys.stderr)
             print("  " + json.dumps(stats), file=sys.stderr)
-        # algorithmic bytes: every byte of a scanned field ONCE per step (however many DFA groups re-read it)
-        # + its n+1 offsets; the verdict kernel is credited with the fixed-width columns.
-        scan_alg = sum(field_bytes[f] + 4 * (n + 1) for f in fields_scanned) * args.steps
         scan_s = scan_ms / 1000.0
         achieved = scan_alg / scan_s / 1e9 if scan_s > 0 else 0.0
         pipeline_alg = dbatch.algorithmic_bytes * args.steps
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes over this very
         # command (tools/profile_round.sh), committed under profiles/ and only quoted for the workload they were measured on
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
         if args.config == 3 and n == 10_000_000 and os.path.exists(tpath):
             try:
                 tk = json.load(open(tpath))["kernels"]
-                sk = [v for k, v in tk.items() if "::scan_kernel" in k]  # one entry per template instantiation (chunks per iteration)
+                sk = [v for k, v in tk.items() if "::" + dom in k]  # one entry per template instantiation
                 traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
-                traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+                traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
             except Exception:  # a malformed profile file must not break the bench line
                 traffic, traffic_src = None, None
-        kernel_s = (scan_ms + verdict_ms) / 1000.0
+        kernel_s = (stream_ms + verdict_ms + sum(other_ms.values())) / 1000.0  # (the attribute kernel runs beside these on a side stream)
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": "scan_kernel",
+            "kernel": dom,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -199,8 +212,11 @@ def main():
                 "alg_bytes_per_request": dbatch.algorithmic_bytes / n,
                 "achieved": pipeline_alg / kernel_s / 1e9 if kernel_s > 0 else 0.0,
                 "frac": (pipeline_alg / kernel_s / 1e9 / HBM_PEAK_GBS) if kernel_s > 0 else 0.0,
-                "scan_ms_per_step": scan_ms / args.steps,
+                "filter_ms_per_step": kinds["filter_kernel"][0] / args.steps,
+                "scan_ms_per_step": kinds["scan_kernel"][0] / args.steps,
                 "verdict_ms_per_step": verdict_ms / args.steps,
+                "attr_ms_per_step_side_stream": attr_ms / args.steps,
+                "other_ms_per_step": {k: v / args.steps for k, v in other_ms.items()},
             },
         }
         # ---- SURVEY §8(d) extras: the part's measured copy bandwidth, bytes per clock and CU, and the PCIe-inclusive rate ----

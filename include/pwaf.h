@@ -112,6 +112,7 @@ void pwaf_list_free(char **items, size_t n);
 
 #define PWAF_OPT_NO_UA_GATE 1u        /* skip gate A (http_listener.rs:196-198)             */
 #define PWAF_OPT_NO_CAPTCHA_BYPASS 2u /* skip gate B (http_listener.rs:200-204)             */
+#define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;
@@ -276,7 +277,7 @@ typedef struct pwaf_stats {
     uint32_t n_rules, n_atoms, n_scan_atoms, n_numeric_atoms;
     uint32_t n_dfa_groups, n_dfa_states_total, max_dfa_states, dfa_table_bytes_total;
     uint32_t n_ip_lists, ipset_trie_nodes, geo_trie_nodes, n_dnf_literals;
-    uint32_t n_warnings, reserved[3];
+    uint32_t n_warnings, n_filtered_groups /* passes behind a bigram prefilter */, reserved[2];
 } pwaf_stats;
 int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
 int pwaf_program_stats(const pwaf_program *, pwaf_stats *out);

@@ -23,7 +23,7 @@ RULE_CAPTCHA_ENDPOINT = 0xFFFFFFFD
 RULE_ACTION_BLOCK, RULE_ACTION_CAPTCHA = 1, 2
 
 LIST_STRING, LIST_INT, LIST_IP = 0, 1, 2
-OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS = 1, 2
+OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER = 1, 2, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CAPTCHA_VERIFIED = 1
 N_FIELDS = 5
@@ -132,7 +132,7 @@ class Stats(C.Structure):
         ("n_rules", C.c_uint32), ("n_atoms", C.c_uint32), ("n_scan_atoms", C.c_uint32), ("n_numeric_atoms", C.c_uint32),
         ("n_dfa_groups", C.c_uint32), ("n_dfa_states_total", C.c_uint32), ("max_dfa_states", C.c_uint32), ("dfa_table_bytes_total", C.c_uint32),
         ("n_ip_lists", C.c_uint32), ("ipset_trie_nodes", C.c_uint32), ("geo_trie_nodes", C.c_uint32), ("n_dnf_literals", C.c_uint32),
-        ("n_warnings", C.c_uint32), ("reserved", C.c_uint32 * 3),
+        ("n_warnings", C.c_uint32), ("n_filtered_groups", C.c_uint32), ("reserved", C.c_uint32 * 2),
     ]
 
 

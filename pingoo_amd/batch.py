@@ -116,6 +116,20 @@ class RequestBatch:
         return RequestBatch(datas, offs, self.ip[lo:hi], self.ip_is_v6[lo:hi], self.port[lo:hi], self.flags[lo:hi],
                             None if self.asn is None else self.asn[lo:hi], None if self.country is None else self.country[lo:hi])
 
+    def tile(self, times: int) -> "RequestBatch":
+        """The batch repeated `times` times (test / bench helper for very large uniform batches)."""
+        datas, offs = [], []
+        for d, o in zip(self.data, self.offsets):
+            body = d[int(o[0]):int(o[-1])]
+            nd = np.concatenate([np.tile(body, times), np.zeros(_abi.ARENA_PAD, dtype=np.uint8)])
+            lens = np.tile(np.diff(o.astype(np.int64)), times)
+            no = np.zeros(self.n * times + 1, dtype=np.uint32)
+            no[1:] = np.cumsum(lens).astype(np.uint32)
+            datas.append(nd)
+            offs.append(no)
+        rep = lambda a: None if a is None else np.tile(a, (times,) + (1,) * (a.ndim - 1))
+        return RequestBatch(datas, offs, rep(self.ip), rep(self.ip_is_v6), rep(self.port), rep(self.flags), rep(self.asn), rep(self.country))
+
     def algorithmic_bytes(self) -> int:
         """sum(field bytes) + 4*(5+1) offset bytes + 22 B numerics + 8 B verdict per request
         (+6 B when GeoIP is precomputed on the host)."""

@@ -1196,6 +1196,15 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         return PWAF_E_UNSUPPORTED;
     }
 
+    // ---- bigram prefilters (filter.cpp): a pass whose patterns all have a literal factor only walks the filter's candidates ----
+    for (auto &terms : rule_terms) for (auto &t : terms) for (uint32_t l : t) if (l & 1) P.atoms[l >> 1].neg_used = true;
+    if (!(P.flags & PWAF_OPT_NO_PREFILTER))
+        for (auto &g : P.groups) build_group_filter(P.atoms, g, nullptr, g.filter);
+    // pass order: plain passes, then filtered ones, then the gated gap passes — the hit records of every list-driven pass are
+    // then contiguous (one memset per batch)
+    std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty() && !g.filter.enabled; });
+    std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty(); });
+
     // ---- numeric atom descriptors ----
     for (size_t a = 1; a < P.atoms.size(); a++) {
         const Atom &at = P.atoms[a];
@@ -1297,6 +1306,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         s.n_dfa_states_total += g.n_states;
         s.max_dfa_states = std::max(s.max_dfa_states, g.n_states);
         s.dfa_table_bytes_total += g.n_states * g.n_classes * 2;
+        if (g.filter.enabled) s.n_filtered_groups++;
     }
     s.n_ip_lists = P.n_ip_lists;
     s.ipset_trie_nodes = P.ipset_trie.n_nodes();
@@ -1344,6 +1354,15 @@ std::vector<uint8_t> dump_program(const Program &p) {
         w.section("GENO", (uint32_t)gi, g.end_off.data(), g.end_off.size() * 4);
         w.section("GENL", (uint32_t)gi, g.end_list.data(), g.end_list.size() * 2);
         w.section("GFLT", (uint32_t)gi, g.filter_cols.data(), g.filter_cols.size() * 4);
+        if (g.filter.enabled) {
+            // bigram prefilter: [init, n_heads] + heads (20 bytes each), then the 4096-entry table
+            std::vector<uint8_t> fh(8 + g.filter.heads.size() * sizeof(FilterHead));
+            const uint32_t hdr[2] = {g.filter.init, (uint32_t)g.filter.heads.size()};
+            memcpy(fh.data(), hdr, 8);
+            if (!g.filter.heads.empty()) memcpy(fh.data() + 8, g.filter.heads.data(), g.filter.heads.size() * sizeof(FilterHead));
+            w.section("GFHD", (uint32_t)gi, fh.data(), fh.size());
+            w.section("GFTB", (uint32_t)gi, g.filter.table.data(), g.filter.table.size() * 4);
+        }
     }
     w.section("NUMA", (uint32_t)p.num_atoms.size(), p.num_atoms.data(), p.num_atoms.size() * sizeof(NumAtomDev));
     w.section("INTP", (uint32_t)p.int_pool.size(), p.int_pool.data(), p.int_pool.size() * 8);

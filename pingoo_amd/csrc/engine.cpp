@@ -80,7 +80,10 @@ struct DevGroup {
     uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base, n_local;
     uint8_t field;
     uint32_t chunks = 1;  // 16-byte chunks per scan iteration (2 for fields whose sampled mean length is >= 48 bytes)
-    int gate = -1;  // >= 0: gated pass, index into the select kernel's lists
+    int gate = -1;  // >= 0: list-driven pass (behind a bigram prefilter, or gated by prefilter factors): index of its request list
+    bool filtered = false;  // the list comes from filter_kernel + compact_kernel
+    GroupFilter filter;     // the prefilter in use (Program's, or rebuilt from a traffic sample by pwaf_engine_tune)
+    DevBuf ftable;
 };
 
 }  // namespace
@@ -101,7 +104,8 @@ struct pwaf_engine {
     std::mutex mu;
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
     DevBuf colmask, gate_lists, attr, dir24;
-    uint32_t n_ungated = 0, n_gated = 0;
+    DevBuf cand_sub, cand_cnt;  // filter_kernel's per-slab candidate regions and counts
+    uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
     unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
@@ -277,6 +281,38 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.dir24 = (const uint64_t *)e->dir24.p;
 }
 
+
+// Decides which passes are list-driven and uploads what that needs: a pass behind a bigram prefilter walks the filter's candidate
+// list, a gated gap pass the list fed by its prefilter factors (owned by earlier passes). Called at creation and again when
+// pwaf_engine_tune has rebuilt the filters from a traffic sample.
+int assign_lists(pwaf_engine *e) {
+    const Program &P = *e->prog.p;
+    int rc;
+    e->n_gated = e->n_filtered = 0;
+    e->select_pass_mask = 0;
+    std::vector<uint32_t> colmask(P.n_cols, 0);
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        DevGroup &d = e->groups[k];
+        d.gate = -1;
+        d.filtered = false;
+        const bool gap = !P.groups[k].filter_cols.empty();
+        if ((!gap && !d.filter.enabled) || e->n_gated >= 32) continue;  // (beyond 32 lists the rest simply walk every request)
+        d.gate = (int)e->n_gated;
+        if (gap) {
+            for (uint32_t c : P.groups[k].filter_cols) colmask[c] |= 1u << e->n_gated;
+        } else {
+            d.filtered = true;
+            e->n_filtered++;
+            if ((rc = upload(d.ftable, d.filter.table))) return rc;
+        }
+        e->n_gated++;
+    }
+    for (size_t k = 0; k < P.groups.size() && k < 64; k++)
+        for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
+            if (colmask[c]) e->select_pass_mask |= 1ull << k;
+    return upload(e->colmask, colmask);
+}
+
 int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
                  uint32_t *d_n_matches, hipStream_t stream) {
     const Program &P = *e->prog.p;
@@ -336,10 +372,12 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     VerdictArgs v{};
     v.n = n;
     v.n_groups = n_groups;
+#ifdef PWAF_PROFILING
     {
         static const uint32_t skip = getenv("PWAF_DEBUG_SKIP") ? (uint32_t)strtoul(getenv("PWAF_DEBUG_SKIP"), nullptr, 0) : 0u;
         v.debug_skip = skip;  // timing experiments only: results are wrong when non-zero
     }
+#endif
     for (int f = 0; f < PWAF_N_FIELDS; f++) v.off[f] = db.field[f].offsets;
     v.ip = db.ip;
     v.ip_is_v6 = db.ip_is_v6;
@@ -395,35 +433,16 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     if ((rc = mark("attr", 0xFEu, e->side))) return rc;
     HIP_TRY(hipEventRecord(e->ev_join, e->side));
 
-    GatedArgs gb{};
-    auto flush_gated = [&]() -> int {
-        if (gb.count == 0) return PWAF_OK;
-        int rc2;
-        if ((rc2 = mark(nullptr, 0))) return rc2;
-        int he = launch_scan_gated(gb, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        char nm[48];
-        snprintf(nm, sizeof nm, "gscan_x%u", gb.count);
-        if ((rc2 = mark(nm, 0xFDu))) return rc2;
-        gb.count = 0;
-        return PWAF_OK;
-    };
-    bool gated_cleared = false;
-    for (size_t gi = 0; gi < e->groups.size(); gi++) {
-        DevGroup &d = e->groups[gi];
+    static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
+    auto scan_args = [&](size_t gi) -> ScanArgs {
+        const DevGroup &d = e->groups[gi];
         ScanArgs a{};
         if (d.gate >= 0) {
-            if (!gated_cleared) {
-                // records of requests a gated pass does not visit must read "nothing matched"; the gated passes are
-                // consecutive (compile.cpp orders them after the ungated ones), so one memset covers them all
-                HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + gi * (size_t)n, 0, (size_t)e->n_gated * n * 4, stream));
-                gated_cleared = true;
-            }
             a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
             a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
         }
-        if (d.gate < 0 && e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
-            // this pass owns prefilter factors: it feeds the gated passes' request lists as requests finish
+        if (e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+            // this pass owns prefilter factors: it feeds the gated gap passes' request lists as requests finish
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
             a.n_local = d.n_local;
             a.gate_lists = (uint32_t *)e->gate_lists.p;
@@ -451,21 +470,109 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.pool_count = (uint32_t *)e->ctrl.p;
         a.pool_cap = pool_cap;
         a.status = (uint32_t *)e->ctrl.p + 1;
-        if (d.gate >= 0) {
-            gb.g[gb.count++] = a;
-            if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
-            continue;
-        }
-        if ((rc = flush_gated())) return rc;  // (only when ungated passes follow gated ones: more than 32 gated passes)
+        return a;
+    };
+    // hit records of list-driven passes must read "nothing matched" for the requests the pass does not visit; compile.cpp orders
+    // those passes last, so one memset covers them all
+    {
+        size_t first_list = e->groups.size();
+        for (size_t gi = 0; gi < e->groups.size(); gi++)
+            if (e->groups[gi].gate >= 0) { first_list = gi; break; }
+        if (first_list < e->groups.size())
+            HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + first_list * (size_t)n, 0, (e->groups.size() - first_list) * (size_t)n * 4, stream));
+    }
+    // ---- 1. plain passes: the DFA walks every request ----
+    for (size_t gi = 0; gi < e->groups.size(); gi++) {
+        const DevGroup &d = e->groups[gi];
+        if (d.gate >= 0) continue;
+        const ScanArgs a = scan_args(gi);
         char nm[48];
-        static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
         snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
         if ((rc = mark(nullptr, 0))) return rc;
         int he = launch_scan(a, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark(nm, (uint64_t)d.field))) return rc;  // alg_bytes slot carries the field id; bench.py supplies bytes
     }
-    if ((rc = flush_gated())) return rc;
+    // ---- 2. bigram prefilters of every filtered pass in one launch, then the compaction of their candidate lists ----
+    if (e->n_filtered) {
+        const uint32_t n_slabs = (n + kFilterSlab - 1) / kFilterSlab;
+        if ((rc = e->cand_sub.reserve((size_t)e->n_filtered * n * 4))) return rc;
+        if ((rc = e->cand_cnt.reserve((size_t)e->n_filtered * n_slabs * 4))) return rc;
+        FilterBatchArgs fb{};
+        uint32_t fi = 0, block = 0, field_mask = 0;
+        auto flush_filters = [&]() -> int {
+            if (fb.count == 0) return PWAF_OK;
+            int rc2;
+            if ((rc2 = mark(nullptr, 0))) return rc2;
+            int he = launch_filter(fb, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc2 = mark("filter", 0x100u | field_mask))) return rc2;  // alg_bytes slot: 0x100 | mask of the fields streamed
+            if ((rc2 = mark(nullptr, 0))) return rc2;
+            he = launch_compact(fb, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc2 = mark("compact", 0xFCu))) return rc2;
+            fb.count = 0;
+            block = 0;
+            field_mask = 0;
+            return PWAF_OK;
+        };
+        for (size_t gi = 0; gi < e->groups.size(); gi++) {
+            const DevGroup &d = e->groups[gi];
+            if (!d.filtered) continue;
+            FilterArgs &f = fb.f[fb.count++];
+            f = FilterArgs{};
+            f.data = db.field[d.field].data;
+            f.off = db.field[d.field].offsets;
+            f.n = n;
+            f.init = d.filter.init;
+            f.table = (const uint32_t *)d.ftable.p;
+            f.n_heads = (uint32_t)std::min<size_t>(2, d.filter.heads.size());
+            for (uint32_t h = 0; h < f.n_heads; h++) {
+                const FilterHead &fh = d.filter.heads[h];
+                uint8_t lit[16] = {0}, msk[16] = {0};
+                memcpy(lit, fh.bytes, fh.len);
+                memset(msk, 0xFF, fh.len);
+                memcpy(f.head_w[h], lit, 16);
+                memcpy(f.head_m[h], msk, 16);
+                f.head_len[h] = fh.len | ((uint32_t)fh.exact << 8);
+                f.head_code[h] = h == 0 ? (uint32_t)fh.local + 1u : ((uint32_t)fh.local + 1u) << 15;
+            }
+            f.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
+            f.sub = (uint32_t *)e->cand_sub.p + (size_t)fi * n;
+            f.sub_count = (uint32_t *)e->cand_cnt.p + (size_t)fi * n_slabs;
+            f.list = (uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
+            f.list_count = (uint32_t *)e->ctrl.p + 2 + d.gate;
+            f.first_block = block;
+            block += (n_slabs + kFilterWaves - 1) / kFilterWaves;
+            field_mask |= 1u << d.field;
+            fi++;
+            if (fb.count == kMaxFiltersPerLaunch && (rc = flush_filters())) return rc;
+        }
+        if ((rc = flush_filters())) return rc;
+    }
+    // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
+    GatedArgs gb{};
+    auto flush_gated = [&]() -> int {
+        if (gb.count == 0) return PWAF_OK;
+        int rc2;
+        if ((rc2 = mark(nullptr, 0))) return rc2;
+        int he = launch_scan_gated(gb, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        char nm[48];
+        snprintf(nm, sizeof nm, "gscan_x%u", gb.count);
+        if ((rc2 = mark(nm, 0xFDu))) return rc2;
+        gb.count = 0;
+        return PWAF_OK;
+    };
+    for (int phase = 0; phase < 2; phase++) {
+        for (size_t gi = 0; gi < e->groups.size(); gi++) {
+            const DevGroup &d = e->groups[gi];
+            if (d.gate < 0 || d.filtered != (phase == 0)) continue;
+            gb.g[gb.count++] = scan_args(gi);
+            if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
+        }
+        if ((rc = flush_gated())) return rc;
+    }
     HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
@@ -587,6 +694,11 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         return dev_fail(PWAF_E_DEVICE);
     }
     e->device = dev;
+    if (hipSetDevice(dev) != hipSuccess) { fail(PWAF_E_DEVICE, "hipSetDevice failed"); return dev_fail(PWAF_E_DEVICE); }
+    if (int ke = configure_kernels(dev)) {
+        fail(PWAF_E_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: ") + hipGetErrorString((hipError_t)ke));
+        return dev_fail(PWAF_E_DEVICE);
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = (uint32_t)cus;
@@ -603,24 +715,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         pass_base.push_back(P.groups[k].atom_base);
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
-    {
-        // gated passes (compile.cpp orders them after every ungated pass): column -> bitmask of the gated passes it triggers
-        std::vector<uint32_t> colmask(P.n_cols, 0);
-        for (size_t k = 0; k < P.groups.size(); k++) {
-            if (P.groups[k].filter_cols.empty() || e->n_gated >= 32) {
-                if (e->n_gated == 0) e->n_ungated = (uint32_t)k + 1;
-                continue;  // (beyond 32 gated passes the rest simply run ungated)
-            }
-            e->groups[k].gate = (int)e->n_gated;
-            for (uint32_t c : P.groups[k].filter_cols) colmask[c] |= 1u << e->n_gated;
-            e->n_gated++;
-        }
-        if (e->n_gated == 0) e->n_ungated = (uint32_t)P.groups.size();
-        for (size_t k = 0; k < P.groups.size() && k < 64; k++)
-            for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
-                if (colmask[c]) e->select_pass_mask |= 1ull << k;
-        if ((rc = upload(e->colmask, colmask))) return dev_fail(rc);
-    }
+    for (size_t k = 0; k < P.groups.size(); k++) e->groups[k].filter = P.groups[k].filter;
+    if ((rc = assign_lists(e.get()))) return dev_fail(rc);
 #define UP(buf, vec)                                     \
     if ((rc = upload(e->buf, vec))) return dev_fail(rc);
     {
@@ -809,9 +905,9 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); }
+    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); g.ftable.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
@@ -932,37 +1028,87 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     const Program &P = *e->prog.p;
     const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
     if (n == 0) return PWAF_OK;
-    // host walk of every pass over the sample: how often each DFA state is the current state
-    std::vector<std::vector<uint64_t>> visits(P.groups.size()), class_freq(P.groups.size());
+    // host walk of every pass over the sample: how often each DFA state is the current state, and for how many requests each
+    // pattern holds (patterns that hold for most traffic must not sit behind the bigram prefilter)
+    std::vector<std::vector<uint64_t>> visits(P.groups.size()), class_freq(P.groups.size()), atom_hits(P.groups.size());
     for (size_t k = 0; k < P.groups.size(); k++) {
         const DfaGroup &g = P.groups[k];
         std::vector<uint64_t> &v = visits[k];
         v.assign(g.n_states, 0);
         std::vector<uint64_t> &cf = class_freq[k];
         cf.assign(256, 0);
+        std::vector<uint64_t> &ah = atom_hits[k];
+        ah.assign(g.n_local, 0);
+        std::vector<uint32_t> stamp(g.n_local, 0);
         const uint8_t *data = sample->field[g.field].data;
         const uint32_t *off = sample->field[g.field].offsets;
         for (uint32_t i = 0; i < n; i++) {
             if (off[i + 1] < off[i]) return fail(PWAF_E_BATCH, "sample offsets are not monotonic");
+            auto note = [&](const std::vector<uint32_t> &o, const std::vector<uint16_t> &l, uint32_t st) {
+                for (uint32_t q = o[st]; q < o[st + 1]; q++)
+                    if (stamp[l[q]] != i + 1) { stamp[l[q]] = i + 1; ah[l[q]]++; }
+            };
             uint32_t s = 0;
+            note(g.emit_off, g.emit_list, s);
             for (uint32_t p = off[i]; p < off[i + 1]; p++) {
                 const uint32_t cl = g.classmap[data[p]];
                 cf[cl]++;
                 s = g.trans[(size_t)s * g.n_classes + cl];
                 v[s]++;
+                if (g.emit_off[s + 1] != g.emit_off[s]) note(g.emit_off, g.emit_list, s);
+            }
+            note(g.end_off, g.end_list, s);
+        }
+    }
+    // bigram prefilters rebuilt for this traffic: window choice and bucketing use the sample's bigram distribution, heads are the
+    // anchored literals the sample actually satisfies; a filter that would flag more than 40 % of the sample is dropped (the pass
+    // then walks every request, as without a filter)
+    if (!(P.flags & PWAF_OPT_NO_PREFILTER)) {
+        std::vector<double> bin_prob[PWAF_N_FIELDS];
+        double mean_len[PWAF_N_FIELDS];
+        for (int f = 0; f < PWAF_N_FIELDS; f++) {
+            std::vector<uint64_t> cnt(kFilterEntries, 0);
+            uint64_t tot = 0;
+            const uint8_t *data = sample->field[f].data;
+            const uint32_t *off = sample->field[f].offsets;
+            for (uint32_t i = 0; i < n; i++)
+                for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[filter_bin(data[p], data[p + 1])]++; tot++; }
+            bin_prob[f].assign(kFilterEntries, 0.0);
+            if (tot)
+                for (uint32_t b = 0; b < kFilterEntries; b++) bin_prob[f][b] = (double)cnt[b] / (double)tot;
+            mean_len[f] = (double)(off[n] - off[0]) / (double)n;
+        }
+        for (size_t k = 0; k < P.groups.size(); k++) {
+            const DfaGroup &g = P.groups[k];
+            FilterHints h;
+            h.bin_prob = bin_prob[g.field].data();
+            h.atom_hits = &atom_hits[k];
+            h.n_requests = n;
+            h.mean_len = mean_len[g.field];
+            GroupFilter &gf = e->groups[k].filter;
+            build_group_filter(P.atoms, g, &h, gf);
+            if (!gf.enabled) continue;
+            const uint8_t *data = sample->field[g.field].data;
+            const uint32_t *off = sample->field[g.field].offsets;
+            uint64_t cand = 0;
+            for (uint32_t i = 0; i < n; i++) cand += filter_candidate_host(gf, data + off[i], off[i + 1] - off[i]) ? 1u : 0u;
+            gf.est_candidate_rate = (double)cand / (double)n;
+            if (cand * 10 > (uint64_t)n * 4) {
+                gf.enabled = false;
+                gf.note = "the filter flags more than 40 % of the sample";
             }
         }
     }
     for (size_t k = 0; k < P.groups.size(); k++) {
         const uint32_t *off = sample->field[P.groups[k].field].offsets;
         const uint64_t total = (uint64_t)(off[n] - off[0]);
-        static const uint32_t t4 = getenv("PWAF_CH4_AT") ? (uint32_t)atoi(getenv("PWAF_CH4_AT")) : 80u;  // (profiling knob)
-        static const uint32_t t2 = getenv("PWAF_CH2_AT") ? (uint32_t)atoi(getenv("PWAF_CH2_AT")) : 48u;  // (profiling knob)
+        const uint32_t t4 = 80u, t2 = 48u;  // mean field length from which a lane takes 4 / 2 chunks per iteration (measured)
         e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)t2 * n ? 2u : 1u;
     }
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
         if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k], &class_freq[k]))) return rc;
+    if ((rc = assign_lists(e))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;
 }

@@ -1,0 +1,442 @@
+// filter.cpp — the bigram prefilter of a scan pass (program.h: GroupFilter; kernels.hip: filter_kernel).
+//
+// The reference evaluates every string predicate of every rule on every request (pingoo/rules.rs:37-51). Nearly all of them are
+// false for nearly all requests — that is what a WAF rule set looks like — so the device first asks a much cheaper question per
+// field: "could ANY pattern of this pass match here?". Every pattern is reduced to a set of necessary literal FACTORS (every match
+// contains one of them), every factor to a window of <= 4 consecutive bigrams, and the windows are spread over 8 buckets of a
+// shift-or automaton whose whole transition function is one 16 KiB table indexed by a hashed, case-folded byte pair. The filter
+// has no false negatives by construction; what it flags is decided exactly by the pass's DFA.
+//
+//   1. factor extraction: the usual prefix / suffix / exact-set algebra over the regex tree, on byte SETS per position so that
+//      (?i) letters and small classes ([0-9], \s) stay inside a factor;
+//   2. window choice: the 4-bigram window of each factor that is least likely in traffic (bin probabilities from a traffic
+//      sample when the engine was tuned, else a built-in prior for URL / header text);
+//   3. bucket assignment: greedy, minimising the summed false-positive probability of the 8 buckets (a bucket accepts a
+//      position when EVERY one of its window positions is hit by SOME member, so members should be few and of equal length);
+//   4. heads: anchored literals that most requests satisfy are taken out of the filter and compared directly.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+
+#include "program.h"
+
+namespace pwaf {
+
+namespace {
+
+using CStr = std::vector<ByteSet>;  // a "class string": one byte set per position
+struct Cover {
+    bool ok = false;
+    std::vector<CStr> s;
+};
+// E: every match IS one of these (exact cover); P / S: every match starts / ends with one of these (always known: {""} is trivial);
+// B: every match CONTAINS one of these somewhere (best inner factor set found so far).
+struct Ext {
+    Cover E, P, S, B;
+};
+
+constexpr size_t kMaxStrs = 24, kMaxLen = 64, kMaxClass = 16;
+
+Cover trivial() {
+    Cover c;
+    c.ok = true;
+    c.s.push_back({});
+    return c;
+}
+
+struct Model {
+    const double *binw;  // kFilterEntries probabilities
+    std::map<std::pair<std::string, std::string>, double> memo;
+    double pair_weight(const ByteSet &a, const ByteSet &b) {
+        // probability that a text bigram falls into one of the bins the pair of sets maps to
+        uint8_t va[256], vb[256];
+        int na = 0, nb = 0;
+        for (int x = 0; x < 256; x++) {
+            if (a[(size_t)x]) va[na++] = (uint8_t)x;
+            if (b[(size_t)x]) vb[nb++] = (uint8_t)x;
+        }
+        std::set<uint32_t> bins;
+        for (int i = 0; i < na; i++)
+            for (int j = 0; j < nb; j++) bins.insert(filter_bin(va[i], vb[j]));
+        double w = 0;
+        for (uint32_t x : bins) w += binw[x];
+        return std::min(1.0, w);
+    }
+    // cheapest window of <= 4 bigrams: returns its cost, start and bigram count
+    double best_window(const CStr &s, size_t &start, size_t &k) {
+        const size_t nb = s.size() - 1;
+        k = std::min<size_t>(4, nb);
+        std::vector<double> w(nb);
+        for (size_t j = 0; j < nb; j++) w[j] = pair_weight(s[j], s[j + 1]);
+        double best = 2;
+        start = 0;
+        for (size_t st = 0; st + k <= nb; st++) {
+            double c = 1;
+            for (size_t j = 0; j < k; j++) c *= w[st + j];
+            if (c < best) { best = c; start = st; }
+        }
+        return best;
+    }
+    // expected false-positive contribution of a factor set; +inf when it is not usable (a string shorter than one bigram)
+    double score(const Cover &c) {
+        if (!c.ok || c.s.empty()) return INFINITY;
+        double t = 0;
+        for (auto &s : c.s) {
+            if (s.size() < 2) return INFINITY;
+            size_t st, k;
+            t += best_window(s, st, k);
+        }
+        return t;
+    }
+};
+
+bool cross(const Cover &a, const Cover &b, Cover &out, int keep /* 0: all (fail when too long), 1: first kMaxLen, 2: last kMaxLen */) {
+    out = Cover();
+    if (!a.ok || !b.ok) return false;
+    if (a.s.size() * b.s.size() > kMaxStrs) return false;
+    std::set<std::string> seen;
+    for (auto &x : a.s)
+        for (auto &y : b.s) {
+            CStr z = x;
+            z.insert(z.end(), y.begin(), y.end());
+            if (z.size() > kMaxLen) {
+                if (keep == 0) return false;
+                if (keep == 1) z.resize(kMaxLen);
+                else z.erase(z.begin(), z.end() - (long)kMaxLen);
+            }
+            std::string key;
+            for (auto &bs : z) key += bs.to_string();
+            if (seen.insert(key).second) out.s.push_back(std::move(z));
+        }
+    out.ok = true;
+    return true;
+}
+
+bool unite(const Cover &a, const Cover &b, Cover &out) {
+    out = Cover();
+    if (!a.ok || !b.ok || a.s.size() + b.s.size() > 2 * kMaxStrs) return false;
+    out.ok = true;
+    out.s = a.s;
+    out.s.insert(out.s.end(), b.s.begin(), b.s.end());
+    return true;
+}
+
+const Cover &better(Model &m, const Cover &a, const Cover &b) { return m.score(b) < m.score(a) ? b : a; }
+
+Ext cat2(Model &m, const Ext &a, const Ext &b) {
+    Ext r;
+    Cover t;
+    if (cross(a.E, b.E, t, 0)) r.E = t;
+    if (a.E.ok && cross(a.E, b.P, t, 1)) r.P = t;
+    else r.P = a.P;
+    if (b.E.ok && cross(a.S, b.E, t, 2)) r.S = t;
+    else r.S = b.S;
+    r.B = better(m, a.B, b.B);
+    if (cross(a.S, b.P, t, 1)) r.B = better(m, r.B, t);
+    if (!std::isfinite(m.score(r.B))) r.B = Cover();
+    return r;
+}
+
+Ext extract(Model &m, const RNode &n) {
+    Ext r;
+    switch (n.k) {
+        case RNode::EMPTY:
+        case RNode::ASSERT:
+            r.E = r.P = r.S = trivial();
+            return r;
+        case RNode::CLASS:
+            if (n.cls.count() >= 1 && n.cls.count() <= kMaxClass) {
+                r.E.ok = true;
+                r.E.s.push_back({n.cls});
+                r.P = r.S = r.E;
+            } else {
+                r.P = r.S = trivial();
+            }
+            return r;
+        case RNode::CAT: {
+            r.E = r.P = r.S = trivial();
+            for (auto &k : n.kids) r = cat2(m, r, extract(m, *k));
+            return r;
+        }
+        case RNode::ALT: {
+            bool first = true, b_ok = true;
+            Cover bset;
+            for (auto &k : n.kids) {
+                Ext c = extract(m, *k);
+                // what a whole alternative guarantees: its best inner factor, or the alternative itself
+                Cover cand = c.B;
+                cand = better(m, cand, c.E);
+                cand = better(m, cand, c.P);
+                cand = better(m, cand, c.S);
+                if (!std::isfinite(m.score(cand))) b_ok = false;
+                if (first) {
+                    r.E = c.E;
+                    r.P = c.P;
+                    r.S = c.S;
+                    bset = cand;
+                    first = false;
+                    continue;
+                }
+                Cover t;
+                if (unite(r.E, c.E, t) && t.s.size() <= kMaxStrs) r.E = t; else r.E = Cover();
+                if (unite(r.P, c.P, t) && t.s.size() <= kMaxStrs) r.P = t; else r.P = trivial();
+                if (unite(r.S, c.S, t) && t.s.size() <= kMaxStrs) r.S = t; else r.S = trivial();
+                if (b_ok && !unite(bset, cand, t)) b_ok = false;
+                else if (b_ok) bset = t;
+            }
+            if (b_ok && !first) r.B = bset;
+            return r;
+        }
+        case RNode::REPEAT: {
+            if (n.rmin <= 0) {
+                if (n.rmax == 0) r.E = trivial();
+                r.P = r.S = trivial();
+                return r;
+            }
+            const Ext c = extract(m, *n.kids[0]);
+            const int copies = std::min(n.rmin, 4);
+            r = c;
+            for (int i = 1; i < copies; i++) r = cat2(m, r, c);
+            if (!(n.rmax == n.rmin && n.rmin <= 4)) {
+                r.E = Cover();  // more may follow the copies taken
+                r.S = c.S;      // ... but the last repetition still ends the match
+            }
+            return r;
+        }
+    }
+    return r;
+}
+
+// pattern == (\A)? literal (\z)?  with literal made of single bytes
+bool anchored_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_end) {
+    std::vector<const RNode *> flat;
+    std::vector<const RNode *> stack{&n};
+    while (!stack.empty()) {
+        const RNode *x = stack.back();
+        stack.pop_back();
+        if (x->k == RNode::CAT) {
+            for (size_t k = x->kids.size(); k-- > 0;) stack.push_back(x->kids[k].get());
+        } else if (x->k != RNode::EMPTY) {
+            flat.push_back(x);
+        }
+    }
+    lit.clear();
+    at_start = at_end = false;
+    size_t i = 0, e = flat.size();
+    if (i < e && flat[i]->k == RNode::ASSERT && flat[i]->ak == A_TEXT_START) { at_start = true; i++; }
+    if (e > i && flat[e - 1]->k == RNode::ASSERT && flat[e - 1]->ak == A_TEXT_END) { at_end = true; e--; }
+    for (; i < e; i++) {
+        if (flat[i]->k != RNode::CLASS || flat[i]->cls.count() != 1) return false;
+        for (int b = 0; b < 256; b++)
+            if (flat[i]->cls[(size_t)b]) lit += (char)b;
+    }
+    return true;
+}
+
+// Prior over the bytes of URL / header text, used when no traffic sample is available. Only relative magnitudes matter:
+// it decides which window of a factor is taken and how factors are bucketed, never a result.
+void default_bin_prob(double *binw) {
+    double p[256];
+    for (int b = 0; b < 256; b++) p[b] = 0.0002;
+    for (int b = 'a'; b <= 'z'; b++) p[b] = 0.024;
+    for (int b = 'A'; b <= 'Z'; b++) p[b] = 0.003;
+    for (int b = '0'; b <= '9'; b++) p[b] = 0.012;
+    const char *common = "/.-_=&% ";
+    for (const char *c = common; *c; c++) p[(unsigned char)*c] = 0.02;
+    p['/'] = 0.05;
+    const char *some = "?;():,+*~@!$'\"";
+    for (const char *c = some; *c; c++) p[(unsigned char)*c] = 0.004;
+    double tot = 0;
+    for (int b = 0; b < 256; b++) tot += p[b];
+    for (uint32_t x = 0; x < kFilterEntries; x++) binw[x] = 0;
+    for (int a = 0; a < 256; a++)
+        for (int b = 0; b < 256; b++) binw[filter_bin((uint8_t)a, (uint8_t)b)] += p[a] / tot * p[b] / tot;
+}
+
+struct Window {
+    size_t k = 0;
+    std::vector<uint16_t> bins[4];
+    double cost = 0;
+};
+
+}  // namespace
+
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out) {
+    out = GroupFilter();
+    std::vector<double> prior;
+    const double *binw = hints ? hints->bin_prob : nullptr;
+    if (!binw) {
+        prior.resize(kFilterEntries);
+        default_bin_prob(prior.data());
+        binw = prior.data();
+    }
+    // smoothed: a bin the sample never showed is still possible
+    std::vector<double> w(kFilterEntries);
+    for (uint32_t x = 0; x < kFilterEntries; x++) w[x] = binw[x] * 0.98 + 0.02 / kFilterEntries;
+    Model m{w.data(), {}};
+
+    if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
+    if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
+    if (!g.filter_atoms.empty()) { out.note = "gated pass"; return; }
+    if (g.emit_off.size() > 1 && g.emit_off[1] > g.emit_off[0]) { out.note = "a pattern matches the empty string"; return; }
+
+    // ---- heads: hot anchored literals ----
+    const uint64_t n_req = hints && hints->atom_hits ? hints->n_requests : 0;
+    auto rate = [&](uint32_t local) -> double {
+        if (n_req && hints->atom_hits && local < hints->atom_hits->size()) return (double)(*hints->atom_hits)[local] / (double)n_req;
+        return -1;  // unknown
+    };
+    struct HeadCand { uint32_t local; double hot; std::string lit; bool exact; };
+    std::vector<HeadCand> hc;
+    std::vector<uint8_t> is_head(g.atoms.size(), 0);
+    for (uint32_t l = 0; l < g.atoms.size(); l++) {
+        const Atom &at = atoms[g.atoms[l]];
+        std::string lit;
+        bool s, e;
+        if (!at.pattern || !anchored_literal(*at.pattern, lit, s, e) || !s || lit.empty() || lit.size() > 16) continue;
+        const double r = rate(l);
+        const double hot = r >= 0 ? r : (at.neg_used ? 0.5 : 0.0);
+        if (hot >= 0.02) hc.push_back({l, hot, lit, e});
+    }
+    std::stable_sort(hc.begin(), hc.end(), [](const HeadCand &a, const HeadCand &b) { return a.hot > b.hot; });
+    if (hc.size() > 2) hc.resize(2);
+    for (auto &h : hc) {
+        FilterHead fh{};
+        memcpy(fh.bytes, h.lit.data(), h.lit.size());
+        fh.len = (uint8_t)h.lit.size();
+        fh.exact = h.exact ? 1 : 0;
+        fh.local = (uint16_t)h.local;
+        if (h.local >= 0x7FFF) continue;  // (does not fit an inline record slot)
+        out.heads.push_back(fh);
+        is_head[h.local] = 1;
+    }
+
+    // ---- factors -> windows ----
+    std::map<std::string, size_t> index;
+    std::vector<Window> wins;
+    for (uint32_t l = 0; l < g.atoms.size(); l++) {
+        if (is_head[l]) continue;
+        const Atom &at = atoms[g.atoms[l]];
+        if (!at.pattern) { out.note = "atom without a pattern"; out.heads.clear(); return; }
+        const double r = rate(l);
+        if (r >= 0.25) {
+            out.note = "a pattern that is not an anchored literal holds for " + std::to_string((int)(r * 100)) + " % of the sample";
+            out.heads.clear();
+            return;
+        }
+        Ext x = extract(m, *at.pattern);
+        Cover f = x.B;
+        f = better(m, f, x.E);
+        f = better(m, f, x.P);
+        f = better(m, f, x.S);
+        if (!std::isfinite(m.score(f))) {
+            out.note = "pattern without a literal factor of two or more bytes: " + at.key.substr(0, 80);
+            out.heads.clear();
+            return;
+        }
+        for (auto &s : f.s) {
+            size_t st, k;
+            Window wd;
+            wd.cost = m.best_window(s, st, k);
+            wd.k = k;
+            std::string key = std::to_string(k) + ":";
+            for (size_t j = 0; j < k; j++) {
+                std::set<uint32_t> bins;
+                for (int a = 0; a < 256; a++)
+                    if (s[st + j][(size_t)a])
+                        for (int b = 0; b < 256; b++)
+                            if (s[st + j + 1][(size_t)b]) bins.insert(filter_bin((uint8_t)a, (uint8_t)b));
+                for (uint32_t bn : bins) {
+                    wd.bins[j].push_back((uint16_t)bn);
+                    key += std::to_string(bn) + ",";
+                }
+                key += ";";
+            }
+            if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
+        }
+    }
+    if (wins.empty() && out.heads.empty()) { out.note = "no patterns"; return; }
+
+    // ---- buckets ----
+    struct Bucket {
+        size_t kmin = 5;  // 5 = empty
+        std::bitset<kFilterEntries> set[4];
+        double wsum[4] = {0, 0, 0, 0};
+        double fp() const {
+            if (kmin > 4) return 0;
+            double f = 1;
+            for (size_t j = 4 - kmin; j < 4; j++) f *= std::min(1.0, wsum[j]);
+            return f;
+        }
+    };
+    Bucket bk[8];
+    std::vector<size_t> order(wins.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].k != wins[b].k ? wins[a].k > wins[b].k : wins[a].cost > wins[b].cost; });
+    for (size_t wi : order) {
+        const Window &wd = wins[wi];
+        int best_b = 0;
+        double best_d = INFINITY;
+        for (int b = 0; b < 8; b++) {
+            Bucket t = bk[b];
+            t.kmin = std::min(t.kmin, wd.k);
+            for (size_t j = 0; j < wd.k; j++) {
+                const size_t pos = 4 - wd.k + j;
+                for (uint16_t bn : wd.bins[j])
+                    if (!t.set[pos][bn]) { t.set[pos].set(bn); t.wsum[pos] += w[bn]; }
+            }
+            const double d = t.fp() - bk[b].fp();
+            if (d < best_d) { best_d = d; best_b = b; }
+        }
+        Bucket &t = bk[best_b];
+        t.kmin = std::min(t.kmin, wd.k);
+        for (size_t j = 0; j < wd.k; j++) {
+            const size_t pos = 4 - wd.k + j;
+            for (uint16_t bn : wd.bins[j])
+                if (!t.set[pos][bn]) { t.set[pos].set(bn); t.wsum[pos] += w[bn]; }
+        }
+    }
+    out.table.assign(kFilterEntries, 0xFFFFFFFFu);
+    out.init = 0xFFFFFFFFu;
+    double fp_pos = 0;
+    for (int b = 0; b < 8; b++) {
+        if (bk[b].kmin > 4) continue;
+        fp_pos += bk[b].fp();
+        for (size_t j = 0; j < 4; j++) {
+            const uint32_t bit = 1u << (8 * j + (size_t)b);
+            if (j < 4 - bk[b].kmin) {  // wildcard position of this bucket
+                for (auto &e : out.table) e &= ~bit;
+                out.init &= ~bit;
+            } else {
+                for (uint32_t bn = 0; bn < kFilterEntries; bn++)
+                    if (bk[b].set[j][bn]) out.table[bn] &= ~bit;
+            }
+        }
+    }
+    const double len = hints && hints->mean_len > 0 ? hints->mean_len : 64.0;
+    out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, fp_pos)), len);
+    out.enabled = true;
+}
+
+bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
+    uint32_t st = f.init;
+    for (size_t i = 0; i + 1 < n; i++) {
+        st = (st << 8) | f.table[filter_bin(bytes[i], bytes[i + 1])];
+        if ((~st) & 0xFF000000u) return true;
+    }
+    return false;
+}
+
+uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
+    uint32_t r = 0;
+    for (size_t k = 0; k < f.heads.size(); k++) {
+        const FilterHead &h = f.heads[k];
+        if (n < h.len || (h.exact && n != h.len)) continue;
+        if (memcmp(bytes, h.bytes, h.len) == 0) r |= 1u << k;
+    }
+    return r;
+}
+
+}  // namespace pwaf

@@ -63,6 +63,41 @@ struct ScanArgs {
     const uint32_t *n_list;
 };
 
+// ---- bigram prefilter (program.h: GroupFilter) ------------------------------------------------------------------------------
+// Work unit = one SLAB of kFilterSlab consecutive requests, walked by one wave (lanes pull the slab's requests one after the
+// other). The slab's candidates are appended to its own region of `sub` (sub[slab * kFilterSlab + k]) with a wave-private counter
+// — no atomics — and compact_kernel then concatenates the regions into the dense request list the confirming DFA pass walks.
+static constexpr uint32_t kFilterSlab = 2048;
+static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup: 7 workgroups per CU at 67 VGPRs
+static constexpr uint32_t kMaxFiltersPerLaunch = 8;
+struct FilterArgs {
+    const uint8_t *data;
+    const uint32_t *off;
+    uint32_t n;
+    uint32_t init;            // state at the start of a field
+    const uint32_t *table;    // kFilterEntries masks
+    uint32_t n_heads;
+    uint32_t head_w[2][4];    // head literal, little-endian dwords
+    uint32_t head_m[2][4];    // byte masks of the literal's length
+    uint32_t head_len[2];     // length | exact << 8
+    uint32_t head_code[2];    // hit-record bits of the head's atom
+    uint32_t *rec;            // n hit records of the pass, zeroed by the host: written only where a head holds
+    uint32_t *sub;            // n: candidate sub-lists, one region per slab
+    uint32_t *sub_count;      // [slabs]
+    uint32_t *list;           // n: dense candidate list (compact_kernel)
+    uint32_t *list_count;     // its length
+    uint32_t first_block;     // first workgroup of this pass in the fused launch
+};
+struct FilterBatchArgs {
+    FilterArgs f[kMaxFiltersPerLaunch];
+    uint32_t count;
+};
+int launch_filter(const FilterBatchArgs &b, void *stream);
+int launch_compact(const FilterBatchArgs &b, void *stream);
+// Sets the dynamic-LDS limit of every kernel on the CURRENT device (once per device and process; engines on several
+// devices of one process each need it).
+int configure_kernels(int device);
+
 struct CmpAtomDev {
     uint32_t col, c;
 };

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 #include "kernels.h"
 
@@ -454,29 +456,23 @@ __global__ __launch_bounds__(kScanThreads) void gscan_kernel(GatedArgs b) {
     scan_body<true, 1, WIDE>(a);
 }
 
-static int configure_lds(const void *fn, uint32_t lds, uint32_t &configured) {
-    if (lds <= configured) return 0;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = lds;
-    return 0;
-}
-
 int launch_scan(const ScanArgs &a, void *stream) {
     const uint32_t lds = scan_lds_bytes(a.n_hot, a.stride, a.colmask_local ? a.n_local : 0u);
-    static thread_local uint32_t configured[6] = {0, 0, 0, 0, 0, 0};
     const bool wide = a.n_classes > 127;
     const int v = (a.chunks == 4 ? 2 : a.chunks == 2 ? 1 : 0) + (wide ? 3 : 0);
     const void *fns[6] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
                           reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
                           reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>)};
     const void *fn = fns[v];
-    if (int e = configure_lds(fn, lds, configured[v])) return e;
     if (a.n == 0) return 0;
     // at least 256 requests per wave so that work-pulling has something to balance
     uint32_t waves = (a.n + 255) / 256;
     uint32_t blocks = (waves + kScanWaves - 1) / kScanWaves;
-    static const uint32_t forced_cap = getenv("PWAF_SCAN_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_SCAN_BLOCKS")) : 0u;  // profiling only
+#ifdef PWAF_PROFILING
+    static const uint32_t forced_cap = getenv("PWAF_SCAN_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_SCAN_BLOCKS")) : 0u;
+#else
+    const uint32_t forced_cap = 0;
+#endif
     const uint32_t cap = forced_cap ? forced_cap : std::max(1u, a.n_cus);  // one persistent workgroup per CU: the table is staged once
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
@@ -489,17 +485,255 @@ int launch_scan_gated(const GatedArgs &b, void *stream) {
     uint32_t lds = 0;
     bool wide = false;
     for (uint32_t k = 0; k < b.count; k++) {
-        lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, 0u));
+        lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, b.g[k].colmask_local ? b.g[k].n_local : 0u));
         wide = wide || b.g[k].n_classes > 127;  // (the u32 class table serves narrow passes too: one variant per launch)
     }
-    static thread_local uint32_t configured[2] = {0, 0};
     const void *fn = wide ? reinterpret_cast<const void *>(gscan_kernel<true>) : reinterpret_cast<const void *>(gscan_kernel<false>);
-    if (int e = configure_lds(fn, lds, configured[wide ? 1 : 0])) return e;
     if (b.count == 0 || b.g[0].n == 0) return 0;
     // the list lengths are only known on the device; lists are short (the prefilters are rare), so a modest fixed grid per
     // pass is enough and idle workgroups exit at once
     void *args[] = {const_cast<GatedArgs *>(&b)};
     hipError_t e = hipLaunchKernel(fn, dim3(64, b.count), dim3(kScanThreads), args, lds, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// bigram prefilter
+// -------------------------------------------------------------------------------------------------
+// filter_kernel: the launch that streams the request bytes. For every byte position of a field ONE independent LDS lookup —
+// table[hash(fold(b[i]), fold(b[i+1]))] — and two vector ops: state = (state << 8) | mask, seen &= state. Nothing on the
+// per-byte path depends on a previous lookup (the DFA walk it replaces chains v_lshl_add -> ds_read_u16 per byte plus a class
+// lookup), so the kernel is bound by LDS gather throughput and HBM streaming, not by LDS latency. A zero bit in the top byte of
+// `seen` at the end of a field = "some position completed a window of some bucket": the request is a CANDIDATE and is walked by
+// the pass's DFA afterwards (gscan_kernel); every other request provably matches no pattern of the pass. Positions past a field's
+// end (and across a chunk fetched for the next request) are not masked: extra positions can only flag more candidates.
+//
+// Hash of a position = top 12 bits of the 16-bit product fold(pair) * kFilterMul: two positions per v_pk_mul_lo_u16; the table's
+// byte offset is (product >> 2) & 0x3FFC.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int CH>
+__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchArgs B) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    __builtin_amdgcn_s_setprio(3);
+    // which pass of the fused launch this workgroup belongs to (uniform: kernel arguments only)
+    uint32_t k = 0;
+    while (k + 1 < B.count && blockIdx.x >= B.f[k + 1].first_block) k++;
+    const FilterArgs &a = B.f[k];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (uint32_t i = tid; i < kFilterEntries / 4; i += kFilterWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
+    if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
+    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
+    const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
+    const uint32_t slab = (blockIdx.x - a.first_block) * kFilterWaves + wave;
+    const uint64_t w0_64 = (uint64_t)slab * kFilterSlab;
+    if (w0_64 >= a.n) return;
+    const uint32_t w0 = (uint32_t)w0_64, w1 = min(a.n, w0 + kFilterSlab), n_items = a.n;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    uint32_t *my_sub = a.sub + w0;
+    uint32_t n_cand = 0;  // wave-uniform
+
+    uint32_t next = w0, blk = w0;
+    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi) {
+        const uint32_t i = min(base + lane, n_items - 1);
+        lo = goff[i];
+        hi = goff[i + 1];
+    };
+    uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0, n_base = kNone;
+    load_off(blk, o_lo, o_hi);
+    uint32_t r = kNone, p = 0, end = 0, r2 = kNone, p2 = 0, end2 = 0;
+    uint32_t st = a.init, seen = 0xFFFFFFFFu, hrec = 0;
+    bool first = false;
+    u32x4 w[CH], wn[CH];
+#pragma unroll
+    for (int q = 0; q < CH; q++) w[q] = wn[q] = u32x4{0, 0, 0, 0};
+    constexpr uint32_t kStep = 16u * CH;
+    const uint32_t mul2 = kFilterMul | (kFilterMul << 16);
+
+    for (;;) {
+        uint32_t f_lo, f_hi;
+        const uint32_t f_base = blk + 64;
+        load_off(f_base, f_lo, f_hi);
+        // ---- 1. lanes on their last chunk (or idle) pull the next request of the slab (as scan_body) ----
+        const bool last = r == kNone || p + kStep >= end;
+        const unsigned long long want = __ballot(last && r2 == kNone);
+        if (want != 0 && next < w1) {
+            const uint32_t avail = min(w1 - next, blk + 64 - next);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(want & lt_mask);
+            const bool take = last && r2 == kNone && rank < avail;
+            const uint32_t j = take ? next + rank - blk : 0;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_lo);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_hi);
+            if (take) {
+                r2 = next + rank;
+                p2 = lo;
+                end2 = hi;
+            }
+            next += min((uint32_t)__builtin_popcountll(want), avail);
+            if (next == blk + 64 && next < w1) {
+                blk += 64;
+                if (n_base == blk) {
+                    o_lo = n_lo;
+                    o_hi = n_hi;
+                } else {
+                    load_off(blk, o_lo, o_hi);
+                }
+            }
+        }
+        if (__ballot(r != kNone || r2 != kNone) == 0) break;
+        {
+            const bool have = last ? (r2 != kNone && p2 < end2) : true;
+            const uint32_t np = have ? (last ? p2 : p + kStep) : 0u;
+            const uint32_t nend = last ? end2 : end;
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const uint32_t at = (q == 0 || (have && np + 16u * q < nend)) ? np + 16u * q : 0u;
+                wn[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
+            }
+        }
+
+        // ---- 2. heads: anchored literals compared against the first 16 bytes of a field ----
+        if (a.n_heads != 0 && first) {
+            const uint32_t flen = end - p;
+#pragma unroll
+            for (int hq = 0; hq < 2; hq++) {
+                if ((uint32_t)hq < a.n_heads) {
+                    const uint32_t diff = ((w[0].x ^ a.head_w[hq][0]) & a.head_m[hq][0]) | ((w[0].y ^ a.head_w[hq][1]) & a.head_m[hq][1]) |
+                                          ((w[0].z ^ a.head_w[hq][2]) & a.head_m[hq][2]) | ((w[0].w ^ a.head_w[hq][3]) & a.head_m[hq][3]);
+                    const uint32_t hl = a.head_len[hq] & 0xFFu;
+                    const bool len_ok = (a.head_len[hq] >> 8) ? flen == hl : flen >= hl;
+                    if (diff == 0 && len_ok) hrec |= a.head_code[hq];
+                }
+            }
+        }
+        first = false;
+
+        // ---- 3. 16 * CH positions: one independent lookup each ----
+        {
+            uint32_t d[4 * CH + 1];
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                d[4 * q + 0] = w[q].x & 0xDFDFDFDFu;
+                d[4 * q + 1] = w[q].y & 0xDFDFDFDFu;
+                d[4 * q + 2] = w[q].z & 0xDFDFDFDFu;
+                d[4 * q + 3] = w[q].w & 0xDFDFDFDFu;
+            }
+            d[4 * CH] = wn[0].x & 0xDFDFDFDFu;  // the byte after this iteration's last one (next chunk of the field, or harmless)
+            uint32_t m[16 * CH];
+#pragma unroll
+            for (int i = 0; i < 4 * CH; i++) {
+                const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
+                const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
+                const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
+                m[4 * i + 0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
+                m[4 * i + 1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
+                m[4 * i + 2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
+                m[4 * i + 3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 18) & 0x3FFCu));
+            }
+#pragma unroll
+            for (int i = 0; i < 16 * CH; i++) {
+                // st = (st << 8) | m[i] as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
+                seen &= st;
+            }
+        }
+        p += kStep;
+
+        // ---- 4. finished requests: head record, candidate list; then switch to the pulled-ahead request ----
+        const bool fin = r != kNone && p >= end;
+        const bool cand = fin && ((~seen) & 0xFF000000u) != 0;
+        const unsigned long long cm = __ballot(cand);
+        if (cm != 0) {
+            if (cand) my_sub[n_cand + (uint32_t)__builtin_popcountll(cm & lt_mask)] = r;
+            n_cand += (uint32_t)__builtin_popcountll(cm);
+        }
+        if (fin) {
+            if (hrec) a.rec[r] = hrec;
+            r = kNone;
+        }
+        if (r == kNone && r2 != kNone) {
+            r = r2;
+            p = p2;
+            end = end2;
+            r2 = kNone;
+            st = a.init;
+            seen = 0xFFFFFFFFu;
+            hrec = 0;
+            first = true;
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) w[q] = wn[q];
+        n_lo = f_lo;
+        n_hi = f_hi;
+        n_base = f_base;
+    }
+    if (lane == 0) a.sub_count[slab] = n_cand;
+}
+
+// compact_kernel: concatenates the per-slab candidate regions of every filtered pass into dense request lists (order:
+// ascending request index) and publishes the list lengths for the confirming gscan_kernel launch. One workgroup covers
+// kCompactSlabs consecutive slabs; its base offset is the sum of the counts of all earlier slabs (a few thousand values).
+static constexpr uint32_t kCompactSlabs = 64;
+__global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
+    __shared__ uint32_t red[256];
+    __shared__ uint32_t pre[kCompactSlabs + 1];
+    const FilterArgs &a = B.f[blockIdx.y];
+    const uint32_t n_slabs = (a.n + kFilterSlab - 1) / kFilterSlab;
+    const uint32_t s0 = blockIdx.x * kCompactSlabs;
+    if (s0 >= n_slabs) return;
+    const uint32_t s1 = min(n_slabs, s0 + kCompactSlabs), tid = threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t s = tid; s < s0; s += 256) acc += a.sub_count[s];
+    red[tid] = acc;
+    __syncthreads();
+    for (uint32_t h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t run = red[0];
+        for (uint32_t s = s0; s < s1; s++) {
+            pre[s - s0] = run;
+            run += a.sub_count[s];
+        }
+        pre[s1 - s0] = run;
+        if (s1 == n_slabs) *a.list_count = run;
+    }
+    __syncthreads();
+    for (uint32_t s = s0; s < s1; s++) {
+        const uint32_t base = pre[s - s0], cnt = pre[s - s0 + 1] - base;
+        const uint32_t *src = a.sub + (size_t)s * kFilterSlab;
+        for (uint32_t i = tid; i < cnt; i += 256) a.list[base + i] = src[i];
+    }
+}
+
+int launch_filter(const FilterBatchArgs &b, void *stream) {
+    if (b.count == 0) return 0;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < b.count; k++) {
+        const uint32_t slabs = (b.f[k].n + kFilterSlab - 1) / kFilterSlab;
+        blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
+    }
+    if (blocks == 0) return 0;
+    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(filter_kernel<2>), dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
+}
+
+int launch_compact(const FilterBatchArgs &b, void *stream) {
+    if (b.count == 0) return 0;
+    uint32_t max_slabs = 0;
+    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (b.f[k].n + kFilterSlab - 1) / kFilterSlab);
+    if (max_slabs == 0) return 0;
+    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(compact_kernel), dim3((max_slabs + kCompactSlabs - 1) / kCompactSlabs, b.count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -569,6 +803,11 @@ template <bool LT>
 __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+#ifdef PWAF_PROFILING
+    const uint32_t dbg_skip = a.debug_skip;  // section switches for timing experiments (wrong results when set): -DPWAF_PROFILING builds only
+#else
+    constexpr uint32_t dbg_skip = 0;
+#endif
     const uint32_t colw = (a.n_cols + 31) / 32, rulew = (a.n_rules + 31) / 32;
     const uint32_t wave_bytes = verdict_wave_lds(a.n_cols, a.n_rules);
     unsigned char *mine = lds + (size_t)wave * wave_bytes;
@@ -623,8 +862,9 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         const bool valid = g < a.n_groups && i < a.n;
 #pragma unroll
         for (int q = 0; q < kPre; q++) {
-            const uint32_t ps = min((uint32_t)q, a.n_passes - 1);
-            in.rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+            // (n_passes == 0 — no string predicate at all — must not wrap: nothing is read then)
+            const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
+            in.rv[q] = (valid && a.n_passes != 0) ? a.rec[(size_t)ps * a.n + i] : 0u;
         }
         in.flags = valid ? (uint32_t)a.flags[i] : 0u;
         const uint32_t gg = min(g, a.n_groups - 1);
@@ -666,7 +906,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
         // 2. scan results: each lane marks the columns its hit records name (passes beyond the prefetched kPre are fetched here,
         //    kPre at a time: independent loads, one wait)
-        for (uint32_t pb = 0; pb < a.n_passes && !(a.debug_skip & 1u); pb += kPre) {
+        for (uint32_t pb = 0; pb < a.n_passes && !(dbg_skip & 1u); pb += kPre) {
             uint32_t rv[kPre];
 #pragma unroll
             for (int q = 0; q < kPre; q++) {
@@ -713,7 +953,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         // 3. everything that is not a string scan (memberships, comparisons) arrives from the attribute kernel as ready-made
         //    column words: one lane per pair, a plain LDS store each
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
-        if (!(a.debug_skip & 2u)) {
+        if (!(dbg_skip & 2u)) {
             for (uint32_t p = lane; p < n_pairs; p += 64) {
                 const uint4 pr = p < 64 ? pair0 : pairs[p];
                 atomicOr(&col[pr.x], ((unsigned long long)pr.w << 32) | pr.z);
@@ -724,7 +964,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
         // 4. candidate rules: a rule can only match some request of this group if one of its terms has a non-zero positive
         //    column (trigger lists, one chosen literal per term) or consists of negations only (always_rules).
-        for (uint32_t wv = lane; wv < colw && !(a.debug_skip & 8u); wv += 64) {
+        for (uint32_t wv = lane; wv < colw && !(dbg_skip & 8u); wv += 64) {
             uint32_t nz = colnz[wv];
             while (nz) {
                 const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
@@ -739,7 +979,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // ordered compaction of the rule bitmap into the candidate list (ascending rule index = evaluation order)
         uint32_t n_cand = 0;
-        for (uint32_t wb = 0; wb < rulew && !(a.debug_skip & 16u); wb += 64) {
+        for (uint32_t wb = 0; wb < rulew && !(dbg_skip & 16u); wb += 64) {
             const uint32_t word = wb + lane < rulew ? rulebm[wb + lane] : 0u;
             const uint32_t pc = (uint32_t)__builtin_popcount(word), incl = wave_scan_add(pc);
             uint32_t pos = n_cand + incl - pc, wrd = word;
@@ -757,7 +997,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         unsigned long long pending = valid_mask;
         bool undecided = valid;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
-        for (uint32_t base = 0; base < n_cand && pending != 0 && !(a.debug_skip & 32u); base += 64) {
+        for (uint32_t base = 0; base < n_cand && pending != 0 && !(dbg_skip & 32u); base += 64) {
             unsigned long long fire = 0;
             if (base + lane < n_cand) {
                 const uint32_t my_cand = cand[base + lane];
@@ -797,10 +1037,10 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                 // a match only decides when the rule's action list yields an effect for that client
                 fire = acc_or & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
             }
-            if (a.debug_skip & 256u) fire = 0;
+            if (dbg_skip & 256u) fire = 0;
             fbuf[lane] = fire;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (__ballot(fire != 0) != 0 && !(a.debug_skip & 128u)) {
+            if (__ballot(fire != 0) != 0 && !(dbg_skip & 128u)) {
                 const uint32_t cnt = min(64u, n_cand - base);
                 uint32_t first = kNone;
                 for (uint32_t j = 0; j < cnt; j += 4) {
@@ -835,7 +1075,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
 
-        if (a.debug_skip & 64u) my_rule = n_cand;  // profiling aid: report the candidate count instead of the deciding rule
+        if (dbg_skip & 64u) my_rule = n_cand;  // profiling aid: report the candidate count instead of the deciding rule
         // 6. outputs
         if (valid) {
             uint2 v;
@@ -1090,7 +1330,11 @@ int launch_attr(const VerdictArgs &a, void *stream) {
     // take the issue slots the scans leave idle (~25 %) instead of competing for them, and 2 of them per SIMD are what still fits
     // the register file next to a 4-chunk scan workgroup (measured on MI355X, DESIGN.md §6.1: 256/384/512/768 workgroups ->
     // 2.71/2.49/2.47/2.76 ms per step).
-    static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;  // profiling only
+#ifdef PWAF_PROFILING
+    static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;
+#else
+    const uint32_t forced = 0;
+#endif
     const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : 2 * std::max(1u, a.attr_blocks));
     hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
@@ -1103,7 +1347,7 @@ VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, u
     VerdictShape s{};
     const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
     const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
-    static const bool force_global = getenv("PWAF_FORCE_GLOBAL_TABLES") != nullptr;  // testing knob: exercise the LT = false variant
+    static const bool force_global = getenv("PWAF_FORCE_GLOBAL_TABLES") != nullptr;  // testing knob: exercises the LT = false variant (same results)
     const bool fits = !force_global && n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
     s.lds_tables = fits ? 1 : 0;
     const uint32_t tables = fits ? t_lds : t_glb;
@@ -1118,10 +1362,12 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
     const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits);
     if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
     const void *fn = sh.lds_tables ? reinterpret_cast<const void *>(verdict_kernel<true>) : reinterpret_cast<const void *>(verdict_kernel<false>);
-    static thread_local uint32_t configured[2] = {0, 0};
-    if (int e = configure_lds(fn, sh.lds_bytes, configured[sh.lds_tables])) return e;
     uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
-    static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;  // profiling only
+#ifdef PWAF_PROFILING
+    static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;
+#else
+    const uint32_t forced_cap = 0;
+#endif
     // with LDS tables a workgroup fills a CU: one persistent workgroup per CU (measured: 0.331 ms vs 0.346 at 4 per CU — every
     // workgroup stages 25 KiB of tables and clears its column files once); small workgroups: a few rounds per CU
     const uint32_t cap = forced_cap ? forced_cap : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
@@ -1130,6 +1376,26 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
     void *args[] = {const_cast<VerdictArgs *>(&a)};
     hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(sh.waves * 64), args, sh.lds_bytes, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
+}
+
+// hipFuncSetAttribute applies to the CURRENT device: every device an engine is created on needs its own call (a per-thread
+// or per-process "already configured" flag left the second device of a multi-GPU host at the 64 KiB default).
+int configure_kernels(int device) {
+    static std::mutex mu;
+    static std::set<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(device)) return 0;
+    const void *fns[] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
+                         reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
+                         reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
+                         reinterpret_cast<const void *>(gscan_kernel<true>), reinterpret_cast<const void *>(gscan_kernel<false>),
+                         reinterpret_cast<const void *>(verdict_kernel<true>), reinterpret_cast<const void *>(verdict_kernel<false>)};
+    for (const void *fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
+        if (e != hipSuccess) return (int)e;
+    }
+    done.insert(device);
+    return 0;
 }
 
 }  // namespace pwaf

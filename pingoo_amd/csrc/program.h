@@ -66,7 +66,48 @@ struct Atom {
     uint32_t ref = 0;          // INTSET: index into int_sets; IPSET: ip list index; COUNTRY: lut index
     uint32_t id = 0;           // device column id (assigned at layout time)
     uint32_t min_len = 0;      // SCAN: length of the shortest string the pattern matches (a proxy for how rare a hit is)
+    bool neg_used = false;     // the atom occurs negated in some rule term (a hint that most requests satisfy it)
     std::string key;           // canonical form for de-duplication
+};
+
+// ---- bigram prefilter (filter.cpp) ------------------------------------------------
+// A pass whose patterns ALL have a necessary literal factor does not walk its DFA over every request. The filter kernel
+// streams the field once with a bucketed shift-or over hashed BIGRAMS (case-folded byte pairs): one independent 4-byte LDS
+// lookup per input byte, no state-dependent address. 8 buckets x 4 bigram positions = one 32-bit state per lane;
+// state' = (state << 8) | table[bin(b[i], b[i+1])], and a zero bit in the top byte says "the last <= 4 bigrams are
+// consistent with some factor window of bucket b". Requests with such a position are CANDIDATES; only they are walked
+// through the pass's DFA, which decides exactly. The filter is conservative by construction (a factor is necessary for
+// a match; extra positions past a field's end can only add candidates), so verdicts never depend on it.
+static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
+static constexpr uint32_t kFilterMul = 0x9E37u;  // 16-bit multiplicative hash of the folded byte pair (v_pk_mul_lo_u16 on the device)
+static inline uint32_t filter_bin(uint8_t b0, uint8_t b1) {
+    const uint32_t p = (uint32_t)(b0 & 0xDFu) | ((uint32_t)(b1 & 0xDFu) << 8);  // bit 5 cleared: ASCII case folding
+    // top 12 bits of the 16-bit product: they mix all 8 bits of the second byte (bits [2, 14) keep only 6 of them, and digits then
+    // alias letters: measured 2.6x the candidates on URLs)
+    return ((p * kFilterMul) & 0xFFFFu) >> (16 - kFilterBits);
+}
+// An anchored literal (starts_with / ==, <= 16 bytes) that most requests satisfy (e.g. a browser User-Agent prefix under a
+// negation) cannot go through the filter — every request would be a candidate. Up to two such HEADS per pass are compared
+// directly against the first 16 bytes of the field by the filter kernel and land in the request's hit record.
+struct FilterHead {
+    uint8_t bytes[16];
+    uint8_t len;
+    uint8_t exact;   // 1: field == literal, 0: field starts with literal
+    uint16_t local;  // local atom id in the pass
+};
+struct GroupFilter {
+    bool enabled = false;
+    std::vector<uint32_t> table;  // kFilterEntries masks: bit 8*j + b = 0 <=> bucket b accepts the bin at window position j
+    uint32_t init = 0xFFFFFFFFu;  // state at the start of a field (zero at a bucket's wildcard positions)
+    std::vector<FilterHead> heads;
+    double est_candidate_rate = 0;  // expected fraction of requests flagged by chance (model or sample)
+    std::string note;               // why the pass is not filtered, for stats / warnings
+};
+struct FilterHints {  // from a traffic sample (pwaf_engine_tune); all optional
+    const double *bin_prob = nullptr;              // kFilterEntries: probability that a text bigram falls into the bin
+    const std::vector<uint64_t> *atom_hits = nullptr;  // per local atom: sample requests it holds for
+    uint64_t n_requests = 0;
+    double mean_len = 0;                           // mean field length in the sample (0 = unknown)
 };
 
 // ---- DFA groups ----------------------------------------------------------------------------------
@@ -90,6 +131,8 @@ struct DfaGroup {
     // visit those requests.
     std::vector<uint32_t> filter_atoms;  // indices into Program::atoms
     std::vector<uint32_t> filter_cols;   // their device columns (filled at layout time)
+    // Bigram prefilter of an otherwise ungated pass (enabled = the pass only walks the filter's candidates)
+    GroupFilter filter;
 };
 static constexpr uint32_t kMaxDfaStates = 32767;   // 15-bit state ids: bit 15 of a table entry flags "target state emits"
 static constexpr uint32_t kMaxLocalAtoms = 32766;  // 15-bit (+1) atom slots in a hit record
@@ -194,6 +237,15 @@ uint32_t rx_min_len(const RNode &n);
 // Runs a DFA on the host over `bytes`, returning local atom ids that hold. COMPILE-TIME USE ONLY
 // (folding predicates over the 676 possible country codes into a lookup table).
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms);
+
+// Builds the bigram prefilter of pass `g` (filter.cpp). `atoms` = Program::atoms. Leaves filter.enabled false (with a note)
+// when some pattern has no usable literal factor.
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out);
+// Host model of the filter kernel over one field value: true = candidate. (Used by tune to measure the candidate rate on the
+// sample; the device may flag MORE requests — it also looks at the bytes just past a field's end — never fewer.)
+bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n);
+// Which heads hold for the field value: bit k = heads[k].
+uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n);
 
 struct PrefixEntry {
     uint8_t addr[16];

@@ -213,3 +213,90 @@ def fuzz_geoip(rng: random.Random):
 
 def fuzz_actions(rng: random.Random):
     return rng.choice([[B], [CAP], [CAP, B], [B, CAP], [], [CAP, CAP]])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# literal-heavy rule sets: every pattern has a literal factor of two or more bytes, so the compiler puts the passes behind
+# the bigram prefilter; requests are built from the same tokens (whole, truncated, case-flipped, glued across
+# field boundaries) so that both matches and near misses are frequent
+# ---------------------------------------------------------------------------------------------------------
+TOKENS = ["/.env", "../", "<script", "union select", "/wp-admin", "cmd.exe", "ab", "Mozilla/", "curl/", "bot", "x9k2", "/api/v1", "=%27", "admin", "select", "q7",
+          ".php", "passwd", "etc", "AbCd", "zz", "/a/b", "hello-world", "0x41", "id=", "__", "a.b"]
+
+
+def lit_token(rng: random.Random) -> str:
+    t = rng.choice(TOKENS)
+    k = rng.random()
+    if k < 0.15 and len(t) > 3:
+        t = t[:rng.randint(2, len(t) - 1)]
+    elif k < 0.25:
+        t = t + rng.choice(TOKENS)
+    return t
+
+
+def lit_pred(rng: random.Random) -> str:
+    f = "http_request." + rng.choice(["host", "url", "path", "user_agent", "url", "path"])
+    t = lit_token(rng)
+    k = rng.randint(0, 11)
+    if k <= 2:
+        return f"{f}.contains({q(t)})"
+    if k == 3:
+        return f"{f}.starts_with({q(t)})"
+    if k == 4:
+        return f"{f}.ends_with({q(t)})"
+    if k == 5:
+        return f"{f} == {q(t)}"
+    esc = "".join("\\" + c if c in ".^$*+?()[]{}|\\/" else c for c in t)
+    if k == 6:
+        return f"{f}.matches({q('(?i)' + esc)})"
+    if k == 7:
+        return f"{f}.matches({q(esc + '[0-9]+' + ''.join(chr(92) + c if c in '.^$*+?()[]{}|/' else c for c in lit_token(rng)))})"
+    if k == 8:
+        return f"{f}.matches({q(esc + '.*' + ''.join(chr(92) + c if c in '.^$*+?()[]{}|/' else c for c in lit_token(rng)))})"
+    if k == 9:
+        return f"{f}.matches({q('^' + esc + '(x|y|' + esc + ')$')})"
+    if k == 10:
+        return f"{f}.matches({q('(' + esc + '|' + ''.join(chr(92) + c if c in '.^$*+?()[]{}|/' else c for c in lit_token(rng)) + ')' + chr(92) + 's?=')})"
+    return f"!{f}.starts_with({q(t)})"
+
+
+def lit_rules(rng: random.Random, n: int):
+    rules = []
+    for k in range(n):
+        e = lit_pred(rng)
+        s = rng.randint(0, 5)
+        if s == 0:
+            e = e + " && " + lit_pred(rng)
+        elif s == 1:
+            e = e + " || " + lit_pred(rng)
+        elif s == 2:
+            e = "(" + e + " || " + lit_pred(rng) + ") && " + lit_pred(rng)
+        rules.append((f"r{k}", e, fuzz_actions(rng)))
+    return rules
+
+
+def lit_field(rng: random.Random, lo=0, hi=6) -> str:
+    parts = []
+    for _ in range(rng.randint(lo, hi)):
+        k = rng.random()
+        if k < 0.45:
+            parts.append(lit_token(rng))
+        elif k < 0.55:
+            t = rng.choice(TOKENS)
+            parts.append(t.swapcase())
+        elif k < 0.7:
+            parts.append(str(rng.randint(0, 99999)))
+        else:
+            parts.append(rstr(rng, 1, 9, "abcdefxyz/.=-_ %"))
+    return "".join(parts)
+
+
+def lit_requests(rng: random.Random, n: int):
+    reqs = []
+    for _ in range(n):
+        path = lit_field(rng, 0, 5)
+        ua = lit_field(rng, 1, 4) if rng.random() < 0.95 else ""
+        reqs.append(Request(host=lit_field(rng, 0, 2), url=path + ("?" + lit_field(rng, 0, 4) if rng.random() < 0.6 else ""), path=path,
+                            method=rng.choice(["GET", "POST"]), user_agent=ua[:255], ip=f"{rng.randint(1, 3)}.{rng.randint(0, 3)}.0.{rng.randint(0, 255)}",
+                            remote_port=rng.randint(0, 65535), captcha_verified=rng.random() < 0.3))
+    return reqs

@@ -65,6 +65,13 @@ class Tables:
                 cur["end_off"] = np.frombuffer(pl, dtype="<u4")
             elif tag == "GENL":
                 cur["end_list"] = np.frombuffer(pl, dtype="<u2")
+            elif tag == "GFHD":
+                init, n_heads = struct.unpack_from("<II", pl, 0)
+                cur["f_init"] = init
+                cur["f_heads"] = [(pl[8 + 20 * k:8 + 20 * k + 16][:pl[8 + 20 * k + 16]], pl[8 + 20 * k + 17], struct.unpack_from("<H", pl, 8 + 20 * k + 18)[0])
+                                  for k in range(n_heads)]  # (literal, exact, local atom)
+            elif tag == "GFTB":
+                cur["f_table"] = np.frombuffer(pl, dtype="<u4")
             elif tag == "NUMA":
                 self.num_atoms = np.frombuffer(pl, dtype=NUMA_DTYPE)
             elif tag == "INTP":
@@ -83,6 +90,36 @@ class Tables:
                 self.geo_recs = np.frombuffer(pl, dtype=GREC_DTYPE)
 
     # --- pieces ---
+    FILTER_MUL = 0x9E37
+
+    @classmethod
+    def filter_bin(cls, b0: int, b1: int) -> int:
+        return ((((b0 & 0xDF) | ((b1 & 0xDF) << 8)) * cls.FILTER_MUL) & 0xFFFF) >> 4
+
+    def filter_candidate(self, g: dict, data: bytes) -> bool:
+        """The bigram prefilter of a pass exactly as filter_kernel applies it to the bytes of ONE field value (the device also
+        looks at a few bytes past the end, which can only flag more requests)."""
+        st, tab = g["f_init"], g["f_table"]
+        for i in range(len(data) - 1):
+            st = ((st << 8) | int(tab[self.filter_bin(data[i], data[i + 1])])) & 0xFFFFFFFF
+            if (~st) & 0xFF000000:
+                return True
+        return False
+
+    def scan_pass(self, g: dict, data: bytes, cols: set):
+        """One pass as the device runs it: behind its prefilter (heads + DFA for candidates only) when it has one."""
+        if "f_table" not in g or not self.use_filter:
+            return self.scan_field(g, data, cols)
+        if self.filter_candidate(g, data):
+            self.n_candidates += 1
+            return self.scan_field(g, data, cols)
+        for lit, exact, local in g["f_heads"]:
+            if data[:len(lit)] == lit and (not exact or len(data) == len(lit)):
+                cols.add(g["atom_base"] + local)
+
+    use_filter = True
+    n_candidates = 0
+
     def scan_field(self, g: dict, data: bytes, cols: set):
         """Walks one field through group g's DFA, adding the device column ids that hold."""
         st = 0  # states are in BFS order from the start state
@@ -130,7 +167,7 @@ class Tables:
         cols = {0}
         fields = [batch.field_bytes(f, i) for f in range(5)]
         for g in self.groups:
-            self.scan_field(g, fields[g["field"]], cols)
+            self.scan_pass(g, fields[g["field"]], cols)
         ip = batch.ip[i].tobytes()
         v6 = bool(batch.ip_is_v6[i])
         port = int(batch.port[i])

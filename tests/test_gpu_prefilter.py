@@ -1,0 +1,107 @@
+"""The bigram prefilter on the device: filter_kernel + compact_kernel + list-driven DFA passes, through the C ABI, against the CPU
+oracle. The filter may only change WHICH requests a pass walks, never a verdict."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi
+from pingoo_amd.engine import RuleEngine
+
+pytestmark = pytest.mark.gpu
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_literal_heavy_fuzz_filtered_matches_oracle(seed):
+    rng = random.Random(9100 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 60))
+    eng = RuleEngine(rules, {}, lds_table_budget=rng.choice([0, 0, 2048]))
+    assert eng.stats()["n_filtered_groups"] >= 1
+    n = rng.choice([1, 64, 65, 500, 2047, 2048, 2049, 5000])
+    batch = RequestBatch.from_requests(H.lit_requests(rng, n))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, f"seed {seed}")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    # the same rules with every pass walking every request
+    plain = RuleEngine(rules, {}, flags=_abi.OPT_NO_PREFILTER)
+    H.assert_verdicts_equal(plain.evaluate_batch(batch), want, batch, f"seed {seed}, no prefilter")
+    # filters rebuilt from a traffic sample (heads, window choice, bucketing change): same verdicts
+    eng.tune(RequestBatch.from_requests(H.lit_requests(rng, 400)))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, tuned")
+    eng.close()
+    plain.close()
+
+
+def test_heads_and_candidates_at_slab_and_chunk_boundaries():
+    """Requests of every length around the 16/32-byte chunking, factors placed at the very start / end of a field and straddling
+    chunk boundaries, head literals present / absent / truncated, across more than one 2048-request slab."""
+    rules = [("ua", '!http_request.user_agent.starts_with("Mozilla/") && http_request.path.contains("/.env")', [B]),
+             ("exact", 'http_request.user_agent == "curl/8.5.0"', [CAP]),
+             ("tail", 'http_request.url.ends_with("x9k2")', [B]),
+             ("head", 'http_request.url.starts_with("/wp-admin")', [CAP]),
+             ("mid", 'http_request.url.matches("(?i)union\\\\s+select")', [B])]
+    reqs = []
+    for k in range(0, 70):
+        pad = "q" * k
+        reqs += [Request(url=pad + "x9k2", path="/.env", user_agent="Mozilla/5.0", host="h"), Request(url=pad + "x9k", path=pad + "/.env", user_agent="Mozill", host="h"),
+                 Request(url="/wp-admin" + pad, path="/" + pad, user_agent="curl/8.5.0", host="h"), Request(url="/wp-admi" + pad, path=pad, user_agent="curl/8.5.01", host="h"),
+                 Request(url=pad + "UNION  SELECT" + pad, path="/a", user_agent="Mozilla/", host="h"), Request(url=pad + "union select", path="/.en" + pad + "v", user_agent="x", host="h")]
+    reqs = reqs * 12  # > 2 slabs
+    batch = RequestBatch.from_requests(reqs)
+    eng = RuleEngine(rules)
+    assert eng.stats()["n_filtered_groups"] >= 3
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "boundaries")
+    assert len(set(want["action"].tolist())) == 3
+    eng.close()
+
+
+def test_every_request_a_candidate_and_none():
+    rules = [("a", 'http_request.path.contains("/.env")', [B]), ("b", 'http_request.url.contains("zz9")', [CAP])]
+    eng = RuleEngine(rules)
+    orc = pyoracle.Oracle(rules)
+    for reqs in ([Request(path="/.env", url="/.env?zz9", host="h")] * 5000, [Request(path="/index.html", url="/index.html?a=1", host="h")] * 5000):
+        batch = RequestBatch.from_requests(reqs)
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), orc.evaluate(batch), batch, "uniform batch")
+    eng.close()
+
+
+def test_synthetic_config3_tuned_and_untuned_at_100k():
+    """Size-independent property at a size the oracle cannot check in seconds: the filtered engine, the tuned filtered engine and the
+    engine without prefilters agree on every verdict of 100k requests; a 4000-request prefix is checked against the oracle."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    batch = w.batch(5_000_000, 100_000)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    plain = RuleEngine(w.rules, w.lists, w.geoip, flags=_abi.OPT_NO_PREFILTER)
+    a = eng.evaluate_batch(batch)
+    b = plain.evaluate_batch(batch)
+    H.assert_verdicts_equal(a, b, batch, "filtered vs plain")
+    eng.tune(w.batch(9_000_000, 8192))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), b, batch, "tuned filtered vs plain")
+    head = batch.slice(0, 4000)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(head, threads=8)
+    H.assert_verdicts_equal(a[:4000], want, head, "oracle prefix")
+    eng.close()
+    plain.close()
+
+
+def test_rule_set_without_string_predicates_at_one_million_requests():
+    """No scan pass at all and both gates off (what ServiceRouter configures): the verdict kernel must not read hit records."""
+    rules = [("port", "client.remote_port < 1024", [B]), ("cc", 'client.country == "XX"', [CAP])]
+    eng = RuleEngine(rules, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    rng = np.random.default_rng(3)
+    n = 1_000_000
+    reqs = RequestBatch.from_requests([Request(host="h", remote_port=1)])
+    big = reqs.tile(n) if hasattr(reqs, "tile") else None
+    if big is None:
+        pytest.skip("RequestBatch.tile not available")
+    big.port[:] = rng.integers(0, 65536, n).astype(np.uint16)
+    got = eng.evaluate_batch(big)
+    assert (got["action"] == np.where(big.port < 1024, 1, 2)).all()
+    eng.close()

@@ -1,0 +1,77 @@
+"""The bigram prefilter (pingoo_amd/csrc/filter.cpp) on the CPU: the compiled filter tables, interpreted by the test-only table
+walker exactly as filter_kernel applies them, must never drop a request the pass's DFA would match (no false negatives), and
+the filtered pipeline must agree with the oracle. The HIP path itself is covered by tests/test_gpu_prefilter.py."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+import table_walker
+from oracle import pyoracle
+from pingoo_amd import RequestBatch, _abi
+from pingoo_amd.engine import CompiledProgram
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_filtered_pipeline_matches_oracle_on_literal_heavy_rules(seed):
+    rng = random.Random(9100 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 40))
+    prog = CompiledProgram(rules, {})
+    assert prog.stats()["n_filtered_groups"] >= 1, "literal rule sets must end up behind the prefilter"
+    t = table_walker.Tables(prog.dump())
+    batch = RequestBatch.from_requests(H.lit_requests(rng, 150))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    for i in range(batch.n):
+        got = t.evaluate(batch, i)
+        assert got == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, i, [batch.field_bytes(f, i) for f in range(5)])
+    assert t.n_candidates > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_filter_has_no_false_negatives_and_heads_are_exact(seed):
+    rng = random.Random(9500 + seed)
+    rules = H.lit_rules(rng, 30)
+    t = table_walker.Tables(CompiledProgram(rules, {}).dump())
+    batch = RequestBatch.from_requests(H.lit_requests(rng, 300))
+    checked = 0
+    for g in t.groups:
+        if "f_table" not in g:
+            continue
+        heads = {local: (lit, exact) for lit, exact, local in g["f_heads"]}
+        for i in range(batch.n):
+            data = batch.field_bytes(g["field"], i)
+            cols = set()
+            t.scan_field(g, data, cols)
+            locals_ = {c - g["atom_base"] for c in cols}
+            if not t.filter_candidate(g, data):
+                # a request the filter lets through unvisited may only match head atoms, and the head comparison must find them
+                assert locals_ <= set(heads), (seed, data, locals_)
+                for local, (lit, exact) in heads.items():
+                    holds = data[:len(lit)] == lit and (not exact or len(data) == len(lit))
+                    assert holds == (local in locals_), (seed, data, lit)
+                checked += 1
+    assert checked > 100
+
+
+def test_prefilter_can_be_switched_off_and_unfilterable_passes_stay_plain():
+    rules = [("a", 'http_request.path.contains("/.env")', [H.B]), ("b", 'http_request.url.matches("[0-9]")', [H.B]), ("c", 'http_request.host.contains("x")', [H.B])]
+    st = CompiledProgram(rules, {}).stats()
+    assert st["n_filtered_groups"] == 1  # path only: a one-byte factor / a digit class has no bigram
+    assert CompiledProgram(rules, {}, flags=_abi.OPT_NO_PREFILTER).stats()["n_filtered_groups"] == 0
+
+
+def test_synthetic_config3_filters_and_candidate_rates():
+    """On the synthetic WAF config every field but `method` is filtered and the filter flags only a few percent of benign traffic."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    prog = CompiledProgram(w.rules, w.lists, w.geoip)
+    t = table_walker.Tables(prog.dump())
+    filtered = {g["field"] for g in t.groups if "f_table" in g}
+    assert filtered == {0, 1, 2, 4}
+    b = w.batch(0, 1500)
+    for g in t.groups:
+        if "f_table" in g:
+            rate = np.mean([t.filter_candidate(g, b.field_bytes(g["field"], i)) for i in range(b.n)])
+            assert rate < 0.12, (g["field"], rate)

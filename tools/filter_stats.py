@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Host-side look at the bigram prefilters of a synthetic config: which passes are filtered, their heads, and the candidate
+rate on a sample of the synthetic stream (numpy model of filter_kernel). Usage: python tools/filter_stats.py [config] [n] [--tune]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from pingoo_amd.engine import CompiledProgram
+from synth import pysynth
+import table_walker
+
+def candidates(g, data, off):
+    """vectorised over one field arena: returns bool per request"""
+    n = len(off) - 1
+    d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
+    p = d[:-1] | (d[1:] << 8)
+    bins = ((p * 0x9E37) & 0xFFFF) >> 4
+    m = g["f_table"][bins].astype(np.uint64)
+    # state after position i = OR_{j<4} (m[i-j] << 8j) restricted to the field; emulate with field-local shifts
+    pos = np.arange(len(m))
+    start = np.repeat(off[:-1], np.diff(off))  # field start per byte
+    start = start[: len(m)] if len(start) >= len(m) else np.concatenate([start, np.full(len(m) - len(start), off[-1])])
+    top = (m >> 24) & 0xFF
+    init = int(g["f_init"])
+    for j in range(1, 4):
+        shifted = np.concatenate([np.zeros(j, dtype=np.uint64), m[:-j]])
+        contrib = (shifted >> (8 * (3 - j))) & 0xFF
+        inside = (pos - j) >= start
+        initb = (init >> (8 * (3 - j) + 0)) & 0xFF if True else 0
+        # before the field start the state comes from init: byte (3 - j + (pos-start)) ... handled approximately: init bits of
+        # position (3 - (pos - start) - 1 ...) -- use exact formula below
+        top |= np.where(inside, contrib, 0)
+    # exact init contribution: after t+1 steps inside the field (t = pos - start), init << 8(t+1) contributes its byte (3 - (t+1)) to the top
+    t = pos - start
+    for tt in range(0, 3):
+        ib = (init >> (8 * (3 - (tt + 1)))) & 0xFF
+        top |= np.where(t == tt, ib, 0).astype(np.uint64)
+    hit = (top & 0xFF) != 0xFF
+    # valid positions: i and i+1 inside the same field
+    endb = np.repeat(off[1:], np.diff(off))
+    endb = endb[: len(m)] if len(endb) >= len(m) else np.concatenate([endb, np.full(len(m) - len(endb), off[-1])])
+    hit &= (pos + 1) < endb
+    csum = np.concatenate([[0], np.cumsum(hit)])
+    o = np.minimum(off, len(m))
+    return (csum[o[1:]] - csum[o[:-1]]) > 0
+
+def main():
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+    wl = pysynth.Workload(cfg)
+    prog = CompiledProgram(wl.rules, wl.lists, wl.geoip)
+    print(prog.stats())
+    t = table_walker.Tables(prog.dump())
+    b = wl.batch(0, n)
+    names = ["host", "url", "path", "method", "user_agent"]
+    for gi, g in enumerate(t.groups):
+        line = f"group {gi} field {names[g['field']]:<10} states {g['n_states']:>6} classes {g['n_classes']:>3} atoms {g['n_local']:>4}"
+        if "f_table" in g:
+            data, off = b.data[g["field"]], b.offsets[g["field"]].astype(np.int64)
+            c = candidates(g, np.concatenate([data, np.zeros(8, np.uint8)]), off)
+            zeros = [(int(g["f_table"][k]) ^ 0xFFFFFFFF) for k in range(0, 4096)]
+            filled = sum(1 for z in zeros if z)
+            line += f"  FILTER init {g['f_init']:08x} heads {[(h[0], h[1]) for h in g['f_heads']]} bins touched {filled}  candidates {c.mean() * 100:.2f} %"
+        print(line)
+
+main()
+
+def crosscheck():
+    wl = pysynth.Workload(3)
+    prog = CompiledProgram(wl.rules, wl.lists, wl.geoip)
+    t = table_walker.Tables(prog.dump())
+    b = wl.batch(0, 3000)
+    for g in t.groups:
+        if "f_table" not in g:
+            continue
+        data, off = b.data[g["field"]], b.offsets[g["field"]].astype(np.int64)
+        c = candidates(g, np.concatenate([data, np.zeros(8, np.uint8)]), off)
+        ref = np.array([t.filter_candidate(g, b.field_bytes(g["field"], i)) for i in range(3000)])
+        # and soundness: any request whose DFA reports a non-head atom must be a candidate
+        missed = 0
+        heads = {h[2] for h in g["f_heads"]}
+        for i in range(3000):
+            cols = set()
+            t.scan_field(g, b.field_bytes(g["field"], i), cols)
+            if any((cc - g["atom_base"]) not in heads for cc in cols) and not ref[i]:
+                missed += 1
+        print("field", g["field"], "numpy==python:", bool((c == ref).all()), "cand", int(ref.sum()), "missed", missed)
+
+if os.environ.get("CROSSCHECK"):
+    crosscheck()
