@@ -74,7 +74,7 @@ def main():
     eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
     # profile-guided LDS residency: the DFA rows kept in LDS are chosen from a traffic sample DISJOINT from the timed batch
     # (a deployment would sample live traffic); verdicts do not depend on it
-    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 8192
+    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 32768
     if tune_n:
         eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
     t_compile = time.time() - t0

@@ -39,6 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(HERE, "..", "include")]
+    # PWAF_EXTRA_CXXFLAGS=-DPWAF_PROFILING builds the timing-experiment variant (env switches that change results); never the default
+    common += os.environ.get("PWAF_EXTRA_CXXFLAGS", "").split()
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")

@@ -82,8 +82,13 @@ struct DevGroup {
     uint32_t chunks = 1;  // 16-byte chunks per scan iteration (2 for fields whose sampled mean length is >= 48 bytes)
     int gate = -1;  // >= 0: list-driven pass (behind a bigram prefilter, or gated by prefilter factors): index of its request list
     bool filtered = false;  // the list comes from filter_kernel + compact_kernel
+    int share_owner = -1;   // a gap pass whose factors all belong to this filtered pass: it walks the owner's list (no list of its own)
+    uint32_t shared_bits = 0;  // owner: list bits of the gap passes sharing its list
+    int need_slot = -1;     // owner: which need-mask array
     GroupFilter filter;     // the prefilter in use (Program's, or rebuilt from a traffic sample by pwaf_engine_tune)
     DevBuf ftable;
+    // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
+    DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
 };
 
 }  // namespace
@@ -94,8 +99,11 @@ struct pwaf_engine {
     hipStream_t stream = nullptr;
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
-    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, geo_row_words = 2, n_trig = 0;
+    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0;
+    uint32_t class_words = 1, acmp_words = 0, geo_default = 0, n_classes = 1;
+    DevBuf class_rows, dir_esc, leaf_root;
     std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
+    std::vector<std::pair<uint32_t, uint32_t>> host_acmp;  // (operator 0: ==, 1: <=; constant) of the client.asn comparisons
     std::vector<int64_t> host_iu_vals1;
     DevBuf iu_vals[2], iu_masks[2];
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
@@ -105,6 +113,8 @@ struct pwaf_engine {
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
     DevBuf colmask, gate_lists, attr, dir24;
     DevBuf cand_sub, cand_cnt;  // filter_kernel's per-slab candidate regions and counts
+    DevBuf need;                // per sharing owner: gap-pass mask of every entry of its candidate list
+    uint32_t n_need = 0;
     uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
     unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
@@ -253,6 +263,20 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     return PWAF_OK;
 }
 
+int build_flat_group(const DfaGroup &g, DevGroup &d) {
+    std::vector<uint16_t> flat(g.trans);
+    for (auto &t : flat)
+        if (g.emit_off[(size_t)t + 1] != g.emit_off[t]) t |= 0x8000u;
+    std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
+    int rc;
+    if ((rc = upload(d.flat, flat))) return rc;
+    if ((rc = upload(d.flat_classmap, cm))) return rc;
+    if ((rc = upload(d.emit_off, g.emit_off))) return rc;
+    if ((rc = upload(d.emit_list, g.emit_list))) return rc;
+    if ((rc = upload(d.end_off, g.end_off))) return rc;
+    return upload(d.end_list, g.end_list);
+}
+
 int validate_batch_header(const pwaf_batch *b) {
     if (!b) return fail(PWAF_E_INVALID_ARG, "batch is NULL");
     if (b->struct_size != sizeof(pwaf_batch)) return fail(PWAF_E_INVALID_ARG, "pwaf_batch.struct_size mismatch");
@@ -268,19 +292,25 @@ int validate_batch_header(const pwaf_batch *b) {
 // the trie part of the kernel arguments (shared by the per-batch pipeline and the one-off DIR-24 table build)
 void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     const Program &P = *e->prog.p;
-    v.ip_root4 = P.ipset_trie.root4.empty() ? nullptr : (const uint32_t *)e->ip_root4.p;
-    v.ip_root6 = P.ipset_trie.root6.empty() ? nullptr : (const uint32_t *)e->ip_root6.p;
+    // a family without prefixes walks an all-leaf root: the kernels never test the pointers
+    const uint32_t *leaf = (const uint32_t *)e->leaf_root.p;
+    v.ip_root4 = P.ipset_trie.root4.empty() ? leaf : (const uint32_t *)e->ip_root4.p;
+    v.ip_root6 = P.ipset_trie.root6.empty() ? leaf : (const uint32_t *)e->ip_root6.p;
     v.ip_nodes = (const uint32_t *)e->ip_nodes.p;
     v.set_masks = (const uint32_t *)e->set_masks.p;
     v.set_words = P.set_words;
     v.n_ip_lists = P.n_ip_lists;
-    v.geo_root4 = P.geo_trie.root4.empty() ? nullptr : (const uint32_t *)e->geo_root4.p;
-    v.geo_root6 = P.geo_trie.root6.empty() ? nullptr : (const uint32_t *)e->geo_root6.p;
+    v.geo_root4 = P.geo_trie.root4.empty() ? leaf : (const uint32_t *)e->geo_root4.p;
+    v.geo_root6 = P.geo_trie.root6.empty() ? leaf : (const uint32_t *)e->geo_root6.p;
     v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
     v.has_geo = P.has_geo ? 1u : 0u;
-    v.dir24 = (const uint64_t *)e->dir24.p;
+    v.dir24 = (const uint32_t *)e->dir24.p;
+    v.dir_esc = (const uint2 *)e->dir_esc.p;
+    v.class_rows = (const uint32_t *)e->class_rows.p;
+    v.class_words = e->class_words;
+    v.acmp_words = e->acmp_words;
+    v.geo_default = e->geo_default;
 }
-
 
 // Decides which passes are list-driven and uploads what that needs: a pass behind a bigram prefilter walks the filter's candidate
 // list, a gated gap pass the list fed by its prefilter factors (owned by earlier passes). Called at creation and again when
@@ -310,6 +340,26 @@ int assign_lists(pwaf_engine *e) {
     for (size_t k = 0; k < P.groups.size() && k < 64; k++)
         for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
             if (colmask[c]) e->select_pass_mask |= 1ull << k;
+    // gap passes whose factors all live in ONE filtered pass walk that pass's candidate list (no atomics, no list of their own)
+    e->n_need = 0;
+    for (auto &d : e->groups) { d.share_owner = -1; d.shared_bits = 0; d.need_slot = -1; }
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        DevGroup &d = e->groups[k];
+        if (d.gate < 0 || d.filtered) continue;
+        int owner = -1;
+        bool single = true;
+        for (uint32_t c : P.groups[k].filter_cols) {
+            int o = -1;
+            for (size_t q = 0; q < P.groups.size(); q++)
+                if (c >= P.groups[q].atom_base && c < P.groups[q].atom_base + P.groups[q].n_local) o = (int)q;
+            if (o < 0 || (owner >= 0 && o != owner)) single = false;
+            owner = o;
+        }
+        if (!single || owner < 0 || !e->groups[owner].filtered) continue;
+        d.share_owner = owner;
+        e->groups[owner].shared_bits |= 1u << d.gate;
+        if (e->groups[owner].need_slot < 0) e->groups[owner].need_slot = (int)e->n_need++;
+    }
     return upload(e->colmask, colmask);
 }
 
@@ -333,6 +383,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     if ((rc = e->ctrl.reserve(4 * 34))) return rc;
     HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
     if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
+    if (e->n_need && (rc = e->need.reserve((size_t)e->n_need * n * 4))) return rc;
 
     // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
     // (half the events; the few microseconds of launch gap or memset in between are charged to the later kernel).
@@ -414,9 +465,6 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_rules = (uint32_t)P.rules.size();
     v.lits = (const uint32_t *)e->lits.p;
     set_trie_args(e, v);
-    v.geo_rows = (const uint32_t *)e->geo_recs.p;
-    v.geo_row_words = e->geo_row_words;
-    v.has_geo = P.has_geo ? 1u : 0u;
     v.out = d_out;
     v.counts = (unsigned long long *)d_counts;
     v.match_idx = d_match_idx;
@@ -427,7 +475,13 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     if ((rc = mark(nullptr, 0, e->side))) return rc;
     {
+#ifdef PWAF_PROFILING
+        static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
+        if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, e->side));
+        int he = skip_attr ? 0 : launch_attr(v, e->side);
+#else
         int he = launch_attr(v, e->side);
+#endif
         if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
     }
     if ((rc = mark("attr", 0xFEu, e->side))) return rc;
@@ -437,10 +491,6 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     auto scan_args = [&](size_t gi) -> ScanArgs {
         const DevGroup &d = e->groups[gi];
         ScanArgs a{};
-        if (d.gate >= 0) {
-            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
-            a.n_list = (const uint32_t *)e->ctrl.p + 2 + d.gate;
-        }
         if (e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
             // this pass owns prefilter factors: it feeds the gated gap passes' request lists as requests finish
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
@@ -459,7 +509,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.start_emit = d.start_emit;
         a.emit_base = d.emit_base;
         a.n_cus = e->n_cus;
-        a.chunks = d.gate >= 0 ? 1u : d.chunks;
+        a.chunks = d.chunks;
         a.special_base = d.special_base;
         a.n_states = d.n_states;
         a.stride = d.stride;
@@ -470,6 +520,44 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.pool_count = (uint32_t *)e->ctrl.p;
         a.pool_cap = pool_cap;
         a.status = (uint32_t *)e->ctrl.p + 1;
+        return a;
+    };
+    auto list_args = [&](size_t gi) -> ListScanArgs {
+        const DevGroup &d = e->groups[gi];
+        ListScanArgs a{};
+        const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
+        a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)src.gate * n;
+        a.n_list = (const uint32_t *)e->ctrl.p + 2 + src.gate;
+        if (d.share_owner >= 0) {
+            a.need_in = (const uint32_t *)e->need.p + (size_t)src.need_slot * n;
+            a.need_bit = (uint32_t)d.gate;
+        }
+        if (e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+            a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
+            a.n_local = d.n_local;
+            a.gate_lists = (uint32_t *)e->gate_lists.p;
+            a.gate_count = (uint32_t *)e->ctrl.p + 2;
+            if (d.need_slot >= 0) {
+                a.need_out = (uint32_t *)e->need.p + (size_t)d.need_slot * n;
+                a.shared_bits = d.shared_bits;
+            }
+        }
+        a.data = db.field[d.field].data;
+        a.off = db.field[d.field].offsets;
+        a.n = n;
+        a.flat = (const uint16_t *)d.flat.p;
+        a.classmap = (const uint8_t *)d.flat_classmap.p;
+        a.n_classes = d.n_classes;
+        a.emit_off = (const uint32_t *)d.emit_off.p;
+        a.emit_list = (const uint16_t *)d.emit_list.p;
+        a.end_off = (const uint32_t *)d.end_off.p;
+        a.end_list = (const uint16_t *)d.end_list.p;
+        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
+        a.pool = (PoolEntry *)e->pool.p;
+        a.pool_count = (uint32_t *)e->ctrl.p;
+        a.pool_cap = pool_cap;
+        a.status = (uint32_t *)e->ctrl.p + 1;
+        a.n_cus = e->n_cus;
         return a;
     };
     // hit records of list-driven passes must read "nothing matched" for the requests the pass does not visit; compile.cpp orders
@@ -559,7 +647,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         int he = launch_scan_gated(gb, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         char nm[48];
-        snprintf(nm, sizeof nm, "gscan_x%u", gb.count);
+        snprintf(nm, sizeof nm, "lscan_x%u", gb.count);
         if ((rc2 = mark(nm, 0xFDu))) return rc2;
         gb.count = 0;
         return PWAF_OK;
@@ -568,7 +656,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
             if (d.gate < 0 || d.filtered != (phase == 0)) continue;
-            gb.g[gb.count++] = scan_args(gi);
+            gb.g[gb.count++] = list_args(gi);
             if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
         }
         if ((rc = flush_gated())) return rc;
@@ -712,6 +800,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     std::vector<uint32_t> pass_base;
     for (size_t k = 0; k < P.groups.size(); k++) {
         if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k]))) return dev_fail(rc);
+        if ((rc = build_flat_group(P.groups[k], e->groups[k]))) return dev_fail(rc);
         pass_base.push_back(P.groups[k].atom_base);
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
@@ -765,7 +854,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         }
         e->n_bit_atoms = (uint32_t)bit_atoms.size();
         // (source word, bit) -> column
-        std::vector<uint32_t> bit_col(24 * 32, 0);
+        std::vector<uint32_t> bit_col(28 * 32, 0);
         for (uint32_t d : bit_atoms) bit_col[(d >> 25) * 32 + ((d >> 20) & 31u)] = d & 0xFFFFFu;
         // Comparison atoms in the canonical form the kernel evaluates: variable (0-4 field lengths, 5 remote_port, 6 asn) against
         // a 32-bit constant with == or <=. Lengths, ports and ASNs are unsigned 32-bit, so constants outside [0, 2^32) fold to
@@ -796,7 +885,16 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         std::vector<CmpAtomDev> cmp_atoms;
         for (const Canon &cn : canon) {
             cmp_atoms.push_back({cn.col | ((2 * cn.vi + cn.op) << 24), cn.c});
+            if (cn.vi == 6) {
+                // client.asn against a constant is a function of the GeoIP record: bit j of the class row's comparison words
+                // (source words 24..27) when the engine resolves the record itself
+                const uint32_t j = (uint32_t)e->host_acmp.size();
+                if (j >= 128) { fail(PWAF_E_UNSUPPORTED, "more than 128 distinct client.asn comparisons"); return dev_fail(PWAF_E_UNSUPPORTED); }
+                bit_col[(24 + j / 32) * 32 + (j & 31)] = cn.col;
+                e->host_acmp.push_back({cn.op, cn.c});
+            }
         }
+        e->acmp_words = ((uint32_t)e->host_acmp.size() + 31) / 32;
         e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
         UP(num_atoms, cmp_atoms)
         UP(bit_atoms, bit_col)
@@ -865,38 +963,62 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     UP(ip_root4, P.ipset_trie.root4)
     UP(ip_root6, P.ipset_trie.root6)
     UP(ip_nodes, P.ipset_trie.nodes)
-    UP(geo_root4, P.geo_trie.root4)
-    UP(geo_root6, P.geo_trie.root6)
-    UP(geo_nodes, P.geo_trie.nodes)
     {
-        // per GeoIP record: everything that is a function of (asn, country), so the device gathers one row per request
-        e->geo_row_words = 2 + e->cc_words + e->iu_words[1];
-        std::vector<uint32_t> rows((size_t)P.geo_recs.size() * e->geo_row_words, 0);
+        // GeoIP classes: everything that depends on the record — country-table bits, asn-set bits, asn comparisons — as one row per
+        // record; records with equal rows share a CLASS (a few hundred for a real rule set), class 0 is the all-zero row. The
+        // device trie's leaves carry class ids, so a request gathers one small cache-resident row instead of a per-record one.
+        e->class_words = std::max(1u, e->cc_words + e->iu_words[1] + e->acmp_words);
+        std::map<std::vector<uint32_t>, uint32_t> class_of;
+        std::vector<uint32_t> rows(e->class_words, 0);  // class 0
+        class_of.emplace(rows, 0u);
+        std::vector<uint32_t> rec_class(P.geo_recs.size(), 0);
         for (size_t r = 0; r < P.geo_recs.size(); r++) {
-            uint32_t *row = &rows[r * e->geo_row_words];
-            row[0] = P.geo_recs[r].asn;
-            row[1] = P.geo_recs[r].country;
+            std::vector<uint32_t> row(e->class_words, 0);
             const uint32_t c0 = (P.geo_recs[r].country & 0xFFu) - 'A', c1 = (P.geo_recs[r].country >> 8) - 'A';
             const uint32_t cidx = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;
-            for (uint32_t w = 0; w < e->cc_words; w++) row[2 + w] = e->host_cc_masks[(size_t)cidx * e->cc_words + w];
-            auto it = std::lower_bound(e->host_iu_vals1.begin(), e->host_iu_vals1.end(), (int64_t)P.geo_recs[r].asn);
-            const size_t mrow = (it != e->host_iu_vals1.end() && *it == (int64_t)P.geo_recs[r].asn) ? (size_t)(it - e->host_iu_vals1.begin()) + 1 : 0;
-            for (uint32_t w = 0; w < e->iu_words[1]; w++) row[2 + e->cc_words + w] = e->host_iu_masks1[mrow * e->iu_words[1] + w];
+            for (uint32_t w = 0; w < e->cc_words; w++) row[w] = e->host_cc_masks[(size_t)cidx * e->cc_words + w];
+            const uint32_t asn = P.geo_recs[r].asn;
+            auto it = std::lower_bound(e->host_iu_vals1.begin(), e->host_iu_vals1.end(), (int64_t)asn);
+            const size_t mrow = (it != e->host_iu_vals1.end() && *it == (int64_t)asn) ? (size_t)(it - e->host_iu_vals1.begin()) + 1 : 0;
+            for (uint32_t w = 0; w < e->iu_words[1]; w++) row[e->cc_words + w] = e->host_iu_masks1[mrow * e->iu_words[1] + w];
+            for (size_t j = 0; j < e->host_acmp.size(); j++)
+                if (e->host_acmp[j].first == 0 ? asn == e->host_acmp[j].second : asn <= e->host_acmp[j].second)
+                    row[e->cc_words + e->iu_words[1] + j / 32] |= 1u << (j & 31);
+            auto ins = class_of.emplace(row, (uint32_t)class_of.size());
+            if (ins.second) rows.insert(rows.end(), row.begin(), row.end());
+            rec_class[r] = ins.first->second;
         }
-        UP(geo_recs, rows)
+        e->n_classes = (uint32_t)class_of.size();
+        e->geo_default = rec_class[0];
+        UP(class_rows, rows)
+        auto remap = [&](const std::vector<uint32_t> &src) {
+            std::vector<uint32_t> out(src);
+            for (auto &x : out)
+                if (x & TRIE_LEAF) x = TRIE_LEAF | rec_class[x & ~TRIE_LEAF];
+            return out;
+        };
+        const std::vector<uint32_t> r4 = remap(P.geo_trie.root4), r6 = remap(P.geo_trie.root6), nd = remap(P.geo_trie.nodes);
+        UP(geo_root4, r4)
+        UP(geo_root6, r6)
+        UP(geo_nodes, nd)
+        const std::vector<uint32_t> leaf(65536, TRIE_LEAF);
+        UP(leaf_root, leaf)
     }
 #undef UP
     if ((P.has_geo && !P.geo_trie.root4.empty()) || (P.n_ip_lists && !P.ipset_trie.root4.empty())) {
-        // DIR-24-8: one 128 MiB table (2^24 x 8 B) so that an IPv4 address resolves its GeoIP record AND its ip-list membership set
-        // with a single gather; built on the device from the two tries that were just uploaded
-        if ((rc = e->dir24.reserve((size_t)8 << 24))) return dev_fail(rc);
+        // DIR-24-8: one 64 MiB table (2^24 x 4 B) so that an IPv4 address resolves its GeoIP class AND its ip-list membership set with
+        // a single gather; built on the device from the two tries that were just uploaded (first launch counts the escapes)
         VerdictArgs tv{};
-        const void *table = e->dir24.p;
-        e->dir24.p = nullptr;  // (the builder itself must walk from the roots)
         set_trie_args(e.get(), tv);
-        e->dir24.p = const_cast<void *>(table);
-        int he = launch_dir24(tv, e->dir24.p, nullptr);
-        if (he || hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
+        DevBuf cnt;
+        if ((rc = cnt.reserve(4))) return dev_fail(rc);
+        uint32_t n_esc = 0;
+        bool ok = hipMemset(cnt.p, 0, 4) == hipSuccess && launch_dir24(tv, nullptr, nullptr, cnt.p, nullptr) == 0 &&
+                  hipMemcpy(&n_esc, cnt.p, 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) ok = e->dir24.reserve((size_t)4 << 24) == PWAF_OK && e->dir_esc.reserve((size_t)std::max(1u, n_esc) * 8) == PWAF_OK;
+        if (ok) ok = hipMemset(cnt.p, 0, 4) == hipSuccess && launch_dir24(tv, e->dir24.p, e->dir_esc.p, cnt.p, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess;
+        cnt.release();
+        if (!ok) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
     }
     if (hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "device synchronize failed after table upload"); return dev_fail(PWAF_E_DEVICE); }
     *out = e.release();
@@ -905,9 +1027,9 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { g.tab.release(); g.classmap.release(); g.special.release(); g.list_off.release(); g.list.release(); g.ftable.release(); }
+    for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->need, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
@@ -1096,6 +1218,19 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             if (cand * 10 > (uint64_t)n * 4) {
                 gf.enabled = false;
                 gf.note = "the filter flags more than 40 % of the sample";
+                continue;
+            }
+            // The DFA of a filtered pass only ever walks the filter's candidates, whose states (deep inside pattern prefixes) are
+            // not the ones average traffic visits: its LDS-resident rows are chosen from the candidates' walks alone.
+            std::vector<uint64_t> &v = visits[k];
+            std::fill(v.begin(), v.end(), 0);
+            for (uint32_t i = 0; i < n; i++) {
+                if (!filter_candidate_host(gf, data + off[i], off[i + 1] - off[i])) continue;
+                uint32_t st = 0;
+                for (uint32_t p = off[i]; p < off[i + 1]; p++) {
+                    st = g.trans[(size_t)st * g.n_classes + g.classmap[data[p]]];
+                    v[st]++;
+                }
             }
         }
     }

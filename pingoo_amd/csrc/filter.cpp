@@ -16,6 +16,8 @@
 //   4. heads: anchored literals that most requests satisfy are taken out of the filter and compared directly.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -48,7 +50,6 @@ Cover trivial() {
 
 struct Model {
     const double *binw;  // kFilterEntries probabilities
-    std::map<std::pair<std::string, std::string>, double> memo;
     double pair_weight(const ByteSet &a, const ByteSet &b) {
         // probability that a text bigram falls into one of the bins the pair of sets maps to
         uint8_t va[256], vb[256];
@@ -64,29 +65,35 @@ struct Model {
         for (uint32_t x : bins) w += binw[x];
         return std::min(1.0, w);
     }
-    // cheapest window of <= 4 bigrams: returns its cost, start and bigram count
-    double best_window(const CStr &s, size_t &start, size_t &k) {
-        const size_t nb = s.size() - 1;
-        k = std::min<size_t>(4, nb);
-        std::vector<double> w(nb);
-        for (size_t j = 0; j < nb; j++) w[j] = pair_weight(s[j], s[j + 1]);
-        double best = 2;
+    // Cheapest window of <= 4 sampled bigrams for a factor whose first byte sits `o` bytes past a sampling point (o < stride):
+    // sampled bigrams start at o' = (stride - o) % stride ... i.e. at internal offsets a, a + stride, ...; returns its cost, the
+    // internal offset of its first bigram and the bigram count (0 = the factor is too short for this alignment).
+    double best_window(const CStr &s, size_t a, size_t &start, size_t &k) {
+        std::vector<size_t> pos;
+        for (size_t j = a; j + 1 < s.size(); j += kFilterStride) pos.push_back(j);
+        k = std::min<size_t>(4, pos.size());
         start = 0;
-        for (size_t st = 0; st + k <= nb; st++) {
+        if (k == 0) return INFINITY;
+        std::vector<double> w(pos.size());
+        for (size_t q = 0; q < pos.size(); q++) w[q] = pair_weight(s[pos[q]], s[pos[q] + 1]);
+        double best = 2;
+        for (size_t st = 0; st + k <= pos.size(); st++) {
             double c = 1;
             for (size_t j = 0; j < k; j++) c *= w[st + j];
-            if (c < best) { best = c; start = st; }
+            if (c < best) { best = c; start = pos[st]; }
         }
         return best;
     }
-    // expected false-positive contribution of a factor set; +inf when it is not usable (a string shorter than one bigram)
+    // expected false-positive contribution of a factor set (every string at every alignment); +inf when it is not usable
     double score(const Cover &c) {
         if (!c.ok || c.s.empty()) return INFINITY;
         double t = 0;
         for (auto &s : c.s) {
-            if (s.size() < 2) return INFINITY;
-            size_t st, k;
-            t += best_window(s, st, k);
+            if (s.size() < 1 + kFilterStride) return INFINITY;
+            for (size_t a = 0; a < kFilterStride; a++) {
+                size_t st, k;
+                t += best_window(s, a, st, k);
+            }
         }
         return t;
     }
@@ -275,7 +282,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     // smoothed: a bin the sample never showed is still possible
     std::vector<double> w(kFilterEntries);
     for (uint32_t x = 0; x < kFilterEntries; x++) w[x] = binw[x] * 0.98 + 0.02 / kFilterEntries;
-    Model m{w.data(), {}};
+    Model m{w.data()};
 
     if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
     if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
@@ -332,30 +339,37 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         f = better(m, f, x.P);
         f = better(m, f, x.S);
         if (!std::isfinite(m.score(f))) {
-            out.note = "pattern without a literal factor of two or more bytes: " + at.key.substr(0, 80);
+            out.note = "pattern without a literal factor of " + std::to_string(1 + kFilterStride) + " or more bytes: " + at.key.substr(0, 80);
             out.heads.clear();
             return;
         }
-        for (auto &s : f.s) {
-            size_t st, k;
-            Window wd;
-            wd.cost = m.best_window(s, st, k);
-            wd.k = k;
-            std::string key = std::to_string(k) + ":";
-            for (size_t j = 0; j < k; j++) {
-                std::set<uint32_t> bins;
-                for (int a = 0; a < 256; a++)
-                    if (s[st + j][(size_t)a])
-                        for (int b = 0; b < 256; b++)
-                            if (s[st + j + 1][(size_t)b]) bins.insert(filter_bin((uint8_t)a, (uint8_t)b));
-                for (uint32_t bn : bins) {
-                    wd.bins[j].push_back((uint16_t)bn);
-                    key += std::to_string(bn) + ",";
+        for (auto &s : f.s)
+            for (size_t al = 0; al < kFilterStride; al++) {
+                size_t st, k;
+                Window wd;
+                wd.cost = m.best_window(s, al, st, k);
+                wd.k = k;
+                std::string key = std::to_string(k) + ":";
+                for (size_t j = 0; j < k; j++) {
+                    const size_t at = st + j * kFilterStride;
+                    std::set<uint32_t> bins;
+                    for (int a = 0; a < 256; a++)
+                        if (s[at][(size_t)a])
+                            for (int b = 0; b < 256; b++)
+                                if (s[at + 1][(size_t)b]) bins.insert(filter_bin((uint8_t)a, (uint8_t)b));
+                    for (uint32_t bn : bins) {
+                        wd.bins[j].push_back((uint16_t)bn);
+                        key += std::to_string(bn) + ",";
+                    }
+                    key += ";";
                 }
-                key += ";";
+                if (getenv("PWAF_FILTER_DEBUG") && wd.cost > 1e-5) {
+                    std::string txt;
+                    for (auto &bs : s) { int c = -1, cnt = 0; for (int b = 0; b < 256; b++) if (bs[(size_t)b]) { c = b; cnt++; } txt += cnt == 1 ? (char)c : '#'; }
+                    fprintf(stderr, "filter field %d: factor '%s' align %zu window at %zu x%zu cost %.2e (atom %s)\n", g.field, txt.c_str(), al, st, k, wd.cost, at.key.substr(0, 60).c_str());
+                }
+                if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
             }
-            if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
-        }
     }
     if (wins.empty() && out.heads.empty()) { out.note = "no patterns"; return; }
 
@@ -415,14 +429,14 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             }
         }
     }
-    const double len = hints && hints->mean_len > 0 ? hints->mean_len : 64.0;
+    const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / kFilterStride;
     out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, fp_pos)), len);
     out.enabled = true;
 }
 
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
     uint32_t st = f.init;
-    for (size_t i = 0; i + 1 < n; i++) {
+    for (size_t i = 0; i + 1 < n; i += kFilterStride) {
         st = (st << 8) | f.table[filter_bin(bytes[i], bytes[i + 1])];
         if ((~st) & 0xFF000000u) return true;
     }

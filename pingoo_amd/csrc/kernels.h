@@ -58,9 +58,42 @@ struct ScanArgs {
     uint32_t n_local;         // atoms of this pass (entries of colmask_local)
     uint32_t *gate_lists;     // [n_gated][n]
     uint32_t *gate_count;     // [n_gated], zeroed by the host per batch
-    // gated pass only (else null): the requests to visit and, on the device, how many
-    const uint32_t *req_list;
+};
+
+// A list-driven pass (behind a bigram prefilter, or gated by prefilter factors): lscan_kernel walks ONE listed request per lane
+// through the pass's DFA, read straight from the L2-resident flat table (no LDS staging, no hot / cold rows: a list holds a few
+// percent of the batch, so what matters is latency per request and full occupancy, not bytes per clock).
+//   flat[s * n_classes + c] = next state | 0x8000 when entering it emits; emit / end lists are indexed by state.
+struct ListScanArgs {
+    const uint8_t *data;
+    const uint32_t *off;
+    uint32_t n;
+    const uint16_t *flat;
+    const uint8_t *classmap;  // 256 bytes
+    uint32_t n_classes;
+    const uint32_t *emit_off;  // [n_states + 1]
+    const uint16_t *emit_list;
+    const uint32_t *end_off;
+    const uint16_t *end_list;
+    uint32_t *rec;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t pool_cap;
+    uint32_t *status;
+    const uint32_t *colmask_local;  // a pass that owns prefilter factors (else null)
+    uint32_t n_local;
+    uint32_t *gate_lists;
+    uint32_t *gate_count;
+    const uint32_t *req_list;  // the requests to visit and, on the device, how many
     const uint32_t *n_list;
+    // Gap passes whose prefilter factors all belong to ONE filtered pass share that pass's candidate list instead of getting lists
+    // of their own through atomics (a returned same-address atomic per enqueued request was 0.5 ms per batch): the owner writes,
+    // per list entry, the mask of gap passes its hits call for (need_out); a sharing pass skips entries without its bit.
+    uint32_t *need_out;        // owner: [list entry] -> gap-pass mask (null: none shares)
+    uint32_t shared_bits;      // owner: the gap passes that read need_out (the other bits of a hit's mask are enqueued with atomics)
+    const uint32_t *need_in;   // sharing pass: the owner's masks (null: the list is its own)
+    uint32_t need_bit;
+    uint32_t n_cus;
 };
 
 // ---- bigram prefilter (program.h: GroupFilter) ------------------------------------------------------------------------------
@@ -121,7 +154,7 @@ struct VerdictArgs {
     const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant): col = column | code << 24 with
                                   // code = 2 * variable (0-4 field lengths, 5 port, 6 asn) + operator (0: ==, 1: <=)
     uint32_t n_cmp;
-    const uint32_t *bit_col;      // [24 source words][32 bits] -> column of the membership atom, 0 = none
+    const uint32_t *bit_col;      // [28 source words][32 bits] -> column of the membership atom, 0 = none
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
     const uint32_t *iu_masks[2];
@@ -141,9 +174,13 @@ struct VerdictArgs {
     uint32_t set_words;
     uint32_t n_ip_lists;
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
-    const uint64_t *dir24;        // IPv4: first 24 bits of both tries flattened, geo entry | ip-list entry << 32 (null = walk from the roots)
-    const uint32_t *geo_rows;   // per GeoIP record: asn, country, country-table words, asn-set words (row 0 = default {0,"XX"})
-    uint32_t geo_row_words;
+    // (roots are never null on the device: a family without prefixes gets an all-leaf root. GeoIP trie leaves are CLASS ids.)
+    const uint32_t *dir24;        // IPv4: first 24 bits of both tries flattened: class | set << 16, or DIR_ESCAPE | index into dir_esc (null = walk from the roots)
+    const uint2 *dir_esc;         // {geo trie entry, ip-list trie entry} of the escaped /24s
+    const uint32_t *class_rows;   // per GeoIP class: country-table words, asn-set words, asn-comparison words (class 0 = all zero)
+    uint32_t class_words;
+    uint32_t acmp_words;          // asn-comparison words per class row
+    uint32_t geo_default;         // class of the default record {0, "XX"}
     uint32_t has_geo;
     // attribute kernel -> verdict kernel: per 64-request group the (column, mask) pairs of every non-scan atom that holds for
     // some request of the group. gpairs[g * pair_stride + k] = {column, 0, mask lo, mask hi}, ghdr[g] = number of pairs
@@ -161,14 +198,14 @@ struct VerdictArgs {
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
 static constexpr uint32_t kGatedPerLaunch = 8;
 struct GatedArgs {
-    ScanArgs g[kGatedPerLaunch];
+    ListScanArgs g[kGatedPerLaunch];
     uint32_t count;
 };
 int launch_scan(const ScanArgs &a, void *stream);
 int launch_scan_gated(const GatedArgs &b, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 int launch_attr(const VerdictArgs &a, void *stream);
-int launch_dir24(const VerdictArgs &a, void *out, void *stream);  // out: 2^24 x uint64
+int launch_dir24(const VerdictArgs &a, void *out /* 2^24 x u32, or null: count only */, void *esc, void *esc_count, void *stream);
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;

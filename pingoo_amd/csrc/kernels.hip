@@ -12,7 +12,7 @@
 //                    visited transition rows live in LDS; the others are read from the L2-resident table. What a request matched is
 //                    written as one 4-byte hit record (two atoms inline, more through an overflow chain): lanes never share state, no
 //                    atomics on the common path.
-//   gscan_kernel     every gated pass (patterns with wide gaps, visited only by requests whose prefilter factor matched) in one launch.
+//   lscan_kernel     every gated pass (patterns with wide gaps, visited only by requests whose prefilter factor matched) in one launch.
 //   attr_kernel      beside the scans, on a side stream at lower wave priority: everything that is not a string scan — GeoIP record and
 //                    ip-list membership (DIR-24-8 table + radix tries), country / integer-set membership, length / port / asn
 //                    comparisons — reduced per 64-request group to (column, 64-request mask) pairs with wave ballots.
@@ -154,10 +154,8 @@ __device__ __noinline__ Walk careful_step(const PWAF_GLOBAL unsigned char *gtab,
     }
     return w;
 }
-// A finished request whose hits include prefilter factors is appended to the lists of the gated passes those factors guard
-// (rare: one atomic per request and gated pass).
-__device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const PoolEntry *pool, uint32_t *gate_lists, uint32_t *gate_count, uint32_t n,
-                                           uint32_t r, Hits h) {
+// The gap passes a finished request's hits call for: OR of the per-atom masks.
+__device__ __noinline__ uint32_t gate_mask(const uint32_t *colmask_local, const PoolEntry *pool, Hits h) {
     uint32_t need = 0;
     if (h.ovf != kNone) {
         for (uint32_t i = h.ovf; i != kNone;) {
@@ -168,11 +166,20 @@ __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const 
         if (h.a0) need |= colmask_local[h.a0 - 1];
         if (h.a1) need |= colmask_local[h.a1 - 1];
     }
+    return need;
+}
+// A finished request whose hits include prefilter factors is appended to the lists of the gated passes those factors guard
+// (rare: one atomic per request and gated pass).
+__device__ __noinline__ void enqueue_mask(uint32_t *gate_lists, uint32_t *gate_count, uint32_t n, uint32_t r, uint32_t need) {
     while (need) {
         const uint32_t g = (uint32_t)__builtin_ctz(need);
         need &= need - 1;
         gate_lists[(size_t)g * n + atomicAdd(&gate_count[g], 1u)] = r;
     }
+}
+__device__ __forceinline__ void enqueue_gated(const uint32_t *colmask_local, const PoolEntry *pool, uint32_t *gate_lists, uint32_t *gate_count, uint32_t n,
+                                              uint32_t r, Hits h) {
+    enqueue_mask(gate_lists, gate_count, n, r, gate_mask(colmask_local, pool, h));
 }
 
 #define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
@@ -182,7 +189,7 @@ __device__ __noinline__ void enqueue_gated(const uint32_t *colmask_local, const 
 // User-Agent), not for short ones (host, method). The engine picks it per pass from the tuning sample's mean field length.
 // WIDE: a row has more than 127 byte classes, so a class's byte offset inside a row (class * 2) no longer fits the 256 x u8 class
 // table; the table is then 256 x u32 (rare: it takes patterns that tell ~128 byte values apart).
-template <bool INDIRECT, int CH, bool WIDE>
+template <int CH, bool WIDE>
 __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t stride2 = a.stride * 2;
@@ -196,13 +203,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
     // the attribute kernel shares the CUs: scan waves issue first, its waves take the slots they leave (default priority 0)
     __builtin_amdgcn_s_setprio(3);
-    if (INDIRECT) {
-        // gated pass: most workgroups of the fixed grid have nothing to do (the request lists are short) — leave before paying
-        // for the table staging
-        const uint32_t n_l = min(*a.n_list, a.n), tw = gridDim.x * kScanWaves;
-        const uint32_t pw = (((n_l + tw - 1) / tw) + 63) & ~63u;
-        if ((uint64_t)blockIdx.x * kScanWaves * pw >= n_l) return;
-    }
     const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
@@ -237,13 +237,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     const uint32_t emit_base = a.emit_base;        // cells >= emit_base: the row emits, or (>= special_base) is cold
     const uint32_t special_base = a.special_base;  // cells >= special_base index the special table
     const uint32_t emit_col2 = (a.n_classes + 2) * 2u;
-    // this wave's slab of work items: contiguous. A work item is request i, or —
-    // for a gated pass — entry i of the list of requests whose prefilter fired (its length lives on the device).
-    const uint32_t n_items = INDIRECT ? min(*a.n_list, a.n) : a.n;
+    // this wave's slab of requests: contiguous, split evenly (rounding 1221 requests per wave up to 1280 would cost 5 % of every scan)
+    const uint32_t n_items = a.n;
     const uint32_t total_waves = gridDim.x * kScanWaves;
-    // (a gated pass rounds its slabs to whole blocks of 64 so that a short list occupies few workgroups; a full pass splits evenly:
-    // rounding 1221 requests per wave up to 1280 would cost 5 % of every scan)
-    const uint32_t per_wave = INDIRECT ? (((n_items + total_waves - 1) / total_waves) + 63) & ~63u : (n_items + total_waves - 1) / total_waves;
+    const uint32_t per_wave = (n_items + total_waves - 1) / total_waves;
     const uint32_t gw = blockIdx.x * kScanWaves + wave;
     const uint32_t w0 = min(n_items, gw * per_wave), w1 = min(n_items, w0 + per_wave);
     if (w0 >= w1) return;
@@ -252,16 +249,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     const uint32_t start_emit = a.start_emit;
 
     uint32_t next = w0, blk = w0;
-    uint32_t o_id = 0, n_id = 0;  // INDIRECT: request index of each block entry
-    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi, uint32_t &id) {
-        uint32_t i = min(base + lane, n_items - 1);  // base + lane < n_items + 63; clamp keeps the load in bounds
-        if (INDIRECT) i = a.req_list[i];
-        id = i;
+    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi) {
+        const uint32_t i = min(base + lane, n_items - 1);  // base + lane < n_items + 63; clamp keeps the load in bounds
         lo = goff[i];
         hi = goff[i + 1];
     };
     uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0, n_base = kNone;
-    load_off(blk, o_lo, o_hi, o_id);
+    load_off(blk, o_lo, o_hi);
     // Software pipeline: while a lane chews on the 16 bytes in `w`, the 16 bytes it will need in the NEXT iteration are
     // already in flight in `wn` — either the next chunk of the same field or, when this is the field's last chunk, the
     // first chunk of the request the lane has just pulled (r2/p2/end2). HBM/L2 latency hides behind 16 DFA steps.
@@ -280,9 +274,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         // offsets of the NEXT block of 64 work items: re-requested every iteration (L1 hits) instead of once per block inside a
         // branch, because a load whose result crosses a branch merge forces an immediate s_waitcnt vmcnt(0) — which would
         // also drain the chunk prefetch
-        uint32_t f_lo, f_hi, f_id;
+        uint32_t f_lo, f_hi;
         const uint32_t f_base = blk + 64;
-        load_off(f_base, f_lo, f_hi, f_id);
+        load_off(f_base, f_lo, f_hi);
         // ---- 1. pull ahead: lanes on their last chunk (or idle) take the next request of the slab ----
         const bool last = r == kNone || p + kStep >= end;
         const unsigned long long want = __ballot(last && r2 == kNone);
@@ -293,10 +287,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             const uint32_t j = take ? next + rank - blk : 0;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_lo);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_hi);
-            uint32_t rid = next + rank;
-            if (INDIRECT) rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_id);
             if (take) {
-                r2 = rid;
+                r2 = next + rank;
                 p2 = lo;
                 end2 = hi;
             }
@@ -306,9 +298,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
                 if (n_base == blk) {  // requested during an earlier iteration for this very block
                     o_lo = n_lo;
                     o_hi = n_hi;
-                    o_id = n_id;
                 } else {              // two block switches in consecutive iterations (very short fields): fetch now
-                    load_off(blk, o_lo, o_hi, o_id);
+                    load_off(blk, o_lo, o_hi);
                 }
             }
         }
@@ -440,20 +431,61 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
         for (int q = 0; q < CH; q++) w[q] = wn[q];
         n_lo = f_lo;
         n_hi = f_hi;
-        n_id = f_id;
         n_base = f_base;
     }
 }
 
 template <int CH, bool WIDE>
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<false, CH, WIDE>(a); }
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<CH, WIDE>(a); }
 
-// Every gated pass of the program in ONE launch (blockIdx.y = pass): their request lists are short, so separate launches were
-// dominated by launch latency and table staging.
-template <bool WIDE>
-__global__ __launch_bounds__(kScanThreads) void gscan_kernel(GatedArgs b) {
-    const ScanArgs a = b.g[blockIdx.y];
-    scan_body<true, 1, WIDE>(a);
+// lscan_kernel: every list-driven pass of a phase in ONE launch (blockIdx.y = pass). One listed request per lane, walked byte by
+// byte through the flat table in L2 (dependent 2-byte loads: ~100 ns per step at an L1 / L2 hit); a list is a few percent of the
+// batch (tens of MB of field bytes), so the whole launch takes tens of microseconds at full occupancy — the wave-lockstep walk of
+// scan_kernel, built for streaming EVERY request, took 0.6 ms on the same lists (every lane a candidate: its slow paths fire in
+// every group of steps).
+__global__ __launch_bounds__(256) void lscan_kernel(GatedArgs b) {
+    __shared__ unsigned char cls[256];
+    const ListScanArgs &a = b.g[blockIdx.y];
+    const uint32_t n_l = min(*a.n_list, a.n);
+    if (blockIdx.x * 256u >= n_l) return;
+    cls[threadIdx.x] = a.classmap[threadIdx.x];
+    __syncthreads();
+    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
+    const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
+    const uint32_t ncls = a.n_classes;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_l; i += gridDim.x * 256u) {
+        if (a.need_in != nullptr && !((a.need_in[i] >> a.need_bit) & 1u)) continue;  // (a sharing gap pass: none of its factors fired here)
+        const uint32_t r = a.req_list[i];
+        uint32_t p = a.off[r];
+        const uint32_t end = a.off[r + 1];
+        uint32_t state = 0;
+        Hits h{0, 0, kNone};
+        if (a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
+        while (p < end) {
+            const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
+            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+            const uint32_t cnt = min(16u, end - p);
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                if (k < cnt) {
+                    const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                    const uint32_t t = flat[state * ncls + cls[byte]];
+                    state = t & 0x7FFFu;
+                    if (t & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+                }
+            }
+            p += 16;
+        }
+        if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+        a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+        if (a.colmask_local != nullptr) {
+            uint32_t need = 0;
+            if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
+            if (a.need_out != nullptr) a.need_out[i] = need;
+            need &= ~a.shared_bits;
+            if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+        }
+    }
 }
 
 int launch_scan(const ScanArgs &a, void *stream) {
@@ -482,21 +514,14 @@ int launch_scan(const ScanArgs &a, void *stream) {
 }
 
 int launch_scan_gated(const GatedArgs &b, void *stream) {
-    uint32_t lds = 0;
-    bool wide = false;
-    for (uint32_t k = 0; k < b.count; k++) {
-        lds = max(lds, scan_lds_bytes(b.g[k].n_hot, b.g[k].stride, b.g[k].colmask_local ? b.g[k].n_local : 0u));
-        wide = wide || b.g[k].n_classes > 127;  // (the u32 class table serves narrow passes too: one variant per launch)
-    }
-    const void *fn = wide ? reinterpret_cast<const void *>(gscan_kernel<true>) : reinterpret_cast<const void *>(gscan_kernel<false>);
     if (b.count == 0 || b.g[0].n == 0) return 0;
-    // the list lengths are only known on the device; lists are short (the prefilters are rare), so a modest fixed grid per
-    // pass is enough and idle workgroups exit at once
+    // the list lengths are only known on the device: a grid that covers the chip once per pass (grid-stride over the list);
+    // workgroups beyond a list's end exit at once
+    const uint32_t blocks = std::min<uint32_t>((b.g[0].n + 255) / 256, std::max(1u, b.g[0].n_cus) * 8u);
     void *args[] = {const_cast<GatedArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(fn, dim3(64, b.count), dim3(kScanThreads), args, lds, (hipStream_t)stream);
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(lscan_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
-
 
 // -------------------------------------------------------------------------------------------------
 // bigram prefilter
@@ -506,7 +531,7 @@ int launch_scan_gated(const GatedArgs &b, void *stream) {
 // per-byte path depends on a previous lookup (the DFA walk it replaces chains v_lshl_add -> ds_read_u16 per byte plus a class
 // lookup), so the kernel is bound by LDS gather throughput and HBM streaming, not by LDS latency. A zero bit in the top byte of
 // `seen` at the end of a field = "some position completed a window of some bucket": the request is a CANDIDATE and is walked by
-// the pass's DFA afterwards (gscan_kernel); every other request provably matches no pattern of the pass. Positions past a field's
+// the pass's DFA afterwards (lscan_kernel); every other request provably matches no pattern of the pass. Positions past a field's
 // end (and across a chunk fetched for the next request) are not masked: extra positions can only flag more candidates.
 //
 // Hash of a position = top 12 bits of the 16-bit product fold(pair) * kFilterMul: two positions per v_pk_mul_lo_u16; the table's
@@ -678,7 +703,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
 }
 
 // compact_kernel: concatenates the per-slab candidate regions of every filtered pass into dense request lists (order:
-// ascending request index) and publishes the list lengths for the confirming gscan_kernel launch. One workgroup covers
+// ascending request index) and publishes the list lengths for the confirming lscan_kernel launch. One workgroup covers
 // kCompactSlabs consecutive slabs; its base offset is the sum of the counts of all earlier slabs (a few thousand values).
 static constexpr uint32_t kCompactSlabs = 64;
 __global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
@@ -723,7 +748,13 @@ int launch_filter(const FilterBatchArgs &b, void *stream) {
     }
     if (blocks == 0) return 0;
     void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(filter_kernel<2>), dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
+    int ch = 2;
+#ifdef PWAF_PROFILING
+    static const int forced_ch = getenv("PWAF_FILTER_CH") ? atoi(getenv("PWAF_FILTER_CH")) : 0;
+    if (forced_ch) ch = forced_ch;
+#endif
+    const void *fn = ch == 1 ? reinterpret_cast<const void *>(filter_kernel<1>) : ch == 4 ? reinterpret_cast<const void *>(filter_kernel<4>) : reinterpret_cast<const void *>(filter_kernel<2>);
+    hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -790,7 +821,7 @@ struct VerdictTables {
 __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool lt) {
     VerdictTables t;
     t.bitcol = 0;
-    t.trig_off = kBitColEntries * 4;
+    t.trig_off = 0;
     t.trig_rules = t.trig_off + (lt ? ((n_cols + 1) * 2 + 3) & ~3u : 0u);
     t.rules = t.trig_rules + (lt ? (n_trig * 2 + 7) & ~7u : 0u);
     t.lits = t.rules + (lt ? n_rules * 8 : 0u);
@@ -818,13 +849,11 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
     unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
     const VerdictTables vt = verdict_tables(a.n_cols, a.n_rules, a.n_trig, a.n_lits, LT);
-    uint32_t *bitcol = reinterpret_cast<uint32_t *>(tables + vt.bitcol);
     uint16_t *l_trig_off = reinterpret_cast<uint16_t *>(tables + vt.trig_off);
     uint16_t *l_trig_rules = reinterpret_cast<uint16_t *>(tables + vt.trig_rules);
     uint2 *l_rules = reinterpret_cast<uint2 *>(tables + vt.rules);
     uint32_t *l_lits = reinterpret_cast<uint32_t *>(tables + vt.lits);
     uint16_t *l_pub = reinterpret_cast<uint16_t *>(tables + vt.pub);  // public rule index, 16 bits (the pseudo rules' 0xFFFFFFFx ids keep their low half)
-    for (uint32_t k = tid; k < kBitColEntries; k += blockDim.x) bitcol[k] = a.bit_col[k];
     if (LT) {
         for (uint32_t k = tid; k <= a.n_cols; k += blockDim.x) l_trig_off[k] = (uint16_t)a.trig_off[k];
         for (uint32_t k = tid; k < a.n_trig; k += blockDim.x) l_trig_rules[k] = a.trig_rules[k];
@@ -1125,22 +1154,68 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 // attributes: everything about a request that is NOT a string scan — GeoIP record, ip-list membership, country / integer-set
 // membership, length / port / asn comparisons — reduced per 64-request group to a list of (column, 64-request mask) pairs
 // -------------------------------------------------------------------------------------------------
-// The lookups are chains of dependent gathers (DIR-24 / trie levels, membership rows, binary searches); inside the verdict kernel,
-// whose LDS column file caps it at ~9 waves per CU, they cost more than a third of its time. This kernel needs no LDS and does
-// not depend on the scans, so it runs BESIDE them on the engine's side stream (a small persistent grid: the scan workgroups need
-// 16 free wave slots and most of a CU's LDS at once) and is off the critical path. One wave = one group; the verdict kernel
-// only copies the group's pairs into its column file.
+// The lookups are chains of dependent gathers (DIR-24 / trie levels, membership rows); the kernel needs no LDS and does not depend on
+// the scans, so it runs BESIDE them on the engine's side stream at the lowest wave priority. One wave = one 64-request group; the
+// verdict kernel only copies the group's pairs into its column file.
+//
+// What keeps it short (round 2: it had become the longest kernel, 2.8 GB fetched for 0.38 GB of input):
+//   * everything that is a function of the GeoIP record — country-table bits, asn-set bits and the asn comparisons — is folded at
+//     engine creation into a CLASS row, and records with equal rows share a class (a few hundred classes for 600k records: the
+//     table is cache-resident, class 0 = "no predicate holds" needs no row at all);
+//   * IPv4: ONE gather into a 2^24 x 4-byte table (DIR-24-8, 64 MiB) yields class | membership-set id << 16; prefixes longer than
+//     /24 and oversized ids escape to an 8-byte side table and continue in the 8-bit trie nodes;
+//   * a group's inputs are requested TWO groups ahead and its DIR-24 / root entries ONE group ahead, so the long-latency loads of the
+//     next groups are in flight while the current group's rows are transposed (few waves per CU: nothing else hides them).
+static constexpr uint32_t kMaxRowWords = 8 + 8 + 4 + 4 + 4;  // ip-set, country, port-set, asn-set, asn-comparison words per request
+static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
+
+struct AttrIn {
+    uint32_t ipw[4];
+    uint32_t v6, port, len[5], asn, country;
+};
+
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
+    const bool dir = a.dir24 != nullptr;
     // group-invariant: the first 64 comparison atoms, one per lane (col | code << 24, constant)
     uint32_t h_col = 0, h_c = 0;
     if (lane < a.n_cmp) {
         h_col = a.cmp[lane].col;
         h_c = a.cmp[lane].c;
     }
-    for (uint32_t g = blockIdx.x * 4 + wave; g < a.n_groups; g += gridDim.x * 4) {
+    const uint32_t g_stride = gridDim.x * 4;
+    // stage A: the fixed-width inputs of a group (unconditional loads, clamped indices: no branch, so no wait is forced)
+    auto load_in = [&](const uint32_t g, AttrIn &in) {
+        const uint32_t i0 = g * 64 + lane;
+        const uint32_t i = (g < a.n_groups && i0 < a.n) ? i0 : 0u;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
+        in.ipw[0] = raw.x; in.ipw[1] = raw.y; in.ipw[2] = raw.z; in.ipw[3] = raw.w;
+        in.v6 = a.ip_is_v6[i];
+        in.port = a.port[i];
+#pragma unroll
+        for (int f = 0; f < 5; f++) in.len[f] = a.off[f][i + 1] - a.off[f][i];
+        in.asn = from_row ? 0u : a.asn[i];
+        in.country = from_row ? 0u : (uint32_t)a.country[i];
+    };
+    // stage B: the first trie step of both tries (three unconditional gathers: the DIR-24 entry for IPv4, the two 16-bit roots otherwise)
+    auto load_root = [&](const AttrIn &in, uint32_t &e24, uint32_t &rg, uint32_t &ri) {
+        const bool v6 = in.v6 != 0;
+        const uint32_t top16 = (ip_byte(in.ipw, 0) << 8) | ip_byte(in.ipw, 1);
+        const uint32_t top24 = (top16 << 8) | ip_byte(in.ipw, 2);
+        e24 = dir ? a.dir24[v6 ? 0u : top24] : 0u;
+        rg = (v6 ? a.geo_root6 : a.geo_root4)[top16];  // (the engine substitutes an all-leaf root for a family without prefixes)
+        ri = (v6 ? a.ip_root6 : a.ip_root4)[top16];
+    };
+    AttrIn cur, nxt;
+    uint32_t c_e24, c_rg, c_ri;
+    const uint32_t g0 = blockIdx.x * 4 + wave;
+    load_in(g0, cur);
+    load_in(g0 + g_stride, nxt);
+    load_root(cur, c_e24, c_rg, c_ri);
+
+    for (uint32_t g = g0; g < a.n_groups; g += g_stride) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
         const unsigned long long valid_mask = __ballot(valid);
@@ -1152,78 +1227,53 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             if (has) pairs[n_pairs + (uint32_t)__builtin_popcountll(em & lt_mask)] = make_uint4(c, 0u, lo, hi);
             n_pairs += (uint32_t)__builtin_popcountll(em);
         };
+        const bool v6 = cur.v6 != 0;
+        const uint32_t port = cur.port;
 
-        uint32_t ipw[4] = {0, 0, 0, 0};
-        bool v6 = false;
-        uint32_t port = 0, asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);
-        uint32_t len0 = 0, len1 = 0, len2 = 0, len3 = 0, len4 = 0;
-        if (valid) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
-            ipw[0] = raw.x; ipw[1] = raw.y; ipw[2] = raw.z; ipw[3] = raw.w;
-            v6 = a.ip_is_v6[i] != 0;
-            port = a.port[i];
-            len0 = a.off[0][i + 1] - a.off[0][i];
-            len1 = a.off[1][i + 1] - a.off[1][i];
-            len2 = a.off[2][i + 1] - a.off[2][i];
-            len3 = a.off[3][i + 1] - a.off[3][i];
-            len4 = a.off[4][i + 1] - a.off[4][i];
-        }
-        // The two radix tries (GeoIP record, ip-list membership set) are walked TOGETHER, level by level, so that their
-        // dependent loads overlap instead of queueing behind each other.
+        // ---- 1. finish the trie walks (GeoipDB::lookup, pingoo/geoip.rs:73-91: loopback / multicast are "not found") ----
         bool geo_walk = false;
-        if (valid && !from_row) {
-            asn = a.asn[i];
-            country = a.country[i];
-        } else if (valid && a.has_geo) {
-            // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
+        if (valid && from_row && a.has_geo) {
             if (!v6) {
-                const uint32_t b0 = ipw[0] & 0xFFu;
+                const uint32_t b0 = cur.ipw[0] & 0xFFu;
                 geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
             } else {
-                const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
-                geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
+                const bool loopback = cur.ipw[0] == 0 && cur.ipw[1] == 0 && cur.ipw[2] == 0 && cur.ipw[3] == 0x01000000u;
+                geo_walk = !(loopback || (cur.ipw[0] & 0xFFu) == 0xFFu);
             }
         }
-        uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;  // leaf 0: no record / member of nothing
-        if (valid) {
-            uint32_t k = 2;
-            if (!v6 && a.dir24 != nullptr) {
-                // IPv4: ONE gather into the 2^24-entry table that flattens the first three levels of BOTH tries (DIR-24-8: sized
-                // for HBM, not for a cache). Prefixes longer than /24 leave a node index and continue below.
-                const unsigned long long e = a.dir24[(ip_byte(ipw, 0) << 16) | (ip_byte(ipw, 1) << 8) | ip_byte(ipw, 2)];
-                if (geo_walk) eg = (uint32_t)e;
-                ei = (uint32_t)(e >> 32);
-                k = 3;
+        uint32_t eg = c_rg, ei = c_ri, k = 2;
+        if (!v6 && dir) {
+            k = 3;
+            if (c_e24 & DIR_ESCAPE) {  // a prefix longer than /24 (or an id too large for the packed entry): rare
+                const uint2 esc = a.dir_esc[c_e24 & ~DIR_ESCAPE];
+                eg = esc.x;
+                ei = esc.y;
             } else {
-                const uint32_t *groot = v6 ? a.geo_root6 : a.geo_root4, *iroot = v6 ? a.ip_root6 : a.ip_root4;
-                const uint32_t top = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
-                if (geo_walk && groot != nullptr) eg = groot[top];
-                if (a.n_ip_lists && iroot != nullptr) ei = iroot[top];
-            }
-            for (; !((eg & ei) & TRIE_LEAF); k++) {
-                const uint32_t byte = ip_byte(ipw, k);
-                const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
-                const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
-                eg = ng;
-                ei = ni;
+                eg = TRIE_LEAF | (c_e24 & 0xFFFFu);
+                ei = TRIE_LEAF | (c_e24 >> 16);
             }
         }
-        const uint32_t geo_rec = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
+        if (!geo_walk) eg = TRIE_LEAF | a.geo_default;  // no lookup: the default record's class
+        if (!valid || a.n_ip_lists == 0) ei = TRIE_LEAF;
+        for (; !((eg & ei) & TRIE_LEAF); k++) {
+            const uint32_t byte = ip_byte(cur.ipw, k);
+            const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
+            const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
+            eg = ng;
+            ei = ni;
+        }
+        const uint32_t cls = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
 
-        // Membership rows: per GeoIP record the engine has precomputed everything that depends on (asn, country); a batch that
-        // brings its own asn / country columns uses the per-country rows and the asn-set rows instead. Integer sets: ONE binary
-        // search per request over the union of every set tested against the variable; the hit's row says which sets contain
-        // the value (the reference scans each list per rule: pingoo/lists.rs:119-121).
-        uint32_t r_geo = geo_rec;
+        // ---- 2. membership rows: every row word of the request requested together, then ONE wait ----
+        uint32_t asn = cur.asn, r_geo = 0;
         if (!from_row) {
-            const uint32_t c0 = (country & 0xFFu) - 'A', c1 = (country >> 8) - 'A';
+            const uint32_t c0 = (cur.country & 0xFFu) - 'A', c1 = (cur.country >> 8) - 'A';
             r_geo = (c0 < 26u && c1 < 26u) ? c0 * 26u + c1 : 23u * 26u + 23u;  // invalid input is treated as "XX"
         }
-        const uint32_t *grow = from_row ? a.geo_rows + (size_t)r_geo * a.geo_row_words + 2 : a.country_masks + (size_t)r_geo * a.cc_words;
-        if (valid && from_row) asn = grow[-2];
         uint32_t r_int[2] = {0, 0};
 #pragma unroll
         for (int var = 0; var < 2; var++) {
+            // integer sets: ONE binary search per request over the union of every set tested against the variable
             if (!valid || a.iu_n[var] == 0 || (var == 1 && from_row)) continue;
             const long long v = var == VAR_PORT ? (long long)port : (long long)asn;
             uint32_t lo = 0, hi = a.iu_n[var];
@@ -1234,36 +1284,55 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             }
             if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) r_int[var] = lo + 1;
         }
-        const uint32_t *arow = from_row ? grow + a.cc_words : a.iu_masks[1] + (size_t)r_int[1] * a.iu_words[1];
-        const uint32_t *prow = a.iu_masks[0] + (size_t)r_int[0] * a.iu_words[0];
+        // sources: [0,8) ip-set row, [8,16) country words, [16,20) port-set row, [20,24) asn-set words, [24,28) asn comparisons
         const uint32_t *srow = a.set_masks + (size_t)set_id * a.set_words;
+        const uint32_t *crow = from_row ? a.class_rows + (size_t)cls * a.class_words : a.country_masks + (size_t)r_geo * a.cc_words;
+        const uint32_t *prow = a.iu_masks[0] + (size_t)r_int[0] * a.iu_words[0];
+        const uint32_t *arow = from_row ? crow + a.cc_words : a.iu_masks[1] + (size_t)r_int[1] * a.iu_words[1];
+        const uint32_t *qrow = crow + a.cc_words + a.iu_words[1];
+        const bool have_s = valid && a.n_ip_lists && set_id, have_c = valid && (from_row ? cls != 0 : true), have_p = valid && r_int[0],
+                   have_a = valid && (from_row ? cls != 0 : r_int[1] != 0), have_q = valid && from_row && cls != 0;
+        uint32_t rw[kMaxRowWords];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) rw[q] = (q < a.set_words && have_s) ? srow[q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) rw[8 + q] = (q < a.cc_words && have_c) ? crow[q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) rw[16 + q] = (q < a.iu_words[0] && have_p) ? prow[q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) rw[20 + q] = (q < a.iu_words[1] && have_a) ? arow[q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) rw[24 + q] = (q < a.acmp_words && have_q) ? qrow[q] : 0u;
 
-        // A membership word is transposed in registers: one ballot per bit that ANY of the 64 requests has set (wave-wide OR
-        // first, so absent bits cost nothing); lane b keeps bit b's request mask and owns that atom's pair.
-        auto member_words = [&](const uint32_t *row, const bool have, const uint32_t words, const uint32_t src0) {
-            for (uint32_t wv = 0; wv < words; wv++) {
-                const uint32_t w = have ? row[wv] : 0u;
-                const uint32_t orw0 = wave_or(w);
-                if (orw0 == 0) continue;
-                unsigned long long mine_m = 0;
-                for (uint32_t orw = orw0; orw; orw &= orw - 1) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(orw);
-                    const unsigned long long m = __ballot((w >> b) & 1u);
-                    if (lane == b) mine_m = m;
-                }
-                const bool owner = lane < 32 && ((orw0 >> lane) & 1u);
-                const uint32_t c = owner ? a.bit_col[(src0 + wv) * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
-                emit_pairs(c != 0, c, (uint32_t)mine_m, (uint32_t)(mine_m >> 32));
+        // ---- 3. prefetch: inputs of the group after next, first trie step of the next group ----
+        AttrIn nn;
+        load_in(g + 2 * g_stride, nn);
+        uint32_t n_e24, n_rg, n_ri;
+        load_root(nxt, n_e24, n_rg, n_ri);
+
+        // ---- 4. transposes: one ballot per bit that ANY of the 64 requests has set (wave-wide OR first, so absent bits cost
+        //         nothing); lane b keeps bit b's request mask and owns that atom's pair ----
+#pragma unroll
+        for (uint32_t q = 0; q < kMaxRowWords; q++) {
+            const uint32_t words = q < 8 ? a.set_words : q < 16 ? a.cc_words + 8 : q < 20 ? a.iu_words[0] + 16 : q < 24 ? a.iu_words[1] + 20 : a.acmp_words + 24;
+            if (q >= words) continue;  // (uniform)
+            const uint32_t w = rw[q];
+            const uint32_t orw0 = wave_or(w);
+            if (orw0 == 0) continue;
+            unsigned long long mine_m = 0;
+            for (uint32_t orw = orw0; orw; orw &= orw - 1) {
+                const uint32_t b = (uint32_t)__builtin_ctz(orw);
+                const unsigned long long m = __ballot((w >> b) & 1u);
+                if (lane == b) mine_m = m;
             }
-        };
-        member_words(srow, valid && a.n_ip_lists && set_id, a.set_words, 0);
-        member_words(grow, valid, a.cc_words, 8);
-        member_words(prow, valid && r_int[0], a.iu_words[0], 16);
-        member_words(arow, valid && (from_row || r_int[1]), a.iu_words[1], 20);
+            const bool owner = lane < 32 && ((orw0 >> lane) & 1u);
+            const uint32_t c = owner ? a.bit_col[q * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
+            emit_pairs(c != 0, c, (uint32_t)mine_m, (uint32_t)(mine_m >> 32));
+        }
 
         // Comparison atoms (lengths, port, asn against constants): the engine has reduced them to `v == c` / `v <= c` on 32-bit
         // values and tagged each with code = 2 * variable + operator; an atom is a scalar broadcast of its constant, one
-        // vector compare and a ballot parked in the atom's lane.
+        // vector compare and a ballot parked in the atom's lane. (asn comparisons of engine-resolved records are class-row bits.)
         for (uint32_t base = 0; base < a.n_cmp; base += 64) {
             uint32_t m_col = h_col, m_c = h_c;
             if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
@@ -1289,38 +1358,49 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                     }
                 }
             };
-            cmp_var(len0, 0);
-            cmp_var(len1, 1);
-            cmp_var(len2, 2);
-            cmp_var(len3, 3);
-            cmp_var(len4, 4);
+            cmp_var(cur.len[0], 0);
+            cmp_var(cur.len[1], 1);
+            cmp_var(cur.len[2], 2);
+            cmp_var(cur.len[3], 3);
+            cmp_var(cur.len[4], 4);
             cmp_var(port, 5);
-            cmp_var(asn, 6);
+            if (!from_row) cmp_var(asn, 6);
             emit_pairs((acc_lo | acc_hi) != 0, m_col & 0xFFFFFFu, acc_lo, acc_hi);
         }
         if (lane == 0) a.ghdr[g] = n_pairs;
+        cur = nxt;
+        nxt = nn;
+        c_e24 = n_e24;
+        c_rg = n_rg;
+        c_ri = n_ri;
     }
 }
 
-// Flattens the first 24 bits of the GeoIP trie and the ip-list trie (IPv4 family) into one table of {geo entry, set entry}: an
-// entry is a leaf (TRIE_LEAF | value) or, for prefixes longer than /24, the index of the node that continues the walk.
-__global__ __launch_bounds__(256) void dir24_kernel(VerdictArgs a, unsigned long long *out) {
+// Flattens the first 24 bits of the GeoIP trie (leaves = class ids) and the ip-list trie (leaves = membership-set ids), IPv4 family,
+// into one table of 4-byte entries: class | set << 16 when both walks end within 24 bits with ids that fit (class < 65536,
+// set < 32768), otherwise DIR_ESCAPE | index of an 8-byte {geo entry, set entry} pair from which the attribute kernel continues.
+// Two launches: `esc == nullptr` only counts the escapes.
+__global__ __launch_bounds__(256) void dir24_kernel(VerdictArgs a, uint32_t *out, uint2 *esc, uint32_t *esc_count) {
     const uint32_t x = blockIdx.x * 256 + threadIdx.x;  // the top 24 address bits
     if (x >= (1u << 24)) return;
-    uint32_t eg = TRIE_LEAF, ei = TRIE_LEAF;
-    if (a.has_geo && a.geo_root4 != nullptr) {
-        eg = a.geo_root4[x >> 8];
-        if (!(eg & TRIE_LEAF)) eg = a.geo_nodes[(size_t)eg * 256 + (x & 0xFFu)];
+    uint32_t eg = a.geo_root4[x >> 8];
+    if (!(eg & TRIE_LEAF)) eg = a.geo_nodes[(size_t)eg * 256 + (x & 0xFFu)];
+    uint32_t ei = a.ip_root4[x >> 8];
+    if (!(ei & TRIE_LEAF)) ei = a.ip_nodes[(size_t)ei * 256 + (x & 0xFFu)];
+    const uint32_t vg = eg & ~TRIE_LEAF, vi = ei & ~TRIE_LEAF;
+    if ((eg & ei & TRIE_LEAF) && vg < 65536u && vi < 32768u) {
+        if (out) out[x] = vg | (vi << 16);
+        return;
     }
-    if (a.n_ip_lists && a.ip_root4 != nullptr) {
-        ei = a.ip_root4[x >> 8];
-        if (!(ei & TRIE_LEAF)) ei = a.ip_nodes[(size_t)ei * 256 + (x & 0xFFu)];
+    const uint32_t idx = atomicAdd(esc_count, 1u);
+    if (esc) {
+        esc[idx] = make_uint2(eg, ei);
+        out[x] = DIR_ESCAPE | idx;
     }
-    out[x] = (unsigned long long)eg | ((unsigned long long)ei << 32);
 }
 
-int launch_dir24(const VerdictArgs &a, void *out, void *stream) {
-    hipLaunchKernelGGL(dir24_kernel, dim3((1u << 24) / 256), dim3(256), 0, (hipStream_t)stream, a, (unsigned long long *)out);
+int launch_dir24(const VerdictArgs &a, void *out, void *esc, void *esc_count, void *stream) {
+    hipLaunchKernelGGL(dir24_kernel, dim3((1u << 24) / 256), dim3(256), 0, (hipStream_t)stream, a, (uint32_t *)out, (uint2 *)esc, (uint32_t *)esc_count);
     return (int)hipGetLastError();
 }
 
@@ -1388,7 +1468,6 @@ int configure_kernels(int device) {
     const void *fns[] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
                          reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
-                         reinterpret_cast<const void *>(gscan_kernel<true>), reinterpret_cast<const void *>(gscan_kernel<false>),
                          reinterpret_cast<const void *>(verdict_kernel<true>), reinterpret_cast<const void *>(verdict_kernel<false>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);

@@ -79,6 +79,11 @@ struct Atom {
 // through the pass's DFA, which decides exactly. The filter is conservative by construction (a factor is necessary for
 // a match; extra positions past a field's end can only add candidates), so verdicts never depend on it.
 static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
+// Bigrams are sampled at every kFilterStride-th byte of a field (counted from its first byte); a factor is entered once per
+// alignment it can have relative to the sampling grid. Stride 2 halves the lookups per input byte (the filter kernel is bound by
+// LDS gathers: 6.3 LDS cycles per wave lookup, two thirds of them bank conflicts) at the price of windows that span up to 8 bytes:
+// factors shorter than 3 bytes cannot be filtered and 3-4 byte factors contribute a single position.
+static constexpr uint32_t kFilterStride = 1;  // (2 was tried: a 3-byte factor such as "../" then owns a single position and floods the candidates)
 static constexpr uint32_t kFilterMul = 0x9E37u;  // 16-bit multiplicative hash of the folded byte pair (v_pk_mul_lo_u16 on the device)
 static inline uint32_t filter_bin(uint8_t b0, uint8_t b1) {
     const uint32_t p = (uint32_t)(b0 & 0xDFu) | ((uint32_t)(b1 & 0xDFu) << 8);  // bit 5 cleared: ASCII case folding

@@ -90,7 +90,7 @@ class Tables:
                 self.geo_recs = np.frombuffer(pl, dtype=GREC_DTYPE)
 
     # --- pieces ---
-    FILTER_MUL = 0x9E37
+    FILTER_MUL, FILTER_STRIDE = 0x9E37, 1
 
     @classmethod
     def filter_bin(cls, b0: int, b1: int) -> int:
@@ -100,7 +100,7 @@ class Tables:
         """The bigram prefilter of a pass exactly as filter_kernel applies it to the bytes of ONE field value (the device also
         looks at a few bytes past the end, which can only flag more requests)."""
         st, tab = g["f_init"], g["f_table"]
-        for i in range(len(data) - 1):
+        for i in range(0, len(data) - 1, self.FILTER_STRIDE):
             st = ((st << 8) | int(tab[self.filter_bin(data[i], data[i + 1])])) & 0xFFFFFFFF
             if (~st) & 0xFF000000:
                 return True

@@ -10,40 +10,40 @@ from pingoo_amd.engine import CompiledProgram
 from synth import pysynth
 import table_walker
 
+STRIDE = 1
+
+
 def candidates(g, data, off):
-    """vectorised over one field arena: returns bool per request"""
-    n = len(off) - 1
+    """numpy model of filter_kernel over one field arena (bigrams sampled every STRIDE bytes from each field's start): bool per request"""
     d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
     p = d[:-1] | (d[1:] << 8)
     bins = ((p * 0x9E37) & 0xFFFF) >> 4
     m = g["f_table"][bins].astype(np.uint64)
-    # state after position i = OR_{j<4} (m[i-j] << 8j) restricted to the field; emulate with field-local shifts
-    pos = np.arange(len(m))
-    start = np.repeat(off[:-1], np.diff(off))  # field start per byte
-    start = start[: len(m)] if len(start) >= len(m) else np.concatenate([start, np.full(len(m) - len(start), off[-1])])
-    top = (m >> 24) & 0xFF
+    L = len(m)
+    pos = np.arange(L)
+    lens = np.diff(off)
+    start = np.repeat(off[:-1], lens)[:L]
+    endb = np.repeat(off[1:], lens)[:L]
+    if len(start) < L:
+        start = np.concatenate([start, np.full(L - len(start), off[-1])])
+        endb = np.concatenate([endb, np.full(L - len(endb), off[-1])])
+    t = (pos - start) // STRIDE  # sampled step index inside the field
+    sampled = ((pos - start) % STRIDE == 0) & ((pos + 1) < endb)
     init = int(g["f_init"])
+    top = (m >> 24) & 0xFF
     for j in range(1, 4):
-        shifted = np.concatenate([np.zeros(j, dtype=np.uint64), m[:-j]])
+        sh = j * STRIDE
+        shifted = np.concatenate([np.zeros(sh, dtype=np.uint64), m[:-sh]])
         contrib = (shifted >> (8 * (3 - j))) & 0xFF
-        inside = (pos - j) >= start
-        initb = (init >> (8 * (3 - j) + 0)) & 0xFF if True else 0
-        # before the field start the state comes from init: byte (3 - j + (pos-start)) ... handled approximately: init bits of
-        # position (3 - (pos - start) - 1 ...) -- use exact formula below
-        top |= np.where(inside, contrib, 0)
-    # exact init contribution: after t+1 steps inside the field (t = pos - start), init << 8(t+1) contributes its byte (3 - (t+1)) to the top
-    t = pos - start
-    for tt in range(0, 3):
+        top |= np.where(t >= j, contrib, 0).astype(np.uint64)
+    for tt in range(0, 3):  # the field's first steps still see the initial state
         ib = (init >> (8 * (3 - (tt + 1)))) & 0xFF
         top |= np.where(t == tt, ib, 0).astype(np.uint64)
-    hit = (top & 0xFF) != 0xFF
-    # valid positions: i and i+1 inside the same field
-    endb = np.repeat(off[1:], np.diff(off))
-    endb = endb[: len(m)] if len(endb) >= len(m) else np.concatenate([endb, np.full(len(m) - len(endb), off[-1])])
-    hit &= (pos + 1) < endb
+    hit = ((top & 0xFF) != 0xFF) & sampled
     csum = np.concatenate([[0], np.cumsum(hit)])
-    o = np.minimum(off, len(m))
+    o = np.minimum(off, L)
     return (csum[o[1:]] - csum[o[:-1]]) > 0
+
 
 def main():
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
