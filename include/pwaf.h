@@ -158,7 +158,7 @@ typedef struct pwaf_batch {
     uint32_t struct_size; /* sizeof(pwaf_batch) */
     uint32_t n;
     uint32_t memory; /* PWAF_MEM_HOST | PWAF_MEM_DEVICE: where EVERY pointer below lives */
-    uint32_t reserved;
+    uint32_t n_headers; /* header columns below (extension, see `headers`); 0 = none */
     pwaf_strcol field[PWAF_N_FIELDS];
     const uint8_t *ip;       /* n x 16; IPv4 in bytes 0..3 (network order), rest ignored  */
     const uint8_t *ip_is_v6; /* n                                                        */
@@ -168,6 +168,16 @@ typedef struct pwaf_batch {
      * own table on the device, or uses {0,"XX"} if it has none (geoip.rs:111-118). */
     const uint32_t *asn;     /* n */
     const uint16_t *country; /* n; two bytes 'A'..'Z' in memory order */
+    /* Byte size of each field arena (= offsets[n]). The bigram prefilter streams an arena as one flat byte range, so the launch
+     * geometry depends on it. HOST batches: ignored (read from the offsets). DEVICE batches: the caller that built the arenas
+     * knows it; 0 = unknown, the engine then reads offsets[n] back with one small synchronous copy per evaluate call. */
+    uint32_t field_bytes[PWAF_N_FIELDS];
+    uint32_t reserved;
+    /* EXTENSION (no reference counterpart: pingoo/rules.rs:16-25 exposes no headers — BASELINE.json configs[4]):
+     * one string column per header name the rule set mentions as http_request.headers["name"], in the order of
+     * pwaf_engine_header_name(); a request without the header carries the empty string. */
+    const pwaf_strcol *headers;    /* n_headers columns, same memory as everything else */
+    const uint32_t *header_bytes;  /* n_headers arena sizes (HOST memory, same rule as field_bytes), or NULL */
 } pwaf_batch;
 
 typedef struct pwaf_verdict {

@@ -89,7 +89,7 @@ class Batch(C.Structure):
         ("struct_size", C.c_uint32),
         ("n", C.c_uint32),
         ("memory", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("n_headers", C.c_uint32),
         ("field", StrCol * N_FIELDS),
         ("ip", C.c_void_p),
         ("ip_is_v6", C.c_void_p),
@@ -97,6 +97,10 @@ class Batch(C.Structure):
         ("flags", C.c_void_p),
         ("asn", C.c_void_p),
         ("country", C.c_void_p),
+        ("field_bytes", C.c_uint32 * N_FIELDS),
+        ("reserved", C.c_uint32),
+        ("headers", C.POINTER(StrCol)),
+        ("header_bytes", C.POINTER(C.c_uint32)),
     ]
 
 

@@ -112,7 +112,7 @@ struct pwaf_engine {
     std::mutex mu;
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
     DevBuf colmask, gate_lists, attr, dir24;
-    DevBuf cand_sub, cand_cnt;  // filter_kernel's per-slab candidate regions and counts
+    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
     DevBuf need;                // per sharing owner: gap-pass mask of every entry of its candidate list
     uint32_t n_need = 0;
     uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
@@ -364,7 +364,7 @@ int assign_lists(pwaf_engine *e) {
 }
 
 int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
-                 uint32_t *d_n_matches, hipStream_t stream) {
+                 uint32_t *d_n_matches, hipStream_t stream, bool totals_known = false) {
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
@@ -581,13 +581,36 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark(nm, (uint64_t)d.field))) return rc;  // alg_bytes slot carries the field id; bench.py supplies bytes
     }
-    // ---- 2. bigram prefilters of every filtered pass in one launch, then the compaction of their candidate lists ----
+    // ---- 2. bigram prefilters of every filtered pass in one launch (the arenas as flat byte streams), hit segments -> candidate
+    //         bitmaps, bitmaps -> dense request lists ----
     if (e->n_filtered) {
-        const uint32_t n_slabs = (n + kFilterSlab - 1) / kFilterSlab;
-        if ((rc = e->cand_sub.reserve((size_t)e->n_filtered * n * 4))) return rc;
-        if ((rc = e->cand_cnt.reserve((size_t)e->n_filtered * n_slabs * 4))) return rc;
+        // arena sizes: a host batch's offsets were read while staging; a device batch says so itself or is asked (one small copy)
+        uint32_t totals[PWAF_N_FIELDS];
+        bool ask = false;
+        for (int f = 0; f < PWAF_N_FIELDS; f++) {
+            totals[f] = db.field_bytes[f];
+            if (!totals[f] && !totals_known) ask = true;
+        }
+        if (ask) {
+            for (int f = 0; f < PWAF_N_FIELDS; f++)
+                if (!totals[f]) HIP_TRY(hipMemcpyAsync(&totals[f], db.field[f].offsets + n, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        const uint32_t words = (n + 31) / 32, n_cblocks = (words + kCompactWords - 1) / kCompactWords;
+        uint64_t sub_entries = 0, n_slabs_all = 0;
+        for (const DevGroup &d : e->groups)
+            if (d.filtered) {
+                const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab;
+                n_slabs_all += slabs;
+                sub_entries += slabs * (kStreamSlab / kStreamSeg);
+            }
+        if ((rc = e->cand_sub.reserve((size_t)sub_entries * 4))) return rc;
+        if ((rc = e->cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
+        if ((rc = e->cand_bits.reserve((size_t)e->n_filtered * words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(e->cand_bits.p, 0, (size_t)e->n_filtered * words * 4, stream));
         FilterBatchArgs fb{};
         uint32_t fi = 0, block = 0, field_mask = 0;
+        uint64_t sub_at = 0, cnt_at = 0;
         auto flush_filters = [&]() -> int {
             if (fb.count == 0) return PWAF_OK;
             int rc2;
@@ -596,9 +619,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc2 = mark("filter", 0x100u | field_mask))) return rc2;  // alg_bytes slot: 0x100 | mask of the fields streamed
             if ((rc2 = mark(nullptr, 0))) return rc2;
-            he = launch_compact(fb, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc2 = mark("compact", 0xFCu))) return rc2;
+            he = launch_resolve(fb, stream);
+            if (!he) he = launch_compact(fb, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc2 = mark("resolve+compact", 0xFCu))) return rc2;
             fb.count = 0;
             block = 0;
             field_mask = 0;
@@ -612,6 +636,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             f.data = db.field[d.field].data;
             f.off = db.field[d.field].offsets;
             f.n = n;
+            f.total = totals[d.field];
             f.init = d.filter.init;
             f.table = (const uint32_t *)d.ftable.p;
             f.n_heads = (uint32_t)std::min<size_t>(2, d.filter.heads.size());
@@ -625,13 +650,18 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
                 f.head_len[h] = fh.len | ((uint32_t)fh.exact << 8);
                 f.head_code[h] = h == 0 ? (uint32_t)fh.local + 1u : ((uint32_t)fh.local + 1u) << 15;
             }
+            const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab);
             f.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
-            f.sub = (uint32_t *)e->cand_sub.p + (size_t)fi * n;
-            f.sub_count = (uint32_t *)e->cand_cnt.p + (size_t)fi * n_slabs;
+            f.sub = (uint32_t *)e->cand_sub.p + sub_at;
+            f.sub_count = (uint32_t *)e->cand_cnt.p + cnt_at;
+            f.block_count = f.sub_count + slabs;
+            f.bitmap = (uint32_t *)e->cand_bits.p + (size_t)fi * words;
             f.list = (uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)e->ctrl.p + 2 + d.gate;
             f.first_block = block;
-            block += (n_slabs + kFilterWaves - 1) / kFilterWaves;
+            sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
+            cnt_at += slabs + n_cblocks;
+            block += (slabs + kFilterWaves - 1) / kFilterWaves;
             field_mask |= 1u << d.field;
             fi++;
             if (fb.count == kMaxFiltersPerLaunch && (rc = flush_filters())) return rc;
@@ -1029,7 +1059,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->need, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->cand_bits, &e->need, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
@@ -1111,6 +1141,7 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         HIP_TRY(hipMemcpyAsync(e->stage_field_off[f].p, o, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
         db.field[f].data = (const uint8_t *)e->stage_field_data[f].p;
         db.field[f].offsets = (const uint32_t *)e->stage_field_off[f].p;
+        db.field_bytes[f] = (uint32_t)hi;
     }
     auto stage = [&](DevBuf &b, const void *src, size_t bytes, const void **dst) -> int {
         int r = b.reserve(bytes);
@@ -1130,7 +1161,7 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     if ((rc = e->stage_out.reserve((size_t)n * sizeof(pwaf_verdict)))) return rc;
     if ((rc = e->stage_counts.reserve(sizeof(pwaf_counts)))) return rc;
     HIP_TRY(hipMemsetAsync(e->stage_counts.p, 0, sizeof(pwaf_counts), s));
-    rc = run_pipeline(e, db, (pwaf_verdict *)e->stage_out.p, (pwaf_counts *)e->stage_counts.p, nullptr, nullptr, s);
+    rc = run_pipeline(e, db, (pwaf_verdict *)e->stage_out.p, (pwaf_counts *)e->stage_counts.p, nullptr, nullptr, s, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, e->stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
     if (counts) HIP_TRY(hipMemcpyAsync(counts, e->stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));

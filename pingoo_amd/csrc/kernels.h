@@ -97,17 +97,28 @@ struct ListScanArgs {
 };
 
 // ---- bigram prefilter (program.h: GroupFilter) ------------------------------------------------------------------------------
-// Work unit = one SLAB of kFilterSlab consecutive requests, walked by one wave (lanes pull the slab's requests one after the
-// other). The slab's candidates are appended to its own region of `sub` (sub[slab * kFilterSlab + k]) with a wave-private counter
-// — no atomics — and compact_kernel then concatenates the regions into the dense request list the confirming DFA pass walks.
-static constexpr uint32_t kFilterSlab = 2048;
-static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup: 7 workgroups per CU at 67 VGPRs
+// The shift-or state only remembers the last four bigrams, so a field's arena is processed as ONE flat byte stream: a wave takes a
+// slab of kStreamSlab consecutive bytes and walks it kStreamIter bytes per iteration — every lane its own aligned 64-byte segment
+// (plus three warm-up bigrams from the bytes before it) — with no per-request logic at all in the loop: loads are perfectly
+// coalesced (every line is fetched exactly once; the per-request-lane version fetched 2x the arena because 7 MB of half-consumed
+// lines per XCD thrashed L2), no lane ever idles, and a window that straddles a request boundary can only ADD a candidate.
+//   filter_kernel   per (segment, 16-byte chunk) a hit bit; non-zero segments are appended to the slab's own region of `sub`
+//                   (wave-private counter: no atomics). Heads (anchored literals) are compared at request starts, which the wave
+//                   finds by walking the offsets column alongside the bytes.
+//   resolve_kernel  hit segments -> requests (binary search in the offsets), one bit per request in `bitmap`.
+//   bitcount_kernel / compact_kernel   bitmap -> dense ascending request list + its length for the confirming lscan_kernel.
+static constexpr uint32_t kStreamSlab = 128 * 1024;   // bytes per wave
+static constexpr uint32_t kStreamSeg = 64;            // bytes per lane and iteration
+static constexpr uint32_t kStreamIter = 64 * kStreamSeg;
+static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup
 static constexpr uint32_t kMaxFiltersPerLaunch = 8;
+static constexpr uint32_t kCompactWords = 2048;       // bitmap words per compact workgroup (65536 requests)
 struct FilterArgs {
     const uint8_t *data;
     const uint32_t *off;
     uint32_t n;
-    uint32_t init;            // state at the start of a field
+    uint32_t total;           // bytes in the arena (= off[n])
+    uint32_t init;            // state of a stream with no history
     const uint32_t *table;    // kFilterEntries masks
     uint32_t n_heads;
     uint32_t head_w[2][4];    // head literal, little-endian dwords
@@ -115,18 +126,21 @@ struct FilterArgs {
     uint32_t head_len[2];     // length | exact << 8
     uint32_t head_code[2];    // hit-record bits of the head's atom
     uint32_t *rec;            // n hit records of the pass, zeroed by the host: written only where a head holds
-    uint32_t *sub;            // n: candidate sub-lists, one region per slab
+    uint32_t *sub;            // hit segments: slab s owns sub[s * (kStreamSlab / kStreamSeg) ...]; entry = segment index in the slab << 4 | chunk mask
     uint32_t *sub_count;      // [slabs]
-    uint32_t *list;           // n: dense candidate list (compact_kernel)
+    uint32_t *bitmap;         // [(n + 31) / 32], zeroed by the host: candidate requests
+    uint32_t *block_count;    // [(words + kCompactWords - 1) / kCompactWords]: candidates per compact workgroup
+    uint32_t *list;           // n: dense candidate list
     uint32_t *list_count;     // its length
-    uint32_t first_block;     // first workgroup of this pass in the fused launch
+    uint32_t first_block;     // first workgroup of this pass in the fused filter launch
 };
 struct FilterBatchArgs {
     FilterArgs f[kMaxFiltersPerLaunch];
     uint32_t count;
 };
 int launch_filter(const FilterBatchArgs &b, void *stream);
-int launch_compact(const FilterBatchArgs &b, void *stream);
+int launch_resolve(const FilterBatchArgs &b, void *stream);
+int launch_compact(const FilterBatchArgs &b, void *stream);  // bitcount_kernel, then compact_kernel
 // Sets the dynamic-LDS limit of every kernel on the CURRENT device (once per device and process; engines on several
 // devices of one process each need it).
 int configure_kernels(int device);

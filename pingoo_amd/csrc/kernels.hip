@@ -526,19 +526,23 @@ int launch_scan_gated(const GatedArgs &b, void *stream) {
 // -------------------------------------------------------------------------------------------------
 // bigram prefilter
 // -------------------------------------------------------------------------------------------------
-// filter_kernel: the launch that streams the request bytes. For every byte position of a field ONE independent LDS lookup —
-// table[hash(fold(b[i]), fold(b[i+1]))] — and two vector ops: state = (state << 8) | mask, seen &= state. Nothing on the
-// per-byte path depends on a previous lookup (the DFA walk it replaces chains v_lshl_add -> ds_read_u16 per byte plus a class
-// lookup), so the kernel is bound by LDS gather throughput and HBM streaming, not by LDS latency. A zero bit in the top byte of
-// `seen` at the end of a field = "some position completed a window of some bucket": the request is a CANDIDATE and is walked by
-// the pass's DFA afterwards (lscan_kernel); every other request provably matches no pattern of the pass. Positions past a field's
-// end (and across a chunk fetched for the next request) are not masked: extra positions can only flag more candidates.
+// filter_kernel: the launch that streams the request bytes (kernels.h: the arena as one flat byte stream). Per input byte ONE
+// independent LDS lookup — table[hash(fold(b[i]), fold(b[i+1]))] — and two vector ops: state = (state << 8) | mask, seen &= state.
+// Nothing on the per-byte path depends on a previous lookup (the DFA walk it replaces chains v_lshl_add -> ds_read_u16 per byte plus
+// a class lookup) and nothing depends on where requests begin or end. A zero bit in the top byte of `seen` after a 16-byte chunk =
+// "some position of the chunk completed a window of some bucket"; the requests overlapping such chunks become CANDIDATES and are
+// walked by the pass's DFA afterwards (lscan_kernel); every other request provably matches no pattern of the pass.
 //
 // Hash of a position = top 12 bits of the 16-bit product fold(pair) * kFilterMul: two positions per v_pk_mul_lo_u16; the table's
 // byte offset is (product >> 2) & 0x3FFC.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-template <int CH>
+struct Segment {
+    u32x4 w[4];
+    uint32_t prev, next;
+};
+
+template <bool HEADS>
 __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchArgs B) {
     extern __shared__ __align__(16) unsigned char lds[];
     __builtin_amdgcn_s_setprio(3);
@@ -556,215 +560,258 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
     // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
     const uint32_t slab = (blockIdx.x - a.first_block) * kFilterWaves + wave;
-    const uint64_t w0_64 = (uint64_t)slab * kFilterSlab;
-    if (w0_64 >= a.n) return;
-    const uint32_t w0 = (uint32_t)w0_64, w1 = min(a.n, w0 + kFilterSlab), n_items = a.n;
+    const uint64_t base64 = (uint64_t)slab * kStreamSlab;
+    if (base64 >= a.total) return;
+    const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
     const unsigned long long lt_mask = (1ull << lane) - 1;
-    uint32_t *my_sub = a.sub + w0;
-    uint32_t n_cand = 0;  // wave-uniform
-
-    uint32_t next = w0, blk = w0;
-    auto load_off = [&](uint32_t base, uint32_t &lo, uint32_t &hi) {
-        const uint32_t i = min(base + lane, n_items - 1);
-        lo = goff[i];
-        hi = goff[i + 1];
-    };
-    uint32_t o_lo, o_hi, n_lo = 0, n_hi = 0, n_base = kNone;
-    load_off(blk, o_lo, o_hi);
-    uint32_t r = kNone, p = 0, end = 0, r2 = kNone, p2 = 0, end2 = 0;
-    uint32_t st = a.init, seen = 0xFFFFFFFFu, hrec = 0;
-    bool first = false;
-    u32x4 w[CH], wn[CH];
-#pragma unroll
-    for (int q = 0; q < CH; q++) w[q] = wn[q] = u32x4{0, 0, 0, 0};
-    constexpr uint32_t kStep = 16u * CH;
+    uint32_t *my_sub = a.sub + (size_t)slab * (kStreamSlab / kStreamSeg);
+    uint32_t n_hit = 0;  // wave-uniform
     const uint32_t mul2 = kFilterMul | (kFilterMul << 16);
 
-    for (;;) {
-        uint32_t f_lo, f_hi;
-        const uint32_t f_base = blk + 64;
-        load_off(f_base, f_lo, f_hi);
-        // ---- 1. lanes on their last chunk (or idle) pull the next request of the slab (as scan_body) ----
-        const bool last = r == kNone || p + kStep >= end;
-        const unsigned long long want = __ballot(last && r2 == kNone);
-        if (want != 0 && next < w1) {
-            const uint32_t avail = min(w1 - next, blk + 64 - next);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(want & lt_mask);
-            const bool take = last && r2 == kNone && rank < avail;
-            const uint32_t j = take ? next + rank - blk : 0;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_lo);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)o_hi);
-            if (take) {
-                r2 = next + rank;
-                p2 = lo;
-                end2 = hi;
-            }
-            next += min((uint32_t)__builtin_popcountll(want), avail);
-            if (next == blk + 64 && next < w1) {
-                blk += 64;
-                if (n_base == blk) {
-                    o_lo = n_lo;
-                    o_hi = n_hi;
-                } else {
-                    load_off(blk, o_lo, o_hi);
-                }
-            }
-        }
-        if (__ballot(r != kNone || r2 != kNone) == 0) break;
-        {
-            const bool have = last ? (r2 != kNone && p2 < end2) : true;
-            const uint32_t np = have ? (last ? p2 : p + kStep) : 0u;
-            const uint32_t nend = last ? end2 : end;
+    // Segment of lane `lane` in the iteration that starts at byte b: [b + 64 * lane, + 64). A chunk is fetched only if it begins
+    // inside the arena (a fetch then ends at most 15 bytes past it: PWAF_ARENA_PAD); everything else reads the arena's first bytes.
+    auto load_seg = [&](const uint32_t b, Segment &sg) {
+        const uint32_t p = b + lane * kStreamSeg;
 #pragma unroll
-            for (int q = 0; q < CH; q++) {
-                const uint32_t at = (q == 0 || (have && np + 16u * q < nend)) ? np + 16u * q : 0u;
-                wn[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
-            }
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t at = p + 16u * q < total ? p + 16u * q : 0u;
+            sg.w[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
         }
+        sg.prev = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p >= 4 && p < total) ? p - 4 : 0u));
+        sg.next = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p + kStreamSeg + 4 <= total + PWAF_ARENA_PAD) ? p + kStreamSeg : 0u));
+    };
 
-        // ---- 2. heads: anchored literals compared against the first 16 bytes of a field ----
-        if (a.n_heads != 0 && first) {
-            const uint32_t flen = end - p;
+    // heads: the wave walks the offsets column alongside the bytes; rq = first request that starts at or after the current byte
+    uint32_t rq = 0;
+    if (HEADS) {
+        uint32_t lo = 0, hi = a.n;  // lower bound of base0 in off[0, n)
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.off[mid] < base0) lo = mid + 1;
+            else hi = mid;
+        }
+        rq = lo;
+    }
+
+    Segment cur, nxt;
+    load_seg(base0, cur);
+    for (uint32_t b = base0; b < slab_end; b += kStreamIter) {
+        load_seg(b + kStreamIter < slab_end ? b + kStreamIter : b, nxt);  // next iteration's bytes are in flight while these are looked up
+        const uint32_t p = b + lane * kStreamSeg;
+
+        // the segment's 16 dwords between the dword before it (warm-up) and the dword after it (the last bigram's second byte)
+        uint32_t d[18];
+        d[0] = cur.prev & 0xDFDFDFDFu;
 #pragma unroll
-            for (int hq = 0; hq < 2; hq++) {
-                if ((uint32_t)hq < a.n_heads) {
-                    const uint32_t diff = ((w[0].x ^ a.head_w[hq][0]) & a.head_m[hq][0]) | ((w[0].y ^ a.head_w[hq][1]) & a.head_m[hq][1]) |
-                                          ((w[0].z ^ a.head_w[hq][2]) & a.head_m[hq][2]) | ((w[0].w ^ a.head_w[hq][3]) & a.head_m[hq][3]);
-                    const uint32_t hl = a.head_len[hq] & 0xFFu;
-                    const bool len_ok = (a.head_len[hq] >> 8) ? flen == hl : flen >= hl;
-                    if (diff == 0 && len_ok) hrec |= a.head_code[hq];
-                }
+        for (int q = 0; q < 4; q++) {
+            d[1 + 4 * q + 0] = cur.w[q].x & 0xDFDFDFDFu;
+            d[1 + 4 * q + 1] = cur.w[q].y & 0xDFDFDFDFu;
+            d[1 + 4 * q + 2] = cur.w[q].z & 0xDFDFDFDFu;
+            d[1 + 4 * q + 3] = cur.w[q].w & 0xDFDFDFDFu;
+        }
+        d[17] = cur.next & 0xDFDFDFDFu;
+        auto lookups = [&](const int i, uint32_t (&mm)[4]) {  // the four bigrams that start in dword i (the last one ends in dword i + 1)
+            const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
+            const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
+            const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
+            mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
+            mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
+            mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
+            mm[3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 18) & 0x3FFCu));
+        };
+        // three warm-up bigrams from the four bytes before the segment (none at the very start of the arena), then 64 positions,
+        // one 16-byte chunk at a time (the scheduling barriers keep at most one chunk's lookups live: without them the compiler
+        // hoists all 67 and the kernel drops to 4 waves per SIMD)
+        uint32_t st = a.init;
+        {
+            uint32_t mw[4];
+            lookups(0, mw);
+            if (p >= 4) {
+#pragma unroll
+                for (int i = 1; i < 4; i++) asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(mw[i]));
             }
         }
-        first = false;
-
-        // ---- 3. 16 * CH positions: one independent lookup each ----
-        {
-            uint32_t d[4 * CH + 1];
+        uint32_t hmask = 0;
 #pragma unroll
-            for (int q = 0; q < CH; q++) {
-                d[4 * q + 0] = w[q].x & 0xDFDFDFDFu;
-                d[4 * q + 1] = w[q].y & 0xDFDFDFDFu;
-                d[4 * q + 2] = w[q].z & 0xDFDFDFDFu;
-                d[4 * q + 3] = w[q].w & 0xDFDFDFDFu;
+        for (int q = 0; q < 4; q++) {
+            uint32_t m[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t mm[4];
+                lookups(1 + 4 * q + i, mm);
+                m[4 * i + 0] = mm[0]; m[4 * i + 1] = mm[1]; m[4 * i + 2] = mm[2]; m[4 * i + 3] = mm[3];
             }
-            d[4 * CH] = wn[0].x & 0xDFDFDFDFu;  // the byte after this iteration's last one (next chunk of the field, or harmless)
-            uint32_t m[16 * CH];
+            uint32_t seen = 0xFFFFFFFFu;
 #pragma unroll
-            for (int i = 0; i < 4 * CH; i++) {
-                const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
-                const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
-                const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
-                m[4 * i + 0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
-                m[4 * i + 1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
-                m[4 * i + 2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
-                m[4 * i + 3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 18) & 0x3FFCu));
-            }
-#pragma unroll
-            for (int i = 0; i < 16 * CH; i++) {
-                // st = (st << 8) | m[i] as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
+            for (int i = 0; i < 16; i++) {
+                // st = (st << 8) | m as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
                 asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
                 seen &= st;
             }
+            if (((~seen) & 0xFF000000u) != 0 && p + 16u * (uint32_t)q < total) hmask |= 1u << q;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        p += kStep;
+        const unsigned long long hm = __ballot(hmask != 0);
+        if (hm != 0) {
+            if (hmask != 0) my_sub[n_hit + (uint32_t)__builtin_popcountll(hm & lt_mask)] = ((((b - base0) / kStreamSeg) + lane) << 4) | hmask;
+            n_hit += (uint32_t)__builtin_popcountll(hm);
+        }
 
-        // ---- 4. finished requests: head record, candidate list; then switch to the pulled-ahead request ----
-        const bool fin = r != kNone && p >= end;
-        const bool cand = fin && ((~seen) & 0xFF000000u) != 0;
-        const unsigned long long cm = __ballot(cand);
-        if (cm != 0) {
-            if (cand) my_sub[n_cand + (uint32_t)__builtin_popcountll(cm & lt_mask)] = r;
-            n_cand += (uint32_t)__builtin_popcountll(cm);
-        }
-        if (fin) {
-            if (hrec) a.rec[r] = hrec;
-            r = kNone;
-        }
-        if (r == kNone && r2 != kNone) {
-            r = r2;
-            p = p2;
-            end = end2;
-            r2 = kNone;
-            st = a.init;
-            seen = 0xFFFFFFFFu;
-            hrec = 0;
-            first = true;
-        }
+        if (HEADS) {
+            // requests that start inside this iteration's bytes: compare the head literals against their first 16 bytes (just streamed:
+            // cache hits) and record the heads that hold
+            const uint32_t lim = min(b + kStreamIter, slab_end);
+            for (;;) {
+                const uint32_t idx = rq + lane;
+                const uint32_t s = idx < a.n ? a.off[idx] : 0xFFFFFFFFu;
+                const bool in = s < lim;
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(in));
+                if (in) {
+                    const uint32_t flen = a.off[idx + 1] - s;
+                    const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + s);
+                    uint32_t hrec = 0;
 #pragma unroll
-        for (int q = 0; q < CH; q++) w[q] = wn[q];
-        n_lo = f_lo;
-        n_hi = f_hi;
-        n_base = f_base;
+                    for (int hq = 0; hq < 2; hq++) {
+                        if ((uint32_t)hq < a.n_heads) {
+                            const uint32_t diff = ((w.x ^ a.head_w[hq][0]) & a.head_m[hq][0]) | ((w.y ^ a.head_w[hq][1]) & a.head_m[hq][1]) |
+                                                  ((w.z ^ a.head_w[hq][2]) & a.head_m[hq][2]) | ((w.w ^ a.head_w[hq][3]) & a.head_m[hq][3]);
+                            const uint32_t hl = a.head_len[hq] & 0xFFu;
+                            const bool len_ok = (a.head_len[hq] >> 8) ? flen == hl : flen >= hl;
+                            if (diff == 0 && len_ok) hrec |= a.head_code[hq];
+                        }
+                    }
+                    if (hrec) a.rec[idx] = hrec;
+                }
+                rq += cnt;
+                if (cnt < 64) break;
+            }
+        }
+        cur = nxt;
     }
-    if (lane == 0) a.sub_count[slab] = n_cand;
+    if (lane == 0) a.sub_count[slab] = n_hit;
 }
 
-// compact_kernel: concatenates the per-slab candidate regions of every filtered pass into dense request lists (order:
-// ascending request index) and publishes the list lengths for the confirming lscan_kernel launch. One workgroup covers
-// kCompactSlabs consecutive slabs; its base offset is the sum of the counts of all earlier slabs (a few thousand values).
-static constexpr uint32_t kCompactSlabs = 64;
+// resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the three
+// bytes a window may reach back and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
+__global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
+    const FilterArgs &a = B.f[blockIdx.y];
+    const uint32_t slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if ((uint64_t)slab * kStreamSlab >= a.total) return;
+    const uint32_t cnt = a.sub_count[slab];
+    const uint32_t *sub = a.sub + (size_t)slab * (kStreamSlab / kStreamSeg);
+    for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t e = sub[i], hmask = e & 15u;
+        const uint32_t p = slab * kStreamSlab + (e >> 4) * kStreamSeg;
+        const uint32_t first = (uint32_t)__builtin_ctz(hmask), last = 31u - (uint32_t)__builtin_clz(hmask);
+        const uint32_t lo_b = p + 16u * first, c0 = lo_b >= 3 ? lo_b - 3 : 0u, c1 = p + 16u * last + 16u;  // bytes [c0, c1] may belong to a completed window
+        // first request with off[r + 1] > c0
+        uint32_t lo = 0, hi = a.n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.off[mid + 1] > c0) hi = mid;
+            else lo = mid + 1;
+        }
+        for (uint32_t r = lo; r < a.n && a.off[r] <= c1; r++) atomicOr(&a.bitmap[r >> 5], 1u << (r & 31));
+    }
+}
+
+// bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
+// (kCompactWords bitmap words each), then every workgroup sums the counts before it (a few hundred values) and writes its part.
+__global__ __launch_bounds__(256) void bitcount_kernel(FilterBatchArgs B) {
+    __shared__ uint32_t red[256];
+    const FilterArgs &a = B.f[blockIdx.y];
+    const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords;
+    if (w0 >= words) return;
+    uint32_t c = 0;
+    for (uint32_t w = w0 + threadIdx.x; w < min(words, w0 + kCompactWords); w += 256) c += (uint32_t)__builtin_popcount(a.bitmap[w]);
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t h = 128; h > 0; h >>= 1) {
+        if (threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.block_count[blockIdx.x] = red[0];
+}
+
 __global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
     __shared__ uint32_t red[256];
-    __shared__ uint32_t pre[kCompactSlabs + 1];
     const FilterArgs &a = B.f[blockIdx.y];
-    const uint32_t n_slabs = (a.n + kFilterSlab - 1) / kFilterSlab;
-    const uint32_t s0 = blockIdx.x * kCompactSlabs;
-    if (s0 >= n_slabs) return;
-    const uint32_t s1 = min(n_slabs, s0 + kCompactSlabs), tid = threadIdx.x;
+    const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords, tid = threadIdx.x;
+    if (w0 >= words) return;
+    const uint32_t n_blocks = (words + kCompactWords - 1) / kCompactWords;
     uint32_t acc = 0;
-    for (uint32_t s = tid; s < s0; s += 256) acc += a.sub_count[s];
+    for (uint32_t bq = tid; bq < blockIdx.x; bq += 256) acc += a.block_count[bq];
     red[tid] = acc;
     __syncthreads();
     for (uint32_t h = 128; h > 0; h >>= 1) {
         if (tid < h) red[tid] += red[tid + h];
         __syncthreads();
     }
-    if (tid == 0) {
-        uint32_t run = red[0];
-        for (uint32_t s = s0; s < s1; s++) {
-            pre[s - s0] = run;
-            run += a.sub_count[s];
-        }
-        pre[s1 - s0] = run;
-        if (s1 == n_slabs) *a.list_count = run;
-    }
+    const uint32_t base = red[0];
     __syncthreads();
-    for (uint32_t s = s0; s < s1; s++) {
-        const uint32_t base = pre[s - s0], cnt = pre[s - s0 + 1] - base;
-        const uint32_t *src = a.sub + (size_t)s * kFilterSlab;
-        for (uint32_t i = tid; i < cnt; i += 256) a.list[base + i] = src[i];
+    // each thread owns kCompactWords / 256 consecutive words; exclusive scan of the per-thread counts
+    constexpr uint32_t kPer = kCompactWords / 256;
+    uint32_t wv[kPer], mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t w = w0 + tid * kPer + q;
+        wv[q] = w < words ? a.bitmap[w] : 0u;
+        mine += (uint32_t)__builtin_popcount(wv[q]);
     }
+    red[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t v = tid >= off ? red[tid - off] : 0u;
+        __syncthreads();
+        red[tid] += v;
+        __syncthreads();
+    }
+    uint32_t pos = base + red[tid] - mine;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        uint32_t w = wv[q];
+        const uint32_t r0 = (w0 + tid * kPer + q) * 32;
+        while (w) {
+            a.list[pos++] = r0 + (uint32_t)__builtin_ctz(w);
+            w &= w - 1;
+        }
+    }
+    if (blockIdx.x == n_blocks - 1 && tid == 255) *a.list_count = base + red[255];
 }
 
 int launch_filter(const FilterBatchArgs &b, void *stream) {
     if (b.count == 0) return 0;
-    uint32_t blocks = 0;
+    uint32_t blocks = 0, max_slabs = 0;
+    bool heads = false;
     for (uint32_t k = 0; k < b.count; k++) {
-        const uint32_t slabs = (b.f[k].n + kFilterSlab - 1) / kFilterSlab;
+        const uint32_t slabs = (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab);
         blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
+        max_slabs = max(max_slabs, slabs);
+        heads = heads || b.f[k].n_heads != 0;
     }
     if (blocks == 0) return 0;
     void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    int ch = 2;
-#ifdef PWAF_PROFILING
-    static const int forced_ch = getenv("PWAF_FILTER_CH") ? atoi(getenv("PWAF_FILTER_CH")) : 0;
-    if (forced_ch) ch = forced_ch;
-#endif
-    const void *fn = ch == 1 ? reinterpret_cast<const void *>(filter_kernel<1>) : ch == 4 ? reinterpret_cast<const void *>(filter_kernel<4>) : reinterpret_cast<const void *>(filter_kernel<2>);
+    const void *fn = heads ? reinterpret_cast<const void *>(filter_kernel<true>) : reinterpret_cast<const void *>(filter_kernel<false>);
     hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
-int launch_compact(const FilterBatchArgs &b, void *stream) {
-    if (b.count == 0) return 0;
+int launch_resolve(const FilterBatchArgs &b, void *stream) {
     uint32_t max_slabs = 0;
-    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (b.f[k].n + kFilterSlab - 1) / kFilterSlab);
-    if (max_slabs == 0) return 0;
+    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab));
+    if (b.count == 0 || max_slabs == 0) return 0;
     void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(compact_kernel), dim3((max_slabs + kCompactSlabs - 1) / kCompactSlabs, b.count), dim3(256), args, 0, (hipStream_t)stream);
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, b.count), dim3(256), args, 0, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
+}
+
+int launch_compact(const FilterBatchArgs &b, void *stream) {
+    if (b.count == 0 || b.f[0].n == 0) return 0;
+    const uint32_t words = (b.f[0].n + 31) / 32, blocks = (words + kCompactWords - 1) / kCompactWords;
+    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(bitcount_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipLaunchKernel(reinterpret_cast<const void *>(compact_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 

@@ -480,6 +480,7 @@ class DeviceBatch:
         self.n = batch.n
         self.algorithmic_bytes = batch.algorithmic_bytes()
         self.field_bytes = [int(o[-1]) - int(o[0]) for o in batch.offsets]
+        self.arena_bytes = [int(o[-1]) for o in batch.offsets]  # offsets[n]: what pwaf_batch.field_bytes carries
         t = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)  # noqa: E731
         self.data = [t(d) for d in batch.data]
         self.offsets = [t(o.view(np.int32)) for o in batch.offsets]
@@ -498,6 +499,7 @@ class DeviceBatch:
         for f in range(_abi.N_FIELDS):
             b.field[f].data = self.data[f].data_ptr()
             b.field[f].offsets = self.offsets[f].data_ptr()
+            b.field_bytes[f] = self.arena_bytes[f]
         b.ip = self.ip.data_ptr()
         b.ip_is_v6 = self.ip_is_v6.data_ptr()
         b.port = self.port.data_ptr()

@@ -31,7 +31,7 @@ def test_struct_sizes_match_header_layout():
     # the numbers are what a C compiler gives for include/pwaf.h on x86-64 (checked by tests/abi_sizes.c at build time)
     assert C.sizeof(_abi.RuleDesc) == 32 and C.sizeof(_abi.ListDesc) == 24 and C.sizeof(_abi.GeoipEntry) == 24
     assert C.sizeof(_abi.Options) == 32 and C.sizeof(_abi.CompileError) == 256 and C.sizeof(_abi.Verdict) == 8
-    assert C.sizeof(_abi.Batch) == 16 + 5 * 16 + 6 * 8 and C.sizeof(_abi.Counts) == 32 and C.sizeof(_abi.Stats) == 64
+    assert C.sizeof(_abi.Batch) == 16 + 5 * 16 + 6 * 8 + 5 * 4 + 4 + 2 * 8 and C.sizeof(_abi.Counts) == 32 and C.sizeof(_abi.Stats) == 64
     assert C.sizeof(_abi.KernelTime) == 64 and C.sizeof(_abi.Request) == 88
 
 
