@@ -85,6 +85,8 @@ struct DevGroup {
     int share_owner = -1;   // a gap pass whose factors all belong to this filtered pass: it walks the owner's list (no list of its own)
     uint32_t shared_bits = 0;  // owner: list bits of the gap passes sharing its list
     int need_slot = -1;     // owner: which need-mask array
+    int visit_slot = -1;    // a gap pass: which visited bitmap (its records are valid only where it walked)
+    bool identity = false;  // a plain pass over a SHORT field (`method`): walked by the list-scan kernel with the identity list
     GroupFilter filter;     // the prefilter in use (Program's, or rebuilt from a traffic sample by pwaf_engine_tune)
     DevBuf ftable;
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
@@ -115,6 +117,9 @@ struct pwaf_engine {
     DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
     DevBuf need;                // per sharing owner: gap-pass mask of every entry of its candidate list
     uint32_t n_need = 0;
+    DevBuf visit_bits;          // per gap pass: visited bitmap
+    uint32_t n_visit = 0;
+    double mean_len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};  // from the tuning sample (0 = unknown)
     uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
     unsigned long long select_pass_mask = 0;
     DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
@@ -341,8 +346,15 @@ int assign_lists(pwaf_engine *e) {
         for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
             if (colmask[c]) e->select_pass_mask |= 1ull << k;
     // gap passes whose factors all live in ONE filtered pass walk that pass's candidate list (no atomics, no list of their own)
-    e->n_need = 0;
-    for (auto &d : e->groups) { d.share_owner = -1; d.shared_bits = 0; d.need_slot = -1; }
+    e->n_need = e->n_visit = 0;
+    for (auto &d : e->groups) { d.share_owner = -1; d.shared_bits = 0; d.need_slot = -1; d.visit_slot = -1; d.identity = false; }
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        DevGroup &d = e->groups[k];
+        if (d.gate >= 0 && !d.filtered) d.visit_slot = (int)e->n_visit++;
+        // a plain pass over a field of a few bytes: the streaming DFA kernel's per-request machinery costs more than the walk itself
+        const double ml = e->mean_len[P.groups[k].field];
+        if (d.gate < 0 && (P.groups[k].field == PWAF_FIELD_METHOD ? (ml == 0 || ml < 12) : (ml > 0 && ml < 12))) d.identity = true;
+    }
     for (size_t k = 0; k < P.groups.size(); k++) {
         DevGroup &d = e->groups[k];
         if (d.gate < 0 || d.filtered) continue;
@@ -384,6 +396,17 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
     if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
     if (e->n_need && (rc = e->need.reserve((size_t)e->n_need * n * 4))) return rc;
+    // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
+    // zeroing the hit records themselves would write
+    const uint32_t bit_words = 2 * n_groups;
+    if (e->n_filtered) {
+        if ((rc = e->cand_bits.reserve((size_t)e->n_filtered * bit_words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(e->cand_bits.p, 0, (size_t)e->n_filtered * bit_words * 4, stream));
+    }
+    if (e->n_visit) {
+        if ((rc = e->visit_bits.reserve((size_t)e->n_visit * bit_words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(e->visit_bits.p, 0, (size_t)e->n_visit * bit_words * 4, stream));
+    }
 
     // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
     // (half the events; the few microseconds of launch gap or memset in between are charged to the later kernel).
@@ -440,6 +463,21 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)e->rec.p;
     for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) v.pass_base_v[k] = e->groups[k].atom_base;
+    {
+        uint32_t fi = 0;
+        for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) {
+            const DevGroup &d = e->groups[k];
+            v.pass_bits[k] = nullptr;
+            if (d.filtered) {
+                // a pass with heads writes records outside its candidate list too: its records are zeroed and read densely
+                if (d.filter.heads.empty()) v.pass_bits[k] = (const uint32_t *)e->cand_bits.p + (size_t)fi * bit_words;
+                else HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
+                fi++;
+            } else if (d.visit_slot >= 0) {
+                v.pass_bits[k] = (const uint32_t *)e->visit_bits.p + (size_t)d.visit_slot * bit_words;
+            }
+        }
+    }
     v.gpairs = (uint4 *)e->attr.p;
     v.ghdr = (uint32_t *)((char *)e->attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
     v.pair_stride = pair_stride;
@@ -526,8 +564,11 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
-        a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)src.gate * n;
-        a.n_list = (const uint32_t *)e->ctrl.p + 2 + src.gate;
+        if (!d.identity) {
+            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)src.gate * n;
+            a.n_list = (const uint32_t *)e->ctrl.p + 2 + src.gate;
+        }
+        if (d.visit_slot >= 0) a.visited = (uint32_t *)e->visit_bits.p + (size_t)d.visit_slot * bit_words;
         if (d.share_owner >= 0) {
             a.need_in = (const uint32_t *)e->need.p + (size_t)src.need_slot * n;
             a.need_bit = (uint32_t)d.gate;
@@ -560,19 +601,10 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.n_cus = e->n_cus;
         return a;
     };
-    // hit records of list-driven passes must read "nothing matched" for the requests the pass does not visit; compile.cpp orders
-    // those passes last, so one memset covers them all
-    {
-        size_t first_list = e->groups.size();
-        for (size_t gi = 0; gi < e->groups.size(); gi++)
-            if (e->groups[gi].gate >= 0) { first_list = gi; break; }
-        if (first_list < e->groups.size())
-            HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + first_list * (size_t)n, 0, (e->groups.size() - first_list) * (size_t)n * 4, stream));
-    }
-    // ---- 1. plain passes: the DFA walks every request ----
+    // ---- 1. plain passes: the DFA walks every request (short fields go through the list-scan kernel below) ----
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
         const DevGroup &d = e->groups[gi];
-        if (d.gate >= 0) continue;
+        if (d.gate >= 0 || d.identity) continue;
         const ScanArgs a = scan_args(gi);
         char nm[48];
         snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
@@ -606,8 +638,6 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             }
         if ((rc = e->cand_sub.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = e->cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
-        if ((rc = e->cand_bits.reserve((size_t)e->n_filtered * words * 4))) return rc;
-        HIP_TRY(hipMemsetAsync(e->cand_bits.p, 0, (size_t)e->n_filtered * words * 4, stream));
         FilterBatchArgs fb{};
         uint32_t fi = 0, block = 0, field_mask = 0;
         uint64_t sub_at = 0, cnt_at = 0;
@@ -655,7 +685,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             f.sub = (uint32_t *)e->cand_sub.p + sub_at;
             f.sub_count = (uint32_t *)e->cand_cnt.p + cnt_at;
             f.block_count = f.sub_count + slabs;
-            f.bitmap = (uint32_t *)e->cand_bits.p + (size_t)fi * words;
+            f.bitmap = (uint32_t *)e->cand_bits.p + (size_t)fi * bit_words;
             f.list = (uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)e->ctrl.p + 2 + d.gate;
             f.first_block = block;
@@ -685,7 +715,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     for (int phase = 0; phase < 2; phase++) {
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
-            if (d.gate < 0 || d.filtered != (phase == 0)) continue;
+            if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
             gb.g[gb.count++] = list_args(gi);
             if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
         }
@@ -1059,7 +1089,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->cand_bits, &e->need, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
+                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->cand_bits, &e->need, &e->visit_bits, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
     for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
@@ -1230,6 +1260,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             if (tot)
                 for (uint32_t b = 0; b < kFilterEntries; b++) bin_prob[f][b] = (double)cnt[b] / (double)tot;
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;
+            e->mean_len[f] = mean_len[f];
         }
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];

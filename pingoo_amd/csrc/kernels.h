@@ -84,8 +84,9 @@ struct ListScanArgs {
     uint32_t n_local;
     uint32_t *gate_lists;
     uint32_t *gate_count;
-    const uint32_t *req_list;  // the requests to visit and, on the device, how many
+    const uint32_t *req_list;  // the requests to visit and, on the device, how many (req_list null: every request, n_list ignored)
     const uint32_t *n_list;
+    uint32_t *visited;         // bitmap: set bit r for every visited request (null: not needed — the list IS the pass's bitmap, or all)
     // Gap passes whose prefilter factors all belong to ONE filtered pass share that pass's candidate list instead of getting lists
     // of their own through atomics (a returned same-address atomic per enqueued request was 0.5 ms per batch): the owner writes,
     // per list entry, the mask of gap passes its hits call for (need_out); a sharing pass skips entries without its bit.
@@ -162,6 +163,10 @@ struct VerdictArgs {
     uint32_t n_passes;
     const uint32_t *rec;        // [n_passes][n]
     uint32_t pass_base_v[kMaxPasses + 1];  // first column of each pass (in the kernel-argument block: scalar loads)
+    // A list-driven pass writes hit records only for the requests it visits; bit r of its VISITED bitmap says record r is valid
+    // (everything else reads as "nothing matched": no memset of 4 bytes per request and pass, no read of them here). Null = the
+    // pass writes (or the host zeroes) every record.
+    const uint32_t *pass_bits[kMaxPasses];
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 __global__ __launch_bounds__(256) void lscan_kernel(GatedArgs b) {
     __shared__ unsigned char cls[256];
     const ListScanArgs &a = b.g[blockIdx.y];
-    const uint32_t n_l = min(*a.n_list, a.n);
+    const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
     if (blockIdx.x * 256u >= n_l) return;
     cls[threadIdx.x] = a.classmap[threadIdx.x];
     __syncthreads();
@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void lscan_kernel(GatedArgs b) {
     const uint32_t ncls = a.n_classes;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_l; i += gridDim.x * 256u) {
         if (a.need_in != nullptr && !((a.need_in[i] >> a.need_bit) & 1u)) continue;  // (a sharing gap pass: none of its factors fired here)
-        const uint32_t r = a.req_list[i];
+        const uint32_t r = a.req_list != nullptr ? a.req_list[i] : i;
+        if (a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31));
         uint32_t p = a.off[r];
         const uint32_t end = a.off[r + 1];
         uint32_t state = 0;
@@ -933,14 +934,31 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         uint32_t flags, n_pairs;
         uint4 pair0;
     };
-    auto request_inputs = [&](const uint32_t g, Inputs &in) {
+    // Sparse passes: the group's 64 visited bits per pass are requested TWO groups ahead (wave-uniform words), so that the record
+    // loads one group ahead can be limited to the lanes whose bit is set.
+    struct Bits {
+        uint32_t lo[kPre], hi[kPre];
+    };
+    auto request_bits = [&](const uint32_t g, Bits &bt) {
+        const uint32_t gg = min(g, a.n_groups - 1);
+#pragma unroll
+        for (int q = 0; q < kPre; q++) {
+            const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
+            const uint32_t *bits = a.pass_bits[ps];
+            // (the bitmap of a batch whose size is not a multiple of 64 is padded to whole groups by the engine)
+            bt.lo[q] = bits != nullptr ? bits[2 * gg] : 0xFFFFFFFFu;
+            bt.hi[q] = bits != nullptr ? bits[2 * gg + 1] : 0xFFFFFFFFu;
+        }
+    };
+    auto request_inputs = [&](const uint32_t g, const Bits &bt, Inputs &in) {
         const uint32_t i = g * 64 + lane;
         const bool valid = g < a.n_groups && i < a.n;
 #pragma unroll
         for (int q = 0; q < kPre; q++) {
             // (n_passes == 0 — no string predicate at all — must not wrap: nothing is read then)
             const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
-            in.rv[q] = (valid && a.n_passes != 0) ? a.rec[(size_t)ps * a.n + i] : 0u;
+            const bool mine = (((lane < 32 ? bt.lo[q] : bt.hi[q]) >> (lane & 31)) & 1u) != 0;
+            in.rv[q] = (valid && mine && a.n_passes != 0) ? a.rec[(size_t)ps * a.n + i] : 0u;
         }
         in.flags = valid ? (uint32_t)a.flags[i] : 0u;
         const uint32_t gg = min(g, a.n_groups - 1);
@@ -951,14 +969,21 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     for (uint32_t k = lane; k < colw; k += 64) colnz[k] = 0;
     const uint32_t g_stride = gridDim.x * n_waves;
     Inputs cur;
-    request_inputs(blockIdx.x * n_waves + wave, cur);
+    Bits b_nxt;
+    {
+        Bits b_cur;
+        request_bits(blockIdx.x * n_waves + wave, b_cur);
+        request_inputs(blockIdx.x * n_waves + wave, b_cur, cur);
+        request_bits(blockIdx.x * n_waves + wave + g_stride, b_nxt);
+    }
 
     for (uint32_t g = blockIdx.x * n_waves + wave; g < a.n_groups; g += g_stride) {
         const uint32_t i = g * 64 + lane;
         const bool valid = i < a.n;
         const unsigned long long valid_mask = __ballot(valid);
         Inputs nxt;
-        request_inputs(g + g_stride, nxt);
+        request_inputs(g + g_stride, b_nxt, nxt);
+        request_bits(g + 2 * g_stride, b_nxt);
 
         // 1. clear the column file and the bitmaps; column 0 is the constant TRUE; rules that can match with every column
         //    zero (a term made of negations only) are always candidates
@@ -990,7 +1015,9 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                     rv[q] = cur.rv[q];
                 } else {
                     const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
-                    rv[q] = valid ? a.rec[(size_t)ps * a.n + i] : 0u;
+                    const uint32_t *bits = a.pass_bits[ps];
+                    const bool mine = bits == nullptr || ((bits[2 * g + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
+                    rv[q] = (valid && mine) ? a.rec[(size_t)ps * a.n + i] : 0u;
                 }
             }
 #pragma unroll
@@ -1453,16 +1480,15 @@ int launch_dir24(const VerdictArgs &a, void *out, void *esc, void *esc_count, vo
 
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    // Two workgroups (8 waves) per CU, at the default wave priority 0 while the scan waves raise theirs to 3: the attribute waves
-    // take the issue slots the scans leave idle (~25 %) instead of competing for them, and 2 of them per SIMD are what still fits
-    // the register file next to a 4-chunk scan workgroup (measured on MI355X, DESIGN.md §6.1: 256/384/512/768 workgroups ->
-    // 2.71/2.49/2.47/2.76 ms per step).
+    // A persistent grid of six workgroups per CU at the default wave priority 0, while the filter waves raise theirs to 3: the
+    // attribute waves take the issue slots the filter leaves idle instead of competing for them (measured on MI355X next to the
+    // stream filter: 512 / 768 / 1024 / 1536 / 2048 workgroups -> 2.00 / 2.00 / 1.98 / 1.94 / 1.94 ms per step).
 #ifdef PWAF_PROFILING
     static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;
 #else
     const uint32_t forced = 0;
 #endif
-    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : 2 * std::max(1u, a.attr_blocks));
+    const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : 6 * std::max(1u, a.attr_blocks));
     hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
