@@ -176,7 +176,7 @@ typedef struct pwaf_batch {
     /* EXTENSION (no reference counterpart: pingoo/rules.rs:16-25 exposes no headers — BASELINE.json configs[4]):
      * one string column per header name the rule set mentions as http_request.headers["name"], in the order of
      * pwaf_engine_header_name(); a request without the header carries the empty string. */
-    const pwaf_strcol *headers;    /* n_headers columns, same memory as everything else */
+    const pwaf_strcol *headers;    /* n_headers column descriptors (the ARRAY is in host memory; the pointers inside follow `memory`) */
     const uint32_t *header_bytes;  /* n_headers arena sizes (HOST memory, same rule as field_bytes), or NULL */
 } pwaf_batch;
 
@@ -230,6 +230,12 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                        pwaf_compile_error *err /* nullable */);
 void pwaf_engine_destroy(pwaf_engine *);
 const pwaf_program *pwaf_engine_program(const pwaf_engine *);
+/* EXTENSION (header fields): the header names the rule set mentions as http_request.headers["name"] (exact, case-sensitive
+ * strings — HTTP/2 and the `http` crate present them in lower case), in the column order pwaf_batch.headers must use. */
+uint32_t pwaf_engine_header_count(const pwaf_engine *);
+const char *pwaf_engine_header_name(const pwaf_engine *, uint32_t i);
+uint32_t pwaf_program_header_count(const pwaf_program *);
+const char *pwaf_program_header_name(const pwaf_program *, uint32_t i);
 void *pwaf_engine_stream(const pwaf_engine *); /* hipStream_t the synchronous entry points run on */
 
 /* Synchronous batch evaluation. HOST batches are copied to the device, evaluated, and verdicts are

@@ -65,6 +65,7 @@ struct Engine {
     std::vector<GeoNode> geo4, geo6;
     std::vector<GeoRec> georecs;
     uint32_t flags = 0;
+    std::vector<std::string> header_names;  // EXTENSION: the names behind the batches' header columns
 
     static void geo_insert(std::vector<GeoNode> &t, const uint8_t *addr, int plen, int rec) {
         if (t.empty()) t.emplace_back();
@@ -146,6 +147,7 @@ static bool parse_i64(std::string_view s, int64_t &out) {
 
 struct ReqView {
     std::string_view host, url, path, method, ua;
+    std::vector<std::string_view> headers;  // EXTENSION: values of the engine-declared header names, in that order
     uint8_t ip[16];
     bool v6;
     uint16_t port;
@@ -155,8 +157,16 @@ struct ReqView {
     uint8_t country[2];
 };
 
-static void build_context(const Engine &e, const ReqView &r, uint32_t asn, const uint8_t country[2], MapVal &http, MapVal &client, Context &ctx) {
+// EXTENSION (the reference's RequestData has no headers, pingoo/rules.rs:16-25): http_request.headers is a
+// Map<String, String> holding exactly the header names declared with pwaf_oracle_set_header_names (absent header = "").
+static void build_context(const Engine &e, const ReqView &r, uint32_t asn, const uint8_t country[2], MapVal &http, MapVal &client, MapVal &headers, Context &ctx) {
+    headers.items.clear();
+    for (size_t k = 0; k < e.header_names.size(); k++) headers.items.emplace(e.header_names[k], Val::str(k < r.headers.size() ? r.headers[k] : std::string_view()));
     http.items.clear();
+    {
+        Val hm; hm.k = Val::Map; hm.map = &headers;
+        http.items.emplace("headers", hm);
+    }
     http.items.emplace("host", Val::str(r.host));
     http.items.emplace("url", Val::str(r.url));
     http.items.emplace("path", Val::str(r.path));
@@ -217,9 +227,9 @@ static void evaluate_one(const Engine &e, const ReqView &r, pwaf_verdict &out) {
         }
     }
     bool verified = (r.flags & PWAF_FLAG_CAPTCHA_VERIFIED) != 0;
-    MapVal http, client;
+    MapVal http, client, headers;
     Context ctx;
-    build_context(e, r, asn, country, http, client, ctx);
+    build_context(e, r, asn, country, http, client, headers, ctx);
     for (size_t k = 0; k < e.rules.size(); k++) {
         const ORule &rule = e.rules[k];
         if (!match_request(rule, ctx)) continue;
@@ -249,6 +259,12 @@ static bool batch_view(const pwaf_batch *b, uint32_t i, ReqView &r) {
         uint32_t o0 = b->field[k].offsets[i], o1 = b->field[k].offsets[i + 1];
         if (o1 < o0) return false;
         *f[k] = std::string_view((const char *)b->field[k].data + o0, o1 - o0);
+    }
+    r.headers.clear();
+    for (uint32_t k = 0; k < b->n_headers && b->headers; k++) {
+        uint32_t o0 = b->headers[k].offsets[i], o1 = b->headers[k].offsets[i + 1];
+        if (o1 < o0) return false;
+        r.headers.emplace_back((const char *)b->headers[k].data + o0, o1 - o0);
     }
     memcpy(r.ip, b->ip + 16 * (size_t)i, 16);
     r.v6 = b->ip_is_v6[i] != 0;
@@ -380,11 +396,59 @@ int pwaf_oracle_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             Engine::geo_insert(g.is_v6 ? e->geo6 : e->geo4, g.addr, g.prefix_len, (int)e->georecs.size() - 1);
         }
     }
+    // EXTENSION: the headers map holds exactly the names the rule set mentions with a literal key — http_request.headers["x"],
+    // http_request.headers.x, "x" in http_request.headers, http_request.headers.contains("x") — in order of first use
+    {
+        auto is_headers = [](const Node &n) {
+            if (n.k == Node::Member) return n.name == "headers" && n.kids.size() == 1 && n.kids[0]->k == Node::Ident && n.kids[0]->name == "http_request";
+            if (n.k == Node::Index)
+                return n.kids.size() == 2 && n.kids[0]->k == Node::Ident && n.kids[0]->name == "http_request" && n.kids[1]->k == Node::Lit &&
+                       n.kids[1]->lit.k == Val::String && n.kids[1]->lit.s == "headers";
+            return false;
+        };
+        auto add = [&](std::string_view name) {
+            for (auto &h : e->header_names) if (h == name) return;
+            e->header_names.emplace_back(name);
+        };
+        std::vector<const Node *> stack;
+        for (auto &r : e->rules)
+            if (r.has_expr && r.prog.root) stack.push_back(r.prog.root.get());
+        std::vector<const Node *> order;  // pre-order, left to right, rule by rule
+        {
+            std::vector<const Node *> roots(stack.begin(), stack.end());
+            for (const Node *root : roots) {
+                std::vector<const Node *> st{root};
+                while (!st.empty()) {
+                    const Node *n = st.back();
+                    st.pop_back();
+                    order.push_back(n);
+                    for (size_t k = n->kids.size(); k-- > 0;) st.push_back(n->kids[k].get());
+                }
+            }
+        }
+        for (const Node *n : order) {
+            if (n->k == Node::Member && n->kids.size() == 1 && is_headers(*n->kids[0])) add(n->name);
+            if (n->k == Node::Index && n->kids.size() == 2 && is_headers(*n->kids[0]) && n->kids[1]->k == Node::Lit && n->kids[1]->lit.k == Val::String)
+                add(n->kids[1]->lit.s);
+            if (n->k == Node::Bin && n->name == "in" && n->kids.size() == 2 && is_headers(*n->kids[1]) && n->kids[0]->k == Node::Lit && n->kids[0]->lit.k == Val::String)
+                add(n->kids[0]->lit.s);
+            if (n->k == Node::Call && n->has_receiver && n->name == "contains" && n->kids.size() == 2 && is_headers(*n->kids[0]) && n->kids[1]->k == Node::Lit &&
+                n->kids[1]->lit.k == Val::String)
+                add(n->kids[1]->lit.s);
+        }
+    }
     *out = e.release();
     return PWAF_OK;
 }
 
 void pwaf_oracle_destroy(void *h) { delete (Engine *)h; }
+
+// EXTENSION: the header names the rule set mentions (first-use order) = the header columns a batch must carry, in this order.
+uint32_t pwaf_oracle_header_count(void *h) { return (uint32_t)((Engine *)h)->header_names.size(); }
+const char *pwaf_oracle_header_name(void *h, uint32_t i) {
+    Engine &e = *(Engine *)h;
+    return i < e.header_names.size() ? e.header_names[i].c_str() : "";
+}
 
 int pwaf_oracle_evaluate(void *h, const pwaf_batch *b, pwaf_verdict *out, int n_threads) {
     const Engine &e = *(const Engine *)h;
@@ -422,9 +486,9 @@ int pwaf_oracle_execute_rule(void *h, uint32_t rule, const pwaf_batch *b, uint32
     uint8_t country[2];
     if (r.has_geo) { asn = r.asn; country[0] = r.country[0]; country[1] = r.country[1]; }
     else e.geo_lookup(r.ip, r.v6, asn, country);
-    MapVal http, client;
+    MapVal http, client, headers;
     Context ctx;
-    build_context(e, r, asn, country, http, client, ctx);
+    build_context(e, r, asn, country, http, client, headers, ctx);
     if (!e.rules[rule].has_expr) return 1;
     Val v = execute(e.rules[rule].prog, ctx);
     if (v.k == Val::Error) return 3;

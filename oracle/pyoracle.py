@@ -41,6 +41,10 @@ def lib():
                                          C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
         L.pwaf_oracle_create.restype = C.c_int
         L.pwaf_oracle_destroy.argtypes = [C.c_void_p]
+        L.pwaf_oracle_header_count.argtypes = [C.c_void_p]
+        L.pwaf_oracle_header_count.restype = C.c_uint32
+        L.pwaf_oracle_header_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.pwaf_oracle_header_name.restype = C.c_char_p
         L.pwaf_oracle_destroy.restype = None
         L.pwaf_oracle_evaluate.argtypes = [C.c_void_p, C.POINTER(_abi.Batch), C.c_void_p, C.c_int]
         L.pwaf_oracle_evaluate.restype = C.c_int
@@ -138,6 +142,8 @@ class Oracle:
             raise OracleError(rc, buf.value.decode(errors="replace"))
         self._h = h
         self.n_rules = nr
+        # EXTENSION: the header names the rule set mentions = the header columns batches are handed over with, in this order
+        self.header_names = [lib().pwaf_oracle_header_name(h, i).decode() for i in range(lib().pwaf_oracle_header_count(h))]
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -146,7 +152,7 @@ class Oracle:
 
     def evaluate(self, batch: RequestBatch, threads: int = 1) -> np.ndarray:
         out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
-        st = batch.as_struct()
+        st = batch.as_struct(self.header_names)
         rc = lib().pwaf_oracle_evaluate(self._h, C.byref(st), out.ctypes.data, threads)
         if rc != 0:
             raise OracleError(rc, "oracle evaluate failed (malformed batch)")
@@ -154,7 +160,7 @@ class Oracle:
 
     def execute_rule(self, rule: int, batch: RequestBatch, i: int) -> int:
         """1 Bool(true), 0 Bool(false), 2 non-Bool, 3 execution error."""
-        st = batch.as_struct()
+        st = batch.as_struct(self.header_names)
         return lib().pwaf_oracle_execute_rule(self._h, rule, C.byref(st), i)
 
     def geoip_lookup(self, ip16: bytes, v6: bool):

@@ -42,6 +42,7 @@ class Request:
     asn: Optional[int] = None  # None => the engine looks the ip up in its GeoIP table
     country: Optional[str] = None
     captcha_verified: bool = False
+    headers: Optional[dict] = None  # EXTENSION: exact header name -> value; an absent header reads as ""
 
 
 def ip_to_bytes16(ip: str) -> tuple[bytes, bool]:
@@ -55,9 +56,16 @@ class RequestBatch:
     """Host-resident SoA batch (numpy). `as_struct()` yields a pwaf_batch pointing at the arrays."""
 
     def __init__(self, data: Sequence[np.ndarray], offsets: Sequence[np.ndarray], ip: np.ndarray, ip_is_v6: np.ndarray,
-                 port: np.ndarray, flags: np.ndarray, asn: Optional[np.ndarray] = None, country: Optional[np.ndarray] = None):
+                 port: np.ndarray, flags: np.ndarray, asn: Optional[np.ndarray] = None, country: Optional[np.ndarray] = None,
+                 headers: Optional[dict] = None):
         assert len(data) == _abi.N_FIELDS and len(offsets) == _abi.N_FIELDS
         self.n = int(len(port))
+        # header columns by name: (arena, offsets) like a field; a consumer orders them by ITS list of names (as_struct)
+        self.headers = {}
+        for name, (hd, ho) in (headers or {}).items():
+            hd, ho = np.ascontiguousarray(hd, dtype=np.uint8), np.ascontiguousarray(ho, dtype=np.uint32)
+            assert len(ho) == self.n + 1 and len(hd) >= int(ho[-1]) + _abi.ARENA_PAD
+            self.headers[name] = (hd, ho)
         self.data = [np.ascontiguousarray(d, dtype=np.uint8) for d in data]
         self.offsets = [np.ascontiguousarray(o, dtype=np.uint32) for o in offsets]
         for d, o in zip(self.data, self.offsets):
@@ -98,9 +106,30 @@ class RequestBatch:
         if with_geoip:
             asn = np.array([r.asn or 0 for r in reqs], dtype=np.uint32)
             country = np.array([int.from_bytes(_b(r.country or "XX")[:2], "little") for r in reqs], dtype=np.uint16)
-        return RequestBatch(datas, offs, ip, v6, port, flags, asn, country)
+        names = []
+        for r in reqs:
+            for k in (r.headers or {}):
+                if k not in names:
+                    names.append(k)
+        headers = {}
+        for name in names:
+            vals = [_b((r.headers or {}).get(name, b"")) for r in reqs]
+            o = np.zeros(n + 1, dtype=np.uint32)
+            if n:
+                o[1:] = np.cumsum([len(v) for v in vals], dtype=np.uint64).astype(np.uint32)
+            headers[name] = (np.frombuffer(b"".join(vals) + b"\0" * _abi.ARENA_PAD, dtype=np.uint8).copy(), o)
+        return RequestBatch(datas, offs, ip, v6, port, flags, asn, country, headers)
 
-    def field_bytes(self, field: int, i: int) -> bytes:
+    def header_bytes(self, name: str, i: int) -> bytes:
+        if name not in self.headers:
+            return b""
+        d, o = self.headers[name]
+        return d[int(o[i]):int(o[i + 1])].tobytes()
+
+    def field_bytes(self, field: int, i: int, header_names: Sequence[str] = ()) -> bytes:
+        """Value of field id `field` of request i: 0..4 the fixed fields, 5 + k the k-th name of `header_names`."""
+        if field >= _abi.N_FIELDS:
+            return self.header_bytes(header_names[field - _abi.N_FIELDS], i)
         o = self.offsets[field]
         return self.data[field][int(o[i]):int(o[i + 1])].tobytes()
 
@@ -113,8 +142,14 @@ class RequestBatch:
             nd[: b1 - b0] = d[b0:b1]
             datas.append(nd)
             offs.append((o[lo:hi + 1] - o[lo]).astype(np.uint32))
+        headers = {}
+        for name, (d, o) in self.headers.items():
+            b0, b1 = int(o[lo]), int(o[hi])
+            nd = np.zeros(b1 - b0 + _abi.ARENA_PAD, dtype=np.uint8)
+            nd[: b1 - b0] = d[b0:b1]
+            headers[name] = (nd, (o[lo:hi + 1] - o[lo]).astype(np.uint32))
         return RequestBatch(datas, offs, self.ip[lo:hi], self.ip_is_v6[lo:hi], self.port[lo:hi], self.flags[lo:hi],
-                            None if self.asn is None else self.asn[lo:hi], None if self.country is None else self.country[lo:hi])
+                            None if self.asn is None else self.asn[lo:hi], None if self.country is None else self.country[lo:hi], headers)
 
     def tile(self, times: int) -> "RequestBatch":
         """The batch repeated `times` times (test / bench helper for very large uniform batches)."""
@@ -128,20 +163,36 @@ class RequestBatch:
             datas.append(nd)
             offs.append(no)
         rep = lambda a: None if a is None else np.tile(a, (times,) + (1,) * (a.ndim - 1))
+        assert not self.headers, "tile(): header columns are not supported"
         return RequestBatch(datas, offs, rep(self.ip), rep(self.ip_is_v6), rep(self.port), rep(self.flags), rep(self.asn), rep(self.country))
 
     def algorithmic_bytes(self) -> int:
         """sum(field bytes) + 4*(5+1) offset bytes + 22 B numerics + 8 B verdict per request
         (+6 B when GeoIP is precomputed on the host)."""
-        strings = sum(int(o[-1]) - int(o[0]) for o in self.offsets)
-        per_req = 24 + 22 + 8 + (6 if self.asn is not None else 0)
+        strings = sum(int(o[-1]) - int(o[0]) for o in self.offsets) + sum(int(o[-1]) - int(o[0]) for _, o in self.headers.values())
+        per_req = 24 + 22 + 8 + (6 if self.asn is not None else 0) + 4 * len(self.headers)
         return strings + per_req * self.n
 
-    def as_struct(self) -> _abi.Batch:
+    def as_struct(self, header_names: Sequence[str] = ()) -> _abi.Batch:
+        """pwaf_batch over the arrays; header columns in the order of `header_names` (a name the batch does not carry = empty)."""
         b = _abi.Batch()
         b.struct_size = C.sizeof(_abi.Batch)
         b.n = self.n
         b.memory = _abi.MEM_HOST
+        if header_names:
+            cols = (_abi.StrCol * len(header_names))()
+            hb = (C.c_uint32 * len(header_names))()
+            empty = (np.zeros(_abi.ARENA_PAD, dtype=np.uint8), np.zeros(self.n + 1, dtype=np.uint32))
+            keep = [cols, hb, empty]
+            for k, name in enumerate(header_names):
+                d, o = self.headers.get(name, empty)
+                cols[k].data = d.ctypes.data
+                cols[k].offsets = o.ctypes.data
+                hb[k] = int(o[-1])
+            b.n_headers = len(header_names)
+            b.headers = cols
+            b.header_bytes = hb
+            b._keep = keep  # (ctypes does not keep the arrays alive by itself)
         for f in range(_abi.N_FIELDS):
             b.field[f].data = self.data[f].ctypes.data
             b.field[f].offsets = self.offsets[f].ctypes.data

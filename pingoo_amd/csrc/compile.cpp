@@ -118,7 +118,7 @@ struct SVal {
         BOOLX,     // boolean over atoms
         LISTREF,   // lists["name"]
         NETCONST,  // an item of an Ip list (no literal syntax exists; only reachable through indexing)
-        MAP_HTTP, MAP_CLIENT, MAP_LISTS
+        MAP_HTTP, MAP_CLIENT, MAP_LISTS, MAP_HEADERS
     } k = ERR;
     CVal c;
     int field = 0;  // FIELD/LEN: PWAF_FIELD_*; INTVAR: IntVar
@@ -147,6 +147,13 @@ public:
     uint32_t max_dfa_states = 0, max_table_bytes = 0;
 
     // ---- atoms ----
+    int header_field(const std::string &name) {
+        for (size_t k = 0; k < prog.header_names.size(); k++)
+            if (prog.header_names[k] == name) return PWAF_N_FIELDS + (int)k;
+        if (prog.header_names.size() >= kMaxHeaders) throw Unsupported{"more than " + std::to_string(kMaxHeaders) + " distinct header names"};
+        prog.header_names.push_back(name);
+        return PWAF_N_FIELDS + (int)prog.header_names.size() - 1;
+    }
     int intern_atom(Atom &&a) {
         auto it = atom_index.find(a.key);
         if (it != atom_index.end()) return it->second;
@@ -469,13 +476,15 @@ public:
             }
             throw Unsupported{"membership test of this value in a list"};
         }
-        if (is_const(coll, CVal::Map) || coll.k == SVal::MAP_HTTP || coll.k == SVal::MAP_CLIENT || coll.k == SVal::MAP_LISTS) {
+        if (is_const(coll, CVal::Map) || coll.k == SVal::MAP_HTTP || coll.k == SVal::MAP_CLIENT || coll.k == SVal::MAP_LISTS || coll.k == SVal::MAP_HEADERS) {
             if (!is_const(x, CVal::Str)) {
                 if (x.k == SVal::CONST) return sv_err("map keys are Strings");
                 if (is_dyn_string(x)) throw Unsupported{"map key lookup with a request field"};
                 return sv_err("map keys are Strings");
             }
-            if (coll.k == SVal::MAP_HTTP) { for (auto f : kFieldNames) if (x.c.s == f) return sv_bool(true); return sv_bool(false); }
+            if (coll.k == SVal::MAP_HTTP) { for (auto f : kFieldNames) if (x.c.s == f) return sv_bool(true); return sv_bool(x.c.s == "headers"); }
+            // (the headers map holds exactly the names the rule set mentions: asking for one makes it one of them)
+            if (coll.k == SVal::MAP_HEADERS) { header_field(x.c.s); return sv_bool(true); }
             if (coll.k == SVal::MAP_CLIENT) return sv_bool(x.c.s == "ip" || x.c.s == "remote_port" || x.c.s == "asn" || x.c.s == "country");
             if (coll.k == SVal::MAP_LISTS) { for (auto &l : lists) if (l.name == x.c.s) return sv_bool(true); return sv_bool(false); }
             for (auto &p : coll.c.pairs) if (p.first == x.c.s) return sv_bool(true);
@@ -568,7 +577,7 @@ public:
                 if (o.k == SVal::ERR) return o;
                 SVal i = lower(e.kids[1]);
                 if (i.k == SVal::ERR) return i;
-                if (o.k == SVal::MAP_HTTP || o.k == SVal::MAP_CLIENT || o.k == SVal::MAP_LISTS || is_const(o, CVal::Map)) {
+                if (o.k == SVal::MAP_HTTP || o.k == SVal::MAP_CLIENT || o.k == SVal::MAP_LISTS || o.k == SVal::MAP_HEADERS || is_const(o, CVal::Map)) {
                     if (is_const(i, CVal::Str)) return select(o, i.c.s);
                     if (is_dyn_string(i)) throw Unsupported{"map index computed from a request field"};
                     return sv_err("map keys are Strings");
@@ -672,7 +681,14 @@ public:
         if (o.k == SVal::MAP_HTTP) {
             for (int f = 0; f < 5; f++)
                 if (key == kFieldNames[f]) { v.k = SVal::FIELD; v.field = f; return v; }
+            if (key == "headers") { v.k = SVal::MAP_HEADERS; return v; }
             return sv_err("no such key: " + key);
+        }
+        if (o.k == SVal::MAP_HEADERS) {
+            // EXTENSION (no reference counterpart, pingoo/rules.rs:16-25): one more String field per header name
+            v.k = SVal::FIELD;
+            v.field = header_field(key);
+            return v;
         }
         if (o.k == SVal::MAP_CLIENT) {
             if (key == "ip") { v.k = SVal::IPVAR; return v; }
@@ -711,7 +727,7 @@ public:
                 return string_fn(F_CONTAINS, recv, args[0]);
             }
             if (recv.k == SVal::LISTREF || is_const(recv, CVal::List)) return membership(recv, args[0]);
-            if (is_const(recv, CVal::Map) || recv.k == SVal::MAP_HTTP || recv.k == SVal::MAP_CLIENT || recv.k == SVal::MAP_LISTS) return membership(recv, args[0]);
+            if (is_const(recv, CVal::Map) || recv.k == SVal::MAP_HTTP || recv.k == SVal::MAP_CLIENT || recv.k == SVal::MAP_LISTS || recv.k == SVal::MAP_HEADERS) return membership(recv, args[0]);
             return sv_err("contains: unsupported receiver type");
         }
         if (f == "starts_with" || f == "ends_with") {
@@ -726,7 +742,8 @@ public:
             if (is_const(recv, CVal::List)) return sv_int((int64_t)recv.c.items.size());
             if (is_const(recv, CVal::Map)) return sv_int((int64_t)recv.c.pairs.size());
             if (recv.k == SVal::LISTREF) return sv_int((int64_t)lists[(size_t)recv.list].size());
-            if (recv.k == SVal::MAP_HTTP) return sv_int(5);
+            if (recv.k == SVal::MAP_HTTP) return sv_int(6);  // host, url, path, method, user_agent + the headers map (extension)
+            if (recv.k == SVal::MAP_HEADERS) throw Unsupported{"length() of the headers map (it holds the names the whole rule set mentions)"};
             if (recv.k == SVal::MAP_CLIENT) return sv_int(4);
             if (recv.k == SVal::MAP_LISTS) { std::set<std::string> names; for (auto &l : lists) names.insert(l.name); return sv_int((int64_t)names.size()); }
             return sv_err("length: unsupported receiver type");
@@ -774,9 +791,9 @@ public:
                 if (con->c.k == CVal::Float) return fin(int_cmp_double(*dyn, OP_EQ, con->c.f));
                 return sv_bool(negate);
             }
-            if (dyn->k == SVal::IPVAR || dyn->k == SVal::LISTREF || dyn->k == SVal::NETCONST || dyn->k == SVal::MAP_HTTP || dyn->k == SVal::MAP_CLIENT || dyn->k == SVal::MAP_LISTS) {
+            if (dyn->k == SVal::IPVAR || dyn->k == SVal::LISTREF || dyn->k == SVal::NETCONST || dyn->k == SVal::MAP_HTTP || dyn->k == SVal::MAP_CLIENT || dyn->k == SVal::MAP_LISTS || dyn->k == SVal::MAP_HEADERS) {
                 if (dyn->k == SVal::LISTREF && con->c.k == CVal::List) throw Unsupported{"comparison of a configured list with a list literal"};
-                if ((dyn->k == SVal::MAP_HTTP || dyn->k == SVal::MAP_CLIENT || dyn->k == SVal::MAP_LISTS) && con->c.k == CVal::Map) throw Unsupported{"comparison of a context map with a map literal"};
+                if ((dyn->k == SVal::MAP_HTTP || dyn->k == SVal::MAP_CLIENT || dyn->k == SVal::MAP_LISTS || dyn->k == SVal::MAP_HEADERS) && con->c.k == CVal::Map) throw Unsupported{"comparison of a context map with a map literal"};
                 return sv_bool(negate);
             }
         }
@@ -846,7 +863,7 @@ public:
             case B_GT: return ordering(l, r, OP_GT);
             case B_GE: return ordering(l, r, OP_GE);
             case B_IN: {
-                if (r.k == SVal::LISTREF || is_const(r, CVal::List) || is_const(r, CVal::Map) || r.k == SVal::MAP_HTTP || r.k == SVal::MAP_CLIENT || r.k == SVal::MAP_LISTS)
+                if (r.k == SVal::LISTREF || is_const(r, CVal::List) || is_const(r, CVal::Map) || r.k == SVal::MAP_HTTP || r.k == SVal::MAP_CLIENT || r.k == SVal::MAP_LISTS || r.k == SVal::MAP_HEADERS)
                     return membership(r, l);
                 return sv_err("in: right operand must be a List or Map");
             }
@@ -1114,7 +1131,8 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // an L2-resident table allows (hot rows are cached in LDS by the kernel), not what fits LDS. Patterns with an
     // unbounded wide-class repetition in the middle (".*") multiply states with each other, so when the joint DFA
     // explodes they are isolated into small groups of their own.
-    for (int f = 0; f < PWAF_N_FIELDS; f++) {
+    auto field_name = [&](int f) { return f < PWAF_N_FIELDS ? std::string(kFieldNames[f]) : "headers[\"" + P.header_names[(size_t)f - PWAF_N_FIELDS] + "\"]"; };
+    for (int f = 0; f < PWAF_N_FIELDS + (int)P.header_names.size(); f++) {
         std::vector<ScanPattern> pats;
         for (size_t a = 1; a < P.atoms.size(); a++)
             if (used[a] && P.atoms[a].kind == ATOM_SCAN && P.atoms[a].field == f) pats.push_back({P.atoms[a].pattern, (uint32_t)a});
@@ -1139,7 +1157,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                 continue;
             }
             if (cur.size() == 1) {
-                set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, std::string("a pattern on http_request.") + kFieldNames[f] + " needs a DFA beyond the state/table budget: " + derr);
+                set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, std::string("a pattern on http_request.") + field_name(f) + " needs a DFA beyond the state/table budget: " + derr);
                 return PWAF_E_UNSUPPORTED;
             }
             std::vector<ScanPattern> gap, plain;
@@ -1187,8 +1205,8 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         for (uint32_t fa : g.filter_atoms) g.filter_cols.push_back(P.atoms[fa].id);
     P.n_scan_cols = next_col - scan_base;
     P.n_cols = next_col;
-    if (P.groups.size() > 64) {
-        set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "the rule set needs more than 64 scan passes");
+    if (P.groups.size() > kMaxGroups) {
+        set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "the rule set needs more than " + std::to_string(kMaxGroups) + " scan passes");
         return PWAF_E_UNSUPPORTED;
     }
     if (P.n_cols >= LIT_ATOM_MASK) {
@@ -1363,6 +1381,11 @@ std::vector<uint8_t> dump_program(const Program &p) {
             w.section("GFHD", (uint32_t)gi, fh.data(), fh.size());
             w.section("GFTB", (uint32_t)gi, g.filter.table.data(), g.filter.table.size() * 4);
         }
+    }
+    {
+        std::string names;
+        for (auto &h : p.header_names) { names += h; names += '\0'; }
+        w.section("HDRS", (uint32_t)p.header_names.size(), names.data(), names.size());
     }
     w.section("NUMA", (uint32_t)p.num_atoms.size(), p.num_atoms.data(), p.num_atoms.size() * sizeof(NumAtomDev));
     w.section("INTP", (uint32_t)p.int_pool.size(), p.int_pool.data(), p.int_pool.size() * 8);

@@ -119,10 +119,15 @@ struct pwaf_engine {
     uint32_t n_need = 0;
     DevBuf visit_bits;          // per gap pass: visited bitmap
     uint32_t n_visit = 0;
-    double mean_len[PWAF_N_FIELDS] = {0, 0, 0, 0, 0};  // from the tuning sample (0 = unknown)
+    std::vector<double> mean_len;  // per field, from the tuning sample (0 = unknown)
     uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
-    unsigned long long select_pass_mask = 0;
-    DevBuf stage_field_data[PWAF_N_FIELDS], stage_field_off[PWAF_N_FIELDS];
+    std::vector<uint8_t> owns_factors;  // per pass: some of its atoms are prefilter factors of gap passes
+    uint32_t n_gap = 0;                 // gated gap passes (list slots [0, kGapLists), one factor-mask bit each)
+    DevBuf pass_table;                  // PassInfo per pass
+    std::vector<uint32_t> hlen_fields;  // header columns whose length some rule compares (comparison variable 7 + k)
+    DevBuf zero_off;                    // n + 1 zero offsets: the column of a header the batch does not carry
+    uint32_t n_fields = PWAF_N_FIELDS;  // 5 + header columns
+    std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // profiling
     bool profiling = false;
@@ -323,28 +328,32 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
 int assign_lists(pwaf_engine *e) {
     const Program &P = *e->prog.p;
     int rc;
-    e->n_gated = e->n_filtered = 0;
-    e->select_pass_mask = 0;
+    e->n_gated = e->n_filtered = e->n_gap = 0;
+    e->owns_factors.assign(P.groups.size(), 0);
     std::vector<uint32_t> colmask(P.n_cols, 0);
+    // list slots: gated gap passes own slots [0, kGapLists) — their index is also their bit in the factor masks — and every
+    // filtered pass one slot after those
     for (size_t k = 0; k < P.groups.size(); k++) {
         DevGroup &d = e->groups[k];
         d.gate = -1;
         d.filtered = false;
         const bool gap = !P.groups[k].filter_cols.empty();
-        if ((!gap && !d.filter.enabled) || e->n_gated >= 32) continue;  // (beyond 32 lists the rest simply walk every request)
-        d.gate = (int)e->n_gated;
         if (gap) {
-            for (uint32_t c : P.groups[k].filter_cols) colmask[c] |= 1u << e->n_gated;
-        } else {
+            if (e->n_gap >= kGapLists) continue;  // (beyond 32 gap passes the rest simply walk every request)
+            d.gate = (int)e->n_gap;
+            for (uint32_t c : P.groups[k].filter_cols) colmask[c] |= 1u << e->n_gap;
+            e->n_gap++;
+        } else if (d.filter.enabled) {
+            d.gate = (int)(kGapLists + e->n_filtered);
             d.filtered = true;
             e->n_filtered++;
             if ((rc = upload(d.ftable, d.filter.table))) return rc;
         }
-        e->n_gated++;
     }
-    for (size_t k = 0; k < P.groups.size() && k < 64; k++)
+    e->n_gated = e->n_gap || e->n_filtered ? kGapLists + e->n_filtered : 0;
+    for (size_t k = 0; k < P.groups.size(); k++)
         for (uint32_t c = P.groups[k].atom_base; c < P.groups[k].atom_base + P.groups[k].n_local; c++)
-            if (colmask[c]) e->select_pass_mask |= 1ull << k;
+            if (colmask[c]) e->owns_factors[k] = 1;
     // gap passes whose factors all live in ONE filtered pass walk that pass's candidate list (no atomics, no list of their own)
     e->n_need = e->n_visit = 0;
     for (auto &d : e->groups) { d.share_owner = -1; d.shared_bits = 0; d.need_slot = -1; d.visit_slot = -1; d.identity = false; }
@@ -352,7 +361,7 @@ int assign_lists(pwaf_engine *e) {
         DevGroup &d = e->groups[k];
         if (d.gate >= 0 && !d.filtered) d.visit_slot = (int)e->n_visit++;
         // a plain pass over a field of a few bytes: the streaming DFA kernel's per-request machinery costs more than the walk itself
-        const double ml = e->mean_len[P.groups[k].field];
+        const double ml = P.groups[k].field < e->mean_len.size() ? e->mean_len[P.groups[k].field] : 0.0;
         if (d.gate < 0 && (P.groups[k].field == PWAF_FIELD_METHOD ? (ml == 0 || ml < 12) : (ml > 0 && ml < 12))) d.identity = true;
     }
     for (size_t k = 0; k < P.groups.size(); k++) {
@@ -371,6 +380,24 @@ int assign_lists(pwaf_engine *e) {
         d.share_owner = owner;
         e->groups[owner].shared_bits |= 1u << d.gate;
         if (e->groups[owner].need_slot < 0) e->groups[owner].need_slot = (int)e->n_need++;
+    }
+    {
+        // the verdict kernel's pass table: first column + where the pass's visited bitmap lives
+        std::vector<PassInfo> pt(std::max<size_t>(1, e->groups.size()));
+        uint32_t fi = 0;
+        for (size_t k = 0; k < e->groups.size(); k++) {
+            const DevGroup &d = e->groups[k];
+            pt[k].base = d.atom_base;
+            pt[k].kind_slot = 0;
+            if (d.filtered) {
+                // (a pass with heads writes records outside its candidate list too: its records are zeroed and read densely)
+                if (d.filter.heads.empty()) pt[k].kind_slot = (1u << 24) | fi;
+                fi++;
+            } else if (d.visit_slot >= 0) {
+                pt[k].kind_slot = (2u << 24) | (uint32_t)d.visit_slot;
+            }
+        }
+        if ((rc = upload(e->pass_table, pt))) return rc;
     }
     return upload(e->colmask, colmask);
 }
@@ -392,8 +419,42 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms);
     if ((rc = e->attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
-    if ((rc = e->ctrl.reserve(4 * 34))) return rc;
-    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * 34, stream));
+    const size_t ctrl_words = 2 + (size_t)std::max(kGapLists, e->n_gated);  // [0] pool allocator, [1] status word, then one length per list slot
+    if ((rc = e->ctrl.reserve(4 * ctrl_words))) return rc;
+    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * ctrl_words, stream));
+    // string columns by field id: the five fixed fields, then one column per header name the rule set mentions (EXTENSION); a header
+    // the batch does not carry reads as the empty string for every request
+    std::vector<pwaf_strcol> cols(e->n_fields);
+    std::vector<uint32_t> col_bytes(e->n_fields, 0);
+    for (int f = 0; f < PWAF_N_FIELDS; f++) {
+        cols[(size_t)f] = db.field[f];
+        col_bytes[(size_t)f] = db.field_bytes[f];
+    }
+    bool missing_header = false;
+    for (uint32_t f = PWAF_N_FIELDS; f < e->n_fields; f++) {
+        const uint32_t k = f - PWAF_N_FIELDS;
+        if (k < db.n_headers && db.headers != nullptr && db.headers[k].data != nullptr && db.headers[k].offsets != nullptr) {
+            cols[f] = db.headers[k];
+            col_bytes[f] = db.header_bytes ? db.header_bytes[k] : 0u;
+        } else {
+            missing_header = true;
+        }
+    }
+    if (missing_header) {
+        if (e->zero_off.cap < (size_t)(n + 1) * 4 + PWAF_ARENA_PAD) {
+            if ((rc = e->zero_off.reserve((size_t)(n + 1) * 4 + PWAF_ARENA_PAD))) return rc;
+            HIP_TRY(hipMemsetAsync(e->zero_off.p, 0, e->zero_off.cap, stream));
+        }
+        for (uint32_t f = PWAF_N_FIELDS; f < e->n_fields; f++)
+            if (cols[f].data == nullptr) {
+                cols[f].data = (const uint8_t *)e->zero_off.p;
+                cols[f].offsets = (const uint32_t *)e->zero_off.p;
+                col_bytes[f] = 0;
+            }
+    }
+    std::vector<uint8_t> col_known(e->n_fields, totals_known ? 1 : 0);
+    for (uint32_t f = 0; f < e->n_fields; f++)
+        if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)e->zero_off.p) col_known[f] = 1;
     if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
     if (e->n_need && (rc = e->need.reserve((size_t)e->n_need * n * 4))) return rc;
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
@@ -462,22 +523,14 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_cols = P.n_cols;
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)e->rec.p;
-    for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) v.pass_base_v[k] = e->groups[k].atom_base;
-    {
-        uint32_t fi = 0;
-        for (size_t k = 0; k < e->groups.size() && k < (size_t)kMaxPasses; k++) {
-            const DevGroup &d = e->groups[k];
-            v.pass_bits[k] = nullptr;
-            if (d.filtered) {
-                // a pass with heads writes records outside its candidate list too: its records are zeroed and read densely
-                if (d.filter.heads.empty()) v.pass_bits[k] = (const uint32_t *)e->cand_bits.p + (size_t)fi * bit_words;
-                else HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
-                fi++;
-            } else if (d.visit_slot >= 0) {
-                v.pass_bits[k] = (const uint32_t *)e->visit_bits.p + (size_t)d.visit_slot * bit_words;
-            }
-        }
-    }
+    v.passes = (const PassInfo *)e->pass_table.p;
+    v.cand_bits = (const uint32_t *)e->cand_bits.p;
+    v.visit_bits = (const uint32_t *)e->visit_bits.p;
+    v.bit_words = bit_words;
+    for (size_t k = 0; k < e->groups.size(); k++)  // a pass with heads writes records outside its candidate list too: zeroed, read densely
+        if (e->groups[k].filtered && !e->groups[k].filter.heads.empty()) HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
+    v.n_hlen = (uint32_t)e->hlen_fields.size();
+    for (size_t k = 0; k < e->hlen_fields.size(); k++) v.hoff[k] = cols[e->hlen_fields[k]].offsets;
     v.gpairs = (uint4 *)e->attr.p;
     v.ghdr = (uint32_t *)((char *)e->attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
     v.pair_stride = pair_stride;
@@ -529,15 +582,15 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     auto scan_args = [&](size_t gi) -> ScanArgs {
         const DevGroup &d = e->groups[gi];
         ScanArgs a{};
-        if (e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+        if (e->n_gap && e->owns_factors[gi]) {
             // this pass owns prefilter factors: it feeds the gated gap passes' request lists as requests finish
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
             a.n_local = d.n_local;
             a.gate_lists = (uint32_t *)e->gate_lists.p;
             a.gate_count = (uint32_t *)e->ctrl.p + 2;
         }
-        a.data = db.field[d.field].data;
-        a.off = db.field[d.field].offsets;
+        a.data = cols[d.field].data;
+        a.off = cols[d.field].offsets;
         a.n = n;
         a.tab = (const uint16_t *)d.tab.p;
         a.classmap = (const uint8_t *)d.classmap.p;
@@ -573,7 +626,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             a.need_in = (const uint32_t *)e->need.p + (size_t)src.need_slot * n;
             a.need_bit = (uint32_t)d.gate;
         }
-        if (e->n_gated && gi < 64 && ((e->select_pass_mask >> gi) & 1ull)) {
+        if (e->n_gap && e->owns_factors[gi]) {
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
             a.n_local = d.n_local;
             a.gate_lists = (uint32_t *)e->gate_lists.p;
@@ -583,8 +636,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
                 a.shared_bits = d.shared_bits;
             }
         }
-        a.data = db.field[d.field].data;
-        a.off = db.field[d.field].offsets;
+        a.data = cols[d.field].data;
+        a.off = cols[d.field].offsets;
         a.n = n;
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
@@ -607,25 +660,24 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         if (d.gate >= 0 || d.identity) continue;
         const ScanArgs a = scan_args(gi);
         char nm[48];
-        snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
+        if (d.field < PWAF_N_FIELDS) snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
+        else snprintf(nm, sizeof nm, "scan_hdr%u_g%zu", d.field - PWAF_N_FIELDS, gi);
         if ((rc = mark(nullptr, 0))) return rc;
         int he = launch_scan(a, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        if ((rc = mark(nm, (uint64_t)d.field))) return rc;  // alg_bytes slot carries the field id; bench.py supplies bytes
+        if ((rc = mark(nm, (uint64_t)col_bytes[d.field] + 4ull * (n + 1)))) return rc;  // algorithmic bytes: the field's bytes + its offsets (0 bytes when the arena size is unknown)
     }
     // ---- 2. bigram prefilters of every filtered pass in one launch (the arenas as flat byte streams), hit segments -> candidate
     //         bitmaps, bitmaps -> dense request lists ----
     if (e->n_filtered) {
         // arena sizes: a host batch's offsets were read while staging; a device batch says so itself or is asked (one small copy)
-        uint32_t totals[PWAF_N_FIELDS];
+        std::vector<uint32_t> &totals = col_bytes;
         bool ask = false;
-        for (int f = 0; f < PWAF_N_FIELDS; f++) {
-            totals[f] = db.field_bytes[f];
-            if (!totals[f] && !totals_known) ask = true;
-        }
+        for (const DevGroup &d : e->groups)
+            if (d.filtered && !col_known[d.field]) ask = true;
         if (ask) {
-            for (int f = 0; f < PWAF_N_FIELDS; f++)
-                if (!totals[f]) HIP_TRY(hipMemcpyAsync(&totals[f], db.field[f].offsets + n, 4, hipMemcpyDeviceToHost, stream));
+            for (const DevGroup &d : e->groups)
+                if (d.filtered && !col_known[d.field]) HIP_TRY(hipMemcpyAsync(&totals[d.field], cols[d.field].offsets + n, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
         const uint32_t words = (n + 31) / 32, n_cblocks = (words + kCompactWords - 1) / kCompactWords;
@@ -639,7 +691,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         if ((rc = e->cand_sub.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = e->cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
         FilterBatchArgs fb{};
-        uint32_t fi = 0, block = 0, field_mask = 0;
+        uint32_t fi = 0, block = 0;
+        uint64_t alg_bytes = 0;
         uint64_t sub_at = 0, cnt_at = 0;
         auto flush_filters = [&]() -> int {
             if (fb.count == 0) return PWAF_OK;
@@ -647,7 +700,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             if ((rc2 = mark(nullptr, 0))) return rc2;
             int he = launch_filter(fb, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc2 = mark("filter", 0x100u | field_mask))) return rc2;  // alg_bytes slot: 0x100 | mask of the fields streamed
+            if ((rc2 = mark("filter", alg_bytes))) return rc2;  // algorithmic bytes: every streamed arena once + its offsets
             if ((rc2 = mark(nullptr, 0))) return rc2;
             he = launch_resolve(fb, stream);
             if (!he) he = launch_compact(fb, stream);
@@ -655,7 +708,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             if ((rc2 = mark("resolve+compact", 0xFCu))) return rc2;
             fb.count = 0;
             block = 0;
-            field_mask = 0;
+            alg_bytes = 0;
             return PWAF_OK;
         };
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
@@ -663,8 +716,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             if (!d.filtered) continue;
             FilterArgs &f = fb.f[fb.count++];
             f = FilterArgs{};
-            f.data = db.field[d.field].data;
-            f.off = db.field[d.field].offsets;
+            f.data = cols[d.field].data;
+            f.off = cols[d.field].offsets;
             f.n = n;
             f.total = totals[d.field];
             f.init = d.filter.init;
@@ -692,7 +745,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
             cnt_at += slabs + n_cblocks;
             block += (slabs + kFilterWaves - 1) / kFilterWaves;
-            field_mask |= 1u << d.field;
+            alg_bytes += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
             if (fb.count == kMaxFiltersPerLaunch && (rc = flush_filters())) return rc;
         }
@@ -856,6 +909,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
         return dev_fail(PWAF_E_DEVICE);
     }
+    e->n_fields = PWAF_N_FIELDS + (uint32_t)P.header_names.size();
+    e->mean_len.assign(e->n_fields, 0.0);
     e->groups.resize(P.groups.size());
     std::vector<uint32_t> pass_base;
     for (size_t k = 0; k < P.groups.size(); k++) {
@@ -899,13 +954,13 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         std::vector<NumAtomDev> cmp_src;
         std::vector<uint32_t> bit_atoms;
         if (P.n_cols >= (1u << 20)) { fail(PWAF_E_UNSUPPORTED, "more than 2^20 predicate columns"); return dev_fail(PWAF_E_UNSUPPORTED); }
-        if (P.set_words > 8) { fail(PWAF_E_UNSUPPORTED, "more than 256 ip lists"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        if (P.set_words > kSetWordsMax) { fail(PWAF_E_UNSUPPORTED, "more than 512 ip lists"); return dev_fail(PWAF_E_UNSUPPORTED); }
         if (P.country_luts.size() > 256) { fail(PWAF_E_UNSUPPORTED, "more than 256 distinct client.country predicates"); return dev_fail(PWAF_E_UNSUPPORTED); }
         for (auto &d : atoms) {
             uint32_t src;
             if (d.kind == ATOM_IPSET) src = d.ref >> 5;
-            else if (d.kind == ATOM_COUNTRY) src = 8 + (d.ref >> 5);
-            else if (d.kind == ATOM_INTSET) src = 16 + 4 * d.var + (d.ref >> 5);
+            else if (d.kind == ATOM_COUNTRY) src = kSrcCc + (d.ref >> 5);
+            else if (d.kind == ATOM_INTSET) src = (d.var == 0 ? kSrcPort : kSrcAsn) + (d.ref >> 5);
             else {
                 cmp_src.push_back(d);
                 continue;
@@ -914,7 +969,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         }
         e->n_bit_atoms = (uint32_t)bit_atoms.size();
         // (source word, bit) -> column
-        std::vector<uint32_t> bit_col(28 * 32, 0);
+        std::vector<uint32_t> bit_col(kSrcWords * 32, 0);
         for (uint32_t d : bit_atoms) bit_col[(d >> 25) * 32 + ((d >> 20) & 31u)] = d & 0xFFFFFu;
         // Comparison atoms in the canonical form the kernel evaluates: variable (0-4 field lengths, 5 remote_port, 6 asn) against
         // a 32-bit constant with == or <=. Lengths, ports and ASNs are unsigned 32-bit, so constants outside [0, 2^32) fold to
@@ -922,8 +977,17 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         struct Canon { uint32_t vi, op, col, c; };
         std::vector<Canon> canon;
         for (const NumAtomDev &d : cmp_src) {
-            const uint32_t vi = d.kind == ATOM_LEN ? d.var : 5u + d.var;
-            if (vi > 6 || (d.kind == ATOM_LEN && d.var > 4)) { fail(PWAF_E_UNSUPPORTED, "comparison atom on an unknown variable"); return dev_fail(PWAF_E_UNSUPPORTED); }
+            uint32_t vi;
+            if (d.kind == ATOM_LEN && d.var >= PWAF_N_FIELDS) {
+                // length of a header column: comparison variable 7 + k for the k-th such column
+                size_t slot = std::find(e->hlen_fields.begin(), e->hlen_fields.end(), (uint32_t)d.var) - e->hlen_fields.begin();
+                if (slot == e->hlen_fields.size()) e->hlen_fields.push_back(d.var);
+                if (slot >= kMaxHeaderLens) { fail(PWAF_E_UNSUPPORTED, "length() of more than 8 distinct headers is compared"); return dev_fail(PWAF_E_UNSUPPORTED); }
+                vi = 7u + (uint32_t)slot;
+            } else {
+                vi = d.kind == ATOM_LEN ? d.var : 5u + d.var;
+                if (vi > 6) { fail(PWAF_E_UNSUPPORTED, "comparison atom on an unknown variable"); return dev_fail(PWAF_E_UNSUPPORTED); }
+            }
             int64_t c = d.c;
             uint32_t op;  // 0: ==, 1: <=
             if (d.op == OP_EQ) {
@@ -950,7 +1014,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                 // (source words 24..27) when the engine resolves the record itself
                 const uint32_t j = (uint32_t)e->host_acmp.size();
                 if (j >= 128) { fail(PWAF_E_UNSUPPORTED, "more than 128 distinct client.asn comparisons"); return dev_fail(PWAF_E_UNSUPPORTED); }
-                bit_col[(24 + j / 32) * 32 + (j & 31)] = cn.col;
+                bit_col[(kSrcAcmp + j / 32) * 32 + (j & 31)] = cn.col;
                 e->host_acmp.push_back({cn.op, cn.c});
             }
         }
@@ -1092,7 +1156,10 @@ void pwaf_engine_destroy(pwaf_engine *e) {
                       &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->cand_bits, &e->need, &e->visit_bits, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
                       &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
         b->release();
-    for (int f = 0; f < PWAF_N_FIELDS; f++) { e->stage_field_data[f].release(); e->stage_field_off[f].release(); }
+    for (auto &b : e->stage_field_data) b.release();
+    for (auto &b : e->stage_field_off) b.release();
+    e->pass_table.release();
+    e->zero_off.release();
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->side) (void)hipStreamDestroy(e->side);
@@ -1102,6 +1169,10 @@ void pwaf_engine_destroy(pwaf_engine *e) {
 }
 
 const pwaf_program *pwaf_engine_program(const pwaf_engine *e) { return e ? &e->prog : nullptr; }
+uint32_t pwaf_program_header_count(const pwaf_program *p) { return p ? (uint32_t)p->p->header_names.size() : 0u; }
+const char *pwaf_program_header_name(const pwaf_program *p, uint32_t i) { return (p && i < p->p->header_names.size()) ? p->p->header_names[i].c_str() : ""; }
+uint32_t pwaf_engine_header_count(const pwaf_engine *e) { return e ? pwaf_program_header_count(&e->prog) : 0u; }
+const char *pwaf_engine_header_name(const pwaf_engine *e, uint32_t i) { return e ? pwaf_program_header_name(&e->prog, i) : ""; }
 void *pwaf_engine_stream(const pwaf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
@@ -1143,8 +1214,17 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     }
     // HOST batch: validate what a device cannot report, stage, run, copy back
     const uint32_t n = in->n;
-    for (int f = 0; f < PWAF_N_FIELDS; f++) {
-        const uint32_t *o = in->field[f].offsets;
+    // host view of every string column by field id (five fields + the header columns the batch carries; the others read as "")
+    const uint32_t n_hdr_in = in->headers ? std::min<uint32_t>(in->n_headers, e->n_fields - PWAF_N_FIELDS) : 0u;
+    auto host_col = [&](uint32_t f) -> const pwaf_strcol * {
+        if (f < PWAF_N_FIELDS) return &in->field[f];
+        const uint32_t k = f - PWAF_N_FIELDS;
+        return (k < n_hdr_in && in->headers[k].data && in->headers[k].offsets) ? &in->headers[k] : nullptr;
+    };
+    for (uint32_t f = 0; f < e->n_fields; f++) {
+        const pwaf_strcol *c = host_col(f);
+        if (!c) continue;
+        const uint32_t *o = c->offsets;
         for (uint32_t i = 0; i < n; i++)
             if (o[i + 1] < o[i]) return fail(PWAF_E_BATCH, "field offsets are not monotone");
     }
@@ -1159,20 +1239,32 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     hipStream_t s = e->stream;
     pwaf_batch db = *in;
     db.memory = PWAF_MEM_DEVICE;
-    for (int f = 0; f < PWAF_N_FIELDS; f++) {
-        const uint32_t *o = in->field[f].offsets;
-        size_t lo = o[0], hi = o[n];
+    if (e->stage_field_data.size() < e->n_fields) { e->stage_field_data.resize(e->n_fields); e->stage_field_off.resize(e->n_fields); }
+    std::vector<pwaf_strcol> hdr_cols(e->n_fields - PWAF_N_FIELDS, pwaf_strcol{nullptr, nullptr});
+    std::vector<uint32_t> hdr_bytes(e->n_fields - PWAF_N_FIELDS, 0);
+    for (uint32_t f = 0; f < e->n_fields; f++) {
+        const pwaf_strcol *c = host_col(f);
+        if (!c) continue;
+        const uint32_t *o = c->offsets;
+        const size_t hi = o[n];
         // the device arena is re-based so that offsets can be used unchanged: copy [0, hi)
-        (void)lo;
         if ((rc = e->stage_field_data[f].reserve(hi + PWAF_ARENA_PAD))) return rc;
         if ((rc = e->stage_field_off[f].reserve((size_t)(n + 1) * 4))) return rc;
-        if (hi) HIP_TRY(hipMemcpyAsync(e->stage_field_data[f].p, in->field[f].data, hi, hipMemcpyHostToDevice, s));
+        if (hi) HIP_TRY(hipMemcpyAsync(e->stage_field_data[f].p, c->data, hi, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync((char *)e->stage_field_data[f].p + hi, 0, PWAF_ARENA_PAD, s));
         HIP_TRY(hipMemcpyAsync(e->stage_field_off[f].p, o, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
-        db.field[f].data = (const uint8_t *)e->stage_field_data[f].p;
-        db.field[f].offsets = (const uint32_t *)e->stage_field_off[f].p;
-        db.field_bytes[f] = (uint32_t)hi;
+        const pwaf_strcol dc{(const uint8_t *)e->stage_field_data[f].p, (const uint32_t *)e->stage_field_off[f].p};
+        if (f < PWAF_N_FIELDS) {
+            db.field[f] = dc;
+            db.field_bytes[f] = (uint32_t)hi;
+        } else {
+            hdr_cols[f - PWAF_N_FIELDS] = dc;
+            hdr_bytes[f - PWAF_N_FIELDS] = (uint32_t)hi;
+        }
     }
+    db.headers = hdr_cols.empty() ? nullptr : hdr_cols.data();
+    db.header_bytes = hdr_bytes.empty() ? nullptr : hdr_bytes.data();
+    db.n_headers = (uint32_t)hdr_cols.size();
     auto stage = [&](DevBuf &b, const void *src, size_t bytes, const void **dst) -> int {
         int r = b.reserve(bytes);
         if (r) return r;
@@ -1211,6 +1303,12 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     const Program &P = *e->prog.p;
     const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
     if (n == 0) return PWAF_OK;
+    // string column of a field id in the sample (header columns the sample does not carry are left untuned)
+    auto sample_col = [&](uint32_t f) -> const pwaf_strcol * {
+        if (f < PWAF_N_FIELDS) return &sample->field[f];
+        const uint32_t k = f - PWAF_N_FIELDS;
+        return (sample->headers && k < sample->n_headers && sample->headers[k].data && sample->headers[k].offsets) ? &sample->headers[k] : nullptr;
+    };
     // host walk of every pass over the sample: how often each DFA state is the current state, and for how many requests each
     // pattern holds (patterns that hold for most traffic must not sit behind the bigram prefilter)
     std::vector<std::vector<uint64_t>> visits(P.groups.size()), class_freq(P.groups.size()), atom_hits(P.groups.size());
@@ -1223,8 +1321,10 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         std::vector<uint64_t> &ah = atom_hits[k];
         ah.assign(g.n_local, 0);
         std::vector<uint32_t> stamp(g.n_local, 0);
-        const uint8_t *data = sample->field[g.field].data;
-        const uint32_t *off = sample->field[g.field].offsets;
+        const pwaf_strcol *sc = sample_col(g.field);
+        if (!sc) continue;
+        const uint8_t *data = sc->data;
+        const uint32_t *off = sc->offsets;
         for (uint32_t i = 0; i < n; i++) {
             if (off[i + 1] < off[i]) return fail(PWAF_E_BATCH, "sample offsets are not monotonic");
             auto note = [&](const std::vector<uint32_t> &o, const std::vector<uint16_t> &l, uint32_t st) {
@@ -1247,16 +1347,18 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     // anchored literals the sample actually satisfies; a filter that would flag more than 40 % of the sample is dropped (the pass
     // then walks every request, as without a filter)
     if (!(P.flags & PWAF_OPT_NO_PREFILTER)) {
-        std::vector<double> bin_prob[PWAF_N_FIELDS];
-        double mean_len[PWAF_N_FIELDS];
-        for (int f = 0; f < PWAF_N_FIELDS; f++) {
+        std::vector<std::vector<double>> bin_prob(e->n_fields);
+        std::vector<double> mean_len(e->n_fields, 0.0);
+        for (uint32_t f = 0; f < e->n_fields; f++) {
+            const pwaf_strcol *c = sample_col(f);
+            bin_prob[f].assign(kFilterEntries, 0.0);
+            if (!c) continue;
             std::vector<uint64_t> cnt(kFilterEntries, 0);
             uint64_t tot = 0;
-            const uint8_t *data = sample->field[f].data;
-            const uint32_t *off = sample->field[f].offsets;
+            const uint8_t *data = c->data;
+            const uint32_t *off = c->offsets;
             for (uint32_t i = 0; i < n; i++)
                 for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[filter_bin(data[p], data[p + 1])]++; tot++; }
-            bin_prob[f].assign(kFilterEntries, 0.0);
             if (tot)
                 for (uint32_t b = 0; b < kFilterEntries; b++) bin_prob[f][b] = (double)cnt[b] / (double)tot;
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;
@@ -1270,10 +1372,12 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             h.n_requests = n;
             h.mean_len = mean_len[g.field];
             GroupFilter &gf = e->groups[k].filter;
+            const pwaf_strcol *sc = sample_col(g.field);
+            if (!sc) continue;
             build_group_filter(P.atoms, g, &h, gf);
             if (!gf.enabled) continue;
-            const uint8_t *data = sample->field[g.field].data;
-            const uint32_t *off = sample->field[g.field].offsets;
+            const uint8_t *data = sc->data;
+            const uint32_t *off = sc->offsets;
             uint64_t cand = 0;
             for (uint32_t i = 0; i < n; i++) cand += filter_candidate_host(gf, data + off[i], off[i + 1] - off[i]) ? 1u : 0u;
             gf.est_candidate_rate = (double)cand / (double)n;
@@ -1297,7 +1401,9 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         }
     }
     for (size_t k = 0; k < P.groups.size(); k++) {
-        const uint32_t *off = sample->field[P.groups[k].field].offsets;
+        const pwaf_strcol *sc = sample_col(P.groups[k].field);
+        if (!sc) continue;
+        const uint32_t *off = sc->offsets;
         const uint64_t total = (uint64_t)(off[n] - off[0]);
         const uint32_t t4 = 80u, t2 = 48u;  // mean field length from which a lane takes 4 / 2 chunks per iteration (measured)
         e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)t2 * n ? 2u : 1u;

@@ -6,7 +6,9 @@
 
 namespace pwaf {
 
-static constexpr int kMaxPasses = 64;
+static constexpr int kMaxPasses = 250;  // (= program.h kMaxGroups)
+static constexpr uint32_t kGapLists = 32;     // gated gap passes own list slots [0, 32) (one bit each in the factor masks); filtered passes follow
+static constexpr uint32_t kMaxHeaderLens = 8; // header columns whose LENGTH rules compare
 
 // Hit record of one (scan pass, request): what the request's field matched in that pass's DFA.
 //   bit 31 = 0: bits [14:0] = first local atom + 1 (0 = none), bits [29:15] = second local atom + 1 (0 = none)
@@ -146,6 +148,14 @@ int launch_compact(const FilterBatchArgs &b, void *stream);  // bitcount_kernel,
 // devices of one process each need it).
 int configure_kernels(int device);
 
+// Source words of the membership atoms of one request (bit_col maps (source word, bit) -> column): ip-list sets, country tables,
+// port sets, asn sets, asn comparisons.
+static constexpr uint32_t kSrcSet = 0, kSetWordsMax = 16, kSrcCc = 16, kCcWordsMax = 8, kSrcPort = 24, kSrcAsn = 28, kIntWordsMax = 4, kSrcAcmp = 32, kAcmpWordsMax = 4,
+                          kSrcWords = 36;
+struct PassInfo {
+    uint32_t base;       // first device column of the pass
+    uint32_t kind_slot;  // kind << 24 | slot
+};
 struct CmpAtomDev {
     uint32_t col, c;
 };
@@ -162,18 +172,23 @@ struct VerdictArgs {
     // scan results
     uint32_t n_passes;
     const uint32_t *rec;        // [n_passes][n]
-    uint32_t pass_base_v[kMaxPasses + 1];  // first column of each pass (in the kernel-argument block: scalar loads)
-    // A list-driven pass writes hit records only for the requests it visits; bit r of its VISITED bitmap says record r is valid
-    // (everything else reads as "nothing matched": no memset of 4 bytes per request and pass, no read of them here). Null = the
-    // pass writes (or the host zeroes) every record.
-    const uint32_t *pass_bits[kMaxPasses];
+    // Per pass (device table, read once per wave): first column, and where its VISITED bitmap lives. A list-driven pass writes hit
+    // records only for the requests it visits; bit r of the bitmap says record r is valid (everything else reads as "nothing
+    // matched": no memset of 4 bytes per request and pass, no read of them here). kind 0 = the pass writes (or the host zeroes)
+    // every record; 1 = bitmap `slot` of cand_bits (a filter's candidates); 2 = bitmap `slot` of visit_bits (a gap pass).
+    const PassInfo *passes;
+    const uint32_t *cand_bits, *visit_bits;
+    uint32_t bit_words;  // words per bitmap (2 per 64-request group)
+    // EXTENSION: header columns whose length is compared (comparison variable 7 + k)
+    const uint32_t *hoff[kMaxHeaderLens];
+    uint32_t n_hlen;
     const PoolEntry *pool;
     // compiled program
     uint32_t n_cols;
     const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant): col = column | code << 24 with
                                   // code = 2 * variable (0-4 field lengths, 5 port, 6 asn) + operator (0: ==, 1: <=)
     uint32_t n_cmp;
-    const uint32_t *bit_col;      // [28 source words][32 bits] -> column of the membership atom, 0 = none
+    const uint32_t *bit_col;      // [kSrcWords source words][32 bits] -> column of the membership atom, 0 = none
     // integer sets, merged per variable (0 = remote_port, 1 = asn): sorted distinct values + membership rows (row 0 = miss)
     const int64_t *iu_vals[2];
     const uint32_t *iu_masks[2];

@@ -939,15 +939,26 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     struct Bits {
         uint32_t lo[kPre], hi[kPre];
     };
+    // the pass table is read once per wave (group-invariant)
+    auto pass_bitmap = [&](const uint32_t ps) -> const uint32_t * {
+        const uint32_t ks = a.passes[ps].kind_slot, kind = ks >> 24, slot = ks & 0xFFFFFFu;
+        return kind == 1 ? a.cand_bits + (size_t)slot * a.bit_words : kind == 2 ? a.visit_bits + (size_t)slot * a.bit_words : nullptr;
+    };
+    const uint32_t *p_bits[kPre];
+    uint32_t p_base[kPre];
+#pragma unroll
+    for (int q = 0; q < kPre; q++) {
+        const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
+        p_bits[q] = a.n_passes ? pass_bitmap(ps) : nullptr;
+        p_base[q] = a.n_passes ? a.passes[ps].base : 0u;
+    }
     auto request_bits = [&](const uint32_t g, Bits &bt) {
         const uint32_t gg = min(g, a.n_groups - 1);
 #pragma unroll
         for (int q = 0; q < kPre; q++) {
-            const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
-            const uint32_t *bits = a.pass_bits[ps];
             // (the bitmap of a batch whose size is not a multiple of 64 is padded to whole groups by the engine)
-            bt.lo[q] = bits != nullptr ? bits[2 * gg] : 0xFFFFFFFFu;
-            bt.hi[q] = bits != nullptr ? bits[2 * gg + 1] : 0xFFFFFFFFu;
+            bt.lo[q] = p_bits[q] != nullptr ? p_bits[q][2 * gg] : 0xFFFFFFFFu;
+            bt.hi[q] = p_bits[q] != nullptr ? p_bits[q][2 * gg + 1] : 0xFFFFFFFFu;
         }
     };
     auto request_inputs = [&](const uint32_t g, const Bits &bt, Inputs &in) {
@@ -1015,7 +1026,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                     rv[q] = cur.rv[q];
                 } else {
                     const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
-                    const uint32_t *bits = a.pass_bits[ps];
+                    const uint32_t *bits = pass_bitmap(ps);
                     const bool mine = bits == nullptr || ((bits[2 * g + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
                     rv[q] = (valid && mine) ? a.rec[(size_t)ps * a.n + i] : 0u;
                 }
@@ -1024,7 +1035,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
             for (int q = 0; q < kPre; q++) {
                 if (pb + (uint32_t)q >= a.n_passes) break;
                 if (__ballot(rv[q] != 0) == 0) continue;  // nobody in the group matched anything in this pass
-                const uint32_t base = a.pass_base_v[pb + q];  // kernel argument: no memory round trip
+                const uint32_t base = pb == 0 ? p_base[q] : a.passes[pb + q].base;
                 if (rv[q] & REC_OVERFLOW) {
                     for (uint32_t k = rv[q] & ~REC_OVERFLOW; k != kNone;) {
                         const PoolEntry pe = a.pool[k];
@@ -1240,7 +1251,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 //     /24 and oversized ids escape to an 8-byte side table and continue in the 8-bit trie nodes;
 //   * a group's inputs are requested TWO groups ahead and its DIR-24 / root entries ONE group ahead, so the long-latency loads of the
 //     next groups are in flight while the current group's rows are transposed (few waves per CU: nothing else hides them).
-static constexpr uint32_t kMaxRowWords = 8 + 8 + 4 + 4 + 4;  // ip-set, country, port-set, asn-set, asn-comparison words per request
+static constexpr uint32_t kMaxRowWords = kSrcWords;  // ip-set, country, port-set, asn-set, asn-comparison words per request
 static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
 
 struct AttrIn {
@@ -1358,7 +1369,7 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             }
             if (lo < a.iu_n[var] && a.iu_vals[var][lo] == v) r_int[var] = lo + 1;
         }
-        // sources: [0,8) ip-set row, [8,16) country words, [16,20) port-set row, [20,24) asn-set words, [24,28) asn comparisons
+        // sources (kernels.h kSrc*): ip-set row, country words, port-set row, asn-set words, asn comparisons
         const uint32_t *srow = a.set_masks + (size_t)set_id * a.set_words;
         const uint32_t *crow = from_row ? a.class_rows + (size_t)cls * a.class_words : a.country_masks + (size_t)r_geo * a.cc_words;
         const uint32_t *prow = a.iu_masks[0] + (size_t)r_int[0] * a.iu_words[0];
@@ -1368,15 +1379,15 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                    have_a = valid && (from_row ? cls != 0 : r_int[1] != 0), have_q = valid && from_row && cls != 0;
         uint32_t rw[kMaxRowWords];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) rw[q] = (q < a.set_words && have_s) ? srow[q] : 0u;
+        for (uint32_t q = 0; q < kSetWordsMax; q++) rw[kSrcSet + q] = (q < a.set_words && have_s) ? srow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) rw[8 + q] = (q < a.cc_words && have_c) ? crow[q] : 0u;
+        for (uint32_t q = 0; q < kCcWordsMax; q++) rw[kSrcCc + q] = (q < a.cc_words && have_c) ? crow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) rw[16 + q] = (q < a.iu_words[0] && have_p) ? prow[q] : 0u;
+        for (uint32_t q = 0; q < kIntWordsMax; q++) rw[kSrcPort + q] = (q < a.iu_words[0] && have_p) ? prow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) rw[20 + q] = (q < a.iu_words[1] && have_a) ? arow[q] : 0u;
+        for (uint32_t q = 0; q < kIntWordsMax; q++) rw[kSrcAsn + q] = (q < a.iu_words[1] && have_a) ? arow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) rw[24 + q] = (q < a.acmp_words && have_q) ? qrow[q] : 0u;
+        for (uint32_t q = 0; q < kAcmpWordsMax; q++) rw[kSrcAcmp + q] = (q < a.acmp_words && have_q) ? qrow[q] : 0u;
 
         // ---- 3. prefetch: inputs of the group after next, first trie step of the next group ----
         AttrIn nn;
@@ -1388,7 +1399,7 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         //         nothing); lane b keeps bit b's request mask and owns that atom's pair ----
 #pragma unroll
         for (uint32_t q = 0; q < kMaxRowWords; q++) {
-            const uint32_t words = q < 8 ? a.set_words : q < 16 ? a.cc_words + 8 : q < 20 ? a.iu_words[0] + 16 : q < 24 ? a.iu_words[1] + 20 : a.acmp_words + 24;
+            const uint32_t words = q < kSrcCc ? a.set_words : q < kSrcPort ? a.cc_words + kSrcCc : q < kSrcAsn ? a.iu_words[0] + kSrcPort : q < kSrcAcmp ? a.iu_words[1] + kSrcAsn : a.acmp_words + kSrcAcmp;
             if (q >= words) continue;  // (uniform)
             const uint32_t w = rw[q];
             const uint32_t orw0 = wave_or(w);
@@ -1439,6 +1450,10 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             cmp_var(cur.len[4], 4);
             cmp_var(port, 5);
             if (!from_row) cmp_var(asn, 6);
+            for (uint32_t f = 0; f < a.n_hlen; f++) {  // EXTENSION: lengths of header columns (rare: fetched here, not prefetched)
+                const uint32_t ii = valid ? i : 0u;
+                cmp_var(a.hoff[f][ii + 1] - a.hoff[f][ii], 7 + (int)f);
+            }
             emit_pairs((acc_lo | acc_hi) != 0, m_col & 0xFFFFFFu, acc_lo, acc_hi);
         }
         if (lane == 0) a.ghdr[g] = n_pairs;

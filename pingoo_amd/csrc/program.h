@@ -177,9 +177,15 @@ struct NumAtomDev {  // numeric atom descriptor consumed by the verdict kernel
     int64_t c;
 };
 
+static constexpr uint32_t kMaxHeaders = 120;   // header columns (field ids 5 .. 5 + kMaxHeaders - 1)
+static constexpr uint32_t kMaxGroups = 250;    // scan passes per program
+
 struct Program {
     // source-level
     std::vector<Atom> atoms;                     // atoms[0] = TRUE
+    // EXTENSION: the names the rule set uses as http_request.headers["name"], in first-use order; field id of
+    // column k = PWAF_N_FIELDS + k. The host supplies one string column per name (absent header = empty string).
+    std::vector<std::string> header_names;
     std::vector<std::vector<int64_t>> int_sets;  // sorted, unique
     std::vector<std::bitset<704>> country_luts;  // index = (c0-'A')*26 + (c1-'A')
     std::vector<std::string> warnings;

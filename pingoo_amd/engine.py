@@ -88,6 +88,12 @@ def lib():
     L.pwaf_engine_program.argtypes = [vp]
     L.pwaf_engine_program.restype = vp
     L.pwaf_engine_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+    for fn_name in ("pwaf_engine_header_count", "pwaf_program_header_count"):
+        getattr(L, fn_name).argtypes = [vp]
+        getattr(L, fn_name).restype = C.c_uint32
+    for fn_name in ("pwaf_engine_header_name", "pwaf_program_header_name"):
+        getattr(L, fn_name).argtypes = [vp, C.c_uint32]
+        getattr(L, fn_name).restype = C.c_char_p
     L.pwaf_engine_stream.argtypes = [vp]
     L.pwaf_engine_stream.restype = vp
     L.pwaf_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
@@ -231,6 +237,11 @@ class CompiledProgram:
         self._h = h
         self._owned = True
 
+    @property
+    def header_names(self) -> List[str]:
+        """EXTENSION: the header names the rule set mentions = the header columns a batch must carry, in this order."""
+        return [lib().pwaf_program_header_name(self._h, i).decode() for i in range(lib().pwaf_program_header_count(self._h))]
+
     @classmethod
     def _borrow(cls, handle) -> "CompiledProgram":
         self = cls.__new__(cls)
@@ -280,6 +291,7 @@ class RuleEngine:
         if rc != 0:
             _raise(rc, err.message.decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
         self._h = h
+        self.header_names = [L.pwaf_engine_header_name(h, i).decode() for i in range(L.pwaf_engine_header_count(h))]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -303,7 +315,7 @@ class RuleEngine:
         """Host batch in, numpy VERDICT_DTYPE array out (and the 4 action counters when asked)."""
         out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
         counts = _abi.Counts()
-        st = batch.as_struct()
+        st = batch.as_struct(self.header_names)
         rc = lib().pwaf_evaluate_batch(self._h, C.byref(st), out.ctypes.data, C.addressof(counts))
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
@@ -324,7 +336,7 @@ class RuleEngine:
             out = torch.empty((dbatch.n, 2), dtype=torch.int32, device=dbatch.device)
         if stream is None:
             stream = torch.cuda.current_stream(dbatch.device).cuda_stream
-        st = dbatch.as_struct()
+        st = dbatch.as_struct(self.header_names)
         rc = lib().pwaf_evaluate_device(self._h, C.byref(st), out.data_ptr(), counts.data_ptr() if counts is not None else None,
                                         match_idx.data_ptr() if match_idx is not None else None, n_matches.data_ptr() if n_matches is not None else None,
                                         C.c_void_p(stream))
@@ -340,7 +352,7 @@ class RuleEngine:
 
     def tune(self, sample: RequestBatch) -> None:
         """Re-selects the LDS-resident DFA rows from a host traffic sample (speed only; verdicts never change)."""
-        st = sample.as_struct()
+        st = sample.as_struct(self.header_names)
         rc = lib().pwaf_engine_tune(self._h, C.byref(st))
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
@@ -490,12 +502,28 @@ class DeviceBatch:
         self.flags = t(batch.flags)
         self.asn = None if batch.asn is None else t(batch.asn.view(np.int32))
         self.country = None if batch.country is None else t(batch.country.view(np.int16))
+        self.headers = {name: (t(d), t(o.view(np.int32)), int(o[-1])) for name, (d, o) in batch.headers.items()}
+        self._empty = None
 
-    def as_struct(self) -> _abi.Batch:
+    def as_struct(self, header_names: Sequence[str] = ()) -> _abi.Batch:
+        import torch
+
         b = _abi.Batch()
         b.struct_size = C.sizeof(_abi.Batch)
         b.n = self.n
         b.memory = _abi.MEM_DEVICE
+        if header_names:
+            cols = (_abi.StrCol * len(header_names))()
+            hb = (C.c_uint32 * len(header_names))()
+            for k, name in enumerate(header_names):
+                if name in self.headers:
+                    d, o, nbytes = self.headers[name]
+                    cols[k].data, cols[k].offsets, hb[k] = d.data_ptr(), o.data_ptr(), nbytes
+                # (a missing name stays NULL: the engine reads it as the empty string for every request)
+            b.n_headers = len(header_names)
+            b.headers = cols
+            b.header_bytes = hb
+            b._keep = [cols, hb]
         for f in range(_abi.N_FIELDS):
             b.field[f].data = self.data[f].data_ptr()
             b.field[f].offsets = self.offsets[f].data_ptr()

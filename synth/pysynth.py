@@ -44,6 +44,15 @@ def lib():
         L.synth_sizes.restype = None
         L.synth_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.synth_fill.restype = None
+        L.synth_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.synth_set_mode.restype = None
+        L.synth_header_count.argtypes = [C.c_void_p]
+        L.synth_header_name.argtypes = [C.c_void_p, C.c_int]
+        L.synth_header_name.restype = C.c_char_p
+        L.synth_header_size.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+        L.synth_header_size.restype = C.c_uint64
+        L.synth_fill_header.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+        L.synth_fill_header.restype = None
         _lib = L
     return _lib
 
@@ -66,6 +75,7 @@ class Workload:
             name, item = line.split("\t", 1)
             lists.setdefault(name, []).append(item)
         self.lists = {k: (_abi.LIST_INT if k.startswith("asn") else _abi.LIST_IP, v) for k, v in lists.items()}
+        self.header_names = [lib().synth_header_name(self._h, k).decode() for k in range(lib().synth_header_count(self._h))]
         n = lib().synth_geoip_count(self._h)
         self.geoip = None
         if n:
@@ -77,7 +87,10 @@ class Workload:
             lib().synth_destroy(self._h)
             self._h = None
 
-    def batch(self, start: int, n: int, threads: int = DEFAULT_THREADS) -> RequestBatch:
+    def batch(self, start: int, n: int, threads: int = DEFAULT_THREADS, adversarial: bool = False) -> RequestBatch:
+        """Requests [start, start + n) of the seeded stream. adversarial: the hostile variant of the same stream (near misses of
+        the rule literals, maximum-length fields, regex-state-heavy inputs: BASELINE.json configs[4])."""
+        lib().synth_set_mode(self._h, 1 if adversarial else 0)
         sizes = (C.c_uint64 * 5)()
         lib().synth_sizes(self._h, start, n, sizes, threads)
         for s in sizes:
@@ -92,4 +105,13 @@ class Workload:
         dp = (C.c_void_p * 5)(*[d.ctypes.data for d in data])
         op = (C.c_void_p * 5)(*[o.ctypes.data for o in offs])
         lib().synth_fill(self._h, start, n, dp, op, ip.ctypes.data, v6.ctypes.data, port.ctypes.data, flags.ctypes.data, threads)
-        return RequestBatch(data, offs, ip, v6, port, flags)
+        headers = {}
+        for k, name in enumerate(self.header_names):
+            size = int(lib().synth_header_size(self._h, k, start, n, threads))
+            if size + _abi.ARENA_PAD >= 2 ** 32:
+                raise ValueError("a header arena would exceed the 32-bit offset range: split the batch")
+            hd, ho = np.zeros(size + _abi.ARENA_PAD, dtype=np.uint8), np.zeros(n + 1, dtype=np.uint32)
+            lib().synth_fill_header(self._h, k, start, n, hd.ctypes.data, ho.ctypes.data, threads)
+            headers[name] = (hd, ho)
+        lib().synth_set_mode(self._h, 0)
+        return RequestBatch(data, offs, ip, v6, port, flags, headers=headers)

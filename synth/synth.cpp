@@ -71,7 +71,13 @@ struct Config {
     std::string rules_text, lists_text;
     struct Geo { uint8_t addr[16]; uint8_t len, v6; char cc[2]; uint32_t asn; };
     std::vector<Geo> geo;
+    // EXTENSION (BASELINE.json configs[4]): header fields. names[k] is the k-th header; a request carries each with probability 0.7
     int n_headers = 0;
+    std::vector<std::string> header_names;
+    std::vector<std::string> header_vals;  // 400 common header values
+    // adversarial traffic (mode 1): near misses of the rule literals — (field id, literal), field 5 + k = header k
+    std::vector<std::pair<int, std::string>> literals;
+    int mode = 0;
 };
 
 static std::string make_word(Rng &r, int minl, int maxl) {
@@ -123,6 +129,49 @@ static void build_pools(Config &c) {
         snprintf(buf, sizeof buf, "%sBot/%u.%u (+http://%s.example/bot)", c.rare[(size_t)(3000 + k)].c_str(), r.range(1, 9), r.range(0, 9), make_word(r, 4, 9).c_str());
         c.rare_uas.push_back(buf);
     }
+    if (c.n_headers) {
+        static const char *real[] = {"accept", "accept-language", "accept-encoding", "referer", "cookie", "origin", "x-forwarded-for", "x-requested-with", "content-type",
+                                     "cache-control", "sec-fetch-site", "sec-fetch-mode", "sec-ch-ua", "authorization", "x-api-key", "if-none-match"};
+        for (int k = 0; k < c.n_headers; k++) {
+            char buf[32];
+            if (k < 16) snprintf(buf, sizeof buf, "%s", real[k]);
+            else snprintf(buf, sizeof buf, "x-app-%02d", k);
+            c.header_names.push_back(buf);
+        }
+        static const char *stems[] = {"text/html,application/xhtml+xml,application/xml;q=0.9,*/*;q=0.8", "en-US,en;q=0.9", "gzip, deflate, br", "same-origin", "navigate",
+                                      "no-cache", "max-age=0", "application/json", "XMLHttpRequest", "keep-alive", "cors", "?1", "document", "u=1, i"};
+        for (int k = 0; k < 400; k++) {
+            std::string v;
+            int fam = (int)r.below(10);
+            if (fam < 4) v = stems[r.below(14)];
+            else if (fam < 6) v = "sid=" + make_word(r, 8, 16) + std::to_string(r.below(100000)) + "; theme=" + make_word(r, 4, 8) + "; lang=" + make_word(r, 2, 3);
+            else if (fam < 8) v = "https://" + c.hosts[r.below(1000)] + "/" + c.words[r.below(5000)] + "/" + c.words[r.below(5000)];
+            else v = make_word(r, 4, 12) + "=" + std::to_string(r.below(1000000)) + ";" + make_word(r, 3, 9) + "-" + make_word(r, 3, 9);
+            if (v.size() > 120) v.resize(120);
+            c.header_vals.push_back(v);
+        }
+    }
+}
+
+// value of header k of request idx: a pure function of (config, idx, k), like everything else here
+static void gen_header(const Config &c, uint64_t idx, int k, std::string &out) {
+    Rng r(c.seed ^ (0x9E3779B97F4A7C15ull * (idx + 1)) ^ (0xC2B2AE3D27D4EB4Full * (uint64_t)(k + 1)));
+    out.clear();
+    if (!r.chance(0.7)) return;  // header absent = empty string
+    out = c.header_vals[r.below(400)];
+    if (r.chance(0.004)) out += ";" + c.rare[r.below(3000)];  // a rare word now and then (rules target them)
+    if (c.mode == 1 && !c.literals.empty() && r.chance(0.25)) {
+        // adversarial: a near miss of a rule literal on this very header (or of any literal): all but its last one or two bytes
+        for (int tries = 0; tries < 4; tries++) {
+            const auto &lit = c.literals[r.below((uint32_t)c.literals.size())];
+            if (lit.first != 5 + k && tries < 3) continue;
+            std::string t = lit.second;
+            if (t.size() > 3) t.resize(t.size() - 1 - r.below(2));
+            out += "&" + t + (r.chance(0.5) ? "x" : "");
+            break;
+        }
+    }
+    if (out.size() > 250) out.resize(250);
 }
 
 // ---- one request ------------------------------------------------------------------------------------------
@@ -187,6 +236,31 @@ static void gen_request(const Config &c, uint64_t idx, Req &q) {
     else if (ur < 0.002) q.ua = std::string(256 + r.below(40), 'A');
     else if (ur < 0.004) q.ua = c.rare_uas[r.below(64)];
     else q.ua = c.uas[r.below(200)];
+    if (c.mode == 1 && !c.literals.empty()) {
+        // adversarial stream (BASELINE.json configs[4]): near misses of the rule literals (everything but the last byte or two), long
+        // runs that keep regex states busy, User-Agent / path / url at their maximum lengths
+        auto near_miss = [&](int field) -> std::string {
+            for (int tries = 0; tries < 6; tries++) {
+                const auto &lit = c.literals[r.below((uint32_t)c.literals.size())];
+                if (lit.first != field && tries < 5) continue;
+                std::string t = lit.second;
+                if (t.size() > 3) t.resize(t.size() - 1 - r.below(2));
+                return t;
+            }
+            return "";
+        };
+        if (r.chance(0.6)) { q.path += "/" + near_miss(2); q.url = q.path + q.url.substr(std::min(q.url.size(), q.url.find('?') == std::string::npos ? q.url.size() : q.url.find('?'))); }
+        if (r.chance(0.6)) q.url += (q.url.find('?') == std::string::npos ? "?q=" : "&q=") + near_miss(1) + "+select+insert+delete+union+select+";
+        if (r.chance(0.3)) q.ua = near_miss(4) + " " + q.ua;
+        if (r.chance(0.3)) q.host = near_miss(0) + "." + q.host;
+        if (r.chance(0.2)) { while (q.path.size() < 120) q.path += "/" + c.words[r.below(5000)]; }
+        if (r.chance(0.2)) { while (q.ua.size() < 240) q.ua += " like Gecko " + c.words[r.below(5000)]; }
+        if (q.path.size() > 128) q.path.resize(128);
+        if (q.url.size() > 512) q.url.resize(512);
+        if (q.ua.size() > 255) q.ua.resize(255);
+        if (q.host.size() > 64) q.host.resize(64);
+        while (!q.path.empty() && q.path.back() == '/') q.path.pop_back();
+    }
     // client
     memset(q.ip, 0, 16);
     if (r.chance(0.9)) {
@@ -222,8 +296,30 @@ static std::string v4str(uint32_t a) {
 
 static const char *kFields[5] = {"host", "url", "path", "method", "user_agent"};
 
+static std::string literal_pred_core(Config &c, Rng &r, int &rare_cursor, int &field, std::string &lit);
 static std::string literal_pred(Config &c, Rng &r, int &rare_cursor) {
+    int field = -1;
+    std::string lit;
+    std::string e = literal_pred_core(c, r, rare_cursor, field, lit);
+    if (field >= 0 && !lit.empty()) c.literals.emplace_back(field, lit);
+    return e;
+}
+static std::string literal_pred_core(Config &c, Rng &r, int &rare_cursor, int &field, std::string &lit) {
     // one atomic string predicate that fires rarely
+    if (c.n_headers && r.chance(0.4)) {
+        // EXTENSION: predicates over header fields
+        const int k = (int)r.below((uint32_t)c.n_headers);
+        const std::string &w = c.rare[(size_t)(rare_cursor++ % 3000)];
+        const std::string h = "http_request.headers[" + quote(c.header_names[(size_t)k]) + "]";
+        field = 5 + k;
+        int kind = (int)r.below(10);
+        if (kind < 5) { lit = ";" + w; return h + ".contains(" + quote(lit) + ")"; }
+        if (kind < 7) { lit = w; return h + ".ends_with(" + quote(lit) + ")"; }
+        if (kind < 8) { lit = w + "="; return h + ".starts_with(" + quote(lit) + ")"; }
+        if (kind < 9) { lit = w; return h + ".matches(" + quote("(?i)" + w + "[0-9a-f]{4,}") + ")"; }
+        lit = w + "/1.0";
+        return h + " == " + quote(lit);
+    }
     int kind = (int)r.below(100);
     if (kind < 12) {
         std::string tok = kAttackTokens[r.below((uint32_t)kNAttack)];
@@ -235,13 +331,13 @@ static std::string literal_pred(Config &c, Rng &r, int &rare_cursor) {
         return "http_request.url.contains(" + quote(tok) + ")";
     }
     const std::string &w = c.rare[(size_t)(rare_cursor++ % 3000)];
-    if (kind < 50) return "http_request.path.contains(" + quote("/" + w) + ")";
-    if (kind < 65) return "http_request.url.contains(" + quote("=" + w) + ")";
-    if (kind < 75) return "http_request.path.ends_with(" + quote(w) + ")";
+    if (kind < 50) { field = 2; lit = "/" + w; return "http_request.path.contains(" + quote("/" + w) + ")"; }
+    if (kind < 65) { field = 1; lit = "=" + w; return "http_request.url.contains(" + quote("=" + w) + ")"; }
+    if (kind < 75) { field = 2; lit = w; return "http_request.path.ends_with(" + quote(w) + ")"; }
     if (kind < 82) return "http_request.user_agent.contains(" + quote(c.rare[(size_t)(3000 + r.below(64))] + "Bot/") + ")";
     if (kind < 88) return "http_request.user_agent.starts_with(" + quote(c.rare[(size_t)(3000 + r.below(64))]) + ")";
-    if (kind < 94) return "http_request.host == " + quote(w + ".example.org");
-    if (kind < 97) return "http_request.host.ends_with(" + quote("." + w + ".internal") + ")";
+    if (kind < 94) { field = 0; lit = w + ".example.org"; return "http_request.host == " + quote(w + ".example.org"); }
+    if (kind < 97) { field = 0; lit = "." + w + ".internal"; return "http_request.host.ends_with(" + quote("." + w + ".internal") + ")"; }
     return "http_request.path == " + quote("/" + w + "/" + c.rare[r.below(3000)]);
 }
 
@@ -375,6 +471,7 @@ static Config *make_config(int id, uint64_t seed) {
     auto *c = new Config();
     c->id = id;
     c->seed = seed ? seed : (0x50494E47ull ^ (uint64_t)id);
+    c->n_headers = id == 5 ? 64 : id == 0 ? 4 : 0;  // header fields: the 4096-rule config of BASELINE.json configs[4], and the tiny unit-test config
     build_pools(*c);
     switch (id) {
         case 1: {  // 16 literal-substring rules (plumbing)
@@ -401,6 +498,64 @@ static Config *make_config(int id, uint64_t seed) {
 extern "C" {
 
 void *synth_create(int config_id, uint64_t seed) { return make_config(config_id, seed); }
+// 0 = benign stream, 1 = adversarial stream (near misses of the rule literals, maximum-length fields, regex-state-heavy inputs)
+void synth_set_mode(void *h, int mode) { ((Config *)h)->mode = mode; }
+int synth_header_count(void *h) { return ((Config *)h)->n_headers; }
+const char *synth_header_name(void *h, int k) { return ((Config *)h)->header_names[(size_t)k].c_str(); }
+// total value bytes of header k over requests [start, start + n)
+uint64_t synth_header_size(void *h, int k, uint64_t start, uint64_t n, int n_threads) {
+    const Config &c = *(Config *)h;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<uint64_t> part((size_t)n_threads, 0);
+    auto work = [&](int t) {
+        std::string v;
+        uint64_t lo = start + n * (uint64_t)t / (uint64_t)n_threads, hi = start + n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        for (uint64_t i = lo; i < hi; i++) { gen_header(c, i, k, v); part[(size_t)t] += v.size(); }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    uint64_t tot = 0;
+    for (auto x : part) tot += x;
+    return tot;
+}
+// fills the (arena, n + 1 offsets) column of header k for requests [start, start + n)
+void synth_fill_header(void *h, int k, uint64_t start, uint64_t n, uint8_t *data, uint32_t *offsets, int n_threads) {
+    const Config &c = *(Config *)h;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<uint64_t> part((size_t)n_threads, 0);
+    auto bounds = [&](int t, uint64_t &lo, uint64_t &hi) { lo = n * (uint64_t)t / (uint64_t)n_threads; hi = n * (uint64_t)(t + 1) / (uint64_t)n_threads; };
+    auto pass1 = [&](int t) {
+        std::string v;
+        uint64_t lo, hi;
+        bounds(t, lo, hi);
+        for (uint64_t i = lo; i < hi; i++) { gen_header(c, start + i, k, v); part[(size_t)t] += v.size(); }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(pass1, t);
+        for (auto &t : th) t.join();
+    }
+    std::vector<uint64_t> base((size_t)n_threads, 0);
+    uint64_t acc = 0;
+    for (int t = 0; t < n_threads; t++) { base[(size_t)t] = acc; acc += part[(size_t)t]; }
+    offsets[n] = (uint32_t)acc;
+    auto pass2 = [&](int t) {
+        std::string v;
+        uint64_t lo, hi;
+        bounds(t, lo, hi);
+        uint64_t pos = base[(size_t)t];
+        for (uint64_t i = lo; i < hi; i++) {
+            gen_header(c, start + i, k, v);
+            offsets[i] = (uint32_t)pos;
+            memcpy(data + pos, v.data(), v.size());
+            pos += v.size();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(pass2, t);
+    for (auto &t : th) t.join();
+}
 void synth_destroy(void *h) { delete (Config *)h; }
 const char *synth_rules_text(void *h) { return ((Config *)h)->rules_text.c_str(); }
 const char *synth_lists_text(void *h) { return ((Config *)h)->lists_text.c_str(); }

@@ -234,10 +234,17 @@ def lit_token(rng: random.Random) -> str:
     return t
 
 
+HEADER_NAMES = ["x-a", "cookie", "x-b"]
+
+
 def lit_pred(rng: random.Random) -> str:
-    f = "http_request." + rng.choice(["host", "url", "path", "user_agent", "url", "path"])
+    f = "http_request." + rng.choice(["host", "url", "path", "user_agent", "url", "path", 'headers["x-a"]', 'headers["cookie"]', "headers.referer"])
     t = lit_token(rng)
-    k = rng.randint(0, 11)
+    k = rng.randint(0, 13)
+    if k == 12:
+        return f"{f}.length() {rng.choice(['>', '<=', '=='])} {rng.randint(0, 12)}"
+    if k == 13:
+        return rng.choice(['"x-a" in http_request.headers', 'http_request.headers.contains("cookie")', '"headers" in http_request', f'{f} == ""'])
     if k <= 2:
         return f"{f}.contains({q(t)})"
     if k == 3:
@@ -296,7 +303,8 @@ def lit_requests(rng: random.Random, n: int):
     for _ in range(n):
         path = lit_field(rng, 0, 5)
         ua = lit_field(rng, 1, 4) if rng.random() < 0.95 else ""
+        hdrs = {h: lit_field(rng, 0, 3) for h in ["x-a", "cookie", "referer", "x-unused"] if rng.random() < 0.6}
         reqs.append(Request(host=lit_field(rng, 0, 2), url=path + ("?" + lit_field(rng, 0, 4) if rng.random() < 0.6 else ""), path=path,
                             method=rng.choice(["GET", "POST"]), user_agent=ua[:255], ip=f"{rng.randint(1, 3)}.{rng.randint(0, 3)}.0.{rng.randint(0, 255)}",
-                            remote_port=rng.randint(0, 65535), captcha_verified=rng.random() < 0.3))
+                            remote_port=rng.randint(0, 65535), captcha_verified=rng.random() < 0.3, headers=hdrs or None))
     return reqs

@@ -72,6 +72,8 @@ class Tables:
                                   for k in range(n_heads)]  # (literal, exact, local atom)
             elif tag == "GFTB":
                 cur["f_table"] = np.frombuffer(pl, dtype="<u4")
+            elif tag == "HDRS":
+                self.header_names = [x.decode() for x in pl.split(b"\0")[:count]]
             elif tag == "NUMA":
                 self.num_atoms = np.frombuffer(pl, dtype=NUMA_DTYPE)
             elif tag == "INTP":
@@ -165,7 +167,7 @@ class Tables:
     def evaluate(self, batch, i: int):
         """Returns (action, rule_idx) for request i of a RequestBatch, exactly as the device pipeline would."""
         cols = {0}
-        fields = [batch.field_bytes(f, i) for f in range(5)]
+        fields = [batch.field_bytes(f, i) for f in range(5)] + [batch.header_bytes(h, i) for h in getattr(self, "header_names", [])]
         for g in self.groups:
             self.scan_pass(g, fields[g["field"]], cols)
         ip = batch.ip[i].tobytes()

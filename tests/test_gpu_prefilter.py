@@ -105,3 +105,59 @@ def test_rule_set_without_string_predicates_at_one_million_requests():
     got = eng.evaluate_batch(big)
     assert (got["action"] == np.where(big.port < 1024, 1, 2)).all()
     eng.close()
+
+
+def test_header_fields_extension_on_the_device():
+    """EXTENSION (BASELINE.json configs[4]): http_request.headers["name"] columns — scan predicates, lengths, membership in the map,
+    absent headers (= ""), a batch that carries none of the columns, and evaluate(Request)."""
+    rules = [("k", 'http_request.headers["x-api-key"].contains("bad") || http_request.headers["x-api-key"].starts_with("tok_")', [B]),
+             ("len", 'http_request.headers.accept.length() > 5 && "accept" in http_request.headers', [CAP]),
+             ("empty", 'http_request.path.starts_with("/a") && http_request.headers["x-api-key"] == ""', [B]),
+             ("re", 'http_request.headers["cookie"].matches("(?i)sid=[0-9a-f]{8};")', [CAP])]
+    eng = RuleEngine(rules)
+    assert sorted(eng.header_names) == ["accept", "cookie", "x-api-key"]
+    orc = pyoracle.Oracle(rules)
+    rng = random.Random(11)
+    reqs = []
+    for _ in range(3000):
+        h = {}
+        if rng.random() < 0.7:
+            h["x-api-key"] = rng.choice(["", "tok_123", "verybadkey", "ok", "TOK_", "bad"])
+        if rng.random() < 0.7:
+            h["accept"] = rng.choice(["*/*", "text/html", "a", ""])
+        if rng.random() < 0.5:
+            h["cookie"] = rng.choice(["sid=0123abcd;x=1", "SID=DEADBEEF;", "sid=12345;", "theme=dark"])
+        if rng.random() < 0.3:
+            h["x-other"] = "ignored"
+        reqs.append(Request(path=rng.choice(["/a", "/b", "/ab/c"]), host="h", headers=h or None))
+    batch = RequestBatch.from_requests(reqs)
+    want = orc.evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "headers")
+    assert len(set(want["action"].tolist())) == 3
+    # a batch without any header column: every header reads as ""
+    bare = RequestBatch.from_requests([Request(path="/a", host="h"), Request(path="/b", host="h")])
+    H.assert_verdicts_equal(eng.evaluate_batch(bare), orc.evaluate(bare), bare, "no header columns")
+    assert int(eng.evaluate(Request(path="/a", host="h")).decision) == 1
+    eng.close()
+
+
+def test_config5_4096_rules_64_header_fields_benign_and_adversarial():
+    """BASELINE.json configs[4] at a size the oracle finishes in seconds: 4096 rules over 5 + 64 string fields; the engine is tuned on
+    benign traffic and evaluated on the adversarial stream (near misses of the rule literals, maximum-length fields)."""
+    from synth import pysynth
+
+    w = pysynth.Workload(5)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    assert len(eng.header_names) == 64 and eng.stats()["n_filtered_groups"] >= 60
+    orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
+    benign = w.batch(0, 6000)
+    hostile = w.batch(100_000, 20000, adversarial=True)
+    want_b = orc.evaluate(benign, threads=16)
+    H.assert_verdicts_equal(eng.evaluate_batch(benign), want_b, benign, "config 5 benign")
+    eng.tune(w.batch(1_000_000, 4096))
+    want_h = orc.evaluate(hostile, threads=16)
+    got_h, counts = eng.evaluate_batch(hostile, with_counts=True)
+    H.assert_verdicts_equal(got_h, want_h, hostile, "config 5 adversarial, tuned on benign")
+    assert counts.tolist() == np.bincount(want_h["action"], minlength=4).tolist()
+    assert np.count_nonzero(want_h["action"]) > 0
+    eng.close()

@@ -40,7 +40,7 @@ def test_filter_has_no_false_negatives_and_heads_are_exact(seed):
             continue
         heads = {local: (lit, exact) for lit, exact, local in g["f_heads"]}
         for i in range(batch.n):
-            data = batch.field_bytes(g["field"], i)
+            data = batch.field_bytes(g["field"], i, t.header_names)
             cols = set()
             t.scan_field(g, data, cols)
             locals_ = {c - g["atom_base"] for c in cols}
