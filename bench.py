@@ -3,17 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path (all scan kernels + the verdict kernel) over one batch of synthetic
-requests that is already resident in HBM. Workload: BASELINE.json configs[2] — 10M requests x 1024 rules
-(600 literal + 200 regex + 124 CIDR lists + 100 GeoIP/ASN rules, 600k-prefix GeoIP table) — the configuration the
-metric ("1k-rule WAF") is quoted on; it fits one GPU. With N GPUs every rank evaluates its own 10M-request slab of
-the same seeded stream (weak scaling); the only collective is the RCCL all-reduce of the four action counters.
+A "step" is one pass of the hot path (filter / scan kernels, list scans, attribute and verdict kernels) over one batch of
+synthetic requests that is already resident in HBM. Default workload: BASELINE.json configs[2] — 10M requests x 1024 rules
+(600 literal + 200 regex + 124 CIDR lists + 100 GeoIP/ASN rules, 600k-prefix GeoIP table) — the configuration the metric
+("1k-rule WAF") is quoted on; it fits one GPU. With N GPUs every rank evaluates its own slab of the same seeded stream (weak
+scaling); the only collective is the RCCL all-reduce of the four action counters.
+`--config 5` is BASELINE.json configs[4]: 4096 rules over 5 + 64 string fields (header-field extension), 1M-request batches,
+with per-batch latency percentiles.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline      HBM roofline of the dominant kernel (scan_kernel), from HIP events recorded on the launch stream
-                during the timed steps; algorithmic bytes per SURVEY.md §8(d) / DESIGN.md §6
-  cpu_baseline  the CPU oracle ("port": a restatement of the reference's interpreter loop, NOT the Rust binary)
-                timed on this box's host cores over a bounded sample of the same request stream (rank 0, N=1 only)
+  roofline       HBM roofline of the dominant kernel (filter_kernel: the launch that streams the request bytes), from HIP events
+                 recorded on the launch stream during the timed steps; algorithmic bytes per SURVEY.md §8(d) / DESIGN.md §6
+  traffic_modes  the same engine UNTUNED (no traffic sample) and on the ADVERSARIAL variant of the stream (near misses of the rule
+                 literals, maximum-length fields), next to the headline (tuned on a benign sample disjoint from the timed batch)
+  cpu_baseline   the CPU oracle ("port": a restatement of the reference's interpreter loop, NOT the Rust binary) timed on this
+                 box's host cores over a bounded sample of the same request stream (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -37,8 +41,10 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="synthetic config id (BASELINE.json configs[id-1]); default 3")
     ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
     ap.add_argument("--lds-budget", type=int, default=0)
+    ap.add_argument("--adversarial", action="store_true", help="time the adversarial variant of the stream as the HEADLINE batch (the tuning sample stays benign)")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the untuned and adversarial side runs (traffic_modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie-inclusive", action="store_true", help="also time a 1M-request HOST batch through pwaf_evaluate_batch (extra launches: keep it out of profiled runs)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) measurements")
     ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -61,65 +67,115 @@ def main():
     shard.init_process_group()
     dev = torch.device("cuda", local)
 
-    default_n = {1: 10_000, 2: 1_000_000, 3: 10_000_000, 5: 10_000_000}.get(args.config, 100_000)
+    default_n = {1: 10_000, 2: 1_000_000, 3: 10_000_000, 5: 1_000_000}.get(args.config, 100_000)
     n = args.requests or default_n
     threads = max(1, (os.cpu_count() or 1) // world)
+    extras = world == 1 and not args.no_extra_modes and not os.environ.get("PWAF_BENCH_NO_TUNE")
 
     t0 = time.time()
     wl = pysynth.Workload(args.config)
-    batch = wl.batch(rank * n, n, threads=threads)  # this rank's slab of the global seeded request stream
+    batch = wl.batch(rank * n, n, threads=threads, adversarial=args.adversarial)  # this rank's slab of the global seeded request stream
     t_gen = time.time() - t0
     t0 = time.time()
     opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
     eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
-    # profile-guided LDS residency: the DFA rows kept in LDS are chosen from a traffic sample DISJOINT from the timed batch
-    # (a deployment would sample live traffic); verdicts do not depend on it
-    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 32768
-    if tune_n:
-        eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
     t_compile = time.time() - t0
     stats = eng.stats()
     dbatch = DeviceBatch(batch, dev)
-    if os.environ.get("PWAF_BENCH_FILL"):  # diagnostic only: constant field bytes => no DFA ever leaves its root (pure hot-loop time)
-        for d in dbatch.data:
-            d.fill_(int(os.environ["PWAF_BENCH_FILL"]))
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     counts = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev)
-
-    def step():
-        counts.zero_()
-        eng.evaluate_device(dbatch, out=out, counts=counts, stream=stream.cuda_stream)
-        shard.allreduce_counts(counts)  # the path's only exchange: 4 counters over RCCL/xGMI
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.set_profiling(not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream, during the timed steps
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ktimes = eng.kernel_times()
-    eng.set_profiling(False)
+    def timed_run(db, steps, warmup):
+        """W untimed + K timed steps over the resident batch `db`; returns (seconds, kernel times, action counters)."""
+        def step():
+            counts.zero_()
+            eng.evaluate_device(db, out=out, counts=counts, stream=stream.cuda_stream)
+            shard.allreduce_counts(counts)  # the path's only exchange: 4 counters over RCCL/xGMI
 
-    total_requests = n * world * args.steps
-    value = total_requests / elapsed
-    final_counts = counts.cpu().tolist()
+        for _ in range(warmup):
+            step()
+        barrier()
+        eng.set_profiling(not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kt = eng.kernel_times()
+        eng.set_profiling(False)
+        return elapsed, kt, counts.cpu().tolist()
 
+    def stream_kernels(kt):
+        """Launches that stream request bytes: filter_kernel (passes behind a bigram prefilter: arenas as flat byte streams) and
+        scan_kernel (a DFA over every request). The engine reports each launch's algorithmic bytes — every byte of a streamed
+        arena ONCE + its n+1 offsets. Returns {kernel: [ms, launches, bytes]} and the other kernels' ms."""
+        kinds = {"filter_kernel": [0.0, 0, 0], "scan_kernel": [0.0, 0, 0]}
+        other = {}
+        for name, ms, tag in kt:
+            key = "filter_kernel" if name == "filter" else "scan_kernel" if name.startswith("scan_") else None
+            if key:
+                kinds[key][0] += ms
+                kinds[key][1] += 1
+                kinds[key][2] += tag
+            else:
+                k2 = name.split("_x")[0]
+                other[k2] = other.get(k2, 0.0) + ms
+        return kinds, other
+
+    def mode_summary(elapsed, kt, steps):
+        kinds, _ = stream_kernels(kt)
+        dom = max(kinds, key=lambda kk: kinds[kk][0])
+        ms, _, nbytes = kinds[dom]
+        ach = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+        return {"requests_per_s": n * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS}
+
+    def phase(msg):
+        if args.verbose and rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    traffic_modes = {}
+    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 32768
+    if extras:
+        # the engine as created: default filter tables and BFS-order LDS rows, no traffic sample
+        phase("untuned run")
+        el, kt, _ = timed_run(dbatch, max(2, args.steps // 2), 1)
+        traffic_modes["untuned_benign"] = mode_summary(el, kt, max(2, args.steps // 2))
+    if tune_n:
+        # profile-guided tables from a traffic sample DISJOINT from the timed batch (a deployment would sample live traffic): bigram
+        # statistics and heads of the prefilters, LDS-resident DFA rows; verdicts do not depend on it. The sample is always BENIGN.
+        phase("tune")
+        t0 = time.time()
+        eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
+        t_compile += time.time() - t0
+
+    phase("headline run")
+    elapsed, ktimes, final_counts = timed_run(dbatch, args.steps, args.warmup)
+    value = n * world * args.steps / elapsed
+    head = mode_summary(elapsed, ktimes, args.steps)
+    headline_out = out[: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite `out`)
+
+    if extras and not args.adversarial:
+        phase("adversarial run")
+        adv = DeviceBatch(wl.batch(rank * n, n, threads=threads, adversarial=True), dev)
+        el, kt, adv_counts = timed_run(adv, max(2, args.steps // 2), 1)
+        traffic_modes["adversarial_tuned_on_benign"] = dict(mode_summary(el, kt, max(2, args.steps // 2)), action_counts_allow_block_captcha_bypass=adv_counts)
+        del adv
+    traffic_modes["tuned_benign" if not args.adversarial else "adversarial_tuned_on_benign (headline)"] = head
+
+    rules_desc = {3: "1k-rule WAF", 5: "4096-rule bot-protection set, 64 header fields (extension)"}.get(args.config, f"{len(wl.rules)}-rule set")
     result = {
-        "metric": "requests/sec matched (whole node), 1k-rule WAF",
+        "metric": f"requests/sec matched (whole node), {rules_desc}",
         "value": value,
         "unit": "requests/s",
         "n_gpus": world,
@@ -133,43 +189,22 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE.json configs[{args.config - 1}]: {n} requests/GPU x {len(wl.rules)} rules "
-                        f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} DFA passes, {stats['n_filtered_groups']} of them behind a bigram prefilter, {stats['n_ip_lists']} CIDR lists, "
-                        f"{0 if wl.geoip is None else len(wl.geoip)} GeoIP prefixes), seed 0x50494E47^{args.config}",
+                        f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} DFA passes, {stats['n_filtered_groups']} of them behind a bigram prefilter, "
+                        f"{stats['n_ip_lists']} CIDR lists, {0 if wl.geoip is None else len(wl.geoip)} GeoIP prefixes, {len(eng.header_names)} header fields), "
+                        f"seed 0x50494E47^{args.config}, {'adversarial' if args.adversarial else 'benign'} stream",
             "requests_per_gpu": n,
             "rules": len(wl.rules),
-            "hot_rows": f"tuned on {tune_n} sample requests disjoint from the timed batch" if tune_n else "BFS order (untuned)",
+            "tuning": f"tuned on {tune_n} benign sample requests disjoint from the timed batch" if tune_n else "none (untuned)",
             "parallelism": f"requests sharded over {world} GPU(s), tables replicated, RCCL all-reduce of 4 counters",
             "action_counts_allow_block_captcha_bypass": final_counts,
         },
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (scan_kernel: the launches that stream the request bytes) ----
-        field_bytes = dbatch.field_bytes
-        # Launches that stream request bytes: filter_kernel (every pass behind a bigram prefilter, all fields in ONE launch) and
-        # scan_kernel (passes whose DFA walks every request). Algorithmic bytes: every byte of a streamed field ONCE per launch
-        # + its n+1 offsets. The roofline object describes whichever of the two takes more time per step.
-        kinds = {"filter_kernel": [0.0, 0, 0], "scan_kernel": [0.0, 0, 0]}  # ms, launches, algorithmic bytes
-        verdict_ms, attr_ms, other_ms = 0.0, 0.0, {}
-        fnames = ["host", "url", "path", "method", "user_agent"]
-        for name, ms, tag in ktimes:
-            if name == "filter":
-                k = kinds["filter_kernel"]
-                k[0] += ms
-                k[1] += 1
-                k[2] += sum(field_bytes[f] + 4 * (n + 1) for f in range(5) if (tag >> f) & 1)
-            elif name.startswith("scan_"):
-                k = kinds["scan_kernel"]
-                k[0] += ms
-                k[1] += 1
-                k[2] += field_bytes[tag] + 4 * (n + 1)
-            elif name == "verdict":
-                verdict_ms += ms
-            elif name == "attr":
-                attr_ms += ms  # side stream, beside the scans
-            else:
-                other_ms[name.split("_x")[0]] = other_ms.get(name.split("_x")[0], 0.0) + ms
-        dom = max(kinds, key=lambda kk: kinds[kk][0])
+        kinds, other_ms = stream_kernels(ktimes)
+        verdict_ms = other_ms.pop("verdict", 0.0)
+        attr_ms = other_ms.pop("attr", 0.0)  # side stream, beside the filter
+        dom = head["kernel"]
         scan_ms, n_scan_launches, scan_alg = kinds[dom]
         stream_ms = sum(v[0] for v in kinds.values())
         if args.verbose:
@@ -179,19 +214,18 @@ def main():
             for name, v in per.items():
                 print(f"  {name:<24} avg {sum(v) / len(v):8.3f} ms  x{len(v)}", file=sys.stderr)
             print("  " + json.dumps(stats), file=sys.stderr)
-        scan_s = scan_ms / 1000.0
-        achieved = scan_alg / scan_s / 1e9 if scan_s > 0 else 0.0
+        achieved = head["achieved_gbs"]
         pipeline_alg = dbatch.algorithmic_bytes * args.steps
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes over this very
         # command (tools/profile_round.sh), committed under profiles/ and only quoted for the workload they were measured on
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
-        if args.config == 3 and n == 10_000_000 and os.path.exists(tpath):
+        if args.config == 3 and n == 10_000_000 and not args.adversarial and os.path.exists(tpath):
             try:
-                tk = json.load(open(tpath))["kernels"]
-                sk = [v for k, v in tk.items() if "::" + dom in k]  # one entry per template instantiation
+                tj = json.load(open(tpath))
+                sk = [v for k, v in tj["kernels"].items() if "::" + dom in k]  # one entry per template instantiation
                 traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
-                traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+                traffic_src = f"profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md; taken at commit {tj.get('commit', '?')})"
             except Exception:  # a malformed profile file must not break the bench line
                 traffic, traffic_src = None, None
         kernel_s = (stream_ms + verdict_ms + sum(other_ms.values())) / 1000.0  # (the attribute kernel runs beside these on a side stream)
@@ -202,7 +236,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,  # HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/), or null
+            "frac_untuned": traffic_modes.get("untuned_benign", {}).get("frac"),
+            "frac_adversarial": traffic_modes.get("adversarial_tuned_on_benign", {}).get("frac"),
+            "traffic": traffic,  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or null
             "traffic_source": traffic_src,
             "alg_bytes_per_launch": scan_alg // max(1, n_scan_launches),
             "launches_per_step": n_scan_launches // max(1, args.steps),
@@ -219,7 +255,8 @@ def main():
                 "other_ms_per_step": {k: v / args.steps for k, v in other_ms.items()},
             },
         }
-        # ---- SURVEY §8(d) extras: the part's measured copy bandwidth, bytes per clock and CU, and the PCIe-inclusive rate ----
+        result["traffic_modes"] = traffic_modes
+        # ---- SURVEY §8(d) extras: the part's measured copy bandwidth, bytes per clock and CU ----
         try:
             src = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
             dst = torch.empty_like(src)
@@ -241,33 +278,58 @@ def main():
         except Exception as exc:  # informational only
             result["roofline"]["peak_measured_copy_gbs"] = None
             print(f"copy-bandwidth probe failed: {exc}", file=sys.stderr)
-        if world == 1 and args.pcie_inclusive:
+
+        def pct(xs, p):
+            xs = sorted(xs)
+            return xs[min(len(xs) - 1, int(round(p / 100.0 * (len(xs) - 1))))]
+
+        if world == 1 and args.config == 5:
+            # per-batch latency (BASELINE.json configs[4]): one synchronised call per batch, device-resident
+            phase("latency calls")
+            lat = []
+            for _ in range(40):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                eng.evaluate_device(dbatch, out=out, stream=stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                lat.append(1e3 * (time.perf_counter() - t0))
+            result["latency_ms"] = {"batch": n, "calls": len(lat), "device_resident": {"p50": pct(lat, 50), "p99": pct(lat, 99), "max": max(lat)}}
+        if world == 1 and not args.no_pcie:
             # host batch in, verdicts out through pwaf_evaluate_batch: H2D + kernels + D2H, on a bounded slice of the same batch
+            phase("host-batch (PCIe-inclusive) calls")
             m = min(n, 1_000_000)
             hb = batch.slice(0, m) if m < n else batch
             eng.evaluate_batch(hb)
-            t0 = time.perf_counter()
-            hv = eng.evaluate_batch(hb)
-            dt = time.perf_counter() - t0
-            gv = out[:m].cpu().numpy().view(np.uint32)
-            result["pcie_inclusive"] = {"value": m / dt, "unit": "requests/s", "sample": f"{m} requests from host memory, synchronous pwaf_evaluate_batch (H2D of ~324 B/request, kernels, D2H of 8 B/request)",
+            lat = []
+            hv = None
+            for _ in range(6 if args.config != 5 else 12):
+                t0 = time.perf_counter()
+                hv = eng.evaluate_batch(hb)
+                lat.append(time.perf_counter() - t0)
+            gv = headline_out[:m].cpu().numpy().view(np.uint32)
+            result["pcie_inclusive"] = {"value": m / pct(lat, 50), "unit": "requests/s",
+                                        "sample": f"{m} requests from host memory, synchronous pwaf_evaluate_batch (H2D of ~{hb.algorithmic_bytes() / m:.0f} B/request, kernels, D2H of 8 B/request), median of {len(lat)} calls",
+                                        "latency_ms": {"p50": 1e3 * pct(lat, 50), "p99": 1e3 * pct(lat, 99)},
                                         "verdicts_match_device_resident_run": bool((hv["action"] == gv[:, 0]).all() and (hv["rule_idx"] == gv[:, 1]).all())}
+            if "latency_ms" in result:
+                result["latency_ms"]["host_batch_pcie_inclusive"] = result["pcie_inclusive"]["latency_ms"]
         # ---- CPU baseline: the oracle (port of the reference's per-request interpreter loop) on host cores ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle
 
+            phase("cpu baseline")
             cores = os.cpu_count() or 1
             orc = pyoracle.Oracle(wl.rules, wl.lists, wl.geoip)
-            probe = wl.batch(0, 2000, threads=cores)
+            probe = batch.slice(0, min(n, 2000))
             t0 = time.perf_counter()
             orc.evaluate(probe, threads=cores)
-            rate = 2000 / max(1e-6, time.perf_counter() - t0)
-            sample_n = int(min(n, max(2000, rate * args.cpu_seconds)))
+            rate = probe.n / max(1e-6, time.perf_counter() - t0)
+            sample_n = int(min(n, len(headline_out), max(2000, rate * args.cpu_seconds)))
             sample = batch.slice(0, sample_n) if sample_n < n else batch
             t0 = time.perf_counter()
             cpu_v = orc.evaluate(sample, threads=cores)
             cpu_t = time.perf_counter() - t0
-            gpu_v = out[:sample_n].cpu().numpy().view(np.uint32)
+            gpu_v = headline_out[:sample_n].cpu().numpy().view(np.uint32)
             same = bool((gpu_v[:, 0] == cpu_v["action"]).all() and (gpu_v[:, 1] == cpu_v["rule_idx"]).all())
             result["cpu_baseline"] = {
                 "value": sample_n / cpu_t,
@@ -278,7 +340,7 @@ def main():
                           f"(oracle/), {cores} threads; verdicts {'identical to' if same else 'DIFFERENT from'} the GPU's",
                 "verdicts_match_gpu": same,
             }
-        result["timing_notes"] = {"generate_s": round(t_gen, 2), "compile_and_upload_tables_s": round(t_compile, 2)}
+        result["timing_notes"] = {"generate_s": round(t_gen, 2), "compile_upload_tune_s": round(t_compile, 2)}
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()

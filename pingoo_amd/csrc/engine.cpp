@@ -485,6 +485,13 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     };
     long open_begin = -1;
     auto mark = [&](const char *name, uint64_t alg_bytes, hipStream_t on = nullptr) -> int {
+#ifdef PWAF_PROFILING
+        static const bool sync_each = getenv("PWAF_SYNC_EACH") != nullptr;  // debugging aid: which launch faults
+        if (sync_each && name) {
+            hipError_t se = hipStreamSynchronize(on ? on : stream);
+            fprintf(stderr, "[pwaf] %s done: %s\n", name, hipGetErrorString(se));
+        }
+#endif
         if (!e->profiling) return PWAF_OK;
         int rc2;
         if (!name) {  // begin

@@ -9,11 +9,11 @@ cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.json
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py --no-cpu-baseline --no-extra-modes --no-pcie > $OUT/trace.log 2>&1
 DB=$(find $OUT/trace -name '*.db' | head -1)
-python $R/tools/rocprof_summary.py $DB "bench.py --no-cpu-baseline (default config 3, 10M requests x 1024 rules, steps 5 warmup 2)" > $OUT/kernel_stats.txt 2>> $OUT/trace.log
+python $R/tools/rocprof_summary.py $DB "bench.py --no-cpu-baseline --no-extra-modes --no-pcie (default config 3, 10M requests x 1024 rules, steps 5 warmup 2)" > $OUT/kernel_stats.txt 2>> $OUT/trace.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-modes --no-pcie > $OUT/pmc_$c.log 2>&1
 done
 python $R/tools/pmc_traffic.py $OUT > $OUT/traffic.json 2>> $OUT/trace.log
 cat $OUT/kernel_stats.txt | head -30; cat $OUT/traffic.json

@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/timeline.sh  — kernel-trace only; prints the last pipeline pass as a timeline (start offset, duration)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $R/gpurun_out/timeline -o t --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/timeline.log 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/timeline -o t --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-modes --no-pcie > $R/gpurun_out/timeline.log 2>&1
 python - <<PY
 import csv, glob
 rows = []
