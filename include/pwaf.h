@@ -240,7 +240,10 @@ void *pwaf_engine_stream(const pwaf_engine *); /* hipStream_t the synchronous en
 
 /* Synchronous batch evaluation. HOST batches are copied to the device, evaluated, and verdicts are
  * copied back into `out` (host, n entries). DEVICE batches are evaluated in place and `out`/`counts`
- * must be device pointers too. `counts` is nullable. Callable concurrently from several threads. */
+ * must be device pointers too. `counts` is nullable. Callable concurrently from several threads: an engine owns a small ring of
+ * per-call contexts (scratch, staging buffers, stream), so one caller's copies overlap another's kernels. A batch that exhausts
+ * the scan overflow pool (more than two distinct matches per pass for very many requests) is evaluated again with a larger pool
+ * before the call returns: PWAF_E_NOMEM is only reported when that does not help. */
 int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts);
 
 /* Asynchronous device-resident evaluation on a caller-supplied HIP stream (hipStream_t as void*, passed through
@@ -251,8 +254,11 @@ int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, 
 int pwaf_evaluate_device(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts,
                          uint32_t *match_idx, uint32_t *n_matches, void *stream);
 
-/* After pwaf_evaluate_device: waits for the device and returns PWAF_OK, or PWAF_E_NOMEM when the last batch ran out of
- * scan scratch (verdicts incomplete; cannot happen below 8 overflowing hits per request on average). */
+/* pwaf_evaluate_device is re-entrant: calls from several threads / on several streams each take the next per-call context of the
+ * engine's ring (the stream first waits, on the device, for that context's previous user), so two in-flight batches never share
+ * scratch. After pwaf_evaluate_device: pwaf_engine_device_status waits for the device and returns PWAF_OK, or PWAF_E_NOMEM when
+ * some device-resident batch since the last status call ran out of scan overflow scratch (its verdicts are incomplete: evaluate it
+ * again — the pool has been grown to what it asked for; cannot happen below 8 overflowing hits per request on average). */
 int pwaf_engine_device_status(pwaf_engine *);
 
 /* Optional tuning from a traffic sample (HOST memory; at most the first 65536 requests are used). Each DFA pass keeps its most
@@ -264,6 +270,24 @@ int pwaf_engine_tune(pwaf_engine *, const pwaf_batch *sample);
 
 /* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
 int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);
+
+/* ---- one process, every GPU of the node ---------------------------------------------
+ * The reference builds its rule state once per process and shares it with every listener (pingoo/server.rs:40-47,76,111-134);
+ * a pwaf_node is that object for a multi-GPU host: one engine replica per device (tables are tens of MB), a HOST batch is cut
+ * into contiguous 64-aligned slabs (pwaf_node_shard_bounds), each slab is evaluated by its device on its own host thread and
+ * stream, verdicts land in `out` at the slab's position and the four action counters are summed on the host. No data-path
+ * exchange between devices. (bench.py's process-per-GPU mode does the same with an RCCL all-reduce of the counters.) */
+typedef struct pwaf_node pwaf_node;
+int pwaf_node_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_list_desc *lists, size_t n_lists,
+                     const pwaf_geoip_table *geoip /* nullable */, const pwaf_options *opts /* nullable; .device is ignored */,
+                     const int *devices, size_t n_devices, pwaf_node **out, pwaf_compile_error *err /* nullable */);
+void pwaf_node_destroy(pwaf_node *);
+size_t pwaf_node_device_count(const pwaf_node *);
+pwaf_engine *pwaf_node_engine(const pwaf_node *, size_t i);
+int pwaf_node_tune(pwaf_node *, const pwaf_batch *sample);
+int pwaf_node_evaluate_batch(pwaf_node *, const pwaf_batch *in /* HOST */, pwaf_verdict *out /* n */, pwaf_counts *counts /* nullable */);
+/* Slab [lo, hi) of device `rank` out of `world` for a batch of n requests. */
+void pwaf_node_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t *lo, uint32_t *hi);
 
 /* ---- deadline micro-batcher ------------------------------------------------------ */
 /* The reference evaluates rules once per request on the tokio worker that owns the connection (http_listener.rs:196-264); a

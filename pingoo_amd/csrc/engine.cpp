@@ -95,10 +95,43 @@ struct DevGroup {
 
 }  // namespace
 
+// Everything one in-flight batch needs besides the immutable tables: device scratch, host-batch staging buffers, its own stream for
+// the synchronous entry points, the side stream of the attribute kernel and the events that order them. An engine owns a small
+// ring of these, so that callers on several threads / streams overlap (one batch's copies under another's kernels) instead of
+// queueing behind one set of buffers; a context's `done` event makes its next user wait (on the device) for the previous one.
+struct Scratch {
+    std::mutex mu;  // held while a call enqueues on this context (device calls) or for the whole call (host batches: staging is reused)
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, done = nullptr;
+    bool used = false;
+    DevBuf status;            // one sticky word: bit 0 = some batch on this context exhausted the overflow pool (cleared when reported)
+    uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
+    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
+    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
+    DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
+    DevBuf visit_bits;                     // per gap pass: visited bitmap
+    DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
+    std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
+    DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
+    void release() {
+        for (DevBuf *b : {&status, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+                          &stage_asn, &stage_country, &stage_out, &stage_counts})
+            b->release();
+        for (auto &b : stage_field_data) b.release();
+        for (auto &b : stage_field_off) b.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        if (side) (void)hipStreamDestroy(side);
+        for (hipEvent_t ev : {ev_fork, ev_join, done})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+};
+static constexpr size_t kContexts = 3;
+
 struct pwaf_engine {
     pwaf_program prog;
     int device = 0;
-    hipStream_t stream = nullptr;
+    std::vector<std::unique_ptr<Scratch>> ctx;  // kContexts
+    size_t next_ctx = 0;
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
     uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0;
@@ -110,34 +143,24 @@ struct pwaf_engine {
     DevBuf iu_vals[2], iu_masks[2];
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
-    // per-call scratch (guarded by mu)
-    std::mutex mu;
-    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, [2..34) gated list lengths */, pass_base;
-    DevBuf colmask, gate_lists, attr, dir24;
-    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
-    DevBuf need;                // per sharing owner: gap-pass mask of every entry of its candidate list
-    uint32_t n_need = 0;
-    DevBuf visit_bits;          // per gap pass: visited bitmap
-    uint32_t n_visit = 0;
+    std::mutex mu;  // guards the context ring, the profiling state and table rebuilds (pwaf_engine_tune)
+    DevBuf pass_base, colmask, dir24;
+    uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
+    uint32_t n_visit = 0;  // gap passes (visited bitmaps per batch)
     std::vector<double> mean_len;  // per field, from the tuning sample (0 = unknown)
     uint32_t n_ungated = 0, n_gated = 0, n_filtered = 0;
     std::vector<uint8_t> owns_factors;  // per pass: some of its atoms are prefilter factors of gap passes
     uint32_t n_gap = 0;                 // gated gap passes (list slots [0, kGapLists), one factor-mask bit each)
     DevBuf pass_table;                  // PassInfo per pass
     std::vector<uint32_t> hlen_fields;  // header columns whose length some rule compares (comparison variable 7 + k)
-    DevBuf zero_off;                    // n + 1 zero offsets: the column of a header the batch does not carry
     uint32_t n_fields = PWAF_N_FIELDS;  // 5 + header columns
-    std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
-    DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<pwaf_kernel_time> times;
     std::vector<std::pair<size_t, size_t>> time_ev;  // (begin, end) event index of each entry of `times`
     size_t n_timed = 0;
-    hipStream_t side = nullptr;  // attribute kernel runs here, beside the scans
     uint32_t n_cus = 256;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -402,8 +425,15 @@ int assign_lists(pwaf_engine *e) {
     return upload(e->colmask, colmask);
 }
 
-int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
-                 uint32_t *d_n_matches, hipStream_t stream, bool totals_known = false) {
+Scratch &next_context(pwaf_engine *e) {
+    std::lock_guard<std::mutex> lock(e->mu);
+    Scratch &S = *e->ctx[e->next_ctx];
+    e->next_ctx = (e->next_ctx + 1) % e->ctx.size();
+    return S;
+}
+
+int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
+                 uint32_t *d_n_matches, hipStream_t stream, bool totals_known = false, const std::vector<uint32_t> *col_begin = nullptr) {
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
@@ -411,17 +441,24 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     int rc;
     // scratch sized for the worst case the 288 GB part can afford: one 4-byte hit record per (pass, request) and an overflow
     // pool of 8 entries per request (exhaustion is reported through the status word, never silently)
-    const uint64_t pool_cap64 = std::max<uint64_t>(1u << 20, (uint64_t)n * 8);
+    // (a batch that exhausts the pool sets the context's sticky status word; the synchronous entry points then grow the pool to
+    // what the batch asked for — the allocator keeps counting past the cap — and run the batch again)
+    const uint64_t pool_cap64 = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)n * 8), S.pool_entries);
     const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
-    if ((rc = e->rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
+    S.pool_entries = pool_cap;
+    if (!S.status.p) {
+        if ((rc = S.status.reserve(4))) return rc;
+        HIP_TRY(hipMemsetAsync(S.status.p, 0, 4, stream));
+    }
+    if ((rc = S.rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
     // the attribute kernel's output: per group a header and room for EVERY non-scan atom (worst case: no overflow path), plus 64
     // pairs of slack so the verdict kernel may read a full wave's worth unconditionally
     const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms);
-    if ((rc = e->attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
-    if ((rc = e->pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
+    if ((rc = S.attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
+    if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     const size_t ctrl_words = 2 + (size_t)std::max(kGapLists, e->n_gated);  // [0] pool allocator, [1] status word, then one length per list slot
-    if ((rc = e->ctrl.reserve(4 * ctrl_words))) return rc;
-    HIP_TRY(hipMemsetAsync(e->ctrl.p, 0, 4 * ctrl_words, stream));
+    if ((rc = S.ctrl.reserve(4 * ctrl_words))) return rc;
+    HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, 4 * ctrl_words, stream));
     // string columns by field id: the five fixed fields, then one column per header name the rule set mentions (EXTENSION); a header
     // the batch does not carry reads as the empty string for every request
     std::vector<pwaf_strcol> cols(e->n_fields);
@@ -441,32 +478,32 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         }
     }
     if (missing_header) {
-        if (e->zero_off.cap < (size_t)(n + 1) * 4 + PWAF_ARENA_PAD) {
-            if ((rc = e->zero_off.reserve((size_t)(n + 1) * 4 + PWAF_ARENA_PAD))) return rc;
-            HIP_TRY(hipMemsetAsync(e->zero_off.p, 0, e->zero_off.cap, stream));
+        if (S.zero_off.cap < (size_t)(n + 1) * 4 + PWAF_ARENA_PAD) {
+            if ((rc = S.zero_off.reserve((size_t)(n + 1) * 4 + PWAF_ARENA_PAD))) return rc;
+            HIP_TRY(hipMemsetAsync(S.zero_off.p, 0, S.zero_off.cap, stream));
         }
         for (uint32_t f = PWAF_N_FIELDS; f < e->n_fields; f++)
             if (cols[f].data == nullptr) {
-                cols[f].data = (const uint8_t *)e->zero_off.p;
-                cols[f].offsets = (const uint32_t *)e->zero_off.p;
+                cols[f].data = (const uint8_t *)S.zero_off.p;
+                cols[f].offsets = (const uint32_t *)S.zero_off.p;
                 col_bytes[f] = 0;
             }
     }
     std::vector<uint8_t> col_known(e->n_fields, totals_known ? 1 : 0);
     for (uint32_t f = 0; f < e->n_fields; f++)
-        if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)e->zero_off.p) col_known[f] = 1;
-    if (e->n_gated && (rc = e->gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
-    if (e->n_need && (rc = e->need.reserve((size_t)e->n_need * n * 4))) return rc;
+        if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)S.zero_off.p) col_known[f] = 1;
+    if (e->n_gated && (rc = S.gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
+    if (e->n_need && (rc = S.need.reserve((size_t)e->n_need * n * 4))) return rc;
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
     // zeroing the hit records themselves would write
     const uint32_t bit_words = 2 * n_groups;
     if (e->n_filtered) {
-        if ((rc = e->cand_bits.reserve((size_t)e->n_filtered * bit_words * 4))) return rc;
-        HIP_TRY(hipMemsetAsync(e->cand_bits.p, 0, (size_t)e->n_filtered * bit_words * 4, stream));
+        if ((rc = S.cand_bits.reserve((size_t)e->n_filtered * bit_words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(S.cand_bits.p, 0, (size_t)e->n_filtered * bit_words * 4, stream));
     }
     if (e->n_visit) {
-        if ((rc = e->visit_bits.reserve((size_t)e->n_visit * bit_words * 4))) return rc;
-        HIP_TRY(hipMemsetAsync(e->visit_bits.p, 0, (size_t)e->n_visit * bit_words * 4, stream));
+        if ((rc = S.visit_bits.reserve((size_t)e->n_visit * bit_words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(S.visit_bits.p, 0, (size_t)e->n_visit * bit_words * 4, stream));
     }
 
     // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
@@ -529,20 +566,20 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.country = db.country;
     v.n_cols = P.n_cols;
     v.n_passes = n_passes;
-    v.rec = (const uint32_t *)e->rec.p;
+    v.rec = (const uint32_t *)S.rec.p;
     v.passes = (const PassInfo *)e->pass_table.p;
-    v.cand_bits = (const uint32_t *)e->cand_bits.p;
-    v.visit_bits = (const uint32_t *)e->visit_bits.p;
+    v.cand_bits = (const uint32_t *)S.cand_bits.p;
+    v.visit_bits = (const uint32_t *)S.visit_bits.p;
     v.bit_words = bit_words;
     for (size_t k = 0; k < e->groups.size(); k++)  // a pass with heads writes records outside its candidate list too: zeroed, read densely
-        if (e->groups[k].filtered && !e->groups[k].filter.heads.empty()) HIP_TRY(hipMemsetAsync((uint32_t *)e->rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
+        if (e->groups[k].filtered && !e->groups[k].filter.heads.empty()) HIP_TRY(hipMemsetAsync((uint32_t *)S.rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
     v.n_hlen = (uint32_t)e->hlen_fields.size();
     for (size_t k = 0; k < e->hlen_fields.size(); k++) v.hoff[k] = cols[e->hlen_fields[k]].offsets;
-    v.gpairs = (uint4 *)e->attr.p;
-    v.ghdr = (uint32_t *)((char *)e->attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
+    v.gpairs = (uint4 *)S.attr.p;
+    v.ghdr = (uint32_t *)((char *)S.attr.p + ((size_t)n_groups * pair_stride + 64) * 16);
     v.pair_stride = pair_stride;
     v.attr_blocks = e->n_cus;
-    v.pool = (const PoolEntry *)e->pool.p;
+    v.pool = (const PoolEntry *)S.pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
     v.n_trig = e->n_trig;
@@ -569,21 +606,21 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
     v.n_matches = d_n_matches;
     // The attribute kernel (GeoIP / ip-list / integer-set lookups: dependent gathers, latency-bound) does not depend on the scans
     // (LDS / issue-bound), so it runs beside them on the engine's side stream and joins before the verdict kernel.
-    HIP_TRY(hipEventRecord(e->ev_fork, stream));
-    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-    if ((rc = mark(nullptr, 0, e->side))) return rc;
+    HIP_TRY(hipEventRecord(S.ev_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(S.side, S.ev_fork, 0));
+    if ((rc = mark(nullptr, 0, S.side))) return rc;
     {
 #ifdef PWAF_PROFILING
         static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
-        if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, e->side));
-        int he = skip_attr ? 0 : launch_attr(v, e->side);
+        if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, S.side));
+        int he = skip_attr ? 0 : launch_attr(v, S.side);
 #else
-        int he = launch_attr(v, e->side);
+        int he = launch_attr(v, S.side);
 #endif
         if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
     }
-    if ((rc = mark("attr", 0xFEu, e->side))) return rc;
-    HIP_TRY(hipEventRecord(e->ev_join, e->side));
+    if ((rc = mark("attr", 0xFEu, S.side))) return rc;
+    HIP_TRY(hipEventRecord(S.ev_join, S.side));
 
     static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
     auto scan_args = [&](size_t gi) -> ScanArgs {
@@ -593,8 +630,8 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
             // this pass owns prefilter factors: it feeds the gated gap passes' request lists as requests finish
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
             a.n_local = d.n_local;
-            a.gate_lists = (uint32_t *)e->gate_lists.p;
-            a.gate_count = (uint32_t *)e->ctrl.p + 2;
+            a.gate_lists = (uint32_t *)S.gate_lists.p;
+            a.gate_count = (uint32_t *)S.ctrl.p + 2;
         }
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
@@ -613,11 +650,11 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.stride = d.stride;
         a.n_classes = d.n_classes;
         a.n_hot = d.n_hot;
-        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
-        a.pool = (PoolEntry *)e->pool.p;
-        a.pool_count = (uint32_t *)e->ctrl.p;
+        a.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
+        a.pool = (PoolEntry *)S.pool.p;
+        a.pool_count = (uint32_t *)S.ctrl.p;
         a.pool_cap = pool_cap;
-        a.status = (uint32_t *)e->ctrl.p + 1;
+        a.status = (uint32_t *)S.status.p;
         return a;
     };
     auto list_args = [&](size_t gi) -> ListScanArgs {
@@ -625,21 +662,21 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
         if (!d.identity) {
-            a.req_list = (const uint32_t *)e->gate_lists.p + (size_t)src.gate * n;
-            a.n_list = (const uint32_t *)e->ctrl.p + 2 + src.gate;
+            a.req_list = (const uint32_t *)S.gate_lists.p + (size_t)src.gate * n;
+            a.n_list = (const uint32_t *)S.ctrl.p + 2 + src.gate;
         }
-        if (d.visit_slot >= 0) a.visited = (uint32_t *)e->visit_bits.p + (size_t)d.visit_slot * bit_words;
+        if (d.visit_slot >= 0) a.visited = (uint32_t *)S.visit_bits.p + (size_t)d.visit_slot * bit_words;
         if (d.share_owner >= 0) {
-            a.need_in = (const uint32_t *)e->need.p + (size_t)src.need_slot * n;
+            a.need_in = (const uint32_t *)S.need.p + (size_t)src.need_slot * n;
             a.need_bit = (uint32_t)d.gate;
         }
         if (e->n_gap && e->owns_factors[gi]) {
             a.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
             a.n_local = d.n_local;
-            a.gate_lists = (uint32_t *)e->gate_lists.p;
-            a.gate_count = (uint32_t *)e->ctrl.p + 2;
+            a.gate_lists = (uint32_t *)S.gate_lists.p;
+            a.gate_count = (uint32_t *)S.ctrl.p + 2;
             if (d.need_slot >= 0) {
-                a.need_out = (uint32_t *)e->need.p + (size_t)d.need_slot * n;
+                a.need_out = (uint32_t *)S.need.p + (size_t)d.need_slot * n;
                 a.shared_bits = d.shared_bits;
             }
         }
@@ -653,11 +690,11 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
         a.end_list = (const uint16_t *)d.end_list.p;
-        a.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
-        a.pool = (PoolEntry *)e->pool.p;
-        a.pool_count = (uint32_t *)e->ctrl.p;
+        a.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
+        a.pool = (PoolEntry *)S.pool.p;
+        a.pool_count = (uint32_t *)S.ctrl.p;
         a.pool_cap = pool_cap;
-        a.status = (uint32_t *)e->ctrl.p + 1;
+        a.status = (uint32_t *)S.status.p;
         a.n_cus = e->n_cus;
         return a;
     };
@@ -691,12 +728,12 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         uint64_t sub_entries = 0, n_slabs_all = 0;
         for (const DevGroup &d : e->groups)
             if (d.filtered) {
-                const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab;
+                const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab - (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u);
                 n_slabs_all += slabs;
                 sub_entries += slabs * (kStreamSlab / kStreamSeg);
             }
-        if ((rc = e->cand_sub.reserve((size_t)sub_entries * 4))) return rc;
-        if ((rc = e->cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
+        if ((rc = S.cand_sub.reserve((size_t)sub_entries * 4))) return rc;
+        if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
         FilterBatchArgs fb{};
         uint32_t fi = 0, block = 0;
         uint64_t alg_bytes = 0;
@@ -740,14 +777,15 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
                 f.head_len[h] = fh.len | ((uint32_t)fh.exact << 8);
                 f.head_code[h] = h == 0 ? (uint32_t)fh.local + 1u : ((uint32_t)fh.local + 1u) << 15;
             }
-            const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab);
-            f.rec = (uint32_t *)e->rec.p + gi * (size_t)n;
-            f.sub = (uint32_t *)e->cand_sub.p + sub_at;
-            f.sub_count = (uint32_t *)e->cand_cnt.p + cnt_at;
+            f.slab0 = col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u;
+            const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
+            f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
+            f.sub = (uint32_t *)S.cand_sub.p + sub_at;
+            f.sub_count = (uint32_t *)S.cand_cnt.p + cnt_at;
             f.block_count = f.sub_count + slabs;
-            f.bitmap = (uint32_t *)e->cand_bits.p + (size_t)fi * bit_words;
-            f.list = (uint32_t *)e->gate_lists.p + (size_t)d.gate * n;
-            f.list_count = (uint32_t *)e->ctrl.p + 2 + d.gate;
+            f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
+            f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
+            f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
             f.first_block = block;
             sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
             cnt_at += slabs + n_cblocks;
@@ -781,7 +819,7 @@ int run_pipeline(pwaf_engine *e, const pwaf_batch &db /* device pointers */, pwa
         }
         if ((rc = flush_gated())) return rc;
     }
-    HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+    HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
     if (he) return fail(PWAF_E_DEVICE, std::string("verdict kernel launch failed: ") + hipGetErrorString((hipError_t)he));
@@ -911,10 +949,15 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = (uint32_t)cus;
     }
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
-        fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
-        return dev_fail(PWAF_E_DEVICE);
+    for (size_t k = 0; k < kContexts; k++) {
+        e->ctx.emplace_back(new Scratch());
+        Scratch &S = *e->ctx.back();
+        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) {
+            fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
+            return dev_fail(PWAF_E_DEVICE);
+        }
     }
     e->n_fields = PWAF_N_FIELDS + (uint32_t)P.header_names.size();
     e->mean_len.assign(e->n_fields, 0.0);
@@ -1159,19 +1202,12 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
-    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits, &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes,
-                      &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->rec, &e->pool, &e->ctrl, &e->pass_base, &e->colmask, &e->gate_lists, &e->attr, &e->dir24, &e->cand_sub, &e->cand_cnt, &e->cand_bits, &e->need, &e->visit_bits, &e->class_rows, &e->dir_esc, &e->leaf_root, &e->stage_ip, &e->stage_v6, &e->stage_port, &e->stage_flags,
-                      &e->stage_asn, &e->stage_country, &e->stage_out, &e->stage_counts})
+    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->pass_base, &e->colmask, &e->dir24, &e->class_rows,
+                      &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
-    for (auto &b : e->stage_field_data) b.release();
-    for (auto &b : e->stage_field_off) b.release();
-    e->pass_table.release();
-    e->zero_off.release();
+    for (auto &c : e->ctx) c->release();
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
-    if (e->side) (void)hipStreamDestroy(e->side);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     delete e;
 }
 
@@ -1180,7 +1216,7 @@ uint32_t pwaf_program_header_count(const pwaf_program *p) { return p ? (uint32_t
 const char *pwaf_program_header_name(const pwaf_program *p, uint32_t i) { return (p && i < p->p->header_names.size()) ? p->p->header_names[i].c_str() : ""; }
 uint32_t pwaf_engine_header_count(const pwaf_engine *e) { return e ? pwaf_program_header_count(&e->prog) : 0u; }
 const char *pwaf_engine_header_name(const pwaf_engine *e, uint32_t i) { return e ? pwaf_program_header_name(&e->prog, i) : ""; }
-void *pwaf_engine_stream(const pwaf_engine *e) { return e ? (void *)e->stream : nullptr; }
+void *pwaf_engine_stream(const pwaf_engine *e) { return (e && !e->ctx.empty()) ? (void *)e->ctx[0]->stream : nullptr; }
 
 int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
     if (!e || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
@@ -1194,9 +1230,16 @@ int pwaf_evaluate_device(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out
     if (rc) return rc;
     if (in->memory != PWAF_MEM_DEVICE) return fail(PWAF_E_INVALID_ARG, "pwaf_evaluate_device needs a DEVICE batch");
     if ((match_idx == nullptr) != (n_matches == nullptr)) return fail(PWAF_E_INVALID_ARG, "match_idx and n_matches must be given together");
-    std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    return run_pipeline(e, *in, out, counts, match_idx, n_matches, (hipStream_t)stream);
+    // Re-entrant: the call takes the next scratch context of the ring; the caller's stream first waits (on the device) for whoever
+    // used that context before, and leaves its own completion event behind. Calls on different streams therefore overlap.
+    Scratch &S = next_context(e);
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, S.done, 0));
+    rc = run_pipeline(e, S, *in, out, counts, match_idx, n_matches, (hipStream_t)stream);
+    S.used = true;
+    HIP_TRY(hipEventRecord(S.done, (hipStream_t)stream));
+    return rc;
 }
 
 int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts) {
@@ -1207,18 +1250,31 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         if (counts && in->memory == PWAF_MEM_HOST) memset(counts, 0, sizeof *counts);
         return PWAF_OK;
     }
-    if (in->memory == PWAF_MEM_DEVICE) {
-        std::lock_guard<std::mutex> lock(e->mu);
-        HIP_TRY(hipSetDevice(e->device));
-        if (counts) HIP_TRY(hipMemsetAsync(counts, 0, sizeof *counts, e->stream));
-        rc = run_pipeline(e, *in, out, counts, nullptr, nullptr, e->stream);
-        if (rc) return rc;
-        uint32_t status = 0;
-        HIP_TRY(hipMemcpyAsync(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
-        return PWAF_OK;
-    }
+    HIP_TRY(hipSetDevice(e->device));
+    // the context is held for the whole call (its staging buffers and its stream are reused); other threads take other contexts
+    Scratch &S = next_context(e);
+    std::lock_guard<std::mutex> lock(S.mu);
+    hipStream_t s = S.stream;
+    if (S.used) HIP_TRY(hipStreamWaitEvent(s, S.done, 0));
+    // runs the pipeline and waits; a batch that exhausted the overflow pool is run again with a pool of the size it asked for
+    auto run_checked = [&](const pwaf_batch &db, pwaf_verdict *d_out, pwaf_counts *d_counts, bool known, const std::vector<uint32_t> *begins = nullptr) -> int {
+        for (int attempt = 0;; attempt++) {
+            if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
+            int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins);
+            S.used = true;
+            HIP_TRY(hipEventRecord(S.done, s));
+            if (r) return r;
+            uint32_t st[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&st[0], S.status.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&st[1], S.ctrl.p, 4, hipMemcpyDeviceToHost, s));  // overflow entries the batch asked for
+            HIP_TRY(hipStreamSynchronize(s));
+            if (!st[0]) return PWAF_OK;
+            HIP_TRY(hipMemsetAsync(S.status.p, 0, 4, s));
+            if (attempt >= 2 || st[1] >= 0x7FFFFFF0u) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
+            S.pool_entries = (uint64_t)st[1] + st[1] / 4 + 1024;
+        }
+    };
+    if (in->memory == PWAF_MEM_DEVICE) return run_checked(*in, out, counts, false);
     // HOST batch: validate what a device cannot report, stage, run, copy back
     const uint32_t n = in->n;
     // host view of every string column by field id (five fields + the header columns the batch carries; the others read as "")
@@ -1241,26 +1297,26 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
             if (c0 < 'A' || c0 > 'Z' || c1 < 'A' || c1 > 'Z') return fail(PWAF_E_BATCH, "country is not two letters A-Z (pingoo/geoip.rs:128-142)");
         }
     }
-    std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
-    hipStream_t s = e->stream;
     pwaf_batch db = *in;
     db.memory = PWAF_MEM_DEVICE;
-    if (e->stage_field_data.size() < e->n_fields) { e->stage_field_data.resize(e->n_fields); e->stage_field_off.resize(e->n_fields); }
+    if (S.stage_field_data.size() < e->n_fields) { S.stage_field_data.resize(e->n_fields); S.stage_field_off.resize(e->n_fields); }
     std::vector<pwaf_strcol> hdr_cols(e->n_fields - PWAF_N_FIELDS, pwaf_strcol{nullptr, nullptr});
     std::vector<uint32_t> hdr_bytes(e->n_fields - PWAF_N_FIELDS, 0);
+    std::vector<uint32_t> col_begin(e->n_fields, 0);
     for (uint32_t f = 0; f < e->n_fields; f++) {
         const pwaf_strcol *c = host_col(f);
         if (!c) continue;
         const uint32_t *o = c->offsets;
-        const size_t hi = o[n];
-        // the device arena is re-based so that offsets can be used unchanged: copy [0, hi)
-        if ((rc = e->stage_field_data[f].reserve(hi + PWAF_ARENA_PAD))) return rc;
-        if ((rc = e->stage_field_off[f].reserve((size_t)(n + 1) * 4))) return rc;
-        if (hi) HIP_TRY(hipMemcpyAsync(e->stage_field_data[f].p, c->data, hi, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync((char *)e->stage_field_data[f].p + hi, 0, PWAF_ARENA_PAD, s));
-        HIP_TRY(hipMemcpyAsync(e->stage_field_off[f].p, o, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
-        const pwaf_strcol dc{(const uint8_t *)e->stage_field_data[f].p, (const uint32_t *)e->stage_field_off[f].p};
+        const size_t lo = o[0], hi = o[n];
+        col_begin[f] = (uint32_t)lo;
+        // offsets are used unchanged on the device: the arena keeps its positions, but only the batch's own bytes [off[0], off[n]) travel
+        // (a slab view of a larger batch — pwaf_node_evaluate_batch — does not re-send what lies before it)
+        if ((rc = S.stage_field_data[f].reserve(hi + PWAF_ARENA_PAD))) return rc;
+        if ((rc = S.stage_field_off[f].reserve((size_t)(n + 1) * 4))) return rc;
+        if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)S.stage_field_data[f].p + lo, c->data + lo, hi - lo, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync((char *)S.stage_field_data[f].p + hi, 0, PWAF_ARENA_PAD, s));
+        HIP_TRY(hipMemcpyAsync(S.stage_field_off[f].p, o, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+        const pwaf_strcol dc{(const uint8_t *)S.stage_field_data[f].p, (const uint32_t *)S.stage_field_off[f].p};
         if (f < PWAF_N_FIELDS) {
             db.field[f] = dc;
             db.field_bytes[f] = (uint32_t)hi;
@@ -1279,25 +1335,21 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         *dst = b.p;
         return PWAF_OK;
     };
-    if ((rc = stage(e->stage_ip, in->ip, (size_t)n * 16, (const void **)&db.ip))) return rc;
-    if ((rc = stage(e->stage_v6, in->ip_is_v6, n, (const void **)&db.ip_is_v6))) return rc;
-    if ((rc = stage(e->stage_port, in->port, (size_t)n * 2, (const void **)&db.port))) return rc;
-    if ((rc = stage(e->stage_flags, in->flags, n, (const void **)&db.flags))) return rc;
+    if ((rc = stage(S.stage_ip, in->ip, (size_t)n * 16, (const void **)&db.ip))) return rc;
+    if ((rc = stage(S.stage_v6, in->ip_is_v6, n, (const void **)&db.ip_is_v6))) return rc;
+    if ((rc = stage(S.stage_port, in->port, (size_t)n * 2, (const void **)&db.port))) return rc;
+    if ((rc = stage(S.stage_flags, in->flags, n, (const void **)&db.flags))) return rc;
     if (in->asn) {
-        if ((rc = stage(e->stage_asn, in->asn, (size_t)n * 4, (const void **)&db.asn))) return rc;
-        if ((rc = stage(e->stage_country, in->country, (size_t)n * 2, (const void **)&db.country))) return rc;
+        if ((rc = stage(S.stage_asn, in->asn, (size_t)n * 4, (const void **)&db.asn))) return rc;
+        if ((rc = stage(S.stage_country, in->country, (size_t)n * 2, (const void **)&db.country))) return rc;
     }
-    if ((rc = e->stage_out.reserve((size_t)n * sizeof(pwaf_verdict)))) return rc;
-    if ((rc = e->stage_counts.reserve(sizeof(pwaf_counts)))) return rc;
-    HIP_TRY(hipMemsetAsync(e->stage_counts.p, 0, sizeof(pwaf_counts), s));
-    rc = run_pipeline(e, db, (pwaf_verdict *)e->stage_out.p, (pwaf_counts *)e->stage_counts.p, nullptr, nullptr, s, true);
+    if ((rc = S.stage_out.reserve((size_t)n * sizeof(pwaf_verdict)))) return rc;
+    if ((rc = S.stage_counts.reserve(sizeof(pwaf_counts)))) return rc;
+    rc = run_checked(db, (pwaf_verdict *)S.stage_out.p, (pwaf_counts *)S.stage_counts.p, true, &col_begin);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, e->stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
-    if (counts) HIP_TRY(hipMemcpyAsync(counts, e->stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));
-    uint32_t status = 0;
-    HIP_TRY(hipMemcpyAsync(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out, S.stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, S.stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
     return PWAF_OK;
 }
 
@@ -1306,7 +1358,11 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     int rc = validate_batch_header(sample);
     if (rc) return rc;
     if (sample->memory != PWAF_MEM_HOST) return fail(PWAF_E_INVALID_ARG, "pwaf_engine_tune needs a HOST-memory sample");
+    // no evaluate call may enqueue while the tables are rebuilt (calls already enqueued are waited for below)
+    std::vector<std::unique_lock<std::mutex>> ctx_locks;
+    for (auto &c : e->ctx) ctx_locks.emplace_back(c->mu);
     std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
     const Program &P = *e->prog.p;
     const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
     if (n == 0) return PWAF_OK;
@@ -1425,13 +1481,24 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
 
 int pwaf_engine_device_status(pwaf_engine *e) {
     if (!e) return fail(PWAF_E_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lock(e->mu);
-    if (!e->ctrl.p) return PWAF_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t status = 0;
-    HIP_TRY(hipMemcpy(&status, (uint32_t *)e->ctrl.p + 1, 4, hipMemcpyDeviceToHost));
-    if (status) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of the last batch are incomplete");
+    uint32_t any = 0;
+    for (auto &c : e->ctx) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!c->status.p) continue;
+        uint32_t status = 0;
+        HIP_TRY(hipMemcpy(&status, c->status.p, 4, hipMemcpyDeviceToHost));
+        if (status) {
+            HIP_TRY(hipMemset(c->status.p, 0, 4));  // sticky until reported
+            uint32_t asked = 0;  // the allocator keeps counting past the cap: what the last batch on this context needed
+            if (c->ctrl.p) HIP_TRY(hipMemcpy(&asked, c->ctrl.p, 4, hipMemcpyDeviceToHost));
+            c->pool_entries = std::max<uint64_t>(c->pool_entries * 2, (uint64_t)asked + asked / 4 + 1024);
+        }
+        any |= status;
+    }
+    if (any) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of a device-resident batch since the last status call are incomplete "
+                                       "(evaluate it again: the pool has been grown; the synchronous entry points retry by themselves)");
     return PWAF_OK;
 }
 

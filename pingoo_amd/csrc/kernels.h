@@ -121,6 +121,7 @@ struct FilterArgs {
     const uint32_t *off;
     uint32_t n;
     uint32_t total;           // bytes in the arena (= off[n])
+    uint32_t slab0;           // first slab to stream (a slab view of a larger arena starts at off[0]: the bytes before it are not the batch's)
     uint32_t init;            // state of a stream with no history
     const uint32_t *table;    // kFilterEntries masks
     uint32_t n_heads;

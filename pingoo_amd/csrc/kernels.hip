@@ -561,12 +561,12 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
     // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const uint32_t slab = (blockIdx.x - a.first_block) * kFilterWaves + wave;
+    const uint32_t rel = (blockIdx.x - a.first_block) * kFilterWaves + wave, slab = a.slab0 + rel;  // rel: index into the pass's sub-lists
     const uint64_t base64 = (uint64_t)slab * kStreamSlab;
     if (base64 >= a.total) return;
     const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
     const unsigned long long lt_mask = (1ull << lane) - 1;
-    uint32_t *my_sub = a.sub + (size_t)slab * (kStreamSlab / kStreamSeg);
+    uint32_t *my_sub = a.sub + (size_t)rel * (kStreamSlab / kStreamSeg);
     uint32_t n_hit = 0;  // wave-uniform
     const uint32_t mul2 = kFilterMul | (kFilterMul << 16);
 
@@ -690,17 +690,17 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
         }
         cur = nxt;
     }
-    if (lane == 0) a.sub_count[slab] = n_hit;
+    if (lane == 0) a.sub_count[rel] = n_hit;
 }
 
 // resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the three
 // bytes a window may reach back and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
 __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
     const FilterArgs &a = B.f[blockIdx.y];
-    const uint32_t slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6), slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
-    const uint32_t cnt = a.sub_count[slab];
-    const uint32_t *sub = a.sub + (size_t)slab * (kStreamSlab / kStreamSeg);
+    const uint32_t cnt = a.sub_count[rel];
+    const uint32_t *sub = a.sub + (size_t)rel * (kStreamSlab / kStreamSeg);
     for (uint32_t i = lane; i < cnt; i += 64) {
         const uint32_t e = sub[i], hmask = e & 15u;
         const uint32_t p = slab * kStreamSlab + (e >> 4) * kStreamSeg;
@@ -786,7 +786,7 @@ int launch_filter(const FilterBatchArgs &b, void *stream) {
     uint32_t blocks = 0, max_slabs = 0;
     bool heads = false;
     for (uint32_t k = 0; k < b.count; k++) {
-        const uint32_t slabs = (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab);
+        const uint32_t slabs = (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab) - b.f[k].slab0;
         blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
         max_slabs = max(max_slabs, slabs);
         heads = heads || b.f[k].n_heads != 0;
@@ -800,7 +800,7 @@ int launch_filter(const FilterBatchArgs &b, void *stream) {
 
 int launch_resolve(const FilterBatchArgs &b, void *stream) {
     uint32_t max_slabs = 0;
-    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab));
+    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab) - b.f[k].slab0);
     if (b.count == 0 || max_slabs == 0) return 0;
     void *args[] = {const_cast<FilterBatchArgs *>(&b)};
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, b.count), dim3(256), args, 0, (hipStream_t)stream);

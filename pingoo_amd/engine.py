@@ -102,6 +102,17 @@ def lib():
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
     L.pwaf_engine_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
+    L.pwaf_node_create.argtypes = create_args + [C.POINTER(C.c_int), C.c_size_t, C.POINTER(vp), C.POINTER(_abi.CompileError)]
+    L.pwaf_node_destroy.argtypes = [vp]
+    L.pwaf_node_destroy.restype = None
+    L.pwaf_node_device_count.argtypes = [vp]
+    L.pwaf_node_device_count.restype = C.c_size_t
+    L.pwaf_node_engine.argtypes = [vp, C.c_size_t]
+    L.pwaf_node_engine.restype = vp
+    L.pwaf_node_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
+    L.pwaf_node_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
+    L.pwaf_node_shard_bounds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pwaf_node_shard_bounds.restype = None
     L.pwaf_batcher_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.pwaf_batcher_evaluate.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
     L.pwaf_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -366,6 +377,58 @@ class RuleEngine:
         if n < 0:
             _raise(n, lib().pwaf_last_error().decode(errors="replace"))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].alg_bytes)) for i in range(n)]
+
+
+class NodeEngine:
+    """One process driving several GPUs (pwaf_node_*): an engine replica per device, host batches cut into 64-aligned slabs, one host
+    thread and stream per device, action counters summed on the host. The single-process counterpart of bench.py's rank-per-GPU mode."""
+
+    def __init__(self, rules, lists=None, geoip=None, devices: Sequence[int] = (0,), **opts):
+        L = lib()
+        m = _abi.Marshalled()
+        r, nr = _abi.marshal_rules(_norm_rules(rules), m)
+        l, nl = _abi.marshal_lists(lists, m)
+        g = _abi.marshal_geoip(geoip, m)
+        o = _options(**opts)
+        h = C.c_void_p()
+        err = _abi.CompileError()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = L.pwaf_node_create(r, nr, l, nl, g, C.byref(o), devs, len(devices), C.byref(h), C.byref(err))
+        if rc != 0:
+            _raise(rc, err.message.decode(errors="replace") or L.pwaf_last_error().decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self._h = h
+        e0 = L.pwaf_node_engine(h, 0)
+        self.header_names = [L.pwaf_engine_header_name(e0, i).decode() for i in range(L.pwaf_engine_header_count(e0))]
+        self.n_devices = L.pwaf_node_device_count(h)
+
+    def evaluate_batch(self, batch: RequestBatch, with_counts: bool = False):
+        out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
+        counts = _abi.Counts()
+        st = batch.as_struct(self.header_names)
+        rc = lib().pwaf_node_evaluate_batch(self._h, C.byref(st), out.ctypes.data, C.addressof(counts))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return (out, np.array(list(counts.by_action), dtype=np.uint64)) if with_counts else out
+
+    def tune(self, sample: RequestBatch) -> None:
+        st = sample.as_struct(self.header_names)
+        rc = lib().pwaf_node_tune(self._h, C.byref(st))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pwaf_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def node_shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    lo, hi = C.c_uint32(), C.c_uint32()
+    lib().pwaf_node_shard_bounds(n, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 class ServiceRouter:

@@ -12,7 +12,7 @@ import pytest
 import helpers as H
 from oracle import pyoracle
 from pingoo_amd import Request, RequestBatch, _abi, geoip_entries
-from pingoo_amd.engine import RuleEngine
+from pingoo_amd.engine import DeviceBatch, RuleEngine
 
 pytestmark = pytest.mark.gpu
 B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
@@ -134,3 +134,67 @@ def test_service_routing_is_first_match_over_route_expressions():
     assert (got2[got >= 0] == got[got >= 0]).all() and (got2[got < 0] == len(routes)).all()
     router.close()
     r2.close()
+
+
+def test_node_api_two_engines_from_one_thread_and_concurrent_device_calls():
+    """The single-process multi-device entry point (pwaf_node_*) with two replicas (both on device 0 here: the driver box has one GPU;
+    what matters is two engines created from ONE thread — per-device kernel configuration — and slabs evaluated on two host threads),
+    then two threads issuing pwaf_evaluate_device on two streams of one engine at the same time (per-call scratch contexts)."""
+    import threading
+
+    import torch
+
+    from pingoo_amd.engine import NodeEngine
+    from synth import pysynth
+
+    w = pysynth.Workload(0)  # tiny mixed config incl. header fields
+    batch = w.batch(0, 20001)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=8)
+    node = NodeEngine(w.rules, w.lists, w.geoip, devices=[0, 0])
+    assert node.n_devices == 2
+    got, counts = node.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, "node, 2 replicas")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    node.tune(w.batch(100000, 2000))
+    H.assert_verdicts_equal(node.evaluate_batch(batch), want, batch, "node, tuned")
+    node.close()
+
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    halves = [batch.slice(0, 10000), batch.slice(10000, 20001)]
+    dbs = [DeviceBatch(h) for h in halves]
+    outs, errs = [None, None], []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            for _ in range(5):  # several in-flight calls per stream: the ring of contexts is reused under load
+                outs[k] = eng.evaluate_device(dbs[k], stream=s.cuda_stream)
+            s.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    eng.device_status()
+    for k, (lo, hi) in enumerate([(0, 10000), (10000, 20001)]):
+        g = outs[k].cpu().numpy().view(np.uint32)
+        assert (g[:, 0] == want["action"][lo:hi]).all() and (g[:, 1] == want["rule_idx"][lo:hi]).all(), f"stream {k}"
+    eng.close()
+
+
+def test_overflow_pool_exhaustion_is_retried_not_reported():
+    """A hostile batch whose requests each match many patterns of one pass (more than the two inline hit-record slots) at a size that
+    exhausts the default overflow pool: the synchronous entry point grows the pool and runs the batch again."""
+    toks = ["aa1", "bb2", "cc3", "dd4", "ee5", "ff6", "gg7", "hh8", "ii9", "jj0", "kk1", "ll2"]
+    rules = [(f"r{k}", f'http_request.url.contains("{t}") && http_request.path.length() > 1000', [B]) for k, t in enumerate(toks)]
+    rules.append(("all", " && ".join(f'http_request.url.contains("{t}")' for t in toks), [CAP]))
+    eng = RuleEngine(rules)
+    n = 200_000  # pool = max(1M, 8 n) = 1.6M entries; every request needs 12
+    batch = RequestBatch.from_requests([Request(url="/" + "-".join(toks), path="/p", host="h")]).tile(n)
+    got = eng.evaluate_batch(batch)
+    assert (got["action"] == 2).all() and (got["rule_idx"] == len(toks)).all()
+    eng.close()

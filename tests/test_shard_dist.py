@@ -29,6 +29,16 @@ def test_shard_bounds_partition_every_batch_size():
         shard.shard_bounds(10, 2, 2)
 
 
+def test_library_slab_split_equals_the_python_one():
+    """pwaf_node_evaluate_batch (one process, N devices) cuts a batch exactly like the process-per-GPU mode does."""
+    from pingoo_amd.engine import node_shard_bounds
+
+    for n in [0, 1, 63, 64, 65, 127, 128, 1000, 4096, 100001, 10_000_000, 2 ** 32 - 1]:
+        for world in [1, 2, 3, 4, 8]:
+            for r in range(world):
+                assert node_shard_bounds(n, r, world) == shard.shard_bounds(n, r, world), (n, r, world)
+
+
 def _worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
