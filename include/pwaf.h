@@ -112,6 +112,8 @@ void pwaf_list_free(char **items, size_t n);
 
 #define PWAF_OPT_NO_UA_GATE 1u        /* skip gate A (http_listener.rs:196-198)             */
 #define PWAF_OPT_NO_CAPTCHA_BYPASS 2u /* skip gate B (http_listener.rs:200-204)             */
+#define PWAF_OPT_STRICT 8u            /* a rule the device compiler cannot take fails engine creation (default: that rule alone never
+                                       * matches and reports why through pwaf_program_rule_status / the warnings) */
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
@@ -220,6 +222,10 @@ void pwaf_program_destroy(pwaf_program *);
 size_t pwaf_program_dump(const pwaf_program *, uint8_t *buf, size_t cap);
 /* Number of per-rule warnings (statically-erroring expressions that can never match,
  * pingoo/rules.rs:41-45) and their text. */
+/* Per caller rule: PWAF_OK, or PWAF_E_UNSUPPORTED with the reason in `msg` when the device compiler cannot evaluate its expression
+ * (DESIGN.md §3.5). The reference evaluates any expression (pingoo/rules.rs:37-51); an unsupported rule here never matches — the
+ * reference's own behaviour for a rule whose execution fails (rules.rs:41-45) — and the host can see which ones. */
+int pwaf_program_rule_status(const pwaf_program *, uint32_t rule_index, char *msg, size_t msg_len);
 size_t pwaf_program_warning_count(const pwaf_program *);
 const char *pwaf_program_warning(const pwaf_program *, size_t i);
 

@@ -64,7 +64,10 @@ struct pwaf_batcher {
     Slot slot[2];  // [0]: requests without GeoIP columns, [1]: requests that bring asn / country (a batch has them for all or none)
     bool stop = false;
     uint64_t n_batches = 0, n_requests = 0;
-    std::thread worker;
+    uint32_t active = 0;  // callers inside pwaf_batcher_evaluate: destroy waits for them
+    // two dispatchers: while one waits for its batch on the device, the other closes and submits the next one (the engine's per-call
+    // contexts let their copies and kernels overlap)
+    std::thread worker[2];
 
     void run() {
         std::unique_lock<std::mutex> lk(mu);
@@ -94,6 +97,7 @@ struct pwaf_batcher {
             pb.n = b.n;
             pb.memory = PWAF_MEM_HOST;
             for (int f = 0; f < PWAF_N_FIELDS; f++) {
+                b.data[f].reserve(b.data[f].size() + PWAF_ARENA_PAD);  // (reserved when the slot was reset: does not throw in practice)
                 b.data[f].resize(b.data[f].size() + PWAF_ARENA_PAD, 0);
                 pb.field[f].data = b.data[f].data();
                 pb.field[f].offsets = b.offs[f].data();
@@ -106,9 +110,17 @@ struct pwaf_batcher {
                 pb.asn = b.asn.data();
                 pb.country = b.country.data();
             }
-            std::vector<pwaf_verdict> out(b.n);
-            const int rc = pwaf_evaluate_batch(engine, &pb, out.data(), nullptr);
-            const std::string err = rc ? pwaf_last_error() : "";
+            std::vector<pwaf_verdict> out;
+            int rc;
+            std::string err;
+            try {
+                out.resize(b.n);
+                rc = pwaf_evaluate_batch(engine, &pb, out.data(), nullptr);
+                if (rc) err = pwaf_last_error();
+            } catch (const std::exception &ex) {
+                rc = PWAF_E_NOMEM;
+                err = std::string("micro-batcher: ") + ex.what();
+            }
             lk.lock();
             b.gen->verdicts = std::move(out);
             b.gen->status = rc;
@@ -132,7 +144,7 @@ int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_de
     b->max_delay = std::chrono::microseconds(max_delay_us);
     b->slot[0].reset();
     b->slot[1].reset();
-    b->worker = std::thread([b] { b->run(); });
+    for (auto &w : b->worker) w = std::thread([b] { b->run(); });
     *out = b;
     return PWAF_OK;
 }
@@ -143,37 +155,58 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
     const uint32_t len[PWAF_N_FIELDS] = {r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
     for (int f = 0; f < PWAF_N_FIELDS; f++)
         if (len[f] && !ptr[f]) return fail(PWAF_E_INVALID_ARG, "NULL field with non-zero length");
+    // what would fail the SHARED batch is refused here, for this caller only (pingoo/geoip.rs:128-142: two letters A-Z)
+    if (r->has_geoip && (r->country[0] < 'A' || r->country[0] > 'Z' || r->country[1] < 'A' || r->country[1] > 'Z'))
+        return fail(PWAF_E_BATCH, "country is not two letters A-Z (pingoo/geoip.rs:128-142)");
     std::shared_ptr<Generation> gen;
-    uint32_t idx;
+    uint32_t idx = 0;
+    int rc = PWAF_OK;
+    std::string emsg;
     {
         std::unique_lock<std::mutex> lk(b->mu);
         if (b->stop) return fail(PWAF_E_INVALID_ARG, "batcher is shutting down");
-        Slot &s = b->slot[r->has_geoip ? 1 : 0];
-        // a full slot the dispatcher has not picked up yet: wait for it to be taken
-        while (s.n >= b->max_batch && !b->stop) {
-            b->cv_work.notify_one();
-            b->cv_done.wait_for(lk, std::chrono::microseconds(50));
+        b->active++;
+        try {
+            // a full slot the dispatcher has not picked up yet: wait for it to be taken
+            while (b->slot[r->has_geoip ? 1 : 0].n >= b->max_batch && !b->stop) {
+                b->cv_work.notify_one();
+                b->cv_done.wait_for(lk, std::chrono::microseconds(50));
+            }
+            if (b->stop) {
+                rc = PWAF_E_INVALID_ARG;
+                emsg = "batcher is shutting down";
+            } else {
+                Slot &t = b->slot[r->has_geoip ? 1 : 0];
+                for (int f = 0; f < PWAF_N_FIELDS && rc == PWAF_OK; f++)
+                    if ((uint64_t)t.data[f].size() + len[f] > 0xFFFFFFF0ull) { rc = PWAF_E_BATCH; emsg = "batch field arena would exceed 4 GiB"; }
+                if (rc == PWAF_OK) {
+                    for (int f = 0; f < PWAF_N_FIELDS; f++) {
+                        t.data[f].insert(t.data[f].end(), (const uint8_t *)ptr[f], (const uint8_t *)ptr[f] + len[f]);
+                        t.offs[f].push_back((uint32_t)t.data[f].size());
+                    }
+                    t.ip.insert(t.ip.end(), r->ip, r->ip + 16);
+                    t.v6.push_back(r->ip_is_v6);
+                    t.flags.push_back(r->flags);
+                    t.port.push_back(r->port);
+                    if (r->has_geoip) {
+                        t.asn.push_back(r->asn);
+                        t.country.push_back((uint16_t)(r->country[0] | (r->country[1] << 8)));
+                    }
+                    idx = t.n++;
+                    gen = t.gen;
+                    if (idx == 0) t.deadline = Clock::now() + b->max_delay;
+                    if (idx == 0 || t.n >= b->max_batch) b->cv_work.notify_one();
+                    b->cv_done.wait(lk, [&] { return gen->done; });
+                }
+            }
+        } catch (const std::exception &ex) {  // (std::bad_alloc while appending: nothing may escape the C ABI)
+            rc = PWAF_E_NOMEM;
+            emsg = std::string("micro-batcher: ") + ex.what();
         }
-        Slot &t = b->slot[r->has_geoip ? 1 : 0];
-        for (int f = 0; f < PWAF_N_FIELDS; f++) {
-            if ((uint64_t)t.data[f].size() + len[f] > 0xFFFFFFF0ull) return fail(PWAF_E_BATCH, "batch field arena would exceed 4 GiB");
-            t.data[f].insert(t.data[f].end(), (const uint8_t *)ptr[f], (const uint8_t *)ptr[f] + len[f]);
-            t.offs[f].push_back((uint32_t)t.data[f].size());
-        }
-        t.ip.insert(t.ip.end(), r->ip, r->ip + 16);
-        t.v6.push_back(r->ip_is_v6);
-        t.flags.push_back(r->flags);
-        t.port.push_back(r->port);
-        if (r->has_geoip) {
-            t.asn.push_back(r->asn);
-            t.country.push_back((uint16_t)(r->country[0] | (r->country[1] << 8)));
-        }
-        idx = t.n++;
-        gen = t.gen;
-        if (idx == 0) t.deadline = Clock::now() + b->max_delay;
-        if (idx == 0 || t.n >= b->max_batch) b->cv_work.notify_one();
-        b->cv_done.wait(lk, [&] { return gen->done; });
+        b->active--;
+        if (b->active == 0) b->cv_done.notify_all();
     }
+    if (rc != PWAF_OK) return fail(rc, emsg);
     if (gen->status != PWAF_OK) return fail(gen->status, gen->error);
     *out = gen->verdicts[idx];
     return PWAF_OK;
@@ -194,7 +227,14 @@ void pwaf_batcher_destroy(pwaf_batcher *b) {
         b->stop = true;  // pending requests are still evaluated (the dispatcher drains both slots before it returns)
     }
     b->cv_work.notify_all();
-    if (b->worker.joinable()) b->worker.join();
+    for (auto &w : b->worker)
+        if (w.joinable()) w.join();
+    {
+        // callers still inside pwaf_batcher_evaluate (woken by their batch, or refused because of `stop`) leave before the object goes
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_done.notify_all();
+        b->cv_done.wait(lk, [&] { return b->active == 0; });
+    }
     delete b;
 }
 

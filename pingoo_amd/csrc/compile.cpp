@@ -212,6 +212,18 @@ public:
         return atom_tf(intern_atom(std::move(a)));
     }
 
+    // one request string field against another (pingoo/rules.rs:37-51 evaluates any expression: `url.contains(host)`,
+    // `host == headers["x-forwarded-host"]`, `path.length() < url.length()` are all legal): a device atom of its own kind
+    TF fcmp_atom(int a, int b, FcmpOp op) {
+        Atom at;
+        at.kind = ATOM_FCMP;
+        at.field = (uint8_t)a;
+        at.ref = (uint32_t)b;
+        at.c = (int64_t)op;
+        at.key = "F" + std::to_string(a) + ":" + std::to_string((int)op) + ":" + std::to_string(b);
+        return atom_tf(intern_atom(std::move(at)));
+    }
+
     static RNodeP anchored(RNodeP body, bool start, bool end) {
         std::vector<RNodeP> k;
         if (start) k.push_back(rx_assert(A_TEXT_START));
@@ -524,7 +536,11 @@ public:
             if (fn == F_ENDS) for (size_t l = 1; l <= h.size(); l++) cands.push_back(h.substr(h.size() - l));
             return sv_tf(string_in_set(arg, cands));
         }
-        throw Unsupported{"string function between two request fields"};
+        if (recv.k == SVal::FIELD && arg.k == SVal::FIELD) {
+            if (recv.field == arg.field) return sv_bool(true);  // every string contains / starts with / ends with itself
+            return sv_tf(fcmp_atom(recv.field, arg.field, fn == F_CONTAINS ? FC_CONTAINS : fn == F_STARTS ? FC_STARTS : FC_ENDS));
+        }
+        throw Unsupported{"string function between client.country and a request field"};
     }
 
     SVal regex_fn(const SVal &recv, const SVal &arg) {
@@ -800,7 +816,15 @@ public:
         // dynamic vs dynamic
         bool ls = is_dyn_string(l), rs = is_dyn_string(r), li = is_dyn_int(l), ri = is_dyn_int(r);
         if ((ls && (ri || r.k == SVal::IPVAR)) || (li && (rs || r.k == SVal::IPVAR)) || (l.k == SVal::IPVAR && (rs || ri))) return sv_bool(negate);  // types differ
-        throw Unsupported{"comparison between two request values"};
+        if (l.k == SVal::FIELD && r.k == SVal::FIELD) {
+            if (l.field == r.field) return sv_bool(!negate);
+            return fin(fcmp_atom(std::min(l.field, r.field), std::max(l.field, r.field), FC_EQ));
+        }
+        if (l.k == SVal::LEN && r.k == SVal::LEN) {
+            if (l.field == r.field) return sv_bool(!negate);
+            return fin(fcmp_atom(std::min(l.field, r.field), std::max(l.field, r.field), FC_LEN_EQ));
+        }
+        throw Unsupported{"comparison between two request values of these kinds"};
     }
 
     SVal ordering(const SVal &l, const SVal &r, CmpOp op) {
@@ -829,7 +853,15 @@ public:
             return sv_err("values are not comparable");
         }
         bool ln = is_dyn_int(l), rn = is_dyn_int(r), ls = is_dyn_string(l), rs = is_dyn_string(r);
-        if ((ln && rn) || (ls && rs)) throw Unsupported{"ordering between two request values"};
+        if (l.k == SVal::LEN && r.k == SVal::LEN) {
+            // a.length() <op> b.length(): LT / LE as atoms, GT / GE by swapping the operands
+            if (l.field == r.field) return sv_bool(op == OP_LE || op == OP_GE);
+            if (op == OP_LT) return sv_tf(fcmp_atom(l.field, r.field, FC_LEN_LT));
+            if (op == OP_LE) return sv_tf(fcmp_atom(l.field, r.field, FC_LEN_LE));
+            if (op == OP_GT) return sv_tf(fcmp_atom(r.field, l.field, FC_LEN_LT));
+            return sv_tf(fcmp_atom(r.field, l.field, FC_LEN_LE));
+        }
+        if ((ln && rn) || (ls && rs)) throw Unsupported{"ordering between two request values of these kinds"};
         return sv_err("values are not comparable");
     }
 
@@ -1053,6 +1085,12 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
 
     // ---- user rules ----
     P.n_user_rules = (uint32_t)in.n_rules;
+    P.rule_status.assign(in.n_rules, {PWAF_OK, std::string()});
+    const bool strict = (P.flags & PWAF_OPT_STRICT) != 0;
+    auto unsupported_rule = [&](size_t k, const std::string &why) {
+        P.rule_status[k] = {PWAF_E_UNSUPPORTED, why};
+        P.warnings.push_back("rule #" + std::to_string(k) + " is NOT evaluated (it never matches): " + why);
+    };
     for (size_t k = 0; k < in.n_rules; k++) {
         const pwaf_rule_desc &rd = in.rules[k];
         std::string rname = rd.name ? rd.name : ("#" + std::to_string(k));
@@ -1091,8 +1129,12 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                     t_root = 0;
                 }
             } catch (Unsupported &u) {
-                set_err(err, PWAF_E_UNSUPPORTED, (uint32_t)k, "rule " + rname + ": " + u.msg);
-                return PWAF_E_UNSUPPORTED;
+                if (strict) {
+                    set_err(err, PWAF_E_UNSUPPORTED, (uint32_t)k, "rule " + rname + ": " + u.msg);
+                    return PWAF_E_UNSUPPORTED;
+                }
+                unsupported_rule(k, "rule " + rname + ": " + u.msg);
+                t_root = 0;
             }
         }
         if (eff_u == PWAF_ACTION_ALLOW && eff_v == PWAF_ACTION_ALLOW) continue;  // no action can ever take effect
@@ -1108,8 +1150,12 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             rule_terms.push_back(dnf.conv(r.t_root, false));
         } catch (Unsupported &u) {
             uint32_t idx = r.public_idx < in.n_rules ? r.public_idx : 0xFFFFFFFFu;
-            set_err(err, PWAF_E_UNSUPPORTED, idx, "rule #" + std::to_string(r.public_idx) + ": " + u.msg);
-            return PWAF_E_UNSUPPORTED;
+            if (strict || idx == 0xFFFFFFFFu) {
+                set_err(err, PWAF_E_UNSUPPORTED, idx, "rule #" + std::to_string(r.public_idx) + ": " + u.msg);
+                return PWAF_E_UNSUPPORTED;
+            }
+            unsupported_rule(idx, u.msg);
+            rule_terms.push_back({});  // no term: never matches
         }
     }
     // atoms that survived simplification
@@ -1121,7 +1167,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     uint32_t col = 1;
     for (size_t a = 1; a < P.atoms.size(); a++) {
         Atom &at = P.atoms[a];
-        if (!used[a] || at.kind == ATOM_SCAN) continue;
+        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP) continue;
         at.id = col++;
     }
     uint32_t n_numeric = col - 1;
@@ -1132,6 +1178,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // unbounded wide-class repetition in the middle (".*") multiply states with each other, so when the joint DFA
     // explodes they are isolated into small groups of their own.
     auto field_name = [&](int f) { return f < PWAF_N_FIELDS ? std::string(kFieldNames[f]) : "headers[\"" + P.header_names[(size_t)f - PWAF_N_FIELDS] + "\"]"; };
+    std::vector<std::pair<uint32_t, std::string>> bad_atoms;  // patterns no DFA could be built for
     for (int f = 0; f < PWAF_N_FIELDS + (int)P.header_names.size(); f++) {
         std::vector<ScanPattern> pats;
         for (size_t a = 1; a < P.atoms.size(); a++)
@@ -1157,8 +1204,10 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                 continue;
             }
             if (cur.size() == 1) {
-                set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, std::string("a pattern on http_request.") + field_name(f) + " needs a DFA beyond the state/table budget: " + derr);
-                return PWAF_E_UNSUPPORTED;
+                // one pattern alone exceeds the budget (typically a bounded gap such as a.{0,40}b: the DFA must remember every
+                // position of the last 40 bytes): the rules that use it are reported and dropped, the rest of the set is unaffected
+                bad_atoms.emplace_back(cur[0].atom, std::string("a pattern on http_request.") + field_name(f) + " needs a DFA beyond the state/table budget: " + derr);
+                continue;
             }
             std::vector<ScanPattern> gap, plain;
             for (auto &p : cur) (has_wide_gap(*p.rx) ? gap : plain).push_back(p);
@@ -1199,11 +1248,46 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             }
         }
     }
+    if (!bad_atoms.empty()) {
+        // every rule with such a pattern in some term: reported by index (strict: creation fails naming the first one)
+        for (size_t k = 0; k < routs.size(); k++) {
+            const std::string *why = nullptr;
+            for (auto &t : rule_terms[k])
+                for (uint32_t l : t)
+                    for (auto &ba : bad_atoms)
+                        if ((l >> 1) == ba.first) why = &ba.second;
+            if (!why) continue;
+            const uint32_t idx = routs[k].public_idx < in.n_rules ? routs[k].public_idx : 0xFFFFFFFFu;
+            if (strict || idx == 0xFFFFFFFFu) {
+                set_err(err, PWAF_E_UNSUPPORTED, idx, *why);
+                return PWAF_E_UNSUPPORTED;
+            }
+            unsupported_rule(idx, *why);
+            rule_terms[k].clear();
+        }
+    }
     // gated groups run after every ungated one (their factors must have been scanned), and resolve factor columns
     std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty(); });
     for (auto &g : P.groups)
         for (uint32_t fa : g.filter_atoms) g.filter_cols.push_back(P.atoms[fa].id);
     P.n_scan_cols = next_col - scan_base;
+    // field-against-field atoms: one more (pseudo) pass after the DFA passes
+    P.fcmp_base = next_col;
+    {
+        std::vector<uint8_t> fields;
+        for (size_t a = 1; a < P.atoms.size(); a++) {
+            Atom &at = P.atoms[a];
+            if (!used[a] || at.kind != ATOM_FCMP) continue;
+            for (uint8_t f : {at.field, (uint8_t)at.ref})
+                if (std::find(fields.begin(), fields.end(), f) == fields.end()) fields.push_back(f);
+            if (P.fcmp.size() >= kMaxFcmpAtoms || fields.size() > kMaxFcmpFields) {
+                set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "more than 32 field-against-field predicates, or more than 8 distinct fields in them");
+                return PWAF_E_UNSUPPORTED;
+            }
+            at.id = next_col++;
+            P.fcmp.push_back({at.id, (uint8_t)at.c, at.field, (uint8_t)at.ref, 0});
+        }
+    }
     P.n_cols = next_col;
     if (P.groups.size() > kMaxGroups) {
         set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "the rule set needs more than " + std::to_string(kMaxGroups) + " scan passes");
@@ -1226,7 +1310,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // ---- numeric atom descriptors ----
     for (size_t a = 1; a < P.atoms.size(); a++) {
         const Atom &at = P.atoms[a];
-        if (!used[a] || at.kind == ATOM_SCAN) continue;
+        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP) continue;
         NumAtomDev d{};
         d.col = at.id;
         d.kind = at.kind;
@@ -1387,6 +1471,7 @@ std::vector<uint8_t> dump_program(const Program &p) {
         for (auto &h : p.header_names) { names += h; names += '\0'; }
         w.section("HDRS", (uint32_t)p.header_names.size(), names.data(), names.size());
     }
+    w.section("FCMP", (uint32_t)p.fcmp.size(), p.fcmp.data(), p.fcmp.size() * sizeof(FcmpAtom));
     w.section("NUMA", (uint32_t)p.num_atoms.size(), p.num_atoms.data(), p.num_atoms.size() * sizeof(NumAtomDev));
     w.section("INTP", (uint32_t)p.int_pool.size(), p.int_pool.data(), p.int_pool.size() * 8);
     w.section("CLUT", (uint32_t)p.country_luts.size(), p.country_lut_words.data(), p.country_lut_words.size() * 4);

@@ -406,7 +406,8 @@ int assign_lists(pwaf_engine *e) {
     }
     {
         // the verdict kernel's pass table: first column + where the pass's visited bitmap lives
-        std::vector<PassInfo> pt(std::max<size_t>(1, e->groups.size()));
+        std::vector<PassInfo> pt(e->groups.size() + 1);
+        pt[e->groups.size()] = PassInfo{P.fcmp_base, 0u};  // the pseudo pass of the field-against-field atoms (dense records)
         uint32_t fi = 0;
         for (size_t k = 0; k < e->groups.size(); k++) {
             const DevGroup &d = e->groups[k];
@@ -437,7 +438,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
-    const uint32_t n_passes = (uint32_t)e->groups.size();
+    const uint32_t n_passes = (uint32_t)e->groups.size() + (P.fcmp.empty() ? 0u : 1u);  // (+ the pseudo pass of the field-against-field atoms)
     int rc;
     // scratch sized for the worst case the 288 GB part can afford: one 4-byte hit record per (pass, request) and an overflow
     // pool of 8 entries per request (exhaustion is reported through the status word, never silently)
@@ -819,6 +820,36 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         }
         if ((rc = flush_gated())) return rc;
     }
+    if (!P.fcmp.empty()) {
+        // field-against-field atoms: the last (pseudo) pass; its hit records are written for every request
+        FcmpArgs fa{};
+        std::vector<uint32_t> slots;  // field ids in use, by slot
+        for (size_t k = 0; k < P.fcmp.size(); k++) {
+            uint32_t sl[2];
+            const uint32_t fld[2] = {P.fcmp[k].a, P.fcmp[k].b};
+            for (int q = 0; q < 2; q++) {
+                size_t at = std::find(slots.begin(), slots.end(), fld[q]) - slots.begin();
+                if (at == slots.size()) slots.push_back(fld[q]);
+                sl[q] = (uint32_t)at;
+            }
+            fa.atoms[k] = P.fcmp[k].op | (sl[0] << 8) | (sl[1] << 16);
+        }
+        for (size_t q = 0; q < slots.size() && q < kMaxFcmpFields; q++) {
+            fa.data[q] = cols[slots[q]].data;
+            fa.off[q] = cols[slots[q]].offsets;
+        }
+        fa.n = n;
+        fa.n_atoms = (uint32_t)P.fcmp.size();
+        fa.rec = (uint32_t *)S.rec.p + e->groups.size() * (size_t)n;
+        fa.pool = (PoolEntry *)S.pool.p;
+        fa.pool_count = (uint32_t *)S.ctrl.p;
+        fa.pool_cap = pool_cap;
+        fa.status = (uint32_t *)S.status.p;
+        if ((rc = mark(nullptr, 0))) return rc;
+        int he = launch_fcmp(fa, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("field comparison kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc = mark("fcmp", 0xFBu))) return rc;
+    }
     HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
@@ -898,6 +929,12 @@ size_t pwaf_program_dump(const pwaf_program *p, uint8_t *buf, size_t cap) {
     if (mp->dump.empty()) mp->dump = dump_program(*p->p);
     if (buf && cap) memcpy(buf, mp->dump.data(), std::min(cap, mp->dump.size()));
     return mp->dump.size();
+}
+int pwaf_program_rule_status(const pwaf_program *p, uint32_t i, char *msg, size_t msg_len) {
+    if (msg && msg_len) msg[0] = 0;
+    if (!p || i >= p->p->rule_status.size()) return PWAF_E_INVALID_ARG;
+    if (msg && msg_len) snprintf(msg, msg_len, "%s", p->p->rule_status[i].second.c_str());
+    return p->p->rule_status[i].first;
 }
 size_t pwaf_program_warning_count(const pwaf_program *p) { return p ? p->p->warnings.size() : 0; }
 const char *pwaf_program_warning(const pwaf_program *p, size_t i) { return (p && i < p->p->warnings.size()) ? p->p->warnings[i].c_str() : ""; }

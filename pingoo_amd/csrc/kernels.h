@@ -157,6 +157,20 @@ struct PassInfo {
     uint32_t base;       // first device column of the pass
     uint32_t kind_slot;  // kind << 24 | slot
 };
+// Field-against-field atoms (program.h: ATOM_FCMP): one lane per request compares the two strings (or their lengths); the results
+// are written as the hit record of one more pass whose local atom k is atoms[k].
+struct FcmpArgs {
+    const uint8_t *data[kMaxFcmpFields];
+    const uint32_t *off[kMaxFcmpFields];
+    uint32_t atoms[kMaxFcmpAtoms];  // op | field slot a << 8 | field slot b << 16
+    uint32_t n, n_atoms;
+    uint32_t *rec;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t pool_cap;
+    uint32_t *status;
+};
+int launch_fcmp(const FcmpArgs &a, void *stream);
 struct CmpAtomDev {
     uint32_t col, c;
 };

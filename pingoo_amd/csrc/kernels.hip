@@ -816,6 +816,46 @@ int launch_compact(const FilterBatchArgs &b, void *stream) {
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
+// fcmp_kernel: field-against-field atoms (one string field of a request against another: ==, contains, starts_with, ends_with, or a
+// comparison of their lengths). One lane per request; rare in rule sets, so plain byte loops (both fields were just streamed: cache hits).
+__global__ __launch_bounds__(256) void fcmp_kernel(FcmpArgs a) {
+    const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < a.n; r += gridDim.x * 256u) {
+        Hits h{0, 0, kNone};
+        for (uint32_t k = 0; k < a.n_atoms; k++) {
+            const uint32_t op = a.atoms[k] & 0xFFu, sa = (a.atoms[k] >> 8) & 0xFFu, sb = (a.atoms[k] >> 16) & 0xFFu;
+            const uint32_t a0 = a.off[sa][r], la = a.off[sa][r + 1] - a0, b0 = a.off[sb][r], lb = a.off[sb][r + 1] - b0;
+            const uint8_t *x = a.data[sa] + a0, *y = a.data[sb] + b0;
+            bool holds = false;
+            auto same = [&](const uint8_t *p, const uint8_t *q, uint32_t len) {
+                for (uint32_t i = 0; i < len; i++)
+                    if (p[i] != q[i]) return false;
+                return true;
+            };
+            switch (op) {
+                case FC_EQ: holds = la == lb && same(x, y, la); break;
+                case FC_STARTS: holds = la >= lb && same(x, y, lb); break;
+                case FC_ENDS: holds = la >= lb && same(x + (la - lb), y, lb); break;
+                case FC_CONTAINS:
+                    if (la >= lb)
+                        for (uint32_t s = 0; s + lb <= la && !holds; s++) holds = same(x + s, y, lb);
+                    break;
+                case FC_LEN_EQ: holds = la == lb; break;
+                case FC_LEN_LT: holds = la < lb; break;
+                default: holds = la <= lb; break;
+            }
+            if (holds) h = record_atom(ctx, k, h);
+        }
+        a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+    }
+}
+
+int launch_fcmp(const FcmpArgs &a, void *stream) {
+    if (a.n == 0 || a.n_atoms == 0) return 0;
+    hipLaunchKernelGGL(fcmp_kernel, dim3(std::min<uint32_t>((a.n + 255) / 256, 4096u)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------------------
 // verdict
 // -------------------------------------------------------------------------------------------------

@@ -53,7 +53,15 @@ enum AtomKind : uint8_t {
     ATOM_INTSET,     // client.remote_port / client.asn in sorted set
     ATOM_IPSET,      // client.ip contained in CIDR list L
     ATOM_COUNTRY,    // client.country in 676-bit table
+    ATOM_FCMP,       // one request string field against ANOTHER (== / contains / starts_with / ends_with, or their lengths)
 };
+// ATOM_FCMP operators (Atom::c): field `field` against field `ref`
+enum FcmpOp : uint8_t { FC_EQ = 0, FC_CONTAINS, FC_STARTS, FC_ENDS, FC_LEN_EQ, FC_LEN_LT, FC_LEN_LE };
+struct FcmpAtom {
+    uint32_t col;  // device column
+    uint8_t op, a, b, pad;
+};
+static constexpr uint32_t kMaxFcmpAtoms = 32, kMaxFcmpFields = 8;
 enum CmpOp : uint8_t { OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE };
 enum IntVar : uint8_t { VAR_PORT = 0, VAR_ASN = 1 };
 
@@ -189,12 +197,17 @@ struct Program {
     std::vector<std::vector<int64_t>> int_sets;  // sorted, unique
     std::vector<std::bitset<704>> country_luts;  // index = (c0-'A')*26 + (c1-'A')
     std::vector<std::string> warnings;
+    // per caller rule: PWAF_OK, or why the device compiler could not take it (PWAF_E_UNSUPPORTED + text). Such a rule never matches
+    // (and says so here and in the warnings) instead of failing the whole rule set, unless PWAF_OPT_STRICT asks for the failure.
+    std::vector<std::pair<int, std::string>> rule_status;
 
     // device-level
     uint32_t n_cols = 0;          // total columns: [0] TRUE, numeric atoms, then each DFA group's atoms
     uint32_t n_scan_cols = 0;     // columns owned by DFA groups
     std::vector<DfaGroup> groups;
     std::vector<NumAtomDev> num_atoms;
+    std::vector<FcmpAtom> fcmp;   // field-against-field atoms: one more (pseudo) pass, columns [fcmp_base, fcmp_base + fcmp.size())
+    uint32_t fcmp_base = 0;
     std::vector<int64_t> int_pool;
     std::vector<uint32_t> country_lut_words;  // 22 words per lut
     std::vector<DevRule> rules;               // pseudo rules first, then the caller's rules with an effect

@@ -82,6 +82,7 @@ def lib():
     L.pwaf_program_warning.argtypes = [vp, C.c_size_t]
     L.pwaf_program_warning.restype = C.c_char_p
     L.pwaf_program_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
+    L.pwaf_program_rule_status.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
     L.pwaf_engine_create.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
     L.pwaf_engine_destroy.argtypes = [vp]
     L.pwaf_engine_destroy.restype = None
@@ -270,6 +271,15 @@ class CompiledProgram:
         buf = C.create_string_buffer(n)
         lib().pwaf_program_dump(self._h, buf, n)
         return buf.raw
+
+    def rule_status(self, i: int) -> Tuple[int, str]:
+        """(PWAF_OK, "") or (PWAF_E_UNSUPPORTED, reason): a rule the device compiler cannot take never matches and says so here."""
+        buf = C.create_string_buffer(300)
+        rc = lib().pwaf_program_rule_status(self._h, i, buf, 300)
+        return rc, buf.value.decode(errors="replace")
+
+    def unsupported_rules(self, n_rules: int) -> List[int]:
+        return [i for i in range(n_rules) if self.rule_status(i)[0] != 0]
 
     def warnings(self) -> List[str]:
         return [lib().pwaf_program_warning(self._h, i).decode(errors="replace") for i in range(lib().pwaf_program_warning_count(self._h))]

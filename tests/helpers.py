@@ -308,3 +308,10 @@ def lit_requests(rng: random.Random, n: int):
                             method=rng.choice(["GET", "POST"]), user_agent=ua[:255], ip=f"{rng.randint(1, 3)}.{rng.randint(0, 3)}.0.{rng.randint(0, 255)}",
                             remote_port=rng.randint(0, 65535), captcha_verified=rng.random() < 0.3, headers=hdrs or None))
     return reqs
+
+
+def as_the_engine_sees(rules, prog):
+    """The rule list with every rule the device compiler reports as unsupported (pwaf_program_rule_status) replaced by one that never
+    matches — the engine's documented behaviour for such a rule — so that the oracle can check everything else in the set."""
+    bad = set(prog.unsupported_rules(len(rules)))
+    return [(n, "false" if i in bad else e, a) for i, (n, e, a) in enumerate(rules)], bad

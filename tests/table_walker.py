@@ -72,6 +72,8 @@ class Tables:
                                   for k in range(n_heads)]  # (literal, exact, local atom)
             elif tag == "GFTB":
                 cur["f_table"] = np.frombuffer(pl, dtype="<u4")
+            elif tag == "FCMP":
+                self.fcmp = np.frombuffer(pl, dtype=np.dtype([("col", "<u4"), ("op", "u1"), ("a", "u1"), ("b", "u1"), ("pad", "u1")]))
             elif tag == "HDRS":
                 self.header_names = [x.decode() for x in pl.split(b"\0")[:count]]
             elif tag == "NUMA":
@@ -170,6 +172,10 @@ class Tables:
         fields = [batch.field_bytes(f, i) for f in range(5)] + [batch.header_bytes(h, i) for h in getattr(self, "header_names", [])]
         for g in self.groups:
             self.scan_pass(g, fields[g["field"]], cols)
+        for d in getattr(self, "fcmp", []):  # one field against another
+            x, y, op = fields[int(d["a"])], fields[int(d["b"])], int(d["op"])
+            if [x == y, y in x, x.startswith(y), x.endswith(y), len(x) == len(y), len(x) < len(y), len(x) <= len(y)][op]:
+                cols.add(int(d["col"]))
         ip = batch.ip[i].tobytes()
         v6 = bool(batch.ip_is_v6[i])
         port = int(batch.port[i])

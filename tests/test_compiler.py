@@ -77,15 +77,13 @@ def test_fuzz_compiled_tables_match_oracle(seed):
     for k in range(rng.randint(1, 12)):
         e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
         acts = H.fuzz_actions(rng)
-        try:
-            CompiledProgram([("r", e, acts)], lists)
-        except UnsupportedExpression:
-            continue
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
     prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
+    # rules the device compiler cannot take are reported per rule and never match; every other rule of the set is checked
+    seen, _ = H.as_the_engine_sees(rules, prog)
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
-    want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
+    want = pyoracle.Oracle(seen, lists, geo, flags=flags).evaluate(batch)
     H.assert_verdicts_equal(walk(prog, batch), want, batch, f"seed {seed}")
 
 
@@ -118,14 +116,18 @@ def test_static_errors_become_warnings_not_failures():
 
 
 def test_unsupported_constructs_are_rejected_with_the_rule_index():
-    cases = ['http_request.host == http_request.path', "client.remote_port + 1 == 81", 'http_request.path < "m"', 'http_request.path.matches(http_request.host)',
+    cases = ['client.country == http_request.host', "client.remote_port + 1 == 81", 'http_request.path < "m"', 'http_request.path.matches(http_request.host)',
              '(http_request.method == "GET" ? http_request.path : http_request.url) == "/"', 'http_request.url.matches("\\\\p{L}")', 'http_request.path + "x" == "/x"',
              "[http_request.method].contains(\"GET\")", 'http_request.path.matches("(?x)a b")']
     for e in cases:
         pyoracle.compile_expression(e)  # valid language, just outside the device subset
         with pytest.raises(UnsupportedExpression) as ei:
-            CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])])
+            CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])], flags=_abi.OPT_STRICT)
         assert ei.value.rule_index == 1 and "bad" in ei.value.message, e
+        # default: that rule alone is reported and never matches; the set compiles
+        prog = CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])])
+        assert prog.rule_status(0) == (0, "") and prog.rule_status(1)[0] == _abi.E_UNSUPPORTED and "bad" in prog.rule_status(1)[1]
+        assert any("NOT evaluated" in w for w in prog.warnings())
     with pytest.raises(ExpressionIsNotValid) as ei:
         CompiledProgram([("x", "a ==", [B])])
     assert ei.value.rule_index == 0

@@ -89,12 +89,9 @@ for seed in range(12):
     rules = []
     for k in range(rng.randint(3, 14)):
         e = H.rexpr(rng, lists)
-        try:
-            CompiledProgram([("r", e, [1])], lists)
-        except UnsupportedExpression:
-            continue
         rules.append((f"r{k}", e, H.fuzz_actions(rng)))
     eng = RuleEngine(rules, lists, geo)
+    rules, _ = H.as_the_engine_sees(rules, eng.program)
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 500, seed %% 3 == 0))
     want = pyoracle.Oracle(rules, lists, geo).evaluate(batch)
     got, counts = eng.evaluate_batch(batch, with_counts=True)
@@ -197,4 +194,33 @@ def test_overflow_pool_exhaustion_is_retried_not_reported():
     batch = RequestBatch.from_requests([Request(url="/" + "-".join(toks), path="/p", host="h")]).tile(n)
     got = eng.evaluate_batch(batch)
     assert (got["action"] == 2).all() and (got["rule_idx"] == len(toks)).all()
+    eng.close()
+
+
+def test_field_against_field_predicates_and_per_rule_unsupported():
+    """One request field against another on the device (pingoo/rules.rs:37-51 evaluates any expression), and a rule the device compiler
+    cannot take (a bounded gap far beyond the DFA budget) failing alone: it is reported by index, never matches, the rest is unaffected."""
+    rules = [("refl", "http_request.url.contains(http_request.host)", [B]),
+             ("fwd", 'http_request.host == http_request.headers["x-forwarded-host"] && http_request.host != ""', [CAP]),
+             ("len", "http_request.path.length() > http_request.url.length()", [B]),
+             ("pre", "http_request.url.starts_with(http_request.path) && !http_request.url.ends_with(http_request.path)", [CAP]),
+             ("gap", 'http_request.url.matches("select.{0,60}from.{0,60}where")', [B]),
+             ("tail", 'http_request.user_agent.ends_with(http_request.method)', [B])]
+    eng = RuleEngine(rules)
+    prog = eng.program
+    assert prog.unsupported_rules(len(rules)) == [4] and "budget" in prog.rule_status(4)[1]
+    seen, bad = H.as_the_engine_sees(rules, prog)
+    assert bad == {4}
+    rng = random.Random(3)
+    words = ["a", "ex.com", "/p", "/p/q", "GET", "x", "", "select 1 from t where", "/p?host=ex.com"]
+    reqs = [Request(host=rng.choice(words), url=rng.choice(words) + rng.choice(words), path=rng.choice(words), method=rng.choice(["GET", "POST"]),
+                    user_agent=rng.choice(["curl GET", "xPOST", "Mozilla"]), headers={"x-forwarded-host": rng.choice(words)} if rng.random() < 0.6 else None)
+            for _ in range(4000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(seen).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "field against field")
+    assert len(set(want["rule_idx"].tolist())) >= 5
+    with pytest.raises(Exception) as ei:
+        RuleEngine(rules, flags=_abi.OPT_STRICT)
+    assert ei.value.rule_index == 4
     eng.close()

@@ -22,10 +22,6 @@ for seed in range(lo, hi):
     for k in range(rng.randint(1, 12)):
         e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
         acts = H.fuzz_actions(rng)
-        try:
-            CompiledProgram([("r", e, acts)], lists)
-        except UnsupportedExpression:
-            continue
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
     try:
@@ -33,6 +29,7 @@ for seed in range(lo, hi):
     except UnsupportedExpression:
         continue
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
+    rules, _ = H.as_the_engine_sees(rules, prog)
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
     t = Tables(prog.dump())
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
