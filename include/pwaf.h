@@ -97,14 +97,19 @@ typedef struct pwaf_geoip_table {
 } pwaf_geoip_table;
 
 /* ---- data-file readers (the callers' data formats on either side of the path) ----------------------------- */
-/* Flattens a MaxMind DB (the uncompressed content of geoip.mmdb; the reference also accepts .zst, which this library does not
- * decompress) into the prefix table above: one entry per network of the search tree, IPv4 networks of an IPv6 database (those
+/* Flattens a MaxMind DB (the uncompressed content of geoip.mmdb; for .zst see pwaf_geoip_from_file_image) into the prefix table above: one entry per network of the search tree, IPv4 networks of an IPv6 database (those
  * below ::/96) emitted as IPv4 entries as well. Records are read the way the reference deserialises them (pingoo/geoip.rs:17-23,
  * serde_utils.rs:1-9): {"asn": "AS<digits>" string, "country": two upper-case letters}; a record that would make the
  * reference's lookup fail yields the default {0, "XX"} for its network (http_listener.rs:143-157). Replaces
  * maxminddb::Reader::from_source + lookup (geoip.rs:57,73-91). *entries_out is malloc'ed: release with pwaf_geoip_free. */
 int pwaf_geoip_from_mmdb(const uint8_t *mmdb, size_t len, pwaf_geoip_entry **entries_out, size_t *n_out);
 void pwaf_geoip_free(pwaf_geoip_entry *entries);
+/* zstd::decode_all for `.zst` databases (pingoo/geoip.rs:49-55; the reference's Docker image ships geoip.mmdb.zst): libzstd is loaded
+ * at run time; PWAF_E_UNSUPPORTED when it is not installed. *out is malloc'ed: release with pwaf_buffer_free. */
+int pwaf_zstd_decompress(const uint8_t *src, size_t len, uint8_t **out, size_t *out_len);
+void pwaf_buffer_free(uint8_t *);
+/* GeoipDB::load on a file image: decompresses when `path` ends in ".zst" (geoip.rs:49-55), then pwaf_geoip_from_mmdb. */
+int pwaf_geoip_from_file_image(const char *path, const uint8_t *content, size_t len, pwaf_geoip_entry **entries_out, size_t *n_out);
 /* The list-file format of pingoo/lists.rs:62-117: CSV without header, 1 or 2 columns, the first column trimmed is the item.
  * Returns the items as malloc'ed NUL-terminated strings for pwaf_list_desc.items: release with pwaf_list_free. */
 int pwaf_list_parse_csv(const char *text, size_t len, char ***items_out, size_t *n_out);

@@ -77,10 +77,13 @@ def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optio
     except yaml.YAMLError as err:
         raise ConfigError(f"error parsing config file ({config_file}): {err}") from err
     rules = _rules_from_mapping(raw.get("rules"), config_file)
-    folder = rules_folder if rules_folder is not None else os.path.join(os.path.dirname(config_file) or DEFAULT_CONFIG_FOLDER, "rules")
+    # the reference always reads DEFAULT_CONFIG_FOLDER/rules, whatever the config file's path (config.rs:381)
+    folder = rules_folder if rules_folder is not None else os.path.join(DEFAULT_CONFIG_FOLDER, "rules")
     from_folder: List[Tuple[str, Optional[str], List[int]]] = []
     if os.path.isdir(folder):
-        for entry in sorted(os.listdir(folder)):  # (the reference iterates in directory order; sorted makes the order reproducible)
+        # The reference visits the folder in read_dir order (config.rs:383-404), which the OS does not define; first match wins makes
+        # that order meaningful, so files are taken in sorted name order here — name them so that sorted order is the intended one.
+        for entry in sorted(os.listdir(folder)):
             if not entry.endswith(".yml"):
                 continue
             p = os.path.join(folder, entry)
@@ -108,12 +111,14 @@ def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optio
 
 
 def load_geoip(paths: Sequence[str] = GEOIP_DATABASE_PATHS):
-    """First existing database of `paths` as a prefix table, or None (geoip.rs:94-110). `.zst` files are recognised but not
-    decompressed here (no zstd in this image): decompress them beforehand."""
+    """First existing database of `paths` as a prefix table, or None (geoip.rs:94-110); a path ending in `.zst` is ZSTD-compressed
+    (geoip.rs:49-55; libzstd is loaded at run time)."""
     for p in paths:
         if os.path.exists(p):
-            if p.endswith(".zst"):
-                raise ConfigError(f"error decompressing geoip database ({p}): zstd is not available in this build")
             with open(p, "rb") as f:
-                return geoip_from_mmdb(f.read())
+                content = f.read()
+            try:
+                return geoip_from_mmdb(content, p)
+            except Exception as err:  # noqa: BLE001
+                raise ConfigError(f"error loading geoip database ({p}): {err}") from err
     return None

@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -280,7 +282,9 @@ struct Walker {
                 walk(rec, depth + 1);
             }
             if (side) bits[depth >> 3] &= (uint8_t)~(0x80u >> (depth & 7));
-            if (out.size() > (size_t)64 << 20) overflow = true;
+            // a tree with node_count inner nodes has at most node_count + 1 leaves (each may add one IPv4 alias): more means shared
+            // children, i.e. a crafted DAG that would expand exponentially
+            if (out.size() > 2 * ((size_t)db.node_count + 1)) overflow = true;
         }
     }
 };
@@ -310,6 +314,89 @@ int pwaf_geoip_from_mmdb(const uint8_t *mmdb, size_t len, pwaf_geoip_entry **ent
 }
 
 void pwaf_geoip_free(pwaf_geoip_entry *entries) { free(entries); }
+
+// zstd::decode_all (pingoo/geoip.rs:49-55: a database whose path ends in .zst is ZSTD-compressed; the reference's Docker image ships
+// geoip.mmdb.zst, config.rs:31-36). libzstd is loaded at run time (this image has libzstd.so.1 but no headers): the stable
+// streaming API, one frame after another until the input is consumed.
+int pwaf_zstd_decompress(const uint8_t *src, size_t len, uint8_t **out, size_t *out_len) {
+    if (!out || !out_len || (!src && len)) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    *out_len = 0;
+    struct InBuf { const void *src; size_t size, pos; };
+    struct OutBuf { void *dst; size_t size, pos; };
+    static void *lib = nullptr;
+    static void *(*create)() = nullptr;
+    static size_t (*destroy)(void *) = nullptr;
+    static size_t (*run)(void *, OutBuf *, InBuf *) = nullptr;
+    static unsigned (*is_error)(size_t) = nullptr;
+    static const char *(*error_name)(size_t) = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"libzstd.so.1", "libzstd.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        create = (void *(*)())dlsym(lib, "ZSTD_createDStream");
+        destroy = (size_t (*)(void *))dlsym(lib, "ZSTD_freeDStream");
+        run = (size_t (*)(void *, OutBuf *, InBuf *))dlsym(lib, "ZSTD_decompressStream");
+        is_error = (unsigned (*)(size_t))dlsym(lib, "ZSTD_isError");
+        error_name = (const char *(*)(size_t))dlsym(lib, "ZSTD_getErrorName");
+    });
+    if (!lib || !create || !destroy || !run || !is_error) return fail(PWAF_E_UNSUPPORTED, "zstd is not available: libzstd.so.1 could not be loaded");
+    void *ds = create();
+    if (!ds) return fail(PWAF_E_NOMEM, "ZSTD_createDStream failed");
+    std::vector<uint8_t> buf;
+    try {
+        buf.resize(std::max<size_t>(1 << 20, len * 4));
+    } catch (const std::bad_alloc &) {
+        destroy(ds);
+        return fail(PWAF_E_NOMEM, "out of memory");
+    }
+    InBuf in{src, len, 0};
+    size_t produced = 0, last = 1;
+    while (in.pos < in.size || last != 0) {
+        if (produced == buf.size()) {
+            if (buf.size() > ((size_t)4 << 30)) { destroy(ds); return fail(PWAF_E_INVALID_ARG, "error decompressing geoip database: output larger than 4 GiB"); }
+            try { buf.resize(buf.size() * 2); } catch (const std::bad_alloc &) { destroy(ds); return fail(PWAF_E_NOMEM, "out of memory"); }
+        }
+        OutBuf ob{buf.data(), buf.size(), produced};
+        const size_t before_in = in.pos;
+        last = run(ds, &ob, &in);
+        if (is_error(last)) {
+            const std::string why = error_name ? error_name(last) : "corrupt frame";
+            destroy(ds);
+            return fail(PWAF_E_INVALID_ARG, "error decompressing geoip database: " + why);
+        }
+        const bool progressed = ob.pos != produced || in.pos != before_in;
+        produced = ob.pos;
+        if (in.pos == in.size && last == 0) break;  // every frame complete
+        if (!progressed && in.pos == in.size) { destroy(ds); return fail(PWAF_E_INVALID_ARG, "error decompressing geoip database: truncated frame"); }
+    }
+    destroy(ds);
+    uint8_t *mem = (uint8_t *)malloc(std::max<size_t>(1, produced));
+    if (!mem) return fail(PWAF_E_NOMEM, "out of memory");
+    memcpy(mem, buf.data(), produced);
+    *out = mem;
+    *out_len = produced;
+    return PWAF_OK;
+}
+void pwaf_buffer_free(uint8_t *p) { free(p); }
+
+// GeoipDB::load on a file image: `.zst` names are decompressed first (geoip.rs:49-55), then the MMDB is flattened.
+int pwaf_geoip_from_file_image(const char *path_for_suffix, const uint8_t *content, size_t len, pwaf_geoip_entry **entries_out, size_t *n_out) {
+    const std::string p = path_for_suffix ? path_for_suffix : "";
+    if (p.size() >= 4 && p.compare(p.size() - 4, 4, ".zst") == 0) {
+        uint8_t *raw = nullptr;
+        size_t raw_len = 0;
+        int rc = pwaf_zstd_decompress(content, len, &raw, &raw_len);
+        if (rc) return rc;
+        rc = pwaf_geoip_from_mmdb(raw, raw_len, entries_out, n_out);
+        free(raw);
+        return rc;
+    }
+    return pwaf_geoip_from_mmdb(content, len, entries_out, n_out);
+}
 
 // lists.rs:62-117: CSV without headers, 1 or 2 columns per record ("flexible"), the FIRST column trimmed is the item. Quoted
 // fields follow RFC 4180 ("" is an escaped quote). Empty lines are skipped (the csv crate does not yield them).

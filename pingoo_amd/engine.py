@@ -120,6 +120,10 @@ def lib():
     L.pwaf_batcher_destroy.argtypes = [vp]
     L.pwaf_batcher_destroy.restype = None
     L.pwaf_geoip_from_mmdb.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(_abi.GeoipEntry)), C.POINTER(C.c_size_t)]
+    L.pwaf_geoip_from_file_image.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(_abi.GeoipEntry)), C.POINTER(C.c_size_t)]
+    L.pwaf_zstd_decompress.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.pwaf_buffer_free.argtypes = [C.c_void_p]
+    L.pwaf_buffer_free.restype = None
     L.pwaf_geoip_free.argtypes = [C.POINTER(_abi.GeoipEntry)]
     L.pwaf_geoip_free.restype = None
     L.pwaf_list_parse_csv.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_size_t)]
@@ -519,12 +523,13 @@ class MicroBatcher:
             pass
 
 
-def geoip_from_mmdb(content: bytes) -> np.ndarray:
-    """MaxMind DB file content -> GEOIP_DTYPE prefix table for RuleEngine(..., geoip=...) (pingoo/geoip.rs:43-91)."""
+def geoip_from_mmdb(content: bytes, path: str = "geoip.mmdb") -> np.ndarray:
+    """MaxMind DB file content -> GEOIP_DTYPE prefix table for RuleEngine(..., geoip=...) (pingoo/geoip.rs:43-91). A `path` ending in
+    ".zst" means the content is ZSTD-compressed (geoip.rs:49-55)."""
     from .batch import GEOIP_DTYPE
 
     ptr, n = C.POINTER(_abi.GeoipEntry)(), C.c_size_t(0)
-    rc = lib().pwaf_geoip_from_mmdb(content, len(content), C.byref(ptr), C.byref(n))
+    rc = lib().pwaf_geoip_from_file_image(path.encode(), content, len(content), C.byref(ptr), C.byref(n))
     if rc != 0:
         _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
     try:
@@ -534,6 +539,17 @@ def geoip_from_mmdb(content: bytes) -> np.ndarray:
     finally:
         lib().pwaf_geoip_free(ptr)
     return out
+
+
+def zstd_decompress(data: bytes) -> bytes:
+    out, n = C.c_void_p(), C.c_size_t(0)
+    rc = lib().pwaf_zstd_decompress(data, len(data), C.byref(out), C.byref(n))
+    if rc != 0:
+        _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().pwaf_buffer_free(out)
 
 
 def parse_list_csv(text) -> List[str]:

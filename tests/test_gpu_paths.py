@@ -224,3 +224,46 @@ def test_field_against_field_predicates_and_per_rule_unsupported():
         RuleEngine(rules, flags=_abi.OPT_STRICT)
     assert ei.value.rule_index == 4
     eng.close()
+
+
+def test_mmdb_database_and_config_files_drive_the_device_engine(tmp_path):
+    """SURVEY §8f on the GPU: a (zstd-compressed) MaxMind DB image -> pwaf_geoip_from_file_image -> HIP engine, and a pingoo.yml + rules
+    folder + CSV lists loaded by pingoo_amd.config -> HIP engine; verdicts against the oracle fed with the same decoded inputs."""
+    import ipaddress
+
+    from mmdb_writer import write_mmdb
+    from pingoo_amd import config
+    from test_loaders import zstd_compress
+
+    rng = random.Random(77)
+    nets = [("203.0.113.0/24", {"asn": "AS64500", "country": "NL"}), ("198.51.100.128/25", {"asn": "AS7", "country": "KP"}), ("10.0.0.0/8", {"asn": "AS1", "country": "US"}),
+            ("2001:db8::/32", {"asn": "AS64501", "country": "FR"}), ("2001:db8:ff00::/40", {"asn": "AS9", "country": "KP"}), ("192.0.2.0/28", {"asn": "bogus", "country": "DE"}),
+            ("100.64.0.0/10", {"asn": "AS5", "country": "zz"})]  # (a record whose country is not A-Z makes the lookup fall back to the default)
+    (tmp_path / "geoip.mmdb.zst").write_bytes(zstd_compress(write_mmdb(nets, ip_version=6)))
+    geo = config.load_geoip([str(tmp_path / "geoip.mmdb.zst")])
+    (tmp_path / "rules").mkdir()
+    (tmp_path / "ips.csv").write_text("203.0.113.7\n10.9.0.0/16, lab\n2001:db8:1::/48\n")
+    (tmp_path / "pingoo.yml").write_text(f"""
+lists:
+  blocked: {{file: "{tmp_path}/ips.csv", type: Ip}}
+rules:
+  kp:
+    expression: client.country == "KP"
+    actions: [{{action: block}}]
+  asn:
+    expression: client.asn == 64500 || client.asn == 64501
+    actions: [{{action: captcha}}]
+""")
+    (tmp_path / "rules" / "10-lists.yml").write_text('listed:\n  expression: lists["blocked"].contains(client.ip)\n  actions:\n    - action: block\n')
+    (tmp_path / "rules" / "20-default.yml").write_text('unknown_country:\n  expression: client.country == "XX" && http_request.path.starts_with("/admin")\n  actions:\n    - action: block\n')
+    rules, lists = config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
+    assert [r[0] for r in rules] == ["kp", "asn", "listed", "unknown_country"]
+    ips = ["203.0.113.7", "203.0.113.9", "198.51.100.129", "198.51.100.1", "10.9.1.1", "10.1.1.1", "2001:db8::1", "2001:db8:ff00::1", "2001:db8:1::5", "192.0.2.3", "100.64.1.1",
+           "8.8.8.8", "::ffff:203.0.113.7", "127.0.0.1", "2001:db9::1"]
+    reqs = [Request(ip=rng.choice(ips), path=rng.choice(["/admin", "/x"]), host="h", captcha_verified=rng.random() < 0.3) for _ in range(3000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, lists, geo).evaluate(batch)
+    eng = RuleEngine(rules, lists, geo)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "mmdb + config files")
+    assert len(set(want["rule_idx"].tolist())) == 5  # every rule decides something, and some requests pass
+    eng.close()

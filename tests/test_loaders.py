@@ -11,7 +11,7 @@ import helpers as H
 from mmdb_writer import write_mmdb
 from oracle import pyoracle
 from pingoo_amd import Request, RequestBatch, _abi, config
-from pingoo_amd.engine import CompiledProgram, PwafError, geoip_from_mmdb, parse_list_csv
+from pingoo_amd.engine import zstd_decompress, CompiledProgram, PwafError, geoip_from_mmdb, parse_list_csv
 from table_walker import Tables
 
 B = _abi.RULE_ACTION_BLOCK
@@ -149,8 +149,10 @@ rules:
     (tmp_path / "rules" / "10-admin.yml").write_text('admin:\n  expression: http_request.path.starts_with("/admin")\n  actions:\n    - action: block\n')
     (tmp_path / "rules" / "20-all.yml").write_text("everything:\n  actions:\n    - action: captcha\n")
     (tmp_path / "rules" / "notes.txt").write_text("ignored: not a .yml file")
-    rules, lists = config.load_rule_config(str(tmp_path / "pingoo.yml"))
+    # (the reference always reads /etc/pingoo/rules, config.rs:381: the folder next to a relocated config file is passed explicitly)
+    rules, lists = config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
     assert [r[0] for r in rules] == ["block_listed", "telnet", "admin", "everything"]
+    assert [r[0] for r in config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "nowhere"))[0]] == ["block_listed", "telnet"]
     assert rules[1][2] == [_abi.RULE_ACTION_CAPTCHA, B] and rules[3][1] is None
     assert lists == {"blocked_ips": (_abi.LIST_IP, ["10.0.0.0/8", "192.168.1.7", "2001:db8::/32"]), "bad_ports": (_abi.LIST_INT, ["23", "2323"])}
     # the loaded configuration compiles and behaves
@@ -165,11 +167,11 @@ rules:
     # duplicate names across the file and the folder, unknown actions, missing files
     (tmp_path / "rules" / "30-dup.yml").write_text("telnet:\n  actions: []\n")
     with pytest.raises(config.ConfigError, match="duplicate rule name: telnet"):
-        config.load_rule_config(str(tmp_path / "pingoo.yml"))
+        config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
     os.remove(tmp_path / "rules" / "30-dup.yml")
     (tmp_path / "rules" / "30-bad.yml").write_text("x:\n  actions:\n    - action: allow\n")
     with pytest.raises(config.ConfigError, match="unknown action"):
-        config.load_rule_config(str(tmp_path / "pingoo.yml"))
+        config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
     with pytest.raises(config.ConfigError, match="error reading config file"):
         config.load_rule_config(str(tmp_path / "missing.yml"))
     with pytest.raises(config.ConfigError, match="not a valid ListType"):
@@ -181,6 +183,30 @@ def test_geoip_path_search(tmp_path):
     (tmp_path / "b.mmdb").write_bytes(write_mmdb([("203.0.113.0/24", {"asn": "AS7", "country": "NL"})]))
     t = config.load_geoip([str(tmp_path / "a.mmdb"), str(tmp_path / "b.mmdb")])
     assert len(t) == 1 and int(t[0]["asn"]) == 7 and bytes(t[0]["country"]) == b"NL"
-    (tmp_path / "a.mmdb.zst").write_bytes(b"\x28\xb5\x2f\xfd")
-    with pytest.raises(config.ConfigError, match="zstd"):
-        config.load_geoip([str(tmp_path / "a.mmdb.zst")])
+    # .zst databases (geoip.rs:49-55; the reference's Docker image ships geoip.mmdb.zst): decompressed through libzstd at run time
+    raw = write_mmdb([("198.51.100.0/24", {"asn": "AS64500", "country": "SE"}), ("2001:db8::/32", {"asn": "AS9", "country": "FI"})], ip_version=6)
+    (tmp_path / "a.mmdb.zst").write_bytes(zstd_compress(raw))
+    t = config.load_geoip([str(tmp_path / "a.mmdb.zst"), str(tmp_path / "b.mmdb")])
+    assert sorted((int(e["asn"]), bytes(e["country"])) for e in t) == sorted([(64500, b"SE"), (64500, b"SE"), (9, b"FI")])
+    assert zstd_decompress(zstd_compress(raw) + zstd_compress(b"tail")) == raw + b"tail"  # frame after frame, like zstd::decode_all
+    (tmp_path / "c.mmdb.zst").write_bytes(b"\x28\xb5\x2f\xfd")
+    with pytest.raises(config.ConfigError, match="decompressing"):
+        config.load_geoip([str(tmp_path / "c.mmdb.zst")])
+    with pytest.raises(config.ConfigError, match="decompressing"):
+        config.load_geoip([str(tmp_path / "b.mmdb").replace("b.mmdb", "d.mmdb.zst")] if (tmp_path / "d.mmdb.zst").write_bytes(raw) else [])
+
+
+def zstd_compress(data: bytes) -> bytes:
+    """TEST-ONLY: ZSTD_compress of the system libzstd (the product only ever decompresses)."""
+    import ctypes
+
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(data))
+    buf = ctypes.create_string_buffer(cap)
+    n = z.ZSTD_compress(buf, cap, data, len(data), 3)
+    assert not z.ZSTD_isError(n)
+    return buf.raw[:n]
