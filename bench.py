@@ -313,6 +313,50 @@ def main():
                                         "verdicts_match_device_resident_run": bool((hv["action"] == gv[:, 0]).all() and (hv["rule_idx"] == gv[:, 1]).all())}
             if "latency_ms" in result:
                 result["latency_ms"]["host_batch_pcie_inclusive"] = result["pcie_inclusive"]["latency_ms"]
+            # the same host batches from several caller threads at once: the engine's per-call contexts (scratch, staging buffers,
+            # stream each) let one batch's copies run under another's kernels
+            import threading
+
+            n_thr, per_thr = 3, 4
+            def host_caller():
+                for _ in range(per_thr):
+                    eng.evaluate_batch(hb)
+            th = [threading.Thread(target=host_caller) for _ in range(n_thr)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            result["pcie_inclusive"]["pipelined"] = {"value": n_thr * per_thr * m / dt, "unit": "requests/s", "sample": f"{n_thr} caller threads x {per_thr} synchronous calls of {m} requests each"}
+            # deadline micro-batcher (the evaluate(Request) -> Action façade): 64 caller threads, 200 us deadline, per-request latency
+            from pingoo_amd import Request
+            from pingoo_amd.engine import MicroBatcher
+
+            mb = MicroBatcher(eng, max_batch=4096, max_delay_us=200)
+            sample_reqs = [Request(host=hb.field_bytes(0, i), url=hb.field_bytes(1, i), path=hb.field_bytes(2, i), method=hb.field_bytes(3, i), user_agent=hb.field_bytes(4, i),
+                                   ip="203.0.113.%d" % (i % 250 + 1), remote_port=int(hb.port[i])) for i in range(256)]
+            lats, lock = [], threading.Lock()
+            def req_caller(k):
+                mine = []
+                for j in range(150):
+                    t1 = time.perf_counter()
+                    mb.evaluate(sample_reqs[(k * 7 + j) % 256])
+                    mine.append(1e3 * (time.perf_counter() - t1))
+                with lock:
+                    lats.extend(mine)
+            th = [threading.Thread(target=req_caller, args=(k,)) for k in range(64)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            nb, nr = mb.stats()
+            mb.close()
+            result["batcher"] = {"caller_threads": 64, "requests": len(lats), "max_batch": 4096, "deadline_us": 200, "batches": nb, "requests_per_s": len(lats) / dt,
+                                 "latency_ms": {"p50": pct(lats, 50), "p99": pct(lats, 99), "max": max(lats)},
+                                 "note": "Python caller threads (GIL-bound between calls): an upper bound on what a native host would see"}
         # ---- CPU baseline: the oracle (port of the reference's per-request interpreter loop) on host cores ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle

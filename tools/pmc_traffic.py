@@ -7,6 +7,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 root = sys.argv[1]
@@ -16,7 +17,7 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(path)):
             if "pwaf::" in r["Kernel_Name"] and r["Counter_Name"] == cname:
                 per[r["Kernel_Name"].split("(")[0].replace("void ", "")][cname].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-out = {"unit": "bytes per launch, last pipeline pass of the trace", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)", "kernels": {}}
+out = {"commit": os.environ.get("PWAF_COMMIT", "?"), "unit": "bytes per launch, last pipeline pass of the trace", "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B)", "kernels": {}}
 passes = max(1, max((len(d["FETCH_SIZE"]) for k, d in per.items() if "verdict" in k), default=1))  # pipeline passes in the trace
 for k, d in per.items():
     f = [v for _, v in sorted(d["FETCH_SIZE"])]

@@ -16,5 +16,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-modes --no-pcie > $OUT/pmc_$c.log 2>&1
 done
 python $R/tools/pmc_traffic.py $OUT > $OUT/traffic.json 2>> $OUT/trace.log
+# issue / LDS counters of the same command (separate passes; SQ_* count quad-cycles, see MI355X_MICROARCH.md)
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  name=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-modes --no-pcie > $OUT/pmc_$name.log 2>&1
+done
+python $R/tools/pmc_report.py $OUT > $OUT/counters.txt 2>> $OUT/trace.log
 cat $OUT/kernel_stats.txt | head -30; cat $OUT/traffic.json
 rm -rf $OUT/trace  # the database is large; the summary is what gets committed
