@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) measurements")
     ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: step i is issued on stream i mod INFLIGHT (pwaf_evaluate_device is re-entrant: every call takes "
+                                                            "its own scratch context), so one batch's small latency-bound kernels run under the next batch's streaming kernels")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,30 +84,35 @@ def main():
     t_compile = time.time() - t0
     stats = eng.stats()
     dbatch = DeviceBatch(batch, dev)
-    out = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    counts = torch.zeros(4, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    inflight = max(1, min(args.inflight, 3))
+    n_streams = max(inflight, 2)
+    outs = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(n_streams)]
+    cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_streams)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    out, counts, stream = outs[0], cnts[0], streams[0]
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_run(db, steps, warmup):
+    def timed_run(db, steps, warmup, inflight=inflight):
         """W untimed + K timed steps over the resident batch `db`; returns (seconds, kernel times, action counters)."""
-        def step():
-            counts.zero_()
-            eng.evaluate_device(db, out=out, counts=counts, stream=stream.cuda_stream)
-            shard.allreduce_counts(counts)  # the path's only exchange: 4 counters over RCCL/xGMI
+        def step(i):
+            k = i % inflight
+            with torch.cuda.stream(streams[k]):
+                cnts[k].zero_()
+                eng.evaluate_device(db, out=outs[k], counts=cnts[k], stream=streams[k].cuda_stream)
+                shard.allreduce_counts(cnts[k])  # the path's only exchange: 4 counters over RCCL/xGMI
 
-        for _ in range(warmup):
-            step()
+        for i in range(warmup):
+            step(i)
         barrier()
         eng.set_profiling(not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for i in range(steps):
+            step(i)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -165,6 +172,13 @@ def main():
     head = mode_summary(elapsed, ktimes, args.steps)
     headline_out = out[: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite `out`)
 
+    if extras and inflight == 1:
+        # the same batch with TWO batches in flight (step i on stream i mod 2; pwaf_evaluate_device is re-entrant: every call takes its
+        # own scratch context): one batch's small latency-bound kernels run under the next batch's streaming kernels. Throughput only —
+        # per-kernel durations (and anything derived from them, like the roofline object) are quoted for one batch at a time.
+        phase("two batches in flight")
+        el, kt, _ = timed_run(dbatch, max(4, args.steps), 2, inflight=2)
+        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * max(4, args.steps) / el, "ms_per_step": 1e3 * el / max(4, args.steps)}
     if extras and not args.adversarial:
         phase("adversarial run")
         adv = DeviceBatch(wl.batch(rank * n, n, threads=threads, adversarial=True), dev)
@@ -196,6 +210,7 @@ def main():
             "rules": len(wl.rules),
             "tuning": f"tuned on {tune_n} benign sample requests disjoint from the timed batch" if tune_n else "none (untuned)",
             "parallelism": f"requests sharded over {world} GPU(s), tables replicated, RCCL all-reduce of 4 counters",
+            "batches_in_flight": inflight,
             "action_counts_allow_block_captcha_bypass": final_counts,
         },
     }

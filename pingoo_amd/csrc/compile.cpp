@@ -1457,9 +1457,9 @@ std::vector<uint8_t> dump_program(const Program &p) {
         w.section("GENL", (uint32_t)gi, g.end_list.data(), g.end_list.size() * 2);
         w.section("GFLT", (uint32_t)gi, g.filter_cols.data(), g.filter_cols.size() * 4);
         if (g.filter.enabled) {
-            // bigram prefilter: [init, n_heads] + heads (20 bytes each), then the 4096-entry table
+            // bigram prefilter: [init, n_heads | hash multiplier << 16] + heads (20 bytes each), then the 4096-entry table
             std::vector<uint8_t> fh(8 + g.filter.heads.size() * sizeof(FilterHead));
-            const uint32_t hdr[2] = {g.filter.init, (uint32_t)g.filter.heads.size()};
+            const uint32_t hdr[2] = {g.filter.init, (uint32_t)g.filter.heads.size() | (g.filter.mul << 16)};
             memcpy(fh.data(), hdr, 8);
             if (!g.filter.heads.empty()) memcpy(fh.data() + 8, g.filter.heads.data(), g.filter.heads.size() * sizeof(FilterHead));
             w.section("GFHD", (uint32_t)gi, fh.data(), fh.size());

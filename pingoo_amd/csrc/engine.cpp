@@ -766,6 +766,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.n = n;
             f.total = totals[d.field];
             f.init = d.filter.init;
+            f.mul = d.filter.mul;
             f.table = (const uint32_t *)d.ftable.p;
             f.n_heads = (uint32_t)std::min<size_t>(2, d.filter.heads.size());
             for (uint32_t h = 0; h < f.n_heads; h++) {
@@ -1447,27 +1448,27 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     // anchored literals the sample actually satisfies; a filter that would flag more than 40 % of the sample is dropped (the pass
     // then walks every request, as without a filter)
     if (!(P.flags & PWAF_OPT_NO_PREFILTER)) {
-        std::vector<std::vector<double>> bin_prob(e->n_fields);
+        std::vector<std::vector<double>> pair_prob(e->n_fields);
         std::vector<double> mean_len(e->n_fields, 0.0);
         for (uint32_t f = 0; f < e->n_fields; f++) {
             const pwaf_strcol *c = sample_col(f);
-            bin_prob[f].assign(kFilterEntries, 0.0);
+            pair_prob[f].assign(65536, 0.0);
             if (!c) continue;
-            std::vector<uint64_t> cnt(kFilterEntries, 0);
+            std::vector<uint64_t> cnt(65536, 0);
             uint64_t tot = 0;
             const uint8_t *data = c->data;
             const uint32_t *off = c->offsets;
             for (uint32_t i = 0; i < n; i++)
-                for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[filter_bin(data[p], data[p + 1])]++; tot++; }
+                for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[(data[p] & 0xDFu) | ((uint32_t)(data[p + 1] & 0xDFu) << 8)]++; tot++; }
             if (tot)
-                for (uint32_t b = 0; b < kFilterEntries; b++) bin_prob[f][b] = (double)cnt[b] / (double)tot;
+                for (uint32_t b = 0; b < 65536; b++) pair_prob[f][b] = (double)cnt[b] / (double)tot;
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;
             e->mean_len[f] = mean_len[f];
         }
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];
             FilterHints h;
-            h.bin_prob = bin_prob[g.field].data();
+            h.pair_prob = pair_prob[g.field].data();
             h.atom_hits = &atom_hits[k];
             h.n_requests = n;
             h.mean_len = mean_len[g.field];

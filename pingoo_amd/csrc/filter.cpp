@@ -48,21 +48,26 @@ Cover trivial() {
     return c;
 }
 
+static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return (uint32_t)(a & 0xDFu) | ((uint32_t)(b & 0xDFu) << 8); }
+
 struct Model {
-    const double *binw;  // kFilterEntries probabilities
+    const double *pairw;  // 65536 probabilities of the case-folded bigrams
+    // the distinct folded pairs of two byte sets
+    static void pairs_of(const ByteSet &a, const ByteSet &b, std::vector<uint16_t> &out) {
+        std::set<uint32_t> ps;
+        for (int x = 0; x < 256; x++)
+            if (a[(size_t)x])
+                for (int y = 0; y < 256; y++)
+                    if (b[(size_t)y]) ps.insert(fold_pair((uint8_t)x, (uint8_t)y));
+        out.assign(ps.begin(), ps.end());
+    }
     double pair_weight(const ByteSet &a, const ByteSet &b) {
-        // probability that a text bigram falls into one of the bins the pair of sets maps to
-        uint8_t va[256], vb[256];
-        int na = 0, nb = 0;
-        for (int x = 0; x < 256; x++) {
-            if (a[(size_t)x]) va[na++] = (uint8_t)x;
-            if (b[(size_t)x]) vb[nb++] = (uint8_t)x;
-        }
-        std::set<uint32_t> bins;
-        for (int i = 0; i < na; i++)
-            for (int j = 0; j < nb; j++) bins.insert(filter_bin(va[i], vb[j]));
+        // probability that a text bigram is one of the (folded) pairs of the two sets: independent of the hash, which only adds
+        // the pairs that happen to share a bin
+        std::vector<uint16_t> ps;
+        pairs_of(a, b, ps);
         double w = 0;
-        for (uint32_t x : bins) w += binw[x];
+        for (uint16_t x : ps) w += pairw[x];
         return std::min(1.0, w);
     }
     // Cheapest window of <= 4 sampled bigrams for a factor whose first byte sits `o` bytes past a sampling point (o < stride):
@@ -244,7 +249,7 @@ bool anchored_literal(const RNode &n, std::string &lit, bool &at_start, bool &at
 
 // Prior over the bytes of URL / header text, used when no traffic sample is available. Only relative magnitudes matter:
 // it decides which window of a factor is taken and how factors are bucketed, never a result.
-void default_bin_prob(double *binw) {
+void default_pair_prob(double *pairw) {
     double p[256];
     for (int b = 0; b < 256; b++) p[b] = 0.0002;
     for (int b = 'a'; b <= 'z'; b++) p[b] = 0.024;
@@ -257,14 +262,14 @@ void default_bin_prob(double *binw) {
     for (const char *c = some; *c; c++) p[(unsigned char)*c] = 0.004;
     double tot = 0;
     for (int b = 0; b < 256; b++) tot += p[b];
-    for (uint32_t x = 0; x < kFilterEntries; x++) binw[x] = 0;
+    for (uint32_t x = 0; x < 65536; x++) pairw[x] = 0;
     for (int a = 0; a < 256; a++)
-        for (int b = 0; b < 256; b++) binw[filter_bin((uint8_t)a, (uint8_t)b)] += p[a] / tot * p[b] / tot;
+        for (int b = 0; b < 256; b++) pairw[fold_pair((uint8_t)a, (uint8_t)b)] += p[a] / tot * p[b] / tot;
 }
 
 struct Window {
     size_t k = 0;
-    std::vector<uint16_t> bins[4];
+    std::vector<uint16_t> pairs[4];  // folded byte pairs per window position
     double cost = 0;
 };
 
@@ -273,16 +278,16 @@ struct Window {
 void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out) {
     out = GroupFilter();
     std::vector<double> prior;
-    const double *binw = hints ? hints->bin_prob : nullptr;
-    if (!binw) {
-        prior.resize(kFilterEntries);
-        default_bin_prob(prior.data());
-        binw = prior.data();
+    const double *pairw0 = hints ? hints->pair_prob : nullptr;
+    if (!pairw0) {
+        prior.resize(65536);
+        default_pair_prob(prior.data());
+        pairw0 = prior.data();
     }
-    // smoothed: a bin the sample never showed is still possible
-    std::vector<double> w(kFilterEntries);
-    for (uint32_t x = 0; x < kFilterEntries; x++) w[x] = binw[x] * 0.98 + 0.02 / kFilterEntries;
-    Model m{w.data()};
+    // smoothed: a bigram the sample never showed is still possible
+    std::vector<double> pw(65536);
+    for (uint32_t x = 0; x < 65536; x++) pw[x] = pairw0[x] * 0.98 + 0.02 / 65536;
+    Model m{pw.data()};
 
     if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
     if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
@@ -352,15 +357,8 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
                 std::string key = std::to_string(k) + ":";
                 for (size_t j = 0; j < k; j++) {
                     const size_t at = st + j * kFilterStride;
-                    std::set<uint32_t> bins;
-                    for (int a = 0; a < 256; a++)
-                        if (s[at][(size_t)a])
-                            for (int b = 0; b < 256; b++)
-                                if (s[at + 1][(size_t)b]) bins.insert(filter_bin((uint8_t)a, (uint8_t)b));
-                    for (uint32_t bn : bins) {
-                        wd.bins[j].push_back((uint16_t)bn);
-                        key += std::to_string(bn) + ",";
-                    }
+                    Model::pairs_of(s[at], s[at + 1], wd.pairs[j]);
+                    for (uint16_t pr : wd.pairs[j]) key += std::to_string(pr) + ",";
                     key += ";";
                 }
                 if (getenv("PWAF_FILTER_DEBUG") && wd.cost > 1e-5) {
@@ -373,7 +371,9 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     }
     if (wins.empty() && out.heads.empty()) { out.note = "no patterns"; return; }
 
-    // ---- buckets ----
+    // ---- buckets, once per candidate multiplier of the bigram hash: the one whose bins keep the factor windows away from the
+    //      traffic's frequent bigrams wins (a three-byte factor such as "../" owns only two positions: one unlucky collision with a
+    //      common bigram and every other request is a candidate) ----
     struct Bucket {
         size_t kmin = 5;  // 5 = empty
         std::bitset<kFilterEntries> set[4];
@@ -385,59 +385,70 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             return f;
         }
     };
-    Bucket bk[8];
     std::vector<size_t> order(wins.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].k != wins[b].k ? wins[a].k > wins[b].k : wins[a].cost > wins[b].cost; });
-    for (size_t wi : order) {
-        const Window &wd = wins[wi];
-        int best_b = 0;
-        double best_d = INFINITY;
-        for (int b = 0; b < 8; b++) {
-            Bucket t = bk[b];
+    static const uint32_t kMuls[] = {kFilterMul, 0x85EBu, 0xC2B3u, 0x27D5u, 0x165Bu, 0xB5A7u, 0x6F4Fu, 0x93D7u, 0xE995u, 0x4F1Du, 0xA3C1u, 0x7A6Bu};
+    double best_fp = INFINITY;
+    std::vector<double> w(kFilterEntries);
+    const bool have_sample = hints && hints->pair_prob;
+    for (uint32_t mul : kMuls) {
+        // (without a traffic sample the estimate rests on a generic prior, which cannot tell the multipliers apart: keep the default)
+        if (!have_sample && mul != kFilterMul) continue;
+        std::fill(w.begin(), w.end(), 0.0);
+        for (uint32_t pr = 0; pr < 65536; pr++) w[filter_bin((uint8_t)pr, (uint8_t)(pr >> 8), mul)] += pw[pr];
+        Bucket bk[8];
+        auto add = [&](Bucket &t, const Window &wd) {
             t.kmin = std::min(t.kmin, wd.k);
             for (size_t j = 0; j < wd.k; j++) {
                 const size_t pos = 4 - wd.k + j;
-                for (uint16_t bn : wd.bins[j])
+                for (uint16_t pr : wd.pairs[j]) {
+                    const uint32_t bn = filter_bin((uint8_t)pr, (uint8_t)(pr >> 8), mul);
                     if (!t.set[pos][bn]) { t.set[pos].set(bn); t.wsum[pos] += w[bn]; }
+                }
             }
-            const double d = t.fp() - bk[b].fp();
-            if (d < best_d) { best_d = d; best_b = b; }
+        };
+        for (size_t wi : order) {
+            int best_b = 0;
+            double best_d = INFINITY;
+            for (int b = 0; b < 8; b++) {
+                Bucket t = bk[b];
+                add(t, wins[wi]);
+                const double d = t.fp() - bk[b].fp();
+                if (d < best_d) { best_d = d; best_b = b; }
+            }
+            add(bk[best_b], wins[wi]);
         }
-        Bucket &t = bk[best_b];
-        t.kmin = std::min(t.kmin, wd.k);
-        for (size_t j = 0; j < wd.k; j++) {
-            const size_t pos = 4 - wd.k + j;
-            for (uint16_t bn : wd.bins[j])
-                if (!t.set[pos][bn]) { t.set[pos].set(bn); t.wsum[pos] += w[bn]; }
-        }
-    }
-    out.table.assign(kFilterEntries, 0xFFFFFFFFu);
-    out.init = 0xFFFFFFFFu;
-    double fp_pos = 0;
-    for (int b = 0; b < 8; b++) {
-        if (bk[b].kmin > 4) continue;
-        fp_pos += bk[b].fp();
-        for (size_t j = 0; j < 4; j++) {
-            const uint32_t bit = 1u << (8 * j + (size_t)b);
-            if (j < 4 - bk[b].kmin) {  // wildcard position of this bucket
-                for (auto &e : out.table) e &= ~bit;
-                out.init &= ~bit;
-            } else {
-                for (uint32_t bn = 0; bn < kFilterEntries; bn++)
-                    if (bk[b].set[j][bn]) out.table[bn] &= ~bit;
+        double fp_pos = 0;
+        for (int b = 0; b < 8; b++) fp_pos += bk[b].fp();
+        if (!(fp_pos < best_fp)) continue;
+        best_fp = fp_pos;
+        out.mul = mul;
+        out.table.assign(kFilterEntries, 0xFFFFFFFFu);
+        out.init = 0xFFFFFFFFu;
+        for (int b = 0; b < 8; b++) {
+            if (bk[b].kmin > 4) continue;
+            for (size_t j = 0; j < 4; j++) {
+                const uint32_t bit = 1u << (8 * j + (size_t)b);
+                if (j < 4 - bk[b].kmin) {  // wildcard position of this bucket
+                    for (auto &e : out.table) e &= ~bit;
+                    out.init &= ~bit;
+                } else {
+                    for (uint32_t bn = 0; bn < kFilterEntries; bn++)
+                        if (bk[b].set[j][bn]) out.table[bn] &= ~bit;
+                }
             }
         }
     }
     const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / kFilterStride;
-    out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, fp_pos)), len);
+    out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, best_fp)), len);
     out.enabled = true;
 }
 
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
     uint32_t st = f.init;
     for (size_t i = 0; i + 1 < n; i += kFilterStride) {
-        st = (st << 8) | f.table[filter_bin(bytes[i], bytes[i + 1])];
+        st = (st << 8) | f.table[filter_bin(bytes[i], bytes[i + 1], f.mul)];
         if ((~st) & 0xFF000000u) return true;
     }
     return false;

@@ -123,6 +123,7 @@ struct FilterArgs {
     uint32_t total;           // bytes in the arena (= off[n])
     uint32_t slab0;           // first slab to stream (a slab view of a larger arena starts at off[0]: the bytes before it are not the batch's)
     uint32_t init;            // state of a stream with no history
+    uint32_t mul;             // multiplier of the bigram hash (GroupFilter::mul)
     const uint32_t *table;    // kFilterEntries masks
     uint32_t n_heads;
     uint32_t head_w[2][4];    // head literal, little-endian dwords

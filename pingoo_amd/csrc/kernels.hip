@@ -534,8 +534,7 @@ int launch_scan_gated(const GatedArgs &b, void *stream) {
 // "some position of the chunk completed a window of some bucket"; the requests overlapping such chunks become CANDIDATES and are
 // walked by the pass's DFA afterwards (lscan_kernel); every other request provably matches no pattern of the pass.
 //
-// Hash of a position = top 12 bits of the 16-bit product fold(pair) * kFilterMul: two positions per v_pk_mul_lo_u16; the table's
-// byte offset is (product >> 2) & 0x3FFC.
+// Hash of a position = 12 bits of the 16-bit product fold(pair) * mul (program.h: filter_bin): two positions per v_pk_mul_lo_u16.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct Segment {
@@ -552,6 +551,9 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
     while (k + 1 < B.count && blockIdx.x >= B.f[k + 1].first_block) k++;
     const FilterArgs &a = B.f[k];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (Bank-private replicas of the table — 4 copies, each lane group of 8 with 8 banks of its own — were measured SLOWER: 1.19 ms
+    // against 0.89 ms. A ds_read_b32 takes as many cycles as its most loaded bank over all 32 lanes, and the maximum over four
+    // groups of 8-in-8 is hardly below 32-in-32, while 64 KiB per workgroup halves the occupancy.)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t *my_sub = a.sub + (size_t)rel * (kStreamSlab / kStreamSeg);
     uint32_t n_hit = 0;  // wave-uniform
-    const uint32_t mul2 = kFilterMul | (kFilterMul << 16);
+    const uint32_t mul2 = a.mul | (a.mul << 16);
 
     // Segment of lane `lane` in the iteration that starts at byte b: [b + 64 * lane, + 64). A chunk is fetched only if it begins
     // inside the arena (a fetch then ends at most 15 bytes past it: PWAF_ARENA_PAD); everything else reads the arena's first bytes.
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
             const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
             const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
             const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
+            // byte offset of a bin = (16-bit product >> 4) * 4
             mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
             mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
             mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
@@ -1596,7 +1599,8 @@ int configure_kernels(int device) {
     const void *fns[] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
                          reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
-                         reinterpret_cast<const void *>(verdict_kernel<true>), reinterpret_cast<const void *>(verdict_kernel<false>)};
+                         reinterpret_cast<const void *>(verdict_kernel<true>), reinterpret_cast<const void *>(verdict_kernel<false>),
+                         reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
         if (e != hipSuccess) return (int)e;

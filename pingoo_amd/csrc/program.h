@@ -92,12 +92,13 @@ static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
 // LDS gathers: 6.3 LDS cycles per wave lookup, two thirds of them bank conflicts) at the price of windows that span up to 8 bytes:
 // factors shorter than 3 bytes cannot be filtered and 3-4 byte factors contribute a single position.
 static constexpr uint32_t kFilterStride = 1;  // (2 was tried: a 3-byte factor such as "../" then owns a single position and floods the candidates)
-static constexpr uint32_t kFilterMul = 0x9E37u;  // 16-bit multiplicative hash of the folded byte pair (v_pk_mul_lo_u16 on the device)
-static inline uint32_t filter_bin(uint8_t b0, uint8_t b1) {
+static constexpr uint32_t kFilterMul = 0x9E37u;  // default 16-bit multiplier of the bigram hash (v_pk_mul_lo_u16 on the device); a pass picks its own from a
+                                                 // few candidates so that its factor windows avoid the bins frequent bigrams fall into (GroupFilter::mul)
+static inline uint32_t filter_bin(uint8_t b0, uint8_t b1, uint32_t mul = kFilterMul) {
     const uint32_t p = (uint32_t)(b0 & 0xDFu) | ((uint32_t)(b1 & 0xDFu) << 8);  // bit 5 cleared: ASCII case folding
     // top 12 bits of the 16-bit product: they mix all 8 bits of the second byte (bits [2, 14) keep only 6 of them, and digits then
     // alias letters: measured 2.6x the candidates on URLs)
-    return ((p * kFilterMul) & 0xFFFFu) >> (16 - kFilterBits);
+    return ((p * mul) & 0xFFFFu) >> (16 - kFilterBits);
 }
 // An anchored literal (starts_with / ==, <= 16 bytes) that most requests satisfy (e.g. a browser User-Agent prefix under a
 // negation) cannot go through the filter — every request would be a candidate. Up to two such HEADS per pass are compared
@@ -112,12 +113,13 @@ struct GroupFilter {
     bool enabled = false;
     std::vector<uint32_t> table;  // kFilterEntries masks: bit 8*j + b = 0 <=> bucket b accepts the bin at window position j
     uint32_t init = 0xFFFFFFFFu;  // state at the start of a field (zero at a bucket's wildcard positions)
+    uint32_t mul = kFilterMul;    // multiplier of the bigram hash chosen for this pass
     std::vector<FilterHead> heads;
     double est_candidate_rate = 0;  // expected fraction of requests flagged by chance (model or sample)
     std::string note;               // why the pass is not filtered, for stats / warnings
 };
 struct FilterHints {  // from a traffic sample (pwaf_engine_tune); all optional
-    const double *bin_prob = nullptr;              // kFilterEntries: probability that a text bigram falls into the bin
+    const double *pair_prob = nullptr;             // 65536 entries indexed by fold(b0) | fold(b1) << 8: probability of the (case-folded) bigram in traffic
     const std::vector<uint64_t> *atom_hits = nullptr;  // per local atom: sample requests it holds for
     uint64_t n_requests = 0;
     double mean_len = 0;                           // mean field length in the sample (0 = unknown)

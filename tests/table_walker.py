@@ -68,6 +68,7 @@ class Tables:
             elif tag == "GFHD":
                 init, n_heads = struct.unpack_from("<II", pl, 0)
                 cur["f_init"] = init
+                cur["f_mul"], n_heads = n_heads >> 16, n_heads & 0xFFFF
                 cur["f_heads"] = [(pl[8 + 20 * k:8 + 20 * k + 16][:pl[8 + 20 * k + 16]], pl[8 + 20 * k + 17], struct.unpack_from("<H", pl, 8 + 20 * k + 18)[0])
                                   for k in range(n_heads)]  # (literal, exact, local atom)
             elif tag == "GFTB":
@@ -96,16 +97,16 @@ class Tables:
     # --- pieces ---
     FILTER_MUL, FILTER_STRIDE = 0x9E37, 1
 
-    @classmethod
-    def filter_bin(cls, b0: int, b1: int) -> int:
-        return ((((b0 & 0xDF) | ((b1 & 0xDF) << 8)) * cls.FILTER_MUL) & 0xFFFF) >> 4
+    @staticmethod
+    def filter_bin(b0: int, b1: int, mul: int) -> int:
+        return ((((b0 & 0xDF) | ((b1 & 0xDF) << 8)) * mul) & 0xFFFF) >> 4
 
     def filter_candidate(self, g: dict, data: bytes) -> bool:
         """The bigram prefilter of a pass exactly as filter_kernel applies it to the bytes of ONE field value (the device also
         looks at a few bytes past the end, which can only flag more requests)."""
         st, tab = g["f_init"], g["f_table"]
         for i in range(0, len(data) - 1, self.FILTER_STRIDE):
-            st = ((st << 8) | int(tab[self.filter_bin(data[i], data[i + 1])])) & 0xFFFFFFFF
+            st = ((st << 8) | int(tab[self.filter_bin(data[i], data[i + 1], g["f_mul"])])) & 0xFFFFFFFF
             if (~st) & 0xFF000000:
                 return True
         return False

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $R
 run() {  # name, env...
   name=$1; shift
-  env "$@" python bench.py --steps 4 --warmup 2 --verbose --no-cpu-baseline --no-extra-modes --no-pcie > $OUT/$name.json 2> $OUT/$name.err
+  env "$@" python bench.py --steps 6 --warmup 2 --verbose --no-cpu-baseline --no-extra-modes --no-pcie $BENCH_EXTRA > $OUT/$name.json 2> $OUT/$name.err
   echo "== $name ($*)"; grep -E "avg" $OUT/$name.err | sed 's/^  //;s/  */ /g' | tr '\n' ';'; echo
   python -c "import json;d=json.load(open('$OUT/$name.json'));print('   ms/step',round(d['ms_per_step'],3),'Greq/s',round(d['value']/1e9,3),'roofline',d['roofline']['kernel'],round(d['roofline']['frac'],4))"
 }

@@ -17,7 +17,7 @@ def candidates(g, data, off):
     """numpy model of filter_kernel over one field arena (bigrams sampled every STRIDE bytes from each field's start): bool per request"""
     d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
     p = d[:-1] | (d[1:] << 8)
-    bins = ((p * 0x9E37) & 0xFFFF) >> 4
+    bins = ((p * int(g["f_mul"])) & 0xFFFF) >> 4
     m = g["f_table"][bins].astype(np.uint64)
     L = len(m)
     pos = np.arange(L)
