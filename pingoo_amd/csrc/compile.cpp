@@ -1204,8 +1204,9 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                 continue;
             }
             if (cur.size() == 1) {
-                // one pattern alone exceeds the budget (typically a bounded gap such as a.{0,40}b: the DFA must remember every
-                // position of the last 40 bytes): the rules that use it are reported and dropped, the rest of the set is unaffected
+                // one pattern alone exceeds the budget (two long counted gaps in a row, `a.{0,60}b.{0,60}c`, need the product
+                // of both distances; a counted gap with a large MINIMUM, `a.{20,40}b`, needs every subset of the last 20
+                // positions): the rules that use it are reported and dropped, the rest of the set is unaffected
                 bad_atoms.emplace_back(cur[0].atom, std::string("a pattern on http_request.") + field_name(f) + " needs a DFA beyond the state/table budget: " + derr);
                 continue;
             }

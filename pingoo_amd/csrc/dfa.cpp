@@ -47,6 +47,19 @@ struct Nfa {
     bool uses_word = false, uses_line = false;
     size_t cap = 0;
     bool overflow = false;
+    // Counted repetitions of ONE byte class (`.{0,40}`, `[^>]{0,64}`, `\s{1,8}`) unroll into a chain of optional
+    // copies; chain_rank[s] = copies still available at entry state s of chain chain_id[s] (0 = not a chain entry).
+    // A thread with more copies left accepts a superset of what a thread of the same chain with fewer copies (or the
+    // chain's continuation, chain_tail) accepts from the same position on, which is what lets prune_core() keep the
+    // subset construction polynomial for `a.{0,n}b` instead of tracking every subset of the n gap positions.
+    std::vector<int> chain_id, chain_rank;
+    std::vector<std::vector<int>> chain_tail;  // per NFA state: chains whose continuation it is
+    int n_chains = 0;
+    void tag(int s, int chain, int rank) {
+        if ((size_t)s >= chain_id.size()) { chain_id.resize(st.size(), -1); chain_rank.resize(st.size(), 0); }
+        chain_id[s] = chain;
+        chain_rank[s] = rank;
+    }
 
     int add(NState s) {
         if (st.size() >= cap) { overflow = true; return 0; }
@@ -104,11 +117,18 @@ struct Nfa {
                     }
                 } else {
                     cur = next;
+                    bool chain = k.k == RNode::CLASS && n.rmax - n.rmin >= 2;
+                    int id = chain ? n_chains++ : -1;
                     for (int c = n.rmin; c < n.rmax; c++) {
                         NState opt{N_EPS, A_TEXT_START};
                         opt.out = build(k, cur);
                         opt.out2 = next;
                         cur = add(opt);
+                        if (chain && !overflow) tag(cur, id, c - n.rmin + 1);
+                    }
+                    if (chain && !overflow) {
+                        if ((size_t)next >= chain_tail.size()) chain_tail.resize(st.size());
+                        chain_tail[next].push_back(id);
                     }
                     for (int c = 0; c < n.rmin; c++) cur = build(k, cur);
                 }
@@ -157,7 +177,33 @@ struct Builder {
     uint32_t stamp = 0;
     std::vector<int> stack;  // also used directly by build_dfa's filtered phase-A walk
 
-    explicit Builder(const Nfa &n) : nfa(n), mark(n.st.size(), 0) {}
+    std::vector<int> best, touched;  // per chain: highest rank present in the core being pruned
+
+    explicit Builder(const Nfa &n) : nfa(n), mark(n.st.size(), 0), best(n.n_chains, 0) {}
+
+    // Drop the states of a (sorted, unique) core that another state of the same core subsumes: lower-ranked entries of
+    // a counted-class chain, and the chain's continuation state when any entry of that chain is present (its closure
+    // contains the continuation). The language of the DFA state is unchanged; only its identity becomes canonical.
+    void prune_core(std::vector<int> &core) {
+        if (!nfa.n_chains) return;
+        for (int s : core)
+            if (nfa.chain_id[s] >= 0) {
+                int c = nfa.chain_id[s];
+                if (!best[c]) touched.push_back(c);
+                best[c] = std::max(best[c], nfa.chain_rank[s]);
+            }
+        if (touched.empty()) return;
+        size_t w = 0;
+        for (int s : core) {
+            bool keep = true;
+            if (nfa.chain_id[s] >= 0) keep = nfa.chain_rank[s] == best[nfa.chain_id[s]];
+            else for (int c : nfa.chain_tail[s]) if (best[c] > 0) { keep = false; break; }
+            if (keep) core[w++] = s;
+        }
+        for (int c : touched) best[c] = 0;
+        touched.clear();
+        core.resize(w);
+    }
 
     // Closure from `seeds` (already-unvisited check by stamp). When nk_known is false, assertions that need
     // the next byte are parked in `pending`; otherwise every assertion is decided under (pk, nk).
@@ -203,6 +249,9 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
             return false;
         }
     }
+    nfa.chain_id.resize(nfa.st.size(), -1);
+    nfa.chain_rank.resize(nfa.st.size(), 0);
+    nfa.chain_tail.resize(nfa.st.size());
     // ---- byte classes: bytes are equivalent when no class set and no assertion kind tells them apart ----
     auto kind_of = [&](int b) -> uint8_t {
         bool w = (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_';
@@ -398,6 +447,7 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
                 for (int s : liveB) if (set_has[nfa.st[s].cls][c]) nkey.core.push_back(nfa.st[s].out);
                 std::sort(nkey.core.begin(), nkey.core.end());
                 nkey.core.erase(std::unique(nkey.core.begin(), nkey.core.end()), nkey.core.end());
+                bl.prune_core(nkey.core);
                 int t = intern(std::move(nkey));
                 ds[d].next[c] = t;
             }
@@ -432,8 +482,13 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
     return true;
 }
 
+// `.*`, `[^>]+`, and counted gaps wide enough to multiply states with the other patterns of a table (`.{0,40}`)
+static bool is_wide_gap(const RNode &n) {
+    return n.k == RNode::REPEAT && (n.rmax < 0 || n.rmax - n.rmin >= 8) && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64;
+}
+
 bool has_wide_gap(const RNode &n) {
-    if (n.k == RNode::REPEAT && n.rmax < 0 && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64) return true;
+    if (is_wide_gap(n)) return true;
     for (auto &k : n.kids) if (has_wide_gap(*k)) return true;
     return false;
 }
@@ -462,9 +517,8 @@ uint32_t rx_min_len(const RNode &n) {
 
 RNodeP gap_prefilter(const RNodeP &rx) {
     if (!rx || rx->k != RNode::CAT) return nullptr;
-    auto is_gap = [](const RNode &n) { return n.k == RNode::REPEAT && n.rmax < 0 && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64; };
     size_t g = 0;
-    while (g < rx->kids.size() && !is_gap(*rx->kids[g])) {
+    while (g < rx->kids.size() && !is_wide_gap(*rx->kids[g])) {
         if (has_wide_gap(*rx->kids[g])) return nullptr;  // a gap nested deeper comes first: no clean prefix
         g++;
     }

@@ -162,3 +162,31 @@ def test_atoms_are_shared_across_rules():
     s = CompiledProgram(rules).stats()
     assert s["n_scan_atoms"] == 2  # "/admin" once + the captcha-endpoint prefix
     assert s["n_numeric_atoms"] == 50 + 2  # 50 ports + the two UA-length gate atoms
+
+
+COUNTED_GAPS = ['select.{0,40}from', 'a.{0,40}b', '<script[^>]{0,64}>', 'union\\\\s{1,8}select', '(a|b).{2,12}c$', 'x.{0,5}x.{0,5}x', 'ab.{1,9}ab', '^/p.{3,30}\\\\.php',
+                '(?i)on\\\\w{0,12}\\\\s{0,4}=', 'select.{0,24}from.{0,24}where', '(?s)a.{0,33}b', 'q{2,13}-', '(select|union).{0,30}(from|where)']
+
+
+def test_counted_gap_patterns_compile_to_small_tables_and_match_the_oracle():
+    """`a.{0,n}b` (the common WAF signature shape; the reference's regex crate takes it, rules/rules.rs compile path): the subset
+    construction keeps one thread per counted-class chain (dfa.cpp prune_core), so the table is polynomial in n; verdicts against the oracle's
+    backtracking matcher on inputs built from the patterns' own pieces (gap lengths on both sides of every bound, newlines inside gaps)."""
+    rules = [(f"r{k}", f'http_request.url.matches("{p}")', [B]) for k, p in enumerate(COUNTED_GAPS)]
+    prog = CompiledProgram(rules)
+    assert prog.unsupported_rules(len(rules)) == []
+    rng = random.Random(1)
+    pieces = ["select", "from", "where", "union", "a", "b", "c", "x", "ab", "<script", ">", " ", "\n", "=", "on", "load", "/p", ".php", "-" * 7, "q" * 13, "q", "A", "SeLeCt", "z" * 11, "z" * 29]
+    reqs = [Request(url="".join(rng.choice(pieces) for _ in range(rng.randrange(0, 12))), path="/", host="h") for _ in range(6000)]
+    for n in (39, 40, 41, 42):   # exact bounds of the first two patterns
+        reqs += [Request(url="select" + "y" * n + "from"), Request(url="a" + "y" * n + "b"), Request(url="a" + "y" * (n // 2) + "\n" + "y" * (n - n // 2 - 1) + "b")]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(walk(prog, batch), want, batch, "counted gaps")
+    assert len(set(want["rule_idx"][want["action"] > 0].tolist())) >= 10
+
+
+def test_a_pattern_beyond_the_table_budget_fails_alone():
+    rules = [("big", 'http_request.url.matches("select.{0,60}from.{0,60}where")', [B]), ("min", 'http_request.url.matches("a.{20,40}b")', [B]), ("ok", 'http_request.url.contains("x")', [CAP])]
+    prog = CompiledProgram(rules)
+    assert prog.unsupported_rules(len(rules)) == [0, 1] and "budget" in prog.rule_status(0)[1]

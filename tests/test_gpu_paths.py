@@ -267,3 +267,25 @@ rules:
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "mmdb + config files")
     assert len(set(want["rule_idx"].tolist())) == 5  # every rule decides something, and some requests pass
     eng.close()
+
+
+def test_counted_gap_patterns_on_the_device():
+    """The counted-gap signatures of test_compiler (a.{0,n}b and friends) through the HIP engine: they are isolated into gated passes
+    (their necessary prefix gates the confirmation scan); verdicts against the oracle, with other rules sharing the field."""
+    from test_compiler import COUNTED_GAPS
+    rules = [(f"g{k}", f'http_request.url.matches("{p}")', [B]) for k, p in enumerate(COUNTED_GAPS)]
+    rules += [("lit", 'http_request.url.contains("zzzzzzzzzzz")', [CAP]), ("ua", 'http_request.user_agent.matches("(?i)sqlmap.{0,20}[0-9]")', [B])]
+    eng = RuleEngine(rules)
+    assert eng.program.unsupported_rules(len(rules)) == []
+    rng = random.Random(5)
+    pieces = ["select", "from", "where", "union", "a", "b", "c", "x", "ab", "<script", ">", " ", "\n", "=", "on", "load", "/p", ".php", "-" * 7, "q" * 13, "q", "A", "SeLeCt", "z" * 11, "z" * 29]
+    reqs = [Request(url="".join(rng.choice(pieces) for _ in range(rng.randrange(0, 12))), path="/", host="h", user_agent=rng.choice(["sqlmap/1.7", "SQLMap " + "-" * 21 + "7", "curl"]))
+            for _ in range(20000)]
+    for n in (39, 40, 41, 42):
+        reqs += [Request(url="select" + "y" * n + "from"), Request(url="a" + "y" * n + "b"), Request(url="a" + "y" * (n // 2) + "\n" + "y" * (n - n // 2 - 1) + "b")]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "counted gaps on the device")
+    eng.tune(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "counted gaps on the device, tuned")
+    eng.close()
