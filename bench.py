@@ -88,16 +88,22 @@ def main():
     n_streams = max(inflight, 2)
     outs = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(n_streams)]
     cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_streams)]
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
-    out, counts, stream = outs[0], cnts[0], streams[0]
+    # one batch in flight: torch's current stream; several: streams of their own (the current stream is HIP's NULL stream, which
+    # synchronises with every other blocking stream — no two batches would overlap)
+    own_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    out, counts = outs[0], cnts[0]
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    issue_ms = [0.0]
+
     def timed_run(db, steps, warmup, inflight=inflight):
         """W untimed + K timed steps over the resident batch `db`; returns (seconds, kernel times, action counters)."""
+        streams = [torch.cuda.current_stream(dev)] if inflight == 1 else own_streams
+
         def step(i):
             k = i % inflight
             with torch.cuda.stream(streams[k]):
@@ -113,6 +119,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
+        issue_ms[0] = 1e3 * (time.perf_counter() - t0) / steps  # host time to enqueue one step (the device runs behind it)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -145,7 +152,11 @@ def main():
         dom = max(kinds, key=lambda kk: kinds[kk][0])
         ms, _, nbytes = kinds[dom]
         ach = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
-        return {"requests_per_s": n * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS}
+        per = {}
+        for name, kms, _ in kt:
+            per[name] = per.get(name, 0.0) + kms / steps
+        return {"requests_per_s": n * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
+                "kernels_ms_per_step": {k: round(v, 4) for k, v in per.items()}}
 
     def phase(msg):
         if args.verbose and rank == 0:
@@ -170,6 +181,7 @@ def main():
     elapsed, ktimes, final_counts = timed_run(dbatch, args.steps, args.warmup)
     value = n * world * args.steps / elapsed
     head = mode_summary(elapsed, ktimes, args.steps)
+    head["host_enqueue_ms_per_step"] = round(issue_ms[0], 3)
     headline_out = out[: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite `out`)
 
     if extras and inflight == 1:
@@ -178,7 +190,8 @@ def main():
         # per-kernel durations (and anything derived from them, like the roofline object) are quoted for one batch at a time.
         phase("two batches in flight")
         el, kt, _ = timed_run(dbatch, max(4, args.steps), 2, inflight=2)
-        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * max(4, args.steps) / el, "ms_per_step": 1e3 * el / max(4, args.steps)}
+        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * max(4, args.steps) / el, "ms_per_step": 1e3 * el / max(4, args.steps),
+                                                                "host_enqueue_ms_per_step": round(issue_ms[0], 3)}
     if extras and not args.adversarial:
         phase("adversarial run")
         adv = DeviceBatch(wl.batch(rank * n, n, threads=threads, adversarial=True), dev)
@@ -305,7 +318,7 @@ def main():
             for _ in range(40):
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                eng.evaluate_device(dbatch, out=out, stream=stream.cuda_stream)
+                eng.evaluate_device(dbatch, out=out)
                 torch.cuda.synchronize(dev)
                 lat.append(1e3 * (time.perf_counter() - t0))
             result["latency_ms"] = {"batch": n, "calls": len(lat), "device_resident": {"p50": pct(lat, 50), "p99": pct(lat, 99), "max": max(lat)}}

@@ -91,6 +91,7 @@ struct DevGroup {
     DevBuf ftable;
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
+    uint32_t flat_hot = 0;  // rows of `flat` lscan_kernel stages in LDS
 };
 
 }  // namespace
@@ -104,6 +105,8 @@ struct Scratch {
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, done = nullptr;
     bool used = false;
+    hipStream_t last = nullptr;  // the stream of the context's latest batch
+    bool last_own = false;       // ... which was the context's own stream (a host batch)
     DevBuf status;            // one sticky word: bit 0 = some batch on this context exhausted the overflow pool (cleared when reported)
     uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
@@ -113,6 +116,23 @@ struct Scratch {
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
     std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
+    // Streams and events are created on first use: every HIP stream takes a share of the few hardware queues of its priority
+    // class, and a context (or its own stream) a caller never uses must not cost the caller's streams their concurrency (measured:
+    // three idle contexts' streams made two caller streams share one queue — no overlap between two batches in flight).
+    // The side stream (attribute kernel) is created at the LOWEST stream priority: priority classes have hardware queues of their
+    // own, so it can never share a queue with the caller's (normal-priority) stream — when it did, the attribute kernel ran in
+    // front of the prefilter instead of beside it (measured: +0.45 ms per 10M-request batch).
+    int ensure(bool own_stream) {
+        if (!side) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess)
+                return fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
+        }
+        if (own_stream && !stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail(PWAF_E_DEVICE, "hipStreamCreate failed");
+        return PWAF_OK;
+    }
     void release() {
         for (DevBuf *b : {&status, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
@@ -296,18 +316,37 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     return PWAF_OK;
 }
 
-int build_flat_group(const DfaGroup &g, DevGroup &d) {
-    std::vector<uint16_t> flat(g.trans);
-    for (auto &t : flat)
-        if (g.emit_off[(size_t)t + 1] != g.emit_off[t]) t |= 0x8000u;
+// The flat form of a group for lscan_kernel. States are renumbered — start state first, then by visits of the tuning sample
+// (discovery order without one) — so that the rows lscan_kernel stages in LDS are the ones its walks spend their steps in.
+int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t> *visits = nullptr) {
+    const uint32_t S = g.n_states, C = g.n_classes;
+    std::vector<uint32_t> order(S), pos(S);
+    for (uint32_t s = 0; s < S; s++) order[s] = s;
+    if (visits && visits->size() == S) std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
+    for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
+    std::vector<uint16_t> flat((size_t)S * C);
+    std::vector<uint32_t> emit_off(1, 0), end_off(1, 0);
+    std::vector<uint16_t> emit_list, end_list;
+    for (uint32_t q = 0; q < S; q++) {
+        const uint32_t s = order[q];
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t t = g.trans[(size_t)s * C + c];
+            flat[(size_t)q * C + c] = (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u));
+        }
+        emit_list.insert(emit_list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[(size_t)s + 1]);
+        emit_off.push_back((uint32_t)emit_list.size());
+        end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
+        end_off.push_back((uint32_t)end_list.size());
+    }
+    d.flat_hot = std::min<uint32_t>(S, kListHotBytes / (2u * C));
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     int rc;
-    if ((rc = upload(d.flat, flat))) return rc;
+    if ((rc = upload(d.flat, flat, 4))) return rc;  // (the LDS staging copies whole 32-bit words)
     if ((rc = upload(d.flat_classmap, cm))) return rc;
-    if ((rc = upload(d.emit_off, g.emit_off))) return rc;
-    if ((rc = upload(d.emit_list, g.emit_list))) return rc;
-    if ((rc = upload(d.end_off, g.end_off))) return rc;
-    return upload(d.end_list, g.end_list);
+    if ((rc = upload(d.emit_off, emit_off))) return rc;
+    if ((rc = upload(d.emit_list, emit_list))) return rc;
+    if ((rc = upload(d.end_off, end_off))) return rc;
+    return upload(d.end_list, end_list);
 }
 
 int validate_batch_header(const pwaf_batch *b) {
@@ -426,11 +465,29 @@ int assign_lists(pwaf_engine *e) {
     return upload(e->colmask, colmask);
 }
 
-Scratch &next_context(pwaf_engine *e) {
-    std::lock_guard<std::mutex> lock(e->mu);
-    Scratch &S = *e->ctx[e->next_ctx];
-    e->next_ctx = (e->next_ctx + 1) % e->ctx.size();
-    return S;
+// The scratch context of a call, locked. The batch will run on `caller` (device batches; NULL is HIP's default stream) or, with
+// `own`, on the context's own stream (host batches). Preference: the context whose latest batch ran on the SAME stream (stream
+// order already protects the buffers: a single-stream caller keeps using one context, and one context's worth of memory), then
+// a fresh one, then the next of the ring — only in that last case must the stream wait (on the device) for the previous user.
+// (Deliberately no "whichever context is idle by hipEventQuery": the choice must not depend on timing.)
+Scratch &acquire_context(pwaf_engine *e, bool own, hipStream_t caller, std::unique_lock<std::mutex> &held, bool &must_wait) {
+    must_wait = false;
+    for (int pass = 0; pass < 2; pass++)
+        for (auto &c : e->ctx) {
+            std::unique_lock<std::mutex> l(c->mu, std::try_to_lock);
+            if (!l.owns_lock()) continue;
+            const bool ok = pass == 0 ? (c->used && (own ? c->last_own : (!c->last_own && c->last == caller))) : !c->used;
+            if (ok) { held = std::move(l); return *c; }
+        }
+    size_t k;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        k = e->next_ctx;
+        e->next_ctx = (e->next_ctx + 1) % e->ctx.size();
+    }
+    held = std::unique_lock<std::mutex>(e->ctx[k]->mu);
+    must_wait = e->ctx[k]->used;
+    return *e->ctx[k];
 }
 
 int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
@@ -687,6 +744,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
+        a.n_hot = d.flat_hot;
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
@@ -987,16 +1045,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = (uint32_t)cus;
     }
-    for (size_t k = 0; k < kContexts; k++) {
-        e->ctx.emplace_back(new Scratch());
-        Scratch &S = *e->ctx.back();
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) {
-            fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
-            return dev_fail(PWAF_E_DEVICE);
-        }
-    }
+    for (size_t k = 0; k < kContexts; k++) e->ctx.emplace_back(new Scratch());
     e->n_fields = PWAF_N_FIELDS + (uint32_t)P.header_names.size();
     e->mean_len.assign(e->n_fields, 0.0);
     e->groups.resize(P.groups.size());
@@ -1254,7 +1303,12 @@ uint32_t pwaf_program_header_count(const pwaf_program *p) { return p ? (uint32_t
 const char *pwaf_program_header_name(const pwaf_program *p, uint32_t i) { return (p && i < p->p->header_names.size()) ? p->p->header_names[i].c_str() : ""; }
 uint32_t pwaf_engine_header_count(const pwaf_engine *e) { return e ? pwaf_program_header_count(&e->prog) : 0u; }
 const char *pwaf_engine_header_name(const pwaf_engine *e, uint32_t i) { return e ? pwaf_program_header_name(&e->prog, i) : ""; }
-void *pwaf_engine_stream(const pwaf_engine *e) { return (e && !e->ctx.empty()) ? (void *)e->ctx[0]->stream : nullptr; }
+void *pwaf_engine_stream(const pwaf_engine *e) {
+    if (!e || e->ctx.empty() || hipSetDevice(e->device) != hipSuccess) return nullptr;
+    Scratch &S = *e->ctx[0];
+    std::lock_guard<std::mutex> lock(S.mu);
+    return S.ensure(true) == PWAF_OK ? (void *)S.stream : nullptr;
+}
 
 int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
     if (!e || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
@@ -1271,11 +1325,15 @@ int pwaf_evaluate_device(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out
     HIP_TRY(hipSetDevice(e->device));
     // Re-entrant: the call takes the next scratch context of the ring; the caller's stream first waits (on the device) for whoever
     // used that context before, and leaves its own completion event behind. Calls on different streams therefore overlap.
-    Scratch &S = next_context(e);
-    std::lock_guard<std::mutex> lock(S.mu);
-    if (S.used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, S.done, 0));
+    std::unique_lock<std::mutex> lock;
+    bool must_wait;
+    Scratch &S = acquire_context(e, false, (hipStream_t)stream, lock, must_wait);
+    if ((rc = S.ensure(false))) return rc;
+    if (must_wait) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, S.done, 0));
     rc = run_pipeline(e, S, *in, out, counts, match_idx, n_matches, (hipStream_t)stream);
     S.used = true;
+    S.last = (hipStream_t)stream;
+    S.last_own = false;
     HIP_TRY(hipEventRecord(S.done, (hipStream_t)stream));
     return rc;
 }
@@ -1290,16 +1348,20 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     }
     HIP_TRY(hipSetDevice(e->device));
     // the context is held for the whole call (its staging buffers and its stream are reused); other threads take other contexts
-    Scratch &S = next_context(e);
-    std::lock_guard<std::mutex> lock(S.mu);
+    std::unique_lock<std::mutex> lock;
+    bool must_wait;
+    Scratch &S = acquire_context(e, true, nullptr, lock, must_wait);
+    if ((rc = S.ensure(true))) return rc;
     hipStream_t s = S.stream;
-    if (S.used) HIP_TRY(hipStreamWaitEvent(s, S.done, 0));
+    if (must_wait) HIP_TRY(hipStreamWaitEvent(s, S.done, 0));
     // runs the pipeline and waits; a batch that exhausted the overflow pool is run again with a pool of the size it asked for
     auto run_checked = [&](const pwaf_batch &db, pwaf_verdict *d_out, pwaf_counts *d_counts, bool known, const std::vector<uint32_t> *begins = nullptr) -> int {
         for (int attempt = 0;; attempt++) {
             if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
             int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins);
             S.used = true;
+            S.last = s;
+            S.last_own = true;
             HIP_TRY(hipEventRecord(S.done, s));
             if (r) return r;
             uint32_t st[2] = {0, 0};
@@ -1511,7 +1573,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     }
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k], &class_freq[k]))) return rc;
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k], &class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], &visits[k]))) return rc;
     if ((rc = assign_lists(e))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;

@@ -7,6 +7,7 @@
 namespace pwaf {
 
 static constexpr int kMaxPasses = 250;  // (= program.h kMaxGroups)
+static constexpr int kVerdictPre = 12;  // hit records per request the verdict kernel requests one group ahead
 static constexpr uint32_t kGapLists = 32;     // gated gap passes own list slots [0, 32) (one bit each in the factor masks); filtered passes follow
 static constexpr uint32_t kMaxHeaderLens = 8; // header columns whose LENGTH rules compare
 
@@ -63,9 +64,12 @@ struct ScanArgs {
 };
 
 // A list-driven pass (behind a bigram prefilter, or gated by prefilter factors): lscan_kernel walks ONE listed request per lane
-// through the pass's DFA, read straight from the L2-resident flat table (no LDS staging, no hot / cold rows: a list holds a few
-// percent of the batch, so what matters is latency per request and full occupancy, not bytes per clock).
-//   flat[s * n_classes + c] = next state | 0x8000 when entering it emits; emit / end lists are indexed by state.
+// through the pass's DFA. A list holds a few percent of the batch, so what matters is latency per step: the table's first n_hot rows
+// (states are numbered by how often the tuning sample's candidates visit them, start state first) are staged in LDS — a step there
+// is two dependent LDS reads (class, cell) instead of an L2 round trip — and the rest is read from the L2-resident flat table.
+//   flat[s * n_classes + c] = next state | 0x8000 when entering it emits; emit / end lists are indexed by (renumbered) state.
+static constexpr uint32_t kListThreads = 512;
+static constexpr uint32_t kListHotBytes = 48 * 1024;  // 3 workgroups (24 waves) per CU
 struct ListScanArgs {
     const uint8_t *data;
     const uint32_t *off;
@@ -73,6 +77,7 @@ struct ListScanArgs {
     const uint16_t *flat;
     const uint8_t *classmap;  // 256 bytes
     uint32_t n_classes;
+    uint32_t n_hot;            // rows staged in LDS: n_hot * n_classes * 2 <= kListHotBytes
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;

@@ -439,21 +439,29 @@ template <int CH, bool WIDE>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<CH, WIDE>(a); }
 
 // lscan_kernel: every list-driven pass of a phase in ONE launch (blockIdx.y = pass). One listed request per lane, walked byte by
-// byte through the flat table in L2 (dependent 2-byte loads: ~100 ns per step at an L1 / L2 hit); a list is a few percent of the
-// batch (tens of MB of field bytes), so the whole launch takes tens of microseconds at full occupancy — the wave-lockstep walk of
-// scan_kernel, built for streaming EVERY request, took 0.6 ms on the same lists (every lane a candidate: its slow paths fire in
-// every group of steps).
-__global__ __launch_bounds__(256) void lscan_kernel(GatedArgs b) {
-    __shared__ unsigned char cls[256];
+// byte: per step one LDS read for the byte's class (independent of the state: issued ahead) and one dependent read of the cell —
+// from the LDS copy of the table's hottest rows, or from the flat table in L2 for the others (~10x the latency). The wave-lockstep
+// walk of scan_kernel, built for streaming EVERY request, took 0.6 ms on the same lists (every lane a candidate: its slow paths
+// fire in every group of steps).
+__global__ __launch_bounds__(kListThreads) void lscan_kernel(GatedArgs b) {
+    extern __shared__ uint32_t lscan_lds[];  // [kListHotBytes / 4] hot rows, then the 256-byte class map
+    __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
     const ListScanArgs &a = b.g[blockIdx.y];
     const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
-    if (blockIdx.x * 256u >= n_l) return;
-    cls[threadIdx.x] = a.classmap[threadIdx.x];
+    if (blockIdx.x * kListThreads >= n_l) return;
+    const uint32_t ncls = a.n_classes;
+    const uint32_t hot_elems = a.n_hot * ncls;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.flat);
+        for (uint32_t k = threadIdx.x; k < (hot_elems + 1) / 2; k += kListThreads) lscan_lds[k] = src[k];
+        if (threadIdx.x < 64) lscan_lds[kListHotBytes / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
+    }
     __syncthreads();
+    const unsigned char *cls = reinterpret_cast<const unsigned char *>(lscan_lds + kListHotBytes / 4);
+    const uint16_t *hot = reinterpret_cast<const uint16_t *>(lscan_lds);
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
-    const uint32_t ncls = a.n_classes;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_l; i += gridDim.x * 256u) {
+    for (uint32_t i = blockIdx.x * kListThreads + threadIdx.x; i < n_l; i += gridDim.x * kListThreads) {
         if (a.need_in != nullptr && !((a.need_in[i] >> a.need_bit) & 1u)) continue;  // (a sharing gap pass: none of its factors fired here)
         const uint32_t r = a.req_list != nullptr ? a.req_list[i] : i;
         if (a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31));
@@ -466,11 +474,14 @@ __global__ __launch_bounds__(256) void lscan_kernel(GatedArgs b) {
             const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
             const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
             const uint32_t cnt = min(16u, end - p);
+            uint32_t c[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) c[k] = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
                 if (k < cnt) {
-                    const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                    const uint32_t t = flat[state * ncls + cls[byte]];
+                    const uint32_t idx = state * ncls + c[k];
+                    const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
                     state = t & 0x7FFFu;
                     if (t & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
                 }
@@ -518,9 +529,9 @@ int launch_scan_gated(const GatedArgs &b, void *stream) {
     if (b.count == 0 || b.g[0].n == 0) return 0;
     // the list lengths are only known on the device: a grid that covers the chip once per pass (grid-stride over the list);
     // workgroups beyond a list's end exit at once
-    const uint32_t blocks = std::min<uint32_t>((b.g[0].n + 255) / 256, std::max(1u, b.g[0].n_cus) * 8u);
+    const uint32_t blocks = std::min<uint32_t>((b.g[0].n + kListThreads - 1) / kListThreads, std::max(1u, b.g[0].n_cus) * 3u);
     void *args[] = {const_cast<GatedArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(lscan_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(lscan_kernel), dim3(blocks, b.count), dim3(kListThreads), args, kListHotBytes + 256, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -699,6 +710,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
 // resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the three
 // bytes a window may reach back and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
 __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
+    __builtin_amdgcn_s_setprio(3);
     const FilterArgs &a = B.f[blockIdx.y];
     const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6), slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
@@ -723,6 +735,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
 // bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
 // (kCompactWords bitmap words each), then every workgroup sums the counts before it (a few hundred values) and writes its part.
 __global__ __launch_bounds__(256) void bitcount_kernel(FilterBatchArgs B) {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t red[256];
     const FilterArgs &a = B.f[blockIdx.y];
     const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords;
@@ -739,6 +752,7 @@ __global__ __launch_bounds__(256) void bitcount_kernel(FilterBatchArgs B) {
 }
 
 __global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t red[256];
     const FilterArgs &a = B.f[blockIdx.y];
     const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords, tid = threadIdx.x;
@@ -921,7 +935,8 @@ __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, 
     return t;
 }
 
-template <bool LT>
+// BR = 64-pass bitmap registers (1: up to 64 passes, else kMaxPasses)
+template <bool LT, int BR>
 __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
@@ -969,51 +984,76 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         atomicOr(&colnz[c >> 5], 1u << (c & 31));
     };
 
-    // A group's inputs — up to kPre hit records per request, the captcha flag, the attribute kernel's pair count and first 64
+    // A group's inputs — the hit records of up to kPre passes, the captcha flag, the attribute kernel's pair count and first 64
     // pairs — are requested ONE GROUP AHEAD: with ~9 waves per CU nothing else hides the ~2 us those first-touch loads take.
-    constexpr int kPre = 12;
+    // Which passes: a list-driven (sparse) pass has a visited bitmap, and in most groups of 64 requests most such passes visited
+    // nobody (a 4096-rule set over 64 header fields has ~90 passes, a handful of them non-empty per group). The group's 64 visited
+    // bits of EVERY pass are requested TWO groups ahead, lane q holding pass q's word (dense passes: all ones); one group ahead a
+    // ballot names the non-empty passes and only those get a record load — limited to the lanes whose bit is set.
+    constexpr int kPre = kVerdictPre;
+    constexpr int kBitRegs = BR;  // 64 passes per register
+    struct Bits {
+        unsigned long long w[kBitRegs];  // lane l of w[r]: the visited bits of pass r * 64 + l for the group's 64 requests
+    };
     struct Inputs {
-        uint32_t rv[kPre];
+        uint32_t rv[kPre];    // the hit records of the group's first kPre non-empty passes ...
+        uint32_t base[kPre];  // ... and their first columns (wave-uniform; kNone = slot unused)
+        Bits bits;            // for the passes left over
+        unsigned long long rest[kBitRegs];  // wave-uniform: non-empty passes that got no slot (fetched inside the group: rare)
         uint32_t flags, n_pairs;
         uint4 pair0;
     };
-    // Sparse passes: the group's 64 visited bits per pass are requested TWO groups ahead (wave-uniform words), so that the record
-    // loads one group ahead can be limited to the lanes whose bit is set.
-    struct Bits {
-        uint32_t lo[kPre], hi[kPre];
-    };
-    // the pass table is read once per wave (group-invariant)
-    auto pass_bitmap = [&](const uint32_t ps) -> const uint32_t * {
-        const uint32_t ks = a.passes[ps].kind_slot, kind = ks >> 24, slot = ks & 0xFFFFFFu;
-        return kind == 1 ? a.cand_bits + (size_t)slot * a.bit_words : kind == 2 ? a.visit_bits + (size_t)slot * a.bit_words : nullptr;
-    };
-    const uint32_t *p_bits[kPre];
-    uint32_t p_base[kPre];
+    // group-invariant, per lane: the bitmap and first column of "my" pass in each register
+    const uint32_t *my_bits[kBitRegs];
+    uint32_t my_base[kBitRegs];
+    bool my_live[kBitRegs];
 #pragma unroll
-    for (int q = 0; q < kPre; q++) {
-        const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
-        p_bits[q] = a.n_passes ? pass_bitmap(ps) : nullptr;
-        p_base[q] = a.n_passes ? a.passes[ps].base : 0u;
+    for (int r = 0; r < kBitRegs; r++) {
+        const uint32_t ps = (uint32_t)r * 64 + lane;
+        my_live[r] = ps < a.n_passes;
+        my_bits[r] = nullptr;
+        my_base[r] = 0;
+        if (my_live[r]) {
+            const PassInfo pi = a.passes[ps];
+            const uint32_t kind = pi.kind_slot >> 24, slot = pi.kind_slot & 0xFFFFFFu;
+            my_bits[r] = kind == 1 ? a.cand_bits + (size_t)slot * a.bit_words : kind == 2 ? a.visit_bits + (size_t)slot * a.bit_words : nullptr;
+            my_base[r] = pi.base;
+        }
     }
     auto request_bits = [&](const uint32_t g, Bits &bt) {
         const uint32_t gg = min(g, a.n_groups - 1);
 #pragma unroll
-        for (int q = 0; q < kPre; q++) {
+        for (int r = 0; r < kBitRegs; r++) {
             // (the bitmap of a batch whose size is not a multiple of 64 is padded to whole groups by the engine)
-            bt.lo[q] = p_bits[q] != nullptr ? p_bits[q][2 * gg] : 0xFFFFFFFFu;
-            bt.hi[q] = p_bits[q] != nullptr ? p_bits[q][2 * gg + 1] : 0xFFFFFFFFu;
+            bt.w[r] = !my_live[r] ? 0ull : my_bits[r] != nullptr ? *reinterpret_cast<const unsigned long long *>(my_bits[r] + 2 * (size_t)gg) : ~0ull;
         }
     };
     auto request_inputs = [&](const uint32_t g, const Bits &bt, Inputs &in) {
         const uint32_t i = g * 64 + lane;
         const bool valid = g < a.n_groups && i < a.n;
+        unsigned long long nz[kBitRegs];
+#pragma unroll
+        for (int r = 0; r < kBitRegs; r++) nz[r] = (uint32_t)r * 64 < a.n_passes ? __ballot(bt.w[r] != 0) : 0ull;
 #pragma unroll
         for (int q = 0; q < kPre; q++) {
-            // (n_passes == 0 — no string predicate at all — must not wrap: nothing is read then)
-            const uint32_t ps = min((uint32_t)q, max(a.n_passes, 1u) - 1);
-            const bool mine = (((lane < 32 ? bt.lo[q] : bt.hi[q]) >> (lane & 31)) & 1u) != 0;
-            in.rv[q] = (valid && mine && a.n_passes != 0) ? a.rec[(size_t)ps * a.n + i] : 0u;
+            uint32_t ps = kNone, base = kNone;
+            unsigned long long word = 0;
+#pragma unroll
+            for (int r = 0; r < kBitRegs; r++) {
+                if (ps == kNone && nz[r] != 0) {  // wave-uniform
+                    const int l = __builtin_ctzll(nz[r]);
+                    nz[r] &= nz[r] - 1;
+                    ps = (uint32_t)r * 64 + (uint32_t)l;
+                    word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(bt.w[r] >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bt.w[r], l);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
+                }
+            }
+            in.base[q] = base;
+            in.rv[q] = (ps != kNone && valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u;
         }
+#pragma unroll
+        for (int r = 0; r < kBitRegs; r++) in.rest[r] = nz[r];
+        in.bits = bt;
         in.flags = valid ? (uint32_t)a.flags[i] : 0u;
         const uint32_t gg = min(g, a.n_groups - 1);
         in.n_pairs = a.ghdr[gg];
@@ -1059,50 +1099,53 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         const uint32_t n_pairs = cur.n_pairs;
         const uint4 pair0 = cur.pair0;
 
-        // 2. scan results: each lane marks the columns its hit records name (passes beyond the prefetched kPre are fetched here,
-        //    kPre at a time: independent loads, one wait)
-        for (uint32_t pb = 0; pb < a.n_passes && !(dbg_skip & 1u); pb += kPre) {
-            uint32_t rv[kPre];
-#pragma unroll
-            for (int q = 0; q < kPre; q++) {
-                if (pb == 0) {
-                    rv[q] = cur.rv[q];
-                } else {
-                    const uint32_t ps = min(pb + (uint32_t)q, a.n_passes - 1);
-                    const uint32_t *bits = pass_bitmap(ps);
-                    const bool mine = bits == nullptr || ((bits[2 * g + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
-                    rv[q] = (valid && mine) ? a.rec[(size_t)ps * a.n + i] : 0u;
+        // 2. scan results: each lane marks the columns its hit records name
+        auto mark_hits = [&](const uint32_t rv, const uint32_t base) {
+            if (__ballot(rv != 0) == 0) return;  // nobody in the group matched anything in this pass
+            if (rv & REC_OVERFLOW) {
+                for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
+                    const PoolEntry pe = a.pool[k];
+                    set_col(base + pe.atom);
+                    k = pe.next;
                 }
             }
+            // inline atoms: lanes that name the SAME atom (frequent atoms such as a browser User-Agent prefix are named by
+            // most of the 64 requests) are folded into one column update instead of 64 serialised LDS atomics
 #pragma unroll
-            for (int q = 0; q < kPre; q++) {
-                if (pb + (uint32_t)q >= a.n_passes) break;
-                if (__ballot(rv[q] != 0) == 0) continue;  // nobody in the group matched anything in this pass
-                const uint32_t base = pb == 0 ? p_base[q] : a.passes[pb + q].base;
-                if (rv[q] & REC_OVERFLOW) {
-                    for (uint32_t k = rv[q] & ~REC_OVERFLOW; k != kNone;) {
-                        const PoolEntry pe = a.pool[k];
-                        set_col(base + pe.atom);
-                        k = pe.next;
+            for (int half = 0; half < 2; half++) {
+                const uint32_t x = (rv & REC_OVERFLOW) ? 0u : (half == 0 ? rv & 0x7FFFu : (rv >> 15) & 0x7FFFu);
+                unsigned long long todo = __ballot(x != 0);
+                while (todo) {
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                    const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)__builtin_amdgcn_readfirstlane(leader));
+                    const unsigned long long same = __ballot(x == xa);
+                    todo &= ~same;
+                    if (lane == leader) {
+                        const uint32_t c = base + xa - 1;
+                        atomicOr(&col[c], same);
+                        atomicOr(&colnz[c >> 5], 1u << (c & 31));
                     }
                 }
-                // inline atoms: lanes that name the SAME atom (frequent atoms such as a browser User-Agent prefix are named by
-                // most of the 64 requests) are folded into one column update instead of 64 serialised LDS atomics
+            }
+        };
+        if (!(dbg_skip & 1u)) {
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const uint32_t x = (rv[q] & REC_OVERFLOW) ? 0u : (half == 0 ? rv[q] & 0x7FFFu : (rv[q] >> 15) & 0x7FFFu);
-                    unsigned long long todo = __ballot(x != 0);
-                    while (todo) {
-                        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-                        const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)__builtin_amdgcn_readfirstlane(leader));
-                        const unsigned long long same = __ballot(x == xa);
-                        todo &= ~same;
-                        if (lane == leader) {
-                            const uint32_t c = base + xa - 1;
-                            atomicOr(&col[c], same);
-                            atomicOr(&colnz[c >> 5], 1u << (c & 31));
-                        }
-                    }
+            for (int q = 0; q < kPre; q++) {
+                if (cur.base[q] == kNone) break;
+                mark_hits(cur.rv[q], cur.base[q]);
+            }
+            // more than kPre non-empty passes in this group (many dense passes, or a burst of candidates): fetched here
+#pragma unroll
+            for (int r = 0; r < kBitRegs; r++) {
+                unsigned long long m = cur.rest[r];
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t ps = (uint32_t)r * 64 + (uint32_t)l;
+                    const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cur.bits.w[r] >> 32), l) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.bits.w[r], l);
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
+                    mark_hits((valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u, base);
                 }
             }
         }
@@ -1572,7 +1615,15 @@ VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, u
 int launch_verdict(const VerdictArgs &a, void *stream) {
     const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits);
     if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
-    const void *fn = sh.lds_tables ? reinterpret_cast<const void *>(verdict_kernel<true>) : reinterpret_cast<const void *>(verdict_kernel<false>);
+    constexpr int kBRmax = (kMaxPasses + 1 + 63) / 64;
+    int variant = a.n_passes <= 64 ? 1 : 0;
+#ifdef PWAF_PROFILING
+    static const int forced_variant = getenv("PWAF_VERDICT_VARIANT") ? atoi(getenv("PWAF_VERDICT_VARIANT")) : -1;  // a MORE general variant may be forced (same results)
+    if (forced_variant >= 0 && forced_variant < variant) variant = forced_variant;
+#endif
+    const void *fns[2][2] = {{reinterpret_cast<const void *>(verdict_kernel<false, kBRmax>), reinterpret_cast<const void *>(verdict_kernel<false, 1>)},
+                             {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax>), reinterpret_cast<const void *>(verdict_kernel<true, 1>)}};
+    const void *fn = fns[sh.lds_tables ? 1 : 0][variant];
     uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
 #ifdef PWAF_PROFILING
     static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;
@@ -1599,8 +1650,10 @@ int configure_kernels(int device) {
     const void *fns[] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
                          reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
-                         reinterpret_cast<const void *>(verdict_kernel<true>), reinterpret_cast<const void *>(verdict_kernel<false>),
-                         reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>)};
+                         reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64>),
+                         reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
+                         reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
+                         reinterpret_cast<const void *>(lscan_kernel)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
         if (e != hipSuccess) return (int)e;
