@@ -134,10 +134,10 @@ def main():
         """Launches that stream request bytes: filter_kernel (passes behind a bigram prefilter: arenas as flat byte streams) and
         scan_kernel (a DFA over every request). The engine reports each launch's algorithmic bytes — every byte of a streamed
         arena ONCE + its n+1 offsets. Returns {kernel: [ms, launches, bytes]} and the other kernels' ms."""
-        kinds = {"filter_kernel": [0.0, 0, 0], "scan_kernel": [0.0, 0, 0]}
+        kinds = {"filter_kernel<stride 1>": [0.0, 0, 0], "filter_kernel<stride 2>": [0.0, 0, 0], "scan_kernel": [0.0, 0, 0]}
         other = {}
         for name, ms, tag in kt:
-            key = "filter_kernel" if name == "filter" else "scan_kernel" if name.startswith("scan_") else None
+            key = {"filter_s1": "filter_kernel<stride 1>", "filter_s2": "filter_kernel<stride 2>"}.get(name, "scan_kernel" if name.startswith("scan_") else None)
             if key:
                 kinds[key][0] += ms
                 kinds[key][1] += 1
@@ -251,7 +251,8 @@ def main():
         if args.config == 3 and n == 10_000_000 and not args.adversarial and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                sk = [v for k, v in tj["kernels"].items() if "::" + dom in k]  # one entry per template instantiation
+                want = {"filter_kernel<stride 1>": ("::filter_kernel<", ", 1>"), "filter_kernel<stride 2>": ("::filter_kernel<", ", 2>"), "scan_kernel": ("::scan_kernel<", "")}[dom]
+                sk = [v for k, v in tj["kernels"].items() if want[0] in k and want[1] in k]  # one entry per template instantiation
                 traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
                 traffic_src = f"profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md; taken at commit {tj.get('commit', '?')})"
             except Exception:  # a malformed profile file must not break the bench line
@@ -276,8 +277,10 @@ def main():
                 "alg_bytes_per_request": dbatch.algorithmic_bytes / n,
                 "achieved": pipeline_alg / kernel_s / 1e9 if kernel_s > 0 else 0.0,
                 "frac": (pipeline_alg / kernel_s / 1e9 / HBM_PEAK_GBS) if kernel_s > 0 else 0.0,
-                "filter_ms_per_step": kinds["filter_kernel"][0] / args.steps,
-                "scan_ms_per_step": kinds["scan_kernel"][0] / args.steps,
+                "streaming_launches": {k: {"ms_per_step": v[0] / args.steps, "alg_bytes_per_step": v[2] // args.steps,
+                                           "achieved": (v[2] / (v[0] / 1e3) / 1e9) if v[0] > 0 else 0.0, "frac": (v[2] / (v[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if v[0] > 0 else 0.0}
+                                       for k, v in kinds.items() if v[1]},
+                "streaming_frac": (sum(v[2] for v in kinds.values()) / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if stream_ms > 0 else 0.0,
                 "verdict_ms_per_step": verdict_ms / args.steps,
                 "attr_ms_per_step_side_stream": attr_ms / args.steps,
                 "other_ms_per_step": {k: v / args.steps for k, v in other_ms.items()},

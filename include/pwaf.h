@@ -120,6 +120,8 @@ void pwaf_list_free(char **items, size_t n);
 #define PWAF_OPT_STRICT 8u            /* a rule the device compiler cannot take fails engine creation (default: that rule alone never
                                        * matches and reports why through pwaf_program_rule_status / the warnings) */
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
+#define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1
+                                       * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */
 typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;

@@ -1302,7 +1302,13 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // ---- bigram prefilters (filter.cpp): a pass whose patterns all have a literal factor only walks the filter's candidates ----
     for (auto &terms : rule_terms) for (auto &t : terms) for (uint32_t l : t) if (l & 1) P.atoms[l >> 1].neg_used = true;
     if (!(P.flags & PWAF_OPT_NO_PREFILTER))
-        for (auto &g : P.groups) build_group_filter(P.atoms, g, nullptr, g.filter);
+        for (auto &g : P.groups) {
+            if (P.flags & PWAF_OPT_FILTER_STRIDE2) {
+                build_group_filter(P.atoms, g, nullptr, g.filter, 2);
+                if (g.filter.enabled) continue;
+            }
+            build_group_filter(P.atoms, g, nullptr, g.filter, 1);
+        }
     // pass order: plain passes, then filtered ones, then the gated gap passes — the hit records of every list-driven pass are
     // then contiguous (one memset per batch)
     std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty() && !g.filter.enabled; });
@@ -1460,7 +1466,7 @@ std::vector<uint8_t> dump_program(const Program &p) {
         if (g.filter.enabled) {
             // bigram prefilter: [init, n_heads | hash multiplier << 16] + heads (20 bytes each), then the 4096-entry table
             std::vector<uint8_t> fh(8 + g.filter.heads.size() * sizeof(FilterHead));
-            const uint32_t hdr[2] = {g.filter.init, (uint32_t)g.filter.heads.size() | (g.filter.mul << 16)};
+            const uint32_t hdr[2] = {g.filter.init, (uint32_t)g.filter.heads.size() | (g.filter.stride << 8) | (g.filter.mul << 16)};
             memcpy(fh.data(), hdr, 8);
             if (!g.filter.heads.empty()) memcpy(fh.data() + 8, g.filter.heads.data(), g.filter.heads.size() * sizeof(FilterHead));
             w.section("GFHD", (uint32_t)gi, fh.data(), fh.size());

@@ -126,6 +126,9 @@ struct Scratch {
         if (!side) {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+#ifdef PWAF_PROFILING
+            if (getenv("PWAF_SIDE_PRIORITY_HIGH")) least = greatest;  // timing experiment
+#endif
             if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess)
                 return fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
@@ -613,6 +616,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     {
         static const uint32_t skip = getenv("PWAF_DEBUG_SKIP") ? (uint32_t)strtoul(getenv("PWAF_DEBUG_SKIP"), nullptr, 0) : 0u;
         v.debug_skip = skip;  // timing experiments only: results are wrong when non-zero
+        static const bool attr_prio = getenv("PWAF_ATTR_PRIO") != nullptr;
+        if (attr_prio) v.debug_skip |= 0x80000000u;
     }
 #endif
     for (int f = 0; f < PWAF_N_FIELDS; f++) v.off[f] = db.field[f].offsets;
@@ -795,15 +800,19 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
         FilterBatchArgs fb{};
         uint32_t fi = 0, block = 0;
-        uint64_t alg_bytes = 0;
+        uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
         uint64_t sub_at = 0, cnt_at = 0;
         auto flush_filters = [&]() -> int {
             if (fb.count == 0) return PWAF_OK;
             int rc2;
-            if ((rc2 = mark(nullptr, 0))) return rc2;
-            int he = launch_filter(fb, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc2 = mark("filter", alg_bytes))) return rc2;  // algorithmic bytes: every streamed arena once + its offsets
+            int he = 0;
+            for (uint32_t stride = 1; stride <= 2; stride++) {
+                if (!alg_bytes[stride]) continue;
+                if ((rc2 = mark(nullptr, 0))) return rc2;
+                he = launch_filter(fb, stride, stream);
+                if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+                if ((rc2 = mark(stride == 1 ? "filter_s1" : "filter_s2", alg_bytes[stride]))) return rc2;  // algorithmic bytes: every streamed arena once + its offsets
+            }
             if ((rc2 = mark(nullptr, 0))) return rc2;
             he = launch_resolve(fb, stream);
             if (!he) he = launch_compact(fb, stream);
@@ -811,7 +820,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             if ((rc2 = mark("resolve+compact", 0xFCu))) return rc2;
             fb.count = 0;
             block = 0;
-            alg_bytes = 0;
+            alg_bytes[1] = alg_bytes[2] = 0;
             return PWAF_OK;
         };
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
@@ -825,6 +834,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.total = totals[d.field];
             f.init = d.filter.init;
             f.mul = d.filter.mul;
+            f.stride = d.filter.stride;
             f.table = (const uint32_t *)d.ftable.p;
             f.n_heads = (uint32_t)std::min<size_t>(2, d.filter.heads.size());
             for (uint32_t h = 0; h < f.n_heads; h++) {
@@ -850,7 +860,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
             cnt_at += slabs + n_cblocks;
             block += (slabs + kFilterWaves - 1) / kFilterWaves;
-            alg_bytes += (uint64_t)f.total + 4ull * (n + 1);
+            alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
             if (fb.count == kMaxFiltersPerLaunch && (rc = flush_filters())) return rc;
         }
@@ -1527,6 +1537,24 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;
             e->mean_len[f] = mean_len[f];
         }
+        // (the device samples the bigrams of a stride-2 pass at the even bytes of the ARENA: a field's phase is its offset's parity)
+        auto flagged = [&](const GroupFilter &f, const pwaf_strcol *sc, uint32_t i) {
+            const uint32_t *off = sc->offsets;
+            return filter_candidate_host(f, sc->data + off[i], off[i + 1] - off[i], f.stride == 2 ? (off[i] & 1u) : 0u);
+        };
+        auto sample_rate = [&](const GroupFilter &f, const pwaf_strcol *sc) {
+            uint64_t c = 0;
+            for (uint32_t i = 0; i < n; i++) c += flagged(f, sc, i) ? 1u : 0u;
+            return (double)c / (double)n;
+        };
+        // Stride 2 halves the table lookups per byte. A pass may take it when its factors stay selective with two to four sampled
+        // bigrams per alignment: at most two points more of the sample flagged than at stride 1 (a candidate costs about ten times
+        // a filtered byte), never above 25 %. But the passes of each stride are one launch, and on long arenas the stride-2 kernel
+        // streams no faster per byte than stride 1 (measured on MI355X: both ~3.2 TB/s — the bound they share is not the lookup),
+        // while short header columns do gain: it is taken only when the passes that may take it hold most of the filtered bytes,
+        // so that the launch is not split in two for nothing. PWAF_OPT_FILTER_STRIDE2 takes it wherever it can be built.
+        std::vector<GroupFilter> alt(P.groups.size());
+        double bytes_all = 0, bytes_alt = 0;
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];
             FilterHints h;
@@ -1537,14 +1565,35 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             GroupFilter &gf = e->groups[k].filter;
             const pwaf_strcol *sc = sample_col(g.field);
             if (!sc) continue;
-            build_group_filter(P.atoms, g, &h, gf);
+            build_group_filter(P.atoms, g, &h, gf, 1);
             if (!gf.enabled) continue;
+            gf.est_candidate_rate = sample_rate(gf, sc);
+            bytes_all += mean_len[g.field];
+            GroupFilter &g2 = alt[k];
+            build_group_filter(P.atoms, g, &h, g2, 2);
+#ifdef PWAF_PROFILING
+            static const long s2_mask = getenv("PWAF_STRIDE2_FIELDS") ? strtol(getenv("PWAF_STRIDE2_FIELDS"), nullptr, 0) : -1;  // timing experiments: fields that may take stride 2
+            if (!((s2_mask >> g.field) & 1)) g2.enabled = false;
+#endif
+            if (!g2.enabled) continue;
+            g2.est_candidate_rate = sample_rate(g2, sc);
+            const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
+            g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);
+            if (g2.enabled) bytes_alt += mean_len[g.field];
+        }
+        bool take_alt = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0 || bytes_alt >= 0.8 * bytes_all;
+#ifdef PWAF_PROFILING
+        if (getenv("PWAF_STRIDE2_FIELDS")) take_alt = true;
+#endif
+        for (size_t k = 0; k < P.groups.size(); k++) {
+            const DfaGroup &g = P.groups[k];
+            GroupFilter &gf = e->groups[k].filter;
+            const pwaf_strcol *sc = sample_col(g.field);
+            if (!sc || !gf.enabled) continue;
+            if (take_alt && alt[k].enabled) gf = alt[k];
             const uint8_t *data = sc->data;
             const uint32_t *off = sc->offsets;
-            uint64_t cand = 0;
-            for (uint32_t i = 0; i < n; i++) cand += filter_candidate_host(gf, data + off[i], off[i + 1] - off[i]) ? 1u : 0u;
-            gf.est_candidate_rate = (double)cand / (double)n;
-            if (cand * 10 > (uint64_t)n * 4) {
+            if (gf.est_candidate_rate > 0.4) {
                 gf.enabled = false;
                 gf.note = "the filter flags more than 40 % of the sample";
                 continue;
@@ -1554,7 +1603,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             std::vector<uint64_t> &v = visits[k];
             std::fill(v.begin(), v.end(), 0);
             for (uint32_t i = 0; i < n; i++) {
-                if (!filter_candidate_host(gf, data + off[i], off[i + 1] - off[i])) continue;
+                if (!flagged(gf, sc, i)) continue;
                 uint32_t st = 0;
                 for (uint32_t p = off[i]; p < off[i + 1]; p++) {
                     st = g.trans[(size_t)st * g.n_classes + g.classmap[data[p]]];

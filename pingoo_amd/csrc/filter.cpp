@@ -52,6 +52,7 @@ static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return (uint32_t)(a & 0
 
 struct Model {
     const double *pairw;  // 65536 probabilities of the case-folded bigrams
+    size_t stride;        // sampling stride of the filter being built
     // the distinct folded pairs of two byte sets
     static void pairs_of(const ByteSet &a, const ByteSet &b, std::vector<uint16_t> &out) {
         std::set<uint32_t> ps;
@@ -75,7 +76,7 @@ struct Model {
     // internal offset of its first bigram and the bigram count (0 = the factor is too short for this alignment).
     double best_window(const CStr &s, size_t a, size_t &start, size_t &k) {
         std::vector<size_t> pos;
-        for (size_t j = a; j + 1 < s.size(); j += kFilterStride) pos.push_back(j);
+        for (size_t j = a; j + 1 < s.size(); j += stride) pos.push_back(j);
         k = std::min<size_t>(4, pos.size());
         start = 0;
         if (k == 0) return INFINITY;
@@ -94,8 +95,8 @@ struct Model {
         if (!c.ok || c.s.empty()) return INFINITY;
         double t = 0;
         for (auto &s : c.s) {
-            if (s.size() < 1 + kFilterStride) return INFINITY;
-            for (size_t a = 0; a < kFilterStride; a++) {
+            if (s.size() < 1 + stride) return INFINITY;
+            for (size_t a = 0; a < stride; a++) {
                 size_t st, k;
                 t += best_window(s, a, st, k);
             }
@@ -275,8 +276,9 @@ struct Window {
 
 }  // namespace
 
-void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out) {
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride) {
     out = GroupFilter();
+    out.stride = stride;
     std::vector<double> prior;
     const double *pairw0 = hints ? hints->pair_prob : nullptr;
     if (!pairw0) {
@@ -287,7 +289,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     // smoothed: a bigram the sample never showed is still possible
     std::vector<double> pw(65536);
     for (uint32_t x = 0; x < 65536; x++) pw[x] = pairw0[x] * 0.98 + 0.02 / 65536;
-    Model m{pw.data()};
+    Model m{pw.data(), stride};
 
     if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
     if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
@@ -344,19 +346,19 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         f = better(m, f, x.P);
         f = better(m, f, x.S);
         if (!std::isfinite(m.score(f))) {
-            out.note = "pattern without a literal factor of " + std::to_string(1 + kFilterStride) + " or more bytes: " + at.key.substr(0, 80);
+            out.note = "pattern without a literal factor of " +  std::to_string(1 + stride) + " or more bytes: " + at.key.substr(0, 80);
             out.heads.clear();
             return;
         }
         for (auto &s : f.s)
-            for (size_t al = 0; al < kFilterStride; al++) {
+            for (size_t al = 0; al < stride; al++) {
                 size_t st, k;
                 Window wd;
                 wd.cost = m.best_window(s, al, st, k);
                 wd.k = k;
                 std::string key = std::to_string(k) + ":";
                 for (size_t j = 0; j < k; j++) {
-                    const size_t at = st + j * kFilterStride;
+                    const size_t at = st + j * stride;
                     Model::pairs_of(s[at], s[at + 1], wd.pairs[j]);
                     for (uint16_t pr : wd.pairs[j]) key += std::to_string(pr) + ",";
                     key += ";";
@@ -440,14 +442,14 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             }
         }
     }
-    const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / kFilterStride;
+    const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / stride;
     out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, best_fp)), len);
     out.enabled = true;
 }
 
-bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
+bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase) {
     uint32_t st = f.init;
-    for (size_t i = 0; i + 1 < n; i += kFilterStride) {
+    for (size_t i = phase; i + 1 < n; i += f.stride) {
         st = (st << 8) | f.table[filter_bin(bytes[i], bytes[i + 1], f.mul)];
         if ((~st) & 0xFF000000u) return true;
     }

@@ -129,6 +129,7 @@ struct FilterArgs {
     uint32_t slab0;           // first slab to stream (a slab view of a larger arena starts at off[0]: the bytes before it are not the batch's)
     uint32_t init;            // state of a stream with no history
     uint32_t mul;             // multiplier of the bigram hash (GroupFilter::mul)
+    uint32_t stride;          // 1: a bigram at every byte; 2: at the even bytes of the arena stream (GroupFilter::stride)
     const uint32_t *table;    // kFilterEntries masks
     uint32_t n_heads;
     uint32_t head_w[2][4];    // head literal, little-endian dwords
@@ -148,7 +149,7 @@ struct FilterBatchArgs {
     FilterArgs f[kMaxFiltersPerLaunch];
     uint32_t count;
 };
-int launch_filter(const FilterBatchArgs &b, void *stream);
+int launch_filter(const FilterBatchArgs &b, uint32_t stride, void *stream);  // the passes of `b` whose stride is `stride`, in one launch
 int launch_resolve(const FilterBatchArgs &b, void *stream);
 int launch_compact(const FilterBatchArgs &b, void *stream);  // bitcount_kernel, then compact_kernel
 // Sets the dynamic-LDS limit of every kernel on the CURRENT device (once per device and process; engines on several

@@ -550,31 +550,15 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct Segment {
     u32x4 w[4];
-    uint32_t prev, next;
+    uint32_t prev, extra;  // extra: the dword after the segment (STRIDE 1) or the one before `prev` (STRIDE 2)
 };
 
-template <bool HEADS>
-__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchArgs B) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    __builtin_amdgcn_s_setprio(3);
-    // which pass of the fused launch this workgroup belongs to (uniform: kernel arguments only)
-    uint32_t k = 0;
-    while (k + 1 < B.count && blockIdx.x >= B.f[k + 1].first_block) k++;
-    const FilterArgs &a = B.f[k];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // (Bank-private replicas of the table — 4 copies, each lane group of 8 with 8 banks of its own — were measured SLOWER: 1.19 ms
-    // against 0.89 ms. A ds_read_b32 takes as many cycles as its most loaded bank over all 32 lanes, and the maximum over four
-    // groups of 8-in-8 is hardly below 32-in-32, while 64 KiB per workgroup halves the occupancy.)
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        for (uint32_t i = tid; i < kFilterEntries / 4; i += kFilterWaves * 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
-    if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
+// STRIDE = 1: a bigram at every byte. STRIDE = 2: only at the even bytes of the arena stream (FilterArgs::stride, chosen per pass
+// by the host: half the lookups; every factor is in the table once per alignment).
+template <bool HEADS, int STRIDE>
+__device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_t blk, const uint32_t wave, const uint32_t lane) {
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const uint32_t rel = (blockIdx.x - a.first_block) * kFilterWaves + wave, slab = a.slab0 + rel;  // rel: index into the pass's sub-lists
+    const uint32_t rel = blk * kFilterWaves + wave, slab = a.slab0 + rel;  // rel: index into the pass's sub-lists
     const uint64_t base64 = (uint64_t)slab * kStreamSlab;
     if (base64 >= a.total) return;
     const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
@@ -593,7 +577,8 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
             sg.w[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
         }
         sg.prev = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p >= 4 && p < total) ? p - 4 : 0u));
-        sg.next = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p + kStreamSeg + 4 <= total + PWAF_ARENA_PAD) ? p + kStreamSeg : 0u));
+        if (STRIDE == 2) sg.extra = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p >= 8 && p < total) ? p - 8 : 0u));
+        else sg.extra = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p + kStreamSeg + 4 <= total + PWAF_ARENA_PAD) ? p + kStreamSeg : 0u));
     };
 
     // heads: the wave walks the offsets column alongside the bytes; rq = first request that starts at or after the current byte
@@ -624,7 +609,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
             d[1 + 4 * q + 2] = cur.w[q].z & 0xDFDFDFDFu;
             d[1 + 4 * q + 3] = cur.w[q].w & 0xDFDFDFDFu;
         }
-        d[17] = cur.next & 0xDFDFDFDFu;
+        d[17] = STRIDE == 2 ? 0u : cur.extra & 0xDFDFDFDFu;
         auto lookups = [&](const int i, uint32_t (&mm)[4]) {  // the four bigrams that start in dword i (the last one ends in dword i + 1)
             const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
             const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
@@ -635,34 +620,63 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
             mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
             mm[3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 18) & 0x3FFCu));
         };
-        // three warm-up bigrams from the four bytes before the segment (none at the very start of the arena), then 64 positions,
+        auto lookups2 = [&](const uint32_t x, uint32_t (&mm)[2]) {  // the two bigrams at the even bytes of (case-folded) dword x
+            const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
+            mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
+            mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
+        };
+        // three warm-up bigrams from the bytes before the segment (none at the very start of the arena), then the segment's positions,
         // one 16-byte chunk at a time (the scheduling barriers keep at most one chunk's lookups live: without them the compiler
         // hoists all 67 and the kernel drops to 4 waves per SIMD)
         uint32_t st = a.init;
-        {
+        if (STRIDE == 1) {
             uint32_t mw[4];
             lookups(0, mw);
             if (p >= 4) {
 #pragma unroll
                 for (int i = 1; i < 4; i++) asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(mw[i]));
             }
+        } else {
+            uint32_t m0[2], m1[2];
+            lookups2(cur.extra & 0xDFDFDFDFu, m0);  // bytes p - 8 .. p - 5: its second bigram (p - 6) is the oldest of the three
+            lookups2(d[0], m1);                     // bytes p - 4 .. p - 1
+            if (p >= 8) {
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m0[1]));
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m1[0]));
+                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m1[1]));
+            }
         }
         uint32_t hmask = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t m[16];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t mm[4];
-                lookups(1 + 4 * q + i, mm);
-                m[4 * i + 0] = mm[0]; m[4 * i + 1] = mm[1]; m[4 * i + 2] = mm[2]; m[4 * i + 3] = mm[3];
-            }
             uint32_t seen = 0xFFFFFFFFu;
+            if (STRIDE == 1) {
+                uint32_t m[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                // st = (st << 8) | m as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
-                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
-                seen &= st;
+                for (int i = 0; i < 4; i++) {
+                    uint32_t mm[4];
+                    lookups(1 + 4 * q + i, mm);
+                    m[4 * i + 0] = mm[0]; m[4 * i + 1] = mm[1]; m[4 * i + 2] = mm[2]; m[4 * i + 3] = mm[3];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    // st = (st << 8) | m as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
+                    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
+                    seen &= st;
+                }
+            } else {
+                uint32_t m[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint32_t mm[2];
+                    lookups2(d[1 + 4 * q + i], mm);
+                    m[2 * i + 0] = mm[0]; m[2 * i + 1] = mm[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
+                    seen &= st;
+                }
             }
             if (((~seen) & 0xFF000000u) != 0 && p + 16u * (uint32_t)q < total) hmask |= 1u << q;
             __builtin_amdgcn_sched_barrier(0);
@@ -707,8 +721,34 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
     if (lane == 0) a.sub_count[rel] = n_hit;
 }
 
-// resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the three
-// bytes a window may reach back and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
+// (One kernel per stride: both bodies behind a branch in one kernel cost 65 VGPRs — 7 waves per SIMD — against 63 and 54 apart.)
+template <bool HEADS, int STRIDE>
+__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchArgs B) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    __builtin_amdgcn_s_setprio(3);
+    // which pass of the fused launch this workgroup belongs to (uniform: kernel arguments only)
+    uint32_t k = 0;
+    while (k + 1 < B.count && blockIdx.x >= B.f[k + 1].first_block) k++;
+    const FilterArgs &a = B.f[k];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (Bank-private replicas of the table — 4 copies, each lane group of 8 with 8 banks of its own — were measured SLOWER: 1.19 ms
+    // against 0.89 ms. A ds_read_b32 takes as many cycles as its most loaded bank over all 32 lanes, and the maximum over four
+    // groups of 8-in-8 is hardly below 32-in-32, while 64 KiB per workgroup halves the occupancy.)
+    // (Starting every wave at a different iteration of its slab — in case waves advancing in step from offset 0 of their 128 KiB
+    // slabs camp on a few HBM channels — changed nothing: 0.868 against 0.874 ms.)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (uint32_t i = tid; i < kFilterEntries / 4; i += kFilterWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
+    if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
+    filter_stream<HEADS, STRIDE>(a, blockIdx.x - a.first_block, wave, lane);
+}
+
+// resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the bytes a
+// window may reach back — three sampled bigrams — and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
 __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
     __builtin_amdgcn_s_setprio(3);
     const FilterArgs &a = B.f[blockIdx.y];
@@ -720,7 +760,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
         const uint32_t e = sub[i], hmask = e & 15u;
         const uint32_t p = slab * kStreamSlab + (e >> 4) * kStreamSeg;
         const uint32_t first = (uint32_t)__builtin_ctz(hmask), last = 31u - (uint32_t)__builtin_clz(hmask);
-        const uint32_t lo_b = p + 16u * first, c0 = lo_b >= 3 ? lo_b - 3 : 0u, c1 = p + 16u * last + 16u;  // bytes [c0, c1] may belong to a completed window
+        const uint32_t back = 3u * a.stride;  // a window reaches back three sampled bigrams from the one that completed it
+        const uint32_t lo_b = p + 16u * first, c0 = lo_b >= back ? lo_b - back : 0u, c1 = p + 16u * last + 16u;  // bytes [c0, c1] may belong to a completed window
         // first request with off[r + 1] > c0
         uint32_t lo = 0, hi = a.n;
         while (lo < hi) {
@@ -798,19 +839,24 @@ __global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
     if (blockIdx.x == n_blocks - 1 && tid == 255) *a.list_count = base + red[255];
 }
 
-int launch_filter(const FilterBatchArgs &b, void *stream) {
-    if (b.count == 0) return 0;
-    uint32_t blocks = 0, max_slabs = 0;
+int launch_filter(const FilterBatchArgs &b, uint32_t stride, void *stream) {
+    // one fused launch per sampling stride in use (the passes of a stride keep their own sub-lists: only first_block is renumbered)
+    FilterBatchArgs sub{};
+    uint32_t blocks = 0;
     bool heads = false;
     for (uint32_t k = 0; k < b.count; k++) {
+        if (b.f[k].stride != stride) continue;
         const uint32_t slabs = (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab) - b.f[k].slab0;
+        FilterArgs &f = sub.f[sub.count++];
+        f = b.f[k];
+        f.first_block = blocks;
         blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
-        max_slabs = max(max_slabs, slabs);
-        heads = heads || b.f[k].n_heads != 0;
+        heads = heads || f.n_heads != 0;
     }
     if (blocks == 0) return 0;
-    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    const void *fn = heads ? reinterpret_cast<const void *>(filter_kernel<true>) : reinterpret_cast<const void *>(filter_kernel<false>);
+    void *args[] = {&sub};
+    const void *fn = stride == 2 ? (heads ? reinterpret_cast<const void *>(filter_kernel<true, 2>) : reinterpret_cast<const void *>(filter_kernel<false, 2>))
+                                 : (heads ? reinterpret_cast<const void *>(filter_kernel<true, 1>) : reinterpret_cast<const void *>(filter_kernel<false, 1>));
     hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
@@ -1346,6 +1392,9 @@ struct AttrIn {
 };
 
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
+#ifdef PWAF_PROFILING
+    if (a.debug_skip & 0x80000000u) __builtin_amdgcn_s_setprio(3);  // timing experiment
+#endif
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
@@ -1652,7 +1701,8 @@ int configure_kernels(int device) {
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
                          reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64>),
                          reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
-                         reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
+                         reinterpret_cast<const void *>(filter_kernel<true, 1>), reinterpret_cast<const void *>(filter_kernel<false, 1>),
+                         reinterpret_cast<const void *>(filter_kernel<true, 2>), reinterpret_cast<const void *>(filter_kernel<false, 2>),
                          reinterpret_cast<const void *>(lscan_kernel)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);

@@ -87,11 +87,13 @@ struct Atom {
 // through the pass's DFA, which decides exactly. The filter is conservative by construction (a factor is necessary for
 // a match; extra positions past a field's end can only add candidates), so verdicts never depend on it.
 static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
-// Bigrams are sampled at every kFilterStride-th byte of a field (counted from its first byte); a factor is entered once per
-// alignment it can have relative to the sampling grid. Stride 2 halves the lookups per input byte (the filter kernel is bound by
-// LDS gathers: 6.3 LDS cycles per wave lookup, two thirds of them bank conflicts) at the price of windows that span up to 8 bytes:
-// factors shorter than 3 bytes cannot be filtered and 3-4 byte factors contribute a single position.
-static constexpr uint32_t kFilterStride = 1;  // (2 was tried: a 3-byte factor such as "../" then owns a single position and floods the candidates)
+// Bigrams are sampled at every stride-th byte of the arena stream; a factor is entered once per alignment it can have relative to
+// the sampling grid. Stride 2 halves the lookups per input byte (the filter kernel is bound by LDS gathers: ~8 LDS cycles per wave
+// lookup, three quarters of them bank conflicts) at the price of windows that span up to 8 bytes: factors shorter than 3 bytes
+// cannot be filtered and 3-4 byte factors contribute a single position.
+// GroupFilter::stride: 1, or 2 for a pass whose factors are long enough (host names, paths, User-Agent tokens) that two to four
+// sampled bigrams per alignment stay selective — half the table lookups per byte. (Stride 2 for EVERY pass was tried first: a 3-byte
+// factor such as "../" then owns a single sampled position and floods the candidates. pwaf_engine_tune decides per pass from the sample.)
 static constexpr uint32_t kFilterMul = 0x9E37u;  // default 16-bit multiplier of the bigram hash (v_pk_mul_lo_u16 on the device); a pass picks its own from a
                                                  // few candidates so that its factor windows avoid the bins frequent bigrams fall into (GroupFilter::mul)
 static inline uint32_t filter_bin(uint8_t b0, uint8_t b1, uint32_t mul = kFilterMul) {
@@ -114,6 +116,7 @@ struct GroupFilter {
     std::vector<uint32_t> table;  // kFilterEntries masks: bit 8*j + b = 0 <=> bucket b accepts the bin at window position j
     uint32_t init = 0xFFFFFFFFu;  // state at the start of a field (zero at a bucket's wildcard positions)
     uint32_t mul = kFilterMul;    // multiplier of the bigram hash chosen for this pass
+    uint32_t stride = 1;          // bigrams are sampled at every stride-th byte of the arena stream (1 or 2); factors are entered once per alignment
     std::vector<FilterHead> heads;
     double est_candidate_rate = 0;  // expected fraction of requests flagged by chance (model or sample)
     std::string note;               // why the pass is not filtered, for stats / warnings
@@ -266,10 +269,10 @@ void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector
 
 // Builds the bigram prefilter of pass `g` (filter.cpp). `atoms` = Program::atoms. Leaves filter.enabled false (with a note)
 // when some pattern has no usable literal factor.
-void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out);
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride = 1);
 // Host model of the filter kernel over one field value: true = candidate. (Used by tune to measure the candidate rate on the
 // sample; the device may flag MORE requests — it also looks at the bytes just past a field's end — never fewer.)
-bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n);
+bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase = 0);  // phase: offset of the first sampled byte (< stride)
 // Which heads hold for the field value: bit k = heads[k].
 uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n);
 

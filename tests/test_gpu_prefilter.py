@@ -161,3 +161,22 @@ def test_config5_4096_rules_64_header_fields_benign_and_adversarial():
     assert counts.tolist() == np.bincount(want_h["action"], minlength=4).tolist()
     assert np.count_nonzero(want_h["action"]) > 0
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_stride_two_filters_on_the_device(seed):
+    """filter_kernel<., 2> (bigrams at the even bytes of the arena stream; fields start at either parity): forced through
+    PWAF_OPT_FILTER_STRIDE2, then chosen per pass by tune; verdicts against the oracle, boundaries included."""
+    rng = random.Random(9900 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 60))
+    eng = RuleEngine(rules, {}, flags=_abi.OPT_FILTER_STRIDE2)
+    n = rng.choice([65, 500, 2049, 6000])
+    reqs = H.lit_requests(rng, n)
+    for k in range(0, 40):  # factors at every offset around the 16 / 64-byte chunking
+        reqs.append(Request(url="q" * k + reqs[k % n].url, path="/" + "p" * k + reqs[(k + 1) % n].path, user_agent="u" * k + reqs[(k + 2) % n].user_agent, host=reqs[k % n].host))
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, stride 2")
+    eng.tune(RequestBatch.from_requests(H.lit_requests(rng, 400)))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, stride 2, tuned")
+    eng.close()

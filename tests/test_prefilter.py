@@ -75,3 +75,41 @@ def test_synthetic_config3_filters_and_candidate_rates():
         if "f_table" in g:
             rate = np.mean([t.filter_candidate(g, b.field_bytes(g["field"], i)) for i in range(b.n)])
             assert rate < 0.12, (g["field"], rate)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_stride_two_filters_have_no_false_negatives_at_either_phase(seed):
+    """PWAF_OPT_FILTER_STRIDE2: bigrams sampled at every second byte of the arena stream, every factor entered once per alignment.
+    A field may start at an even or an odd arena offset: the walker samples from byte 0 and from byte 1, and in both cases a request
+    the filter does not flag may only match head atoms; the filtered pipeline agrees with the oracle."""
+    rng = random.Random(9900 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 40))
+    prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2)
+    t = table_walker.Tables(prog.dump())
+    strides = {g["f_stride"] for g in t.groups if "f_table" in g}
+    batch = RequestBatch.from_requests(H.lit_requests(rng, 200))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    for phase in (0, 1):
+        t.filter_phase = phase
+        for i in range(batch.n):
+            assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, phase, i, [batch.field_bytes(f, i) for f in range(5)])
+        for g in t.groups:
+            if "f_table" not in g:
+                continue
+            heads = {local for _, _, local in g["f_heads"]}
+            for i in range(batch.n):
+                data = batch.field_bytes(g["field"], i, t.header_names)
+                if not t.filter_candidate(g, data):
+                    cols = set()
+                    t.scan_field(g, data, cols)
+                    assert {c - g["atom_base"] for c in cols} <= heads, (seed, phase, data)
+    assert strides <= {1, 2}
+
+
+def test_stride_two_is_taken_where_the_factors_allow_it():
+    rules = [("ua", 'http_request.user_agent.contains("sqlmap") || http_request.user_agent.contains("nikto/2")', [H.B]), ("p", 'http_request.path.contains("../")', [H.B])]
+    t = table_walker.Tables(CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2).dump())
+    by_field = {g["field"]: g["f_stride"] for g in t.groups if "f_table" in g}
+    assert by_field[4] == 2 and by_field[2] == 2  # ("../" still has one sampled bigram per alignment)
+    t1 = table_walker.Tables(CompiledProgram(rules, {}).dump())
+    assert {g["f_stride"] for g in t1.groups if "f_table" in g} == {1}

@@ -10,10 +10,10 @@ from pingoo_amd.engine import CompiledProgram
 from synth import pysynth
 import table_walker
 
-STRIDE = 1
 
 
 def candidates(g, data, off):
+    STRIDE = int(g.get("f_stride", 1))
     """numpy model of filter_kernel over one field arena (bigrams sampled every STRIDE bytes from each field's start): bool per request"""
     d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
     p = d[:-1] | (d[1:] << 8)
@@ -27,8 +27,8 @@ def candidates(g, data, off):
     if len(start) < L:
         start = np.concatenate([start, np.full(L - len(start), off[-1])])
         endb = np.concatenate([endb, np.full(L - len(endb), off[-1])])
-    t = (pos - start) // STRIDE  # sampled step index inside the field
-    sampled = ((pos - start) % STRIDE == 0) & ((pos + 1) < endb)
+    t = (pos - start + (start % STRIDE)) // STRIDE  # sampled step index inside the field (grid: even arena offsets at stride 2)
+    sampled = (pos % STRIDE == 0) & ((pos + 1) < endb)
     init = int(g["f_init"])
     top = (m >> 24) & 0xFF
     for j in range(1, 4):
@@ -49,13 +49,13 @@ def main():
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     wl = pysynth.Workload(cfg)
-    prog = CompiledProgram(wl.rules, wl.lists, wl.geoip)
+    prog = CompiledProgram(wl.rules, wl.lists, wl.geoip, flags=16 if '--stride2' in sys.argv else 0)
     print(prog.stats())
     t = table_walker.Tables(prog.dump())
     b = wl.batch(0, n)
     names = ["host", "url", "path", "method", "user_agent"]
     for gi, g in enumerate(t.groups):
-        line = f"group {gi} field {names[g['field']]:<10} states {g['n_states']:>6} classes {g['n_classes']:>3} atoms {g['n_local']:>4}"
+        line = f"group {gi} field {names[g['field']] if g['field'] < 5 else 'hdr' + str(g['field'] - 5):<10} stride {g.get('f_stride', '-')} states {g['n_states']:>6} classes {g['n_classes']:>3} atoms {g['n_local']:>4}"
         if "f_table" in g:
             data, off = b.data[g["field"]], b.offsets[g["field"]].astype(np.int64)
             c = candidates(g, np.concatenate([data, np.zeros(8, np.uint8)]), off)
