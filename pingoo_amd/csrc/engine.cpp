@@ -667,23 +667,36 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.counts = (unsigned long long *)d_counts;
     v.match_idx = d_match_idx;
     v.n_matches = d_n_matches;
-    // The attribute kernel (GeoIP / ip-list / integer-set lookups: dependent gathers, latency-bound) does not depend on the scans
-    // (LDS / issue-bound), so it runs beside them on the engine's side stream and joins before the verdict kernel.
-    HIP_TRY(hipEventRecord(S.ev_fork, stream));
-    HIP_TRY(hipStreamWaitEvent(S.side, S.ev_fork, 0));
-    if ((rc = mark(nullptr, 0, S.side))) return rc;
-    {
+    // The attribute kernel (GeoIP / ip-list / integer-set lookups: ~1.2 GB of gathers per 10M requests) does not depend on the scans:
+    // it runs on the context's side stream and joins before the verdict kernel. WHERE it forks matters: beside the prefilter launch
+    // the two compete for the memory system (measured: the filter 0.76 -> 1.0 ms, the attribute kernel 0.44 -> 1.2 ms), so it forks
+    // AFTER the filter launches and runs beside resolve / compact / the list scans, which are short latency-bound kernels that leave
+    // most of the machine idle.
+    bool attr_launched = false;
+    auto launch_attr_side = [&]() -> int {
+        if (attr_launched) return PWAF_OK;
+        attr_launched = true;
+        int rc2;
+        HIP_TRY(hipEventRecord(S.ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(S.side, S.ev_fork, 0));
+        if ((rc2 = mark(nullptr, 0, S.side))) return rc2;
+        {
 #ifdef PWAF_PROFILING
-        static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
-        if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, S.side));
-        int he = skip_attr ? 0 : launch_attr(v, S.side);
+            static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
+            if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, S.side));
+            int he = skip_attr ? 0 : launch_attr(v, S.side);
 #else
-        int he = launch_attr(v, S.side);
+            int he = launch_attr(v, S.side);
 #endif
-        if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-    }
-    if ((rc = mark("attr", 0xFEu, S.side))) return rc;
-    HIP_TRY(hipEventRecord(S.ev_join, S.side));
+            if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        }
+        if ((rc2 = mark("attr", 0xFEu, S.side))) return rc2;
+        HIP_TRY(hipEventRecord(S.ev_join, S.side));
+        return PWAF_OK;
+    };
+#ifdef PWAF_PROFILING
+    if (getenv("PWAF_ATTR_EARLY") && (rc = launch_attr_side())) return rc;  // timing experiment: fork at the start of the batch
+#endif
 
     static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
     auto scan_args = [&](size_t gi) -> ScanArgs {
@@ -813,6 +826,11 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
                 if ((rc2 = mark(stride == 1 ? "filter_s1" : "filter_s2", alg_bytes[stride]))) return rc2;  // algorithmic bytes: every streamed arena once + its offsets
             }
+#ifdef PWAF_PROFILING
+            static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
+            if (!attr_after_compact)
+#endif
+            if ((rc2 = launch_attr_side())) return rc2;
             if ((rc2 = mark(nullptr, 0))) return rc2;
             he = launch_resolve(fb, stream);
             if (!he) he = launch_compact(fb, stream);
@@ -835,6 +853,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.init = d.filter.init;
             f.mul = d.filter.mul;
             f.stride = d.filter.stride;
+#ifdef PWAF_PROFILING
+            static const uint32_t fdebug = getenv("PWAF_FILTER_DEBUG_SKIP") ? (uint32_t)atoi(getenv("PWAF_FILTER_DEBUG_SKIP")) : 0u;
+            f.debug = fdebug;
+#endif
             f.table = (const uint32_t *)d.ftable.p;
             f.n_heads = (uint32_t)std::min<size_t>(2, d.filter.heads.size());
             for (uint32_t h = 0; h < f.n_heads; h++) {
@@ -866,6 +888,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         }
         if ((rc = flush_filters())) return rc;
     }
+    if ((rc = launch_attr_side())) return rc;  // (no filtered pass: beside the list scans / the verdict kernel's predecessors)
     // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
     GatedArgs gb{};
     auto flush_gated = [&]() -> int {

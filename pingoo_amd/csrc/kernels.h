@@ -144,6 +144,7 @@ struct FilterArgs {
     uint32_t *list;           // n: dense candidate list
     uint32_t *list_count;     // its length
     uint32_t first_block;     // first workgroup of this pass in the fused filter launch
+    uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration
 };
 struct FilterBatchArgs {
     FilterArgs f[kMaxFiltersPerLaunch];

@@ -581,9 +581,37 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
         else sg.extra = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p + kStreamSeg + 4 <= total + PWAF_ARENA_PAD) ? p + kStreamSeg : 0u));
     };
 
-    // heads: the wave walks the offsets column alongside the bytes; rq = first request that starts at or after the current byte
-    uint32_t rq = 0;
-    if (HEADS) {
+    // heads: the wave walks the offsets column alongside the bytes; rq = first request that starts at or after the current byte.
+    // Software-pipelined so that nothing on this path waits for memory: the offsets of the next 128 requests are requested one
+    // iteration ahead; the first 16 bytes of the requests that start inside the current iteration (bytes this wave has just
+    // streamed: cache hits) are requested BEFORE the next iteration's segment loads, so that waiting for them (loads complete in
+    // order) does not wait for those; the compares run after the lookups. (The first version — a loop of dependent loads per
+    // iteration behind the segment prefetch — cost 0.20 ms of a 0.88 ms launch.)
+    uint32_t rq = 0, ho[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, hn[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto load_offs = [&](const uint32_t r0) {
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t idx = r0 + 64u * q + lane;
+            ho[q] = idx < a.n ? a.off[idx] : 0xFFFFFFFFu;
+            hn[q] = idx < a.n ? a.off[idx + 1] : 0xFFFFFFFFu;
+        }
+    };
+    auto head_record = [&](const u32x4 w, const uint32_t flen) {
+        uint32_t hrec = 0;
+#pragma unroll
+        for (int hq = 0; hq < 2; hq++) {
+            if ((uint32_t)hq < a.n_heads) {
+                const uint32_t diff = ((w.x ^ a.head_w[hq][0]) & a.head_m[hq][0]) | ((w.y ^ a.head_w[hq][1]) & a.head_m[hq][1]) |
+                                      ((w.z ^ a.head_w[hq][2]) & a.head_m[hq][2]) | ((w.w ^ a.head_w[hq][3]) & a.head_m[hq][3]);
+                const uint32_t hl = a.head_len[hq] & 0xFFu;
+                const bool len_ok = (a.head_len[hq] >> 8) ? flen == hl : flen >= hl;
+                if (diff == 0 && len_ok) hrec |= a.head_code[hq];
+            }
+        }
+        return hrec;
+    };
+    const bool heads = HEADS && a.n_heads != 0;  // (a fused launch has passes with and without heads)
+    if (heads) {
         uint32_t lo = 0, hi = a.n;  // lower bound of base0 in off[0, n)
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -591,11 +619,52 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
             else hi = mid;
         }
         rq = lo;
+        load_offs(rq);
     }
 
     Segment cur, nxt;
     load_seg(base0, cur);
     for (uint32_t b = base0; b < slab_end; b += kStreamIter) {
+        // heads, first half: the requests that start inside this iteration's bytes (up to 128 through the pipelined path)
+        u32x4 hw[2];
+        uint32_t hlen[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // field length, or "none"
+        uint32_t rq_here = rq;
+#ifdef PWAF_PROFILING
+        if (heads && !(a.debug & 4u)) {
+#else
+        if (heads) {
+#endif
+            const uint32_t lim = min(b + kStreamIter, slab_end);
+            const bool in0 = ho[0] < lim;
+            const uint32_t c0 = (uint32_t)__builtin_popcountll(__ballot(in0));
+            const bool in1 = c0 == 64 && ho[1] < lim;
+            const uint32_t c1 = (uint32_t)__builtin_popcountll(__ballot(in1));
+            hw[0] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (in0 ? ho[0] : 0u));
+            hw[1] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (in1 ? ho[1] : 0u));
+            if (in0) hlen[0] = hn[0] - ho[0];
+            if (in1) hlen[1] = hn[1] - ho[1];
+            rq += c0 + c1;
+            if (c0 + c1 == 128) {
+                // more than 128 requests start within 4 KiB (very short fields): the rest synchronously
+                for (;;) {
+                    const uint32_t idx = rq + lane;
+                    const uint32_t s = idx < a.n ? a.off[idx] : 0xFFFFFFFFu;
+                    const bool in = s < lim;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(in));
+                    if (in) {
+                        const uint32_t hrec = head_record(*reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + s), a.off[idx + 1] - s);
+                        if (hrec) a.rec[idx] = hrec;
+                    }
+                    rq += cnt;
+                    if (cnt < 64) break;
+                }
+            }
+            load_offs(rq);  // for the next iteration
+        }
+#ifdef PWAF_PROFILING
+        if (a.debug & 2u) nxt = cur;
+        else
+#endif
         load_seg(b + kStreamIter < slab_end ? b + kStreamIter : b, nxt);  // next iteration's bytes are in flight while these are looked up
         const uint32_t p = b + lane * kStreamSeg;
 
@@ -615,6 +684,9 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
             const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
             const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
             // byte offset of a bin = (16-bit product >> 4) * 4
+#ifdef PWAF_PROFILING
+            if (a.debug & 1u) { mm[0] = hx | 0xFF000000u; mm[1] = hz | 0xFF000000u; mm[2] = (hx >> 3) | 0xFF000000u; mm[3] = (hz >> 5) | 0xFF000000u; return; }
+#endif
             mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
             mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
             mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
@@ -687,33 +759,14 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
             n_hit += (uint32_t)__builtin_popcountll(hm);
         }
 
-        if (HEADS) {
-            // requests that start inside this iteration's bytes: compare the head literals against their first 16 bytes (just streamed:
-            // cache hits) and record the heads that hold
-            const uint32_t lim = min(b + kStreamIter, slab_end);
-            for (;;) {
-                const uint32_t idx = rq + lane;
-                const uint32_t s = idx < a.n ? a.off[idx] : 0xFFFFFFFFu;
-                const bool in = s < lim;
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(in));
-                if (in) {
-                    const uint32_t flen = a.off[idx + 1] - s;
-                    const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + s);
-                    uint32_t hrec = 0;
+        if (heads) {
+            // heads, second half: compare the head literals against the first 16 bytes requested above and record the heads that hold
 #pragma unroll
-                    for (int hq = 0; hq < 2; hq++) {
-                        if ((uint32_t)hq < a.n_heads) {
-                            const uint32_t diff = ((w.x ^ a.head_w[hq][0]) & a.head_m[hq][0]) | ((w.y ^ a.head_w[hq][1]) & a.head_m[hq][1]) |
-                                                  ((w.z ^ a.head_w[hq][2]) & a.head_m[hq][2]) | ((w.w ^ a.head_w[hq][3]) & a.head_m[hq][3]);
-                            const uint32_t hl = a.head_len[hq] & 0xFFu;
-                            const bool len_ok = (a.head_len[hq] >> 8) ? flen == hl : flen >= hl;
-                            if (diff == 0 && len_ok) hrec |= a.head_code[hq];
-                        }
-                    }
-                    if (hrec) a.rec[idx] = hrec;
+            for (uint32_t q = 0; q < 2; q++) {
+                if (hlen[q] != 0xFFFFFFFFu) {
+                    const uint32_t hrec = head_record(hw[q], hlen[q]);
+                    if (hrec) a.rec[rq_here + 64u * q + lane] = hrec;
                 }
-                rq += cnt;
-                if (cnt < 64) break;
             }
         }
         cur = nxt;
