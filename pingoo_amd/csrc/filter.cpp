@@ -390,13 +390,32 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     std::vector<size_t> order(wins.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].k != wins[b].k ? wins[a].k > wins[b].k : wins[a].cost > wins[b].cost; });
-    static const uint32_t kMuls[] = {kFilterMul, 0x85EBu, 0xC2B3u, 0x27D5u, 0x165Bu, 0xB5A7u, 0x6F4Fu, 0x93D7u, 0xE995u, 0x4F1Du, 0xA3C1u, 0x7A6Bu};
-    double best_fp = INFINITY;
-    std::vector<double> w(kFilterEntries);
+    static const uint32_t kMuls[] = {kFilterMul, 0x85EBu, 0xC2B3u, 0x27D5u, 0x165Bu, 0xB5A7u, 0x6F4Fu, 0x93D7u, 0xE995u, 0x4F1Du, 0xA3C1u, 0x7A6Bu,
+                                     0x3C6Fu, 0xD1B5u, 0x5BD1u, 0xE6A9u, 0x2F8Du, 0x9A4Bu, 0x7F4Bu, 0xC34Fu};
+    // Two things depend on the multiplier: how far the factor windows stay from the traffic's frequent bigrams (false positives ->
+    // candidates) and how evenly the traffic's bigrams spread over the 32 LDS banks (filter_kernel is bound by the bank conflicts
+    // of its table gather: a ds_read_b32 takes as many cycles as its most loaded bank; lanes reading the SAME bin are a broadcast).
+    // Pass 1 finds the lowest false-positive estimate; pass 2 takes, among the multipliers within 25 % of it, the one with the
+    // lowest probability that two text positions read different bins of one bank (measured spread: 0.037 .. 0.074, uniform 0.031).
+    auto bank_collision = [&](const std::vector<double> &w) {
+        double bank[32] = {0}, same_bin = 0;
+        for (uint32_t bn = 0; bn < kFilterEntries; bn++) { bank[bn & 31] += w[bn]; same_bin += w[bn] * w[bn]; }
+        double c = 0;
+        for (double x : bank) c += x * x;
+        return c - same_bin;
+    };
+    double lowest_fp = INFINITY;
     const bool have_sample = hints && hints->pair_prob;
+    std::vector<double> w(kFilterEntries);
+    std::vector<double> mul_fp, mul_bank;
+    double best_fp = INFINITY, best_bank = INFINITY;
+    for (int pass = 0; pass < 2; pass++) {
+    size_t mul_index = 0;
     for (uint32_t mul : kMuls) {
         // (without a traffic sample the estimate rests on a generic prior, which cannot tell the multipliers apart: keep the default)
         if (!have_sample && mul != kFilterMul) continue;
+        const size_t mi = mul_index++;
+        if (pass == 1 && !(mul_fp[mi] <= lowest_fp * 1.25 + 1e-12 && mul_bank[mi] < best_bank)) continue;
         std::fill(w.begin(), w.end(), 0.0);
         for (uint32_t pr = 0; pr < 65536; pr++) w[filter_bin((uint8_t)pr, (uint8_t)(pr >> 8), mul)] += pw[pr];
         Bucket bk[8];
@@ -423,7 +442,13 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         }
         double fp_pos = 0;
         for (int b = 0; b < 8; b++) fp_pos += bk[b].fp();
-        if (!(fp_pos < best_fp)) continue;
+        if (pass == 0) {
+            mul_fp.push_back(fp_pos);
+            mul_bank.push_back(bank_collision(w));
+            lowest_fp = std::min(lowest_fp, fp_pos);
+            continue;
+        }
+        best_bank = mul_bank[mi];
         best_fp = fp_pos;
         out.mul = mul;
         out.table.assign(kFilterEntries, 0xFFFFFFFFu);
@@ -442,6 +467,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             }
         }
     }
+    }  // passes
     const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / stride;
     out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, best_fp)), len);
     out.enabled = true;
