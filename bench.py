@@ -253,6 +253,8 @@ def main():
                 tj = json.load(open(tpath))
                 want = {"filter_kernel<stride 1>": ("::filter_kernel<", ", 1>"), "filter_kernel<stride 2>": ("::filter_kernel<", ", 2>"), "scan_kernel": ("::scan_kernel<", "")}[dom]
                 sk = [v for k, v in tj["kernels"].items() if want[0] in k and want[1] in k]  # one entry per template instantiation
+                if not sk:
+                    raise KeyError(dom)  # the committed passes predate this kernel: no figure rather than a wrong one
                 traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
                 traffic_src = f"profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor {sk[0].get('fetch_factor', 2) if sk else '?'} for this kernel, see tools/pmc_traffic.py; taken at commit {tj.get('commit', '?')})"
             except Exception:  # a malformed profile file must not break the bench line

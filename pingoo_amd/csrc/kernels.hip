@@ -6,21 +6,26 @@
 // lane per RULE — instead of one interpreter walk per rule per request (pingoo/rules.rs:37-51,
 // http_listener.rs:251-264).
 //
-//   scan_kernel<CH>  one launch per DFA pass (ideally one per request field), one persistent workgroup per CU. Every lane walks
-//                    ONE request's field through the multi-pattern DFA, CH 16-byte chunks per iteration, and PULLS the next request of
-//                    its wave's slab when it is done (ballot + prefix popcount), so ragged field lengths do not idle lanes. The most
-//                    visited transition rows live in LDS; the others are read from the L2-resident table. What a request matched is
-//                    written as one 4-byte hit record (two atoms inline, more through an overflow chain): lanes never share state, no
-//                    atomics on the common path.
-//   lscan_kernel     every gated pass (patterns with wide gaps, visited only by requests whose prefilter factor matched) in one launch.
-//   attr_kernel      beside the scans, on a side stream at lower wave priority: everything that is not a string scan — GeoIP record and
+//   filter_kernel    the launch that streams the request bytes: every string pass whose patterns all have a literal factor sits behind
+//                    a bucketed shift-or BIGRAM PREFILTER. A field's arena is one flat byte stream; per byte one independent lookup of
+//                    a 16 KiB LDS table and two vector ops; the requests overlapping a completed window become CANDIDATES
+//                    (resolve_kernel: hit segments -> bitmap; bitcount / compact_kernel: bitmap -> dense ascending list).
+//   lscan_kernel     every list-driven pass of a phase in one launch: the candidates of the filtered passes, then the gap passes
+//                    (patterns with wide gaps, visited only by requests whose prefilter factor matched). One listed request per lane
+//                    through the pass's DFA, hot rows in LDS. What a request matched is written as one 4-byte hit record (two atoms
+//                    inline, more through an overflow chain): lanes never share state, no atomics on the common path.
+//   scan_kernel<CH>  a pass without a usable prefilter: the round-1 design, a DFA over EVERY request (one persistent workgroup per CU,
+//                    lanes pull the next request of their wave's slab when done, hot rows in LDS, cold rows from the L2-resident table).
+//   fcmp_kernel      predicates between two request fields (one lane per request compares the byte ranges).
+//   attr_kernel      on the engine's low-priority side stream, forked after the filter launches: everything that is not a string scan — GeoIP record and
 //                    ip-list membership (DIR-24-8 table + radix tries), country / integer-set membership, length / port / asn
 //                    comparisons — reduced per 64-request group to (column, 64-request mask) pairs with wave ballots.
 //   verdict_kernel   per group: turns hit records and pairs into LDS column words, finds the candidate rules through trigger lists,
 //                    evaluates each candidate's DNF with one lane per rule, resolves first-match-wins, writes verdicts, action
 //                    counters and the compacted index list of non-Allow requests.
 //
-// No MFMA: this is byte/integer work bounded by LDS lookups per input byte and HBM streaming.
+// No MFMA: this is byte/integer work bounded by LDS lookups per input byte and HBM streaming (filter_kernel runs
+// at 0.47 of the HBM roofline, bound by the bank conflicts of its table gather).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
