@@ -92,6 +92,7 @@ struct DevGroup {
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
     uint32_t flat_hot = 0;  // rows of `flat` lscan_kernel stages in LDS
+    bool short_lit = false;  // every atom is an anchored literal of <= 8 bytes: evaluated by the attribute kernel, the pass is never walked
 };
 
 }  // namespace
@@ -158,6 +159,9 @@ struct pwaf_engine {
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
     uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0;
+    uint32_t n_short = 0;  // short-literal atoms (kernels.h: ShortAtom) of the one field handled that way
+    int short_field = -1;
+    DevBuf short_atoms;
     uint32_t class_words = 1, acmp_words = 0, geo_default = 0, n_classes = 1;
     DevBuf class_rows, dir_esc, leaf_root;
     std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
@@ -429,6 +433,40 @@ int assign_lists(pwaf_engine *e) {
         const double ml = P.groups[k].field < e->mean_len.size() ? e->mean_len[P.groups[k].field] : 0.0;
         if (d.gate < 0 && (P.groups[k].field == PWAF_FIELD_METHOD ? (ml == 0 || ml < 12) : (ml > 0 && ml < 12))) d.identity = true;
     }
+    // A pass whose atoms are all anchored literals of <= 8 bytes (`method == "POST"`: the only thing rules ask of the method) is not
+    // walked at all: the attribute kernel compares the field's first 8 bytes (one field per engine: the first pass that qualifies).
+    {
+        std::vector<ShortAtom> sa;
+        e->short_field = -1;
+        for (size_t k = 0; k < P.groups.size(); k++) {
+            DevGroup &d = e->groups[k];
+            d.short_lit = false;
+            const DfaGroup &g = P.groups[k];
+            if (d.gate >= 0 || e->owns_factors[k] || g.field >= PWAF_N_FIELDS || e->short_field >= 0 || (P.flags & PWAF_OPT_NO_PREFILTER)) continue;
+            std::vector<ShortAtom> mine;
+            for (uint32_t l = 0; l < g.atoms.size(); l++) {
+                const Atom &at = P.atoms[g.atoms[l]];
+                std::string lit;
+                bool exact = false;
+                if (!at.pattern || !short_literal_atom(*at.pattern, lit, exact)) { mine.clear(); break; }
+                uint8_t b[8] = {0};
+                memcpy(b, lit.data(), lit.size());
+                ShortAtom x{};
+                x.col = g.atom_base + l;
+                x.len_exact = (uint32_t)lit.size() | (exact ? 0x100u : 0u);
+                memcpy(&x.lit_lo, b, 4);
+                memcpy(&x.lit_hi, b + 4, 4);
+                mine.push_back(x);
+            }
+            if (mine.empty()) continue;
+            d.short_lit = true;
+            d.identity = false;
+            e->short_field = (int)g.field;
+            sa = mine;
+        }
+        e->n_short = (uint32_t)sa.size();
+        if (!sa.empty() && (rc = upload(e->short_atoms, sa))) return rc;
+    }
     for (size_t k = 0; k < P.groups.size(); k++) {
         DevGroup &d = e->groups[k];
         if (d.gate < 0 || d.filtered) continue;
@@ -455,7 +493,9 @@ int assign_lists(pwaf_engine *e) {
             const DevGroup &d = e->groups[k];
             pt[k].base = d.atom_base;
             pt[k].kind_slot = 0;
-            if (d.filtered) {
+            if (d.short_lit) {
+                pt[k].kind_slot = 3u << 24;  // no records at all
+            } else if (d.filtered) {
                 // (a pass with heads writes records outside its candidate list too: its records are zeroed and read densely)
                 if (d.filter.heads.empty()) pt[k].kind_slot = (1u << 24) | fi;
                 fi++;
@@ -514,7 +554,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     if ((rc = S.rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
     // the attribute kernel's output: per group a header and room for EVERY non-scan atom (worst case: no overflow path), plus 64
     // pairs of slack so the verdict kernel may read a full wave's worth unconditionally
-    const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms);
+    const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms + e->n_short);
     if ((rc = S.attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     const size_t ctrl_words = 2 + (size_t)std::max(kGapLists, e->n_gated);  // [0] pool allocator, [1] status word, then one length per list slot
@@ -645,6 +685,12 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.pool = (const PoolEntry *)S.pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
+    v.n_short = e->n_short;
+    v.short_atoms = (const ShortAtom *)e->short_atoms.p;
+    if (e->n_short) {
+        v.short_data = cols[(size_t)e->short_field].data;
+        v.short_off = cols[(size_t)e->short_field].offsets;
+    }
     v.n_trig = e->n_trig;
     v.n_lits = (uint32_t)P.lits.size();
     v.bit_col = (const uint32_t *)e->bit_atoms.p;
@@ -778,7 +824,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     // ---- 1. plain passes: the DFA walks every request (short fields go through the list-scan kernel below) ----
     for (size_t gi = 0; gi < e->groups.size(); gi++) {
         const DevGroup &d = e->groups[gi];
-        if (d.gate >= 0 || d.identity) continue;
+        if (d.gate >= 0 || d.identity || d.short_lit) continue;
         const ScanArgs a = scan_args(gi);
         char nm[48];
         if (d.field < PWAF_N_FIELDS) snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
@@ -907,6 +953,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
             if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
+#ifdef PWAF_PROFILING
+            static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
+            if (skip_identity && d.identity) continue;
+#endif
             gb.g[gb.count++] = list_args(gi);
             if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
         }

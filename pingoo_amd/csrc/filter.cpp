@@ -473,6 +473,13 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     out.enabled = true;
 }
 
+bool short_literal_atom(const RNode &n, std::string &lit, bool &exact) {
+    bool at_start = false, at_end = false;
+    if (!anchored_literal(n, lit, at_start, at_end) || !at_start || lit.size() > 8) return false;
+    exact = at_end;
+    return true;
+}
+
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase) {
     uint32_t st = f.init;
     for (size_t i = phase; i + 1 < n; i += f.stride) {

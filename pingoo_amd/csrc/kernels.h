@@ -182,6 +182,14 @@ int launch_fcmp(const FcmpArgs &a, void *stream);
 struct CmpAtomDev {
     uint32_t col, c;
 };
+// A string atom that is an anchored literal of at most 8 bytes (`method == "POST"`, `method.starts_with("P")`) on a field whose
+// pass consists of such atoms only: evaluated by the attribute kernel from the field's first 8 bytes instead of a DFA pass over
+// every request (the pass then does not exist on the device: no walk, no hit records for the verdict kernel to read).
+struct ShortAtom {
+    uint32_t col;        // device column
+    uint32_t len_exact;  // literal length | exact << 8 (exact: the field IS the literal; else it starts with it)
+    uint32_t lit_lo, lit_hi;
+};
 struct VerdictArgs {
     uint32_t n, n_groups;
     uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
@@ -204,6 +212,10 @@ struct VerdictArgs {
     uint32_t bit_words;  // words per bitmap (2 per 64-request group)
     // EXTENSION: header columns whose length is compared (comparison variable 7 + k)
     const uint32_t *hoff[kMaxHeaderLens];
+    const ShortAtom *short_atoms;  // atoms of the short-literal field (see ShortAtom), n_short of them (0: none)
+    uint32_t n_short;
+    const uint8_t *short_data;     // that field's arena and offsets
+    const uint32_t *short_off;
     uint32_t n_hlen;
     const PoolEntry *pool;
     // compiled program

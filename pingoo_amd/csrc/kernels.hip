@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         if (my_live[r]) {
             const PassInfo pi = a.passes[ps];
             const uint32_t kind = pi.kind_slot >> 24, slot = pi.kind_slot & 0xFFFFFFu;
+            if (kind == 3) my_live[r] = false;  // a short-literal pass: its columns arrive as attribute pairs, it has no records
             my_bits[r] = kind == 1 ? a.cand_bits + (size_t)slot * a.bit_words : kind == 2 ? a.visit_bits + (size_t)slot * a.bit_words : nullptr;
             my_base[r] = pi.base;
         }
@@ -1452,6 +1453,7 @@ static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
 struct AttrIn {
     uint32_t ipw[4];
     uint32_t v6, port, len[5], asn, country;
+    uint32_t sstart, slen;  // the short-literal field's value: offset and length
 };
 
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
@@ -1481,9 +1483,15 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         for (int f = 0; f < 5; f++) in.len[f] = a.off[f][i + 1] - a.off[f][i];
         in.asn = from_row ? 0u : a.asn[i];
         in.country = from_row ? 0u : (uint32_t)a.country[i];
+        in.sstart = a.n_short ? a.short_off[i] : 0u;
+        in.slen = a.n_short ? a.short_off[i + 1] - in.sstart : 0u;
     };
     // stage B: the first trie step of both tries (three unconditional gathers: the DIR-24 entry for IPv4, the two 16-bit roots otherwise)
-    auto load_root = [&](const AttrIn &in, uint32_t &e24, uint32_t &rg, uint32_t &ri) {
+    auto load_root = [&](const AttrIn &in, uint32_t &e24, uint32_t &rg, uint32_t &ri, uint32_t &s_lo, uint32_t &s_hi) {
+        // (the short-literal field's first 8 bytes: arenas carry 16 readable slack bytes)
+        const uint8_t *sp = a.n_short ? a.short_data + in.sstart : reinterpret_cast<const uint8_t *>(a.ip);
+        s_lo = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(sp);
+        s_hi = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(sp + 4);
         const bool v6 = in.v6 != 0;
         const uint32_t top16 = (ip_byte(in.ipw, 0) << 8) | ip_byte(in.ipw, 1);
         const uint32_t top24 = (top16 << 8) | ip_byte(in.ipw, 2);
@@ -1492,11 +1500,14 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         ri = (v6 ? a.ip_root6 : a.ip_root4)[top16];
     };
     AttrIn cur, nxt;
-    uint32_t c_e24, c_rg, c_ri;
+    uint32_t c_e24, c_rg, c_ri, c_slo, c_shi;
     const uint32_t g0 = blockIdx.x * 4 + wave;
     load_in(g0, cur);
     load_in(g0 + g_stride, nxt);
-    load_root(cur, c_e24, c_rg, c_ri);
+    load_root(cur, c_e24, c_rg, c_ri, c_slo, c_shi);
+    // group-invariant: the first 64 short-literal atoms, one per lane
+    ShortAtom h_short{0, 0, 0, 0};
+    if (lane < a.n_short) h_short = a.short_atoms[lane];
 
     for (uint32_t g = g0; g < a.n_groups; g += g_stride) {
         const uint32_t i = g * 64 + lane;
@@ -1590,8 +1601,8 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         // ---- 3. prefetch: inputs of the group after next, first trie step of the next group ----
         AttrIn nn;
         load_in(g + 2 * g_stride, nn);
-        uint32_t n_e24, n_rg, n_ri;
-        load_root(nxt, n_e24, n_rg, n_ri);
+        uint32_t n_e24, n_rg, n_ri, n_slo, n_shi;
+        load_root(nxt, n_e24, n_rg, n_ri, n_slo, n_shi);
 
         // ---- 4. transposes: one ballot per bit that ANY of the 64 requests has set (wave-wide OR first, so absent bits cost
         //         nothing); lane b keeps bit b's request mask and owns that atom's pair ----
@@ -1654,12 +1665,35 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             }
             emit_pairs((acc_lo | acc_hi) != 0, m_col & 0xFFFFFFu, acc_lo, acc_hi);
         }
+        // Short-literal atoms (kernels.h: ShortAtom): the field's first 8 bytes against each literal under its length mask — a
+        // scalar broadcast of the atom, two vector compares and a ballot parked in the atom's lane.
+        for (uint32_t base = 0; base < a.n_short; base += 64) {
+            ShortAtom m = h_short;
+            if (base != 0) {
+                m = ShortAtom{0, 0, 0, 0};
+                if (base + lane < a.n_short) m = a.short_atoms[base + lane];
+            }
+            const uint32_t cnt = min(64u, a.n_short - base);
+            uint32_t acc_lo = 0, acc_hi = 0;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)m.len_exact, (int)j), len = le & 0xFFu;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m.lit_lo, (int)j), hi = (uint32_t)__builtin_amdgcn_readlane((int)m.lit_hi, (int)j);
+                const uint32_t mlo = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u, mhi = len >= 8 ? 0xFFFFFFFFu : len > 4 ? (1u << (8 * (len - 4))) - 1u : 0u;
+                const bool len_ok = (le >> 8) ? cur.slen == len : cur.slen >= len;
+                const unsigned long long hit = __ballot(len_ok && ((c_slo ^ lo) & mlo) == 0 && ((c_shi ^ hi) & mhi) == 0) & valid_mask;
+                acc_lo = lane == j ? (uint32_t)hit : acc_lo;
+                acc_hi = lane == j ? (uint32_t)(hit >> 32) : acc_hi;
+            }
+            emit_pairs((acc_lo | acc_hi) != 0, m.col, acc_lo, acc_hi);
+        }
         if (lane == 0) a.ghdr[g] = n_pairs;
         cur = nxt;
         nxt = nn;
         c_e24 = n_e24;
         c_rg = n_rg;
         c_ri = n_ri;
+        c_slo = n_slo;
+        c_shi = n_shi;
     }
 }
 

@@ -272,6 +272,8 @@ void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector
 void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride = 1);
 // Host model of the filter kernel over one field value: true = candidate. (Used by tune to measure the candidate rate on the
 // sample; the device may flag MORE requests — it also looks at the bytes just past a field's end — never fewer.)
+// `\A literal` / `\A literal \z` with a literal of at most 8 single bytes (kernels.h: ShortAtom)
+bool short_literal_atom(const RNode &n, std::string &lit, bool &exact);
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase = 0);  // phase: offset of the first sampled byte (< stride)
 // Which heads hold for the field value: bit k = heads[k].
 uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n);

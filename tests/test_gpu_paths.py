@@ -289,3 +289,25 @@ def test_counted_gap_patterns_on_the_device():
     eng.tune(batch)
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "counted gaps on the device, tuned")
     eng.close()
+
+
+def test_short_literal_atoms_are_answered_by_the_attribute_kernel():
+    """A pass whose atoms are all anchored literals of <= 8 bytes (what rules ask of the method) is not walked: the attribute kernel compares
+    the field's first 8 bytes (kernels.h: ShortAtom). Exact / prefix / empty / 8-byte literals, values longer than 8 bytes, an engine whose
+    method pass also has a regex (then it stays a DFA pass), and the same rules with PWAF_OPT_NO_PREFILTER (DFA pass): all against the oracle."""
+    short = [("post", 'http_request.method == "POST"', [B]), ("p", 'http_request.method.starts_with("P") && http_request.path.contains("x")', [CAP]),
+             ("pf", 'http_request.method == "PROPFIND"', [B]), ("empty", 'http_request.method == ""', [CAP]), ("notget", '!(http_request.method == "GET") && http_request.url.contains("zz")', [B]),
+             ("pre8", 'http_request.method.starts_with("PROPFIND")', [CAP]), ("any", 'http_request.method.starts_with("")  && http_request.host == "never"', [B])]
+    methods = ["GET", "POST", "PUT", "PATCH", "PROPFIND", "PROPFINDX", "PROPFIN", "", "P", "post", "OPTIONS", "DELETE", "G", "GETT", "MKCALENDAR"]
+    rng = random.Random(11)
+    reqs = [Request(method=rng.choice(methods), url=rng.choice(["/", "/zz", "/a?zz=1"]), path=rng.choice(["/", "/x", "/ax"]), host=rng.choice(["h", "never"])) for _ in range(5000)]
+    batch = RequestBatch.from_requests(reqs)
+    for rules in (short, short + [("rx", 'http_request.method.matches("^(PUT|DEL)")', [B])], short + [("long", 'http_request.method == "MKCALENDAR"', [B])]):
+        want = pyoracle.Oracle(rules).evaluate(batch)
+        for flags in (0, _abi.OPT_NO_PREFILTER):
+            eng = RuleEngine(rules, flags=flags)
+            H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"short literals, {len(rules)} rules, flags {flags}")
+            eng.tune(batch.slice(0, 2000))
+            H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"short literals tuned, {len(rules)} rules, flags {flags}")
+            eng.close()
+    assert len(set(pyoracle.Oracle(short).evaluate(batch)["rule_idx"].tolist())) >= 6
