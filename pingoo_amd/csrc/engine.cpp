@@ -115,6 +115,7 @@ struct Scratch {
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
     DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
+    DevBuf args_filter, args_list;         // per-pass launch descriptors (kernels.h: FilterTable / GatedTable)
     std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
     // Streams and events are created on first use: every HIP stream takes a share of the few hardware queues of its priority
@@ -138,7 +139,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -857,40 +858,15 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             }
         if ((rc = S.cand_sub.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
-        FilterBatchArgs fb{};
-        uint32_t fi = 0, block = 0;
+        std::vector<FilterArgs> fall;  // every filtered pass, in pass order
+        uint32_t fi = 0;
         uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
         uint64_t sub_at = 0, cnt_at = 0;
-        auto flush_filters = [&]() -> int {
-            if (fb.count == 0) return PWAF_OK;
-            int rc2;
-            int he = 0;
-            for (uint32_t stride = 1; stride <= 2; stride++) {
-                if (!alg_bytes[stride]) continue;
-                if ((rc2 = mark(nullptr, 0))) return rc2;
-                he = launch_filter(fb, stride, stream);
-                if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-                if ((rc2 = mark(stride == 1 ? "filter_s1" : "filter_s2", alg_bytes[stride]))) return rc2;  // algorithmic bytes: every streamed arena once + its offsets
-            }
-#ifdef PWAF_PROFILING
-            static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
-            if (!attr_after_compact)
-#endif
-            if ((rc2 = launch_attr_side())) return rc2;
-            if ((rc2 = mark(nullptr, 0))) return rc2;
-            he = launch_resolve(fb, stream);
-            if (!he) he = launch_compact(fb, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc2 = mark("resolve+compact", 0xFCu))) return rc2;
-            fb.count = 0;
-            block = 0;
-            alg_bytes[1] = alg_bytes[2] = 0;
-            return PWAF_OK;
-        };
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
             if (!d.filtered) continue;
-            FilterArgs &f = fb.f[fb.count++];
+            fall.emplace_back();
+            FilterArgs &f = fall.back();
             f = FilterArgs{};
             f.data = cols[d.field].data;
             f.off = cols[d.field].offsets;
@@ -924,43 +900,76 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
             f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
-            f.first_block = block;
+            f.first_block = 0;
             sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
             cnt_at += slabs + n_cblocks;
-            block += (slabs + kFilterWaves - 1) / kFilterWaves;
             alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
-            if (fb.count == kMaxFiltersPerLaunch && (rc = flush_filters())) return rc;
         }
-        if ((rc = flush_filters())) return rc;
+        // descriptor tables in device memory: [all passes] [stride-1 passes, first_block numbered] [stride-2 passes]
+        const uint32_t nf = (uint32_t)fall.size();
+        if ((rc = S.args_filter.reserve((size_t)3 * nf * sizeof(FilterArgs)))) return rc;
+        FilterArgs *d_all = (FilterArgs *)S.args_filter.p;
+        int he = upload_filter_args(fall.data(), nf, d_all, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+        FilterArgs *d_at = d_all + nf;
+        for (uint32_t stride = 1; stride <= 2; stride++) {
+            std::vector<FilterArgs> sub;
+            uint32_t block = 0;
+            for (const FilterArgs &f : fall) {
+                if (f.stride != stride) continue;
+                sub.push_back(f);
+                sub.back().first_block = block;
+                block += ((uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0 + kFilterWaves - 1) / kFilterWaves;
+            }
+            if (sub.empty()) continue;
+            if ((he = upload_filter_args(sub.data(), (uint32_t)sub.size(), d_at, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark(nullptr, 0))) return rc;
+            he = launch_filter(sub.data(), (uint32_t)sub.size(), d_at, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark(stride == 1 ? "filter_s1" : "filter_s2", alg_bytes[stride]))) return rc;  // algorithmic bytes: every streamed arena once + its offsets
+            d_at += sub.size();
+        }
+#ifdef PWAF_PROFILING
+        static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
+        if (!attr_after_compact)
+#endif
+        if ((rc = launch_attr_side())) return rc;
+        if ((rc = mark(nullptr, 0))) return rc;
+        he = launch_resolve(fall.data(), nf, d_all, stream);
+        if (!he) he = launch_compact(fall.data(), nf, d_all, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc = mark("resolve+compact", 0xFCu))) return rc;
     }
     if ((rc = launch_attr_side())) return rc;  // (no filtered pass: beside the list scans / the verdict kernel's predecessors)
     // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
-    GatedArgs gb{};
-    auto flush_gated = [&]() -> int {
-        if (gb.count == 0) return PWAF_OK;
-        int rc2;
-        if ((rc2 = mark(nullptr, 0))) return rc2;
-        int he = launch_scan_gated(gb, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        char nm[48];
-        snprintf(nm, sizeof nm, "lscan_x%u", gb.count);
-        if ((rc2 = mark(nm, 0xFDu))) return rc2;
-        gb.count = 0;
-        return PWAF_OK;
-    };
-    for (int phase = 0; phase < 2; phase++) {
-        for (size_t gi = 0; gi < e->groups.size(); gi++) {
-            const DevGroup &d = e->groups[gi];
-            if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
+    {
+        std::vector<ListScanArgs> la[2];
+        for (int phase = 0; phase < 2; phase++)
+            for (size_t gi = 0; gi < e->groups.size(); gi++) {
+                const DevGroup &d = e->groups[gi];
+                if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
 #ifdef PWAF_PROFILING
-            static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
-            if (skip_identity && d.identity) continue;
+                static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
+                if (skip_identity && d.identity) continue;
 #endif
-            gb.g[gb.count++] = list_args(gi);
-            if (gb.count == kGatedPerLaunch && (rc = flush_gated())) return rc;
+                la[phase].push_back(list_args(gi));
+            }
+        if ((rc = S.args_list.reserve((la[0].size() + la[1].size() + 1) * sizeof(ListScanArgs)))) return rc;
+        ListScanArgs *d_at = (ListScanArgs *)S.args_list.p;
+        for (int phase = 0; phase < 2; phase++) {
+            const uint32_t cnt = (uint32_t)la[phase].size();
+            if (!cnt) continue;
+            int he = upload_list_args(la[phase].data(), cnt, d_at, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark(nullptr, 0))) return rc;
+            he = launch_scan_gated(la[phase].data(), cnt, d_at, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            char nm[48];
+            snprintf(nm, sizeof nm, "lscan_x%u", cnt);
+            if ((rc = mark(nm, 0xFDu))) return rc;
+            d_at += cnt;
         }
-        if ((rc = flush_gated())) return rc;
     }
     if (!P.fcmp.empty()) {
         // field-against-field atoms: the last (pseudo) pass; its hit records are written for every request

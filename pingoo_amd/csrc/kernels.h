@@ -146,13 +146,22 @@ struct FilterArgs {
     uint32_t first_block;     // first workgroup of this pass in the fused filter launch
     uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration
 };
-struct FilterBatchArgs {
+// The descriptors of all passes of a launch live in DEVICE memory (a 4096-rule set over 64 header fields has ~70 filtered passes:
+// 15 KB of descriptors, kernel arguments hold 8). They get there as the by-value arguments of small store launches on the same
+// stream — stream-ordered, and no staging buffer that a later batch could overwrite before an asynchronous copy has run.
+struct FilterBatchArgs {  // a chunk of descriptors on its way to the device
     FilterArgs f[kMaxFiltersPerLaunch];
     uint32_t count;
 };
-int launch_filter(const FilterBatchArgs &b, uint32_t stride, void *stream);  // the passes of `b` whose stride is `stride`, in one launch
-int launch_resolve(const FilterBatchArgs &b, void *stream);
-int launch_compact(const FilterBatchArgs &b, void *stream);  // bitcount_kernel, then compact_kernel
+struct FilterTable {
+    const FilterArgs *f;  // device
+    uint32_t count;
+};
+int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, void *stream);
+// `host` = the same `count` descriptors as `dev` (launch geometry). launch_filter: all of one stride, first_block numbered by the caller.
+int launch_filter(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);
+int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);
+int launch_compact(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);  // bitcount_kernel, then compact_kernel
 // Sets the dynamic-LDS limit of every kernel on the CURRENT device (once per device and process; engines on several
 // devices of one process each need it).
 int configure_kernels(int device);
@@ -271,7 +280,12 @@ struct GatedArgs {
     uint32_t count;
 };
 int launch_scan(const ScanArgs &a, void *stream);
-int launch_scan_gated(const GatedArgs &b, void *stream);
+struct GatedTable {
+    const ListScanArgs *g;  // device
+    uint32_t count;
+};
+int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream);
+int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
 int launch_attr(const VerdictArgs &a, void *stream);
 int launch_dir24(const VerdictArgs &a, void *out /* 2^24 x u32, or null: count only */, void *esc, void *esc_count, void *stream);

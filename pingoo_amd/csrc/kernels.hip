@@ -187,6 +187,22 @@ __device__ __forceinline__ void enqueue_gated(const uint32_t *colmask_local, con
     enqueue_mask(gate_lists, gate_count, n, r, gate_mask(colmask_local, pool, h));
 }
 
+// A pass descriptor read from the device-resident table into SCALAR registers (the address is wave-uniform; through a plain
+// reference every use inside the hot loops became a reload from memory — the compiler must assume the kernel's own stores alias it —
+// and the filter launch went from 0.74 to 0.85 ms).
+template <class T>
+__device__ __forceinline__ T load_descriptor(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "descriptor size");
+    typedef uint32_t __attribute__((may_alias)) word_t;  // (the descriptor's members are read and written as plain words)
+    uint32_t w[sizeof(T) / 4];
+    const word_t *s = reinterpret_cast<const word_t *>(p);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s[i]);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+
 #define PWAF_EMIT(id) h = emit_list(a.list_off, a.list, a.pool, a.pool_count, a.status, a.pool_cap, (id), h)
 
 // CH = 16-byte chunks a lane walks per loop iteration. 2 halves the per-byte cost of the pull / finish logic (a third of the
@@ -448,12 +464,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 // from the LDS copy of the table's hottest rows, or from the flat table in L2 for the others (~10x the latency). The wave-lockstep
 // walk of scan_kernel, built for streaming EVERY request, took 0.6 ms on the same lists (every lane a candidate: its slow paths
 // fire in every group of steps).
-__global__ __launch_bounds__(kListThreads) void lscan_kernel(GatedArgs b) {
+__global__ __launch_bounds__(kListThreads) void lscan_kernel(GatedTable b) {
     extern __shared__ uint32_t lscan_lds[];  // [kListHotBytes / 4] hot rows, then the 256-byte class map
     __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
-    const ListScanArgs &a = b.g[blockIdx.y];
-    const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
+    // (most workgroups of a short list leave at once: they look at three words of the descriptor, not all of it)
+    const ListScanArgs *pa = &b.g[blockIdx.y];
+    const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
     if (blockIdx.x * kListThreads >= n_l) return;
+    const ListScanArgs a = load_descriptor(pa);
     const uint32_t ncls = a.n_classes;
     const uint32_t hot_elems = a.n_hot * ncls;
     {
@@ -530,12 +548,44 @@ int launch_scan(const ScanArgs &a, void *stream) {
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
-int launch_scan_gated(const GatedArgs &b, void *stream) {
-    if (b.count == 0 || b.g[0].n == 0) return 0;
+// Descriptor chunks to device memory: the chunk is the launch's by-value argument, every thread stores a few of its words.
+template <class CHUNK, class T>
+__global__ __launch_bounds__(256) void store_args_kernel(CHUNK c, T *dst) {
+    typedef uint32_t __attribute__((may_alias)) word_t;
+    const uint32_t words = c.count * (uint32_t)(sizeof(T) / 4);
+    const word_t *src = reinterpret_cast<const word_t *>(&c);
+    for (uint32_t i = threadIdx.x; i < words; i += 256) reinterpret_cast<word_t *>(dst)[i] = src[i];
+}
+int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream) {
+    for (uint32_t at = 0; at < count; at += kGatedPerLaunch) {
+        GatedArgs c{};
+        c.count = std::min(kGatedPerLaunch, count - at);
+        for (uint32_t k = 0; k < c.count; k++) c.g[k] = host[at + k];
+        hipLaunchKernelGGL((store_args_kernel<GatedArgs, ListScanArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, void *stream) {
+    for (uint32_t at = 0; at < count; at += kMaxFiltersPerLaunch) {
+        FilterBatchArgs c{};
+        c.count = std::min(kMaxFiltersPerLaunch, count - at);
+        for (uint32_t k = 0; k < c.count; k++) c.f[k] = host[at + k];
+        hipLaunchKernelGGL((store_args_kernel<FilterBatchArgs, FilterArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, void *stream) {
+    if (count == 0 || host[0].n == 0) return 0;
+    GatedTable b{dev, count};
     // the list lengths are only known on the device: a grid that covers the chip once per pass (grid-stride over the list);
     // workgroups beyond a list's end exit at once
-    const uint32_t blocks = std::min<uint32_t>((b.g[0].n + kListThreads - 1) / kListThreads, std::max(1u, b.g[0].n_cus) * 3u);
-    void *args[] = {const_cast<GatedArgs *>(&b)};
+    const uint32_t blocks = std::min<uint32_t>((host[0].n + kListThreads - 1) / kListThreads, std::max(1u, host[0].n_cus) * 3u);
+    void *args[] = {&b};
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(lscan_kernel), dim3(blocks, b.count), dim3(kListThreads), args, kListHotBytes + 256, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
@@ -781,13 +831,18 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
 
 // (One kernel per stride: both bodies behind a branch in one kernel cost 65 VGPRs — 7 waves per SIMD — against 63 and 54 apart.)
 template <bool HEADS, int STRIDE>
-__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchArgs B) {
+__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterTable B) {
     extern __shared__ __align__(16) unsigned char lds[];
     __builtin_amdgcn_s_setprio(3);
-    // which pass of the fused launch this workgroup belongs to (uniform: kernel arguments only)
+    // which pass of the fused launch this workgroup belongs to (uniform: the last pass whose first_block is <= blockIdx.x)
     uint32_t k = 0;
-    while (k + 1 < B.count && blockIdx.x >= B.f[k + 1].first_block) k++;
-    const FilterArgs &a = B.f[k];
+    for (uint32_t lo = 0, hi = B.count; lo + 1 < hi;) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blockIdx.x >= B.f[mid].first_block) lo = mid;
+        else hi = mid;
+        k = lo;
+    }
+    const FilterArgs a = load_descriptor(&B.f[k]);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // (Bank-private replicas of the table — 4 copies, each lane group of 8 with 8 banks of its own — were measured SLOWER: 1.19 ms
     // against 0.89 ms. A ds_read_b32 takes as many cycles as its most loaded bank over all 32 lanes, and the maximum over four
@@ -807,9 +862,11 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterBatchAr
 
 // resolve_kernel: one wave per slab; every hit segment marks the requests that overlap its flagged chunks (extended by the bytes a
 // window may reach back — three sampled bigrams — and the one byte its last bigram reaches forward) in the pass's candidate bitmap.
-__global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
+__global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
-    const FilterArgs &a = B.f[blockIdx.y];
+    const FilterArgs *pa = &B.f[blockIdx.y];
+    if ((uint64_t)(pa->slab0 + blockIdx.x * 4) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
+    const FilterArgs a = load_descriptor(pa);
     const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6), slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];
@@ -833,10 +890,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterBatchArgs B) {
 
 // bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
 // (kCompactWords bitmap words each), then every workgroup sums the counts before it (a few hundred values) and writes its part.
-__global__ __launch_bounds__(256) void bitcount_kernel(FilterBatchArgs B) {
+__global__ __launch_bounds__(256) void bitcount_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t red[256];
-    const FilterArgs &a = B.f[blockIdx.y];
+    const FilterArgs a = load_descriptor(&B.f[blockIdx.y]);
     const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords;
     if (w0 >= words) return;
     uint32_t c = 0;
@@ -850,45 +907,43 @@ __global__ __launch_bounds__(256) void bitcount_kernel(FilterBatchArgs B) {
     if (threadIdx.x == 0) a.block_count[blockIdx.x] = red[0];
 }
 
-__global__ void compact_kernel(FilterBatchArgs B);  // (defined below, next to the wave scan it uses)
+__global__ void compact_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
 
-int launch_filter(const FilterBatchArgs &b, uint32_t stride, void *stream) {
-    // one fused launch per sampling stride in use (the passes of a stride keep their own sub-lists: only first_block is renumbered)
-    FilterBatchArgs sub{};
+int launch_filter(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream) {
+    // one fused launch for the passes of one sampling stride (first_block numbered by the caller)
     uint32_t blocks = 0;
     bool heads = false;
-    for (uint32_t k = 0; k < b.count; k++) {
-        if (b.f[k].stride != stride) continue;
-        const uint32_t slabs = (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab) - b.f[k].slab0;
-        FilterArgs &f = sub.f[sub.count++];
-        f = b.f[k];
-        f.first_block = blocks;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t slabs = (uint32_t)(((uint64_t)host[k].total + kStreamSlab - 1) / kStreamSlab) - host[k].slab0;
         blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
-        heads = heads || f.n_heads != 0;
+        heads = heads || host[k].n_heads != 0;
     }
     if (blocks == 0) return 0;
-    void *args[] = {&sub};
-    const void *fn = stride == 2 ? (heads ? reinterpret_cast<const void *>(filter_kernel<true, 2>) : reinterpret_cast<const void *>(filter_kernel<false, 2>))
-                                 : (heads ? reinterpret_cast<const void *>(filter_kernel<true, 1>) : reinterpret_cast<const void *>(filter_kernel<false, 1>));
+    FilterTable t{dev, count};
+    void *args[] = {&t};
+    const void *fn = host[0].stride == 2 ? (heads ? reinterpret_cast<const void *>(filter_kernel<true, 2>) : reinterpret_cast<const void *>(filter_kernel<false, 2>))
+                                         : (heads ? reinterpret_cast<const void *>(filter_kernel<true, 1>) : reinterpret_cast<const void *>(filter_kernel<false, 1>));
     hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
-int launch_resolve(const FilterBatchArgs &b, void *stream) {
+int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream) {
     uint32_t max_slabs = 0;
-    for (uint32_t k = 0; k < b.count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)b.f[k].total + kStreamSlab - 1) / kStreamSlab) - b.f[k].slab0);
-    if (b.count == 0 || max_slabs == 0) return 0;
-    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, b.count), dim3(256), args, 0, (hipStream_t)stream);
+    for (uint32_t k = 0; k < count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)host[k].total + kStreamSlab - 1) / kStreamSlab) - host[k].slab0);
+    if (count == 0 || max_slabs == 0) return 0;
+    FilterTable t{dev, count};
+    void *args[] = {&t};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
-int launch_compact(const FilterBatchArgs &b, void *stream) {
-    if (b.count == 0 || b.f[0].n == 0) return 0;
-    const uint32_t words = (b.f[0].n + 31) / 32, blocks = (words + kCompactWords - 1) / kCompactWords;
-    void *args[] = {const_cast<FilterBatchArgs *>(&b)};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(bitcount_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipLaunchKernel(reinterpret_cast<const void *>(compact_kernel), dim3(blocks, b.count), dim3(256), args, 0, (hipStream_t)stream);
+int launch_compact(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream) {
+    if (count == 0 || host[0].n == 0) return 0;
+    const uint32_t words = (host[0].n + 31) / 32, n_blocks = (words + kCompactWords - 1) / kCompactWords;
+    FilterTable t{dev, count};
+    void *args[] = {&t};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(bitcount_kernel), dim3(n_blocks, count), dim3(256), args, 0, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipLaunchKernel(reinterpret_cast<const void *>(compact_kernel), dim3(n_blocks, count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -973,10 +1028,10 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
 // consecutive words and takes them 64 at a time — lane = word — so that the lanes of one store instruction write neighbouring list
 // entries (the first version gave every thread 8 consecutive words: its stores were 20 entries apart per lane and it took
 // 180 us next to the attribute kernel, 8 us alone).
-__global__ __launch_bounds__(256) void compact_kernel(FilterBatchArgs B) {
+__global__ __launch_bounds__(256) void compact_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t red[256];
-    const FilterArgs &a = B.f[blockIdx.y];
+    const FilterArgs a = load_descriptor(&B.f[blockIdx.y]);
     const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (w0 >= words) return;
     const uint32_t n_blocks = (words + kCompactWords - 1) / kCompactWords;
