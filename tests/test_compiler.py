@@ -190,3 +190,41 @@ def test_a_pattern_beyond_the_table_budget_fails_alone():
     rules = [("big", 'http_request.url.matches("select.{0,60}from.{0,60}where")', [B]), ("min", 'http_request.url.matches("a.{20,40}b")', [B]), ("ok", 'http_request.url.contains("x")', [CAP])]
     prog = CompiledProgram(rules)
     assert prog.unsupported_rules(len(rules)) == [0, 1] and "budget" in prog.rule_status(0)[1]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_counted_repetitions_match_the_oracle(seed):
+    """Random patterns around counted repetitions of byte classes (the chains dfa.cpp prune_core keeps one thread of): several chains per
+    pattern, chains inside groups and alternations, anchors, min > 0 — against the oracle's backtracking matcher on short random strings
+    over the patterns' own alphabet."""
+    rng = random.Random(4200 + seed)
+    alpha = "abc-"
+    def cls():
+        return rng.choice([".", "[ab]", "[^a]", "\\\\w", "[a-c]", "[^-]"])
+    def piece(depth=0):
+        r = rng.random()
+        if r < 0.35:
+            return rng.choice(alpha[:3]) * rng.randint(1, 2)
+        if r < 0.75:
+            lo = rng.choice([0, 0, 0, 1, 2])
+            return f"{cls()}{{{lo},{lo + rng.randint(2, 9)}}}"
+        if r < 0.85 and depth < 2:
+            return "(" + "|".join("".join(piece(depth + 1) for _ in range(rng.randint(1, 2))) for _ in range(2)) + ")"
+        return rng.choice(["-", "a?", "b+", "c*"])
+    pats = []
+    for _ in range(10):
+        p = "".join(piece() for _ in range(rng.randint(2, 4)))
+        pats.append(rng.choice(["", "^"]) + p + rng.choice(["", "", "$"]))
+    rules = [(f"r{k}", f'http_request.url.matches("{p}")', [B]) for k, p in enumerate(pats)]
+    prog = CompiledProgram(rules)
+    seen, bad = H.as_the_engine_sees(rules, prog)
+    reqs = [Request(url="".join(rng.choice(alpha) for _ in range(rng.randint(0, 14)))) for _ in range(400)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(seen).evaluate(batch)
+    H.assert_verdicts_equal(walk(prog, batch), want, batch, f"seed {seed}: {pats}")
+    assert len(bad) <= 3
+    for k, rule in enumerate(rules):  # and every pattern on its own (first-match-wins hides the later ones above)
+        if k in bad:
+            continue
+        one = CompiledProgram([rule])
+        H.assert_verdicts_equal(walk(one, batch), pyoracle.Oracle([rule]).evaluate(batch), batch, f"seed {seed}: {pats[k]}")

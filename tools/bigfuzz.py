@@ -1,5 +1,5 @@
 """Extended CPU fuzz: compiled tables (interpreted by tests/table_walker.py) against the oracle on random rule sets.
-usage: python tools/bigfuzz.py <first seed> <last seed>   (about 30 seeds per second and core; no GPU involved)"""
+usage: [PWAF_FUZZ_STRIDE2=1] python tools/bigfuzz.py <first seed> <last seed>   (about 70 seeds per second and core; no GPU involved)"""
 import sys, random, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,6 +24,8 @@ for seed in range(lo, hi):
         acts = H.fuzz_actions(rng)
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
+    if os.environ.get("PWAF_FUZZ_STRIDE2"):
+        flags |= _abi.OPT_FILTER_STRIDE2  # stride-2 prefilters wherever they can be built; the walker samples from the seed's parity
     try:
         prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
     except UnsupportedExpression:
@@ -32,6 +34,7 @@ for seed in range(lo, hi):
     rules, _ = H.as_the_engine_sees(rules, prog)
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
     t = Tables(prog.dump())
+    t.filter_phase = seed & 1
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     try:
         H.assert_verdicts_equal(got, want, batch, f"seed {seed}")
