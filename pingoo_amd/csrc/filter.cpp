@@ -363,11 +363,13 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
                     for (uint16_t pr : wd.pairs[j]) key += std::to_string(pr) + ",";
                     key += ";";
                 }
+#ifdef PWAF_PROFILING
                 if (getenv("PWAF_FILTER_DEBUG") && wd.cost > 1e-5) {
                     std::string txt;
                     for (auto &bs : s) { int c = -1, cnt = 0; for (int b = 0; b < 256; b++) if (bs[(size_t)b]) { c = b; cnt++; } txt += cnt == 1 ? (char)c : '#'; }
                     fprintf(stderr, "filter field %d: factor '%s' align %zu window at %zu x%zu cost %.2e (atom %s)\n", g.field, txt.c_str(), al, st, k, wd.cost, at.key.substr(0, 60).c_str());
                 }
+#endif
                 if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
             }
     }
