@@ -280,6 +280,10 @@ int pwaf_engine_device_status(pwaf_engine *);
  * and re-uploads the scan tables. No reference counterpart (the reference interprets each rule per request:
  * pingoo/rules.rs:37-51); the closest analogue is warming its caches. */
 int pwaf_engine_tune(pwaf_engine *, const pwaf_batch *sample);
+/* The host half of the same tuning on a compiled PROGRAM (no device needed): the program's bigram prefilters are replaced by the
+ * ones rebuilt for the sample, and show up in pwaf_program_dump. Lets a deployment (and the CPU tests) inspect what tuning would
+ * do to the tables before any engine exists; an engine is not affected. */
+int pwaf_program_tune(pwaf_program *, const pwaf_batch *sample);
 
 /* evaluate(Request) -> Action: a batch of one (north_star's RuleEngine::evaluate façade). */
 int pwaf_evaluate_one(pwaf_engine *, const pwaf_request *req, pwaf_verdict *out);

@@ -1270,7 +1270,10 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // gated groups run after every ungated one (their factors must have been scanned), and resolve factor columns
     std::stable_partition(P.groups.begin(), P.groups.end(), [](const DfaGroup &g) { return g.filter_atoms.empty(); });
     for (auto &g : P.groups)
-        for (uint32_t fa : g.filter_atoms) g.filter_cols.push_back(P.atoms[fa].id);
+        for (uint32_t fa : g.filter_atoms) {
+            g.filter_cols.push_back(P.atoms[fa].id);
+            P.atoms[fa].gates = true;
+        }
     P.n_scan_cols = next_col - scan_base;
     // field-against-field atoms: one more (pseudo) pass after the DFA passes
     P.fcmp_base = next_col;

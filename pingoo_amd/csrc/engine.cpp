@@ -1545,19 +1545,19 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     return PWAF_OK;
 }
 
-int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
-    if (!e) return fail(PWAF_E_INVALID_ARG, "engine is NULL");
-    int rc = validate_batch_header(sample);
-    if (rc) return rc;
-    if (sample->memory != PWAF_MEM_HOST) return fail(PWAF_E_INVALID_ARG, "pwaf_engine_tune needs a HOST-memory sample");
-    // no evaluate call may enqueue while the tables are rebuilt (calls already enqueued are waited for below)
-    std::vector<std::unique_lock<std::mutex>> ctx_locks;
-    for (auto &c : e->ctx) ctx_locks.emplace_back(c->mu);
-    std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
-    const Program &P = *e->prog.p;
+// The host half of tuning (no device involved): walks every pass over the sample and rebuilds the bigram prefilters for this traffic.
+// Shared by pwaf_engine_tune (which then rebuilds the device tables) and pwaf_program_tune (host-only: the tuned filters replace the
+// program's, so that the table dump shows them — CPU tests interpret tuned tables without a GPU).
+namespace {
+struct TuneOut {
+    std::vector<std::vector<uint64_t>> visits, class_freq;
+    std::vector<GroupFilter> filters;  // per pass
+    std::vector<double> mean_len;      // per field (0 = the sample does not carry it)
+    std::vector<uint32_t> chunks;      // per pass: 16-byte chunks per scan_kernel iteration
+};
+int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
+    const uint32_t n_fields = PWAF_N_FIELDS + (uint32_t)P.header_names.size();
     const uint32_t n = (uint32_t)std::min<uint64_t>(sample->n, 65536);
-    if (n == 0) return PWAF_OK;
     // string column of a field id in the sample (header columns the sample does not carry are left untuned)
     auto sample_col = [&](uint32_t f) -> const pwaf_strcol * {
         if (f < PWAF_N_FIELDS) return &sample->field[f];
@@ -1566,7 +1566,13 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     };
     // host walk of every pass over the sample: how often each DFA state is the current state, and for how many requests each
     // pattern holds (patterns that hold for most traffic must not sit behind the bigram prefilter)
-    std::vector<std::vector<uint64_t>> visits(P.groups.size()), class_freq(P.groups.size()), atom_hits(P.groups.size());
+    std::vector<std::vector<uint64_t>> &visits = T.visits, &class_freq = T.class_freq;
+    std::vector<std::vector<uint64_t>> atom_hits(P.groups.size());
+    visits.assign(P.groups.size(), {});
+    class_freq.assign(P.groups.size(), {});
+    if (T.filters.size() != P.groups.size()) return fail(PWAF_E_INVALID_ARG, "tune: filters must be pre-filled with the filters in use");
+    T.mean_len.assign(n_fields, 0.0);
+    T.chunks.assign(P.groups.size(), 0u);  // 0 = the sample does not carry the pass's column: keep
     for (size_t k = 0; k < P.groups.size(); k++) {
         const DfaGroup &g = P.groups[k];
         std::vector<uint64_t> &v = visits[k];
@@ -1602,9 +1608,9 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     // anchored literals the sample actually satisfies; a filter that would flag more than 40 % of the sample is dropped (the pass
     // then walks every request, as without a filter)
     if (!(P.flags & PWAF_OPT_NO_PREFILTER)) {
-        std::vector<std::vector<double>> pair_prob(e->n_fields);
-        std::vector<double> mean_len(e->n_fields, 0.0);
-        for (uint32_t f = 0; f < e->n_fields; f++) {
+        std::vector<std::vector<double>> pair_prob(n_fields);
+        std::vector<double> &mean_len = T.mean_len;
+        for (uint32_t f = 0; f < n_fields; f++) {
             const pwaf_strcol *c = sample_col(f);
             pair_prob[f].assign(65536, 0.0);
             if (!c) continue;
@@ -1617,7 +1623,6 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             if (tot)
                 for (uint32_t b = 0; b < 65536; b++) pair_prob[f][b] = (double)cnt[b] / (double)tot;
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;
-            e->mean_len[f] = mean_len[f];
         }
         // (the device samples the bigrams of a stride-2 pass at the even bytes of the ARENA: a field's phase is its offset's parity)
         auto flagged = [&](const GroupFilter &f, const pwaf_strcol *sc, uint32_t i) {
@@ -1644,9 +1649,9 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             h.atom_hits = &atom_hits[k];
             h.n_requests = n;
             h.mean_len = mean_len[g.field];
-            GroupFilter &gf = e->groups[k].filter;
+            GroupFilter &gf = T.filters[k];
             const pwaf_strcol *sc = sample_col(g.field);
-            if (!sc) continue;
+            if (!sc) continue;  // (a pass on a column the sample does not carry keeps the filter it has)
             build_group_filter(P.atoms, g, &h, gf, 1);
             if (!gf.enabled) continue;
             gf.est_candidate_rate = sample_rate(gf, sc);
@@ -1669,7 +1674,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
 #endif
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];
-            GroupFilter &gf = e->groups[k].filter;
+            GroupFilter &gf = T.filters[k];
             const pwaf_strcol *sc = sample_col(g.field);
             if (!sc || !gf.enabled) continue;
             if (take_alt && alt[k].enabled) gf = alt[k];
@@ -1677,6 +1682,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
             const uint32_t *off = sc->offsets;
             if (gf.est_candidate_rate > 0.4) {
                 gf.enabled = false;
+                gf.heads.clear();
                 gf.note = "the filter flags more than 40 % of the sample";
                 continue;
             }
@@ -1700,11 +1706,50 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         const uint32_t *off = sc->offsets;
         const uint64_t total = (uint64_t)(off[n] - off[0]);
         const uint32_t t4 = 80u, t2 = 48u;  // mean field length from which a lane takes 4 / 2 chunks per iteration (measured)
-        e->groups[k].chunks = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)t2 * n ? 2u : 1u;
+        T.chunks[k] = total >= (uint64_t)t4 * n ? 4u : total >= (uint64_t)t2 * n ? 2u : 1u;
     }
+    return PWAF_OK;
+}
+}  // namespace
+
+int pwaf_program_tune(pwaf_program *p, const pwaf_batch *sample) {
+    if (!p || !p->p) return fail(PWAF_E_INVALID_ARG, "program is NULL");
+    int rc = validate_batch_header(sample);
+    if (rc) return rc;
+    if (sample->memory != PWAF_MEM_HOST) return fail(PWAF_E_INVALID_ARG, "pwaf_program_tune needs a HOST-memory sample");
+    if (sample->n == 0) return PWAF_OK;
+    TuneOut T;
+    for (const DfaGroup &g : p->p->groups) T.filters.push_back(g.filter);
+    if ((rc = tune_host(*p->p, sample, T))) return rc;
+    for (size_t k = 0; k < p->p->groups.size(); k++) p->p->groups[k].filter = T.filters[k];
+    p->dump.clear();
+    return PWAF_OK;
+}
+
+int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
+    if (!e) return fail(PWAF_E_INVALID_ARG, "engine is NULL");
+    int rc = validate_batch_header(sample);
+    if (rc) return rc;
+    if (sample->memory != PWAF_MEM_HOST) return fail(PWAF_E_INVALID_ARG, "pwaf_engine_tune needs a HOST-memory sample");
+    // no evaluate call may enqueue while the tables are rebuilt (calls already enqueued are waited for below)
+    std::vector<std::unique_lock<std::mutex>> ctx_locks;
+    for (auto &c : e->ctx) ctx_locks.emplace_back(c->mu);
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const Program &P = *e->prog.p;
+    if (sample->n == 0) return PWAF_OK;
+    TuneOut T;
+    for (const DevGroup &d : e->groups) T.filters.push_back(d.filter);
+    if ((rc = tune_host(P, sample, T))) return rc;
+    for (size_t k = 0; k < P.groups.size(); k++) {
+        e->groups[k].filter = T.filters[k];
+        if (T.chunks[k]) e->groups[k].chunks = T.chunks[k];
+    }
+    for (uint32_t f = 0; f < e->n_fields && f < T.mean_len.size(); f++)
+        if (T.mean_len[f] > 0) e->mean_len[f] = T.mean_len[f];
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &visits[k], &class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], &visits[k]))) return rc;
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &T.visits[k], &T.class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], &T.visits[k]))) return rc;
     if ((rc = assign_lists(e))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;

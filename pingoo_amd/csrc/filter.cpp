@@ -310,6 +310,11 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         std::string lit;
         bool s, e;
         if (!at.pattern || !anchored_literal(*at.pattern, lit, s, e) || !s || lit.empty() || lit.size() > 16) continue;
+        // A prefilter factor of a gap pass (`\A/api/` of `^/api/.*foo`) must not become a head: a head is compared by the filter kernel
+        // and only lands in the hit record — the request is neither a bigram candidate nor enqueued for the gap pass, whose `.*` rule
+        // would then silently never match for requests outside the candidate list. It stays in the filter windows;
+        // if that makes most of the sample a candidate, tune drops the filter and the pass streams every request.
+        if (at.gates) continue;
         const double r = rate(l);
         const double hot = r >= 0 ? r : (at.neg_used ? 0.5 : 0.0);
         if (hot >= 0.02) hc.push_back({l, hot, lit, e});

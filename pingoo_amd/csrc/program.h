@@ -75,6 +75,8 @@ struct Atom {
     uint32_t id = 0;           // device column id (assigned at layout time)
     uint32_t min_len = 0;      // SCAN: length of the shortest string the pattern matches (a proxy for how rare a hit is)
     bool neg_used = false;     // the atom occurs negated in some rule term (a hint that most requests satisfy it)
+    bool gates = false;        // SCAN: a prefilter factor of some gap pass (DfaGroup::filter_atoms): a request that satisfies it must reach
+                               // that pass's request list, which only the DFA walk of the owning pass does — never a filter HEAD
     std::string key;           // canonical form for de-duplication
 };
 

@@ -103,6 +103,7 @@ def lib():
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
     L.pwaf_engine_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
+    L.pwaf_program_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
     L.pwaf_node_create.argtypes = create_args + [C.POINTER(C.c_int), C.c_size_t, C.POINTER(vp), C.POINTER(_abi.CompileError)]
     L.pwaf_node_destroy.argtypes = [vp]
     L.pwaf_node_destroy.restype = None
@@ -284,6 +285,13 @@ class CompiledProgram:
 
     def unsupported_rules(self, n_rules: int) -> List[int]:
         return [i for i in range(n_rules) if self.rule_status(i)[0] != 0]
+
+    def tune(self, sample: RequestBatch) -> None:
+        """The host half of RuleEngine.tune on this program alone (no device): the prefilters in the dump become the tuned ones."""
+        st = sample.as_struct(self.header_names)
+        rc = lib().pwaf_program_tune(self._h, C.byref(st))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
 
     def warnings(self) -> List[str]:
         return [lib().pwaf_program_warning(self._h, i).decode(errors="replace") for i in range(lib().pwaf_program_warning_count(self._h))]

@@ -73,6 +73,8 @@ class Tables:
                                   for k in range(n_heads)]  # (literal, exact, local atom)
             elif tag == "GFTB":
                 cur["f_table"] = np.frombuffer(pl, dtype="<u4")
+            elif tag == "GFLT":
+                cur["filter_cols"] = [int(x) for x in np.frombuffer(pl, dtype="<u4")]
             elif tag == "FCMP":
                 self.fcmp = np.frombuffer(pl, dtype=np.dtype([("col", "<u4"), ("op", "u1"), ("a", "u1"), ("b", "u1"), ("pad", "u1")]))
             elif tag == "HDRS":
@@ -111,18 +113,35 @@ class Tables:
                 return True
         return False
 
-    def scan_pass(self, g: dict, data: bytes, cols: set):
-        """One pass as the device runs it: behind its prefilter (heads + DFA for candidates only) when it has one."""
+    def scan_pass(self, g: dict, data: bytes, cols: set, walked: set = None):
+        """One pass as the device runs it: behind its prefilter (heads + DFA for candidates only) when it has one; a GATED gap pass
+        only visits a request when one of its prefilter factors was found by a DFA WALK of the owning pass — that walk is what
+        enqueues the request (a column set by a filter head enqueues nothing). `walked` collects the columns set by walks."""
+        walked = walked if walked is not None else set()
+        if g.get("filter_cols") and self.use_gates:
+            if not (set(g["filter_cols"]) & walked):
+                return
+            self.n_gated_walks += 1
         if "f_table" not in g or not self.use_filter:
-            return self.scan_field(g, data, cols)
+            mine = set()
+            self.scan_field(g, data, mine)
+            cols |= mine
+            walked |= mine
+            return
         if self.filter_candidate(g, data):
             self.n_candidates += 1
-            return self.scan_field(g, data, cols)
+            mine = set()
+            self.scan_field(g, data, mine)
+            cols |= mine
+            walked |= mine
+            return
         for lit, exact, local in g["f_heads"]:
             if data[:len(lit)] == lit and (not exact or len(data) == len(lit)):
                 cols.add(g["atom_base"] + local)
 
     use_filter = True
+    use_gates = True
+    n_gated_walks = 0
     filter_phase = 0  # offset of the first sampled byte of a field (the device: parity of the field's arena offset, stride-2 passes)
     n_candidates = 0
 
@@ -172,8 +191,9 @@ class Tables:
         """Returns (action, rule_idx) for request i of a RequestBatch, exactly as the device pipeline would."""
         cols = {0}
         fields = [batch.field_bytes(f, i) for f in range(5)] + [batch.header_bytes(h, i) for h in getattr(self, "header_names", [])]
+        walked = set()
         for g in self.groups:
-            self.scan_pass(g, fields[g["field"]], cols)
+            self.scan_pass(g, fields[g["field"]], cols, walked)
         for d in getattr(self, "fcmp", []):  # one field against another
             x, y, op = fields[int(d["a"])], fields[int(d["b"])], int(d["op"])
             if [x == y, y in x, x.startswith(y), x.endswith(y), len(x) == len(y), len(x) < len(y), len(x) <= len(y)][op]:

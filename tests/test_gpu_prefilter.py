@@ -180,3 +180,32 @@ def test_stride_two_filters_on_the_device(seed):
     eng.tune(RequestBatch.from_requests(H.lit_requests(rng, 400)))
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, stride 2, tuned")
     eng.close()
+
+
+def test_hot_prefix_factor_of_gated_gap_passes_after_tuning():
+    """`^/api/.*foo.*bar` rules isolated into gated gap passes whose factor `\\A/api/` is hot in the tuning sample.
+    A factor promoted to a filter head would only land in the hit record — requests outside the bigram candidates would never reach
+    the gap passes and their rules would silently never match. Checked before and after tuning, against the oracle."""
+    import test_prefilter as TP
+
+    rules = TP._gated_head_rules()
+    rng = random.Random(11)
+
+    def reqs(n):
+        out = []
+        for _ in range(n):
+            mid = "".join(rng.choice("abcxyz/") for _ in range(rng.randint(0, 12)))
+            a, b = rng.choice([("foo", "bar"), ("select", "from"), ("aa", "bb"), ("cmd", "exe"), ("nope", "never")])
+            pre = rng.choice(["/api/", "/api/", "/api/", "/ap/", "/x/api/"])
+            out.append(Request(path=pre + mid + a + mid + (b if rng.random() < 0.7 else ""), url="/", host="h"))
+        return out
+
+    eng = RuleEngine(rules, {}, max_dfa_states=600)
+    assert eng.stats()["n_gated_groups"] >= 1
+    batch = RequestBatch.from_requests(reqs(6000))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    assert len(set(want["action"].tolist())) >= 2
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "gated gap passes, untuned")
+    eng.tune(RequestBatch.from_requests(reqs(2000)))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "gated gap passes, tuned on traffic where the factor is hot")
+    eng.close()

@@ -113,3 +113,69 @@ def test_stride_two_is_taken_where_the_factors_allow_it():
     assert by_field[4] == 2 and by_field[2] == 2  # ("../" still has one sampled bigram per alignment)
     t1 = table_walker.Tables(CompiledProgram(rules, {}).dump())
     assert {g["f_stride"] for g in t1.groups if "f_table" in g} == {1}
+
+
+def _gated_head_rules():
+    # gap patterns whose anchored prefix factor (`\A/api/`) is ALSO a user-visible atom used under a negation: such an atom is the
+    # textbook filter head (hot = most requests satisfy it) — and it gates the gap passes
+    rules = [("neg", '!http_request.path.starts_with("/api/") && http_request.path.contains("zz9")', [H.B])]
+    for k, (a, b) in enumerate([("foo", "bar"), ("select", "from"), ("x9k2", "q7"), ("admin", "passwd"), ("cmd", "exe"), ("etc", "shadow"), ("union", "all"), ("wp", "php"),
+                                ("aa", "bb"), ("cc", "dd")]):
+        rules.append((f"gap{k}", f'http_request.path.matches("^/api/.*{a}.*{b}")', [H.CAP if k % 2 else H.B]))
+    return rules
+
+
+def test_a_prefilter_factor_of_a_gap_pass_is_never_a_filter_head():
+    """a head is compared by the filter kernel and only lands in the hit record; a request that satisfies it is not
+    enqueued for the gap passes the atom gates. The walker models exactly that (gated passes visit a request only when a factor was
+    found by a DFA walk), so a factor promoted to a head shows up as a verdict mismatch on requests the bigram filter does not flag.
+    Heads are chosen by TUNING (an anchored literal that >= 2 % of the sample satisfies): the program is tuned on traffic where
+    most paths start with the factor."""
+    from pingoo_amd import Request
+
+    rules = _gated_head_rules()
+    prog = CompiledProgram(rules, {}, max_dfa_states=600)
+    rng = random.Random(5)
+
+    def reqs(n):
+        out = []
+        for _ in range(n):
+            mid = "".join(rng.choice("abcxyz/") for _ in range(rng.randint(0, 12)))
+            a, b = rng.choice([("foo", "bar"), ("select", "from"), ("aa", "bb"), ("cmd", "exe"), ("nope", "never")])
+            pre = rng.choice(["/api/", "/api/", "/api/", "/ap/", "/x/api/"])
+            out.append(Request(path=pre + mid + a + mid + (b if rng.random() < 0.7 else ""), url="/", host="h"))
+        return out
+
+    for tuned in (False, True):
+        if tuned:
+            prog.tune(RequestBatch.from_requests(reqs(500)))
+        t = table_walker.Tables(prog.dump())
+        gated = [g for g in t.groups if g.get("filter_cols")]
+        assert gated, "the state budget must force gated gap passes"
+        factor_cols = {c for g in gated for c in g["filter_cols"]}
+        for g in t.groups:
+            for _, _, local in g.get("f_heads", []):
+                assert g["atom_base"] + local not in factor_cols, "a prefilter factor became a filter head"
+        batch = RequestBatch.from_requests(reqs(300))
+        want = pyoracle.Oracle(rules, {}).evaluate(batch)
+        assert len(set(want["action"].tolist())) >= 2
+        for i in range(batch.n):
+            assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (tuned, i, batch.field_bytes(2, i))
+        assert t.n_gated_walks > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tuned_filters_keep_every_verdict(seed):
+    """pwaf_program_tune (the host half of pwaf_engine_tune) rebuilds heads, windows, buckets, hash multiplier and stride from a
+    traffic sample; the tuned tables, interpreted by the walker (with gating), still agree with the oracle on fresh traffic."""
+    rng = random.Random(7700 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 40))
+    prog = CompiledProgram(rules, {}, max_dfa_states=rng.choice([0, 0, 400]))
+    prog.tune(RequestBatch.from_requests(H.lit_requests(rng, 400)))
+    t = table_walker.Tables(prog.dump())
+    batch = RequestBatch.from_requests(H.lit_requests(rng, 120))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    for phase in (0, 1):
+        t.filter_phase = phase
+        for i in range(batch.n):
+            assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, phase, i, [batch.field_bytes(f, i) for f in range(5)])
