@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — requests/s matched by the MI355X WAF batch matcher on BASELINE.json's workload.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 as a plain command it re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` (one rank per GPU); launched by torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
 
 A "step" is one pass of the hot path (filter / scan kernels, list scans, attribute and verdict kernels) over one batch of
 synthetic requests that is already resident in HBM. Default workload: BASELINE.json configs[2] — 10M requests x 1024 rules
 (600 literal + 200 regex + 124 CIDR lists + 100 GeoIP/ASN rules, 600k-prefix GeoIP table) — the configuration the metric
 ("1k-rule WAF") is quoted on; it fits one GPU. With N GPUs every rank evaluates its own slab of the same seeded stream (weak
-scaling); the only collective is the RCCL all-reduce of the four action counters.
+scaling); the only collective is the RCCL all-reduce of the four action counters (`rccl_ranks` = the world size that all-reduce saw).
 `--config 5` is BASELINE.json configs[4]: 4096 rules over 5 + 64 string fields (header-field extension), 1M-request batches,
-with per-batch latency percentiles.
+with per-batch latency percentiles; the default run carries a short leg of it as `config5`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline       HBM roofline of the dominant kernel (filter_kernel: the launch that streams the request bytes), from HIP events
                  recorded on the launch stream during the timed steps; algorithmic bytes per SURVEY.md §8(d) / DESIGN.md §6
   traffic_modes  the same engine UNTUNED (no traffic sample) and on the ADVERSARIAL variant of the stream (near misses of the rule
                  literals, maximum-length fields), next to the headline (tuned on a benign sample disjoint from the timed batch)
+  config5        BASELINE.json configs[4] on this GPU: requests/s, per-batch latency p50 / p99, adversarial, untuned
   cpu_baseline   the CPU oracle ("port": a restatement of the reference's interpreter loop, NOT the Rust binary) timed on this
                  box's host cores over a bounded sample of the same request stream (rank 0, N=1 only)
 """
@@ -24,112 +28,89 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~5.4-6.3 TB/s is the measured copy ceiling
+DEFAULT_N = {1: 10_000, 2: 1_000_000, 3: 10_000_000, 5: 1_000_000}
+TUNE_N = 32768
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, help="synthetic config id (BASELINE.json configs[id-1]); default 3")
-    ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
-    ap.add_argument("--lds-budget", type=int, default=0)
-    ap.add_argument("--adversarial", action="store_true", help="time the adversarial variant of the stream as the HEADLINE batch (the tuning sample stays benign)")
-    ap.add_argument("--no-extra-modes", action="store_true", help="skip the untuned and adversarial side runs (traffic_modes)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) measurements")
-    ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: step i is issued on stream i mod INFLIGHT (pwaf_evaluate_device is re-entrant: every call takes "
-                                                            "its own scratch context), so one batch's small latency-bound kernels run under the next batch's streaming kernels")
-    args = ap.parse_args()
+def pct(xs, p):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(p / 100.0 * (len(xs) - 1))))]
 
-    import numpy as np
-    import torch
 
-    from pingoo_amd import shard
-    from pingoo_amd.engine import DeviceBatch, RuleEngine
-    from synth import pysynth
+def self_launch(args_list, n):
+    """`python bench.py --gpus N` as a plain command: become N ranks (one per GPU) under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + args_list
+    os.execv(sys.executable, cmd)
 
-    rank, world, local = shard.env_rank()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local)
-    shard.init_process_group()
-    dev = torch.device("cuda", local)
 
-    default_n = {1: 10_000, 2: 1_000_000, 3: 10_000_000, 5: 1_000_000}.get(args.config, 100_000)
-    n = args.requests or default_n
-    threads = max(1, (os.cpu_count() or 1) // world)
-    extras = world == 1 and not args.no_extra_modes and not os.environ.get("PWAF_BENCH_NO_TUNE")
+class Runner:
+    """One engine + one HBM-resident batch: timed steps, per-kernel summaries."""
 
-    t0 = time.time()
-    wl = pysynth.Workload(args.config)
-    batch = wl.batch(rank * n, n, threads=threads, adversarial=args.adversarial)  # this rank's slab of the global seeded request stream
-    t_gen = time.time() - t0
-    t0 = time.time()
-    opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
-    eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
-    t_compile = time.time() - t0
-    stats = eng.stats()
-    dbatch = DeviceBatch(batch, dev)
-    inflight = max(1, min(args.inflight, 3))
-    n_streams = max(inflight, 2)
-    outs = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(n_streams)]
-    cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_streams)]
-    # one batch in flight: torch's current stream; several: streams of their own (the current stream is HIP's NULL stream, which
-    # synchronises with every other blocking stream — no two batches would overlap)
-    own_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
-    out, counts = outs[0], cnts[0]
+    def __init__(self, eng, n, dev, world, inflight):
+        import torch
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
+        self.torch, self.eng, self.n, self.dev, self.world = torch, eng, n, dev, world
+        self.inflight = inflight
+        n_streams = max(inflight, 2)
+        self.outs = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(n_streams)]
+        self.cnts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_streams)]
+        # one batch in flight: torch's current stream; several: streams of their own (the current stream is HIP's NULL stream, which
+        # synchronises with every other blocking stream — no two batches would overlap)
+        self.own_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+        self.issue_ms = 0.0
 
-    issue_ms = [0.0]
+    def barrier(self):
+        if self.world > 1:
+            self.torch.distributed.barrier()
+        self.torch.cuda.synchronize(self.dev)
 
-    def timed_run(db, steps, warmup, inflight=inflight):
+    def timed_run(self, db, steps, warmup, inflight=None, events=True):
         """W untimed + K timed steps over the resident batch `db`; returns (seconds, kernel times, action counters)."""
-        streams = [torch.cuda.current_stream(dev)] if inflight == 1 else own_streams
+        from pingoo_amd import shard
+
+        torch = self.torch
+        inflight = inflight or self.inflight
+        streams = [torch.cuda.current_stream(self.dev)] if inflight == 1 else self.own_streams
 
         def step(i):
             k = i % inflight
             with torch.cuda.stream(streams[k]):
-                cnts[k].zero_()
-                eng.evaluate_device(db, out=outs[k], counts=cnts[k], stream=streams[k].cuda_stream)
-                shard.allreduce_counts(cnts[k])  # the path's only exchange: 4 counters over RCCL/xGMI
+                self.cnts[k].zero_()
+                self.eng.evaluate_device(db, out=self.outs[k], counts=self.cnts[k], stream=streams[k].cuda_stream)
+                shard.allreduce_counts(self.cnts[k])  # the path's only exchange: 4 counters over RCCL/xGMI
 
         for i in range(warmup):
             step(i)
-        barrier()
-        eng.set_profiling(not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream
-        barrier()
+        self.barrier()
+        self.eng.set_profiling(events and not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream
+        self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
-        issue_ms[0] = 1e3 * (time.perf_counter() - t0) / steps  # host time to enqueue one step (the device runs behind it)
-        barrier()
+        self.issue_ms = 1e3 * (time.perf_counter() - t0) / steps  # host time to enqueue one step (the device runs behind it)
+        self.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        kt = eng.kernel_times()
-        eng.set_profiling(False)
-        return elapsed, kt, counts.cpu().tolist()
+        kt = self.eng.kernel_times()
+        self.eng.set_profiling(False)
+        return elapsed, kt, self.cnts[0].cpu().tolist()
 
+    @staticmethod
     def stream_kernels(kt):
         """Launches that stream request bytes: filter_kernel (passes behind a bigram prefilter: arenas as flat byte streams) and
         scan_kernel (a DFA over every request). The engine reports each launch's algorithmic bytes — every byte of a streamed
@@ -147,28 +128,153 @@ def main():
                 other[k2] = other.get(k2, 0.0) + ms
         return kinds, other
 
-    def mode_summary(elapsed, kt, steps):
-        kinds, _ = stream_kernels(kt)
+    def mode_summary(self, elapsed, kt, steps):
+        kinds, _ = self.stream_kernels(kt)
         dom = max(kinds, key=lambda kk: kinds[kk][0])
         ms, _, nbytes = kinds[dom]
         ach = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
         per = {}
         for name, kms, _ in kt:
             per[name] = per.get(name, 0.0) + kms / steps
-        return {"requests_per_s": n * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
+        return {"requests_per_s": self.n * self.world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
                 "kernels_ms_per_step": {k: round(v, 4) for k, v in per.items()}}
+
+    def batch_latency(self, db, calls=40):
+        """Per-batch latency: one synchronised device-resident call per batch."""
+        torch = self.torch
+        lat = []
+        for _ in range(calls):
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            self.eng.evaluate_device(db, out=self.outs[0])
+            torch.cuda.synchronize(self.dev)
+            lat.append(1e3 * (time.perf_counter() - t0))
+        return {"p50": pct(lat, 50), "p99": pct(lat, 99), "max": max(lat)}
+
+
+def native_batcher_bench(eng, hb):
+    """tools/batcher_bench (C++, 64 pthreads over pwaf_batcher_evaluate): what a native per-request host sees. None when the
+    harness has not been built."""
+    try:
+        from pingoo_amd.engine import native_batcher_latency
+    except ImportError:
+        return None
+    try:
+        return native_batcher_latency(eng, hb)
+    except Exception as exc:  # informational only
+        print(f"native batcher benchmark failed: {exc}", file=sys.stderr)
+        return None
+
+
+def config5_leg(dev, threads, steps, verbose):
+    """BASELINE.json configs[4] on one GPU, short: 4096 rules over 5 + 64 string fields, 1M-request batches (the per-GPU batch of the
+    50M-request / 8-GPU configuration is 6.25M: `--config 5 --requests 6250000` times that). Tuned on a benign sample."""
+    import torch
+
+    from pingoo_amd.engine import DeviceBatch, RuleEngine
+    from synth import pysynth
+
+    n = DEFAULT_N[5]
+    t0 = time.time()
+    wl = pysynth.Workload(5)
+    eng = RuleEngine(wl.rules, wl.lists, wl.geoip)
+    db = DeviceBatch(wl.batch(0, n, threads=threads), dev)
+    r = Runner(eng, n, dev, 1, 1)
+    out = {"workload": f"BASELINE.json configs[4] per GPU: {n} requests x {len(wl.rules)} rules, {len(eng.header_names)} header fields, benign stream; device-resident"}
+    el, kt, _ = r.timed_run(db, max(2, steps // 2), 1)
+    out["untuned"] = {k: v for k, v in r.mode_summary(el, kt, max(2, steps // 2)).items() if k in ("requests_per_s", "ms_per_step", "frac")}
+    eng.tune(wl.batch(n, TUNE_N, threads=threads))
+    el, kt, cnt = r.timed_run(db, steps, 2)
+    head = r.mode_summary(el, kt, steps)
+    out.update({"requests_per_s": head["requests_per_s"], "ms_per_step": head["ms_per_step"], "kernel": head["kernel"], "frac": head["frac"],
+                "kernels_ms_per_step": head["kernels_ms_per_step"], "action_counts_allow_block_captcha_bypass": cnt})
+    out["latency_ms"] = dict(r.batch_latency(db, 40), batch=n, calls=40)
+    adv = DeviceBatch(wl.batch(0, n, threads=threads, adversarial=True), dev)
+    el, kt, acnt = r.timed_run(adv, max(2, steps // 2), 1)
+    a = r.mode_summary(el, kt, max(2, steps // 2))
+    out["adversarial"] = {"requests_per_s": a["requests_per_s"], "ms_per_step": a["ms_per_step"], "frac": a["frac"], "kernels_ms_per_step": a["kernels_ms_per_step"],
+                          "latency_ms": r.batch_latency(adv, 20), "action_counts_allow_block_captcha_bypass": acnt}
+    out["adversarial_over_benign"] = a["ms_per_step"] / head["ms_per_step"]
+    out["setup_s"] = round(time.time() - t0, 1)
+    del adv, db
+    eng.close()
+    torch.cuda.empty_cache()
+    if verbose:
+        print(f"[bench] config5 leg: {json.dumps(out)}", file=sys.stderr)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, help="synthetic config id (BASELINE.json configs[id-1]); default 3")
+    ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
+    ap.add_argument("--lds-budget", type=int, default=0)
+    ap.add_argument("--adversarial", action="store_true", help="time the adversarial variant of the stream as the HEADLINE batch (the tuning sample stays benign)")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the untuned and adversarial side runs (traffic_modes)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the short BASELINE configs[4] leg of the default run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) and micro-batcher measurements")
+    ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: step i is issued on stream i mod INFLIGHT (pwaf_evaluate_device is re-entrant: every call takes "
+                                                            "its own scratch context), so one batch's small latency-bound kernels run under the next batch's streaming kernels")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)  # does not return
+
+    import numpy as np
+    import torch
+
+    from pingoo_amd import shard
+    from pingoo_amd.engine import DeviceBatch, RuleEngine
+    from synth import pysynth
+
+    rank, world, local = shard.env_rank()
+    args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({torch.cuda.device_count()} visible): --gpus {world} needs {world} GPUs on this node")
+    torch.cuda.set_device(local)
+    shard.init_process_group()
+    dev = torch.device("cuda", local)
+    # the world size the counters' all-reduce actually sees (1 = no collective ran)
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    shard.allreduce_counts(ones)
+    rccl_ranks = int(ones.item())
+
+    n = args.requests or DEFAULT_N.get(args.config, 100_000)
+    threads = max(1, (os.cpu_count() or 1) // world)
+    extras = world == 1 and not args.no_extra_modes and not os.environ.get("PWAF_BENCH_NO_TUNE")
 
     def phase(msg):
         if args.verbose and rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    t0 = time.time()
+    wl = pysynth.Workload(args.config)
+    batch = wl.batch(rank * n, n, threads=threads, adversarial=args.adversarial)  # this rank's slab of the global seeded request stream
+    t_gen = time.time() - t0
+    t0 = time.time()
+    opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
+    eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
+    t_compile = time.time() - t0
+    stats = eng.stats()
+    dbatch = DeviceBatch(batch, dev)
+    inflight = max(1, min(args.inflight, 3))
+    R = Runner(eng, n, dev, world, inflight)
+
     traffic_modes = {}
-    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else 32768
+    tune_n = 0 if os.environ.get("PWAF_BENCH_NO_TUNE") else TUNE_N
     if extras:
         # the engine as created: default filter tables and BFS-order LDS rows, no traffic sample
         phase("untuned run")
-        el, kt, _ = timed_run(dbatch, max(2, args.steps // 2), 1)
-        traffic_modes["untuned_benign"] = mode_summary(el, kt, max(2, args.steps // 2))
+        el, kt, _ = R.timed_run(dbatch, max(2, args.steps // 2), 1)
+        traffic_modes["untuned_benign"] = R.mode_summary(el, kt, max(2, args.steps // 2))
     if tune_n:
         # profile-guided tables from a traffic sample DISJOINT from the timed batch (a deployment would sample live traffic): bigram
         # statistics and heads of the prefilters, LDS-resident DFA rows; verdicts do not depend on it. The sample is always BENIGN.
@@ -178,25 +284,26 @@ def main():
         t_compile += time.time() - t0
 
     phase("headline run")
-    elapsed, ktimes, final_counts = timed_run(dbatch, args.steps, args.warmup)
+    elapsed, ktimes, final_counts = R.timed_run(dbatch, args.steps, args.warmup)
     value = n * world * args.steps / elapsed
-    head = mode_summary(elapsed, ktimes, args.steps)
-    head["host_enqueue_ms_per_step"] = round(issue_ms[0], 3)
-    headline_out = out[: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite `out`)
+    head = R.mode_summary(elapsed, ktimes, args.steps)
+    head["host_enqueue_ms_per_step"] = round(R.issue_ms, 3)
+    headline_out = R.outs[0][: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite the buffer)
 
     if extras and inflight == 1:
         # the same batch with TWO batches in flight (step i on stream i mod 2; pwaf_evaluate_device is re-entrant: every call takes its
         # own scratch context): one batch's small latency-bound kernels run under the next batch's streaming kernels. Throughput only —
         # per-kernel durations (and anything derived from them, like the roofline object) are quoted for one batch at a time.
         phase("two batches in flight")
-        el, kt, _ = timed_run(dbatch, max(4, args.steps), 2, inflight=2)
-        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * max(4, args.steps) / el, "ms_per_step": 1e3 * el / max(4, args.steps),
-                                                                "host_enqueue_ms_per_step": round(issue_ms[0], 3)}
+        k2 = max(4, args.steps)
+        el, kt, _ = R.timed_run(dbatch, k2, 2, inflight=2)
+        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * k2 / el, "ms_per_step": 1e3 * el / k2, "host_enqueue_ms_per_step": round(R.issue_ms, 3)}
     if extras and not args.adversarial:
         phase("adversarial run")
         adv = DeviceBatch(wl.batch(rank * n, n, threads=threads, adversarial=True), dev)
-        el, kt, adv_counts = timed_run(adv, max(2, args.steps // 2), 1)
-        traffic_modes["adversarial_tuned_on_benign"] = dict(mode_summary(el, kt, max(2, args.steps // 2)), action_counts_allow_block_captcha_bypass=adv_counts)
+        ka = max(2, args.steps // 2)
+        el, kt, adv_counts = R.timed_run(adv, ka, 1)
+        traffic_modes["adversarial_tuned_on_benign"] = dict(R.mode_summary(el, kt, ka), action_counts_allow_block_captcha_bypass=adv_counts)
         del adv
     traffic_modes["tuned_benign" if not args.adversarial else "adversarial_tuned_on_benign (headline)"] = head
 
@@ -214,6 +321,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
+        "rccl_ranks": rccl_ranks,
         "config": {
             "workload": f"BASELINE.json configs[{args.config - 1}]: {n} requests/GPU x {len(wl.rules)} rules "
                         f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} DFA passes, {stats['n_filtered_groups']} of them behind a bigram prefilter, "
@@ -225,13 +333,15 @@ def main():
             "parallelism": f"requests sharded over {world} GPU(s), tables replicated, RCCL all-reduce of 4 counters",
             "batches_in_flight": inflight,
             "action_counts_allow_block_captcha_bypass": final_counts,
+            "parity_note": "verdicts of the timed batch are checked against the CPU oracle on the cpu_baseline sample (a prefix of the batch), not on all of it: "
+                           "the oracle evaluates ~14k requests/s",
         },
     }
 
     if rank == 0:
-        kinds, other_ms = stream_kernels(ktimes)
+        kinds, other_ms = R.stream_kernels(ktimes)
         verdict_ms = other_ms.pop("verdict", 0.0)
-        attr_ms = other_ms.pop("attr", 0.0)  # side stream, beside the filter
+        attr_ms = other_ms.pop("attr", 0.0)  # side stream
         dom = head["kernel"]
         scan_ms, n_scan_launches, scan_alg = kinds[dom]
         stream_ms = sum(v[0] for v in kinds.values())
@@ -247,8 +357,10 @@ def main():
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes over this very
         # command (tools/profile_round.sh), committed under profiles/ and only quoted for the workload they were measured on
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
-        if args.config == 3 and n == 10_000_000 and not args.adversarial and os.path.exists(tpath):
+        for tname in ("r3_traffic.json", "r2_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is not None or not (args.config == 3 and n == 10_000_000 and not args.adversarial and os.path.exists(tpath)):
+                continue
             try:
                 tj = json.load(open(tpath))
                 want = {"filter_kernel<stride 1>": ("::filter_kernel<", ", 1>"), "filter_kernel<stride 2>": ("::filter_kernel<", ", 2>"), "scan_kernel": ("::scan_kernel<", "")}[dom]
@@ -256,7 +368,7 @@ def main():
                 if not sk:
                     raise KeyError(dom)  # the committed passes predate this kernel: no figure rather than a wrong one
                 traffic = sum(sum(v["fetch_bytes"]) + sum(v["write_bytes"]) for v in sk) // max(1, sum(v["launches"] for v in sk))
-                traffic_src = f"profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor {sk[0].get('fetch_factor', 2) if sk else '?'} for this kernel, see tools/pmc_traffic.py; taken at commit {tj.get('commit', '?')})"
+                traffic_src = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor {sk[0].get('fetch_factor', 2) if sk else '?'} for this kernel, see tools/pmc_traffic.py; taken at commit {tj.get('commit', '?')})"
             except Exception:  # a malformed profile file must not break the bench line
                 traffic, traffic_src = None, None
         kernel_s = (stream_ms + verdict_ms + sum(other_ms.values())) / 1000.0  # (the attribute kernel runs beside these on a side stream)
@@ -279,6 +391,7 @@ def main():
                 "alg_bytes_per_request": dbatch.algorithmic_bytes / n,
                 "achieved": pipeline_alg / kernel_s / 1e9 if kernel_s > 0 else 0.0,
                 "frac": (pipeline_alg / kernel_s / 1e9 / HBM_PEAK_GBS) if kernel_s > 0 else 0.0,
+                "frac_of_step_wall_time": dbatch.algorithmic_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "streaming_launches": {k: {"ms_per_step": v[0] / args.steps, "alg_bytes_per_step": v[2] // args.steps,
                                            "achieved": (v[2] / (v[0] / 1e3) / 1e9) if v[0] > 0 else 0.0, "frac": (v[2] / (v[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if v[0] > 0 else 0.0}
                                        for k, v in kinds.items() if v[1]},
@@ -312,21 +425,10 @@ def main():
             result["roofline"]["peak_measured_copy_gbs"] = None
             print(f"copy-bandwidth probe failed: {exc}", file=sys.stderr)
 
-        def pct(xs, p):
-            xs = sorted(xs)
-            return xs[min(len(xs) - 1, int(round(p / 100.0 * (len(xs) - 1))))]
-
         if world == 1 and args.config == 5:
             # per-batch latency (BASELINE.json configs[4]): one synchronised call per batch, device-resident
             phase("latency calls")
-            lat = []
-            for _ in range(40):
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                eng.evaluate_device(dbatch, out=out)
-                torch.cuda.synchronize(dev)
-                lat.append(1e3 * (time.perf_counter() - t0))
-            result["latency_ms"] = {"batch": n, "calls": len(lat), "device_resident": {"p50": pct(lat, 50), "p99": pct(lat, 99), "max": max(lat)}}
+            result["latency_ms"] = {"batch": n, "calls": 40, "device_resident": R.batch_latency(dbatch, 40)}
         if world == 1 and not args.no_pcie:
             # host batch in, verdicts out through pwaf_evaluate_batch: H2D + kernels + D2H, on a bounded slice of the same batch
             phase("host-batch (PCIe-inclusive) calls")
@@ -351,6 +453,7 @@ def main():
             import threading
 
             n_thr, per_thr = 3, 4
+
             def host_caller():
                 for _ in range(per_thr):
                     eng.evaluate_batch(hb)
@@ -362,34 +465,19 @@ def main():
                 t.join()
             dt = time.perf_counter() - t0
             result["pcie_inclusive"]["pipelined"] = {"value": n_thr * per_thr * m / dt, "unit": "requests/s", "sample": f"{n_thr} caller threads x {per_thr} synchronous calls of {m} requests each"}
-            # deadline micro-batcher (the evaluate(Request) -> Action façade): 64 caller threads, 200 us deadline, per-request latency
-            from pingoo_amd import Request
-            from pingoo_amd.engine import MicroBatcher
-
-            mb = MicroBatcher(eng, max_batch=4096, max_delay_us=200)
-            sample_reqs = [Request(host=hb.field_bytes(0, i), url=hb.field_bytes(1, i), path=hb.field_bytes(2, i), method=hb.field_bytes(3, i), user_agent=hb.field_bytes(4, i),
-                                   ip="203.0.113.%d" % (i % 250 + 1), remote_port=int(hb.port[i])) for i in range(256)]
-            lats, lock = [], threading.Lock()
-            def req_caller(k):
-                mine = []
-                for j in range(150):
-                    t1 = time.perf_counter()
-                    mb.evaluate(sample_reqs[(k * 7 + j) % 256])
-                    mine.append(1e3 * (time.perf_counter() - t1))
-                with lock:
-                    lats.extend(mine)
-            th = [threading.Thread(target=req_caller, args=(k,)) for k in range(64)]
-            t0 = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            dt = time.perf_counter() - t0
-            nb, nr = mb.stats()
-            mb.close()
-            result["batcher"] = {"caller_threads": 64, "requests": len(lats), "max_batch": 4096, "deadline_us": 200, "batches": nb, "requests_per_s": len(lats) / dt,
-                                 "latency_ms": {"p50": pct(lats, 50), "p99": pct(lats, 99), "max": max(lats)},
-                                 "note": "Python caller threads (GIL-bound between calls): an upper bound on what a native host would see"}
+            # deadline micro-batcher (the evaluate(Request) -> Action façade) driven by NATIVE caller threads (tools/batcher_bench.cpp:
+            # 64 pthreads, 200 us deadline): per-request latency as a compiled host would see it
+            phase("micro-batcher (native callers)")
+            nb = native_batcher_bench(eng, hb)
+            if nb is not None:
+                result["batcher"] = nb
+        if world == 1 and args.config == 3 and not args.no_config5 and extras:
+            phase("config 5 leg")
+            # (the 10M-request batch and its scratch stay resident: config 5 adds ~6 GB)
+            try:
+                result["config5"] = config5_leg(dev, threads, max(4, args.steps), args.verbose)
+            except Exception as exc:  # the headline line must survive a failure of the side leg
+                result["config5"] = {"error": repr(exc)}
         # ---- CPU baseline: the oracle (port of the reference's per-request interpreter loop) on host cores ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle

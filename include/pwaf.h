@@ -334,7 +334,8 @@ typedef struct pwaf_stats {
     uint32_t n_rules, n_atoms, n_scan_atoms, n_numeric_atoms;
     uint32_t n_dfa_groups, n_dfa_states_total, max_dfa_states, dfa_table_bytes_total;
     uint32_t n_ip_lists, ipset_trie_nodes, geo_trie_nodes, n_dnf_literals;
-    uint32_t n_warnings, n_filtered_groups /* passes behind a bigram prefilter */, reserved[2];
+    uint32_t n_warnings, n_filtered_groups /* passes behind a bigram prefilter */,
+        n_gated_groups /* gap passes visited only by requests whose prefix factor was found */, reserved[1];
 } pwaf_stats;
 int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
 int pwaf_program_stats(const pwaf_program *, pwaf_stats *out);

@@ -136,7 +136,7 @@ class Stats(C.Structure):
         ("n_rules", C.c_uint32), ("n_atoms", C.c_uint32), ("n_scan_atoms", C.c_uint32), ("n_numeric_atoms", C.c_uint32),
         ("n_dfa_groups", C.c_uint32), ("n_dfa_states_total", C.c_uint32), ("max_dfa_states", C.c_uint32), ("dfa_table_bytes_total", C.c_uint32),
         ("n_ip_lists", C.c_uint32), ("ipset_trie_nodes", C.c_uint32), ("geo_trie_nodes", C.c_uint32), ("n_dnf_literals", C.c_uint32),
-        ("n_warnings", C.c_uint32), ("n_filtered_groups", C.c_uint32), ("reserved", C.c_uint32 * 2),
+        ("n_warnings", C.c_uint32), ("n_filtered_groups", C.c_uint32), ("n_gated_groups", C.c_uint32), ("reserved", C.c_uint32 * 1),
     ]
 
 

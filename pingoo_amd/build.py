@@ -24,23 +24,27 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (needed to build pingoo_amd/libpwaf.so)")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def is_stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
+def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
+    """variant "prof": libpwaf_prof.so, the -DPWAF_PROFILING build (timing-experiment switches for tools/*.sh; never the product)."""
+    lib = LIB if not variant else os.path.join(HERE, f"libpwaf_{variant}.so")
+    if not force and not is_stale(lib):
+        return lib
     objs = []
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", os.path.join(HERE, "..", "include")]
     # PWAF_EXTRA_CXXFLAGS=-DPWAF_PROFILING builds the timing-experiment variant (env switches that change results); never the default
     common += os.environ.get("PWAF_EXTRA_CXXFLAGS", "").split()
+    if variant == "prof":
+        common.append("-DPWAF_PROFILING")
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
@@ -63,12 +67,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, variant="prof" if "--prof" in sys.argv else ""))

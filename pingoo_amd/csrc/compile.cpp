@@ -1419,6 +1419,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         s.max_dfa_states = std::max(s.max_dfa_states, g.n_states);
         s.dfa_table_bytes_total += g.n_states * g.n_classes * 2;
         if (g.filter.enabled) s.n_filtered_groups++;
+        if (!g.filter_atoms.empty()) s.n_gated_groups++;
     }
     s.n_ip_lists = P.n_ip_lists;
     s.ipset_trie_nodes = P.ipset_trie.n_nodes();

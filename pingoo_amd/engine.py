@@ -26,7 +26,9 @@ from . import _abi
 from .batch import VERDICT_DTYPE, Request, RequestBatch
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpwaf.so")
+# PWAF_LIB_VARIANT=prof loads libpwaf_prof.so, the -DPWAF_PROFILING build with the timing-experiment switches (tools/ only: results may
+# be wrong when a switch is set). Nothing else is ever loaded: there is no fallback of any kind.
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpwaf_prof.so" if os.environ.get("PWAF_LIB_VARIANT") == "prof" else "libpwaf.so")
 
 
 class PwafError(RuntimeError):
