@@ -341,7 +341,7 @@ def main():
     if rank == 0:
         kinds, other_ms = R.stream_kernels(ktimes)
         verdict_ms = other_ms.pop("verdict", 0.0)
-        attr_ms = other_ms.pop("attr", 0.0)  # side stream
+        attr_ms = other_ms.pop("attr", 0.0) + other_ms.pop("ipres", 0.0)  # side stream: address lookups, then rows / transposes / comparisons
         dom = head["kernel"]
         scan_ms, n_scan_launches, scan_alg = kinds[dom]
         stream_ms = sum(v[0] for v in kinds.values())

@@ -91,7 +91,6 @@ struct DevGroup {
     DevBuf ftable;
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
-    uint32_t flat_hot = 0;  // rows of `flat` lscan_kernel stages in LDS
     bool short_lit = false;  // every atom is an anchored literal of <= 8 bytes: evaluated by the attribute kernel, the pass is never walked
 };
 
@@ -110,6 +109,7 @@ struct Scratch {
     bool last_own = false;       // ... which was the context's own stream (a host batch)
     DevBuf status;            // one sticky word: bit 0 = some batch on this context exhausted the overflow pool (cleared when reported)
     uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
+    DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
     DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
@@ -139,7 +139,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -346,7 +346,6 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
         end_off.push_back((uint32_t)end_list.size());
     }
-    d.flat_hot = std::min<uint32_t>(S, kListHotBytes / (2u * C));
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     int rc;
     if ((rc = upload(d.flat, flat, 4))) return rc;  // (the LDS staging copies whole 32-bit words)
@@ -390,6 +389,8 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.class_words = e->class_words;
     v.acmp_words = e->acmp_words;
     v.geo_default = e->geo_default;
+    const size_t n_sets = P.set_words ? P.set_masks.size() / P.set_words : 1;
+    v.ipres_packed = (e->n_classes <= 65536u && n_sets <= 65536u) ? 1u : 0u;
 }
 
 // Decides which passes are list-driven and uploads what that needs: a pass behind a bigram prefilter walks the filter's candidate
@@ -710,6 +711,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.n_rules = (uint32_t)P.rules.size();
     v.lits = (const uint32_t *)e->lits.p;
     set_trie_args(e, v);
+    if ((rc = S.ipres.reserve((size_t)n * (v.ipres_packed ? 4 : 8) + 64))) return rc;
+    v.ipres = (uint32_t *)S.ipres.p;
     v.out = d_out;
     v.counts = (unsigned long long *)d_counts;
     v.match_idx = d_match_idx;
@@ -728,12 +731,21 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         HIP_TRY(hipStreamWaitEvent(S.side, S.ev_fork, 0));
         if ((rc2 = mark(nullptr, 0, S.side))) return rc2;
         {
+            int he = 0;
 #ifdef PWAF_PROFILING
             static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
+            static const bool skip_ipres = getenv("PWAF_SKIP_IPRES") != nullptr;  // ... every address resolves to class 0 / set 0
             if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, S.side));
-            int he = skip_attr ? 0 : launch_attr(v, S.side);
+            if (skip_ipres) HIP_TRY(hipMemsetAsync(v.ipres, 0, (size_t)n * 8, S.side));
+            if (!skip_attr && !skip_ipres) he = launch_ipres(v, S.side);
+            if (!he && (rc2 = mark("ipres", 0xFAu, S.side))) return rc2;
+            if (!he && (rc2 = mark(nullptr, 0, S.side))) return rc2;
+            if (!he && !skip_attr) he = launch_attr(v, S.side);
 #else
-            int he = launch_attr(v, S.side);
+            he = launch_ipres(v, S.side);
+            if (!he && (rc2 = mark("ipres", 0xFAu, S.side))) return rc2;
+            if (!he && (rc2 = mark(nullptr, 0, S.side))) return rc2;
+            if (!he) he = launch_attr(v, S.side);
 #endif
             if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         }
@@ -780,6 +792,12 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.status = (uint32_t *)S.status.p;
         return a;
     };
+    uint32_t list_variant = 0;
+#ifdef PWAF_PROFILING
+    static const uint32_t forced_shape = getenv("PWAF_LIST_SHAPE") ? (uint32_t)atoi(getenv("PWAF_LIST_SHAPE")) : 0u;  // timing experiments (same results)
+    list_variant = forced_shape;
+#endif
+    const ListShape lshape = list_shape(list_variant);
     auto list_args = [&](size_t gi) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
@@ -809,7 +827,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
-        a.n_hot = d.flat_hot;
+        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * d.n_classes));  // (states are in visit order: the first rows are the hot ones)
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
@@ -955,15 +973,18 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
 #endif
                 la[phase].push_back(list_args(gi));
             }
-        if ((rc = S.args_list.reserve((la[0].size() + la[1].size() + 1) * sizeof(ListScanArgs)))) return rc;
+        const size_t n_desc = la[0].size() + la[1].size();
+        if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (n_desc + 2) * 4))) return rc;
         ListScanArgs *d_at = (ListScanArgs *)S.args_list.p;
+        uint32_t *plan_at = (uint32_t *)((char *)S.args_list.p + (n_desc + 1) * sizeof(ListScanArgs));  // work-item prefix sums, one set per phase
         for (int phase = 0; phase < 2; phase++) {
             const uint32_t cnt = (uint32_t)la[phase].size();
             if (!cnt) continue;
             int he = upload_list_args(la[phase].data(), cnt, d_at, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc = mark(nullptr, 0))) return rc;
-            he = launch_scan_gated(la[phase].data(), cnt, d_at, stream);
+            he = launch_scan_gated(la[phase].data(), cnt, d_at, plan_at, lshape, stream);
+            plan_at += cnt + 1;
             if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             char nm[48];
             snprintf(nm, sizeof nm, "lscan_x%u", cnt);

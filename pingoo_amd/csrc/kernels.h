@@ -77,7 +77,7 @@ struct ListScanArgs {
     const uint16_t *flat;
     const uint8_t *classmap;  // 256 bytes
     uint32_t n_classes;
-    uint32_t n_hot;            // rows staged in LDS: n_hot * n_classes * 2 <= kListHotBytes
+    uint32_t n_hot;            // rows staged in LDS: n_hot * n_classes * 2 <= the launch's ListShape::hot_bytes
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;
@@ -259,6 +259,8 @@ struct VerdictArgs {
     uint32_t class_words;
     uint32_t acmp_words;          // asn-comparison words per class row
     uint32_t geo_default;         // class of the default record {0, "XX"}
+    uint32_t *ipres;              // per-batch scratch, ipres_kernel -> attr_kernel: GeoIP class and membership-set id of every request
+    uint32_t ipres_packed;        // 1: one word per request (class | set << 16: both fit 16 bits), 0: two words
     uint32_t has_geo;
     // attribute kernel -> verdict kernel: per 64-request group the (column, mask) pairs of every non-scan atom that holds for
     // some request of the group. gpairs[g * pair_stride + k] = {column, 0, mask lo, mask hi}, ghdr[g] = number of pairs
@@ -285,8 +287,15 @@ struct GatedTable {
     uint32_t count;
 };
 int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream);
-int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, void *stream);
+// Workgroup shape of the list scan: threads per workgroup, LDS bytes of hot rows per workgroup, workgroups per CU.
+struct ListShape {
+    uint32_t threads, hot_bytes, wg_per_cu;
+};
+ListShape list_shape(uint32_t variant);  // 0 = default
+// `plan`: count + 1 words of device scratch (the work-item prefix sums, written by lscan_plan_kernel on the same stream)
+int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);
+int launch_ipres(const VerdictArgs &a, void *stream);  // address lookups -> a.ipres; then, on the same stream:
 int launch_attr(const VerdictArgs &a, void *stream);
 int launch_dir24(const VerdictArgs &a, void *out /* 2^24 x u32, or null: count only */, void *esc, void *esc_count, void *stream);
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);

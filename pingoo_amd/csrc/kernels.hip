@@ -459,66 +459,129 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
 template <int CH, bool WIDE>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_body<CH, WIDE>(a); }
 
-// lscan_kernel: every list-driven pass of a phase in ONE launch (blockIdx.y = pass). One listed request per lane, walked byte by
-// byte: per step one LDS read for the byte's class (independent of the state: issued ahead) and one dependent read of the cell —
-// from the LDS copy of the table's hottest rows, or from the flat table in L2 for the others (~10x the latency). The wave-lockstep
-// walk of scan_kernel, built for streaming EVERY request, took 0.6 ms on the same lists (every lane a candidate: its slow paths
-// fire in every group of steps).
-__global__ __launch_bounds__(kListThreads) void lscan_kernel(GatedTable b) {
-    extern __shared__ uint32_t lscan_lds[];  // [kListHotBytes / 4] hot rows, then the 256-byte class map
-    __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
-    // (most workgroups of a short list leave at once: they look at three words of the descriptor, not all of it)
-    const ListScanArgs *pa = &b.g[blockIdx.y];
-    const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
-    if (blockIdx.x * kListThreads >= n_l) return;
-    const ListScanArgs a = load_descriptor(pa);
-    const uint32_t ncls = a.n_classes;
-    const uint32_t hot_elems = a.n_hot * ncls;
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.flat);
-        for (uint32_t k = threadIdx.x; k < (hot_elems + 1) / 2; k += kListThreads) lscan_lds[k] = src[k];
-        if (threadIdx.x < 64) lscan_lds[kListHotBytes / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
+// lscan_kernel: every list-driven pass of a phase in ONE persistent launch. One listed request per lane, walked byte by byte: per step
+// one LDS read for the byte's class (independent of the state: issued ahead) and one dependent read of the cell from the LDS copy of
+// the table's hottest rows. (The wave-lockstep walk of scan_kernel, built for streaming EVERY request, took 0.6 ms on the same
+// lists: every lane a candidate, its slow paths fire in every group of steps.)
+//
+// Cold rows (round 3). A cell outside the LDS copy lives in the L2-resident flat table, ~1 us away. Candidates are near misses by
+// construction and visit deeper states than average traffic, so although a single lane needs a cold row every few dozen steps, SOME
+// lane of the 64 needs one at almost every step — and in lockstep the whole wave waited for each of them (round 2: 65-80 % of wave
+// cycles waiting, one L2 round trip per DFA step on adversarial traffic). Now a lane that needs a cold cell PARKS: it stops consuming
+// bytes, the other lanes finish their 16-byte window, then the parked lanes' loads are issued together and consumed at the start of
+// the next window — at most ONE round trip per window instead of up to sixteen. Lanes are independent (own position p), so a parked
+// lane simply resumes one byte further.
+//
+// Work distribution (round 3): the list lengths are only known on the device. lscan_plan_kernel turns them into a prefix sum of work
+// items (kListThreads entries of one pass each); the scan launch is a persistent grid in which workgroup b takes the contiguous items
+// [total * b / G, total * (b + 1) / G) — consecutive items are mostly of one pass, whose hot rows are staged once. (Round 2 launched
+// ceil(n / 512) x passes workgroups, nearly all of which found their list exhausted: 53k launches-and-exits for the 69 filtered
+// passes of the 4096-rule set.)
+__global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t *plan /* [count + 1] */, uint32_t threads) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x;
+    uint32_t items = 0;
+    if (t < b.count) {
+        const ListScanArgs *pa = &b.g[t];
+        const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
+        items = (n_l + threads - 1) / threads;
     }
+    part[t] = items;
     __syncthreads();
-    const unsigned char *cls = reinterpret_cast<const unsigned char *>(lscan_lds + kListHotBytes / 4);
+    for (uint32_t d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan (count <= 250)
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t < b.count) plan[t] = part[t] - items;
+    if (t == 0) plan[b.count] = part[255];
+}
+
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint32_t *plan, uint32_t hot_bytes) {
+    extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows, then the 256-byte class map
+    __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
+    const uint32_t total = plan[b.count];
+    const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
+    const unsigned char *cls = reinterpret_cast<const unsigned char *>(lscan_lds + hot_bytes / 4);
     const uint16_t *hot = reinterpret_cast<const uint16_t *>(lscan_lds);
-    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
-    for (uint32_t i = blockIdx.x * kListThreads + threadIdx.x; i < n_l; i += gridDim.x * kListThreads) {
-        if (a.need_in != nullptr && !((a.need_in[i] >> a.need_bit) & 1u)) continue;  // (a sharing gap pass: none of its factors fired here)
-        const uint32_t r = a.req_list != nullptr ? a.req_list[i] : i;
-        if (a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31));
-        uint32_t p = a.off[r];
-        const uint32_t end = a.off[r + 1];
-        uint32_t state = 0;
-        Hits h{0, 0, kNone};
-        if (a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
-        while (p < end) {
-            const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
-            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
-            const uint32_t cnt = min(16u, end - p);
-            uint32_t c[16];
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) c[k] = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                if (k < cnt) {
-                    const uint32_t idx = state * ncls + c[k];
-                    const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
-                    state = t & 0x7FFFu;
-                    if (t & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
-                }
-            }
-            p += 16;
+    for (uint32_t it = it0; it < it1;) {
+        // the pass of item `it`: the last p with plan[p] <= it (uniform)
+        uint32_t ps = 0;
+        for (uint32_t lo = 0, hi = b.count; lo + 1 < hi;) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (plan[mid] <= it) lo = mid;
+            else hi = mid;
+            ps = lo;
         }
-        if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
-        a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-        if (a.colmask_local != nullptr) {
-            uint32_t need = 0;
-            if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
-            if (a.need_out != nullptr) a.need_out[i] = need;
-            need &= ~a.shared_bits;
-            if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+        const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
+        const ListScanArgs a = load_descriptor(&b.g[ps]);
+        const uint32_t ncls = a.n_classes;
+        const uint32_t hot_elems = a.n_hot * ncls;
+        __syncthreads();  // (every wave is done with the previous pass's rows)
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.flat);
+            for (uint32_t k = threadIdx.x; k < (hot_elems + 1) / 2; k += THREADS) lscan_lds[k] = src[k];
+            if (threadIdx.x < 64) lscan_lds[hot_bytes / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
+        }
+        __syncthreads();
+        const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
+        const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
+        const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
+        for (; it < it_end; it++) {
+            const uint32_t i = (it - first) * THREADS + threadIdx.x;
+            bool live = i < n_l;
+            if (live && a.need_in != nullptr) live = ((a.need_in[i] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
+            const uint32_t r = live ? (a.req_list != nullptr ? a.req_list[i] : i) : 0u;
+            if (live && a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31));
+            uint32_t p = live ? a.off[r] : 0u;
+            const uint32_t end = live ? a.off[r + 1] : 0u;
+            uint32_t state = 0;
+            Hits h{0, 0, kNone};
+            if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
+            uint32_t cold = kNone;  // flat-table index of the cell a parked lane waits for
+            while (__ballot(p < end || cold != kNone) != 0) {
+                const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (p < end ? p : 0u));
+                // the cells the parked lanes stopped at: all of a wave's cold loads of one window travel together
+                const uint32_t tc = cold != kNone ? (uint32_t)flat[cold] : 0u;
+                const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+                uint32_t c[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) c[k] = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+                if (cold != kNone) {
+                    state = tc & 0x7FFFu;
+                    if (tc & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+                    cold = kNone;
+                }
+                uint32_t rem = p < end ? min(16u, end - p) : 0u;  // bytes this lane may still consume in this window
+                uint32_t used = rem;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const uint32_t idx = state * ncls + c[k];
+                    const bool alive = k < rem, in_lds = idx < hot_elems;
+                    const uint32_t t = (uint32_t)hot[in_lds ? idx : 0u];
+                    if (alive && !in_lds) {  // park: byte k is consumed by the pending transition
+                        cold = idx;
+                        rem = 0;
+                        used = k + 1;
+                    } else if (alive) {
+                        state = t & 0x7FFFu;
+                        if (t & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+                    }
+                }
+                p += used;
+            }
+            if (!live) continue;
+            if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+            if (a.colmask_local != nullptr) {
+                uint32_t need = 0;
+                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
+                if (a.need_out != nullptr) a.need_out[i] = need;
+                need &= ~a.shared_bits;
+                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+            }
         }
     }
 }
@@ -579,15 +642,34 @@ int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, 
     return 0;
 }
 
-int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, void *stream) {
+int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream) {
     if (count == 0 || host[0].n == 0) return 0;
+    if (count > 256) return (int)hipErrorInvalidValue;
     GatedTable b{dev, count};
-    // the list lengths are only known on the device: a grid that covers the chip once per pass (grid-stride over the list);
-    // workgroups beyond a list's end exit at once
-    const uint32_t blocks = std::min<uint32_t>((host[0].n + kListThreads - 1) / kListThreads, std::max(1u, host[0].n_cus) * 3u);
-    void *args[] = {&b};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(lscan_kernel), dim3(blocks, b.count), dim3(kListThreads), args, kListHotBytes + 256, (hipStream_t)stream);
+    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, shape.threads);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // persistent grid: what the chip holds at this LDS size (the work items are split evenly over it), never more than the items
+    // a full batch could produce
+    const uint64_t max_items = (uint64_t)count * ((host[0].n + shape.threads - 1) / shape.threads);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, host[0].n_cus) * shape.wg_per_cu);
+    const uint32_t *cplan = plan;
+    uint32_t hot_bytes = shape.hot_bytes;
+    void *args[] = {&b, &cplan, &hot_bytes};
+    const void *fn = shape.threads == 1024 ? reinterpret_cast<const void *>(lscan_kernel<1024>) : reinterpret_cast<const void *>(lscan_kernel<512>);
+    e = hipLaunchKernel(fn, dim3(blocks), dim3(shape.threads), args, shape.hot_bytes + 256, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
+}
+
+// LDS budget of the list scan: 160 KiB per CU shared by wg_per_cu workgroups. Default 3 x (48 KiB, 512 threads) = 24 waves per CU;
+// PWAF_LIST_SHAPE (profiling builds) tries the others.
+ListShape list_shape(uint32_t variant) {
+    switch (variant) {
+        case 1: return ListShape{512, 72u * 1024u, 2};     // 16 waves per CU, 1.5x the rows
+        case 2: return ListShape{1024, 144u * 1024u, 1};   // 16 waves per CU, 3x the rows
+        case 3: return ListShape{512, 32u * 1024u, 4};     // 32 waves per CU
+        default: return ListShape{kListThreads, kListHotBytes, 3};
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1049,17 +1131,40 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     const uint32_t back = 3u * a.stride;
     const uint64_t b0 = (uint64_t)slab * kStreamSlab;
     const uint32_t c_first = (uint32_t)(b0 / 16);  // global index of the slab's first chunk
-    uint32_t lo = 0, hi = a.n;  // first request with off[r + 1] + back > b0
+    // first request with off[r + 1] + back > b0: a 64-ary search — every lane probes one of 64 evenly spaced offsets, a ballot
+    // narrows the range 64-fold per step (4 dependent loads for 10M requests; the binary search this replaces took 23, about
+    // 10 us of every wave's life in a kernel that is nothing but latency)
+    uint32_t lo = 0, hi = a.n;  // the answer lies in [lo, hi]; index a.n stands for "none" (treated as satisfying the predicate)
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint64_t)a.off[mid + 1] + back > b0) hi = mid;
-        else lo = mid + 1;
+        const uint32_t span = hi - lo, step = (span + 63) / 64;
+        const uint32_t probe = lo + lane * step;
+        const bool ok = probe >= hi || (uint64_t)a.off[probe + 1] + back > b0;  // monotone in the lane index
+        const unsigned long long m = __ballot(ok);
+        if (m == 0) {  // all 64 probes fail: the answer lies beyond the last one
+            lo += 63u * step + 1u;
+            continue;
+        }
+        const uint32_t f = (uint32_t)__builtin_ctzll(m);
+        const uint32_t nh = min(hi, lo + f * step);  // probe f holds (or is past the range)
+        lo = f == 0 ? lo : lo + (f - 1u) * step + 1u;  // probe f - 1 fails
+        hi = nh;
     }
     const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
+    // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
+    uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
+    {
+        const uint32_t r = lo + lane;
+        if (r < a.n) { s_n = a.off[r]; e_n = a.off[r + 1]; }
+    }
     for (uint32_t rb = lo; rb < a.n; rb += 64) {
         const uint32_t r = rb + lane;
         const bool live = r < a.n;
-        const uint32_t s = live ? a.off[r] : 0xFFFFFFFFu, e = live ? a.off[r + 1] : 0xFFFFFFFFu;
+        const uint32_t s = s_n, e = e_n;
+        {
+            const uint32_t r2 = r + 64;
+            s_n = e_n = 0xFFFFFFFFu;
+            if (r2 < a.n) { s_n = a.off[r2]; e_n = a.off[r2 + 1]; }
+        }
         bool mark = false;
         if (live && (uint64_t)s < b1 + 16) {
             // chunks j with 16 j - back < e and 16 j + 16 >= s, clipped to the slab
@@ -1562,20 +1667,88 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 static constexpr uint32_t kMaxRowWords = kSrcWords;  // ip-set, country, port-set, asn-set, asn-comparison words per request
 static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
 
+// ipres_kernel (round 3): the address lookups of the attribute path as a kernel of their own — one lane per request, ~20 registers,
+// full occupancy. Round 2 did them inside attr_kernel, whose transposes need ~128 registers (4 waves per SIMD) and whose waves each
+// walked one 64-request group at a time: every group waited for its own DIR-24 line (a miss to the Infinity Cache / HBM) and then
+// for the trie levels of its few IPv6 lanes, with 16 waves per CU to hide it all — 0.44 ms alone for 10M requests, the longest
+// kernel of the step. Here 32 waves per CU overlap those waits, and an IPv4 address behind the DIR-24 table costs ONE gather (round 2
+// also fetched both 16-bit root entries for every lane and threw them away). Output: the GeoIP CLASS and the ip-list membership SET
+// of every request, packed into one word (class | set << 16) when both fit 16 bits (else two words).
+template <bool PACKED>
+__global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
+    const bool from_row = a.asn == nullptr;
+    const bool dir = a.dir24 != nullptr;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
+        const uint32_t ipw[4] = {raw.x, raw.y, raw.z, raw.w};
+        const bool v6 = a.ip_is_v6[i] != 0;
+        // GeoipDB::lookup, pingoo/geoip.rs:73-91: loopback / multicast are "not found"
+        bool geo_walk = false;
+        if (from_row && a.has_geo) {
+            if (!v6) {
+                const uint32_t b0 = ipw[0] & 0xFFu;
+                geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
+            } else {
+                const bool loopback = ipw[0] == 0 && ipw[1] == 0 && ipw[2] == 0 && ipw[3] == 0x01000000u;
+                geo_walk = !(loopback || (ipw[0] & 0xFFu) == 0xFFu);
+            }
+        }
+        const uint32_t top16 = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
+        uint32_t eg, ei, k;
+        if (!v6 && dir) {
+            const uint32_t e24 = a.dir24[(top16 << 8) | ip_byte(ipw, 2)];
+            k = 3;
+            if (e24 & DIR_ESCAPE) {  // a prefix longer than /24 (or an id too large for the packed entry): rare
+                const uint2 esc = a.dir_esc[e24 & ~DIR_ESCAPE];
+                eg = esc.x;
+                ei = esc.y;
+            } else {
+                eg = TRIE_LEAF | (e24 & 0xFFFFu);
+                ei = TRIE_LEAF | (e24 >> 16);
+            }
+        } else {
+            k = 2;
+            eg = geo_walk ? (v6 ? a.geo_root6 : a.geo_root4)[top16] : TRIE_LEAF;  // (the engine substitutes an all-leaf root for a family without prefixes)
+            ei = a.n_ip_lists ? (v6 ? a.ip_root6 : a.ip_root4)[top16] : TRIE_LEAF;
+        }
+        if (!geo_walk) eg = TRIE_LEAF | a.geo_default;  // no lookup: the default record's class
+        if (a.n_ip_lists == 0) ei = TRIE_LEAF;
+        for (; !((eg & ei) & TRIE_LEAF); k++) {
+            const uint32_t byte = ip_byte(ipw, k);
+            const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
+            const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
+            eg = ng;
+            ei = ni;
+        }
+        const uint32_t cls = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
+        if (PACKED) a.ipres[i] = cls | (set_id << 16);
+        else reinterpret_cast<uint2 *>(a.ipres)[i] = make_uint2(cls, set_id);
+    }
+}
+
 struct AttrIn {
-    uint32_t ipw[4];
-    uint32_t v6, port, len[5], asn, country;
+    uint32_t cls, set_id;
+    uint32_t port, len[5], asn, country;
     uint32_t sstart, slen;  // the short-literal field's value: offset and length
 };
 
+// SMALL: the rule set's membership rows fit 4 ip-set words, 2 country words and one word each of port sets, asn sets and asn
+// comparisons (a 1k-rule set with 124 CIDR lists does): 9 row registers instead of 36.
+template <bool PACKED, bool SMALL>
 __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
+    constexpr uint32_t SW = SMALL ? 4 : kSetWordsMax, CW = SMALL ? 2 : kCcWordsMax, IW = SMALL ? 1 : kIntWordsMax, QW = SMALL ? 1 : kAcmpWordsMax;
 #ifdef PWAF_PROFILING
     if (a.debug_skip & 0x80000000u) __builtin_amdgcn_s_setprio(3);  // timing experiment
 #endif
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
-    const bool dir = a.dir24 != nullptr;
+#ifdef PWAF_PROFILING
+    // timing experiments (wrong results): which part of the kernel costs what
+    const bool skip_rows = (a.debug_skip >> 18) & 1u, skip_transpose = (a.debug_skip >> 19) & 1u, skip_cmp = (a.debug_skip >> 20) & 1u;
+#else
+    constexpr bool skip_rows = false, skip_transpose = false, skip_cmp = false;
+#endif
     // group-invariant: the first 64 comparison atoms, one per lane (col | code << 24, constant)
     uint32_t h_col = 0, h_c = 0;
     if (lane < a.n_cmp) {
@@ -1587,9 +1760,15 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
     auto load_in = [&](const uint32_t g, AttrIn &in) {
         const uint32_t i0 = g * 64 + lane;
         const uint32_t i = (g < a.n_groups && i0 < a.n) ? i0 : 0u;
-        const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
-        in.ipw[0] = raw.x; in.ipw[1] = raw.y; in.ipw[2] = raw.z; in.ipw[3] = raw.w;
-        in.v6 = a.ip_is_v6[i];
+        if (PACKED) {
+            const uint32_t w = a.ipres[i];
+            in.cls = w & 0xFFFFu;
+            in.set_id = w >> 16;
+        } else {
+            const uint2 w = reinterpret_cast<const uint2 *>(a.ipres)[i];
+            in.cls = w.x;
+            in.set_id = w.y;
+        }
         in.port = a.port[i];
 #pragma unroll
         for (int f = 0; f < 5; f++) in.len[f] = a.off[f][i + 1] - a.off[f][i];
@@ -1598,25 +1777,20 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         in.sstart = a.n_short ? a.short_off[i] : 0u;
         in.slen = a.n_short ? a.short_off[i + 1] - in.sstart : 0u;
     };
-    // stage B: the first trie step of both tries (three unconditional gathers: the DIR-24 entry for IPv4, the two 16-bit roots otherwise)
-    auto load_root = [&](const AttrIn &in, uint32_t &e24, uint32_t &rg, uint32_t &ri, uint32_t &s_lo, uint32_t &s_hi) {
-        // (the short-literal field's first 8 bytes: arenas carry 16 readable slack bytes)
-        const uint8_t *sp = a.n_short ? a.short_data + in.sstart : reinterpret_cast<const uint8_t *>(a.ip);
-        s_lo = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(sp);
-        s_hi = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(sp + 4);
-        const bool v6 = in.v6 != 0;
-        const uint32_t top16 = (ip_byte(in.ipw, 0) << 8) | ip_byte(in.ipw, 1);
-        const uint32_t top24 = (top16 << 8) | ip_byte(in.ipw, 2);
-        e24 = dir ? a.dir24[v6 ? 0u : top24] : 0u;
-        rg = (v6 ? a.geo_root6 : a.geo_root4)[top16];  // (the engine substitutes an all-leaf root for a family without prefixes)
-        ri = (v6 ? a.ip_root6 : a.ip_root4)[top16];
+    // stage B: the short-literal field's first 8 bytes (arenas carry 16 readable slack bytes)
+    auto load_short = [&](const AttrIn &in, uint32_t &s_lo, uint32_t &s_hi) {
+        typedef uint2 __attribute__((aligned(1))) uint2_u;
+        uint2 sv = make_uint2(0u, 0u);
+        if (a.n_short) sv = *reinterpret_cast<const uint2_u *>(a.short_data + in.sstart);
+        s_lo = sv.x;
+        s_hi = sv.y;
     };
     AttrIn cur, nxt;
-    uint32_t c_e24, c_rg, c_ri, c_slo, c_shi;
+    uint32_t c_slo, c_shi;
     const uint32_t g0 = blockIdx.x * 4 + wave;
     load_in(g0, cur);
     load_in(g0 + g_stride, nxt);
-    load_root(cur, c_e24, c_rg, c_ri, c_slo, c_shi);
+    load_short(cur, c_slo, c_shi);
     // group-invariant: the first 64 short-literal atoms, one per lane
     ShortAtom h_short{0, 0, 0, 0};
     if (lane < a.n_short) h_short = a.short_atoms[lane];
@@ -1633,44 +1807,10 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
             if (has) pairs[n_pairs + (uint32_t)__builtin_popcountll(em & lt_mask)] = make_uint4(c, 0u, lo, hi);
             n_pairs += (uint32_t)__builtin_popcountll(em);
         };
-        const bool v6 = cur.v6 != 0;
         const uint32_t port = cur.port;
+        const uint32_t cls = cur.cls, set_id = cur.set_id;
 
-        // ---- 1. finish the trie walks (GeoipDB::lookup, pingoo/geoip.rs:73-91: loopback / multicast are "not found") ----
-        bool geo_walk = false;
-        if (valid && from_row && a.has_geo) {
-            if (!v6) {
-                const uint32_t b0 = cur.ipw[0] & 0xFFu;
-                geo_walk = !(b0 == 127u || (b0 & 0xF0u) == 0xE0u);
-            } else {
-                const bool loopback = cur.ipw[0] == 0 && cur.ipw[1] == 0 && cur.ipw[2] == 0 && cur.ipw[3] == 0x01000000u;
-                geo_walk = !(loopback || (cur.ipw[0] & 0xFFu) == 0xFFu);
-            }
-        }
-        uint32_t eg = c_rg, ei = c_ri, k = 2;
-        if (!v6 && dir) {
-            k = 3;
-            if (c_e24 & DIR_ESCAPE) {  // a prefix longer than /24 (or an id too large for the packed entry): rare
-                const uint2 esc = a.dir_esc[c_e24 & ~DIR_ESCAPE];
-                eg = esc.x;
-                ei = esc.y;
-            } else {
-                eg = TRIE_LEAF | (c_e24 & 0xFFFFu);
-                ei = TRIE_LEAF | (c_e24 >> 16);
-            }
-        }
-        if (!geo_walk) eg = TRIE_LEAF | a.geo_default;  // no lookup: the default record's class
-        if (!valid || a.n_ip_lists == 0) ei = TRIE_LEAF;
-        for (; !((eg & ei) & TRIE_LEAF); k++) {
-            const uint32_t byte = ip_byte(cur.ipw, k);
-            const uint32_t ng = (eg & TRIE_LEAF) ? eg : a.geo_nodes[(size_t)eg * 256 + byte];
-            const uint32_t ni = (ei & TRIE_LEAF) ? ei : a.ip_nodes[(size_t)ei * 256 + byte];
-            eg = ng;
-            ei = ni;
-        }
-        const uint32_t cls = eg & ~TRIE_LEAF, set_id = ei & ~TRIE_LEAF;
-
-        // ---- 2. membership rows: every row word of the request requested together, then ONE wait ----
+        // ---- 1. membership rows: every row word of the request requested together, then ONE wait ----
         uint32_t asn = cur.asn, r_geo = 0;
         if (!from_row) {
             const uint32_t c0 = (cur.country & 0xFFu) - 'A', c1 = (cur.country >> 8) - 'A';
@@ -1696,35 +1836,32 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         const uint32_t *prow = a.iu_masks[0] + (size_t)r_int[0] * a.iu_words[0];
         const uint32_t *arow = from_row ? crow + a.cc_words : a.iu_masks[1] + (size_t)r_int[1] * a.iu_words[1];
         const uint32_t *qrow = crow + a.cc_words + a.iu_words[1];
-        const bool have_s = valid && a.n_ip_lists && set_id, have_c = valid && (from_row ? cls != 0 : true), have_p = valid && r_int[0],
-                   have_a = valid && (from_row ? cls != 0 : r_int[1] != 0), have_q = valid && from_row && cls != 0;
-        uint32_t rw[kMaxRowWords];
+        const bool rows_on = valid && !skip_rows;
+        const bool have_s = rows_on && a.n_ip_lists && set_id, have_c = rows_on && (from_row ? cls != 0 : true), have_p = rows_on && r_int[0],
+                   have_a = rows_on && (from_row ? cls != 0 : r_int[1] != 0), have_q = rows_on && from_row && cls != 0;
+        uint32_t rs[SW], rc[CW], rp[IW], ra[IW], rq[QW];
 #pragma unroll
-        for (uint32_t q = 0; q < kSetWordsMax; q++) rw[kSrcSet + q] = (q < a.set_words && have_s) ? srow[q] : 0u;
+        for (uint32_t q = 0; q < SW; q++) rs[q] = (q < a.set_words && have_s) ? srow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < kCcWordsMax; q++) rw[kSrcCc + q] = (q < a.cc_words && have_c) ? crow[q] : 0u;
+        for (uint32_t q = 0; q < CW; q++) rc[q] = (q < a.cc_words && have_c) ? crow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < kIntWordsMax; q++) rw[kSrcPort + q] = (q < a.iu_words[0] && have_p) ? prow[q] : 0u;
+        for (uint32_t q = 0; q < IW; q++) rp[q] = (q < a.iu_words[0] && have_p) ? prow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < kIntWordsMax; q++) rw[kSrcAsn + q] = (q < a.iu_words[1] && have_a) ? arow[q] : 0u;
+        for (uint32_t q = 0; q < IW; q++) ra[q] = (q < a.iu_words[1] && have_a) ? arow[q] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < kAcmpWordsMax; q++) rw[kSrcAcmp + q] = (q < a.acmp_words && have_q) ? qrow[q] : 0u;
+        for (uint32_t q = 0; q < QW; q++) rq[q] = (q < a.acmp_words && have_q) ? qrow[q] : 0u;
 
-        // ---- 3. prefetch: inputs of the group after next, first trie step of the next group ----
+        // ---- 2. prefetch: inputs of the group after next, the next group's short-literal bytes ----
         AttrIn nn;
         load_in(g + 2 * g_stride, nn);
-        uint32_t n_e24, n_rg, n_ri, n_slo, n_shi;
-        load_root(nxt, n_e24, n_rg, n_ri, n_slo, n_shi);
+        uint32_t n_slo, n_shi;
+        load_short(nxt, n_slo, n_shi);
 
-        // ---- 4. transposes: one ballot per bit that ANY of the 64 requests has set (wave-wide OR first, so absent bits cost
+        // ---- 3. transposes: one ballot per bit that ANY of the 64 requests has set (wave-wide OR first, so absent bits cost
         //         nothing); lane b keeps bit b's request mask and owns that atom's pair ----
-#pragma unroll
-        for (uint32_t q = 0; q < kMaxRowWords; q++) {
-            const uint32_t words = q < kSrcCc ? a.set_words : q < kSrcPort ? a.cc_words + kSrcCc : q < kSrcAsn ? a.iu_words[0] + kSrcPort : q < kSrcAcmp ? a.iu_words[1] + kSrcAsn : a.acmp_words + kSrcAcmp;
-            if (q >= words) continue;  // (uniform)
-            const uint32_t w = rw[q];
+        auto transpose = [&](const uint32_t w, const uint32_t src_word) {
             const uint32_t orw0 = wave_or(w);
-            if (orw0 == 0) continue;
+            if (orw0 == 0) return;
             unsigned long long mine_m = 0;
             for (uint32_t orw = orw0; orw; orw &= orw - 1) {
                 const uint32_t b = (uint32_t)__builtin_ctz(orw);
@@ -1732,14 +1869,26 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                 if (lane == b) mine_m = m;
             }
             const bool owner = lane < 32 && ((orw0 >> lane) & 1u);
-            const uint32_t c = owner ? a.bit_col[q * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
+            const uint32_t c = owner ? a.bit_col[src_word * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
             emit_pairs(c != 0, c, (uint32_t)mine_m, (uint32_t)(mine_m >> 32));
+        };
+        if (!skip_transpose) {
+#pragma unroll
+            for (uint32_t q = 0; q < SW; q++) if (q < a.set_words) transpose(rs[q], kSrcSet + q);  // (uniform conditions)
+#pragma unroll
+            for (uint32_t q = 0; q < CW; q++) if (q < a.cc_words) transpose(rc[q], kSrcCc + q);
+#pragma unroll
+            for (uint32_t q = 0; q < IW; q++) if (q < a.iu_words[0]) transpose(rp[q], kSrcPort + q);
+#pragma unroll
+            for (uint32_t q = 0; q < IW; q++) if (q < a.iu_words[1]) transpose(ra[q], kSrcAsn + q);
+#pragma unroll
+            for (uint32_t q = 0; q < QW; q++) if (q < a.acmp_words) transpose(rq[q], kSrcAcmp + q);
         }
 
         // Comparison atoms (lengths, port, asn against constants): the engine has reduced them to `v == c` / `v <= c` on 32-bit
         // values and tagged each with code = 2 * variable + operator; an atom is a scalar broadcast of its constant, one
         // vector compare and a ballot parked in the atom's lane. (asn comparisons of engine-resolved records are class-row bits.)
-        for (uint32_t base = 0; base < a.n_cmp; base += 64) {
+        for (uint32_t base = 0; base < a.n_cmp && !skip_cmp; base += 64) {
             uint32_t m_col = h_col, m_c = h_c;
             if (base != 0) {  // more than 64 comparison atoms: the later chunks are re-read per group
                 m_col = m_c = 0;
@@ -1801,9 +1950,6 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         if (lane == 0) a.ghdr[g] = n_pairs;
         cur = nxt;
         nxt = nn;
-        c_e24 = n_e24;
-        c_rg = n_rg;
-        c_ri = n_ri;
         c_slo = n_slo;
         c_shi = n_shi;
     }
@@ -1837,18 +1983,31 @@ int launch_dir24(const VerdictArgs &a, void *out, void *esc, void *esc_count, vo
     return (int)hipGetLastError();
 }
 
+// address lookups: one lane per request at full occupancy (grid-stride; 8 workgroups of 256 per CU)
+int launch_ipres(const VerdictArgs &a, void *stream) {
+    if (a.n == 0) return 0;
+    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, 8 * std::max(1u, a.attr_blocks));
+    if (a.ipres_packed) hipLaunchKernelGGL(ipres_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ipres_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 int launch_attr(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    // A persistent grid of six workgroups per CU at the default wave priority 0, while the filter waves raise theirs to 3: the
-    // attribute waves take the issue slots the filter leaves idle instead of competing for them (measured on MI355X next to the
-    // stream filter: 512 / 768 / 1024 / 1536 / 2048 workgroups -> 2.00 / 2.00 / 1.98 / 1.94 / 1.94 ms per step).
+    // rows, transposes, comparisons (after launch_ipres on the same stream). A persistent grid of six workgroups per CU at the default wave priority 0, while the filter
+    // waves raise theirs to 3: the attribute waves take the issue slots the filter leaves idle instead of competing for them
+    // (measured on MI355X next to the stream filter: 512 / 768 / 1024 / 1536 / 2048 workgroups -> 2.00 / 2.00 / 1.98 / 1.94 / 1.94 ms per step).
 #ifdef PWAF_PROFILING
     static const uint32_t forced = getenv("PWAF_ATTR_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_ATTR_BLOCKS")) : 0u;
 #else
     const uint32_t forced = 0;
 #endif
     const uint32_t blocks = std::min<uint32_t>((a.n_groups + 3) / 4, forced ? forced : 6 * std::max(1u, a.attr_blocks));
-    hipLaunchKernelGGL(attr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const bool small = a.set_words <= 4 && a.cc_words <= 2 && a.iu_words[0] <= 1 && a.iu_words[1] <= 1 && a.acmp_words <= 1;
+    if (a.ipres_packed && small) hipLaunchKernelGGL((attr_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if (a.ipres_packed) hipLaunchKernelGGL((attr_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if (small) hipLaunchKernelGGL((attr_kernel<false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attr_kernel<false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
@@ -1912,7 +2071,7 @@ int configure_kernels(int device) {
                          reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
                          reinterpret_cast<const void *>(filter_kernel<true, 1>), reinterpret_cast<const void *>(filter_kernel<false, 1>),
                          reinterpret_cast<const void *>(filter_kernel<true, 2>), reinterpret_cast<const void *>(filter_kernel<false, 2>),
-                         reinterpret_cast<const void *>(lscan_kernel)};
+                         reinterpret_cast<const void *>(lscan_kernel<512>), reinterpret_cast<const void *>(lscan_kernel<1024>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
         if (e != hipSuccess) return (int)e;
