@@ -172,7 +172,7 @@ struct pwaf_engine {
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
     std::mutex mu;  // guards the context ring, the profiling state and table rebuilds (pwaf_engine_tune)
-    DevBuf pass_base, colmask, dir24;
+    DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir16, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
     uint32_t n_visit = 0;  // gap passes (visited bitmaps per batch)
     std::vector<double> mean_len;  // per field, from the tuning sample (0 = unknown)
@@ -348,7 +348,7 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     }
     std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     int rc;
-    if ((rc = upload(d.flat, flat, 4))) return rc;  // (the LDS staging copies whole 32-bit words)
+    if ((rc = upload(d.flat, flat, 16))) return rc;  // (the LDS staging copies whole 16-byte units)
     if ((rc = upload(d.flat_classmap, cm))) return rc;
     if ((rc = upload(d.emit_off, emit_off))) return rc;
     if ((rc = upload(d.emit_list, emit_list))) return rc;
@@ -384,6 +384,9 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
     v.has_geo = P.has_geo ? 1u : 0u;
     v.dir24 = (const uint32_t *)e->dir24.p;
+    v.dir16 = (const uint32_t *)e->dir16.p;
+    v.dir_chunks = (const uint32_t *)e->dir_chunks.p;
+    v.dir_vals = (const uint32_t *)e->dir_vals.p;
     v.dir_esc = (const uint2 *)e->dir_esc.p;
     v.class_rows = (const uint32_t *)e->class_rows.p;
     v.class_words = e->class_words;
@@ -727,30 +730,35 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (attr_launched) return PWAF_OK;
         attr_launched = true;
         int rc2;
+        hipStream_t side_q = S.side;
+#ifdef PWAF_PROFILING
+        static const bool attr_inline = getenv("PWAF_ATTR_INLINE") != nullptr;  // timing experiment: no side stream, every kernel runs alone
+        if (attr_inline) side_q = stream;
+#endif
         HIP_TRY(hipEventRecord(S.ev_fork, stream));
-        HIP_TRY(hipStreamWaitEvent(S.side, S.ev_fork, 0));
-        if ((rc2 = mark(nullptr, 0, S.side))) return rc2;
+        HIP_TRY(hipStreamWaitEvent(side_q, S.ev_fork, 0));
+        if ((rc2 = mark(nullptr, 0, side_q))) return rc2;
         {
             int he = 0;
 #ifdef PWAF_PROFILING
             static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
             static const bool skip_ipres = getenv("PWAF_SKIP_IPRES") != nullptr;  // ... every address resolves to class 0 / set 0
-            if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, S.side));
-            if (skip_ipres) HIP_TRY(hipMemsetAsync(v.ipres, 0, (size_t)n * 8, S.side));
-            if (!skip_attr && !skip_ipres) he = launch_ipres(v, S.side);
-            if (!he && (rc2 = mark("ipres", 0xFAu, S.side))) return rc2;
-            if (!he && (rc2 = mark(nullptr, 0, S.side))) return rc2;
-            if (!he && !skip_attr) he = launch_attr(v, S.side);
+            if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, side_q));
+            if (skip_ipres) HIP_TRY(hipMemsetAsync(v.ipres, 0, (size_t)n * (v.ipres_packed ? 4 : 8), side_q));
+            if (!skip_attr && !skip_ipres) he = launch_ipres(v, side_q);
+            if (!he && (rc2 = mark("ipres", 0xFAu, side_q))) return rc2;
+            if (!he && (rc2 = mark(nullptr, 0, side_q))) return rc2;
+            if (!he && !skip_attr) he = launch_attr(v, side_q);
 #else
-            he = launch_ipres(v, S.side);
-            if (!he && (rc2 = mark("ipres", 0xFAu, S.side))) return rc2;
-            if (!he && (rc2 = mark(nullptr, 0, S.side))) return rc2;
-            if (!he) he = launch_attr(v, S.side);
+            he = launch_ipres(v, side_q);
+            if (!he && (rc2 = mark("ipres", 0xFAu, side_q))) return rc2;
+            if (!he && (rc2 = mark(nullptr, 0, side_q))) return rc2;
+            if (!he) he = launch_attr(v, side_q);
 #endif
             if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         }
-        if ((rc2 = mark("attr", 0xFEu, S.side))) return rc2;
-        HIP_TRY(hipEventRecord(S.ev_join, S.side));
+        if ((rc2 = mark("attr", 0xFEu, side_q))) return rc2;
+        HIP_TRY(hipEventRecord(S.ev_join, side_q));
         return PWAF_OK;
     };
 #ifdef PWAF_PROFILING
@@ -1393,6 +1401,38 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         if (ok) ok = hipMemset(cnt.p, 0, 4) == hipSuccess && launch_dir24(tv, e->dir24.p, e->dir_esc.p, cnt.p, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess;
         cnt.release();
         if (!ok) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
+        // Compressed for the lookups (round 3): 10M uniformly random addresses against the flat 64 MiB table are 10M misses to HBM (the
+        // batch's own 3 GB of streaming flush every cache level in between): 0.29 ms per batch for ipres_kernel at full occupancy,
+        // ~35 G random 64-byte reads per second, the fabric's limit. Consecutive /24s mostly share their entry (a /20 prefix covers 16
+        // of them), so per /16 the 256 entries are stored as RUNS: a 256-bit bitmap of run starts with per-word prefix counts and one
+        // value per run; a /16 with a single run is a leaf of the 2^16-entry first level. ~5 MB for 600k GeoIP prefixes + 124 CIDR
+        // lists instead of 64 MiB: L2 / Infinity-Cache resident. Lookup: first level -> (prefix count, bitmap word) -> value.
+        {
+            std::vector<uint32_t> d24((size_t)1 << 24);
+            if (hipMemcpy(d24.data(), e->dir24.p, d24.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(PWAF_E_DEVICE, "DIR-24 download failed"); return dev_fail(PWAF_E_DEVICE); }
+            std::vector<uint32_t> d16(65536), chunks, vals;
+            for (uint32_t x = 0; x < 65536; x++) {
+                const uint32_t *en = &d24[(size_t)x << 8];
+                bool uniform = !(en[0] & 0x80000000u);
+                for (uint32_t j = 1; j < 256 && uniform; j++) uniform = en[j] == en[0];
+                if (uniform) { d16[x] = 0x80000000u | en[0]; continue; }
+                d16[x] = (uint32_t)(chunks.size() / kDirChunkWords);
+                uint32_t bm[8] = {0}, pre[8] = {0};
+                const uint32_t base = (uint32_t)vals.size();
+                for (uint32_t j = 0; j < 256; j++)
+                    if (j == 0 || en[j] != en[j - 1]) { bm[j >> 5] |= 1u << (j & 31); vals.push_back(en[j]); }
+                for (uint32_t w = 1; w < 8; w++) pre[w] = pre[w - 1] + (uint32_t)__builtin_popcount(bm[w - 1]);
+                chunks.push_back(base);
+                chunks.push_back(pre[0] | pre[1] << 8 | pre[2] << 16 | pre[3] << 24);
+                chunks.push_back(pre[4] | pre[5] << 8 | pre[6] << 16 | pre[7] << 24);
+                for (uint32_t w = 0; w < 8; w++) chunks.push_back(bm[w]);
+                chunks.push_back(0);  // pad to kDirChunkWords
+            }
+            if (chunks.empty()) chunks.assign(kDirChunkWords, 0);
+            if (vals.empty()) vals.push_back(0);
+            if ((rc = upload(e->dir16, d16)) || (rc = upload(e->dir_chunks, chunks)) || (rc = upload(e->dir_vals, vals))) return dev_fail(rc);
+            e->dir24.release();
+        }
     }
     if (hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "device synchronize failed after table upload"); return dev_fail(PWAF_E_DEVICE); }
     *out = e.release();
@@ -1403,7 +1443,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
-                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->pass_base, &e->colmask, &e->dir24, &e->class_rows,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->pass_base, &e->colmask, &e->dir24, &e->dir16, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
     for (auto &c : e->ctx) c->release();

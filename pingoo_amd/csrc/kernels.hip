@@ -464,13 +464,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 // the table's hottest rows. (The wave-lockstep walk of scan_kernel, built for streaming EVERY request, took 0.6 ms on the same
 // lists: every lane a candidate, its slow paths fire in every group of steps.)
 //
-// Cold rows (round 3). A cell outside the LDS copy lives in the L2-resident flat table, ~1 us away. Candidates are near misses by
-// construction and visit deeper states than average traffic, so although a single lane needs a cold row every few dozen steps, SOME
-// lane of the 64 needs one at almost every step — and in lockstep the whole wave waited for each of them (round 2: 65-80 % of wave
-// cycles waiting, one L2 round trip per DFA step on adversarial traffic). Now a lane that needs a cold cell PARKS: it stops consuming
-// bytes, the other lanes finish their 16-byte window, then the parked lanes' loads are issued together and consumed at the start of
-// the next window — at most ONE round trip per window instead of up to sixteen. Lanes are independent (own position p), so a parked
-// lane simply resumes one byte further.
+// Cold rows: a cell outside the LDS copy lives in the L2-resident flat table (~1 us away) and the wave waits for it. (Round 3 tried
+// PARKING such lanes — stop consuming bytes, issue all of a window's cold loads together at its end, resume one byte further: at most
+// one round trip per 16-byte window instead of one per step. Measured slower everywhere: benign 0.234 vs 0.177 ms, adversarial 5.3 vs
+// 3.9 ms for the filtered passes of the 1k-rule set. The extra selects per step cost more than the waits they save — on adversarial
+// traffic the walk is bound by VALU + LDS issue, ~10 instructions per byte and lane, not by latency — and a lane deep in rarely
+// visited states, which parks at every byte, became twice as slow and sets the wave's time.)
 //
 // Work distribution (round 3): the list lengths are only known on the device. lscan_plan_kernel turns them into a prefix sum of work
 // items (kListThreads entries of one pass each); the scan launch is a persistent grid in which workgroup b takes the contiguous items
@@ -521,8 +520,19 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         const uint32_t hot_elems = a.n_hot * ncls;
         __syncthreads();  // (every wave is done with the previous pass's rows)
         {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.flat);
-            for (uint32_t k = threadIdx.x; k < (hot_elems + 1) / 2; k += THREADS) lscan_lds[k] = src[k];
+            // 16 bytes per lane and load, four loads in flight (a dword-per-lane loop of dependent load -> store pairs took a dozen L2
+            // round trips per workgroup: as long as the walk of a short list). The flat table is padded to whole 16-byte units.
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.flat);
+            uint4 *dst = reinterpret_cast<uint4 *>(lscan_lds);
+            const uint32_t units = (hot_elems * 2u + 15u) / 16u;
+            for (uint32_t k = threadIdx.x; k < units; k += THREADS * 4u) {
+                uint4 v[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) v[q] = k + q * THREADS < units ? src[k + q * THREADS] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++)
+                    if (k + q * THREADS < units) dst[k + q * THREADS] = v[q];
+            }
             if (threadIdx.x < 64) lscan_lds[hot_bytes / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
         }
         __syncthreads();
@@ -540,37 +550,23 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
             uint32_t state = 0;
             Hits h{0, 0, kNone};
             if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
-            uint32_t cold = kNone;  // flat-table index of the cell a parked lane waits for
-            while (__ballot(p < end || cold != kNone) != 0) {
-                const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (p < end ? p : 0u));
-                // the cells the parked lanes stopped at: all of a wave's cold loads of one window travel together
-                const uint32_t tc = cold != kNone ? (uint32_t)flat[cold] : 0u;
+            while (p < end) {
+                const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
                 const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+                const uint32_t cnt = min(16u, end - p);
                 uint32_t c[16];
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) c[k] = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-                if (cold != kNone) {
-                    state = tc & 0x7FFFu;
-                    if (tc & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
-                    cold = kNone;
-                }
-                uint32_t rem = p < end ? min(16u, end - p) : 0u;  // bytes this lane may still consume in this window
-                uint32_t used = rem;
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {
-                    const uint32_t idx = state * ncls + c[k];
-                    const bool alive = k < rem, in_lds = idx < hot_elems;
-                    const uint32_t t = (uint32_t)hot[in_lds ? idx : 0u];
-                    if (alive && !in_lds) {  // park: byte k is consumed by the pending transition
-                        cold = idx;
-                        rem = 0;
-                        used = k + 1;
-                    } else if (alive) {
+                    if (k < cnt) {
+                        const uint32_t idx = state * ncls + c[k];
+                        const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
                         state = t & 0x7FFFu;
                         if (t & 0x8000u) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
                     }
                 }
-                p += used;
+                p += 16;
             }
             if (!live) continue;
             if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
@@ -1677,7 +1673,7 @@ static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
 template <bool PACKED>
 __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
     const bool from_row = a.asn == nullptr;
-    const bool dir = a.dir24 != nullptr;
+    const bool dir = a.dir16 != nullptr;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(a.ip + (size_t)i * 16);
         const uint32_t ipw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -1696,7 +1692,17 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
         const uint32_t top16 = (ip_byte(ipw, 0) << 8) | ip_byte(ipw, 1);
         uint32_t eg, ei, k;
         if (!v6 && dir) {
-            const uint32_t e24 = a.dir24[(top16 << 8) | ip_byte(ipw, 2)];
+            // first level: the /16; then (for a /16 that is not uniform) the run that holds the /24
+            uint32_t e24 = a.dir16[top16];
+            if (e24 & 0x80000000u) {
+                e24 &= 0x7FFFFFFFu;
+            } else {
+                const uint32_t *ck = a.dir_chunks + (size_t)e24 * kDirChunkWords;
+                const uint32_t b2 = ip_byte(ipw, 2), w = b2 >> 5;
+                const uint32_t pre = ((w < 4 ? ck[1] : ck[2]) >> ((w & 3u) * 8u)) & 0xFFu;
+                const uint32_t rank = pre + (uint32_t)__builtin_popcount(ck[3 + w] & (0xFFFFFFFFu >> (31u - (b2 & 31u))));  // run starts at or before the /24
+                e24 = a.dir_vals[ck[0] + rank - 1u];
+            }
             k = 3;
             if (e24 & DIR_ESCAPE) {  // a prefix longer than /24 (or an id too large for the packed entry): rare
                 const uint2 esc = a.dir_esc[e24 & ~DIR_ESCAPE];
