@@ -332,15 +332,23 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     for (uint32_t s = 0; s < S; s++) order[s] = s;
     if (visits && visits->size() == S) std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
     for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
-    std::vector<uint16_t> flat((size_t)S * C);
+    // row = C transition cells (next state | 0x8000 when entering it emits) + one EMIT cell: what entering THIS state emits —
+    // 0 = nothing, 0x8000 | local atom = exactly one atom (the common case: settled in registers by the kernel), else 1 + the state's
+    // index into emit_off (a list). The cell rides with the row into LDS: round 2 called the out-of-line list walk (three dependent
+    // global loads, ~2 us for the whole wave) for every match of every lane — benign candidates are mostly true hits, so a wave of
+    // 64 candidates stalled on the order of a hundred times per walk.
+    const uint32_t stride = C + 1;
+    std::vector<uint16_t> flat((size_t)S * stride);
     std::vector<uint32_t> emit_off(1, 0), end_off(1, 0);
     std::vector<uint16_t> emit_list, end_list;
     for (uint32_t q = 0; q < S; q++) {
         const uint32_t s = order[q];
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t t = g.trans[(size_t)s * C + c];
-            flat[(size_t)q * C + c] = (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u));
+            flat[(size_t)q * stride + c] = (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u));
         }
+        const uint32_t ne = g.emit_off[(size_t)s + 1] - g.emit_off[s];
+        flat[(size_t)q * stride + C] = ne == 0 ? (uint16_t)0 : (ne == 1 && g.emit_list[g.emit_off[s]] < 0x7FFFu) ? (uint16_t)(0x8000u | g.emit_list[g.emit_off[s]]) : (uint16_t)1;
         emit_list.insert(emit_list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[(size_t)s + 1]);
         emit_off.push_back((uint32_t)emit_list.size());
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
@@ -835,7 +843,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
-        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * d.n_classes));  // (states are in visit order: the first rows are the hot ones)
+        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * (d.n_classes + 1u)));  // (states are in visit order: the first rows are the hot ones)
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;

@@ -68,7 +68,8 @@ struct ScanArgs {
 // through the pass's DFA. A list holds a few percent of the batch, so what matters is latency per step: the table's first n_hot rows
 // (states are numbered by how often the tuning sample's candidates visit them, start state first) are staged in LDS — a step there
 // is two dependent LDS reads (class, cell) instead of an L2 round trip — and the rest is read from the L2-resident flat table.
-//   flat[s * n_classes + c] = next state | 0x8000 when entering it emits; emit / end lists are indexed by (renumbered) state.
+//   flat[s * (n_classes + 1) + c] = next state | 0x8000 when entering it emits; cell n_classes of a row = what entering that state
+//   emits (0, 0x8000 | the single local atom, or 1 = a list); emit / end lists are indexed by (renumbered) state.
 static constexpr uint32_t kListThreads = 512;
 static constexpr uint32_t kListHotBytes = 48 * 1024;  // 3 workgroups (24 waves) per CU
 struct ListScanArgs {
@@ -78,7 +79,7 @@ struct ListScanArgs {
     const uint16_t *flat;
     const uint8_t *classmap;  // 256 bytes
     uint32_t n_classes;
-    uint32_t n_hot;            // rows staged in LDS: n_hot * n_classes * 2 <= the launch's ListShape::hot_bytes
+    uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 1) * 2 <= the launch's ListShape::hot_bytes
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;

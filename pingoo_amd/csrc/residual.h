@@ -1,0 +1,563 @@
+// residual.h — the per-request bytecode interpreter for rules the column compiler cannot take.
+//
+// The reference evaluates ANY valid expression per request (Program::execute, pingoo/rules.rs:37-51). The column compiler
+// (compile.cpp) turns the predicates WAF rules are made of into atoms, DFAs and tries; expressions that compute with request values —
+// arithmetic on lengths / ports / ASNs, string concatenation, lists and maps holding request values, orderings and equalities between
+// two request values, conditionals that select non-Bool values, boolean structures whose DNF explodes — have no column form. Such a
+// rule is compiled WHOLE into a small stack program (residual.cpp) and evaluated by residual_kernel with one lane per request:
+// dynamically typed values, the interpreter's left-to-right short circuit and error propagation, result
+// `Bool(true)` = the rule matches. The result lands in the hit record of a pseudo pass, one column per residual rule; the verdict
+// kernel treats it like any other atom, so rule order / first-match-wins / actions are untouched.
+//
+// This file is shared by the device kernel (kernels.hip) and by a TEST-ONLY host build (tests/rvm_host.cpp): the same interpreter
+// source runs under g++ so that the CPU suite can fuzz it against the oracle without a GPU. The product library exports no host
+// evaluation entry point.
+//
+// Not covered (such a rule stays PWAF_E_UNSUPPORTED): `matches` with a pattern that is not a String literal (the regex would
+// have to be compiled per request), a literal pattern whose DFA exceeds the residual budget, dynamic keys into the context maps
+// (http_request[...] / client[...] / lists[...] with a computed key), nesting / stack / heap beyond the limits below.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PWAF_HD __host__ __device__ __forceinline__
+#define PWAF_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define PWAF_HD inline
+#define PWAF_HD_NOINLINE inline
+#endif
+
+namespace pwaf {
+namespace rvm {
+
+// ---- value model -----------------------------------------------------------------------------------------------------------------
+enum Type : uint32_t { T_ERR = 0, T_NULL, T_BOOL, T_INT, T_FLT, T_STR, T_IP, T_NET, T_LIST, T_CLIST, T_MAP };
+// T_STR   a = length; p = src << 48 | offset. src: < S_CONST = string column (field id: the request's bytes), S_CONST = the program's
+//         string pool, S_INLINE = up to 6 bytes held in p itself (client.country), S_ROPE = a concatenation: offset = index of its
+//         first segment in the lane's heap | segments << 24 (segments are plain T_STR values)
+// T_LIST  a = item count, p = index of the first item: bit 63 clear = the program's constant values, set = the lane's heap
+// T_CLIST a = configured list id (lists["name"]): typed items in the program's list tables
+// T_NET   p = index into the program's network table (an item of an Ip list; there is no literal syntax)
+// T_MAP   like T_LIST with 2 * a values: key (T_STR), value, key, value ...; keys are distinct
+struct Val {
+    uint32_t t, a;
+    uint64_t p;
+};
+static constexpr uint32_t S_CONST = 0xF0, S_INLINE = 0xF1, S_ROPE = 0xF2;
+static constexpr uint64_t kHeapBit = 1ull << 63;
+
+// ---- program -----------------------------------------------------------------------------------------------------------------------
+enum Op : uint8_t {
+    R_END = 0,
+    R_CONST,    // b = index into consts
+    R_FIELD,    // b = string column (0-4 fixed fields, 5+ header columns)
+    R_COUNTRY, R_PORT, R_ASN, R_IP,
+    R_CLIST,    // b = configured list id
+    R_INDEX,    // [obj, idx] -> item
+    R_SELECT,   // a map value [obj] . const key b (string const index)
+    R_CALL,     // a = function (Fn), b = argc << 12 | aux (matches: regex table id, 0xFFF = invalid pattern)
+    R_NOT, R_NEG,
+    R_BIN,      // a = BinOp (frontend.h numbering from B_EQ on)
+    R_AND_L,    // b = target: pops the left operand of &&; undecided -> falls through to the right operand
+    R_OR_L,
+    R_BOOL_CHK, // the right operand of && / || must be a Bool (an error stays an error)
+    R_COND,     // b = else target: pops the condition
+    R_JMP,      // b = target
+    R_MKLIST,   // b = n: pops n values into a heap list
+    R_MKMAP,    // b = n pairs: pops 2n values (key, value ...) into a heap map (later duplicates win)
+};
+enum Fn : uint8_t { FN_CONTAINS = 0, FN_STARTS, FN_ENDS, FN_LENGTH, FN_MATCHES };
+struct Ins {
+    uint8_t op, a;
+    uint16_t b;
+};
+static constexpr uint32_t kStack = 24, kHeap = 64, kMaxNest = 4, kMaxRope = 16;
+
+struct NetItem {
+    uint8_t addr[16];
+    uint8_t prefix, v6, pad[2];
+};
+struct ListDesc {     // one configured list
+    uint32_t type;    // PWAF_LIST_STRING / _INT / _IP
+    uint32_t first, n;  // STRING: entries [first, first + n) of lstr (offset, length pairs into strpool); INT: of lints; IP: of nets
+    uint32_t pad;
+};
+struct RegexDesc {    // one literal `matches` pattern compiled to a DFA (a single-pattern DfaGroup, see program.h)
+    uint32_t trans;   // byte offset in the blob of uint16 trans[n_states][n_classes]
+    uint32_t classmap;  // ... of 256 class bytes
+    uint32_t flags;   // ... of n_states bytes: bit 0 = entering the state is a match, bit 1 = ending the haystack in it is a match
+    uint32_t n_classes;
+};
+// The whole residual program of a rule set is ONE blob (uploaded as is): header, then sections at the header's byte offsets.
+struct Header {
+    uint32_t magic;          // 'RVM1'
+    uint32_t n_rules;        // residual rules = columns of the pseudo pass
+    uint32_t rules;          // -> uint32 entry[n_rules]: first instruction of each rule
+    uint32_t code;           // -> Ins[]
+    uint32_t consts;         // -> Val[]
+    uint32_t strpool;        // -> bytes
+    uint32_t lists;          // -> ListDesc[]
+    uint32_t lstr;           // -> uint32 pairs (offset into strpool, length)
+    uint32_t lints;          // -> int64[]
+    uint32_t nets;           // -> NetItem[]
+    uint32_t regexes;        // -> RegexDesc[]
+    uint32_t needs_geo;      // some rule reads client.asn / client.country
+    uint32_t total_bytes;
+    uint32_t pad[3];
+};
+
+// ---- request view ------------------------------------------------------------------------------------------------------------------
+struct Req {
+    const uint8_t *const *data;   // per string column: arena
+    const uint32_t *const *off;   // ... and offsets (n + 1)
+    uint32_t r;                   // request index
+    const uint8_t *ip;            // 16 bytes
+    uint32_t v6, port, asn;
+    uint32_t country;             // two bytes, memory order
+};
+
+struct Machine {
+    const uint8_t *blob;
+    const Header *h;
+    Req q;
+    Val heap[kHeap];
+    uint32_t heap_n;
+};
+
+// ---- helpers -------------------------------------------------------------------------------------------------------------------------
+PWAF_HD Val mk(uint32_t t, uint32_t a = 0, uint64_t p = 0) { Val v; v.t = t; v.a = a; v.p = p; return v; }
+PWAF_HD Val mk_bool(bool b) { return mk(T_BOOL, 0, b ? 1u : 0u); }
+PWAF_HD Val mk_int(int64_t i) { return mk(T_INT, 0, (uint64_t)i); }
+PWAF_HD Val mk_flt(double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return mk(T_FLT, 0, u); }
+PWAF_HD double as_flt(const Val &v) { double d; __builtin_memcpy(&d, &v.p, 8); return d; }
+PWAF_HD uint32_t str_src(const Val &v) { return (uint32_t)(v.p >> 48); }
+
+template <class T>
+PWAF_HD const T *section(const Machine &m, uint32_t off) { return reinterpret_cast<const T *>(m.blob + off); }
+PWAF_HD const Val *items_of(const Machine &m, const Val &l) {
+    return (l.p & kHeapBit) ? &m.heap[(uint32_t)(l.p & 0xFFFFFFFFu)] : section<Val>(m, m.h->consts) + (uint32_t)(l.p & 0xFFFFFFFFu);
+}
+
+// Bytes of a non-rope string (nullptr for a rope).
+PWAF_HD const uint8_t *flat_ptr(const Machine &m, const Val &s, uint8_t (&inl)[8]) {
+    const uint32_t src = str_src(s);
+    const uint32_t off = (uint32_t)(s.p & 0xFFFFFFFFu);
+    if (src < S_CONST) return m.q.data[src] + m.q.off[src][m.q.r] + off;
+    if (src == S_CONST) return m.blob + m.h->strpool + off;
+    if (src == S_INLINE) {
+        for (int k = 0; k < 6; k++) inl[k] = (uint8_t)(s.p >> (8 * k));
+        return inl;
+    }
+    return nullptr;
+}
+// Byte i of any string (ropes: a walk over the segments — residual rules are rare, clarity over speed).
+PWAF_HD_NOINLINE uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
+    uint8_t inl[8];
+    if (str_src(s) != S_ROPE) return flat_ptr(m, s, inl)[i];
+    const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = (uint32_t)((s.p >> 24) & 0xFFu);
+    for (uint32_t k = 0; k < nseg; k++) {
+        const Val &sg = m.heap[first + k];
+        if (i < sg.a) return flat_ptr(m, sg, inl)[i];
+        i -= sg.a;
+    }
+    return 0;
+}
+PWAF_HD_NOINLINE bool str_eq_at(const Machine &m, const Val &h, uint32_t at, const Val &n) {  // h[at, at + n.a) == n (caller checks the bounds)
+    uint8_t i1[8], i2[8];
+    const uint8_t *ph = str_src(h) != S_ROPE ? flat_ptr(m, h, i1) : nullptr, *pn = str_src(n) != S_ROPE ? flat_ptr(m, n, i2) : nullptr;
+    if (ph && pn) {
+        for (uint32_t k = 0; k < n.a; k++)
+            if (ph[at + k] != pn[k]) return false;
+        return true;
+    }
+    for (uint32_t k = 0; k < n.a; k++)
+        if (str_byte(m, h, at + k) != str_byte(m, n, k)) return false;
+    return true;
+}
+PWAF_HD int str_cmp(const Machine &m, const Val &a, const Val &b) {  // bytewise, like std::string_view::compare
+    const uint32_t n = a.a < b.a ? a.a : b.a;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint8_t x = str_byte(m, a, k), y = str_byte(m, b, k);
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return a.a < b.a ? -1 : a.a > b.a ? 1 : 0;
+}
+PWAF_HD bool str_find(const Machine &m, const Val &h, const Val &n) {
+    if (n.a > h.a) return false;
+    for (uint32_t s = 0; s + n.a <= h.a; s++)
+        if (str_eq_at(m, h, s, n)) return true;
+    return false;
+}
+PWAF_HD bool net_contains(const NetItem &nt, const uint8_t *ip, uint32_t v6) {  // ipnetwork semantics: family must match, mask compare
+    if ((nt.v6 != 0) != (v6 != 0)) return false;
+    const uint32_t bytes = v6 ? 16u : 4u;
+    uint32_t left = nt.prefix;
+    for (uint32_t k = 0; k < bytes && left; k++) {
+        const uint32_t take = left >= 8 ? 8u : left;
+        const uint8_t mask = (uint8_t)(0xFFu << (8u - take));
+        if ((nt.addr[k] & mask) != (ip[k] & mask)) return false;
+        left -= take;
+    }
+    return true;
+}
+
+// val_eq (D4: cross-type equality is false). Lists and maps nest at most kMaxNest deep (the compiler rejects deeper literals), so the
+// recursion is unrolled at compile time through the depth parameter instead of recursing on the device.
+template <int D>
+struct Eq {
+    static PWAF_HD_NOINLINE bool eq(const Machine &m, const Val &a, const Val &b) {
+        if (a.t == T_INT && b.t == T_FLT) return (double)(int64_t)a.p == as_flt(b);
+        if (a.t == T_FLT && b.t == T_INT) return as_flt(a) == (double)(int64_t)b.p;
+        if (a.t != b.t) return false;
+        switch (a.t) {
+            case T_NULL: return true;
+            case T_BOOL: case T_INT: return a.p == b.p;
+            case T_FLT: return as_flt(a) == as_flt(b);
+            case T_STR: return a.a == b.a && str_eq_at(m, a, 0, b);
+            case T_IP: return true;  // the only Ip value is the request's client.ip
+            case T_NET: {
+                const NetItem *nets = section<NetItem>(m, m.h->nets);
+                const NetItem &p = nets[a.p], &q = nets[b.p];
+                if (p.prefix != q.prefix || p.v6 != q.v6) return false;
+                for (int k = 0; k < 16; k++) if (p.addr[k] != q.addr[k]) return false;
+                return true;
+            }
+            case T_LIST: {
+                if (a.a != b.a) return false;
+                const Val *ia = items_of(m, a), *ib = items_of(m, b);
+                for (uint32_t k = 0; k < a.a; k++)
+                    if (!Eq<D - 1>::eq(m, ia[k], ib[k])) return false;
+                return true;
+            }
+            case T_MAP: {  // same key set, equal values
+                if (a.a != b.a) return false;
+                const Val *ia = items_of(m, a), *ib = items_of(m, b);
+                for (uint32_t k = 0; k < a.a; k++) {
+                    bool found = false;
+                    for (uint32_t j = 0; j < b.a && !found; j++)
+                        if (ia[2 * k].a == ib[2 * j].a && str_eq_at(m, ia[2 * k], 0, ib[2 * j])) {
+                            found = true;
+                            if (!Eq<D - 1>::eq(m, ia[2 * k + 1], ib[2 * j + 1])) return false;
+                        }
+                    if (!found) return false;
+                }
+                return true;
+            }
+            default: return false;  // (T_CLIST: the compiler rejects comparisons of configured lists)
+        }
+    }
+};
+template <>
+struct Eq<-1> {
+    static PWAF_HD bool eq(const Machine &, const Val &, const Val &) { return false; }  // unreachable: nesting is bounded at compile time
+};
+PWAF_HD bool val_eq(const Machine &m, const Val &a, const Val &b) { return Eq<(int)kMaxNest>::eq(m, a, b); }
+
+// -1 / 0 / 1, or 2 when not comparable (D5)
+PWAF_HD int val_cmp(const Machine &m, const Val &a, const Val &b) {
+    const bool an = a.t == T_INT || a.t == T_FLT, bn = b.t == T_INT || b.t == T_FLT;
+    if (a.t == T_INT && b.t == T_INT) return (int64_t)a.p < (int64_t)b.p ? -1 : (int64_t)a.p > (int64_t)b.p ? 1 : 0;
+    if (an && bn) {
+        const double x = a.t == T_INT ? (double)(int64_t)a.p : as_flt(a), y = b.t == T_INT ? (double)(int64_t)b.p : as_flt(b);
+        if (x != x || y != y) return 2;
+        return x < y ? -1 : x > y ? 1 : 0;
+    }
+    if (a.t == T_STR && b.t == T_STR) return str_cmp(m, a, b);
+    return 2;
+}
+
+// list.contains(x) / x in list (D10, D12: a network item contains an Ip by CIDR containment)
+PWAF_HD_NOINLINE bool list_contains(const Machine &m, const Val &l, const Val &x) {
+    if (l.t == T_LIST) {
+        const Val *it = items_of(m, l);
+        const NetItem *nets = section<NetItem>(m, m.h->nets);
+        for (uint32_t k = 0; k < l.a; k++) {
+            if (it[k].t == T_NET && x.t == T_IP) {
+                if (net_contains(nets[it[k].p], m.q.ip, m.q.v6)) return true;
+            } else if (val_eq(m, it[k], x)) {
+                return true;
+            }
+        }
+        return false;
+    }
+    const ListDesc &d = section<ListDesc>(m, m.h->lists)[l.a];
+    if (d.type == 0 /* PWAF_LIST_STRING */) {
+        if (x.t != T_STR) return false;
+        const uint32_t *sp = section<uint32_t>(m, m.h->lstr) + 2 * (size_t)d.first;
+        for (uint32_t k = 0; k < d.n; k++) {
+            if (sp[2 * k + 1] != x.a) continue;
+            const Val item = mk(T_STR, sp[2 * k + 1], ((uint64_t)S_CONST << 48) | sp[2 * k]);
+            if (str_eq_at(m, x, 0, item)) return true;
+        }
+        return false;
+    }
+    if (d.type == 1 /* PWAF_LIST_INT */) {
+        const int64_t *li = section<int64_t>(m, m.h->lints) + d.first;
+        if (x.t == T_INT) { for (uint32_t k = 0; k < d.n; k++) if (li[k] == (int64_t)x.p) return true; }
+        else if (x.t == T_FLT) { const double f = as_flt(x); for (uint32_t k = 0; k < d.n; k++) if ((double)li[k] == f) return true; }
+        return false;
+    }
+    const NetItem *nets = section<NetItem>(m, m.h->nets) + d.first;
+    if (x.t == T_IP) { for (uint32_t k = 0; k < d.n; k++) if (net_contains(nets[k], m.q.ip, m.q.v6)) return true; }
+    else if (x.t == T_NET) {
+        const NetItem &q = section<NetItem>(m, m.h->nets)[x.p];
+        for (uint32_t k = 0; k < d.n; k++) {
+            bool same = nets[k].prefix == q.prefix && nets[k].v6 == q.v6;
+            for (int b = 0; b < 16 && same; b++) same = nets[k].addr[b] == q.addr[b];
+            if (same) return true;
+        }
+    }
+    return false;
+}
+PWAF_HD bool map_has(const Machine &m, const Val &mp, const Val &key, Val *out) {
+    const Val *it = items_of(m, mp);
+    for (uint32_t k = 0; k < mp.a; k++)
+        if (it[2 * k].a == key.a && str_eq_at(m, it[2 * k], 0, key)) {
+            if (out) *out = it[2 * k + 1];
+            return true;
+        }
+    return false;
+}
+
+PWAF_HD_NOINLINE bool regex_match(const Machine &m, uint32_t id, const Val &s) {
+    const RegexDesc &d = section<RegexDesc>(m, m.h->regexes)[id];
+    const uint16_t *trans = section<uint16_t>(m, d.trans);
+    const uint8_t *cm = m.blob + d.classmap, *fl = m.blob + d.flags;
+    uint32_t st = 0;
+    if (fl[0] & 1u) return true;
+    for (uint32_t i = 0; i < s.a; i++) {
+        st = trans[st * d.n_classes + cm[str_byte(m, s, i)]];
+        if (fl[st] & 1u) return true;
+    }
+    return (fl[st] & 2u) != 0;
+}
+
+PWAF_HD Val arith(uint32_t op /* B_ADD.. */, const Val &l, const Val &r, Machine &m);
+
+// ---- the interpreter: one rule, one request ---------------------------------------------------------------------------------------------
+// BinOp numbering of frontend.h: B_OR 0, B_AND 1, B_EQ 2, B_NE 3, B_LT 4, B_LE 5, B_GT 6, B_GE 7, B_IN 8, B_ADD 9, B_SUB 10, B_MUL 11, B_DIV 12, B_MOD 13
+PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
+    const Ins *code = section<Ins>(m, m.h->code);
+    const Val *consts = section<Val>(m, m.h->consts);
+    uint32_t pc = section<uint32_t>(m, m.h->rules)[rule];
+    Val st[kStack];
+    uint32_t sp = 0;
+    m.heap_n = 0;
+    const Val ERR = mk(T_ERR);
+    for (;;) {
+        const Ins in = code[pc++];
+        switch (in.op) {
+            case R_END: return sp == 1 && st[0].t == T_BOOL && st[0].p == 1;
+            case R_CONST: st[sp++] = consts[in.b]; break;
+            case R_FIELD: st[sp++] = mk(T_STR, m.q.off[in.b][m.q.r + 1] - m.q.off[in.b][m.q.r], (uint64_t)in.b << 48); break;
+            case R_COUNTRY: st[sp++] = mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); break;
+            case R_PORT: st[sp++] = mk_int((int64_t)m.q.port); break;
+            case R_ASN: st[sp++] = mk_int((int64_t)m.q.asn); break;
+            case R_IP: st[sp++] = mk(T_IP); break;
+            case R_CLIST: st[sp++] = mk(T_CLIST, in.b); break;
+            case R_NOT: {
+                Val &x = st[sp - 1];
+                if (x.t == T_ERR) break;
+                x = x.t == T_BOOL ? mk_bool(x.p == 0) : ERR;
+                break;
+            }
+            case R_NEG: {
+                Val &x = st[sp - 1];
+                if (x.t == T_INT) x = (int64_t)x.p == INT64_MIN ? ERR : mk_int(-(int64_t)x.p);
+                else if (x.t == T_FLT) x = mk_flt(-as_flt(x));
+                else x = ERR;
+                break;
+            }
+            case R_AND_L: case R_OR_L: {
+                const Val l = st[--sp];
+                if (l.t == T_ERR || l.t != T_BOOL) { st[sp++] = ERR; pc = in.b; break; }
+                if ((in.op == R_OR_L) == (l.p != 0)) { st[sp++] = l; pc = in.b; }  // decided by the left operand
+                break;
+            }
+            case R_BOOL_CHK: {
+                Val &x = st[sp - 1];
+                if (x.t != T_BOOL) x = ERR;
+                break;
+            }
+            case R_COND: {
+                const Val c = st[--sp];
+                if (c.t != T_BOOL) { st[sp++] = ERR; pc = code[in.b - 1].b; break; }  // (the instruction before the else branch is the then-branch's R_JMP to the end)
+                if (c.p == 0) pc = in.b;
+                break;
+            }
+            case R_JMP: pc = in.b; break;
+            case R_MKLIST: {
+                const uint32_t n = in.b;
+                bool err = false;
+                for (uint32_t k = 0; k < n; k++) err = err || st[sp - n + k].t == T_ERR;
+                Val v = ERR;
+                if (!err) {
+                    v = mk(T_LIST, n, kHeapBit | m.heap_n);
+                    for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = st[sp - n + k];
+                }
+                sp -= n;
+                st[sp++] = v;
+                break;
+            }
+            case R_MKMAP: {
+                const uint32_t n = in.b;
+                bool err = false;
+                for (uint32_t k = 0; k < 2 * n; k++) err = err || st[sp - 2 * n + k].t == T_ERR || ((k & 1) == 0 && st[sp - 2 * n + k].t != T_STR);
+                Val v = ERR;
+                if (!err) {
+                    const uint32_t base = m.heap_n;
+                    uint32_t cnt = 0;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const Val &key = st[sp - 2 * n + 2 * k], &val = st[sp - 2 * n + 2 * k + 1];
+                        bool dup = false;
+                        for (uint32_t j = 0; j < cnt && !dup; j++)
+                            if (m.heap[base + 2 * j].a == key.a && str_eq_at(m, m.heap[base + 2 * j], 0, key)) { m.heap[base + 2 * j + 1] = val; dup = true; }
+                        if (!dup) { m.heap[base + 2 * cnt] = key; m.heap[base + 2 * cnt + 1] = val; cnt++; }
+                    }
+                    m.heap_n = base + 2 * cnt;
+                    v = mk(T_MAP, cnt, kHeapBit | base);
+                }
+                sp -= 2 * n;
+                st[sp++] = v;
+                break;
+            }
+            case R_INDEX: {
+                const Val i = st[--sp], o = st[--sp];
+                Val v = ERR;
+                if (o.t == T_ERR || i.t == T_ERR) {}
+                else if (o.t == T_MAP) { if (i.t == T_STR) { Val out; if (map_has(m, o, i, &out)) v = out; } }
+                else if (o.t == T_LIST) { if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < o.a) v = items_of(m, o)[i.p]; }
+                else if (o.t == T_CLIST) {
+                    const ListDesc &d = section<ListDesc>(m, m.h->lists)[o.a];
+                    if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < d.n) {
+                        if (d.type == 0) { const uint32_t *sp2 = section<uint32_t>(m, m.h->lstr) + 2 * (size_t)(d.first + i.p); v = mk(T_STR, sp2[1], ((uint64_t)S_CONST << 48) | sp2[0]); }
+                        else if (d.type == 1) v = mk_int(section<int64_t>(m, m.h->lints)[d.first + i.p]);
+                        else v = mk(T_NET, 0, d.first + i.p);
+                    }
+                }
+                st[sp++] = v;
+                break;
+            }
+            case R_SELECT: {
+                Val &o = st[sp - 1];
+                if (o.t == T_ERR) break;
+                Val out = ERR;
+                if (o.t == T_MAP) { Val got; if (map_has(m, o, consts[in.b], &got)) out = got; }
+                o = out;
+                break;
+            }
+            case R_CALL: {
+                const uint32_t argc = in.b >> 12, aux = in.b & 0xFFFu;
+                bool err = false;
+                for (uint32_t k = 0; k <= argc; k++) err = err || st[sp - 1 - argc + k].t == T_ERR;
+                const Val recv = st[sp - 1 - argc], arg = argc ? st[sp - argc] : ERR;
+                sp -= argc + 1;
+                Val v = ERR;
+                if (err) { st[sp++] = v; break; }
+                switch (in.a) {
+                    case FN_CONTAINS:
+                        if (argc != 1) break;
+                        if (recv.t == T_STR) { if (arg.t == T_STR) v = mk_bool(str_find(m, recv, arg)); }
+                        else if (recv.t == T_LIST || recv.t == T_CLIST) v = mk_bool(list_contains(m, recv, arg));
+                        else if (recv.t == T_MAP) { if (arg.t == T_STR) v = mk_bool(map_has(m, recv, arg, nullptr)); }
+                        break;
+                    case FN_STARTS: case FN_ENDS:
+                        if (argc != 1 || recv.t != T_STR || arg.t != T_STR) break;
+                        if (arg.a > recv.a) v = mk_bool(false);
+                        else v = mk_bool(str_eq_at(m, recv, in.a == FN_STARTS ? 0u : recv.a - arg.a, arg));
+                        break;
+                    case FN_LENGTH:
+                        if (argc != 0) break;
+                        if (recv.t == T_STR || recv.t == T_LIST || recv.t == T_MAP) v = mk_int((int64_t)recv.a);
+                        else if (recv.t == T_CLIST) v = mk_int((int64_t)section<ListDesc>(m, m.h->lists)[recv.a].n);
+                        break;
+                    case FN_MATCHES:
+                        if (argc != 1 || recv.t != T_STR || arg.t != T_STR || aux == 0xFFFu) break;  // (an invalid pattern is an execution error)
+                        v = mk_bool(regex_match(m, aux, recv));
+                        break;
+                    default: break;
+                }
+                st[sp++] = v;
+                break;
+            }
+            case R_BIN: {
+                const Val r = st[--sp], l = st[--sp];
+                Val v = ERR;
+                if (l.t == T_ERR || r.t == T_ERR) { st[sp++] = v; break; }
+                switch (in.a) {
+                    case 2: v = mk_bool(val_eq(m, l, r)); break;
+                    case 3: v = mk_bool(!val_eq(m, l, r)); break;
+                    case 4: case 5: case 6: case 7: {
+                        const int c = val_cmp(m, l, r);
+                        if (c != 2) v = mk_bool(in.a == 4 ? c < 0 : in.a == 5 ? c <= 0 : in.a == 6 ? c > 0 : c >= 0);
+                        break;
+                    }
+                    case 8:
+                        if (r.t == T_LIST || r.t == T_CLIST) v = mk_bool(list_contains(m, r, l));
+                        else if (r.t == T_MAP && l.t == T_STR) v = mk_bool(map_has(m, r, l, nullptr));
+                        break;
+                    default: v = arith(in.a, l, r, m); break;
+                }
+                st[sp++] = v;
+                break;
+            }
+            default: return false;
+        }
+    }
+}
+
+PWAF_HD Val arith(uint32_t op, const Val &l, const Val &r, Machine &m) {
+    const Val ERR = mk(T_ERR);
+    if (l.t == T_INT && r.t == T_INT) {
+        const int64_t a = (int64_t)l.p, b = (int64_t)r.p;
+        int64_t o;
+        switch (op) {
+            case 9: return __builtin_add_overflow(a, b, &o) ? ERR : mk_int(o);
+            case 10: return __builtin_sub_overflow(a, b, &o) ? ERR : mk_int(o);
+            case 11: return __builtin_mul_overflow(a, b, &o) ? ERR : mk_int(o);
+            case 12: if (b == 0 || (a == INT64_MIN && b == -1)) return ERR; return mk_int(a / b);
+            case 13: if (b == 0) return ERR; if (a == INT64_MIN && b == -1) return mk_int(0); return mk_int(a % b);
+            default: return ERR;
+        }
+    }
+    const bool ln = l.t == T_INT || l.t == T_FLT, rn = r.t == T_INT || r.t == T_FLT;
+    if (ln && rn) {  // at least one Float
+        const double a = l.t == T_FLT ? as_flt(l) : (double)(int64_t)l.p, b = r.t == T_FLT ? as_flt(r) : (double)(int64_t)r.p;
+        switch (op) {
+            case 9: return mk_flt(a + b);
+            case 10: return mk_flt(a - b);
+            case 11: return mk_flt(a * b);
+            case 12: return mk_flt(a / b);
+            default: return ERR;
+        }
+    }
+    if (op == 9 && l.t == T_STR && r.t == T_STR) {
+        // concatenation: a rope over the operands' segments (no bytes are copied)
+        if (l.a == 0) return r;
+        if (r.a == 0) return l;
+        const uint32_t first = m.heap_n;
+        uint32_t n = 0;
+        for (int side = 0; side < 2; side++) {
+            const Val &s = side == 0 ? l : r;
+            if (str_src(s) == S_ROPE) {
+                const uint32_t f0 = (uint32_t)(s.p & 0xFFFFFFu), ns = (uint32_t)((s.p >> 24) & 0xFFu);
+                for (uint32_t k = 0; k < ns; k++) m.heap[m.heap_n++] = m.heap[f0 + k], n++;
+            } else {
+                m.heap[m.heap_n++] = s;
+                n++;
+            }
+        }
+        return mk(T_STR, l.a + r.a, ((uint64_t)S_ROPE << 48) | ((uint64_t)n << 24) | first);
+    }
+    if (op == 9 && l.t == T_LIST && r.t == T_LIST) {
+        const uint32_t first = m.heap_n;
+        const Val *a = items_of(m, l), *b = items_of(m, r);
+        for (uint32_t k = 0; k < l.a; k++) m.heap[m.heap_n++] = a[k];
+        for (uint32_t k = 0; k < r.a; k++) m.heap[m.heap_n++] = b[k];
+        return mk(T_LIST, l.a + r.a, kHeapBit | first);
+    }
+    return ERR;
+}
+
+}  // namespace rvm
+}  // namespace pwaf
