@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PWAF_ABI_VERSION 1u
+#define PWAF_ABI_VERSION 2u /* 2: pwaf_batch carries header columns; strict rule compilation by default (PWAF_OPT_LENIENT, PWAF_W_PARTIAL);
+                            * residual rules; pwaf_request carries header values; pwaf_node_evaluate_device; pwaf_program_tune */
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define PWAF_OK 0
@@ -42,6 +43,7 @@ extern "C" {
 #define PWAF_E_DEVICE (-5)       /* HIP error / no GPU: host may fail open                    */
 #define PWAF_E_BATCH (-6)        /* malformed batch (offsets not monotone, bad country, ...)  */
 #define PWAF_E_NOMEM (-7)
+#define PWAF_W_PARTIAL 1          /* (positive: a warning, the object WAS created) with PWAF_OPT_LENIENT some rule is not evaluated */
 
 /* ---- verdict vocabulary (rules::Action, rules/rules.rs:30-35) ------------------------ */
 #define PWAF_ACTION_ALLOW 0u   /* no rule fired: proceed to routing (http_listener.rs:266)   */
@@ -117,8 +119,13 @@ void pwaf_list_free(char **items, size_t n);
 
 #define PWAF_OPT_NO_UA_GATE 1u        /* skip gate A (http_listener.rs:196-198)             */
 #define PWAF_OPT_NO_CAPTCHA_BYPASS 2u /* skip gate B (http_listener.rs:200-204)             */
-#define PWAF_OPT_STRICT 8u            /* a rule the device compiler cannot take fails engine creation (default: that rule alone never
-                                       * matches and reports why through pwaf_program_rule_status / the warnings) */
+#define PWAF_OPT_STRICT 8u            /* (deprecated: strict is the default since ABI 2) */
+#define PWAF_OPT_LENIENT 32u          /* a rule neither the column compiler nor the residual interpreter can take does NOT fail creation:
+                                       * that rule alone never matches, pwaf_program_rule_status / the warnings say why, and creation
+                                       * returns PWAF_W_PARTIAL instead of PWAF_OK. Default (ABI 2): creation fails with the rule's index —
+                                       * the reference evaluates every valid expression (pingoo/rules.rs:37-51), a silently dropped Block
+                                       * rule is a fail-open hole */
+#define PWAF_OPT_NO_RESIDUAL 64u      /* do not use the per-request residual interpreter (testing / benchmarking the column path alone) */
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 #define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1
                                        * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */

@@ -5,7 +5,7 @@ Kept in one place so the product wrapper (pingoo_amd.engine) and the test-side o
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 E_INVALID_ARG = -1
@@ -23,7 +23,8 @@ RULE_CAPTCHA_ENDPOINT = 0xFFFFFFFD
 RULE_ACTION_BLOCK, RULE_ACTION_CAPTCHA = 1, 2
 
 LIST_STRING, LIST_INT, LIST_IP = 0, 1, 2
-OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER, OPT_STRICT, OPT_FILTER_STRIDE2 = 1, 2, 4, 8, 16
+OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER, OPT_STRICT, OPT_FILTER_STRIDE2, OPT_LENIENT, OPT_NO_RESIDUAL = 1, 2, 4, 8, 16, 32, 64
+W_PARTIAL = 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CAPTCHA_VERIFIED = 1
 N_FIELDS = 5

@@ -13,8 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpwaf.so")
-SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "filter.cpp", "compile.cpp", "loaders.cpp", "batcher.cpp", "node.cpp", "engine.cpp", "kernels.hip"]
-HEADERS = ["frontend.h", "program.h", "kernels.h", os.path.join("..", "..", "include", "pwaf.h")]
+SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "filter.cpp", "residual.cpp", "compile.cpp", "loaders.cpp", "batcher.cpp", "node.cpp", "engine.cpp", "kernels.hip"]
+HEADERS = ["frontend.h", "program.h", "kernels.h", "residual.h", os.path.join("..", "..", "include", "pwaf.h")]
 
 
 def hipcc() -> str:

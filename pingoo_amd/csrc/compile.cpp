@@ -1086,10 +1086,32 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // ---- user rules ----
     P.n_user_rules = (uint32_t)in.n_rules;
     P.rule_status.assign(in.n_rules, {PWAF_OK, std::string()});
-    const bool strict = (P.flags & PWAF_OPT_STRICT) != 0;
+    const bool strict = !(P.flags & PWAF_OPT_LENIENT);
     auto unsupported_rule = [&](size_t k, const std::string &why) {
         P.rule_status[k] = {PWAF_E_UNSUPPORTED, why};
         P.warnings.push_back("rule #" + std::to_string(k) + " is NOT evaluated (it never matches): " + why);
+    };
+    // A rule the column compiler cannot take is lowered WHOLE to a stack program for the residual interpreter (residual.h): it
+    // becomes ONE atom whose column residual_kernel fills per request. Only what that compiler refuses as well stays unsupported.
+    ResidualBuilder residual;
+    std::vector<ResidualList> rlists;
+    for (auto &l : lists) {
+        ResidualList rl;
+        rl.name = l.name; rl.type = l.type; rl.strs = l.strs; rl.ints = l.ints; rl.nets = l.nets;
+        rlists.push_back(std::move(rl));
+    }
+    std::vector<Syntax> syntaxes(in.n_rules);
+    auto try_residual = [&](size_t k, const std::string &col_why, std::string &why) -> int {
+        if (P.flags & PWAF_OPT_NO_RESIDUAL) { why = col_why; return -1; }
+        std::string rwhy;
+        const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_field(name); }, rwhy);
+        if (idx < 0) { why = col_why + "; and the residual interpreter cannot take it either: " + rwhy; return -1; }
+        Atom a;
+        a.kind = ATOM_RESIDUAL;
+        a.ref = (uint32_t)idx;
+        a.key = "R" + std::to_string(idx);
+        P.warnings.push_back("rule #" + std::to_string(k) + " is evaluated by the per-request residual interpreter (slow path): " + col_why);
+        return rc.intern_atom(std::move(a));
     };
     for (size_t k = 0; k < in.n_rules; k++) {
         const pwaf_rule_desc &rd = in.rules[k];
@@ -1107,7 +1129,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         }
         int t_root = 1;  // expression None => match all (pingoo/rules.rs:48-50)
         if (rd.expression) {
-            Syntax syn;
+            Syntax &syn = syntaxes[k];
             std::string perr;
             if (!parse_expression(rd.expression, syn, perr)) {
                 set_err(err, PWAF_E_SYNTAX, (uint32_t)k, "error parsing rules: Expression is not valid: " + perr + " (rule " + rname + ")");
@@ -1129,12 +1151,18 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                     t_root = 0;
                 }
             } catch (Unsupported &u) {
-                if (strict) {
-                    set_err(err, PWAF_E_UNSUPPORTED, (uint32_t)k, "rule " + rname + ": " + u.msg);
-                    return PWAF_E_UNSUPPORTED;
+                std::string why;
+                const int ra = try_residual(k, u.msg, why);
+                if (ra >= 0) {
+                    t_root = dag.atom(ra);
+                } else {
+                    if (strict) {
+                        set_err(err, PWAF_E_UNSUPPORTED, (uint32_t)k, "rule " + rname + ": " + why);
+                        return PWAF_E_UNSUPPORTED;
+                    }
+                    unsupported_rule(k, "rule " + rname + ": " + why);
+                    t_root = 0;
                 }
-                unsupported_rule(k, "rule " + rname + ": " + u.msg);
-                t_root = 0;
             }
         }
         if (eff_u == PWAF_ACTION_ALLOW && eff_v == PWAF_ACTION_ALLOW) continue;  // no action can ever take effect
@@ -1150,11 +1178,17 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             rule_terms.push_back(dnf.conv(r.t_root, false));
         } catch (Unsupported &u) {
             uint32_t idx = r.public_idx < in.n_rules ? r.public_idx : 0xFFFFFFFFu;
+            std::string why = u.msg;
+            const int ra = idx != 0xFFFFFFFFu ? try_residual(idx, u.msg, why) : -1;
+            if (ra >= 0) {
+                rule_terms.push_back({Term{(uint32_t)ra << 1}});  // the rule = its residual atom
+                continue;
+            }
             if (strict || idx == 0xFFFFFFFFu) {
-                set_err(err, PWAF_E_UNSUPPORTED, idx, "rule #" + std::to_string(r.public_idx) + ": " + u.msg);
+                set_err(err, PWAF_E_UNSUPPORTED, idx, "rule #" + std::to_string(r.public_idx) + ": " + why);
                 return PWAF_E_UNSUPPORTED;
             }
-            unsupported_rule(idx, u.msg);
+            unsupported_rule(idx, why);
             rule_terms.push_back({});  // no term: never matches
         }
     }
@@ -1167,7 +1201,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     uint32_t col = 1;
     for (size_t a = 1; a < P.atoms.size(); a++) {
         Atom &at = P.atoms[a];
-        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP) continue;
+        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP || at.kind == ATOM_RESIDUAL) continue;
         at.id = col++;
     }
     uint32_t n_numeric = col - 1;
@@ -1259,11 +1293,19 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                         if ((l >> 1) == ba.first) why = &ba.second;
             if (!why) continue;
             const uint32_t idx = routs[k].public_idx < in.n_rules ? routs[k].public_idx : 0xFFFFFFFFu;
+            std::string why2 = *why;
+            const int ra = idx != 0xFFFFFFFFu ? try_residual(idx, *why, why2) : -1;
+            if (ra >= 0) {  // (the interpreter walks a DFA of the pattern alone, within a budget of its own)
+                rule_terms[k] = {Term{(uint32_t)ra << 1}};
+                if ((size_t)ra >= used.size()) used.resize((size_t)ra + 1, 0);
+                used[(size_t)ra] = 1;
+                continue;
+            }
             if (strict || idx == 0xFFFFFFFFu) {
-                set_err(err, PWAF_E_UNSUPPORTED, idx, *why);
+                set_err(err, PWAF_E_UNSUPPORTED, idx, why2);
                 return PWAF_E_UNSUPPORTED;
             }
-            unsupported_rule(idx, *why);
+            unsupported_rule(idx, why2);
             rule_terms[k].clear();
         }
     }
@@ -1291,6 +1333,21 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             at.id = next_col++;
             P.fcmp.push_back({at.id, (uint8_t)at.c, at.field, (uint8_t)at.ref, 0});
         }
+    }
+    // residual rules: the last pseudo pass, column = residual_base + the rule's index among the residual rules (every one that was
+    // lowered has a column, used or not: the kernel evaluates the blob's rules by index)
+    P.residual_base = next_col;
+    P.n_residual = (uint32_t)residual.n_rules();
+    next_col += P.n_residual;
+    for (size_t a = 1; a < P.atoms.size(); a++)
+        if (P.atoms[a].kind == ATOM_RESIDUAL) P.atoms[a].id = P.residual_base + P.atoms[a].ref;
+    if (P.n_residual) {
+        P.residual_blob = residual.blob();
+        P.residual_needs_geo = residual.needs_geo();
+    }
+    if (P.n_residual > kMaxLocalAtoms) {
+        set_err(err, PWAF_E_UNSUPPORTED, 0xFFFFFFFFu, "too many rules for the residual interpreter");
+        return PWAF_E_UNSUPPORTED;
     }
     P.n_cols = next_col;
     if (P.groups.size() > kMaxGroups) {
@@ -1320,7 +1377,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     // ---- numeric atom descriptors ----
     for (size_t a = 1; a < P.atoms.size(); a++) {
         const Atom &at = P.atoms[a];
-        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP) continue;
+        if (!used[a] || at.kind == ATOM_SCAN || at.kind == ATOM_FCMP || at.kind == ATOM_RESIDUAL) continue;
         NumAtomDev d{};
         d.col = at.id;
         d.kind = at.kind;
@@ -1496,6 +1553,11 @@ std::vector<uint8_t> dump_program(const Program &p) {
     w.section("GR6 ", 0, p.geo_trie.root6.data(), p.geo_trie.root6.size() * 4);
     w.section("GNOD", p.geo_trie.n_nodes(), p.geo_trie.nodes.data(), p.geo_trie.nodes.size() * 4);
     w.section("GREC", (uint32_t)p.geo_recs.size(), p.geo_recs.data(), p.geo_recs.size() * sizeof(GeoRec));
+    if (p.n_residual) {
+        const uint32_t rs[2] = {p.n_residual, p.residual_base};
+        w.section("RSDL", 2, rs, sizeof rs);
+        w.section("RVMB", p.n_residual, p.residual_blob.data(), p.residual_blob.size());  // the residual interpreter's program image (residual.h)
+    }
     return w.buf;
 }
 

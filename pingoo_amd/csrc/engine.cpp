@@ -109,6 +109,7 @@ struct Scratch {
     bool last_own = false;       // ... which was the context's own stream (a host batch)
     DevBuf status;            // one sticky word: bit 0 = some batch on this context exhausted the overflow pool (cleared when reported)
     uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
+    DevBuf res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
     DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
@@ -139,7 +140,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -172,6 +173,7 @@ struct pwaf_engine {
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
     std::mutex mu;  // guards the context ring, the profiling state and table rebuilds (pwaf_engine_tune)
+    DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
     DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir16, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
     uint32_t n_visit = 0;  // gap passes (visited bitmaps per batch)
@@ -337,7 +339,8 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     // index into emit_off (a list). The cell rides with the row into LDS: round 2 called the out-of-line list walk (three dependent
     // global loads, ~2 us for the whole wave) for every match of every lane — benign candidates are mostly true hits, so a wave of
     // 64 candidates stalled on the order of a hundred times per walk.
-    const uint32_t stride = C + 1;
+    // ... and one STAY cell (= the state itself, unflagged): what a lane past its field's end "reads", so that no step is conditional.
+    const uint32_t stride = C + 2;
     std::vector<uint16_t> flat((size_t)S * stride);
     std::vector<uint32_t> emit_off(1, 0), end_off(1, 0);
     std::vector<uint16_t> emit_list, end_list;
@@ -349,6 +352,7 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
         }
         const uint32_t ne = g.emit_off[(size_t)s + 1] - g.emit_off[s];
         flat[(size_t)q * stride + C] = ne == 0 ? (uint16_t)0 : (ne == 1 && g.emit_list[g.emit_off[s]] < 0x7FFFu) ? (uint16_t)(0x8000u | g.emit_list[g.emit_off[s]]) : (uint16_t)1;
+        flat[(size_t)q * stride + C + 1] = (uint16_t)q;
         emit_list.insert(emit_list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[(size_t)s + 1]);
         emit_off.push_back((uint32_t)emit_list.size());
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
@@ -499,8 +503,10 @@ int assign_lists(pwaf_engine *e) {
     }
     {
         // the verdict kernel's pass table: first column + where the pass's visited bitmap lives
-        std::vector<PassInfo> pt(e->groups.size() + 1);
+        std::vector<PassInfo> pt(e->groups.size() + 2);
         pt[e->groups.size()] = PassInfo{P.fcmp_base, 0u};  // the pseudo pass of the field-against-field atoms (dense records)
+        // ... and the one of the residual rules (right after it, or in its place when there are no such atoms)
+        pt[e->groups.size() + (P.fcmp.empty() ? 0u : 1u)] = PassInfo{P.residual_base, 0u};
         uint32_t fi = 0;
         for (size_t k = 0; k < e->groups.size(); k++) {
             const DevGroup &d = e->groups[k];
@@ -551,7 +557,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
-    const uint32_t n_passes = (uint32_t)e->groups.size() + (P.fcmp.empty() ? 0u : 1u);  // (+ the pseudo pass of the field-against-field atoms)
+    const uint32_t residual_pass = (uint32_t)e->groups.size() + (P.fcmp.empty() ? 0u : 1u);
+    const uint32_t n_passes = residual_pass + (P.n_residual ? 1u : 0u);  // (+ the pseudo passes of the field-against-field atoms and of the residual rules)
     int rc;
     // scratch sized for the worst case the 288 GB part can afford: one 4-byte hit record per (pass, request) and an overflow
     // pool of 8 entries per request (exhaustion is reported through the status word, never silently)
@@ -843,7 +850,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
-        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * (d.n_classes + 1u)));  // (states are in visit order: the first rows are the hot ones)
+        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * (d.n_classes + 2u)));  // (states are in visit order: the first rows are the hot ones)
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
@@ -1038,6 +1045,39 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (he) return fail(PWAF_E_DEVICE, std::string("field comparison kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark("fcmp", 0xFBu))) return rc;
     }
+    if (P.n_residual) {
+        // rules the column compiler could not take: interpreted per request (residual.h), results = the hit records of the last pseudo pass
+        ResidualArgs ra{};
+        const size_t nc = e->n_fields;
+        if ((rc = S.res_cols.reserve(nc * 16))) return rc;
+        std::vector<const void *> ptrs(2 * nc);
+        for (size_t f = 0; f < nc; f++) { ptrs[f] = cols[f].data; ptrs[nc + f] = cols[f].offsets; }
+        HIP_TRY(hipMemcpyAsync(S.res_cols.p, ptrs.data(), nc * 16, hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+        ra.data = (const uint8_t *const *)S.res_cols.p;
+        ra.off = (const uint32_t *const *)((const char *)S.res_cols.p + nc * 8);
+        ra.blob = (const uint8_t *)e->residual_blob.p;
+        ra.n = n;
+        ra.n_rules = P.n_residual;
+        ra.ip = db.ip;
+        ra.ip_is_v6 = db.ip_is_v6;
+        ra.port = db.port;
+        ra.asn = db.asn;
+        ra.country = db.country;
+        ra.has_geo = (P.has_geo && P.residual_needs_geo) ? 1u : 0u;
+        ra.geo_root4 = (const uint32_t *)e->geo_rec_root4.p;
+        ra.geo_root6 = (const uint32_t *)e->geo_rec_root6.p;
+        ra.geo_nodes = (const uint32_t *)e->geo_rec_nodes.p;
+        ra.geo_recs = (const GeoRec *)e->geo_recs.p;
+        ra.rec = (uint32_t *)S.rec.p + (size_t)residual_pass * n;
+        ra.pool = (PoolEntry *)S.pool.p;
+        ra.pool_count = (uint32_t *)S.ctrl.p;
+        ra.pool_cap = pool_cap;
+        ra.status = (uint32_t *)S.status.p;
+        if ((rc = mark(nullptr, 0))) return rc;
+        int he2 = launch_residual(ra, stream);
+        if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
+        if ((rc = mark("residual", 0xF9u))) return rc;
+    }
     HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
@@ -1106,6 +1146,8 @@ int pwaf_program_compile(const pwaf_rule_desc *rules, size_t n_rules, const pwaf
     auto *pp = new pwaf_program();
     pp->p = std::move(p);
     *out = pp;
+    for (auto &st : pp->p->rule_status)
+        if (st.first != PWAF_OK) return PWAF_W_PARTIAL;  // (PWAF_OPT_LENIENT: created, but some rule is not evaluated)
     return PWAF_OK;
 }
 
@@ -1137,7 +1179,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     if (!out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     pwaf_program *pp = nullptr;
     int rc = pwaf_program_compile(rules, n_rules, lists, n_lists, geoip, opts, &pp, err);
-    if (rc) return rc;
+    if (rc < 0) return rc;
+    const int partial = rc;  // PWAF_W_PARTIAL or PWAF_OK
     std::unique_ptr<pwaf_engine> e(new pwaf_engine());
     e->prog.p = std::move(pp->p);
     delete pp;
@@ -1394,6 +1437,17 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         const std::vector<uint32_t> leaf(65536, TRIE_LEAF);
         UP(leaf_root, leaf)
     }
+    if (P.n_residual) {
+        UP(residual_blob, P.residual_blob)
+        if (P.has_geo && P.residual_needs_geo) {
+            // client.asn / client.country VALUES (the class trie above only keeps which predicates hold): the trie with record leaves
+            const std::vector<uint32_t> leaf0(65536, TRIE_LEAF);  // record 0 = the default {0, "XX"}
+            UP(geo_rec_root4, (P.geo_trie.root4.empty() ? leaf0 : P.geo_trie.root4))
+            UP(geo_rec_root6, (P.geo_trie.root6.empty() ? leaf0 : P.geo_trie.root6))
+            UP(geo_rec_nodes, P.geo_trie.nodes)
+            UP(geo_recs, P.geo_recs)
+        }
+    }
 #undef UP
     if ((P.has_geo && !P.geo_trie.root4.empty()) || (P.n_ip_lists && !P.ipset_trie.root4.empty())) {
         // DIR-24-8: one 64 MiB table (2^24 x 4 B) so that an IPv4 address resolves its GeoIP class AND its ip-list membership set with
@@ -1444,14 +1498,14 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     }
     if (hipDeviceSynchronize() != hipSuccess) { fail(PWAF_E_DEVICE, "device synchronize failed after table upload"); return dev_fail(PWAF_E_DEVICE); }
     *out = e.release();
-    return PWAF_OK;
+    return partial;
 }
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
-                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->pass_base, &e->colmask, &e->dir24, &e->dir16, &e->dir_chunks, &e->dir_vals, &e->class_rows,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir16, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
     for (auto &c : e->ctx) c->release();

@@ -68,8 +68,9 @@ struct ScanArgs {
 // through the pass's DFA. A list holds a few percent of the batch, so what matters is latency per step: the table's first n_hot rows
 // (states are numbered by how often the tuning sample's candidates visit them, start state first) are staged in LDS — a step there
 // is two dependent LDS reads (class, cell) instead of an L2 round trip — and the rest is read from the L2-resident flat table.
-//   flat[s * (n_classes + 1) + c] = next state | 0x8000 when entering it emits; cell n_classes of a row = what entering that state
-//   emits (0, 0x8000 | the single local atom, or 1 = a list); emit / end lists are indexed by (renumbered) state.
+//   flat[s * (n_classes + 2) + c] = next state | 0x8000 when entering it emits; cell n_classes of a row = what entering that state
+//   emits (0, 0x8000 | the single local atom, or 1 = a list), cell n_classes + 1 = the state itself (the STAY cell: the "transition"
+//   of a lane past its field's end); emit / end lists are indexed by (renumbered) state.
 static constexpr uint32_t kListThreads = 512;
 static constexpr uint32_t kListHotBytes = 48 * 1024;  // 3 workgroups (24 waves) per CU
 struct ListScanArgs {
@@ -79,7 +80,7 @@ struct ListScanArgs {
     const uint16_t *flat;
     const uint8_t *classmap;  // 256 bytes
     uint32_t n_classes;
-    uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 1) * 2 <= the launch's ListShape::hot_bytes
+    uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 2) * 2 <= the launch's ListShape::hot_bytes
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;
@@ -190,6 +191,28 @@ struct FcmpArgs {
     uint32_t *status;
 };
 int launch_fcmp(const FcmpArgs &a, void *stream);
+// Residual rules (residual.h): one lane per request interprets every residual rule's stack program; rule k that ends in Bool(true) is
+// local atom k of the pseudo pass whose hit records `rec` holds.
+struct ResidualArgs {
+    const uint8_t *const *data;   // device arrays: per string column (5 fields, then the header columns) arena ...
+    const uint32_t *const *off;   // ... and offsets
+    const uint8_t *blob;          // rvm::Header + sections
+    uint32_t n, n_rules;
+    const uint8_t *ip;
+    const uint8_t *ip_is_v6;
+    const uint16_t *port;
+    const uint32_t *asn;          // nullable: then the GeoIP record of the address supplies client.asn / client.country
+    const uint16_t *country;
+    uint32_t has_geo;             // the engine has a GeoIP table AND some rule reads asn / country
+    const uint32_t *geo_root4, *geo_root6, *geo_nodes;  // the LPM trie with RECORD leaves
+    const GeoRec *geo_recs;
+    uint32_t *rec;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t pool_cap;
+    uint32_t *status;
+};
+int launch_residual(const ResidualArgs &a, void *stream);
 struct CmpAtomDev {
     uint32_t col, c;
 };

@@ -33,6 +33,7 @@
 #include <set>
 
 #include "kernels.h"
+#include "residual.h"
 
 namespace pwaf {
 
@@ -499,11 +500,11 @@ __global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t 
 
 template <uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint32_t *plan, uint32_t hot_bytes) {
-    extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows, then the 256-byte class map
+    extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows + 16 bytes for the sentinel cell, then the 256-byte class map
     __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
     const uint32_t total = plan[b.count];
     const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
-    const unsigned char *cls = reinterpret_cast<const unsigned char *>(lscan_lds + hot_bytes / 4);
+    const unsigned char *cls = reinterpret_cast<const unsigned char *>(lscan_lds + (hot_bytes + 16u) / 4);
     const uint16_t *hot = reinterpret_cast<const uint16_t *>(lscan_lds);
     for (uint32_t it = it0; it < it1;) {
         // the pass of item `it`: the last p with plan[p] <= it (uniform)
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         }
         const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
         const ListScanArgs a = load_descriptor(&b.g[ps]);
-        const uint32_t ncls = a.n_classes, stride = ncls + 1u;
+        const uint32_t ncls = a.n_classes, stride = ncls + 2u;  // row: ncls transitions, the EMIT cell, the STAY cell
         const uint32_t hot_elems = a.n_hot * stride;
         __syncthreads();  // (every wave is done with the previous pass's rows)
         {
@@ -533,8 +534,12 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
                 for (uint32_t q = 0; q < 4; q++)
                     if (k + q * THREADS < units) dst[k + q * THREADS] = v[q];
             }
-            if (threadIdx.x < 64) lscan_lds[hot_bytes / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
+            if (threadIdx.x < 64) lscan_lds[(hot_bytes + 16u) / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];
         }
+        __syncthreads();
+        // the SENTINEL cell right behind the hot rows (after the barrier: the staging loop's last 16-byte unit may cover it): every
+        // index beyond the hot rows is clamped onto it and reads 0xFFFF = "this cell is cold" (no state has id 0x7FFF)
+        if (threadIdx.x == 0) reinterpret_cast<uint16_t *>(lscan_lds)[hot_elems] = 0xFFFFu;
         __syncthreads();
         const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
         const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
@@ -550,37 +555,69 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
             uint32_t state = 0;
             Hits h{0, 0, kNone};
             if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
+            // what entering state `st` emits rides in its row: a single atom that is already in the record, or fits a free slot, is
+            // settled in registers (no memory access at all for a hot row)
+            auto record_emit = [&](const uint32_t st) {
+                const uint32_t ei = st * stride + ncls;
+                const uint32_t code = ei < hot_elems ? (uint32_t)hot[ei] : (uint32_t)flat[ei];
+                const uint32_t x = (code & 0x7FFFu) + 1u;
+                bool slow = !(code & 0x8000u) || h.ovf != kNone;
+                if (!slow) {
+                    if (h.a0 == x || h.a1 == x) {}
+                    else if (h.a0 == 0) h.a0 = x;
+                    else if (h.a1 == 0) h.a1 = x;
+                    else slow = true;
+                }
+                if (slow) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, h);
+            };
+            // The walk's critical path is ONE lane: the longest candidate of the list (every workgroup of a benign batch fits the chip
+            // at once, so the kernel lasts as long as its slowest wave). Per byte that path is now mad -> min -> ds_read -> and, in
+            // groups of four steps checked once: a step into a cold row reads the sentinel (and stays there for the rest of the group),
+            // a step into an emitting state carries bit 15; bytes past the field's end take the STAY cell, so no step is conditional.
+            // Only a group that met a cold cell is re-walked step by step; emits are recorded after the group, off the chain. The next
+            // 16-byte window is in flight while this one is walked. (Round 2: ~25 instructions and three branches per byte, and a full
+            // global round trip per window on the critical path.)
+            u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
             while (p < end) {
-                const u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
+                const uint32_t pn = p + 16u;
+                const u32x4 wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end ? pn : 0u));
                 const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
                 const uint32_t cnt = min(16u, end - p);
                 uint32_t c[16];
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) c[k] = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-#pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {
-                    if (k < cnt) {
-                        const uint32_t idx = state * stride + c[k];
-                        const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
-                        state = t & 0x7FFFu;
-                        if (t & 0x8000u) {
-                            // what the state emits rides in its row: a single atom that is already in the record, or fits a free
-                            // slot, is settled in registers (no memory access at all for a hot row)
-                            const uint32_t ei = state * stride + ncls;
-                            const uint32_t code = ei < hot_elems ? (uint32_t)hot[ei] : (uint32_t)flat[ei];
-                            const uint32_t x = (code & 0x7FFFu) + 1u;
-                            bool slow = !(code & 0x8000u) || h.ovf != kNone;
-                            if (!slow) {
-                                if (h.a0 == x || h.a1 == x) {}
-                                else if (h.a0 == 0) h.a0 = x;
-                                else if (h.a1 == 0) h.a1 = x;
-                                else slow = true;
+                    const uint32_t cl = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+                    c[k] = k < cnt ? cl : ncls + 1u;
+                }
+#pragma unroll
+                for (uint32_t k0 = 0; k0 < 16; k0 += 4) {
+                    const uint32_t t1 = hot[min(state * stride + c[k0], hot_elems)], s1 = t1 & 0x7FFFu;
+                    const uint32_t t2 = hot[min(s1 * stride + c[k0 + 1], hot_elems)], s2 = t2 & 0x7FFFu;
+                    const uint32_t t3 = hot[min(s2 * stride + c[k0 + 2], hot_elems)], s3 = t3 & 0x7FFFu;
+                    const uint32_t t4 = hot[min(s3 * stride + c[k0 + 3], hot_elems)], s4 = t4 & 0x7FFFu;
+                    if ((t1 | t2 | t3 | t4) & 0x8000u) {
+                        if (max(max(t1, t2), max(t3, t4)) == 0xFFFFu) {
+                            // a cold cell: the group step by step, cold cells from the L2-resident table
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t idx = state * stride + c[k0 + k];
+                                const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
+                                state = t & 0x7FFFu;
+                                if (t & 0x8000u) record_emit(state);
                             }
-                            if (slow) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+                        } else {
+                            if (t1 & 0x8000u) record_emit(s1);
+                            if (t2 & 0x8000u) record_emit(s2);
+                            if (t3 & 0x8000u) record_emit(s3);
+                            if (t4 & 0x8000u) record_emit(s4);
+                            state = s4;
                         }
+                    } else {
+                        state = s4;
                     }
                 }
-                p += 16;
+                p = pn;
+                w = wn;
             }
             if (!live) continue;
             if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
@@ -667,7 +704,7 @@ int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanAr
     uint32_t hot_bytes = shape.hot_bytes;
     void *args[] = {&b, &cplan, &hot_bytes};
     const void *fn = shape.threads == 1024 ? reinterpret_cast<const void *>(lscan_kernel<1024>) : reinterpret_cast<const void *>(lscan_kernel<512>);
-    e = hipLaunchKernel(fn, dim3(blocks), dim3(shape.threads), args, shape.hot_bytes + 256, (hipStream_t)stream);
+    e = hipLaunchKernel(fn, dim3(blocks), dim3(shape.threads), args, shape.hot_bytes + 16 + 256, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -1050,6 +1087,58 @@ __global__ __launch_bounds__(256) void fcmp_kernel(FcmpArgs a) {
 int launch_fcmp(const FcmpArgs &a, void *stream) {
     if (a.n == 0 || a.n_atoms == 0) return 0;
     hipLaunchKernelGGL(fcmp_kernel, dim3(std::min<uint32_t>((a.n + 255) / 256, 4096u)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// residual_kernel: the rules no column form exists for (residual.h), interpreted with one lane per request. The interpreter's value
+// stack and heap live in the lane's private memory: this is the slow path by design (a rule set without such rules never launches it).
+__global__ __launch_bounds__(128) void residual_kernel(ResidualArgs a) {
+    const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
+    rvm::Machine m;
+    m.blob = a.blob;
+    m.h = reinterpret_cast<const rvm::Header *>(a.blob);
+    m.q.data = a.data;
+    m.q.off = a.off;
+    for (uint32_t r = blockIdx.x * 128u + threadIdx.x; r < a.n; r += gridDim.x * 128u) {
+        m.q.r = r;
+        m.q.ip = a.ip + (size_t)r * 16;
+        m.q.v6 = a.ip_is_v6[r];
+        m.q.port = a.port[r];
+        uint32_t asn = 0, country = (uint32_t)'X' | ((uint32_t)'X' << 8);  // the default record {0, "XX"} (http_listener.rs:148-156)
+        if (a.asn != nullptr) {
+            asn = a.asn[r];
+            const uint32_t cc = a.country[r], c0 = (cc & 0xFFu) - 'A', c1 = (cc >> 8) - 'A';
+            if (c0 < 26u && c1 < 26u) country = cc;  // (invalid input is treated as "XX", like the attribute kernel does)
+        } else if (a.has_geo) {
+            // GeoipDB::lookup (pingoo/geoip.rs:73-91): loopback / multicast are "not found"
+            const uint8_t *ip = m.q.ip;
+            bool walk;
+            if (!m.q.v6) walk = !(ip[0] == 127u || (ip[0] & 0xF0u) == 0xE0u);
+            else {
+                bool loopback = ip[15] == 1;
+                for (int k = 0; k < 15; k++) loopback = loopback && ip[k] == 0;
+                walk = !(loopback || ip[0] == 0xFFu);
+            }
+            if (walk) {
+                uint32_t e = (m.q.v6 ? a.geo_root6 : a.geo_root4)[((uint32_t)ip[0] << 8) | ip[1]];
+                for (uint32_t k = 2; !(e & TRIE_LEAF); k++) e = a.geo_nodes[(size_t)e * 256 + ip[k]];
+                const GeoRec g = a.geo_recs[e & ~TRIE_LEAF];
+                asn = g.asn;
+                country = g.country;
+            }
+        }
+        m.q.asn = asn;
+        m.q.country = country;
+        Hits h{0, 0, kNone};
+        for (uint32_t k = 0; k < a.n_rules; k++)
+            if (rvm::run_rule(m, k)) h = record_atom(ctx, k, h);
+        a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+    }
+}
+
+int launch_residual(const ResidualArgs &a, void *stream) {
+    if (a.n == 0 || a.n_rules == 0) return 0;
+    hipLaunchKernelGGL(residual_kernel, dim3(std::min<uint32_t>((a.n + 127) / 128, 8192u)), dim3(128), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 //   GeoIP prefixes --> one multibit radix trie (record ids).
 #pragma once
 #include <array>
+#include <functional>
 #include <bitset>
 #include <cstdint>
 #include <map>
@@ -54,6 +55,7 @@ enum AtomKind : uint8_t {
     ATOM_IPSET,      // client.ip contained in CIDR list L
     ATOM_COUNTRY,    // client.country in 676-bit table
     ATOM_FCMP,       // one request string field against ANOTHER (== / contains / starts_with / ends_with, or their lengths)
+    ATOM_RESIDUAL,   // a whole rule evaluated per request by the residual interpreter (residual.h): ref = its index among the residual rules
 };
 // ATOM_FCMP operators (Atom::c): field `field` against field `ref`
 enum FcmpOp : uint8_t { FC_EQ = 0, FC_CONTAINS, FC_STARTS, FC_ENDS, FC_LEN_EQ, FC_LEN_LT, FC_LEN_LE };
@@ -215,6 +217,10 @@ struct Program {
     std::vector<NumAtomDev> num_atoms;
     std::vector<FcmpAtom> fcmp;   // field-against-field atoms: one more (pseudo) pass, columns [fcmp_base, fcmp_base + fcmp.size())
     uint32_t fcmp_base = 0;
+    // residual rules (residual.h): one more pseudo pass after the field-against-field one, one column per rule, evaluated by residual_kernel
+    std::vector<uint8_t> residual_blob;  // rvm::Header + sections (empty: none)
+    uint32_t n_residual = 0, residual_base = 0;
+    bool residual_needs_geo = false;     // some residual rule reads client.asn / client.country
     std::vector<int64_t> int_pool;
     std::vector<uint32_t> country_lut_words;  // 22 words per lut
     std::vector<DevRule> rules;               // pseudo rules first, then the caller's rules with an effect
@@ -292,5 +298,33 @@ void build_ip_trie(const std::vector<PrefixEntry> &prefixes, int mode, uint32_t 
 
 bool parse_ipnet_text(const std::string &s, PrefixEntry &out, std::string &err);
 bool parse_i64_text(const std::string &s, int64_t &out);
+
+// ---- residual rules (residual.h / residual.cpp) ---------------------------------------------------------------------------------
+// A rule the column compiler cannot take is lowered WHOLE to a stack program evaluated per request by residual_kernel.
+struct Syntax;
+struct ResidualList {  // a configured list as the residual compiler sees it (parsed items, lists.rs:90-108)
+    std::string name;
+    uint32_t type = 0;
+    std::vector<std::string> strs;
+    std::vector<int64_t> ints;
+    std::vector<PrefixEntry> nets;
+    size_t size() const { return type == PWAF_LIST_STRING ? strs.size() : type == PWAF_LIST_INT ? ints.size() : nets.size(); }
+};
+class ResidualBuilder {
+public:
+    ResidualBuilder();
+    ~ResidualBuilder();
+    ResidualBuilder(const ResidualBuilder &) = delete;
+    ResidualBuilder &operator=(const ResidualBuilder &) = delete;
+    // Lowers one rule; returns its index among the residual rules, or -1 with the reason (nothing of the rule is kept then).
+    // header_field(name) = string column of a header name (registers the name with the program on first use).
+    int compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why);
+    size_t n_rules() const;
+    bool needs_geo() const;  // some rule reads client.asn / client.country
+    std::vector<uint8_t> blob() const;  // the device image (rvm::Header + sections)
+private:
+    struct Impl;
+    Impl *impl;
+};
 
 }  // namespace pwaf

@@ -1,0 +1,515 @@
+// residual.cpp — compiles a whole rule expression into the stack program of residual.h.
+//
+// Used by compile.cpp for a rule the column compiler rejected (Unsupported): instead of dropping the rule, its syntax tree is lowered
+// to bytecode that residual_kernel interprets per request with the interpreter's dynamic semantics (the reference evaluates every
+// valid expression: pingoo/rules.rs:37-51). The lowering is a plain post-order walk: no constant folding beyond what the context
+// objects need (http_request / client / lists / http_request.headers are compile-time objects: a member with a literal key becomes
+// the variable's own instruction), jumps for the short circuit of && || ?:. What cannot be lowered is reported (the rule then
+// keeps its PWAF_E_UNSUPPORTED status): see residual.h.
+#include <cstring>
+#include <map>
+#include <set>
+
+#include <functional>
+
+#include "frontend.h"
+#include "program.h"
+#include "residual.h"
+
+namespace pwaf {
+
+namespace {
+using namespace rvm;
+
+struct Reject {
+    std::string why;
+};
+
+// what is statically known about the value an expression leaves on the stack
+struct Info {
+    int ctx = 0;          // 1 http_request, 2 client, 3 lists, 4 http_request.headers: a compile-time object, nothing was emitted
+    bool clist = false;   // may be a configured list (lists["x"]): only a receiver of contains / length / [] or the right side of `in`
+    uint32_t seg = 1;     // most rope segments a String in (or being) this value can have
+    uint32_t nest = 0;    // deepest list / map nesting
+    uint32_t len = 0;     // most items if it is a list
+};
+}  // namespace
+
+struct ResidualBuilder::Impl {
+    std::vector<Ins> code;
+    std::vector<uint32_t> entries;
+    std::vector<Val> consts;
+    std::string strpool;
+    std::vector<ListDesc> lists;      // by configured-list id of this builder
+    std::vector<uint32_t> lstr;
+    std::vector<int64_t> lints;
+    std::vector<NetItem> nets;
+    std::vector<RegexDesc> regexes;
+    std::vector<std::vector<uint8_t>> regex_tabs;  // trans | classmap | flags per regex, appended to the blob
+    std::map<std::string, uint32_t> list_ids, regex_ids;
+    bool needs_geo = false;
+
+    // per rule
+    const Syntax *syn = nullptr;
+    const std::vector<ResidualList> *host_lists = nullptr;
+    std::function<int(const std::string &)> header_field;
+    uint32_t depth = 0, max_depth = 0, heap = 0;
+
+    uint32_t str_const(const std::string &s) {
+        const uint32_t off = (uint32_t)strpool.size();
+        strpool += s;
+        return off;
+    }
+    uint32_t add_const(const Val &v) {
+        consts.push_back(v);
+        if (consts.size() > 0xFFFF) throw Reject{"more than 65535 constants in the residual programs"};
+        return (uint32_t)consts.size() - 1;
+    }
+    void emit(uint8_t op, uint8_t a = 0, uint32_t b = 0) {
+        if (b > 0xFFFF) throw Reject{"residual program too large"};
+        code.push_back(Ins{op, a, (uint16_t)b});
+        if (code.size() > 0xFFF0) throw Reject{"residual program too large"};
+    }
+    void push(int n = 1) {
+        depth += (uint32_t)n;
+        max_depth = std::max(max_depth, depth);
+        if (max_depth > kStack) throw Reject{"expression needs more than " + std::to_string(kStack) + " stack slots in the residual interpreter"};
+    }
+    void pop(int n = 1) { depth -= (uint32_t)n; }
+    void use_heap(uint32_t n) {
+        heap += n;
+        if (heap > kHeap) throw Reject{"expression builds more than " + std::to_string(kHeap) + " list / map / concatenation items per request"};
+    }
+    void push_err() { emit(R_CONST, 0, add_const(mk(T_ERR))); push(); }
+    void push_bool(bool b) { emit(R_CONST, 0, add_const(mk_bool(b))); push(); }
+    void push_int(int64_t i) { emit(R_CONST, 0, add_const(mk_int(i))); push(); }
+    void push_str(const std::string &s) { emit(R_CONST, 0, add_const(mk(T_STR, (uint32_t)s.size(), ((uint64_t)S_CONST << 48) | str_const(s)))); push(); }
+
+    uint32_t list_id(size_t k) {
+        const ResidualList &hl = (*host_lists)[k];
+        auto it = list_ids.find(hl.name + "#" + std::to_string(k));
+        if (it != list_ids.end()) return it->second;
+        ListDesc d{};
+        d.type = hl.type;
+        if (hl.type == PWAF_LIST_STRING) {
+            d.first = (uint32_t)(lstr.size() / 2);
+            d.n = (uint32_t)hl.strs.size();
+            for (auto &s : hl.strs) { lstr.push_back(str_const(s)); lstr.push_back((uint32_t)s.size()); }
+        } else if (hl.type == PWAF_LIST_INT) {
+            d.first = (uint32_t)lints.size();
+            d.n = (uint32_t)hl.ints.size();
+            lints.insert(lints.end(), hl.ints.begin(), hl.ints.end());
+        } else {
+            d.first = (uint32_t)nets.size();
+            d.n = (uint32_t)hl.nets.size();
+            for (auto &pe : hl.nets) {
+                NetItem ni{};
+                memcpy(ni.addr, pe.addr, 16);
+                ni.prefix = pe.len;
+                ni.v6 = pe.v6 ? 1 : 0;
+                nets.push_back(ni);
+            }
+        }
+        lists.push_back(d);
+        if (lists.size() > 0xFFFF) throw Reject{"too many configured lists in residual programs"};
+        list_ids.emplace(hl.name + "#" + std::to_string(k), (uint32_t)lists.size() - 1);
+        return (uint32_t)lists.size() - 1;
+    }
+
+    uint32_t regex_id(const std::string &pattern) {
+        auto it = regex_ids.find(pattern);
+        if (it != regex_ids.end()) return it->second;
+        int status;
+        std::string err;
+        RNodeP rx = regex_parse(pattern, status, err);
+        uint32_t id;
+        if (status == 1) {
+            id = 0xFFFu;  // invalid pattern: an execution error in the reference
+        } else {
+            if (status == 2) throw Reject{err};
+            std::vector<ScanPattern> one{{rx, 0}};
+            DfaGroup g;
+            std::string e2;
+            if (!build_dfa(one, 8192, 2u << 20, g, e2)) throw Reject{"matches(): the pattern's DFA exceeds the residual interpreter's budget: " + e2};
+            if (regexes.size() >= 0xFFE) throw Reject{"too many regex literals in residual programs"};
+            std::vector<uint8_t> tab(g.trans.size() * 2 + 256 + g.n_states);
+            memcpy(tab.data(), g.trans.data(), g.trans.size() * 2);
+            memcpy(tab.data() + g.trans.size() * 2, g.classmap, 256);
+            for (uint32_t s = 0; s < g.n_states; s++)
+                tab[g.trans.size() * 2 + 256 + s] = (uint8_t)((g.emit_off[s + 1] != g.emit_off[s] ? 1 : 0) | (g.end_off[s + 1] != g.end_off[s] ? 2 : 0));
+            RegexDesc d{};
+            d.n_classes = g.n_classes;
+            d.trans = (uint32_t)g.trans.size() * 2;  // (sizes for now: resolved to blob offsets in blob())
+            d.flags = g.n_states;
+            regexes.push_back(d);
+            regex_tabs.push_back(std::move(tab));
+            id = (uint32_t)regexes.size() - 1;
+        }
+        regex_ids.emplace(pattern, id);
+        return id;
+    }
+
+    static Info merge(const Info &a, const Info &b) {
+        Info r;
+        r.clist = a.clist || b.clist;
+        r.seg = std::max(a.seg, b.seg);
+        r.nest = std::max(a.nest, b.nest);
+        r.len = std::max(a.len, b.len);
+        return r;
+    }
+    static void no_ctx(const Info &i, const char *what) {
+        if (i.ctx) throw Reject{std::string("a context map (http_request / client / lists / headers) used as a value: ") + what};
+    }
+    static void no_clist(const Info &i, const char *what) {
+        if (i.clist) throw Reject{std::string("a configured list used as a plain value: ") + what};
+    }
+
+    // Member / index with a literal key on a context object
+    Info select_ctx(int ctx, const std::string &key) {
+        static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
+        Info r;
+        if (ctx == 1) {
+            for (int f = 0; f < 5; f++)
+                if (key == kFields[f]) { emit(R_FIELD, 0, (uint32_t)f); push(); return r; }
+            if (key == "headers") { r.ctx = 4; return r; }
+            push_err();
+            return r;
+        }
+        if (ctx == 4) {  // EXTENSION: one String column per header name the rule set mentions
+            emit(R_FIELD, 0, (uint32_t)header_field(key));
+            push();
+            return r;
+        }
+        if (ctx == 2) {
+            if (key == "ip") { emit(R_IP); push(); return r; }
+            if (key == "remote_port") { emit(R_PORT); push(); return r; }
+            if (key == "asn") { needs_geo = true; emit(R_ASN); push(); return r; }
+            if (key == "country") { needs_geo = true; emit(R_COUNTRY); push(); return r; }
+            push_err();
+            return r;
+        }
+        // lists
+        for (size_t k = 0; k < host_lists->size(); k++)
+            if ((*host_lists)[k].name == key) { emit(R_CLIST, 0, list_id(k)); push(); r.clist = true; r.len = (uint32_t)(*host_lists)[k].size(); return r; }
+        push_err();
+        return r;
+    }
+    bool ctx_has(int ctx, const std::string &key) {
+        static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
+        if (ctx == 1) { for (auto f : kFields) if (key == f) return true; return key == "headers"; }
+        if (ctx == 4) { header_field(key); return true; }  // (the headers map holds exactly the names the rule set mentions: asking for one makes it one of them)
+        if (ctx == 2) return key == "ip" || key == "remote_port" || key == "asn" || key == "country";
+        for (auto &l : *host_lists) if (l.name == key) return true;
+        return false;
+    }
+
+    // does the node denote a context object? (decided from the syntax alone: nothing is emitted)
+    int ctx_of(int ni) const {
+        const Ex &e = syn->nodes[(size_t)ni];
+        if (e.kind == EX_IDENT) return e.text == "http_request" ? 1 : e.text == "client" ? 2 : e.text == "lists" ? 3 : 0;
+        if (e.kind == EX_MEMBER && e.text == "headers" && ctx_of(e.kids[0]) == 1) return 4;
+        if (e.kind == EX_INDEX && ctx_of(e.kids[0]) == 1) {
+            const Ex &ix = syn->nodes[(size_t)e.kids[1]];
+            if (ix.kind == EX_STR && ix.text == "headers") return 4;
+        }
+        return 0;
+    }
+
+    Info gen(int ni) {
+        const Ex &e = syn->nodes[(size_t)ni];
+        Info r;
+        switch (e.kind) {
+            case EX_INT: push_int(e.ival); return r;
+            case EX_FLOAT: emit(R_CONST, 0, add_const(mk_flt(e.fval))); push(); return r;
+            case EX_STR: push_str(e.text); return r;
+            case EX_BOOL: push_bool(e.bval); return r;
+            case EX_NULL: emit(R_CONST, 0, add_const(mk(T_NULL))); push(); return r;
+            case EX_IDENT:
+                if (e.text == "http_request") { r.ctx = 1; return r; }
+                if (e.text == "client") { r.ctx = 2; return r; }
+                if (e.text == "lists") { r.ctx = 3; return r; }
+                push_err();  // undeclared reference
+                return r;
+            case EX_MEMBER: {
+                Info o = gen(e.kids[0]);
+                if (o.ctx) return select_ctx(o.ctx, e.text);
+                no_clist(o, "member access");
+                emit(R_SELECT, 0, add_const(mk(T_STR, (uint32_t)e.text.size(), ((uint64_t)S_CONST << 48) | str_const(e.text))));
+                r = o;
+                r.len = 0;
+                return r;
+            }
+            case EX_INDEX: {
+                Info o = gen(e.kids[0]);
+                if (o.ctx) {
+                    const Ex &ix = syn->nodes[(size_t)e.kids[1]];
+                    if (ix.kind == EX_STR) return select_ctx(o.ctx, ix.text);
+                    if (ix.kind == EX_INT || ix.kind == EX_FLOAT || ix.kind == EX_BOOL || ix.kind == EX_NULL) { push_err(); return r; }  // map keys are Strings
+                    throw Reject{"a context map indexed with a computed key"};
+                }
+                Info i = gen(e.kids[1]);
+                no_ctx(i, "as an index");
+                no_clist(i, "as an index");
+                emit(R_INDEX);
+                pop();
+                r = o;
+                r.clist = false;
+                r.len = o.len;  // (an item of a list of lists: bounded by the outer bound — conservative)
+                return r;
+            }
+            case EX_GCALL: push_err(); return r;  // undeclared function
+            case EX_MCALL: return call(e);
+            case EX_LIST: {
+                uint32_t n = 0;
+                for (int k : e.kids) {
+                    Info it = gen(k);
+                    no_ctx(it, "as a list element");
+                    no_clist(it, "as a list element");
+                    r = merge(r, it);
+                    n++;
+                }
+                r.nest += 1;
+                if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+                r.len = n;
+                r.clist = false;
+                use_heap(n);
+                emit(R_MKLIST, 0, n);
+                pop((int)n);
+                push();
+                return r;
+            }
+            case EX_MAP: {
+                uint32_t n = 0;
+                for (size_t k = 0; k + 1 < e.kids.size(); k += 2) {
+                    Info key = gen(e.kids[k]);
+                    no_ctx(key, "as a map key");
+                    no_clist(key, "as a map key");
+                    Info val = gen(e.kids[k + 1]);
+                    no_ctx(val, "as a map value");
+                    no_clist(val, "as a map value");
+                    r = merge(r, merge(key, val));
+                    n++;
+                }
+                r.nest += 1;
+                if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+                r.len = n;
+                use_heap(2 * n);
+                emit(R_MKMAP, 0, n);
+                pop((int)(2 * n));
+                push();
+                return r;
+            }
+            case EX_NOT: {
+                Info x = gen(e.kids[0]);
+                if (x.ctx) { push_err(); return r; }  // '!' requires a Bool
+                emit(R_NOT);
+                return r;
+            }
+            case EX_NEG: {
+                Info x = gen(e.kids[0]);
+                if (x.ctx) { push_err(); return r; }
+                emit(R_NEG);
+                return r;
+            }
+            case EX_COND: {
+                Info c = gen(e.kids[0]);
+                if (c.ctx) { push_err(); return r; }  // conditional requires a Bool
+                const size_t jc = code.size();
+                emit(R_COND);
+                pop();
+                const uint32_t d0 = depth;
+                Info a = gen(e.kids[1]);
+                no_ctx(a, "as a conditional branch");
+                const size_t ja = code.size();
+                emit(R_JMP);
+                depth = d0;
+                code[jc].b = (uint16_t)code.size();
+                Info b = gen(e.kids[2]);
+                no_ctx(b, "as a conditional branch");
+                code[ja].b = (uint16_t)code.size();
+                return merge(a, b);
+            }
+            case EX_BIN: return binary(e);
+        }
+        throw Reject{"internal: unknown node"};
+    }
+
+    Info call(const Ex &e) {
+        Info r;
+        const std::string &f = e.text;
+        const size_t argc = e.kids.size() - 1;
+        Info recv = gen(e.kids[0]);
+        if (recv.ctx) {
+            // the context maps answer contains(literal key) / length() at compile time
+            if (f == "contains" && argc == 1) {
+                const Ex &k = syn->nodes[(size_t)e.kids[1]];
+                if (k.kind == EX_STR) { push_bool(ctx_has(recv.ctx, k.text)); return r; }
+                if (k.kind == EX_INT || k.kind == EX_FLOAT || k.kind == EX_BOOL || k.kind == EX_NULL) { push_err(); return r; }
+                throw Reject{"contains() on a context map with a computed key"};
+            }
+            if (f == "length" && argc == 0) {
+                if (recv.ctx == 1) { push_int(6); return r; }  // host, url, path, method, user_agent + the headers map (extension)
+                if (recv.ctx == 2) { push_int(4); return r; }
+                if (recv.ctx == 3) { std::set<std::string> names; for (auto &l : *host_lists) names.insert(l.name); push_int((int64_t)names.size()); return r; }
+                throw Reject{"length() of the headers map (it holds the names the whole rule set mentions)"};
+            }
+            // any other method on a map: the arguments are evaluated, then the call fails (or the argument count is wrong)
+            push_err();
+            return r;
+        }
+        uint8_t fn;
+        if (f == "contains") fn = FN_CONTAINS;
+        else if (f == "starts_with") fn = FN_STARTS;
+        else if (f == "ends_with") fn = FN_ENDS;
+        else if (f == "length") fn = FN_LENGTH;
+        else if (f == "matches") fn = FN_MATCHES;
+        else fn = 0xFF;  // undeclared function: the operands are evaluated, then the call fails
+        const bool arity_ok = fn != 0xFF && (fn == FN_LENGTH ? argc == 0 : argc == 1);
+        uint32_t aux = 0;
+        if (fn == FN_MATCHES && argc == 1) {
+            const Ex &p = syn->nodes[(size_t)e.kids[1]];
+            if (p.kind != EX_STR) {
+                if (p.kind == EX_INT || p.kind == EX_FLOAT || p.kind == EX_BOOL || p.kind == EX_NULL) aux = 0xFFFu;  // String operands required: an error either way
+                else throw Reject{"matches() with a pattern that is not a String literal"};
+            } else {
+                aux = regex_id(p.text);
+            }
+        }
+        for (size_t k = 1; k <= argc; k++) {
+            Info a = gen(e.kids[k]);
+            if (a.ctx) {
+                // a context map as an argument: no function takes one (contains(list, map) compares values: unsupported as a value)
+                throw Reject{"a context map used as a function argument"};
+            }
+            if (a.clist) throw Reject{"a configured list used as a function argument"};
+        }
+        if (!arity_ok || argc > 15) {
+            emit(R_FAIL, 0, (uint32_t)argc + 1);
+            pop((int)argc);
+            return r;
+        }
+        emit(R_CALL, fn, (uint32_t)(argc << 12) | aux);
+        pop((int)argc);
+        return r;
+    }
+
+    Info binary(const Ex &e) {
+        Info r;
+        if (e.op == B_OR || e.op == B_AND) {
+            Info l = gen(e.kids[0]);
+            if (l.ctx) { push_err(); return r; }  // Bool operands required (the right side is not evaluated)
+            const size_t j = code.size();
+            emit(e.op == B_AND ? R_AND_L : R_OR_L);
+            pop();
+            Info rr = gen(e.kids[1]);
+            if (rr.ctx) push_err();
+            emit(R_BOOL_CHK);
+            code[j].b = (uint16_t)code.size();
+            return r;
+        }
+        if (e.op == B_IN) {
+            // x in <context map>: a literal key is answered at compile time
+            const int rc = ctx_of(e.kids[1]);
+            if (rc) {
+                const Ex &k = syn->nodes[(size_t)e.kids[0]];
+                if (k.kind == EX_STR) { push_bool(ctx_has(rc, k.text)); return r; }
+                if (k.kind == EX_INT || k.kind == EX_FLOAT || k.kind == EX_BOOL || k.kind == EX_NULL) { push_err(); return r; }
+                throw Reject{"`in` on a context map with a computed key"};
+            }
+            Info l = gen(e.kids[0]);
+            if (l.ctx) throw Reject{"a context map on the left of `in`"};
+            no_clist(l, "on the left of `in`");
+            gen(e.kids[1]);
+            emit(R_BIN, (uint8_t)B_IN);
+            pop();
+            return r;
+        }
+        Info l = gen(e.kids[0]);
+        Info rr = gen(e.kids[1]);
+        if (l.ctx || rr.ctx) throw Reject{"a context map as an operand"};
+        if (l.clist || rr.clist) throw Reject{"a configured list as an operand of a comparison or of `+`"};
+        emit(R_BIN, (uint8_t)e.op);
+        pop();
+        if (e.op == B_ADD) {
+            r.seg = l.seg + rr.seg;
+            if (r.seg > kMaxRope) throw Reject{"a concatenation of more than " + std::to_string(kMaxRope) + " strings"};
+            r.len = l.len + rr.len;
+            r.nest = std::max(l.nest, rr.nest);
+            use_heap(std::max(r.seg, r.len));
+        }
+        return r;
+    }
+};
+
+ResidualBuilder::ResidualBuilder() : impl(new Impl) {}
+ResidualBuilder::~ResidualBuilder() { delete impl; }
+size_t ResidualBuilder::n_rules() const { return impl->entries.size(); }
+bool ResidualBuilder::needs_geo() const { return impl->needs_geo; }
+
+int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why) {
+    Impl &m = *impl;
+    // a failed rule must leave no trace: snapshot the growing tables
+    const size_t c0 = m.code.size(), k0 = m.consts.size(), s0 = m.strpool.size(), l0 = m.lists.size(), ls0 = m.lstr.size(), li0 = m.lints.size(), n0 = m.nets.size(), r0 = m.regexes.size();
+    const auto list_ids0 = m.list_ids;
+    const auto regex_ids0 = m.regex_ids;
+    const bool geo0 = m.needs_geo;
+    m.syn = &syn;
+    m.host_lists = &lists;
+    m.header_field = header_field;
+    m.depth = m.max_depth = m.heap = 0;
+    try {
+        const uint32_t entry = (uint32_t)m.code.size();
+        Info top = m.gen(syn.root);
+        if (top.ctx) m.push_err();  // a map is not Bool(true)
+        m.emit(R_END);
+        m.entries.push_back(entry);
+        return (int)m.entries.size() - 1;
+    } catch (Reject &rj) {
+        why = rj.why;
+    }
+    m.code.resize(c0); m.consts.resize(k0); m.strpool.resize(s0); m.lists.resize(l0); m.lstr.resize(ls0); m.lints.resize(li0); m.nets.resize(n0);
+    m.regexes.resize(r0); m.regex_tabs.resize(r0);
+    m.list_ids = list_ids0; m.regex_ids = regex_ids0; m.needs_geo = geo0;
+    return -1;
+}
+
+std::vector<uint8_t> ResidualBuilder::blob() const {
+    const Impl &m = *impl;
+    std::vector<uint8_t> out(sizeof(Header));
+    auto align = [&](size_t a) { while (out.size() % a) out.push_back(0); };
+    auto put = [&](const void *p, size_t n, size_t a) -> uint32_t {
+        align(a);
+        const uint32_t at = (uint32_t)out.size();
+        const uint8_t *b = (const uint8_t *)p;
+        out.insert(out.end(), b, b + n);
+        return at;
+    };
+    Header h{};
+    h.magic = 0x314D5652u;  // "RVM1"
+    h.n_rules = (uint32_t)m.entries.size();
+    h.rules = put(m.entries.data(), m.entries.size() * 4, 4);
+    h.code = put(m.code.data(), m.code.size() * sizeof(Ins), 4);
+    h.consts = put(m.consts.data(), m.consts.size() * sizeof(Val), 8);
+    h.strpool = put(m.strpool.data(), m.strpool.size(), 1);
+    h.lists = put(m.lists.data(), m.lists.size() * sizeof(ListDesc), 4);
+    h.lstr = put(m.lstr.data(), m.lstr.size() * 4, 4);
+    h.lints = put(m.lints.data(), m.lints.size() * 8, 8);
+    h.nets = put(m.nets.data(), m.nets.size() * sizeof(NetItem), 4);
+    std::vector<RegexDesc> rd = m.regexes;
+    for (size_t k = 0; k < rd.size(); k++) {
+        const uint32_t trans_bytes = rd[k].trans, n_states = rd[k].flags;
+        const uint32_t at = put(m.regex_tabs[k].data(), m.regex_tabs[k].size(), 4);
+        rd[k].trans = at;
+        rd[k].classmap = at + trans_bytes;
+        rd[k].flags = at + trans_bytes + 256;
+        (void)n_states;
+    }
+    h.regexes = put(rd.data(), rd.size() * sizeof(RegexDesc), 4);
+    h.needs_geo = m.needs_geo ? 1u : 0u;
+    align(16);
+    h.total_bytes = (uint32_t)out.size();
+    memcpy(out.data(), &h, sizeof h);
+    return out;
+}
+
+}  // namespace pwaf

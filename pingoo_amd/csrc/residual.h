@@ -65,6 +65,7 @@ enum Op : uint8_t {
     R_JMP,      // b = target
     R_MKLIST,   // b = n: pops n values into a heap list
     R_MKMAP,    // b = n pairs: pops 2n values (key, value ...) into a heap map (later duplicates win)
+    R_FAIL,     // b = n: pops n values, pushes an execution error (an undeclared method, a wrong argument count: operands are evaluated, then the call fails)
 };
 enum Fn : uint8_t { FN_CONTAINS = 0, FN_STARTS, FN_ENDS, FN_LENGTH, FN_MATCHES };
 struct Ins {
@@ -386,6 +387,7 @@ PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
                 break;
             }
             case R_JMP: pc = in.b; break;
+            case R_FAIL: sp -= in.b; st[sp++] = ERR; break;
             case R_MKLIST: {
                 const uint32_t n = in.b;
                 bool err = false;

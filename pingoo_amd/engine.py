@@ -251,8 +251,9 @@ class CompiledProgram:
         h = C.c_void_p()
         err = _abi.CompileError()
         rc = L.pwaf_program_compile(r, nr, l, nl, g, C.byref(o), C.byref(h), C.byref(err))
-        if rc != 0:
+        if rc < 0:
             _raise(rc, err.message.decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self.partial = rc == _abi.W_PARTIAL  # PWAF_OPT_LENIENT: some rule is not evaluated (rule_status / warnings say which)
         self._h = h
         self._owned = True
 
@@ -323,8 +324,9 @@ class RuleEngine:
         h = C.c_void_p()
         err = _abi.CompileError()
         rc = L.pwaf_engine_create(r, nr, l, nl, g, C.byref(o), C.byref(h), C.byref(err))
-        if rc != 0:
+        if rc < 0:
             _raise(rc, err.message.decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self.partial = rc == _abi.W_PARTIAL  # PWAF_OPT_LENIENT: some rule is not evaluated (program.rule_status / warnings say which)
         self._h = h
         self.header_names = [L.pwaf_engine_header_name(h, i).decode() for i in range(L.pwaf_engine_header_count(h))]
 

@@ -310,8 +310,16 @@ def lit_requests(rng: random.Random, n: int):
     return reqs
 
 
-def as_the_engine_sees(rules, prog):
-    """The rule list with every rule the device compiler reports as unsupported (pwaf_program_rule_status) replaced by one that never
-    matches — the engine's documented behaviour for such a rule — so that the oracle can check everything else in the set."""
+REWRITTEN = {"rules": 0, "unsupported": 0}  # how often the fuzzers meet a rule the engine does not evaluate (the gap must be measured, not masked)
+
+
+def as_the_engine_sees(rules, prog, allow=0):
+    """The rule list with every rule the engine reports as unsupported (pwaf_program_rule_status; only possible with
+    PWAF_OPT_LENIENT) replaced by one that never matches — the engine's documented behaviour for such a rule — so that the oracle can
+    check everything else in the set. Since round 3 rules outside the column compiler's reach run in the residual interpreter, so
+    the fuzz grammars produce NO such rule: `allow` is how many a test tolerates (default none)."""
     bad = set(prog.unsupported_rules(len(rules)))
+    REWRITTEN["rules"] += len(rules)
+    REWRITTEN["unsupported"] += len(bad)
+    assert len(bad) <= allow, [(i, prog.rule_status(i)[1]) for i in sorted(bad)]
     return [(n, "false" if i in bad else e, a) for i, (n, e, a) in enumerate(rules)], bad

@@ -95,6 +95,10 @@ class Tables:
                 setattr(self, tag.strip().lower(), np.frombuffer(pl, dtype="<u4"))
             elif tag == "GREC":
                 self.geo_recs = np.frombuffer(pl, dtype=GREC_DTYPE)
+            elif tag == "RSDL":
+                self.n_residual, self.residual_base = struct.unpack("<2I", pl)
+            elif tag == "RVMB":
+                self.residual_blob = bytes(pl)
 
     # --- pieces ---
     FILTER_MUL = 0x9E37
@@ -225,6 +229,20 @@ class Tables:
                 t = bool((int(self.country_luts[int(d["ref"]) * 22 + (cidx >> 5)]) >> (cidx & 31)) & 1)
             if t:
                 cols.add(int(d["col"]))
+        if getattr(self, "n_residual", 0):
+            # residual rules: the program image compile.cpp produced, run by the TEST-ONLY host build of the interpreter
+            # (tests/rvm_host.cpp — the same residual.h the device kernel compiles)
+            import test_residual as TR
+
+            if getattr(self, "_rvm", None) is None:
+                self._rvm = TR.HostVM.from_blob(self.residual_blob, getattr(self, "header_names", []))
+            if getattr(self, "_rvm_batch", None) is not batch:
+                self._rvm.bind(batch)
+                self._rvm_batch = batch
+            geo_asn, geo_cc = (asn, country)
+            for k in range(self.n_residual):
+                if self._rvm.eval(k, i, asn=geo_asn, country=int.from_bytes(geo_cc, "little")):
+                    cols.add(self.residual_base + k)
         for r in self.rules:
             acc_or, acc_and = False, True
             for k in range(int(r["lit_off"]), int(r["lit_off"]) + int(r["lit_cnt"])):

@@ -79,8 +79,9 @@ def test_fuzz_compiled_tables_match_oracle(seed):
         acts = H.fuzz_actions(rng)
         rules.append((f"r{k}", e, acts))
     flags = rng.choice([0, 0, _abi.OPT_NO_UA_GATE, _abi.OPT_NO_CAPTCHA_BYPASS, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
-    prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
-    # rules the device compiler cannot take are reported per rule and never match; every other rule of the set is checked
+    prog = CompiledProgram(rules, lists, geo, flags=flags | _abi.OPT_LENIENT, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
+    # (lenient only so that a rule NOBODY can take would show up as a count instead of an exception: the grammar produces none —
+    # what the column compiler cannot take runs in the residual interpreter, evaluated here by its host build)
     seen, _ = H.as_the_engine_sees(rules, prog)
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
     want = pyoracle.Oracle(seen, lists, geo, flags=flags).evaluate(batch)
@@ -116,18 +117,28 @@ def test_static_errors_become_warnings_not_failures():
 
 
 def test_unsupported_constructs_are_rejected_with_the_rule_index():
-    cases = ['client.country == http_request.host', "client.remote_port + 1 == 81", 'http_request.path < "m"', 'http_request.path.matches(http_request.host)',
-             '(http_request.method == "GET" ? http_request.path : http_request.url) == "/"', 'http_request.url.matches("\\\\p{L}")', 'http_request.path + "x" == "/x"',
-             "[http_request.method].contains(\"GET\")", 'http_request.path.matches("(?x)a b")']
+    # what neither the column compiler nor the residual interpreter takes: a regex compiled per request, Unicode classes, verbose mode
+    cases = ['http_request.path.matches(http_request.host)', 'http_request.url.matches("\\\\p{L}")', 'http_request.path.matches("(?x)a b")',
+             'http_request[http_request.method] == "x"']
     for e in cases:
-        pyoracle.compile_expression(e)  # valid language, just outside the device subset
-        with pytest.raises(UnsupportedExpression) as ei:
-            CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])], flags=_abi.OPT_STRICT)
+        pyoracle.compile_expression(e)  # valid language, just outside what the device evaluates
+        with pytest.raises(UnsupportedExpression) as ei:  # the default since ABI 2: creation fails, naming the rule
+            CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])])
         assert ei.value.rule_index == 1 and "bad" in ei.value.message, e
-        # default: that rule alone is reported and never matches; the set compiles
-        prog = CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])])
+        # PWAF_OPT_LENIENT: that rule alone is reported and never matches; the set compiles (with a warning status)
+        prog = CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("bad", e, [B])], flags=_abi.OPT_LENIENT)
+        assert prog.partial
         assert prog.rule_status(0) == (0, "") and prog.rule_status(1)[0] == _abi.E_UNSUPPORTED and "bad" in prog.rule_status(1)[1]
         assert any("NOT evaluated" in w for w in prog.warnings())
+    # what only the column compiler cannot take runs in the residual interpreter: no error, a warning says so
+    residual = ['client.country == http_request.host', "client.remote_port + 1 == 81", 'http_request.path < "m"',
+                '(http_request.method == "GET" ? http_request.path : http_request.url) == "/"', 'http_request.path + "x" == "/x"', "[http_request.method].contains(\"GET\")"]
+    for e in residual:
+        prog = CompiledProgram([("fine", 'http_request.path == "/"', [B]), ("slow", e, [B])])
+        assert not prog.partial and prog.unsupported_rules(2) == []
+        assert any("residual interpreter" in w for w in prog.warnings()), (e, prog.warnings())
+        with pytest.raises(UnsupportedExpression):
+            CompiledProgram([("slow", e, [B])], flags=_abi.OPT_NO_RESIDUAL)
     with pytest.raises(ExpressionIsNotValid) as ei:
         CompiledProgram([("x", "a ==", [B])])
     assert ei.value.rule_index == 0
@@ -188,8 +199,10 @@ def test_counted_gap_patterns_compile_to_small_tables_and_match_the_oracle():
 
 def test_a_pattern_beyond_the_table_budget_fails_alone():
     rules = [("big", 'http_request.url.matches("select.{0,60}from.{0,60}where")', [B]), ("min", 'http_request.url.matches("a.{20,40}b")', [B]), ("ok", 'http_request.url.contains("x")', [CAP])]
-    prog = CompiledProgram(rules)
+    prog = CompiledProgram(rules, flags=_abi.OPT_LENIENT)
     assert prog.unsupported_rules(len(rules)) == [0, 1] and "budget" in prog.rule_status(0)[1]
+    with pytest.raises(UnsupportedExpression):
+        CompiledProgram(rules)
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -216,8 +229,8 @@ def test_random_counted_repetitions_match_the_oracle(seed):
         p = "".join(piece() for _ in range(rng.randint(2, 4)))
         pats.append(rng.choice(["", "^"]) + p + rng.choice(["", "", "$"]))
     rules = [(f"r{k}", f'http_request.url.matches("{p}")', [B]) for k, p in enumerate(pats)]
-    prog = CompiledProgram(rules)
-    seen, bad = H.as_the_engine_sees(rules, prog)
+    prog = CompiledProgram(rules, flags=_abi.OPT_LENIENT)
+    seen, bad = H.as_the_engine_sees(rules, prog, allow=3)
     reqs = [Request(url="".join(rng.choice(alpha) for _ in range(rng.randint(0, 14)))) for _ in range(400)]
     batch = RequestBatch.from_requests(reqs)
     want = pyoracle.Oracle(seen).evaluate(batch)

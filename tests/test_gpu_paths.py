@@ -90,7 +90,7 @@ for seed in range(12):
     for k in range(rng.randint(3, 14)):
         e = H.rexpr(rng, lists)
         rules.append((f"r{k}", e, H.fuzz_actions(rng)))
-    eng = RuleEngine(rules, lists, geo)
+    eng = RuleEngine(rules, lists, geo, flags=_abi.OPT_LENIENT)
     rules, _ = H.as_the_engine_sees(rules, eng.program)
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 500, seed %% 3 == 0))
     want = pyoracle.Oracle(rules, lists, geo).evaluate(batch)
@@ -206,10 +206,11 @@ def test_field_against_field_predicates_and_per_rule_unsupported():
              ("pre", "http_request.url.starts_with(http_request.path) && !http_request.url.ends_with(http_request.path)", [CAP]),
              ("gap", 'http_request.url.matches("select.{0,60}from.{0,60}where")', [B]),
              ("tail", 'http_request.user_agent.ends_with(http_request.method)', [B])]
-    eng = RuleEngine(rules)
+    eng = RuleEngine(rules, flags=_abi.OPT_LENIENT)
+    assert eng.partial
     prog = eng.program
     assert prog.unsupported_rules(len(rules)) == [4] and "budget" in prog.rule_status(4)[1]
-    seen, bad = H.as_the_engine_sees(rules, prog)
+    seen, bad = H.as_the_engine_sees(rules, prog, allow=1)
     assert bad == {4}
     rng = random.Random(3)
     words = ["a", "ex.com", "/p", "/p/q", "GET", "x", "", "select 1 from t where", "/p?host=ex.com"]
@@ -220,8 +221,8 @@ def test_field_against_field_predicates_and_per_rule_unsupported():
     want = pyoracle.Oracle(seen).evaluate(batch)
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "field against field")
     assert len(set(want["rule_idx"].tolist())) >= 5
-    with pytest.raises(Exception) as ei:
-        RuleEngine(rules, flags=_abi.OPT_STRICT)
+    with pytest.raises(Exception) as ei:  # the default: a rule nobody can evaluate fails creation, naming the rule
+        RuleEngine(rules)
     assert ei.value.rule_index == 4
     eng.close()
 

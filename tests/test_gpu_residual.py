@@ -1,0 +1,67 @@
+"""The residual interpreter on the device (residual_kernel, through the C ABI): rules the column compiler cannot take are evaluated per
+request by the stack interpreter of residual.h and land in a pseudo pass of the verdict kernel. Verdicts must be the oracle's —
+whichever path evaluates a rule."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+import test_residual as TR
+from oracle import pyoracle
+from pingoo_amd import Request, RequestBatch, _abi
+from pingoo_amd.engine import RuleEngine
+
+pytestmark = pytest.mark.gpu
+B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_mixed_rule_sets_on_the_device(seed):
+    rng = random.Random(717100 + seed)
+    rules = []
+    for k in range(rng.randint(2, 12)):
+        e = TR.dbool(rng) if rng.random() < 0.5 else H.rexpr(rng, TR.LISTS)
+        try:
+            pyoracle.compile_expression(e)
+        except pyoracle.OracleError:
+            e = "true"
+        rules.append((f"r{k}", e, H.fuzz_actions(rng)))
+    geo = H.fuzz_geoip(rng) if seed % 2 else None
+    flags = rng.choice([0, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
+    eng = RuleEngine(rules, TR.LISTS, geo, flags=flags | _abi.OPT_LENIENT)
+    seen, _ = H.as_the_engine_sees(rules, eng.program)
+    n = rng.choice([1, 64, 65, 300, 1000])
+    reqs = TR.requests(rng, n)
+    if geo is not None:  # the engine resolves client.asn / client.country itself: through the trie with RECORD leaves
+        for r in reqs:
+            r.asn = r.country = None
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(seen, TR.LISTS, geo, flags=flags).evaluate(batch)
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    H.assert_verdicts_equal(got, want, batch, f"seed {seed}: {[r[1] for r in rules]}")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    eng.close()
+
+
+def test_residual_known_answers_and_dnf_explosion_on_the_device():
+    rules = [("arith", "http_request.path.length() + 1 > http_request.url.length() && client.remote_port % 2 == 0", [B]),
+             ("concat", '(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && http_request.path + "x" == "/qx"', [CAP]),
+             ("list", '[http_request.host, "zz"].contains(http_request.path)', [B]),
+             ("order", 'http_request.host < http_request.path && http_request.path < "c"', [CAP]),
+             ("country", "http_request.url.contains(client.country) && client.asn * 2 == 128", [B]),
+             ("cond", '(http_request.path.starts_with("/a") ? http_request.host : http_request.url).ends_with("!")', [B]),
+             ("big", " && ".join(f'(http_request.path.contains("a{k}") || http_request.url.contains("b{k}") || http_request.host.contains("c{k}"))' for k in range(8)), [CAP]),
+             ("plain", 'http_request.path.contains("plain")', [B])]
+    eng = RuleEngine(rules)
+    assert not eng.partial and sum("residual interpreter" in w for w in eng.program.warnings()) == 7
+    rng = random.Random(5)
+    words = ["/q", "a", "b", "zz", "ab:", "x!", "/a!", "FR", "plain", "a0a1a2a3a4a5a6a7", "b0", "c1c2", "/abc", ""]
+    reqs = [Request(host=rng.choice(words) + rng.choice(words), url=rng.choice(words) + rng.choice(words) + rng.choice(words), path=rng.choice(words) + rng.choice(words),
+                    method=rng.choice(["GET", "POST", "PUT"]), user_agent="ua", remote_port=rng.randint(1, 9), asn=rng.choice([64, 65]), country=rng.choice(["FR", "US"]))
+            for _ in range(5000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "residual rules on the device")
+    assert len(set(want["rule_idx"].tolist())) >= 6
+    eng.close()

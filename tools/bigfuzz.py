@@ -27,7 +27,7 @@ for seed in range(lo, hi):
     if os.environ.get("PWAF_FUZZ_STRIDE2"):
         flags |= _abi.OPT_FILTER_STRIDE2  # stride-2 prefilters wherever they can be built; the walker samples from the seed's parity
     try:
-        prog = CompiledProgram(rules, lists, geo, flags=flags, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
+        prog = CompiledProgram(rules, lists, geo, flags=flags | _abi.OPT_LENIENT, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
     except UnsupportedExpression:
         continue
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
