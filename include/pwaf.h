@@ -206,6 +206,12 @@ typedef struct pwaf_counts {
     uint64_t by_action[4]; /* indexed by PWAF_ACTION_* */
 } pwaf_counts;
 
+typedef struct pwaf_span {
+    const char *data; /* not NUL-terminated */
+    uint32_t len;
+    uint32_t reserved;
+} pwaf_span;
+
 /* One request, for the evaluate(Request)->Action convenience wrapper. */
 typedef struct pwaf_request {
     const char *host, *url, *path, *method, *user_agent; /* not NUL-terminated */
@@ -218,6 +224,11 @@ typedef struct pwaf_request {
     uint8_t country[2];
     uint8_t pad;
     uint32_t asn;
+    /* EXTENSION (ABI 2): header values for rule sets that read http_request.headers["name"]: headers[k] is the value of header name k of
+     * the engine (pwaf_engine_header_name(k); an absent header = {NULL, 0}), n_headers <= pwaf_engine_header_count — the rest reads as "".
+     * The reference's RequestData has no headers (pingoo/rules.rs:16-25); the call shape served is http_listener.rs:206-264. */
+    uint32_t n_headers;
+    const struct pwaf_span *headers;
 } pwaf_request;
 
 /* ---- expression front-end (no GPU needed) ------------------------------------------------ */

@@ -125,7 +125,13 @@ class Request(C.Structure):
         ("country", C.c_uint8 * 2),
         ("pad", C.c_uint8),
         ("asn", C.c_uint32),
+        ("n_headers", C.c_uint32),
+        ("headers", C.c_void_p),  # pwaf_span[n_headers]
     ]
+
+
+class Span(C.Structure):
+    _fields_ = [("data", C.c_char_p), ("len", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class KernelTime(C.Structure):

@@ -33,20 +33,18 @@ struct Generation {  // one batch: the callers that joined it share this
     bool done = false;
 };
 
-struct Slot {  // a batch being filled (struct of arrays, exactly the pwaf_batch layout)
-    std::vector<uint8_t> data[PWAF_N_FIELDS];
-    std::vector<uint32_t> offs[PWAF_N_FIELDS];
+struct Slot {  // a batch being filled (struct of arrays, exactly the pwaf_batch layout); columns: the 5 fields, then the engine's header columns
+    std::vector<std::vector<uint8_t>> data;
+    std::vector<std::vector<uint32_t>> offs;
     std::vector<uint8_t> ip, v6, flags;
     std::vector<uint16_t> port, country;
     std::vector<uint32_t> asn;
     uint32_t n = 0;
     Clock::time_point deadline;
     std::shared_ptr<Generation> gen = std::make_shared<Generation>();
-    void reset() {
-        for (int f = 0; f < PWAF_N_FIELDS; f++) {
-            data[f].clear();
-            offs[f].assign(1, 0u);
-        }
+    void reset(size_t n_cols) {
+        data.assign(n_cols, {});
+        offs.assign(n_cols, std::vector<uint32_t>(1, 0u));
         ip.clear(); v6.clear(); flags.clear(); port.clear(); country.clear(); asn.clear();
         n = 0;
         gen = std::make_shared<Generation>();
@@ -57,6 +55,7 @@ struct Slot {  // a batch being filled (struct of arrays, exactly the pwaf_batch
 
 struct pwaf_batcher {
     pwaf_engine *engine = nullptr;
+    size_t n_cols = PWAF_N_FIELDS;  // 5 + pwaf_engine_header_count(engine)
     uint32_t max_batch = 0;
     std::chrono::microseconds max_delay{0};
     std::mutex mu;
@@ -89,31 +88,40 @@ struct pwaf_batcher {
             }
             Slot b = std::move(slot[due]);
             slot[due] = Slot();
-            slot[due].reset();
+            slot[due].reset(n_cols);
             lk.unlock();
             // evaluate outside the lock: callers keep filling the next batch meanwhile
             pwaf_batch pb{};
-            pb.struct_size = sizeof pb;
-            pb.n = b.n;
-            pb.memory = PWAF_MEM_HOST;
-            for (int f = 0; f < PWAF_N_FIELDS; f++) {
-                b.data[f].reserve(b.data[f].size() + PWAF_ARENA_PAD);  // (reserved when the slot was reset: does not throw in practice)
-                b.data[f].resize(b.data[f].size() + PWAF_ARENA_PAD, 0);
-                pb.field[f].data = b.data[f].data();
-                pb.field[f].offsets = b.offs[f].data();
-            }
-            pb.ip = b.ip.data();
-            pb.ip_is_v6 = b.v6.data();
-            pb.port = b.port.data();
-            pb.flags = b.flags.data();
-            if (due == 1) {
-                pb.asn = b.asn.data();
-                pb.country = b.country.data();
-            }
+            std::vector<pwaf_strcol> hcols(n_cols - PWAF_N_FIELDS);
+            std::vector<uint32_t> hbytes(n_cols - PWAF_N_FIELDS);
             std::vector<pwaf_verdict> out;
-            int rc;
+            int rc = PWAF_OK;
             std::string err;
             try {
+                pb.struct_size = sizeof pb;
+                pb.n = b.n;
+                pb.memory = PWAF_MEM_HOST;
+                for (size_t f = 0; f < n_cols; f++) {
+                    const uint32_t bytes = (uint32_t)b.data[f].size();
+                    b.data[f].resize(b.data[f].size() + PWAF_ARENA_PAD, 0);  // (may throw: inside the worker's try block)
+                    pwaf_strcol &c = f < PWAF_N_FIELDS ? pb.field[f] : hcols[f - PWAF_N_FIELDS];
+                    c.data = b.data[f].data();
+                    c.offsets = b.offs[f].data();
+                    if (f >= PWAF_N_FIELDS) hbytes[f - PWAF_N_FIELDS] = bytes;
+                }
+                if (n_cols > PWAF_N_FIELDS) {
+                    pb.n_headers = (uint32_t)(n_cols - PWAF_N_FIELDS);
+                    pb.headers = hcols.data();
+                    pb.header_bytes = hbytes.data();
+                }
+                pb.ip = b.ip.data();
+                pb.ip_is_v6 = b.v6.data();
+                pb.port = b.port.data();
+                pb.flags = b.flags.data();
+                if (due == 1) {
+                    pb.asn = b.asn.data();
+                    pb.country = b.country.data();
+                }
                 out.resize(b.n);
                 rc = pwaf_evaluate_batch(engine, &pb, out.data(), nullptr);
                 if (rc) err = pwaf_last_error();
@@ -142,8 +150,9 @@ int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_de
     b->engine = engine;
     b->max_batch = max_batch;
     b->max_delay = std::chrono::microseconds(max_delay_us);
-    b->slot[0].reset();
-    b->slot[1].reset();
+    b->n_cols = PWAF_N_FIELDS + (size_t)pwaf_engine_header_count(engine);
+    b->slot[0].reset(b->n_cols);
+    b->slot[1].reset(b->n_cols);
     for (auto &w : b->worker) w = std::thread([b] { b->run(); });
     *out = b;
     return PWAF_OK;
@@ -151,9 +160,16 @@ int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_de
 
 int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *out) {
     if (!b || !r || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
-    const char *ptr[PWAF_N_FIELDS] = {r->host, r->url, r->path, r->method, r->user_agent};
-    const uint32_t len[PWAF_N_FIELDS] = {r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
-    for (int f = 0; f < PWAF_N_FIELDS; f++)
+    if (r->n_headers && !r->headers) return fail(PWAF_E_INVALID_ARG, "n_headers without a headers array");
+    const size_t n_cols = b->n_cols;
+    std::vector<const char *> ptr{r->host, r->url, r->path, r->method, r->user_agent};
+    std::vector<uint32_t> len{r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
+    for (size_t k = 0; k + PWAF_N_FIELDS < n_cols; k++) {  // header values in the engine's header order; an absent one reads as ""
+        const bool have = k < r->n_headers;
+        ptr.push_back(have ? r->headers[k].data : nullptr);
+        len.push_back(have ? r->headers[k].len : 0u);
+    }
+    for (size_t f = 0; f < n_cols; f++)
         if (len[f] && !ptr[f]) return fail(PWAF_E_INVALID_ARG, "NULL field with non-zero length");
     // what would fail the SHARED batch is refused here, for this caller only (pingoo/geoip.rs:128-142: two letters A-Z)
     if (r->has_geoip && (r->country[0] < 'A' || r->country[0] > 'Z' || r->country[1] < 'A' || r->country[1] > 'Z'))
@@ -177,10 +193,25 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
                 emsg = "batcher is shutting down";
             } else {
                 Slot &t = b->slot[r->has_geoip ? 1 : 0];
-                for (int f = 0; f < PWAF_N_FIELDS && rc == PWAF_OK; f++)
+                for (size_t f = 0; f < n_cols && rc == PWAF_OK; f++)
                     if ((uint64_t)t.data[f].size() + len[f] > 0xFFFFFFF0ull) { rc = PWAF_E_BATCH; emsg = "batch field arena would exceed 4 GiB"; }
                 if (rc == PWAF_OK) {
-                    for (int f = 0; f < PWAF_N_FIELDS; f++) {
+                    // Transactional append: every column first gets the CAPACITY it needs — the only step that can throw —
+                    // and only then the request's values; a std::bad_alloc can no longer leave the shared batch's columns with
+                    // different lengths (every later request of that batch would have been evaluated with shifted offsets).
+                    for (size_t f = 0; f < n_cols; f++) {
+                        t.data[f].reserve(t.data[f].size() + len[f] + PWAF_ARENA_PAD);
+                        t.offs[f].reserve(t.offs[f].size() + 1);
+                    }
+                    t.ip.reserve(t.ip.size() + 16);
+                    t.v6.reserve(t.v6.size() + 1);
+                    t.flags.reserve(t.flags.size() + 1);
+                    t.port.reserve(t.port.size() + 1);
+                    if (r->has_geoip) {
+                        t.asn.reserve(t.asn.size() + 1);
+                        t.country.reserve(t.country.size() + 1);
+                    }
+                    for (size_t f = 0; f < n_cols; f++) {
                         t.data[f].insert(t.data[f].end(), (const uint8_t *)ptr[f], (const uint8_t *)ptr[f] + len[f]);
                         t.offs[f].push_back((uint32_t)t.data[f].size());
                     }

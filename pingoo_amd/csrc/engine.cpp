@@ -174,7 +174,7 @@ struct pwaf_engine {
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
     std::mutex mu;  // guards the context ring, the profiling state and table rebuilds (pwaf_engine_tune)
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
-    DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir16, dir_chunks, dir_vals;
+    DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
     uint32_t n_visit = 0;  // gap passes (visited bitmaps per batch)
     std::vector<double> mean_len;  // per field, from the tuning sample (0 = unknown)
@@ -396,7 +396,6 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
     v.has_geo = P.has_geo ? 1u : 0u;
     v.dir24 = (const uint32_t *)e->dir24.p;
-    v.dir16 = (const uint32_t *)e->dir16.p;
     v.dir_chunks = (const uint32_t *)e->dir_chunks.p;
     v.dir_vals = (const uint32_t *)e->dir_vals.p;
     v.dir_esc = (const uint2 *)e->dir_esc.p;
@@ -815,13 +814,15 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.status = (uint32_t *)S.status.p;
         return a;
     };
-    uint32_t list_variant = 0;
+    // (the shape is per PHASE: the filtered passes' candidate lists are long, the gap passes' short)
+    uint32_t list_variant[2] = {0, 0};
 #ifdef PWAF_PROFILING
-    static const uint32_t forced_shape = getenv("PWAF_LIST_SHAPE") ? (uint32_t)atoi(getenv("PWAF_LIST_SHAPE")) : 0u;  // timing experiments (same results)
-    list_variant = forced_shape;
+    static const uint32_t forced_shape = getenv("PWAF_LIST_SHAPE") ? (uint32_t)atoi(getenv("PWAF_LIST_SHAPE")) : 0u;  // timing experiments (same results): phase 0 | phase 1 << 4
+    list_variant[0] = forced_shape & 15u;
+    list_variant[1] = forced_shape >> 4;
 #endif
-    const ListShape lshape = list_shape(list_variant);
-    auto list_args = [&](size_t gi) -> ListScanArgs {
+    const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
+    auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
@@ -994,7 +995,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
                 if (skip_identity && d.identity) continue;
 #endif
-                la[phase].push_back(list_args(gi));
+                la[phase].push_back(list_args(gi, lshapes[phase]));
             }
         const size_t n_desc = la[0].size() + la[1].size();
         if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (n_desc + 2) * 4))) return rc;
@@ -1006,7 +1007,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             int he = upload_list_args(la[phase].data(), cnt, d_at, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc = mark(nullptr, 0))) return rc;
-            he = launch_scan_gated(la[phase].data(), cnt, d_at, plan_at, lshape, stream);
+            he = launch_scan_gated(la[phase].data(), cnt, d_at, plan_at, lshapes[phase], stream);
             plan_at += cnt + 1;
             if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             char nm[48];
@@ -1464,35 +1465,34 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         cnt.release();
         if (!ok) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
         // Compressed for the lookups (round 3): 10M uniformly random addresses against the flat 64 MiB table are 10M misses to HBM (the
-        // batch's own 3 GB of streaming flush every cache level in between): 0.29 ms per batch for ipres_kernel at full occupancy,
-        // ~35 G random 64-byte reads per second, the fabric's limit. Consecutive /24s mostly share their entry (a /20 prefix covers 16
-        // of them), so per /16 the 256 entries are stored as RUNS: a 256-bit bitmap of run starts with per-word prefix counts and one
-        // value per run; a /16 with a single run is a leaf of the 2^16-entry first level. ~5 MB for 600k GeoIP prefixes + 124 CIDR
-        // lists instead of 64 MiB: L2 / Infinity-Cache resident. Lookup: first level -> (prefix count, bitmap word) -> value.
+        // batch's own 3 GB of streaming flush every cache level in between), and a gather pays a whole 128-byte line per 4-byte entry.
+        // Consecutive /24s mostly share their entry (a /20 prefix covers 16 of them), so per /16 the 256 entries are stored as RUNS in
+        // ONE 128-byte line: a 256-bit bitmap of run starts, the run counts before each bitmap word, and up to kDirInlineRuns run
+        // values inline (a /16 with more runs keeps its values in dir_vals). 8 MiB for any table: L2 / Infinity-Cache resident, and a
+        // lookup is two loads from the same line.
         {
             std::vector<uint32_t> d24((size_t)1 << 24);
             if (hipMemcpy(d24.data(), e->dir24.p, d24.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(PWAF_E_DEVICE, "DIR-24 download failed"); return dev_fail(PWAF_E_DEVICE); }
-            std::vector<uint32_t> d16(65536), chunks, vals;
+            std::vector<uint32_t> chunks((size_t)65536 * kDirChunkWords, 0), vals;
             for (uint32_t x = 0; x < 65536; x++) {
                 const uint32_t *en = &d24[(size_t)x << 8];
-                bool uniform = !(en[0] & 0x80000000u);
-                for (uint32_t j = 1; j < 256 && uniform; j++) uniform = en[j] == en[0];
-                if (uniform) { d16[x] = 0x80000000u | en[0]; continue; }
-                d16[x] = (uint32_t)(chunks.size() / kDirChunkWords);
-                uint32_t bm[8] = {0}, pre[8] = {0};
-                const uint32_t base = (uint32_t)vals.size();
+                uint32_t *ck = &chunks[(size_t)x * kDirChunkWords];
+                uint32_t pre[8] = {0}, runs[256], n_runs = 0;
                 for (uint32_t j = 0; j < 256; j++)
-                    if (j == 0 || en[j] != en[j - 1]) { bm[j >> 5] |= 1u << (j & 31); vals.push_back(en[j]); }
-                for (uint32_t w = 1; w < 8; w++) pre[w] = pre[w - 1] + (uint32_t)__builtin_popcount(bm[w - 1]);
-                chunks.push_back(base);
-                chunks.push_back(pre[0] | pre[1] << 8 | pre[2] << 16 | pre[3] << 24);
-                chunks.push_back(pre[4] | pre[5] << 8 | pre[6] << 16 | pre[7] << 24);
-                for (uint32_t w = 0; w < 8; w++) chunks.push_back(bm[w]);
-                chunks.push_back(0);  // pad to kDirChunkWords
+                    if (j == 0 || en[j] != en[j - 1]) { ck[j >> 5] |= 1u << (j & 31); runs[n_runs++] = en[j]; }
+                for (uint32_t w = 1; w < 8; w++) pre[w] = pre[w - 1] + (uint32_t)__builtin_popcount(ck[w - 1]);
+                ck[8] = pre[0] | pre[1] << 8 | pre[2] << 16 | pre[3] << 24;
+                ck[9] = pre[4] | pre[5] << 8 | pre[6] << 16 | pre[7] << 24;
+                if (n_runs <= kDirInlineRuns) {
+                    ck[10] = 0xFFFFFFFFu;
+                    for (uint32_t k = 0; k < n_runs; k++) ck[11 + k] = runs[k];
+                } else {
+                    ck[10] = (uint32_t)vals.size();
+                    vals.insert(vals.end(), runs, runs + n_runs);
+                }
             }
-            if (chunks.empty()) chunks.assign(kDirChunkWords, 0);
             if (vals.empty()) vals.push_back(0);
-            if ((rc = upload(e->dir16, d16)) || (rc = upload(e->dir_chunks, chunks)) || (rc = upload(e->dir_vals, vals))) return dev_fail(rc);
+            if ((rc = upload(e->dir_chunks, chunks)) || (rc = upload(e->dir_vals, vals))) return dev_fail(rc);
             e->dir24.release();
         }
     }
@@ -1505,7 +1505,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
-                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir16, &e->dir_chunks, &e->dir_vals, &e->class_rows,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
     for (auto &c : e->ctx) c->release();
@@ -1903,24 +1903,41 @@ int pwaf_engine_device_status(pwaf_engine *e) {
 
 int pwaf_evaluate_one(pwaf_engine *e, const pwaf_request *r, pwaf_verdict *out) {
     if (!e || !r || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
-    const char *ptr[5] = {r->host, r->url, r->path, r->method, r->user_agent};
-    const uint32_t len[5] = {r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
-    std::vector<uint8_t> arena[5];
-    uint32_t offs[5][2];
+    if (r->n_headers && !r->headers) return fail(PWAF_E_INVALID_ARG, "n_headers without a headers array");
+    const uint32_t n_hdr = e->n_fields - PWAF_N_FIELDS;  // header columns the rule set reads
+    const uint32_t n_cols = PWAF_N_FIELDS + n_hdr;
+    std::vector<const char *> ptr{r->host, r->url, r->path, r->method, r->user_agent};
+    std::vector<uint32_t> len{r->host_len, r->url_len, r->path_len, r->method_len, r->user_agent_len};
+    for (uint32_t k = 0; k < n_hdr; k++) {
+        const bool have = k < r->n_headers;
+        ptr.push_back(have ? r->headers[k].data : nullptr);
+        len.push_back(have ? r->headers[k].len : 0u);
+    }
+    std::vector<std::vector<uint8_t>> arena(n_cols);
+    std::vector<uint32_t> offs(2 * (size_t)n_cols);
+    std::vector<pwaf_strcol> hcols(n_hdr);
+    std::vector<uint32_t> hbytes(n_hdr);
     pwaf_batch b{};
     b.struct_size = sizeof b;
     b.n = 1;
     b.memory = PWAF_MEM_HOST;
-    for (int f = 0; f < 5; f++) {
+    for (uint32_t f = 0; f < n_cols; f++) {
         arena[f].assign(len[f] + PWAF_ARENA_PAD, 0);
         if (len[f]) {
             if (!ptr[f]) return fail(PWAF_E_INVALID_ARG, "NULL field with non-zero length");
             memcpy(arena[f].data(), ptr[f], len[f]);
         }
-        offs[f][0] = 0;
-        offs[f][1] = len[f];
-        b.field[f].data = arena[f].data();
-        b.field[f].offsets = offs[f];
+        offs[2 * f] = 0;
+        offs[2 * f + 1] = len[f];
+        pwaf_strcol &c = f < PWAF_N_FIELDS ? b.field[f] : hcols[f - PWAF_N_FIELDS];
+        c.data = arena[f].data();
+        c.offsets = &offs[2 * f];
+        if (f >= PWAF_N_FIELDS) hbytes[f - PWAF_N_FIELDS] = len[f];
+    }
+    if (n_hdr) {
+        b.n_headers = n_hdr;
+        b.headers = hcols.data();
+        b.header_bytes = hbytes.data();
     }
     uint16_t port = r->port, country = (uint16_t)(r->country[0] | r->country[1] << 8);
     uint8_t v6 = r->ip_is_v6, flags = r->flags;

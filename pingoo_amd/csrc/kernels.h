@@ -10,7 +10,7 @@ static constexpr int kMaxPasses = 250;  // (= program.h kMaxGroups)
 static constexpr int kVerdictPre = 12;  // hit records per request the verdict kernel requests one group ahead
 static constexpr uint32_t kGapLists = 32;     // gated gap passes own list slots [0, 32) (one bit each in the factor masks); filtered passes follow
 static constexpr uint32_t kMaxHeaderLens = 8; // header columns whose LENGTH rules compare
-static constexpr uint32_t kDirChunkWords = 12; // words per /16 chunk of the compressed DIR-24 table (VerdictArgs::dir_chunks)
+static constexpr uint32_t kDirChunkWords = 32, kDirInlineRuns = 21; // one 128-byte line per /16 of the compressed DIR-24 table (VerdictArgs::dir_chunks)
 
 // Hit record of one (scan pass, request): what the request's field matched in that pass's DFA.
 //   bit 31 = 0: bits [14:0] = first local atom + 1 (0 = none), bits [29:15] = second local atom + 1 (0 = none)
@@ -279,10 +279,11 @@ struct VerdictArgs {
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
     // (roots are never null on the device: a family without prefixes gets an all-leaf root. GeoIP trie leaves are CLASS ids.)
     const uint32_t *dir24;        // BUILD TIME ONLY (dir24_kernel's output): first 24 bits of both IPv4 tries flattened: class | set << 16, or DIR_ESCAPE | index into dir_esc
-    // ... compressed for the lookups: dir16[top 16 bits] = 0x80000000 | entry when the whole /16 shares one entry, else the index of a
-    // chunk of kDirChunkWords words {first value index, 8 x u8 run counts before each bitmap word (2 words), 256-bit bitmap of run
-    // starts (8 words), pad}; dir_vals[first + runs up to and including the /24 - 1] = the entry. dir16 null = walk from the roots.
-    const uint32_t *dir16, *dir_chunks, *dir_vals;
+    // ... compressed for the lookups: one 128-byte chunk per /16 (index = the address's top 16 bits) of kDirChunkWords words:
+    // [0, 8) 256-bit bitmap of the /24s where a run of equal entries starts, [8, 10) 8 x u8 runs before each bitmap word,
+    // [10] 0xFFFFFFFF = the run values are inline in [11, 11 + kDirInlineRuns), else the index of the first value in dir_vals.
+    // dir_chunks null = walk from the roots.
+    const uint32_t *dir_chunks, *dir_vals;
     const uint2 *dir_esc;         // {geo trie entry, ip-list trie entry} of the escaped /24s
     const uint32_t *class_rows;   // per GeoIP class: country-table words, asn-set words, asn-comparison words (class 0 = all zero)
     uint32_t class_words;

@@ -1781,7 +1781,7 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
     // the loads of all four before any is used.
     constexpr uint32_t U = 4;
     const bool from_row = a.asn == nullptr;
-    const bool dir = a.dir16 != nullptr;
+    const bool dir = a.dir_chunks != nullptr;
     const uint32_t T = gridDim.x * 256u;
     for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < a.n; i0 += T * U) {
         uint32_t idx[U], ipw[U][4], eg[U], ei[U], k[U];
@@ -1813,40 +1813,38 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
                 }
             }
             top16[u] = (ip_byte(ipw[u], 0) << 8) | ip_byte(ipw[u], 1);
-            // phase 1: the first level — the /16 of the compressed DIR table (IPv4), or the two 16-bit roots
+            // phase 1: the /16's line of the compressed DIR table (IPv4) — bitmap word, run counts, where the values live — or the two
+            // 16-bit roots
             eg[u] = ei[u] = TRIE_LEAF;
+            chunked[u] = !v6[u] && dir;
             first[u] = 0;
-            chunked[u] = false;
-            if (!v6[u] && dir) {
-                first[u] = a.dir16[top16[u]];
-            } else {
+            if (!chunked[u]) {
                 if (geo_walk[u]) eg[u] = (v6[u] ? a.geo_root6 : a.geo_root4)[top16[u]];  // (the engine substitutes an all-leaf root for a family without prefixes)
                 if (a.n_ip_lists) ei[u] = (v6[u] ? a.ip_root6 : a.ip_root4)[top16[u]];
             }
         }
-        // phase 2: the run bitmap of a /16 that is not uniform
-        uint32_t ck0[U], pre[U], bmw[U];
+        uint32_t pre[U], bmw[U], ext[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            ck0[u] = pre[u] = bmw[u] = 0;
-            if (!v6[u] && dir && !(first[u] & 0x80000000u)) {
-                chunked[u] = true;
-                const uint32_t *ck = a.dir_chunks + (size_t)first[u] * kDirChunkWords;
+            pre[u] = bmw[u] = 0;
+            ext[u] = 0xFFFFFFFFu;
+            if (chunked[u]) {
+                const uint32_t *ck = a.dir_chunks + (size_t)top16[u] * kDirChunkWords;
                 const uint32_t w = ip_byte(ipw[u], 2) >> 5;
-                ck0[u] = ck[0];
-                pre[u] = w < 4 ? ck[1] : ck[2];
-                bmw[u] = ck[3 + w];
+                bmw[u] = ck[w];
+                pre[u] = w < 4 ? ck[8] : ck[9];
+                ext[u] = ck[10];
             }
         }
-        // phase 3: the run's value
+        // phase 2: the run's value — the same line again (an L1 hit), or dir_vals for a /16 with many runs
         uint32_t e24[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            e24[u] = first[u] & 0x7FFFFFFFu;
+            e24[u] = 0;
             if (chunked[u]) {
                 const uint32_t b2 = ip_byte(ipw[u], 2), w = b2 >> 5;
                 const uint32_t rank = ((pre[u] >> ((w & 3u) * 8u)) & 0xFFu) + (uint32_t)__builtin_popcount(bmw[u] & (0xFFFFFFFFu >> (31u - (b2 & 31u))));  // run starts at or before the /24
-                e24[u] = a.dir_vals[ck0[u] + rank - 1u];
+                e24[u] = ext[u] == 0xFFFFFFFFu ? a.dir_chunks[(size_t)top16[u] * kDirChunkWords + 10u + rank] : a.dir_vals[ext[u] + rank - 1u];
             }
         }
         // phase 4: escapes (a prefix longer than /24, or an id too large for the packed entry: rare)

@@ -361,9 +361,13 @@ class RuleEngine:
         return out
 
     def evaluate(self, request: Request) -> Verdict:
-        """RuleEngine::evaluate(Request) -> Action: a batch of one through the same device path."""
-        v = self.evaluate_batch(RequestBatch.from_requests([request]))[0]
-        return verdict_from_record(v)
+        """RuleEngine::evaluate(Request) -> Action (pwaf_evaluate_one): a batch of one through the same device path."""
+        st, _keep = _request_struct(request, self.header_names)
+        out = _abi.Verdict()
+        rc = lib().pwaf_evaluate_one(self._h, C.byref(st), C.byref(out))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return verdict_from_record({"action": out.action, "rule_idx": out.rule_idx})
 
     def evaluate_device(self, dbatch: "DeviceBatch", out=None, counts=None, match_idx=None, n_matches=None, stream=None):
         """Device-resident evaluation on torch's current stream (or `stream`). Tensors stay on the GPU."""
@@ -476,8 +480,9 @@ class ServiceRouter:
         self._engine.close()
 
 
-def _request_struct(r: Request):
-    """pwaf_request for one Request; returns (struct, keepalive) — the byte strings must outlive the call."""
+def _request_struct(r: Request, header_names: Sequence[str] = ()):
+    """pwaf_request for one Request; returns (struct, keepalive) — the byte strings must outlive the call. header_names = the engine's
+    header columns: the request's values are handed over in that order (an absent header reads as "")."""
     from .batch import ip_to_bytes16
 
     fields = [x.encode() if isinstance(x, str) else bytes(x) for x in (r.host, r.url, r.path, r.method, r.user_agent)]
@@ -495,7 +500,22 @@ def _request_struct(r: Request):
         cc = r.country.encode() if isinstance(r.country, str) else bytes(r.country)
         st.country[0], st.country[1] = cc[0], cc[1]
         st.asn = r.asn
-    return st, fields
+    keep = [fields]
+    if header_names:
+        spans = (_abi.Span * len(header_names))()
+        vals = []
+        for k, name in enumerate(header_names):
+            v = (r.headers or {}).get(name)
+            if v is None:
+                continue
+            v = v.encode() if isinstance(v, str) else bytes(v)
+            vals.append(v)
+            spans[k].data = v
+            spans[k].len = len(v)
+        st.n_headers = len(header_names)
+        st.headers = C.cast(spans, C.c_void_p)
+        keep += [spans, vals]
+    return st, keep
 
 
 class MicroBatcher:
@@ -511,7 +531,7 @@ class MicroBatcher:
         self._h = h
 
     def evaluate(self, request: Request) -> Verdict:
-        st, _keep = _request_struct(request)
+        st, _keep = _request_struct(request, self._engine.header_names)
         out = _abi.Verdict()
         rc = lib().pwaf_batcher_evaluate(self._h, C.byref(st), C.byref(out))
         if rc != 0:
