@@ -321,6 +321,18 @@ size_t pwaf_node_device_count(const pwaf_node *);
 pwaf_engine *pwaf_node_engine(const pwaf_node *, size_t i);
 int pwaf_node_tune(pwaf_node *, const pwaf_batch *sample);
 int pwaf_node_evaluate_batch(pwaf_node *, const pwaf_batch *in /* HOST */, pwaf_verdict *out /* n */, pwaf_counts *counts /* nullable */);
+/* DEVICE-resident slabs, one per device of the node (ABI 2): batches[r] lives on device r (its slab of the request stream:
+ * pwaf_node_shard_bounds), outs[r] / counts[r] (nullable, ACCUMULATED into like pwaf_evaluate_device's) are device pointers on device
+ * r, streams[r] (nullable array / entries) is a HIP stream of device r. No host staging: the enqueue runs on the node's persistent
+ * per-device host threads in parallel and returns without waiting for the devices. Replaces, for a single-process host, what
+ * pingoo/server.rs:111-134 does when it hands the shared rule state to every listener. */
+int pwaf_node_evaluate_device(pwaf_node *, const pwaf_batch *const *batches, pwaf_verdict *const *outs, pwaf_counts *const *counts, void *const *streams);
+/* Waits for every device; PWAF_E_NOMEM when a device-resident slab since the last call ran out of scan scratch (see pwaf_engine_device_status). */
+int pwaf_node_synchronize(pwaf_node *);
+/* The path's only cross-device exchange — the sum of the four action counters — as an RCCL all-reduce over xGMI, in place on the
+ * per-device counters: comms[r] = the caller's ncclComm_t for device r (librccl.so is loaded on first use). Hosts that add the 4 x 8
+ * bytes per device up themselves do not need it. */
+int pwaf_node_allreduce_counts(pwaf_node *, void *const *comms, pwaf_counts *const *counts, void *const *streams);
 /* Slab [lo, hi) of device `rank` out of `world` for a batch of n requests. */
 void pwaf_node_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t *lo, uint32_t *hi);
 

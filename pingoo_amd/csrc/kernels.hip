@@ -1781,7 +1781,14 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
     // the loads of all four before any is used.
     constexpr uint32_t U = 4;
     const bool from_row = a.asn == nullptr;
+#ifdef PWAF_PROFILING
+    // timing experiments (wrong results): bit 16 = no table lookups for IPv4, bit 17 = no trie walks for IPv6
+    const bool dir = a.dir_chunks != nullptr && !((a.debug_skip >> 16) & 1u);
+    const bool skip_v6 = (a.debug_skip >> 17) & 1u, skip_v4 = (a.debug_skip >> 16) & 1u;
+#else
     const bool dir = a.dir_chunks != nullptr;
+    constexpr bool skip_v6 = false, skip_v4 = false;
+#endif
     const uint32_t T = gridDim.x * 256u;
     for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < a.n; i0 += T * U) {
         uint32_t idx[U], ipw[U][4], eg[U], ei[U], k[U];
@@ -1818,7 +1825,7 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
             eg[u] = ei[u] = TRIE_LEAF;
             chunked[u] = !v6[u] && dir;
             first[u] = 0;
-            if (!chunked[u]) {
+            if (!chunked[u] && !(v6[u] ? skip_v6 : skip_v4)) {
                 if (geo_walk[u]) eg[u] = (v6[u] ? a.geo_root6 : a.geo_root4)[top16[u]];  // (the engine substitutes an all-leaf root for a family without prefixes)
                 if (a.n_ip_lists) ei[u] = (v6[u] ? a.ip_root6 : a.ip_root4)[top16[u]];
             }

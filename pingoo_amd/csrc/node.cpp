@@ -5,11 +5,17 @@
 // that device's engine replica on its own host thread and stream. There is no data-path exchange between devices: the only
 // cross-device result is the sum of the four action counters, added up on the host (the process-per-GPU mode of bench.py does the
 // same with an RCCL all-reduce). Verdicts land directly in the caller's output array at the slab's position.
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../include/pwaf.h"
@@ -18,9 +24,66 @@ namespace pwaf {
 int fail(int code, const std::string &msg);  // engine.cpp: sets the thread's last-error text
 }
 
+// One persistent host thread per device (round 3; round 2 spawned std::threads per call): a call posts one job per device and waits
+// for all of them. A job runs on the thread that owns the device for the node's lifetime, so the HIP runtime's per-thread
+// current-device state is set once.
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, stop = false, done = true;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop && !has_job) return;
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            j();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        job = std::move(j);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+};
+
 struct pwaf_node {
     std::vector<pwaf_engine *> engines;
     std::vector<int> devices;
+    std::vector<std::unique_ptr<Worker>> workers;  // one per device but the first (the caller's thread serves device 0)
+    std::mutex call_mu;                            // one node-level call at a time posts to the workers
+    ~pwaf_node() {
+        for (auto &w : workers) {
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->stop = true;
+            }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+    // runs work(r) for every device r: r = 0 on the calling thread, the others on their persistent threads
+    void for_each_device(const std::function<void(uint32_t)> &work) {
+        std::lock_guard<std::mutex> lk(call_mu);
+        const uint32_t world = (uint32_t)engines.size();
+        for (uint32_t r = 1; r < world; r++) workers[r - 1]->post([&work, r] { work(r); });
+        work(0);
+        for (uint32_t r = 1; r < world; r++) workers[r - 1]->wait();
+    }
 };
 
 extern "C" {
@@ -54,6 +117,11 @@ int pwaf_node_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_lis
         }
         nd->engines.push_back(e);
         nd->devices.push_back(devices[k]);
+    }
+    for (size_t k = 1; k < n_devices; k++) {
+        nd->workers.emplace_back(new Worker());
+        Worker *w = nd->workers.back().get();
+        w->th = std::thread([w] { w->run(); });
     }
     *out = nd;
     return PWAF_OK;
@@ -113,15 +181,90 @@ int pwaf_node_evaluate_batch(pwaf_node *nd, const pwaf_batch *in, pwaf_verdict *
         rcs[r] = pwaf_evaluate_batch(nd->engines[r], &sub, out + lo, &part[r]);
         if (rcs[r]) msgs[r] = pwaf_last_error();  // (the error text is thread-local: carry it to the caller's thread)
     };
-    std::vector<std::thread> th;
-    for (uint32_t r = 1; r < world; r++) th.emplace_back(work, r);
-    work(0);
-    for (auto &t : th) t.join();
+    nd->for_each_device(work);
     for (uint32_t r = 0; r < world; r++)
         if (rcs[r]) return pwaf::fail(rcs[r], "device " + std::to_string(nd->devices[r]) + ": " + msgs[r]);
     if (counts)
         for (uint32_t r = 0; r < world; r++)
             for (int a = 0; a < 4; a++) counts->by_action[a] += part[r].by_action[a];
+    return PWAF_OK;
+}
+
+// Device-resident multi-GPU entry point (round 3): every device already holds its slab of the request stream (pwaf_node_shard_bounds
+// says which) — no host staging, no copy: slab r is enqueued on device r's engine replica and stream by that device's persistent
+// thread (an enqueue costs ~0.2 ms of host time: in parallel, not one after the other). Asynchronous like pwaf_evaluate_device:
+// verdicts and per-device counters are valid once the caller has synchronised the streams (or calls pwaf_node_synchronize).
+int pwaf_node_evaluate_device(pwaf_node *nd, const pwaf_batch *const *batches, pwaf_verdict *const *outs, pwaf_counts *const *counts, void *const *streams) {
+    if (!nd || !batches || !outs) return pwaf::fail(PWAF_E_INVALID_ARG, "NULL argument");
+    const uint32_t world = (uint32_t)nd->engines.size();
+    for (uint32_t r = 0; r < world; r++) {
+        if (!batches[r]) return pwaf::fail(PWAF_E_INVALID_ARG, "batches[" + std::to_string(r) + "] is NULL (pass a batch with n = 0 for an idle device)");
+        if (batches[r]->struct_size != sizeof(pwaf_batch)) return pwaf::fail(PWAF_E_INVALID_ARG, "pwaf_batch.struct_size mismatch");
+        if (batches[r]->memory != PWAF_MEM_DEVICE) return pwaf::fail(PWAF_E_INVALID_ARG, "pwaf_node_evaluate_device takes DEVICE-resident slabs (host batches: pwaf_node_evaluate_batch)");
+        if (batches[r]->n && !outs[r]) return pwaf::fail(PWAF_E_INVALID_ARG, "outs[" + std::to_string(r) + "] is NULL");
+    }
+    std::vector<int> rcs(world, PWAF_OK);
+    std::vector<std::string> msgs(world);
+    nd->for_each_device([&](uint32_t r) {
+        if (batches[r]->n == 0) return;
+        rcs[r] = pwaf_evaluate_device(nd->engines[r], batches[r], outs[r], counts ? counts[r] : nullptr, nullptr, nullptr, streams ? streams[r] : nullptr);
+        if (rcs[r]) msgs[r] = pwaf_last_error();
+    });
+    for (uint32_t r = 0; r < world; r++)
+        if (rcs[r]) return pwaf::fail(rcs[r], "device " + std::to_string(nd->devices[r]) + ": " + msgs[r]);
+    return PWAF_OK;
+}
+
+// Waits for every device of the node and reports (like pwaf_engine_device_status per device) whether some device-resident batch
+// since the last call ran out of scan scratch.
+int pwaf_node_synchronize(pwaf_node *nd) {
+    if (!nd) return pwaf::fail(PWAF_E_INVALID_ARG, "node is NULL");
+    const uint32_t world = (uint32_t)nd->engines.size();
+    std::vector<int> rcs(world, PWAF_OK);
+    std::vector<std::string> msgs(world);
+    nd->for_each_device([&](uint32_t r) {
+        rcs[r] = pwaf_engine_device_status(nd->engines[r]);
+        if (rcs[r]) msgs[r] = pwaf_last_error();
+    });
+    for (uint32_t r = 0; r < world; r++)
+        if (rcs[r]) return pwaf::fail(rcs[r], "device " + std::to_string(nd->devices[r]) + ": " + msgs[r]);
+    return PWAF_OK;
+}
+
+// The path's only exchange between devices, for a single-process host: the four action counters (32 bytes per device) summed over
+// xGMI by RCCL — `comms[r]` is the caller's ncclComm_t of device r (one communicator spanning the node's devices, e.g. from
+// ncclCommInitAll), the all-reduce is enqueued in place on counts[r] / streams[r] inside one RCCL group. librccl is loaded at run time
+// (it is only needed by callers that pass communicators: hosts that sum the counters themselves never touch it).
+int pwaf_node_allreduce_counts(pwaf_node *nd, void *const *comms, pwaf_counts *const *counts, void *const *streams) {
+    if (!nd || !comms || !counts) return pwaf::fail(PWAF_E_INVALID_ARG, "NULL argument");
+    const uint32_t world = (uint32_t)nd->engines.size();
+    for (uint32_t r = 0; r < world; r++)
+        if (!comms[r] || !counts[r]) return pwaf::fail(PWAF_E_INVALID_ARG, "comms / counts must hold one entry per device");
+    typedef int (*group_fn)(void);
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, void *);
+    static void *lib = nullptr;
+    static group_fn g_start = nullptr, g_end = nullptr;
+    static allreduce_fn allreduce = nullptr;
+    static std::mutex load_mu;
+    {
+        std::lock_guard<std::mutex> lk(load_mu);
+        if (!lib) {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
+            if (!lib) return pwaf::fail(PWAF_E_UNSUPPORTED, "librccl.so could not be loaded");
+            g_start = (group_fn)dlsym(lib, "ncclGroupStart");
+            g_end = (group_fn)dlsym(lib, "ncclGroupEnd");
+            allreduce = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+        }
+        if (!g_start || !g_end || !allreduce) return pwaf::fail(PWAF_E_UNSUPPORTED, "librccl.so lacks ncclGroupStart / ncclGroupEnd / ncclAllReduce");
+    }
+    constexpr int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+    int rc = g_start();
+    for (uint32_t r = 0; r < world && rc == 0; r++) rc = allreduce(counts[r], counts[r], 4, kNcclUint64, kNcclSum, comms[r], streams ? streams[r] : nullptr);
+    const int rc2 = g_end();
+    if (rc || rc2) return pwaf::fail(PWAF_E_DEVICE, "RCCL all-reduce of the action counters failed (ncclResult " + std::to_string(rc ? rc : rc2) + ")");
     return PWAF_OK;
 }
 

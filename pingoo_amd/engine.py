@@ -115,6 +115,9 @@ def lib():
     L.pwaf_node_engine.restype = vp
     L.pwaf_node_tune.argtypes = [vp, C.POINTER(_abi.Batch)]
     L.pwaf_node_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
+    L.pwaf_node_evaluate_device.argtypes = [vp, C.POINTER(C.POINTER(_abi.Batch)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pwaf_node_synchronize.argtypes = [vp]
+    L.pwaf_node_allreduce_counts.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pwaf_node_shard_bounds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.pwaf_node_shard_bounds.restype = None
     L.pwaf_batcher_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
@@ -440,6 +443,25 @@ class NodeEngine:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
         return (out, np.array(list(counts.by_action), dtype=np.uint64)) if with_counts else out
 
+    def evaluate_device(self, dbatches, outs, counts=None, streams=None) -> None:
+        """pwaf_node_evaluate_device: one DEVICE-resident slab per device of the node (DeviceBatch list), verdict tensors `outs`
+        ((n_r, 2) int32 on device r), optional per-device int64[4] counter tensors (accumulated into). Asynchronous: call
+        synchronize() before reading."""
+        k = len(dbatches)
+        structs = [b.as_struct(self.header_names) for b in dbatches]
+        arr = (C.POINTER(_abi.Batch) * k)(*[C.pointer(s) for s in structs])
+        o = (C.c_void_p * k)(*[t.data_ptr() for t in outs])
+        c = (C.c_void_p * k)(*[t.data_ptr() for t in counts]) if counts is not None else None
+        st = (C.c_void_p * k)(*[int(x) for x in streams]) if streams is not None else None
+        rc = lib().pwaf_node_evaluate_device(self._h, arr, o, c, st)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+
+    def synchronize(self) -> None:
+        rc = lib().pwaf_node_synchronize(self._h)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+
     def tune(self, sample: RequestBatch) -> None:
         st = sample.as_struct(self.header_names)
         rc = lib().pwaf_node_tune(self._h, C.byref(st))
@@ -553,6 +575,39 @@ class MicroBatcher:
             self.close()
         except Exception:
             pass
+
+
+def native_batcher_latency(engine: "RuleEngine", batch: RequestBatch, threads: int = 64, per_thread: int = 150, max_batch: int = 4096, max_delay_us: int = 200, pool: int = 256) -> dict:
+    """Per-request latency through the deadline micro-batcher as a NATIVE host sees it: tools/libbatcher_bench.so (C++, `threads`
+    std::threads calling pwaf_batcher_evaluate back to back over the first `pool` requests of `batch`). Measurement only."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libbatcher_bench.so")
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing (built by __graft_entry__.build())")
+    bb = C.CDLL(path)
+    bb.bb_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.Request), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
+    pool = min(pool, batch.n)
+    reqs = (_abi.Request * pool)()
+    keep = []
+    names = engine.header_names
+    for i in range(pool):
+        hdrs = {h: batch.header_bytes(h, i) for h in names} if names else None
+        r = Request(host=batch.field_bytes(0, i), url=batch.field_bytes(1, i), path=batch.field_bytes(2, i), method=batch.field_bytes(3, i), user_agent=batch.field_bytes(4, i),
+                    ip="203.0.113.%d" % (i % 250 + 1), remote_port=int(batch.port[i]), headers=hdrs)
+        st, k = _request_struct(r, names)
+        reqs[i] = st
+        keep.append(k)
+    mb = MicroBatcher(engine, max_batch=max_batch, max_delay_us=max_delay_us)
+    n = threads * per_thread
+    lat = (C.c_double * n)()
+    secs = C.c_double(0)
+    fn = C.cast(lib().pwaf_batcher_evaluate, C.c_void_p)
+    failed = bb.bb_run(fn, mb._h, reqs, pool, threads, per_thread, lat, None, C.byref(secs))
+    nb, nr = mb.stats()
+    mb.close()
+    xs = sorted(lat)
+    pct = lambda p: xs[min(n - 1, int(round(p / 100.0 * (n - 1))))]  # noqa: E731
+    return {"caller_threads": threads, "callers": "native (std::thread, tools/batcher_bench.cpp)", "requests": n, "failed": failed, "max_batch": max_batch, "deadline_us": max_delay_us,
+            "batches": nb, "requests_per_s": n / secs.value if secs.value > 0 else 0.0, "latency_ms": {"p50": pct(50), "p99": pct(99), "max": xs[-1]}}
 
 
 def geoip_from_mmdb(content: bytes, path: str = "geoip.mmdb") -> np.ndarray:

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_abi.RuleDesc) == 32 and C.sizeof(_abi.ListDesc) == 24 and C.sizeof(_abi.GeoipEntry) == 24
     assert C.sizeof(_abi.Options) == 32 and C.sizeof(_abi.CompileError) == 256 and C.sizeof(_abi.Verdict) == 8
     assert C.sizeof(_abi.Batch) == 16 + 5 * 16 + 6 * 8 + 5 * 4 + 4 + 2 * 8 and C.sizeof(_abi.Counts) == 32 and C.sizeof(_abi.Stats) == 64
-    assert C.sizeof(_abi.KernelTime) == 64 and C.sizeof(_abi.Request) == 88
+    assert C.sizeof(_abi.KernelTime) == 64 and C.sizeof(_abi.Request) == 104
 
 
 def test_struct_sizes_against_c_compiler(tmp_path):
@@ -51,6 +51,8 @@ def test_struct_sizes_against_c_compiler(tmp_path):
 
 def test_error_paths_do_not_need_a_gpu():
     L = engine.lib()
+    assert L.pwaf_node_evaluate_device(None, None, None, None, None) == _abi.E_INVALID_ARG
+    assert L.pwaf_node_synchronize(None) == _abi.E_INVALID_ARG and L.pwaf_node_allreduce_counts(None, None, None, None) == _abi.E_INVALID_ARG
     assert L.pwaf_evaluate_batch(None, None, None, None) == _abi.E_INVALID_ARG
     assert b"NULL" in L.pwaf_last_error()
     with pytest.raises(engine.ExpressionIsNotValid):

@@ -154,6 +154,23 @@ def test_node_api_two_engines_from_one_thread_and_concurrent_device_calls():
     assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
     node.tune(w.batch(100000, 2000))
     H.assert_verdicts_equal(node.evaluate_batch(batch), want, batch, "node, tuned")
+    # DEVICE-resident slabs (pwaf_node_evaluate_device): one slab per replica, already in HBM, enqueued by the node's persistent
+    # per-device host threads; the per-device counters are accumulated on the device
+    from pingoo_amd import shard
+    bounds = [shard.shard_bounds(batch.n, r, 2) for r in range(2)]
+    slabs = [DeviceBatch(batch.slice(lo, hi)) for lo, hi in bounds]
+    outs_d = [torch.empty((hi - lo, 2), dtype=torch.int32, device="cuda") for lo, hi in bounds]
+    cnts_d = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in bounds]
+    streams_d = [torch.cuda.Stream() for _ in bounds]
+    for _ in range(3):
+        for c in cnts_d:
+            c.zero_()
+        torch.cuda.synchronize()
+        node.evaluate_device(slabs, outs_d, cnts_d, [s.cuda_stream for s in streams_d])
+        node.synchronize()
+    got_d = np.concatenate([o.cpu().numpy().view(np.uint32) for o in outs_d])
+    assert (got_d[:, 0] == want["action"]).all() and (got_d[:, 1] == want["rule_idx"]).all(), "node, device-resident slabs"
+    assert (cnts_d[0] + cnts_d[1]).cpu().tolist() == np.bincount(want["action"], minlength=4).tolist()
     node.close()
 
     eng = RuleEngine(w.rules, w.lists, w.geoip)
@@ -312,3 +329,46 @@ def test_short_literal_atoms_are_answered_by_the_attribute_kernel():
             H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"short literals tuned, {len(rules)} rules, flags {flags}")
             eng.close()
     assert len(set(pyoracle.Oracle(short).evaluate(batch)["rule_idx"].tolist())) >= 6
+
+
+def test_header_values_through_evaluate_one_and_the_micro_batcher():
+    """ABI 2: pwaf_request carries header values (in the engine's header order), so rule sets over http_request.headers[...] give the
+    same verdicts through evaluate(Request) and the deadline micro-batcher as through a batch (the call shape is
+    http_listener.rs:206-264). The native harness (tools/batcher_bench.cpp) drives the batcher from std::threads."""
+    import threading
+    from pingoo_amd.engine import MicroBatcher, native_batcher_latency
+
+    rules = [("tok", 'http_request.headers["x-token"].contains("evil") && http_request.method == "POST"', [B]),
+             ("ref", 'http_request.headers["referer"].starts_with("http://spam.") || http_request.headers["cookie"].matches("sid=[0-9]{4}")', [CAP]),
+             ("len", 'http_request.headers["x-token"].length() > 20', [B]),
+             ("mix", 'http_request.headers["cookie"] + http_request.path == "a=1/p"', [B])]  # (a residual rule over a header column)
+    eng = RuleEngine(rules)
+    assert set(eng.header_names) == {"x-token", "referer", "cookie"}
+    rng = random.Random(12)
+    vals = ["", "evil", "xx evil yy", "http://spam.example", "sid=1234", "sid=12a4", "a=1", "t" * 25, "benign"]
+    reqs = [Request(path=rng.choice(["/p", "/q"]), url="/p", host="h", method=rng.choice(["GET", "POST"]), user_agent="ua",
+                    headers={k: rng.choice(vals) for k in ("x-token", "referer", "cookie", "unused") if rng.random() < 0.7} or None) for _ in range(600)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "headers, batch")
+    assert len(set(want["rule_idx"].tolist())) >= 4
+    for i in range(0, 60):
+        v = eng.evaluate(reqs[i])
+        assert int(v.decision) == int(want[i]["action"]) and (v.rule_idx is None or v.rule_idx == int(want[i]["rule_idx"])), (i, v)
+    mb = MicroBatcher(eng, max_batch=64, max_delay_us=300)
+    got = [None] * len(reqs)
+
+    def caller(k):
+        for i in range(k, len(reqs), 16):
+            got[i] = mb.evaluate(reqs[i])
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    mb.close()
+    for i, v in enumerate(got):
+        assert int(v.decision) == int(want[i]["action"]), (i, reqs[i])
+    stats = native_batcher_latency(eng, batch, threads=16, per_thread=40, max_batch=256, max_delay_us=200, pool=128)
+    assert stats["failed"] == 0 and stats["requests"] == 640 and stats["latency_ms"]["p50"] > 0
+    eng.close()

@@ -245,3 +245,16 @@ def test_list_loading_errors_and_trimming():
         with pytest.raises(pyoracle.OracleError) as ei:
             pyoracle.Oracle([("r", None, [B])], lists)
         assert ei.value.code == _abi.E_LIST
+
+
+def test_regex_rule_sets_of_the_synthetic_configs_match_cpython_re():
+    """tools/regex_crosscheck.py at reduced size: every `matches` pattern of BASELINE configs[2] / configs[4] against the field values
+    of benign and adversarial requests, oracle regex engine vs CPython `re` (the full run is the script's default)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("regex_crosscheck", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "regex_crosscheck.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_pats, checked, bad = mod.crosscheck(3, 150, verbose=False)
+    assert n_pats >= 150 and checked > 50_000 and bad == 0
