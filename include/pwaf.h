@@ -125,6 +125,7 @@ void pwaf_list_free(char **items, size_t n);
                                        * returns PWAF_W_PARTIAL instead of PWAF_OK. Default (ABI 2): creation fails with the rule's index —
                                        * the reference evaluates every valid expression (pingoo/rules.rs:37-51), a silently dropped Block
                                        * rule is a fail-open hole */
+#define PWAF_OPT_GLOBAL_VERDICT_TABLES 128u /* testing: the verdict kernel variant for programs whose tables do not fit LDS (same verdicts) */
 #define PWAF_OPT_NO_RESIDUAL 64u      /* do not use the per-request residual interpreter (testing / benchmarking the column path alone) */
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 #define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1

@@ -172,7 +172,8 @@ struct pwaf_engine {
     DevBuf iu_vals[2], iu_masks[2];
     uint32_t iu_n[2] = {0, 0}, iu_words[2] = {1, 1};
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
-    std::mutex mu;  // guards the context ring, the profiling state and table rebuilds (pwaf_engine_tune)
+    std::mutex mu;  // guards the context ring and table rebuilds (pwaf_engine_tune)
+    std::mutex prof_mu;  // while profiling is on, calls enqueue one at a time: the event / timing tables below are per engine
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
     DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
@@ -552,7 +553,7 @@ Scratch &acquire_context(pwaf_engine *e, bool own, hipStream_t caller, std::uniq
 }
 
 int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device pointers */, pwaf_verdict *d_out, pwaf_counts *d_counts, uint32_t *d_match_idx,
-                 uint32_t *d_n_matches, hipStream_t stream, bool totals_known = false, const std::vector<uint32_t> *col_begin = nullptr) {
+                 uint32_t *d_n_matches, hipStream_t stream, bool totals_known = false, const std::vector<uint32_t> *col_begin = nullptr, bool sync_status = false) {
     const Program &P = *e->prog.p;
     const uint32_t n = db.n, n_groups = (n + 63) / 64;
     if (n == 0) return PWAF_OK;
@@ -566,10 +567,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const uint64_t pool_cap64 = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)n * 8), S.pool_entries);
     const uint32_t pool_cap = (uint32_t)std::min<uint64_t>(pool_cap64, 0x7FFFFFF0u);
     S.pool_entries = pool_cap;
+    // two sticky status words per context: [0] device-resident batches (reported and cleared by pwaf_engine_device_status),
+    // [1] the synchronous entry points (read and cleared by their own retry loop) — a synchronous batch on the same context can no
+    // longer swallow the overflow bit of an earlier asynchronous one
     if (!S.status.p) {
-        if ((rc = S.status.reserve(4))) return rc;
-        HIP_TRY(hipMemsetAsync(S.status.p, 0, 4, stream));
+        if ((rc = S.status.reserve(8))) return rc;
+        HIP_TRY(hipMemsetAsync(S.status.p, 0, 8, stream));
     }
+    uint32_t *const status_word = (uint32_t *)S.status.p + (sync_status ? 1 : 0);
     if ((rc = S.rec.reserve((size_t)std::max(1u, n_passes) * n * 4))) return rc;
     // the attribute kernel's output: per group a header and room for EVERY non-scan atom (worst case: no overflow path), plus 64
     // pairs of slack so the verdict kernel may read a full wave's worth unconditionally
@@ -628,6 +633,9 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
 
     // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
     // (half the events; the few microseconds of launch gap or memset in between are charged to the later kernel).
+    // (evaluate calls are re-entrant, the timing tables are not — a profiled call holds this lock while it enqueues)
+    std::unique_lock<std::mutex> prof_lock;
+    if (e->profiling) prof_lock = std::unique_lock<std::mutex>(e->prof_mu);
     size_t ev_i = e->profiling ? e->n_timed : 0;
     long last_main = -1;  // index of the last event recorded on `stream` during this call
     auto record = [&](hipStream_t on) -> int {
@@ -671,6 +679,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     VerdictArgs v{};
     v.n = n;
     v.n_groups = n_groups;
+    v.force_global_tables = (P.flags & PWAF_OPT_GLOBAL_VERDICT_TABLES) ? 1u : 0u;
 #ifdef PWAF_PROFILING
     {
         static const uint32_t skip = getenv("PWAF_DEBUG_SKIP") ? (uint32_t)strtoul(getenv("PWAF_DEBUG_SKIP"), nullptr, 0) : 0u;
@@ -734,50 +743,69 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.counts = (unsigned long long *)d_counts;
     v.match_idx = d_match_idx;
     v.n_matches = d_n_matches;
-    // The attribute kernel (GeoIP / ip-list / integer-set lookups: ~1.2 GB of gathers per 10M requests) does not depend on the scans:
-    // it runs on the context's side stream and joins before the verdict kernel. WHERE it forks matters: beside the prefilter launch
-    // the two compete for the memory system (measured: the filter 0.76 -> 1.0 ms, the attribute kernel 0.44 -> 1.2 ms), so it forks
-    // AFTER the filter launches and runs beside resolve / compact / the list scans, which are short latency-bound kernels that leave
-    // most of the machine idle.
-    bool attr_launched = false;
-    auto launch_attr_side = [&]() -> int {
-        if (attr_launched) return PWAF_OK;
-        attr_launched = true;
-        int rc2;
-        hipStream_t side_q = S.side;
+    // The attribute path — ipres_kernel (address lookups: one scattered 16-byte gather per request, bound by the texture addresser) and
+    // attr_kernel (rows, transposes, comparisons: bound by vector-ALU issue) — does not depend on the scans. Placement (measured on
+    // MI355X, 10M requests; `PWAF_PLACEMENT` in profiling builds):
+    //   0  ipres on the side stream from the START of the batch (beside the prefilter: they are bound by different units), attr_kernel
+    //      on the main stream after the prefilter                                                              <- default
+    //   1  both on the main stream after the prefilter (every kernel alone)
+    //   2  both on the side stream, forked after the prefilter (round 2)      3  both on the side stream from the start
+    // Kernels that run beside each other take about as long as one after the other here (the step is the SUM of what its kernels
+    // cost alone, give or take 2 %), so the placement only matters where the two really use different units.
+    int placement = 0;
 #ifdef PWAF_PROFILING
-        static const bool attr_inline = getenv("PWAF_ATTR_INLINE") != nullptr;  // timing experiment: no side stream, every kernel runs alone
-        if (attr_inline) side_q = stream;
+    static const int forced_placement = getenv("PWAF_PLACEMENT") ? atoi(getenv("PWAF_PLACEMENT")) : (getenv("PWAF_ATTR_INLINE") ? 1 : getenv("PWAF_ATTR_EARLY") ? 3 : 0);
+    placement = forced_placement;
 #endif
-        HIP_TRY(hipEventRecord(S.ev_fork, stream));
-        HIP_TRY(hipStreamWaitEvent(side_q, S.ev_fork, 0));
-        if ((rc2 = mark(nullptr, 0, side_q))) return rc2;
-        {
-            int he = 0;
-#ifdef PWAF_PROFILING
-            static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
-            static const bool skip_ipres = getenv("PWAF_SKIP_IPRES") != nullptr;  // ... every address resolves to class 0 / set 0
-            if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, side_q));
-            if (skip_ipres) HIP_TRY(hipMemsetAsync(v.ipres, 0, (size_t)n * (v.ipres_packed ? 4 : 8), side_q));
-            if (!skip_attr && !skip_ipres) he = launch_ipres(v, side_q);
-            if (!he && (rc2 = mark("ipres", 0xFAu, side_q))) return rc2;
-            if (!he && (rc2 = mark(nullptr, 0, side_q))) return rc2;
-            if (!he && !skip_attr) he = launch_attr(v, side_q);
-#else
-            he = launch_ipres(v, side_q);
-            if (!he && (rc2 = mark("ipres", 0xFAu, side_q))) return rc2;
-            if (!he && (rc2 = mark(nullptr, 0, side_q))) return rc2;
-            if (!he) he = launch_attr(v, side_q);
-#endif
-            if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+    bool ipres_launched = false, attr_launched = false;
+    auto launch_ipres_stage = [&](hipStream_t q) -> int {
+        if (ipres_launched) return PWAF_OK;
+        ipres_launched = true;
+        int rc2, he = 0;
+        if (q != stream) {
+            HIP_TRY(hipEventRecord(S.ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(q, S.ev_fork, 0));
         }
-        if ((rc2 = mark("attr", 0xFEu, side_q))) return rc2;
-        HIP_TRY(hipEventRecord(S.ev_join, side_q));
+        if ((rc2 = mark(nullptr, 0, q != stream ? q : nullptr))) return rc2;
+#ifdef PWAF_PROFILING
+        static const bool skip_ipres = getenv("PWAF_SKIP_IPRES") != nullptr || getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every address resolves to class 0 / set 0
+        if (skip_ipres) HIP_TRY(hipMemsetAsync(v.ipres, 0, (size_t)n * (v.ipres_packed ? 4 : 8), q));
+        else
+#endif
+        he = launch_ipres(v, q);
+        if (he) return fail(PWAF_E_DEVICE, std::string("ipres kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc2 = mark("ipres", 0xFAu, q != stream ? q : nullptr))) return rc2;
+        if (q != stream) HIP_TRY(hipEventRecord(S.ev_join, q));
         return PWAF_OK;
     };
+    auto launch_attr_stage = [&](hipStream_t q) -> int {
+        if (attr_launched) return PWAF_OK;
+        attr_launched = true;
+        int rc2, he = 0;
+        if (q == stream && (placement == 0)) HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));  // the side stream's ipres results
+        if ((rc2 = mark(nullptr, 0, q != stream ? q : nullptr))) return rc2;
 #ifdef PWAF_PROFILING
-    if (getenv("PWAF_ATTR_EARLY") && (rc = launch_attr_side())) return rc;  // timing experiment: fork at the start of the batch
+        static const bool skip_attr = getenv("PWAF_SKIP_ATTR") != nullptr;  // timing experiments only: every non-scan predicate reads false
+        if (skip_attr) HIP_TRY(hipMemsetAsync(v.ghdr, 0, (size_t)n_groups * 4, q));
+        else
 #endif
+        he = launch_attr(v, q);
+        if (he) return fail(PWAF_E_DEVICE, std::string("attribute kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc2 = mark("attr", 0xFEu, q != stream ? q : nullptr))) return rc2;
+        if (q != stream) HIP_TRY(hipEventRecord(S.ev_join, q));
+        return PWAF_OK;
+    };
+    // batch start: what forks here
+    if (placement == 0 && (rc = launch_ipres_stage(S.side))) return rc;
+    if (placement == 3 && ((rc = launch_ipres_stage(S.side)) || (rc = launch_attr_stage(S.side)))) return rc;
+    // after the prefilter (or, without one, before the list scans)
+    auto launch_attr_side = [&]() -> int {
+        int rc2;
+        if (placement == 0) return launch_attr_stage(stream);
+        if (placement == 1) { if ((rc2 = launch_ipres_stage(stream))) return rc2; return launch_attr_stage(stream); }
+        if (placement == 2) { if ((rc2 = launch_ipres_stage(S.side))) return rc2; return launch_attr_stage(S.side); }
+        return PWAF_OK;
+    };
 
     static const char *fn[5] = {"host", "url", "path", "method", "user_agent"};
     auto scan_args = [&](size_t gi) -> ScanArgs {
@@ -811,7 +839,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.pool = (PoolEntry *)S.pool.p;
         a.pool_count = (uint32_t *)S.ctrl.p;
         a.pool_cap = pool_cap;
-        a.status = (uint32_t *)S.status.p;
+        a.status = status_word;
         return a;
     };
     // (the shape is per PHASE: the filtered passes' candidate lists are long, the gap passes' short)
@@ -862,7 +890,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.pool = (PoolEntry *)S.pool.p;
         a.pool_count = (uint32_t *)S.ctrl.p;
         a.pool_cap = pool_cap;
-        a.status = (uint32_t *)S.status.p;
+        a.status = status_word;
         a.n_cus = e->n_cus;
         return a;
     };
@@ -1042,7 +1070,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         fa.pool = (PoolEntry *)S.pool.p;
         fa.pool_count = (uint32_t *)S.ctrl.p;
         fa.pool_cap = pool_cap;
-        fa.status = (uint32_t *)S.status.p;
+        fa.status = status_word;
         if ((rc = mark(nullptr, 0))) return rc;
         int he = launch_fcmp(fa, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("field comparison kernel launch failed: ") + hipGetErrorString((hipError_t)he));
@@ -1075,13 +1103,13 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ra.pool = (PoolEntry *)S.pool.p;
         ra.pool_count = (uint32_t *)S.ctrl.p;
         ra.pool_cap = pool_cap;
-        ra.status = (uint32_t *)S.status.p;
+        ra.status = status_word;
         if ((rc = mark(nullptr, 0))) return rc;
         int he2 = launch_residual(ra, stream);
         if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
         if ((rc = mark("residual", 0xF9u))) return rc;
     }
-    HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));
+    if (placement >= 2) HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));  // (the attribute kernel ran on the side stream)
     if ((rc = mark(nullptr, 0))) return rc;
     int he = launch_verdict(v, stream);
     if (he) return fail(PWAF_E_DEVICE, std::string("verdict kernel launch failed: ") + hipGetErrorString((hipError_t)he));
@@ -1467,30 +1495,33 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         cnt.release();
         if (!ok) { fail(PWAF_E_DEVICE, "DIR-24 table build failed"); return dev_fail(PWAF_E_DEVICE); }
         // Compressed for the lookups (round 3): 10M uniformly random addresses against the flat 64 MiB table are 10M misses to HBM (the
-        // batch's own 3 GB of streaming flush every cache level in between), and a gather pays a whole 128-byte line per 4-byte entry.
-        // Consecutive /24s mostly share their entry (a /20 prefix covers 16 of them), so per /16 the 256 entries are stored as RUNS in
-        // ONE 128-byte line: a 256-bit bitmap of run starts, the run counts before each bitmap word, and up to kDirInlineRuns run
-        // values inline (a /16 with more runs keeps its values in dir_vals). 8 MiB for any table: L2 / Infinity-Cache resident, and a
-        // lookup is two loads from the same line.
+        // batch's own 3 GB of streaming flush every cache level in between). Consecutive /24s mostly share their entry (a /20 prefix
+        // covers 16 of them), so per /16 the 256 entries are stored as RUNS, 32 /24s per 16-byte record (8 records = one 128-byte line
+        // per /16): {bitmap of the /24s of this group where a run starts, the entry in force when the group begins, the entry of the
+        // first run that starts inside it, where the entries of further runs live in dir_vals}. One 16-byte gather answers every lookup
+        // whose /24 lies in the carried-in run or in the first run of its group (nearly all: ~12 runs per /16 over 8 groups); 8 MiB for
+        // any table: L2 / Infinity-Cache resident. (Measured: the lookup kernel is bound by the NUMBER of scattered load instructions —
+        // the texture addresser takes them one lane-address at a time — not by bytes or latency: four loads per lookup from one line
+        // took as long as four from different lines.)
         {
             std::vector<uint32_t> d24((size_t)1 << 24);
             if (hipMemcpy(d24.data(), e->dir24.p, d24.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(PWAF_E_DEVICE, "DIR-24 download failed"); return dev_fail(PWAF_E_DEVICE); }
             std::vector<uint32_t> chunks((size_t)65536 * kDirChunkWords, 0), vals;
             for (uint32_t x = 0; x < 65536; x++) {
                 const uint32_t *en = &d24[(size_t)x << 8];
-                uint32_t *ck = &chunks[(size_t)x * kDirChunkWords];
-                uint32_t pre[8] = {0}, runs[256], n_runs = 0;
-                for (uint32_t j = 0; j < 256; j++)
-                    if (j == 0 || en[j] != en[j - 1]) { ck[j >> 5] |= 1u << (j & 31); runs[n_runs++] = en[j]; }
-                for (uint32_t w = 1; w < 8; w++) pre[w] = pre[w - 1] + (uint32_t)__builtin_popcount(ck[w - 1]);
-                ck[8] = pre[0] | pre[1] << 8 | pre[2] << 16 | pre[3] << 24;
-                ck[9] = pre[4] | pre[5] << 8 | pre[6] << 16 | pre[7] << 24;
-                if (n_runs <= kDirInlineRuns) {
-                    ck[10] = 0xFFFFFFFFu;
-                    for (uint32_t k = 0; k < n_runs; k++) ck[11 + k] = runs[k];
-                } else {
-                    ck[10] = (uint32_t)vals.size();
-                    vals.insert(vals.end(), runs, runs + n_runs);
+                for (uint32_t w = 0; w < 8; w++) {
+                    uint32_t *rec = &chunks[(size_t)x * kDirChunkWords + 4 * w];
+                    uint32_t bm = 0, n_starts = 0;
+                    for (uint32_t j = 32 * w; j < 32 * w + 32; j++)
+                        if (j == 0 || en[j] != en[j - 1]) {
+                            bm |= 1u << (j & 31);
+                            if (n_starts == 1) rec[3] = (uint32_t)vals.size();
+                            if (n_starts == 0) rec[2] = en[j];
+                            else vals.push_back(en[j]);
+                            n_starts++;
+                        }
+                    rec[0] = bm;
+                    rec[1] = w ? en[32 * w - 1] : 0u;  // (group 0 always starts a run at its first /24)
                 }
             }
             if (vals.empty()) vals.push_back(0);
@@ -1575,18 +1606,18 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     auto run_checked = [&](const pwaf_batch &db, pwaf_verdict *d_out, pwaf_counts *d_counts, bool known, const std::vector<uint32_t> *begins = nullptr) -> int {
         for (int attempt = 0;; attempt++) {
             if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
-            int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins);
+            int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins, true);
             S.used = true;
             S.last = s;
             S.last_own = true;
             HIP_TRY(hipEventRecord(S.done, s));
             if (r) return r;
             uint32_t st[2] = {0, 0};
-            HIP_TRY(hipMemcpyAsync(&st[0], S.status.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&st[0], (uint32_t *)S.status.p + 1, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&st[1], S.ctrl.p, 4, hipMemcpyDeviceToHost, s));  // overflow entries the batch asked for
             HIP_TRY(hipStreamSynchronize(s));
             if (!st[0]) return PWAF_OK;
-            HIP_TRY(hipMemsetAsync(S.status.p, 0, 4, s));
+            HIP_TRY(hipMemsetAsync((uint32_t *)S.status.p + 1, 0, 4, s));
             if (attempt >= 2 || st[1] >= 0x7FFFFFF0u) return fail(PWAF_E_NOMEM, "scan overflow pool exhausted: verdicts of this batch are incomplete");
             S.pool_entries = (uint64_t)st[1] + st[1] / 4 + 1024;
         }
@@ -1958,6 +1989,7 @@ int pwaf_evaluate_one(pwaf_engine *e, const pwaf_request *r, pwaf_verdict *out) 
 int pwaf_engine_set_profiling(pwaf_engine *e, int on) {
     if (!e) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::mutex> plk(e->prof_mu);
     e->profiling = on != 0;
     e->times.clear();  // (re)starting a measurement window: kernel_times() reports every launch since this call
     e->time_ev.clear();

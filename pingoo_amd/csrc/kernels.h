@@ -10,7 +10,7 @@ static constexpr int kMaxPasses = 250;  // (= program.h kMaxGroups)
 static constexpr int kVerdictPre = 12;  // hit records per request the verdict kernel requests one group ahead
 static constexpr uint32_t kGapLists = 32;     // gated gap passes own list slots [0, 32) (one bit each in the factor masks); filtered passes follow
 static constexpr uint32_t kMaxHeaderLens = 8; // header columns whose LENGTH rules compare
-static constexpr uint32_t kDirChunkWords = 32, kDirInlineRuns = 21; // one 128-byte line per /16 of the compressed DIR-24 table (VerdictArgs::dir_chunks)
+static constexpr uint32_t kDirChunkWords = 32; // one 128-byte line per /16 of the compressed DIR-24 table (VerdictArgs::dir_chunks)
 
 // Hit record of one (scan pass, request): what the request's field matched in that pass's DFA.
 //   bit 31 = 0: bits [14:0] = first local atom + 1 (0 = none), bits [29:15] = second local atom + 1 (0 = none)
@@ -227,6 +227,7 @@ struct ShortAtom {
 struct VerdictArgs {
     uint32_t n, n_groups;
     uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
+    uint32_t force_global_tables;  // PWAF_OPT_GLOBAL_VERDICT_TABLES: the verdict kernel variant for programs whose tables do not fit LDS (same results)
     const uint32_t *off[PWAF_N_FIELDS];
     const uint8_t *ip;
     const uint8_t *ip_is_v6;
@@ -279,9 +280,9 @@ struct VerdictArgs {
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
     // (roots are never null on the device: a family without prefixes gets an all-leaf root. GeoIP trie leaves are CLASS ids.)
     const uint32_t *dir24;        // BUILD TIME ONLY (dir24_kernel's output): first 24 bits of both IPv4 tries flattened: class | set << 16, or DIR_ESCAPE | index into dir_esc
-    // ... compressed for the lookups: one 128-byte chunk per /16 (index = the address's top 16 bits) of kDirChunkWords words:
-    // [0, 8) 256-bit bitmap of the /24s where a run of equal entries starts, [8, 10) 8 x u8 runs before each bitmap word,
-    // [10] 0xFFFFFFFF = the run values are inline in [11, 11 + kDirInlineRuns), else the index of the first value in dir_vals.
+    // ... compressed for the lookups: one 128-byte chunk per /16 (index = the address's top 16 bits) = 8 records of 4 words, one per
+    // group of 32 /24s: {bitmap of the /24s where a run of equal entries starts, the entry in force when the group begins, the
+    // entry of the first run starting inside the group, index in dir_vals of the entries of the group's further runs}.
     // dir_chunks null = walk from the roots.
     const uint32_t *dir_chunks, *dir_vals;
     const uint2 *dir_esc;         // {geo trie entry, ip-list trie entry} of the escaped /24s
@@ -332,6 +333,7 @@ uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;
 };
-VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits);
+// force_global (PWAF_OPT_GLOBAL_VERDICT_TABLES): take the variant whose program tables stay in global memory even when they would fit LDS
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false);
 
 }  // namespace pwaf

@@ -1830,28 +1830,21 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
                 if (a.n_ip_lists) ei[u] = (v6[u] ? a.ip_root6 : a.ip_root4)[top16[u]];
             }
         }
-        uint32_t pre[U], bmw[U], ext[U];
+        uint4 rec4[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            pre[u] = bmw[u] = 0;
-            ext[u] = 0xFFFFFFFFu;
-            if (chunked[u]) {
-                const uint32_t *ck = a.dir_chunks + (size_t)top16[u] * kDirChunkWords;
-                const uint32_t w = ip_byte(ipw[u], 2) >> 5;
-                bmw[u] = ck[w];
-                pre[u] = w < 4 ? ck[8] : ck[9];
-                ext[u] = ck[10];
-            }
+            rec4[u] = make_uint4(0u, 0u, 0u, 0u);
+            // ONE 16-byte gather: the record of the address's group of 32 /24s
+            if (chunked[u]) rec4[u] = *reinterpret_cast<const uint4 *>(a.dir_chunks + (size_t)top16[u] * kDirChunkWords + 4u * (ip_byte(ipw[u], 2) >> 5));
         }
-        // phase 2: the run's value — the same line again (an L1 hit), or dir_vals for a /16 with many runs
+        // phase 2: the run's entry — carried into the group, the first run inside it, or (rarely) a further run from dir_vals
         uint32_t e24[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             e24[u] = 0;
             if (chunked[u]) {
-                const uint32_t b2 = ip_byte(ipw[u], 2), w = b2 >> 5;
-                const uint32_t rank = ((pre[u] >> ((w & 3u) * 8u)) & 0xFFu) + (uint32_t)__builtin_popcount(bmw[u] & (0xFFFFFFFFu >> (31u - (b2 & 31u))));  // run starts at or before the /24
-                e24[u] = ext[u] == 0xFFFFFFFFu ? a.dir_chunks[(size_t)top16[u] * kDirChunkWords + 10u + rank] : a.dir_vals[ext[u] + rank - 1u];
+                const uint32_t rank = (uint32_t)__builtin_popcount(rec4[u].x & (0xFFFFFFFFu >> (31u - (ip_byte(ipw[u], 2) & 31u))));  // run starts at or before the /24, inside its group
+                e24[u] = rank == 0 ? rec4[u].y : rank == 1 ? rec4[u].z : a.dir_vals[rec4[u].w + rank - 2u];
             }
         }
         // phase 4: escapes (a prefix longer than /24, or an id too large for the packed entry: rare)
@@ -2190,11 +2183,10 @@ int launch_attr(const VerdictArgs &a, void *stream) {
 // Workgroup shape of the verdict kernel: as many waves as LDS (160 KiB) holds column files for, next to one copy of the program
 // tables; if the tables do not leave room for at least 4 column files they stay in global memory (LT = false).
 static constexpr uint32_t kLdsPerGroup = 160u * 1024u;
-VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits) {
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global) {
     VerdictShape s{};
     const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
     const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
-    static const bool force_global = getenv("PWAF_FORCE_GLOBAL_TABLES") != nullptr;  // testing knob: exercises the LT = false variant (same results)
     const bool fits = !force_global && n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
     s.lds_tables = fits ? 1 : 0;
     const uint32_t tables = fits ? t_lds : t_glb;
@@ -2206,7 +2198,7 @@ VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, u
 }
 
 int launch_verdict(const VerdictArgs &a, void *stream) {
-    const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits);
+    const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0);
     if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
     constexpr int kBRmax = (kMaxPasses + 1 + 63) / 64;
     int variant = a.n_passes <= 64 ? 1 : 0;

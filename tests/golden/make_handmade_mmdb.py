@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Assembles tests/golden/handmade_v4.mmdb BYTE BY BYTE from the public MaxMind DB File Format Specification v2.0
+(https://maxmind.github.io/MaxMind-DB/), independently of tests/mmdb_writer.py (the repo's own writer, which the reader was so far
+only checked against — VERDICT r2 #8b). Every field below cites the section of the spec it follows. Nothing is computed by a helper
+that knows the format: the file is a literal concatenation of hand-written byte strings; only the three data-pointer record values are
+derived from the offsets written next to them.
+
+The tree (IPv4, record_size 24, 3 nodes = 18 bytes):
+    node 0: bit 0 = 0 -> node 1            bit 0 = 1 -> data A   (128.0.0.0/1)
+    node 1: bits 00   -> "no data"         bits 01   -> node 2
+    node 2: bits 010  -> data B (64.0.0.0/3)   bits 011 -> data C (96.0.0.0/3)
+Records as the reference deserialises them (pingoo/geoip.rs:17-23, serde_utils.rs:1-9): {"asn": "AS<digits>", "country": "<2 letters>"}.
+    A = {"asn": "AS64500", "country": "FR"}    B = {"asn": "AS15169", "country": "US"}    C = {"asn": "AS1", "country": "xx"} (country fails
+    CountryCode validation, geoip.rs:128-142: the request path falls back to {0, "XX"}, http_listener.rs:148-156)
+"""
+import os
+
+NODE_COUNT = 3
+
+# ---- "Output Data Section": each field = control byte (type << 5 | size) + payload. map = type 7, UTF-8 string = type 2. ----
+REC_A = (b"\xE2"                      # map (7 << 5) with 2 entries
+         b"\x43asn" b"\x47AS64500"    # string(3) "asn" -> string(7) "AS64500"
+         b"\x47country" b"\x42FR")    # string(7) "country" -> string(2) "FR"
+REC_B = b"\xE2" b"\x43asn" b"\x47AS15169" b"\x47country" b"\x42US"
+REC_C = b"\xE2" b"\x43asn" b"\x43AS1" b"\x47country" b"\x42xx"
+OFF_A, OFF_B, OFF_C = 0, len(REC_A), len(REC_A) + len(REC_B)  # offsets inside the data section
+assert (OFF_A, OFF_B, OFF_C) == (0, 24, 48)
+DATA = REC_A + REC_B + REC_C
+
+
+def rec24(value: int) -> bytes:
+    """"Binary Search Tree Section", 24-bit records: three bytes, big endian."""
+    return bytes([(value >> 16) & 0xFF, (value >> 8) & 0xFF, value & 0xFF])
+
+
+# a record value > node_count points into the data section: value = node_count + 16 + offset ("Data Section Separator": the 16 is
+# the separator's size, so that offset 0 is the first byte after it)
+PTR_A, PTR_B, PTR_C = NODE_COUNT + 16 + OFF_A, NODE_COUNT + 16 + OFF_B, NODE_COUNT + 16 + OFF_C
+NO_DATA = NODE_COUNT  # a record equal to node_count = "no data for this network"
+TREE = (rec24(1) + rec24(PTR_A)          # node 0
+        + rec24(NO_DATA) + rec24(2)      # node 1
+        + rec24(PTR_B) + rec24(PTR_C))   # node 2
+assert len(TREE) == NODE_COUNT * 6
+
+SEPARATOR = b"\x00" * 16  # "Data Section Separator": 16 zero bytes between the search tree and the data section
+
+# ---- "Database Metadata": the marker, then ONE map; keys are strings, values typed. uint16 = type 5, uint32 = type 6, uint64 = type 9
+#      (extended: control byte type 0, next byte = type - 7), array = type 11 (extended), map = type 7. ----
+META = (b"\xAB\xCD\xEFMaxMind.com"
+        b"\xE9"                                                  # map with 9 entries
+        b"\x5Bbinary_format_major_version" b"\xA1\x02"           # string(27) -> uint16 (5 << 5 | 1 byte) = 2
+        b"\x5Bbinary_format_minor_version" b"\xA0"               # uint16 with 0 bytes = 0
+        b"\x4Bbuild_epoch" b"\x04\x02\x65\x00\x00\x00"           # string(11) -> uint64: control 0x04 (type 0 = extended, 4 bytes), 0x02 (9 - 7), value 0x65000000
+        b"\x4Ddatabase_type" b"\x4Bpingoo-test"                  # string(13) -> string(11)
+        b"\x4Bdescription" b"\xE1" b"\x42en" b"\x48handmade"     # string(11) -> map(1) {"en": "handmade"}
+        b"\x4Aip_version" b"\xA1\x04"                            # string(10) -> uint16 = 4
+        b"\x49languages" b"\x01\x04" b"\x42en"                   # string(9) -> array: control 0x01 (extended, size 1), 0x04 (11 - 7), ["en"]
+        b"\x4Anode_count" b"\xC1\x03"                            # string(10) -> uint32 (6 << 5 | 1 byte) = 3
+        b"\x4Brecord_size" b"\xA1\x18")                          # string(11) -> uint16 = 24
+
+MMDB = TREE + SEPARATOR + DATA + META
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "handmade_v4.mmdb")
+    with open(out, "wb") as f:
+        f.write(MMDB)
+    print(out, len(MMDB), "bytes")

@@ -73,7 +73,7 @@ def test_prefixes_longer_than_24_bits_and_ipv6_depth():
 
 
 def test_verdict_kernel_with_program_tables_in_global_memory():
-    """The LT = false variant (programs whose tables do not fit LDS) on the fuzz cases, in a subprocess with the testing knob set."""
+    """The LT = false variant (programs whose tables do not fit LDS) on the fuzz cases, through PWAF_OPT_GLOBAL_VERDICT_TABLES."""
     code = """
 import random, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -90,7 +90,7 @@ for seed in range(12):
     for k in range(rng.randint(3, 14)):
         e = H.rexpr(rng, lists)
         rules.append((f"r{k}", e, H.fuzz_actions(rng)))
-    eng = RuleEngine(rules, lists, geo, flags=_abi.OPT_LENIENT)
+    eng = RuleEngine(rules, lists, geo, flags=_abi.OPT_LENIENT | _abi.OPT_GLOBAL_VERDICT_TABLES)
     rules, _ = H.as_the_engine_sees(rules, eng.program)
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 500, seed %% 3 == 0))
     want = pyoracle.Oracle(rules, lists, geo).evaluate(batch)
@@ -100,7 +100,7 @@ for seed in range(12):
     eng.close()
 print("GLOBAL-TABLES-OK")
 """ % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, PWAF_FORCE_GLOBAL_TABLES="1")
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GLOBAL-TABLES-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
