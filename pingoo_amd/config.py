@@ -66,9 +66,14 @@ def load_list(path: str, type_: str) -> Tuple[int, List[str]]:
     return LIST_TYPES[type_], parse_list_csv(content)
 
 
-def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optional[str] = None):
+def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optional[str] = None, folder_order: str = "sorted"):
     """-> (rules, lists): rules = [(name, expression | None, [action, ...])] in evaluation order (config file first, then the
-    rules folder), lists = {name: (type, items)}."""
+    rules folder), lists = {name: (type, items)}.
+
+    folder_order: "sorted" (default: file names in sorted order) or "read_dir" (whatever order the OS lists the folder in — what the
+    reference does, pingoo/config/config.rs:383-404). First match wins makes the order of rule FILES part of the policy: when more
+    than one file of the folder defines rules a warning says which order was taken, so that a deployment whose behaviour depended on
+    its directory order notices the switch."""
     try:
         with open(config_file, "rb") as f:
             raw = yaml.safe_load(f) or {}
@@ -83,9 +88,13 @@ def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optio
     if os.path.isdir(folder):
         # The reference visits the folder in read_dir order (config.rs:383-404), which the OS does not define; first match wins makes
         # that order meaningful, so files are taken in sorted name order here — name them so that sorted order is the intended one.
-        for entry in sorted(os.listdir(folder)):
-            if not entry.endswith(".yml"):
-                continue
+        if folder_order not in ("sorted", "read_dir"):
+            raise ConfigError(f"folder_order must be 'sorted' or 'read_dir', not {folder_order!r}")
+        entries = [x for x in os.listdir(folder) if x.endswith(".yml")]  # (os.listdir = the directory's own order, like read_dir)
+        if folder_order == "sorted":
+            entries.sort()
+        files_with_rules = []
+        for entry in entries:
             p = os.path.join(folder, entry)
             try:
                 with open(p, "rb") as f:
@@ -97,6 +106,14 @@ def load_rule_config(config_file: str = DEFAULT_CONFIG_FILE, rules_folder: Optio
                 if r[0] in seen:
                     raise ConfigError(f"duplicate rule name: {r[0]}")
             from_folder.extend(more)
+            if more:
+                files_with_rules.append(entry)
+        if len(files_with_rules) > 1:
+            import warnings
+
+            warnings.warn(f"rules folder {folder!r}: {len(files_with_rules)} files define rules; they are evaluated in {folder_order} order "
+                          f"({', '.join(files_with_rules)}). The reference takes read_dir order (config.rs:383-404), which the OS does not define: "
+                          "pass folder_order='read_dir' to keep that, or name the files so that sorted order is the intended one.", stacklevel=2)
     names = {r[0] for r in rules}
     for r in from_folder:
         if r[0] in names:

@@ -746,15 +746,17 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     // The attribute path — ipres_kernel (address lookups: one scattered 16-byte gather per request, bound by the texture addresser) and
     // attr_kernel (rows, transposes, comparisons: bound by vector-ALU issue) — does not depend on the scans. Placement (measured on
     // MI355X, 10M requests; `PWAF_PLACEMENT` in profiling builds):
-    //   0  ipres on the side stream from the START of the batch (beside the prefilter: they are bound by different units), attr_kernel
-    //      on the main stream after the prefilter                                                              <- default
-    //   1  both on the main stream after the prefilter (every kernel alone)
-    //   2  both on the side stream, forked after the prefilter (round 2)      3  both on the side stream from the start
+    //   0  ipres on the side stream from the START of the batch, attr_kernel on the main stream after the prefilter    1.838 ms / step
+    //   1  both on the main stream after the prefilter (every kernel alone)                                              1.861
+    //   2  both on the side stream, forked after the prefilter                                        <- default          1.779
+    //   3  both on the side stream from the start                                                                         1.762
+    // 3 is 1 % faster than 2 but slows the prefilter launch itself from 0.73 to 0.95 ms (0 to 0.86): the streaming kernel is what the
+    // roofline is quoted on, so it runs undisturbed.
     // Kernels that run beside each other take about as long as one after the other here (the step is the SUM of what its kernels
     // cost alone, give or take 2 %), so the placement only matters where the two really use different units.
-    int placement = 0;
+    int placement = 2;
 #ifdef PWAF_PROFILING
-    static const int forced_placement = getenv("PWAF_PLACEMENT") ? atoi(getenv("PWAF_PLACEMENT")) : (getenv("PWAF_ATTR_INLINE") ? 1 : getenv("PWAF_ATTR_EARLY") ? 3 : 0);
+    static const int forced_placement = getenv("PWAF_PLACEMENT") ? atoi(getenv("PWAF_PLACEMENT")) : (getenv("PWAF_ATTR_INLINE") ? 1 : getenv("PWAF_ATTR_EARLY") ? 3 : 2);
     placement = forced_placement;
 #endif
     bool ipres_launched = false, attr_launched = false;

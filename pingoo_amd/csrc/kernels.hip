@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t 
     if (t < b.count) {
         const ListScanArgs *pa = &b.g[t];
         const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
-        items = (n_l + threads - 1) / threads;
+        items = (n_l + threads - 1) / threads;  // (`threads` = entries per work item: the workgroup's lanes x kListWalks)
     }
     part[t] = items;
     __syncthreads();
@@ -545,89 +545,145 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
         const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
         for (; it < it_end; it++) {
-            const uint32_t i = (it - first) * THREADS + threadIdx.x;
-            bool live = i < n_l;
-            if (live && a.need_in != nullptr) live = ((a.need_in[i] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
-            const uint32_t r = live ? (a.req_list != nullptr ? a.req_list[i] : i) : 0u;
-            if (live && a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31));
-            uint32_t p = live ? a.off[r] : 0u;
-            const uint32_t end = live ? a.off[r + 1] : 0u;
-            uint32_t state = 0;
-            Hits h{0, 0, kNone};
-            if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
+            // TWO listed requests per lane, walked in lockstep (kListWalks): the chains of dependent LDS reads interleave, and — what
+            // matters on hostile traffic, where near misses of the rule literals drive most walks deep into states that are not
+            // LDS-resident — a lane's two cold cells travel to L2 together. (One walk per lane: 3.9 ms for the filtered passes of the
+            // 1k-rule set on the adversarial stream, nearly all of it waiting for one cold cell per step and wave.)
+            uint32_t li[kListWalks], r[kListWalks], p[kListWalks], end[kListWalks], state[kListWalks];
+            bool live[kListWalks];
+            Hits h[kListWalks];
+            u32x4 w[kListWalks];
+#pragma unroll
+            for (uint32_t u = 0; u < kListWalks; u++) {
+                li[u] = ((it - first) * kListWalks + u) * THREADS + threadIdx.x;
+                live[u] = li[u] < n_l;
+                if (live[u] && a.need_in != nullptr) live[u] = ((a.need_in[li[u]] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
+                r[u] = live[u] ? (a.req_list != nullptr ? a.req_list[li[u]] : li[u]) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kListWalks; u++) {
+                if (live[u] && a.visited != nullptr) atomicOr(&a.visited[r[u] >> 5], 1u << (r[u] & 31));
+                p[u] = live[u] ? a.off[r[u]] : 0u;
+                end[u] = live[u] ? a.off[r[u] + 1] : 0u;
+                state[u] = 0;
+                h[u] = Hits{0, 0, kNone};
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kListWalks; u++) {
+                if (live[u] && a.emit_off[1] != a.emit_off[0]) h[u] = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h[u]);
+                w[u] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p[u]);
+            }
             // what entering state `st` emits rides in its row: a single atom that is already in the record, or fits a free slot, is
             // settled in registers (no memory access at all for a hot row)
-            auto record_emit = [&](const uint32_t st) {
+            auto record_emit = [&](const uint32_t st, Hits &hh) {
                 const uint32_t ei = st * stride + ncls;
                 const uint32_t code = ei < hot_elems ? (uint32_t)hot[ei] : (uint32_t)flat[ei];
                 const uint32_t x = (code & 0x7FFFu) + 1u;
-                bool slow = !(code & 0x8000u) || h.ovf != kNone;
+                bool slow = !(code & 0x8000u) || hh.ovf != kNone;
                 if (!slow) {
-                    if (h.a0 == x || h.a1 == x) {}
-                    else if (h.a0 == 0) h.a0 = x;
-                    else if (h.a1 == 0) h.a1 = x;
+                    if (hh.a0 == x || hh.a1 == x) {}
+                    else if (hh.a0 == 0) hh.a0 = x;
+                    else if (hh.a1 == 0) hh.a1 = x;
                     else slow = true;
                 }
-                if (slow) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, h);
+                if (slow) hh = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, hh);
             };
-            // The walk's critical path is ONE lane: the longest candidate of the list (every workgroup of a benign batch fits the chip
-            // at once, so the kernel lasts as long as its slowest wave). Per byte that path is now mad -> min -> ds_read -> and, in
-            // groups of four steps checked once: a step into a cold row reads the sentinel (and stays there for the rest of the group),
-            // a step into an emitting state carries bit 15; bytes past the field's end take the STAY cell, so no step is conditional.
-            // Only a group that met a cold cell is re-walked step by step; emits are recorded after the group, off the chain. The next
-            // 16-byte window is in flight while this one is walked. (Round 2: ~25 instructions and three branches per byte, and a full
-            // global round trip per window on the critical path.)
-            u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
-            while (p < end) {
-                const uint32_t pn = p + 16u;
-                const u32x4 wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end ? pn : 0u));
-                const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
-                const uint32_t cnt = min(16u, end - p);
-                uint32_t c[16];
+            // Per byte the walk is mad -> min -> ds_read -> and, in groups of four steps checked once: a step into a cold row reads the
+            // sentinel (and stays there for the rest of the group), a step into an emitting state carries bit 15; bytes past the field's
+            // end take the STAY cell, so no step is conditional. Only a group that met a cold cell is re-walked step by step (both walks
+            // of the lane together: their L2 loads are issued back to back); emits are recorded after the group, off the chain. The next
+            // 16-byte window of each walk is in flight while this one is walked. (Round 2: ~25 instructions and three branches per byte,
+            // and a full global round trip per window on the critical path.)
+            for (;;) {
+                bool more = false;
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) {
-                    const uint32_t cl = cls[(wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-                    c[k] = k < cnt ? cl : ncls + 1u;
+                for (uint32_t u = 0; u < kListWalks; u++) more = more || p[u] < end[u];
+                if (!more) break;
+                u32x4 wn[kListWalks];
+                uint32_t cnt[kListWalks];
+#pragma unroll
+                for (uint32_t u = 0; u < kListWalks; u++) {
+                    const uint32_t pn = p[u] + 16u;
+                    wn[u] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end[u] ? pn : 0u));
+                    cnt[u] = p[u] < end[u] ? min(16u, end[u] - p[u]) : 0u;
                 }
 #pragma unroll
                 for (uint32_t k0 = 0; k0 < 16; k0 += 4) {
-                    const uint32_t t1 = hot[min(state * stride + c[k0], hot_elems)], s1 = t1 & 0x7FFFu;
-                    const uint32_t t2 = hot[min(s1 * stride + c[k0 + 1], hot_elems)], s2 = t2 & 0x7FFFu;
-                    const uint32_t t3 = hot[min(s2 * stride + c[k0 + 2], hot_elems)], s3 = t3 & 0x7FFFu;
-                    const uint32_t t4 = hot[min(s3 * stride + c[k0 + 3], hot_elems)], s4 = t4 & 0x7FFFu;
-                    if ((t1 | t2 | t3 | t4) & 0x8000u) {
-                        if (max(max(t1, t2), max(t3, t4)) == 0xFFFFu) {
-                            // a cold cell: the group step by step, cold cells from the L2-resident table
+                    uint32_t c[kListWalks][4], t[kListWalks][4], sv[kListWalks][4];
+#pragma unroll
+                    for (uint32_t u = 0; u < kListWalks; u++) {
+                        const uint32_t wd = k0 == 0 ? w[u].x : k0 == 4 ? w[u].y : k0 == 8 ? w[u].z : w[u].w;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t cl = cls[(wd >> (k * 8)) & 0xFFu];
+                            c[u][k] = k0 + k < cnt[u] ? cl : ncls + 1u;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+#pragma unroll
+                        for (uint32_t u = 0; u < kListWalks; u++) {
+                            t[u][k] = hot[min((k == 0 ? state[u] : sv[u][k - 1]) * stride + c[u][k], hot_elems)];
+                            sv[u][k] = t[u][k] & 0x7FFFu;
+                        }
+                    }
+                    uint32_t any = 0, top = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < kListWalks; u++)
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) { any |= t[u][k]; top = max(top, t[u][k]); }
+                    if (any & 0x8000u) {
+                        if (top == 0xFFFFu) {
+                            // a cold cell: the group step by step for both walks, cold cells from the L2-resident table
 #pragma unroll
                             for (uint32_t k = 0; k < 4; k++) {
-                                const uint32_t idx = state * stride + c[k0 + k];
-                                const uint32_t t = idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx];
-                                state = t & 0x7FFFu;
-                                if (t & 0x8000u) record_emit(state);
+                                uint32_t idx[kListWalks], tg[kListWalks], tl[kListWalks];
+#pragma unroll
+                                for (uint32_t u = 0; u < kListWalks; u++) {
+                                    idx[u] = state[u] * stride + c[u][k];
+                                    tg[u] = 0;
+                                    if (idx[u] >= hot_elems) tg[u] = flat[idx[u]];
+                                    tl[u] = hot[min(idx[u], hot_elems)];
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < kListWalks; u++) {
+                                    const uint32_t tt = idx[u] < hot_elems ? tl[u] : tg[u];
+                                    state[u] = tt & 0x7FFFu;
+                                    if (tt & 0x8000u) record_emit(state[u], h[u]);
+                                }
                             }
                         } else {
-                            if (t1 & 0x8000u) record_emit(s1);
-                            if (t2 & 0x8000u) record_emit(s2);
-                            if (t3 & 0x8000u) record_emit(s3);
-                            if (t4 & 0x8000u) record_emit(s4);
-                            state = s4;
+#pragma unroll
+                            for (uint32_t u = 0; u < kListWalks; u++) {
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; k++)
+                                    if (t[u][k] & 0x8000u) record_emit(sv[u][k], h[u]);
+                                state[u] = sv[u][3];
+                            }
                         }
                     } else {
-                        state = s4;
+#pragma unroll
+                        for (uint32_t u = 0; u < kListWalks; u++) state[u] = sv[u][3];
                     }
                 }
-                p = pn;
-                w = wn;
+#pragma unroll
+                for (uint32_t u = 0; u < kListWalks; u++) {
+                    if (p[u] < end[u]) p[u] += 16u;
+                    w[u] = wn[u];
+                }
             }
-            if (!live) continue;
-            if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
-            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-            if (a.colmask_local != nullptr) {
-                uint32_t need = 0;
-                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
-                if (a.need_out != nullptr) a.need_out[i] = need;
-                need &= ~a.shared_bits;
-                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+#pragma unroll
+            for (uint32_t u = 0; u < kListWalks; u++) {
+                if (!live[u]) continue;
+                if (a.end_off[state[u] + 1] != a.end_off[state[u]]) h[u] = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state[u], h[u]);
+                a.rec[r[u]] = h[u].ovf != kNone ? (REC_OVERFLOW | h[u].ovf) : (h[u].a0 | (h[u].a1 << 15));
+                if (a.colmask_local != nullptr) {
+                    uint32_t need = 0;
+                    if ((h[u].a0 | (h[u].ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h[u]);
+                    if (a.need_out != nullptr) a.need_out[li[u]] = need;
+                    need &= ~a.shared_bits;
+                    if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r[u], need);
+                }
             }
         }
     }
@@ -693,12 +749,12 @@ int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanAr
     if (count == 0 || host[0].n == 0) return 0;
     if (count > 256) return (int)hipErrorInvalidValue;
     GatedTable b{dev, count};
-    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, shape.threads);
+    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, shape.threads * kListWalks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     // persistent grid: what the chip holds at this LDS size (the work items are split evenly over it), never more than the items
     // a full batch could produce
-    const uint64_t max_items = (uint64_t)count * ((host[0].n + shape.threads - 1) / shape.threads);
+    const uint64_t max_items = (uint64_t)count * ((host[0].n + shape.threads * kListWalks - 1) / (shape.threads * kListWalks));
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, host[0].n_cus) * shape.wg_per_cu);
     const uint32_t *cplan = plan;
     uint32_t hot_bytes = shape.hot_bytes;

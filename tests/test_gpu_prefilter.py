@@ -209,3 +209,42 @@ def test_hot_prefix_factor_of_gated_gap_passes_after_tuning():
     eng.tune(RequestBatch.from_requests(reqs(2000)))
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "gated gap passes, tuned on traffic where the factor is hot")
     eng.close()
+
+
+def test_config5_per_gpu_share_properties_at_6_25M():
+    """BASELINE.json configs[4] at the size one GPU gets of it (50M requests over 8 GPUs = 6.25M per batch; 4096 rules over 5 + 64 string
+    columns): too big for the oracle to check in seconds, so the size-independent properties of test_full_size_config2_properties:
+    (1) a 3000-request slab checked bit-exactly against the oracle, (2) counters == histogram of the verdict array, (3) evaluating
+    slabs separately (cut at non-aligned points) equals evaluating the whole, (4) tuning changes no verdict."""
+    import torch
+    from pingoo_amd.engine import DeviceBatch
+    from synth import pysynth
+
+    w = pysynth.Workload(5)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    n = 6_250_000
+    batch = w.batch(0, n, threads=64)
+    db = DeviceBatch(batch)
+    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    out = eng.evaluate_device(db, counts=counts)
+    eng.device_status()
+    got = out.cpu().numpy().view(np.uint32)
+    assert counts.cpu().tolist() == np.bincount(got[:, 0], minlength=4).tolist() and int(counts.sum()) == n
+    frac = counts.cpu().numpy() / n
+    assert 0.85 < frac[0] < 0.99 and frac[1] > 0.01, frac
+    rng = np.random.default_rng(11)
+    lo = int(rng.integers(0, n - 3000))
+    sub = batch.slice(lo, lo + 3000)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(sub, threads=16)
+    assert (got[lo:lo + 3000, 0] == want["action"]).all() and (got[lo:lo + 3000, 1] == want["rule_idx"]).all()
+    cuts = [0, 2_000_001, 2_000_001 + 64 * 5000 + 13, n]
+    for a, b in zip(cuts, cuts[1:]):
+        part = eng.evaluate_device(DeviceBatch(batch.slice(a, b)))
+        eng.device_status()
+        p = part.cpu().numpy().view(np.uint32)
+        assert (p == got[a:b]).all(), (a, b)
+    eng.tune(w.batch(n, 32768, threads=64))
+    out2 = eng.evaluate_device(db)
+    eng.device_status()
+    assert (out2.cpu().numpy().view(np.uint32) == got).all()
+    eng.close()

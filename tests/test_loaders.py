@@ -150,8 +150,15 @@ rules:
     (tmp_path / "rules" / "20-all.yml").write_text("everything:\n  actions:\n    - action: captcha\n")
     (tmp_path / "rules" / "notes.txt").write_text("ignored: not a .yml file")
     # (the reference always reads /etc/pingoo/rules, config.rs:381: the folder next to a relocated config file is passed explicitly)
-    rules, lists = config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
+    with pytest.warns(UserWarning, match="2 files define rules.*sorted order"):  # first match wins: the order of rule FILES is policy
+        rules, lists = config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"))
     assert [r[0] for r in rules] == ["block_listed", "telnet", "admin", "everything"]
+    # the reference's own order (read_dir, config.rs:383-404) on request: same rules, in whatever order the OS lists the folder
+    with pytest.warns(UserWarning, match="read_dir order"):
+        rd, _ = config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "rules"), folder_order="read_dir")
+    assert [r[0] for r in rd][:2] == ["block_listed", "telnet"] and sorted(r[0] for r in rd[2:]) == ["admin", "everything"]
+    want_rd = [x for x in os.listdir(tmp_path / "rules") if x.endswith(".yml")]
+    assert [r[0] for r in rd[2:]] == [{"10-admin.yml": "admin", "20-all.yml": "everything"}[x] for x in want_rd]
     assert [r[0] for r in config.load_rule_config(str(tmp_path / "pingoo.yml"), str(tmp_path / "nowhere"))[0]] == ["block_listed", "telnet"]
     assert rules[1][2] == [_abi.RULE_ACTION_CAPTCHA, B] and rules[3][1] is None
     assert lists == {"blocked_ips": (_abi.LIST_IP, ["10.0.0.0/8", "192.168.1.7", "2001:db8::/32"]), "bad_ports": (_abi.LIST_INT, ["23", "2323"])}
