@@ -72,7 +72,7 @@ struct ScanArgs {
 //   emits (0, 0x8000 | the single local atom, or 1 = a list), cell n_classes + 1 = the state itself (the STAY cell: the "transition"
 //   of a lane past its field's end); emit / end lists are indexed by (renumbered) state.
 static constexpr uint32_t kListThreads = 512;
-static constexpr uint32_t kListWalks = 2;      // listed requests a lane walks in lockstep
+static constexpr uint32_t kListWalks = 1;      // listed requests a lane walks in lockstep (2 was measured: see lscan_kernel)
 static constexpr uint32_t kListHotBytes = 48 * 1024;  // 3 workgroups (24 waves) per CU
 struct ListScanArgs {
     const uint8_t *data;

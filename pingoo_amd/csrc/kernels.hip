@@ -545,10 +545,12 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
         const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
         for (; it < it_end; it++) {
-            // TWO listed requests per lane, walked in lockstep (kListWalks): the chains of dependent LDS reads interleave, and — what
-            // matters on hostile traffic, where near misses of the rule literals drive most walks deep into states that are not
-            // LDS-resident — a lane's two cold cells travel to L2 together. (One walk per lane: 3.9 ms for the filtered passes of the
-            // 1k-rule set on the adversarial stream, nearly all of it waiting for one cold cell per step and wave.)
+            // kListWalks listed requests per lane, walked in lockstep. Measured with 2 (round 3), in the hope that a lane's two cold cells
+            // travelling to L2 together would help hostile traffic (near misses of the rule literals drive most walks deep into states
+            // that are not LDS-resident): adversarial filtered passes 3.87 -> 3.41 ms, but benign 0.143 -> 0.204 ms and the gap
+            // passes 0.087 -> 0.117 (adversarial 0.24 -> 0.49): a single wave issues an instruction every few cycles at best, so two
+            // interleaved chains cost a step twice the issue slots while the list's longest walk — the kernel's critical path on
+            // benign traffic — gets no shorter. One walk per lane and as many waves as the LDS copy allows is the better trade.
             uint32_t li[kListWalks], r[kListWalks], p[kListWalks], end[kListWalks], state[kListWalks];
             bool live[kListWalks];
             Hits h[kListWalks];
