@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         if (!(dbg_skip & 2u)) {
             for (uint32_t p = lane; p < n_pairs; p += 64) {
                 const uint4 pr = p < 64 ? pair0 : pairs[p];
-                atomicOr(&col[pr.x], ((unsigned long long)pr.w << 32) | pr.z);
+                col[pr.x] = ((unsigned long long)pr.w << 32) | pr.z;  // (one pair per atom and group, and no scan pass owns these columns: a plain store)
                 atomicOr(&colnz[pr.x >> 5], 1u << (pr.x & 31));
             }
         }
