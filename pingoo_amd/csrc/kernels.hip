@@ -2256,8 +2256,12 @@ VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, u
 }
 
 int launch_verdict(const VerdictArgs &a, void *stream) {
-    const VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0);
+    VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0);
     if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
+#ifdef PWAF_PROFILING
+    static const uint32_t cap_waves = getenv("PWAF_VERDICT_WAVES") ? (uint32_t)atoi(getenv("PWAF_VERDICT_WAVES")) : 0u;  // timing experiment: fewer waves per CU (same results)
+    if (cap_waves && cap_waves < sh.waves) sh.waves = cap_waves;
+#endif
     constexpr int kBRmax = (kMaxPasses + 1 + 63) / 64;
     int variant = a.n_passes <= 64 ? 1 : 0;
 #ifdef PWAF_PROFILING
