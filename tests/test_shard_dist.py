@@ -81,3 +81,22 @@ def test_two_rank_gloo_counter_allreduce_matches_single_process():
     assert [a + b for a, b in zip(res[0][3], res[1][3])] == want
     assert res[0][4] == want and res[1][4] == want
     assert want[0] > 0 and sum(want[1:]) > 0
+
+
+def test_bench_self_launch_becomes_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` started plainly re-executes itself under torch.distributed.run on 127.0.0.1 (the driver's own
+    command line, so that both ways of starting it run the same N ranks)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(bench.os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv))
+    bench.self_launch(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4)
+    argv = seen["argv"]
+    assert seen["exe"] == sys.executable and argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
+    script = argv.index(os.path.abspath(bench.__file__))
+    assert argv[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
