@@ -980,30 +980,27 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
         }
-        // descriptor tables in device memory: [all passes] [stride-1 passes, first_block numbered] [stride-2 passes]
+        // descriptor tables in device memory: [all passes] [stride-1 passes, first_block numbered] [stride-2 passes, numbered from 0 again]
         const uint32_t nf = (uint32_t)fall.size();
         if ((rc = S.args_filter.reserve((size_t)3 * nf * sizeof(FilterArgs)))) return rc;
         FilterArgs *d_all = (FilterArgs *)S.args_filter.p;
         int he = upload_filter_args(fall.data(), nf, d_all, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-        FilterArgs *d_at = d_all + nf;
-        for (uint32_t stride = 1; stride <= 2; stride++) {
-            std::vector<FilterArgs> sub;
-            uint32_t block = 0;
-            for (const FilterArgs &f : fall) {
-                if (f.stride != stride) continue;
-                sub.push_back(f);
-                sub.back().first_block = block;
-                block += ((uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0 + kFilterWaves - 1) / kFilterWaves;
-            }
-            if (sub.empty()) continue;
-            if ((he = upload_filter_args(sub.data(), (uint32_t)sub.size(), d_at, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc = mark(nullptr, 0))) return rc;
-            he = launch_filter(sub.data(), (uint32_t)sub.size(), d_at, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-            if ((rc = mark(stride == 1 ? "filter_s1" : "filter_s2", alg_bytes[stride]))) return rc;  // algorithmic bytes: every streamed arena once + its offsets
-            d_at += sub.size();
+        std::vector<FilterArgs> by_stride[2];
+        for (const FilterArgs &f : fall) {
+            std::vector<FilterArgs> &sub = by_stride[f.stride == 2 ? 1 : 0];
+            const uint32_t block = sub.empty() ? 0u : sub.back().first_block + ((uint32_t)(((uint64_t)sub.back().total + kStreamSlab - 1) / kStreamSlab) - sub.back().slab0 + kFilterWaves - 1) / kFilterWaves;
+            sub.push_back(f);
+            sub.back().first_block = block;
         }
+        FilterArgs *d_s1 = d_all + nf, *d_s2 = d_s1 + by_stride[0].size();
+        if (!by_stride[0].empty() && (he = upload_filter_args(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+        if (!by_stride[1].empty() && (he = upload_filter_args(by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc = mark(nullptr, 0))) return rc;
+        he = launch_filter(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        // algorithmic bytes: every streamed arena once + its offsets. The mark's name tells the bench which strides the launch mixed.
+        if ((rc = mark(by_stride[1].empty() ? "filter_s1" : by_stride[0].empty() ? "filter_s2" : "filter_mix", alg_bytes[1] + alg_bytes[2]))) return rc;
 #ifdef PWAF_PROFILING
         static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
         if (!attr_after_compact)
@@ -1792,14 +1789,12 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             for (uint32_t i = 0; i < n; i++) c += flagged(f, sc, i) ? 1u : 0u;
             return (double)c / (double)n;
         };
-        // Stride 2 halves the table lookups per byte. A pass may take it when its factors stay selective with two to four sampled
-        // bigrams per alignment: at most two points more of the sample flagged than at stride 1 (a candidate costs about ten times
-        // a filtered byte), never above 25 %. But the passes of each stride are one launch, and on long arenas the stride-2 kernel
-        // streams no faster per byte than stride 1 (measured on MI355X: both ~3.2 TB/s — the bound they share is not the lookup),
-        // while short header columns do gain: it is taken only when the passes that may take it hold most of the filtered bytes,
-        // so that the launch is not split in two for nothing. PWAF_OPT_FILTER_STRIDE2 takes it wherever it can be built.
+        // Stride 2 halves the table lookups per byte: a stride-1 pass is bound by them (LDS), a stride-2 pass by HBM. A pass takes it
+        // when its factors stay selective with two to four sampled bigrams per alignment: at most two points more of the sample
+        // flagged than at stride 1 (a candidate costs about ten times a filtered byte), never above 25 %. Every pass decides for
+        // itself: both strides run in ONE launch with their workgroups interleaved (kernels.hip: filter_kernel).
+        // PWAF_OPT_FILTER_STRIDE2 takes it wherever it can be built.
         std::vector<GroupFilter> alt(P.groups.size());
-        double bytes_all = 0, bytes_alt = 0;
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];
             FilterHints h;
@@ -1813,29 +1808,29 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             build_group_filter(P.atoms, g, &h, gf, 1);
             if (!gf.enabled) continue;
             gf.est_candidate_rate = sample_rate(gf, sc);
-            bytes_all += mean_len[g.field];
             GroupFilter &g2 = alt[k];
             build_group_filter(P.atoms, g, &h, g2, 2);
 #ifdef PWAF_PROFILING
             static const long s2_mask = getenv("PWAF_STRIDE2_FIELDS") ? strtol(getenv("PWAF_STRIDE2_FIELDS"), nullptr, 0) : -1;  // timing experiments: fields that may take stride 2
             if (!((s2_mask >> g.field) & 1)) g2.enabled = false;
 #endif
+#ifdef PWAF_PROFILING
+            if (getenv("PWAF_TUNE_DEBUG") && !g2.enabled) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample, %zu heads; stride 2 not built: %s\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.note.c_str());
+#endif
             if (!g2.enabled) continue;
             g2.est_candidate_rate = sample_rate(g2, sc);
+#ifdef PWAF_PROFILING
+            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads), stride 2 %.4f (%zu heads), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.est_candidate_rate, g2.heads.size(), mean_len[g.field]);
+#endif
             const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
             g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);
-            if (g2.enabled) bytes_alt += mean_len[g.field];
         }
-        bool take_alt = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0 || bytes_alt >= 0.8 * bytes_all;
-#ifdef PWAF_PROFILING
-        if (getenv("PWAF_STRIDE2_FIELDS")) take_alt = true;
-#endif
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];
             GroupFilter &gf = T.filters[k];
             const pwaf_strcol *sc = sample_col(g.field);
             if (!sc || !gf.enabled) continue;
-            if (take_alt && alt[k].enabled) gf = alt[k];
+            if (alt[k].enabled) gf = alt[k];
             const uint8_t *data = sc->data;
             const uint32_t *off = sc->offsets;
             if (gf.est_candidate_rate > 0.4) {

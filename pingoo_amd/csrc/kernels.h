@@ -110,17 +110,18 @@ struct ListScanArgs {
 
 // ---- bigram prefilter (program.h: GroupFilter) ------------------------------------------------------------------------------
 // The shift-or state only remembers the last four bigrams, so a field's arena is processed as ONE flat byte stream: a wave takes a
-// slab of kStreamSlab consecutive bytes and walks it kStreamIter bytes per iteration — every lane its own aligned 64-byte segment
-// (plus three warm-up bigrams from the bytes before it) — with no per-request logic at all in the loop: loads are perfectly
-// coalesced (every line is fetched exactly once; the per-request-lane version fetched 2x the arena because 7 MB of half-consumed
-// lines per XCD thrashed L2), no lane ever idles, and a window that straddles a request boundary can only ADD a candidate.
+// slab of kStreamSlab consecutive bytes and walks it kStreamIter bytes per iteration — four rows of 1 KiB, every lane one 16-byte
+// chunk of each row, the state a chunk starts from handed over by its neighbour lane (kernels.hip: filter_rows) — with no
+// per-request logic at all in the loop: every load instruction is one contiguous KiB (every line is fetched exactly once; the
+// per-request-lane version fetched 2x the arena because 7 MB of half-consumed lines per XCD thrashed L2), no lane ever idles,
+// and a window that straddles a request boundary can only ADD a candidate.
 //   filter_kernel   per (segment, 16-byte chunk) a hit bit; non-zero segments are appended to the slab's own region of `sub`
 //                   (wave-private counter: no atomics). Heads (anchored literals) are compared at request starts, which the wave
 //                   finds by walking the offsets column alongside the bytes.
 //   resolve_kernel  hit segments -> requests (binary search in the offsets), one bit per request in `bitmap`.
 //   bitcount_kernel / compact_kernel   bitmap -> dense ascending request list + its length for the confirming lscan_kernel.
 static constexpr uint32_t kStreamSlab = 128 * 1024;   // bytes per wave
-static constexpr uint32_t kStreamSeg = 64;            // bytes per lane and iteration
+static constexpr uint32_t kStreamSeg = 64;            // bytes per hit record (a segment = four 16-byte chunks = one nibble of chunk bits)
 static constexpr uint32_t kStreamIter = 64 * kStreamSeg;
 static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup
 static constexpr uint32_t kMaxFiltersPerLaunch = 8;
@@ -161,9 +162,14 @@ struct FilterTable {
     const FilterArgs *f;  // device
     uint32_t count;
 };
+struct FilterMix {  // the fused filter launch: the stride-1 passes and the stride-2 passes, each class with first_block numbered from 0
+    const FilterArgs *f1, *f2;  // device
+    uint32_t count1, count2, blocks1, blocks2;
+};
 int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, void *stream);
-// `host` = the same `count` descriptors as `dev` (launch geometry). launch_filter: all of one stride, first_block numbered by the caller.
-int launch_filter(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);
+// `host` = the same `count` descriptors as `dev` (launch geometry). launch_filter: ONE launch, the passes of stride 1 and of stride 2
+// as two tables (either may be empty), first_block numbered within each by the caller.
+int launch_filter(const FilterArgs *host1, uint32_t count1, const FilterArgs *dev1, const FilterArgs *host2, uint32_t count2, const FilterArgs *dev2, void *stream);
 int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);
 int launch_compact(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream);  // bitcount_kernel, then compact_kernel
 // Sets the dynamic-LDS limit of every kernel on the CURRENT device (once per device and process; engines on several

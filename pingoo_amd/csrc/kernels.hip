@@ -191,6 +191,11 @@ __device__ __forceinline__ void enqueue_gated(const uint32_t *colmask_local, con
 // A pass descriptor read from the device-resident table into SCALAR registers (the address is wave-uniform; through a plain
 // reference every use inside the hot loops became a reload from memory — the compiler must assume the kernel's own stores alias it —
 // and the filter launch went from 0.74 to 0.85 ms).
+// The wave's index in its workgroup, as a value the compiler KNOWS to be wave-uniform (threadIdx.x >> 6 is, but is not provably so:
+// everything derived from it — slab and group numbers, loop bounds, base addresses — would be computed per lane in vector registers
+// and every branch on it would be an exec-mask branch).
+__device__ __forceinline__ uint32_t wave_index() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <class T>
 __device__ __forceinline__ T load_descriptor(const T *p) {
     static_assert(sizeof(T) % 4 == 0, "descriptor size");
@@ -228,7 +233,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
     const PWAF_GLOBAL unsigned char *gtab = (const PWAF_GLOBAL unsigned char *)a.tab;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint32_t *goff = (const PWAF_GLOBAL uint32_t *)a.off;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
 
     // stage the hot rows, the sentinel row and the byte-class map into LDS (coalesced 16 B per lane)
     for (uint32_t i = tid * 16; i < tab_bytes; i += kScanThreads * 16) {
@@ -790,17 +795,24 @@ ListShape list_shape(uint32_t variant) {
 // Hash of a position = 12 bits of the 16-bit product fold(pair) * mul (program.h: filter_bin): two positions per v_pk_mul_lo_u16.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-struct Segment {
-    u32x4 w[4];
-    uint32_t prev, extra;  // extra: the dword after the segment (STRIDE 1) or the one before `prev` (STRIDE 2)
-};
-
 // STRIDE = 1: a bigram at every byte. STRIDE = 2: only at the even bytes of the arena stream (FilterArgs::stride, chosen per pass
 // by the host: half the lookups; every factor is in the table once per alignment).
+// The stream is laid out in ROWS: one iteration = 4 rows of 1 KiB, lane l of row q holds the 16-byte chunk at b + 1024 q + 16 l.
+// Every load instruction is one contiguous KiB (round 2 gave every lane its own 64-byte segment: 64 lines per load instruction and
+// two more scattered dword loads per lane for the bytes around the segment — the texture addresser, not LDS, bounded that kernel:
+// 0.73 ms against 0.68 on the 10M-request batch, and stride 2 was no faster than stride 1); what a chunk needs from its
+// neighbours travels through the wave instead of memory:
+//   * the byte after the chunk (second half of its last bigram) = the first dword of lane l + 1's chunk (DPP wave_shl:1; lane 63:
+//     lane 0 of the next row, a scalar),
+//   * the shift-or state it starts from = what the three last bigrams of lane l - 1's chunk leave behind, which that lane computes
+//     from its OWN lookups (two v_lshl_or_b32 — the state forgets everything older than four bigrams) and hands on (DPP
+//     wave_shr:1; lane 0: lane 63 of the previous row, a scalar carried from row to row and iteration to iteration) —
+//     no warm-up lookups at all.
+// A row's registers are reloaded with the NEXT iteration's row as soon as its lookups are issued: 16 data registers instead of 36.
 template <bool HEADS, int STRIDE>
-__device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_t blk, const uint32_t wave, const uint32_t lane) {
+__device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t blk, const uint32_t wave, const uint32_t lane) {
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const uint32_t rel = blk * kFilterWaves + wave, slab = a.slab0 + rel;  // rel: index into the pass's sub-lists
+    const uint32_t rel = blk * kFilterWaves + wave, slab = a.slab0 + rel;
     const uint64_t base64 = (uint64_t)slab * kStreamSlab;
     if (base64 >= a.total) return;
     const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
@@ -808,27 +820,57 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
     uint32_t *my_sub = a.sub + (size_t)rel * (kStreamSlab / kStreamSeg);
     uint32_t n_hit = 0;  // wave-uniform
     const uint32_t mul2 = a.mul | (a.mul << 16);
+    constexpr uint32_t kRow = 1024;
 
-    // Segment of lane `lane` in the iteration that starts at byte b: [b + 64 * lane, + 64). A chunk is fetched only if it begins
-    // inside the arena (a fetch then ends at most 15 bytes past it: PWAF_ARENA_PAD); everything else reads the arena's first bytes.
-    auto load_seg = [&](const uint32_t b, Segment &sg) {
-        const uint32_t p = b + lane * kStreamSeg;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t at = p + 16u * q < total ? p + 16u * q : 0u;
-            sg.w[q] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + at);
-        }
-        sg.prev = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p >= 4 && p < total) ? p - 4 : 0u));
-        if (STRIDE == 2) sg.extra = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p >= 8 && p < total) ? p - 8 : 0u));
-        else sg.extra = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + ((p + kStreamSeg + 4 <= total + PWAF_ARENA_PAD) ? p + kStreamSeg : 0u));
+    auto load_row = [&](const uint32_t b, const uint32_t q) {
+        const uint32_t p = b + kRow * q + 16u * lane;
+        return *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (p < total ? p : 0u));
     };
+    auto dword_at = [&](const uint32_t p) {  // (wave-uniform address)
+        return *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + p) & 0xDFDFDFDFu;
+    };
+    // LDS byte offset of a bin = (16-bit product >> 4) * 4, for the two products of one v_pk_mul_lo_u16: ONE mask for both halves,
+    // then one SDWA shift per half (v_lshrrev_b32 reading WORD_0 / WORD_1 zero-extended) — three instructions per two lookups where
+    // a shift and a mask per lookup took four (a quarter of the loop's vector instructions).
+    auto slot_lo = [](const uint32_t masked) {
+        uint32_t r;
+        asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(masked));
+        return r;
+    };
+    auto slot_hi = [](const uint32_t masked) {
+        uint32_t r;
+        asm("v_lshrrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(masked));
+        return r;
+    };
+    auto bins4 = [&](const uint32_t x, const uint32_t next, uint32_t (&mm)[4]) {  // the four bigrams that start in (case-folded) dword x
+        const uint32_t z = __builtin_amdgcn_alignbit(next, x, 8);
+        const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
+        const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
+#ifdef PWAF_PROFILING
+        if (a.debug & 1u) { mm[0] = hx | 0xFF000000u; mm[1] = hz | 0xFF000000u; mm[2] = (hx >> 3) | 0xFF000000u; mm[3] = (hz >> 5) | 0xFF000000u; return; }
+#endif
+        const uint32_t kx = hx & 0xFFF0FFF0u, kz = hz & 0xFFF0FFF0u;
+        mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_lo(kx));
+        mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_lo(kz));
+        mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_hi(kx));
+        mm[3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_hi(kz));
+    };
+    auto bins2 = [&](const uint32_t x, uint32_t (&mm)[2]) {  // the two bigrams at the even bytes of (case-folded) dword x
+        const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
+#ifdef PWAF_PROFILING
+        if (a.debug & 1u) { mm[0] = hx | 0xFF000000u; mm[1] = (hx >> 3) | 0xFF000000u; return; }
+#endif
+        const uint32_t kx = hx & 0xFFF0FFF0u;
+        mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_lo(kx));
+        mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)slot_hi(kx));
+    };
+    auto push = [](uint32_t &st, const uint32_t m) { asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m)); };
 
     // heads: the wave walks the offsets column alongside the bytes; rq = first request that starts at or after the current byte.
     // Software-pipelined so that nothing on this path waits for memory: the offsets of the next 128 requests are requested one
     // iteration ahead; the first 16 bytes of the requests that start inside the current iteration (bytes this wave has just
-    // streamed: cache hits) are requested BEFORE the next iteration's segment loads, so that waiting for them (loads complete in
-    // order) does not wait for those; the compares run after the lookups. (The first version — a loop of dependent loads per
-    // iteration behind the segment prefetch — cost 0.20 ms of a 0.88 ms launch.)
+    // streamed: cache hits) are requested BEFORE the rows are looked up and compared after them. (The first version — a loop of
+    // dependent loads per iteration — cost 0.20 ms of a 0.88 ms launch.)
     uint32_t rq = 0, ho[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, hn[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     auto load_offs = [&](const uint32_t r0) {
 #pragma unroll
@@ -852,7 +894,7 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
         }
         return hrec;
     };
-    const bool heads = HEADS && a.n_heads != 0;  // (a fused launch has passes with and without heads)
+    const bool heads = HEADS && a.n_heads != 0;
     if (heads) {
         uint32_t lo = 0, hi = a.n;  // lower bound of base0 in off[0, n)
         while (lo < hi) {
@@ -864,12 +906,31 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
         load_offs(rq);
     }
 
-    Segment cur, nxt;
-    load_seg(base0, cur);
+    // the state the slab's first chunk starts from: the three sampled bigrams before the slab (none at the very start of the arena)
+    uint32_t carry = a.init;  // wave-uniform
+    if (STRIDE == 1) {
+        if (base0 >= 4) {
+            uint32_t mw[4];
+            bins4(dword_at(base0 - 4), dword_at(base0), mw);
+            push(carry, mw[1]); push(carry, mw[2]); push(carry, mw[3]);
+        }
+    } else if (base0 >= 8) {
+        uint32_t m0[2], m1[2];
+        bins2(dword_at(base0 - 8), m0);
+        bins2(dword_at(base0 - 4), m1);
+        push(carry, m0[1]); push(carry, m1[0]); push(carry, m1[1]);
+    }
+    carry = __builtin_amdgcn_readfirstlane(carry);
+    // the dword after the slab (second byte of the slab's last bigram)
+    const uint32_t after = (STRIDE == 1 && slab_end < total) ? __builtin_amdgcn_readfirstlane(dword_at(slab_end)) : 0u;
+
+    u32x4 w[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) w[q] = load_row(base0, q);
     for (uint32_t b = base0; b < slab_end; b += kStreamIter) {
-        // heads, first half: the requests that start inside this iteration's bytes (up to 128 through the pipelined path)
+        const bool more = b + kStreamIter < slab_end;  // wave-uniform
         u32x4 hw[2];
-        uint32_t hlen[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // field length, or "none"
+        uint32_t hlen[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         uint32_t rq_here = rq;
 #ifdef PWAF_PROFILING
         if (heads && !(a.debug & 4u)) {
@@ -879,16 +940,18 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
             const uint32_t lim = min(b + kStreamIter, slab_end);
             const bool in0 = ho[0] < lim;
             const uint32_t c0 = (uint32_t)__builtin_popcountll(__ballot(in0));
-            const bool in1 = c0 == 64 && ho[1] < lim;
-            const uint32_t c1 = (uint32_t)__builtin_popcountll(__ballot(in1));
             hw[0] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (in0 ? ho[0] : 0u));
-            hw[1] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (in1 ? ho[1] : 0u));
             if (in0) hlen[0] = hn[0] - ho[0];
-            if (in1) hlen[1] = hn[1] - ho[1];
+            uint32_t c1 = 0;
+            if (c0 == 64) {  // (wave-uniform: the second gather is issued only when more than 64 requests start in these 4 KiB)
+                const bool in1 = ho[1] < lim;
+                c1 = (uint32_t)__builtin_popcountll(__ballot(in1));
+                hw[1] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (in1 ? ho[1] : 0u));
+                if (in1) hlen[1] = hn[1] - ho[1];
+            }
             rq += c0 + c1;
             if (c0 + c1 == 128) {
-                // more than 128 requests start within 4 KiB (very short fields): the rest synchronously
-                for (;;) {
+                for (;;) {  // more than 128 requests start within 4 KiB (very short fields): the rest synchronously
                     const uint32_t idx = rq + lane;
                     const uint32_t s = idx < a.n ? a.off[idx] : 0xFFFFFFFFu;
                     const bool in = s < lim;
@@ -903,106 +966,65 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
             }
             load_offs(rq);  // for the next iteration
         }
-#ifdef PWAF_PROFILING
-        if (a.debug & 2u) nxt = cur;
-        else
-#endif
-        load_seg(b + kStreamIter < slab_end ? b + kStreamIter : b, nxt);  // next iteration's bytes are in flight while these are looked up
-        const uint32_t p = b + lane * kStreamSeg;
 
-        // the segment's 16 dwords between the dword before it (warm-up) and the dword after it (the last bigram's second byte)
-        uint32_t d[18];
-        d[0] = cur.prev & 0xDFDFDFDFu;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            d[1 + 4 * q + 0] = cur.w[q].x & 0xDFDFDFDFu;
-            d[1 + 4 * q + 1] = cur.w[q].y & 0xDFDFDFDFu;
-            d[1 + 4 * q + 2] = cur.w[q].z & 0xDFDFDFDFu;
-            d[1 + 4 * q + 3] = cur.w[q].w & 0xDFDFDFDFu;
-        }
-        d[17] = STRIDE == 2 ? 0u : cur.extra & 0xDFDFDFDFu;
-        auto lookups = [&](const int i, uint32_t (&mm)[4]) {  // the four bigrams that start in dword i (the last one ends in dword i + 1)
-            const uint32_t x = d[i], z = __builtin_amdgcn_alignbit(d[i + 1], x, 8);
-            const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
-            const uint32_t hz = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, z) * __builtin_bit_cast(u16x2, mul2));
-            // byte offset of a bin = (16-bit product >> 4) * 4
-#ifdef PWAF_PROFILING
-            if (a.debug & 1u) { mm[0] = hx | 0xFF000000u; mm[1] = hz | 0xFF000000u; mm[2] = (hx >> 3) | 0xFF000000u; mm[3] = (hz >> 5) | 0xFF000000u; return; }
-#endif
-            mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
-            mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 2) & 0x3FFCu));
-            mm[2] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
-            mm[3] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hz >> 18) & 0x3FFCu));
-        };
-        auto lookups2 = [&](const uint32_t x, uint32_t (&mm)[2]) {  // the two bigrams at the even bytes of (case-folded) dword x
-            const uint32_t hx = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, mul2));
-            mm[0] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 2) & 0x3FFCu));
-            mm[1] = *reinterpret_cast<lds_u32_ptr>((uintptr_t)((hx >> 18) & 0x3FFCu));
-        };
-        // three warm-up bigrams from the bytes before the segment (none at the very start of the arena), then the segment's positions,
-        // one 16-byte chunk at a time (the scheduling barriers keep at most one chunk's lookups live: without them the compiler
-        // hoists all 67 and the kernel drops to 4 waves per SIMD)
-        uint32_t st = a.init;
-        if (STRIDE == 1) {
-            uint32_t mw[4];
-            lookups(0, mw);
-            if (p >= 4) {
-#pragma unroll
-                for (int i = 1; i < 4; i++) asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(mw[i]));
-            }
-        } else {
-            uint32_t m0[2], m1[2];
-            lookups2(cur.extra & 0xDFDFDFDFu, m0);  // bytes p - 8 .. p - 5: its second bigram (p - 6) is the oldest of the three
-            lookups2(d[0], m1);                     // bytes p - 4 .. p - 1
-            if (p >= 8) {
-                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m0[1]));
-                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m1[0]));
-                asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m1[1]));
-            }
-        }
-        uint32_t hmask = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t seen = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t x0 = w[q].x & 0xDFDFDFDFu, x1 = w[q].y & 0xDFDFDFDFu, x2 = w[q].z & 0xDFDFDFDFu, x3 = w[q].w & 0xDFDFDFDFu;
+            uint32_t st, seen = 0xFFFFFFFFu, tail;
             if (STRIDE == 1) {
+                // lane 63's next dword: lane 0 of the next row (row 0 already holds the NEXT iteration's chunk; the slab's last row: `after`)
+                const uint32_t first_next = (q == 3 && !more) ? after : (__builtin_amdgcn_readfirstlane(w[(q + 1) & 3].x) & 0xDFDFDFDFu);
+                const uint32_t x4 = (uint32_t)__builtin_amdgcn_update_dpp((int)first_next, (int)x0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
                 uint32_t m[16];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
+                {
                     uint32_t mm[4];
-                    lookups(1 + 4 * q + i, mm);
-                    m[4 * i + 0] = mm[0]; m[4 * i + 1] = mm[1]; m[4 * i + 2] = mm[2]; m[4 * i + 3] = mm[3];
+                    bins4(x0, x1, mm); m[0] = mm[0]; m[1] = mm[1]; m[2] = mm[2]; m[3] = mm[3];
+                    bins4(x1, x2, mm); m[4] = mm[0]; m[5] = mm[1]; m[6] = mm[2]; m[7] = mm[3];
+                    bins4(x2, x3, mm); m[8] = mm[0]; m[9] = mm[1]; m[10] = mm[2]; m[11] = mm[3];
+                    bins4(x3, x4, mm); m[12] = mm[0]; m[13] = mm[1]; m[14] = mm[2]; m[15] = mm[3];
                 }
+#ifdef PWAF_PROFILING
+                if (more && !(a.debug & 2u)) w[q] = load_row(b + kStreamIter, q);
+#else
+                if (more) w[q] = load_row(b + kStreamIter, q);
+#endif
+                tail = m[13]; push(tail, m[14]); push(tail, m[15]);
+                st = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)tail, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    // st = (st << 8) | m as ONE v_lshl_or_b32 (left to itself the compiler re-associates the chain into shift + or)
-                    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
-                    seen &= st;
-                }
+                for (int i = 0; i < 16; i++) { push(st, m[i]); seen &= st; }
             } else {
                 uint32_t m[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
+                {
                     uint32_t mm[2];
-                    lookups2(d[1 + 4 * q + i], mm);
-                    m[2 * i + 0] = mm[0]; m[2 * i + 1] = mm[1];
+                    bins2(x0, mm); m[0] = mm[0]; m[1] = mm[1];
+                    bins2(x1, mm); m[2] = mm[0]; m[3] = mm[1];
+                    bins2(x2, mm); m[4] = mm[0]; m[5] = mm[1];
+                    bins2(x3, mm); m[6] = mm[0]; m[7] = mm[1];
                 }
+#ifdef PWAF_PROFILING
+                if (more && !(a.debug & 2u)) w[q] = load_row(b + kStreamIter, q);
+#else
+                if (more) w[q] = load_row(b + kStreamIter, q);
+#endif
+                tail = m[5]; push(tail, m[6]); push(tail, m[7]);
+                st = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)tail, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(st) : "v"(st), "v"(m[i]));
-                    seen &= st;
-                }
+                for (int i = 0; i < 8; i++) { push(st, m[i]); seen &= st; }
             }
-            if (((~seen) & 0xFF000000u) != 0 && p + 16u * (uint32_t)q < total) hmask |= 1u << q;
+            carry = __builtin_amdgcn_readlane(tail, 63);
+            const bool hit = ((~seen) & 0xFF000000u) != 0 && b + kRow * q + 16u * lane < total;
+            const unsigned long long hm = __ballot(hit);
+            if (hm != 0) {
+                // a record = one 64-byte segment (four consecutive chunks = four consecutive lanes of the row) with its chunk mask
+                const uint32_t nib = lane < 16 ? (uint32_t)(hm >> (4u * lane)) & 15u : 0u;
+                const unsigned long long rm = __ballot(nib != 0);
+                if (nib != 0) my_sub[n_hit + (uint32_t)__builtin_popcountll(rm & lt_mask)] = (((b - base0) / kStreamSeg + 16u * q + lane) << 4) | nib;
+                n_hit += (uint32_t)__builtin_popcountll(rm);
+            }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        const unsigned long long hm = __ballot(hmask != 0);
-        if (hm != 0) {
-            if (hmask != 0) my_sub[n_hit + (uint32_t)__builtin_popcountll(hm & lt_mask)] = ((((b - base0) / kStreamSeg) + lane) << 4) | hmask;
-            n_hit += (uint32_t)__builtin_popcountll(hm);
         }
 
         if (heads) {
-            // heads, second half: compare the head literals against the first 16 bytes requested above and record the heads that hold
 #pragma unroll
             for (uint32_t q = 0; q < 2; q++) {
                 if (hlen[q] != 0xFFFFFFFFu) {
@@ -1011,31 +1033,36 @@ __device__ __forceinline__ void filter_stream(const FilterArgs &a, const uint32_
                 }
             }
         }
-        cur = nxt;
     }
     if (lane == 0) a.sub_count[rel] = n_hit;
 }
 
-// (One kernel per stride: both bodies behind a branch in one kernel cost 65 VGPRs — 7 waves per SIMD — against 63 and 54 apart.)
-template <bool HEADS, int STRIDE>
-__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterTable B) {
+// ONE launch for every filtered pass, both strides: stride-1 passes are bound by the LDS lookups, stride-2 passes by HBM, so their
+// workgroups are INTERLEAVED in proportion (block i is the floor(i * n1 / N)-th stride-1 block if that count steps at i, else the
+// next stride-2 block) and every CU holds both kinds at any time — one launch per stride ran them one after the other, each
+// phase leaving the other resource idle.
+template <bool HEADS>
+__global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterMix M) {
     extern __shared__ __align__(16) unsigned char lds[];
     __builtin_amdgcn_s_setprio(3);
-    // which pass of the fused launch this workgroup belongs to (uniform: the last pass whose first_block is <= blockIdx.x)
+    const uint32_t n_all = M.blocks1 + M.blocks2;
+    const uint32_t before = (uint32_t)(((uint64_t)blockIdx.x * M.blocks1) / n_all), upto = (uint32_t)(((uint64_t)(blockIdx.x + 1) * M.blocks1) / n_all);
+    const bool one = upto > before;  // a stride-1 block
+    const uint32_t blk = one ? before : blockIdx.x - before;
+    const FilterArgs *tab = one ? M.f1 : M.f2;
+    // which pass of its class this workgroup belongs to (uniform: the last pass whose first_block is <= blk)
     uint32_t k = 0;
-    for (uint32_t lo = 0, hi = B.count; lo + 1 < hi;) {
+    for (uint32_t lo = 0, hi = one ? M.count1 : M.count2; lo + 1 < hi;) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (blockIdx.x >= B.f[mid].first_block) lo = mid;
+        if (blk >= tab[mid].first_block) lo = mid;
         else hi = mid;
         k = lo;
     }
-    const FilterArgs a = load_descriptor(&B.f[k]);
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const FilterArgs a = load_descriptor(&tab[k]);
+    const uint32_t tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
     // (Bank-private replicas of the table — 4 copies, each lane group of 8 with 8 banks of its own — were measured SLOWER: 1.19 ms
     // against 0.89 ms. A ds_read_b32 takes as many cycles as its most loaded bank over all 32 lanes, and the maximum over four
     // groups of 8-in-8 is hardly below 32-in-32, while 64 KiB per workgroup halves the occupancy.)
-    // (Starting every wave at a different iteration of its slab — in case waves advancing in step from offset 0 of their 128 KiB
-    // slabs camp on a few HBM channels — changed nothing: 0.868 against 0.874 ms.)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -1044,7 +1071,8 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterTable B
     __syncthreads();
     // (no static LDS in this kernel: the table starts at LDS address 0 and lookups use plain integer addresses)
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lds != 0u) __builtin_trap();
-    filter_stream<HEADS, STRIDE>(a, blockIdx.x - a.first_block, wave, lane);
+    if (one) filter_rows<HEADS, 1>(a, blk - a.first_block, wave, lane);
+    else filter_rows<HEADS, 2>(a, blk - a.first_block, wave, lane);
 }
 
 __global__ void resolve_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
@@ -1070,21 +1098,24 @@ __global__ __launch_bounds__(256) void bitcount_kernel(FilterTable B) {
 
 __global__ void compact_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
 
-int launch_filter(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream) {
-    // one fused launch for the passes of one sampling stride (first_block numbered by the caller)
+static uint32_t filter_blocks(const FilterArgs *host, uint32_t count, bool *heads) {
     uint32_t blocks = 0;
-    bool heads = false;
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t slabs = (uint32_t)(((uint64_t)host[k].total + kStreamSlab - 1) / kStreamSlab) - host[k].slab0;
         blocks += (slabs + kFilterWaves - 1) / kFilterWaves;
-        heads = heads || host[k].n_heads != 0;
+        *heads = *heads || host[k].n_heads != 0;
     }
-    if (blocks == 0) return 0;
-    FilterTable t{dev, count};
-    void *args[] = {&t};
-    const void *fn = host[0].stride == 2 ? (heads ? reinterpret_cast<const void *>(filter_kernel<true, 2>) : reinterpret_cast<const void *>(filter_kernel<false, 2>))
-                                         : (heads ? reinterpret_cast<const void *>(filter_kernel<true, 1>) : reinterpret_cast<const void *>(filter_kernel<false, 1>));
-    hipError_t e = hipLaunchKernel(fn, dim3(blocks), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
+    return blocks;
+}
+
+int launch_filter(const FilterArgs *host1, uint32_t count1, const FilterArgs *dev1, const FilterArgs *host2, uint32_t count2, const FilterArgs *dev2, void *stream) {
+    // the passes of each stride, first_block numbered within their class by the caller
+    bool heads = false;
+    FilterMix m{dev1, dev2, count1, count2, filter_blocks(host1, count1, &heads), filter_blocks(host2, count2, &heads)};
+    if (m.blocks1 + m.blocks2 == 0) return 0;
+    void *args[] = {&m};
+    const void *fn = heads ? reinterpret_cast<const void *>(filter_kernel<true>) : reinterpret_cast<const void *>(filter_kernel<false>);
+    hipError_t e = hipLaunchKernel(fn, dim3(m.blocks1 + m.blocks2), dim3(kFilterWaves * 64), args, kFilterEntries * 4, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -1250,7 +1281,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     const FilterArgs *pa = &B.f[blockIdx.y];
     if ((uint64_t)(pa->slab0 + blockIdx.x * 4) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
     const FilterArgs a = load_descriptor(pa);
-    const uint32_t wave = threadIdx.x >> 6, rel = blockIdx.x * 4 + wave, slab = a.slab0 + rel, lane = threadIdx.x & 63;
+    const uint32_t wave = wave_index(), rel = blockIdx.x * 4 + wave, slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];
     if (cnt == 0) return;
@@ -1351,7 +1382,7 @@ __global__ __launch_bounds__(256) void compact_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t red[256];
     const FilterArgs a = load_descriptor(&B.f[blockIdx.y]);
-    const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t words = (a.n + 31) / 32, w0 = blockIdx.x * kCompactWords, tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
     if (w0 >= words) return;
     const uint32_t n_blocks = (words + kCompactWords - 1) / kCompactWords;
     uint32_t acc = 0;
@@ -1422,7 +1453,7 @@ __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, 
 template <bool LT, int BR>
 __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const uint32_t tid = threadIdx.x, wave = wave_index(), lane = tid & 63, n_waves = blockDim.x >> 6;
 #ifdef PWAF_PROFILING
     const uint32_t dbg_skip = a.debug_skip;  // section switches for timing experiments (wrong results when set): -DPWAF_PROFILING builds only
 #else
@@ -1967,7 +1998,7 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
 #ifdef PWAF_PROFILING
     if (a.debug_skip & 0x80000000u) __builtin_amdgcn_s_setprio(3);  // timing experiment
 #endif
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = wave_index();
     const unsigned long long lt_mask = (1ull << lane) - 1;
     const bool from_row = a.asn == nullptr;  // asn / country come from the engine's own GeoIP record (or its default)
 #ifdef PWAF_PROFILING
@@ -2299,8 +2330,7 @@ int configure_kernels(int device) {
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
                          reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64>),
                          reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
-                         reinterpret_cast<const void *>(filter_kernel<true, 1>), reinterpret_cast<const void *>(filter_kernel<false, 1>),
-                         reinterpret_cast<const void *>(filter_kernel<true, 2>), reinterpret_cast<const void *>(filter_kernel<false, 2>),
+                         reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
                          reinterpret_cast<const void *>(lscan_kernel<512>), reinterpret_cast<const void *>(lscan_kernel<1024>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
