@@ -92,6 +92,8 @@ struct DevGroup {
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
     bool short_lit = false;  // every atom is an anchored literal of <= 8 bytes: evaluated by the attribute kernel, the pass is never walked
+    uint32_t n_quiet = 1;    // flat rows [0, n_quiet): the start state and the quiet states
+    bool can_skip = false;   // the flat table has an empty state for every byte kind: a walk may start inside a field
 };
 
 }  // namespace
@@ -112,7 +114,7 @@ struct Scratch {
     DevBuf res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
-    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's per-slab hit segments and counts; candidate bitmaps
+    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
     DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
@@ -334,14 +336,21 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     std::vector<uint32_t> order(S), pos(S);
     for (uint32_t s = 0; s < S; s++) order[s] = s;
     if (visits && visits->size() == S) std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
+    // The QUIET states (no thread older than one byte: program.h) come right after the start state, so that "row < n_quiet" is the
+    // kernel's test for ending a localized walk; they are where benign text spends its steps anyway.
+    const bool has_quiet = g.quiet.size() == S;
+    if (has_quiet) std::stable_partition(order.begin() + 1, order.end(), [&](uint32_t x) { return g.quiet[x] != 0; });
+    d.n_quiet = 1;
+    if (has_quiet) for (uint32_t s = 1; s < S; s++) d.n_quiet += g.quiet[s] ? 1u : 0u;
     for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
     // row = C transition cells (next state | 0x8000 when entering it emits) + one EMIT cell: what entering THIS state emits —
     // 0 = nothing, 0x8000 | local atom = exactly one atom (the common case: settled in registers by the kernel), else 1 + the state's
     // index into emit_off (a list). The cell rides with the row into LDS: round 2 called the out-of-line list walk (three dependent
     // global loads, ~2 us for the whole wave) for every match of every lane — benign candidates are mostly true hits, so a wave of
     // 64 candidates stalled on the order of a hundred times per walk.
-    // ... and one STAY cell (= the state itself, unflagged): what a lane past its field's end "reads", so that no step is conditional.
-    const uint32_t stride = C + 2;
+    // ... one STAY cell (= the state itself, unflagged): what a lane past its field's end "reads", so that no step is conditional,
+    // and one END cell (1 = the field ending in this state emits): a finished walk learns it from the row instead of two global loads.
+    const uint32_t stride = C + 3;
     std::vector<uint16_t> flat((size_t)S * stride);
     std::vector<uint32_t> emit_off(1, 0), end_off(1, 0);
     std::vector<uint16_t> emit_list, end_list;
@@ -354,12 +363,26 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
         const uint32_t ne = g.emit_off[(size_t)s + 1] - g.emit_off[s];
         flat[(size_t)q * stride + C] = ne == 0 ? (uint16_t)0 : (ne == 1 && g.emit_list[g.emit_off[s]] < 0x7FFFu) ? (uint16_t)(0x8000u | g.emit_list[g.emit_off[s]]) : (uint16_t)1;
         flat[(size_t)q * stride + C + 1] = (uint16_t)q;
+        flat[(size_t)q * stride + C + 2] = g.end_off[(size_t)s + 1] != g.end_off[s] ? (uint16_t)1 : (uint16_t)0;  // the END cell: the field ending in this state emits (a list)
         emit_list.insert(emit_list.end(), g.emit_list.begin() + g.emit_off[s], g.emit_list.begin() + g.emit_off[(size_t)s + 1]);
         emit_off.push_back((uint32_t)emit_list.size());
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
         end_off.push_back((uint32_t)end_list.size());
     }
-    std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
+    // class map (256 bytes), then per byte value the row of the empty state a walk takes when it starts right AFTER such a byte
+    // (0xFFFF: the DFA has none — walks start at the field's first byte)
+    std::vector<uint8_t> cm(256 + 512);
+    memcpy(cm.data(), g.classmap, 256);
+    d.can_skip = has_quiet && g.class_kind.size() == C;
+    for (int b = 0; b < 256; b++) {
+        uint16_t row = 0xFFFFu;
+        if (d.can_skip) {
+            const uint16_t es = g.empty_state[g.class_kind[g.classmap[b]] & 3u];
+            if (es != 0xFFFFu) row = (uint16_t)pos[es];
+            else d.can_skip = false;
+        }
+        memcpy(cm.data() + 256 + 2 * b, &row, 2);
+    }
     int rc;
     if ((rc = upload(d.flat, flat, 16))) return rc;  // (the LDS staging copies whole 16-byte units)
     if ((rc = upload(d.flat_classmap, cm))) return rc;
@@ -854,7 +877,16 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     }
 #endif
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
-    auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
+    std::vector<const uint32_t *> chunk_bits_of(e->groups.size(), nullptr);  // filtered passes: this batch's chunk bitmap (set in step 2)
+    std::vector<uint32_t> chunk_base_of(e->groups.size(), 0);
+#ifdef PWAF_PROFILING
+    // timing experiments (same results): every candidate walked from its first byte to its last, by the lane-independent loop
+    // (PWAF_WHOLE_WALKS) or by the lockstep loop the gap passes use (PWAF_LOCKSTEP_WALKS)
+    static const bool whole_walks = getenv("PWAF_WHOLE_WALKS") != nullptr, lockstep_walks = getenv("PWAF_LOCKSTEP_WALKS") != nullptr;
+#else
+    constexpr bool whole_walks = false, lockstep_walks = false;
+#endif
+    auto list_args = [&](size_t gi, const ListShape &lshape, bool phase_is_local) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
@@ -877,13 +909,21 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 a.shared_bits = d.shared_bits;
             }
         }
+        if (d.filtered && chunk_bits_of[gi] != nullptr) {
+            // localized walks: between the candidate's first and last flagged chunk, give or take the filter's reach
+            a.chunk_bits = chunk_bits_of[gi];
+            a.chunk_base = chunk_base_of[gi];
+            a.reach = d.can_skip && !whole_walks ? d.filter.reach : kUnboundedReach;
+            a.n_quiet = whole_walks ? 0u : d.n_quiet;
+            a.has_heads = d.filter.heads.empty() ? 0u : 1u;  // (exactly the passes whose records the host zeroes)
+        }
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
         a.n = n;
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
-        a.n_hot = std::min<uint32_t>(d.n_states, lshape.hot_bytes / (2u * (d.n_classes + 2u)));  // (states are in visit order: the first rows are the hot ones)
+        a.n_hot = std::min<uint32_t>(d.n_states, list_hot_bytes(lshape, phase_is_local) / (2u * (d.n_classes + 3u)));  // (states are in visit order: the first rows are the hot ones)
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
@@ -928,7 +968,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             if (d.filtered) {
                 const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab - (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u);
                 n_slabs_all += slabs;
-                sub_entries += slabs * (kStreamSlab / kStreamSeg);
+                sub_entries += slabs * (kStreamSlab / 512);  // chunk bitmap words
             }
         if ((rc = S.cand_sub.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
@@ -968,14 +1008,18 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.slab0 = col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u;
             const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
-            f.sub = (uint32_t *)S.cand_sub.p + sub_at;
+            f.chunk_bits = (uint32_t *)S.cand_sub.p + sub_at;
+            if (!lockstep_walks) {
+                chunk_bits_of[gi] = f.chunk_bits;
+                chunk_base_of[gi] = (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u) * (kStreamSlab / 16);
+            }
             f.sub_count = (uint32_t *)S.cand_cnt.p + cnt_at;
             f.block_count = f.sub_count + slabs;
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
             f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
             f.first_block = 0;
-            sub_at += (uint64_t)slabs * (kStreamSlab / kStreamSeg);
+            sub_at += (uint64_t)slabs * (kStreamSlab / 512);
             cnt_at += slabs + n_cblocks;
             alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
@@ -1016,6 +1060,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
     {
         std::vector<ListScanArgs> la[2];
+        bool phase0_local = false;  // (launch_scan_gated takes the local kernel — less LDS for hot rows — when a pass of the launch has a chunk bitmap)
+        for (size_t gi = 0; gi < e->groups.size(); gi++) phase0_local = phase0_local || (e->groups[gi].filtered && chunk_bits_of[gi] != nullptr);
         for (int phase = 0; phase < 2; phase++)
             for (size_t gi = 0; gi < e->groups.size(); gi++) {
                 const DevGroup &d = e->groups[gi];
@@ -1024,7 +1070,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
                 if (skip_identity && d.identity) continue;
 #endif
-                la[phase].push_back(list_args(gi, lshapes[phase]));
+                la[phase].push_back(list_args(gi, lshapes[phase], phase == 0 && phase0_local));
             }
         const size_t n_desc = la[0].size() + la[1].size();
         if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (n_desc + 2) * 4))) return rc;
@@ -1820,7 +1866,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             if (!g2.enabled) continue;
             g2.est_candidate_rate = sample_rate(g2, sc);
 #ifdef PWAF_PROFILING
-            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads), stride 2 %.4f (%zu heads), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.est_candidate_rate, g2.heads.size(), mean_len[g.field]);
+            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads, reach %d), stride 2 %.4f (%zu heads, reach %d), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), (int)gf.reach, g2.est_candidate_rate, g2.heads.size(), (int)g2.reach, mean_len[g.field]);
 #endif
             const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
             g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);

@@ -68,9 +68,10 @@ struct ScanArgs {
 // through the pass's DFA. A list holds a few percent of the batch, so what matters is latency per step: the table's first n_hot rows
 // (states are numbered by how often the tuning sample's candidates visit them, start state first) are staged in LDS — a step there
 // is two dependent LDS reads (class, cell) instead of an L2 round trip — and the rest is read from the L2-resident flat table.
-//   flat[s * (n_classes + 2) + c] = next state | 0x8000 when entering it emits; cell n_classes of a row = what entering that state
+//   flat[s * (n_classes + 3) + c] = next state | 0x8000 when entering it emits; cell n_classes of a row = what entering that state
 //   emits (0, 0x8000 | the single local atom, or 1 = a list), cell n_classes + 1 = the state itself (the STAY cell: the "transition"
-//   of a lane past its field's end); emit / end lists are indexed by (renumbered) state.
+//   of a lane past its field's end), cell n_classes + 2 = 1 when the field ending in this state emits; emit / end lists are indexed
+//   by (renumbered) state.
 static constexpr uint32_t kListThreads = 512;
 static constexpr uint32_t kListWalks = 1;      // listed requests a lane walks in lockstep (2 was measured: see lscan_kernel)
 static constexpr uint32_t kListHotBytes = 48 * 1024;  // 3 workgroups (24 waves) per CU
@@ -79,9 +80,9 @@ struct ListScanArgs {
     const uint32_t *off;
     uint32_t n;
     const uint16_t *flat;
-    const uint8_t *classmap;  // 256 bytes
+    const uint8_t *classmap;  // 256 bytes (+ 512: the empty-state rows, see chunk_bits)
     uint32_t n_classes;
-    uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 2) * 2 <= the launch's ListShape::hot_bytes
+    uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 3) * 2 <= the launch's ListShape::hot_bytes
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;
@@ -95,6 +96,13 @@ struct ListScanArgs {
     uint32_t n_local;
     uint32_t *gate_lists;
     uint32_t *gate_count;
+    // A pass behind a bigram prefilter walks its candidates LOCALLY: chunk_bits = the pass's chunk bitmap of this batch (bit c = the
+    // arena's 16-byte chunk chunk_base + c was flagged); a walk starts `reach` bytes before the field's first flagged chunk, in
+    // the empty state of the byte before (classmap + 256: uint16 row per byte value), and ends once its state is below n_quiet past
+    // the last flagged chunk. Null: whole fields.
+    const uint32_t *chunk_bits;
+    uint32_t chunk_base, reach, n_quiet;
+    uint32_t has_heads;        // the filter kernel compared heads for this pass: rec[] holds them (zeroed by the host), the walk merges them
     const uint32_t *req_list;  // the requests to visit and, on the device, how many (req_list null: every request, n_list ignored)
     const uint32_t *n_list;
     uint32_t *visited;         // bitmap: set bit r for every visited request (null: not needed — the list IS the pass's bitmap, or all)
@@ -115,14 +123,13 @@ struct ListScanArgs {
 // per-request logic at all in the loop: every load instruction is one contiguous KiB (every line is fetched exactly once; the
 // per-request-lane version fetched 2x the arena because 7 MB of half-consumed lines per XCD thrashed L2), no lane ever idles,
 // and a window that straddles a request boundary can only ADD a candidate.
-//   filter_kernel   per (segment, 16-byte chunk) a hit bit; non-zero segments are appended to the slab's own region of `sub`
-//                   (wave-private counter: no atomics). Heads (anchored literals) are compared at request starts, which the wave
-//                   finds by walking the offsets column alongside the bytes.
-//   resolve_kernel  hit segments -> requests (binary search in the offsets), one bit per request in `bitmap`.
+//   filter_kernel   per 16-byte chunk a hit bit, written as the pass's dense chunk bitmap (a row's ballot is its 64-bit word: no
+//                   lists, no atomics). Heads (anchored literals) are compared at request starts, which the wave finds by walking
+//                   the offsets column alongside the bytes.
+//   resolve_kernel  flagged chunks -> requests (rank queries over the slab's bitmap), one bit per request in `bitmap`.
 //   bitcount_kernel / compact_kernel   bitmap -> dense ascending request list + its length for the confirming lscan_kernel.
 static constexpr uint32_t kStreamSlab = 128 * 1024;   // bytes per wave
-static constexpr uint32_t kStreamSeg = 64;            // bytes per hit record (a segment = four 16-byte chunks = one nibble of chunk bits)
-static constexpr uint32_t kStreamIter = 64 * kStreamSeg;
+static constexpr uint32_t kStreamIter = 4096;          // bytes per iteration of a wave: four rows of 64 lanes x 16 bytes
 static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup
 static constexpr uint32_t kMaxFiltersPerLaunch = 8;
 static constexpr uint32_t kCompactWords = 2048;       // bitmap words per compact workgroup (65536 requests)
@@ -142,8 +149,8 @@ struct FilterArgs {
     uint32_t head_len[2];     // length | exact << 8
     uint32_t head_code[2];    // hit-record bits of the head's atom
     uint32_t *rec;            // n hit records of the pass, zeroed by the host: written only where a head holds
-    uint32_t *sub;            // hit segments: slab s owns sub[s * (kStreamSlab / kStreamSeg) ...]; entry = segment index in the slab << 4 | chunk mask
-    uint32_t *sub_count;      // [slabs]
+    uint32_t *chunk_bits;     // the pass's chunk bitmap: bit c = the 16-byte chunk c of the streamed slabs holds a position that completed a window (kStreamSlab / 512 words per slab)
+    uint32_t *sub_count;      // [slabs]: flagged chunks of the slab
     uint32_t *bitmap;         // [(n + 31) / 32], zeroed by the host: candidate requests
     uint32_t *block_count;    // [(words + kCompactWords - 1) / kCompactWords]: candidates per compact workgroup
     uint32_t *list;           // n: dense candidate list
@@ -330,6 +337,8 @@ struct ListShape {
     uint32_t threads, hot_bytes, wg_per_cu;
 };
 ListShape list_shape(uint32_t variant);  // 0 = default
+// LDS bytes left for hot rows in a launch of this shape (`local`: every pass is behind a prefilter — the waves' queues of deferred walks take their share)
+uint32_t list_hot_bytes(const ListShape &shape, bool local);
 // `plan`: count + 1 words of device scratch (the work-item prefix sums, written by lscan_plan_kernel on the same stream)
 int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);

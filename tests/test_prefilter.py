@@ -9,7 +9,7 @@ import pytest
 import helpers as H
 import table_walker
 from oracle import pyoracle
-from pingoo_amd import RequestBatch, _abi
+from pingoo_amd import Request, RequestBatch, _abi
 from pingoo_amd.engine import CompiledProgram
 
 
@@ -179,3 +179,61 @@ def test_tuned_filters_keep_every_verdict(seed):
         t.filter_phase = phase
         for i in range(batch.n):
             assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, phase, i, [batch.field_bytes(f, i) for f in range(5)])
+
+
+def _long_requests(rng, n):
+    """Long fields with rule tokens (whole, cut short, case-swapped) at the start, in the middle and at the end of filler text: the
+    inputs on which a localized walk differs from a whole-field walk."""
+    def filler(lo, hi):
+        return H.rstr(rng, lo, hi, "abcdefxyz/.=-_ %0123456789")
+
+    def field(max_len):
+        parts = []
+        for _ in range(rng.randint(1, 4)):
+            k = rng.random()
+            if k < 0.5:
+                parts.append(H.lit_token(rng))
+            elif k < 0.6:
+                parts.append(rng.choice(H.TOKENS).swapcase())
+            parts.append(filler(0, 90) if rng.random() < 0.8 else "")
+        if rng.random() < 0.5:
+            parts.insert(0, filler(10, 120))
+        return "".join(parts)[:max_len]
+
+    reqs = []
+    for _ in range(n):
+        path = field(200)
+        reqs.append(Request(host=field(60), url=path + ("?" + field(250) if rng.random() < 0.7 else ""), path=path, method="GET", user_agent=field(255),
+                            headers={"x-a": field(120)} if rng.random() < 0.5 else None))
+    return reqs
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_localized_walks_keep_every_verdict(seed):
+    """A candidate of a bounded prefilter pass is walked from `reach` bytes before its first flagged chunk (in the empty state of the
+    byte before) until no thread older than the byte after its last flagged chunk is alive (table_walker.scan_field = lscan_kernel's
+    rule, at its most aggressive). Verdicts equal the oracle's at every alignment of the field in its arena, tuned or not, and the
+    walks are shorter."""
+    rng = random.Random(9100 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 30))
+    prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0)
+    if seed % 2:
+        prog.tune(RequestBatch.from_requests(_long_requests(rng, 300)))
+    t = table_walker.Tables(prog.dump())
+    batch = RequestBatch.from_requests(_long_requests(rng, 100))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    steps = {}
+    for local in (False, True):
+        t.use_local_walks, t.n_steps = local, 0
+        for off in ([0] if not local else rng.sample(range(16), 4)):
+            t.arena_offset = off
+            for i in range(batch.n):
+                assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, local, off, i, [batch.field_bytes(f, i) for f in range(5)])
+        steps[local] = t.n_steps / (4 if local else 1)
+    bounded = [g for g in t.groups if g.get("f_reach", t.UNBOUNDED) != t.UNBOUNDED]
+    if bounded and steps[False] > 2000:
+        assert steps[True] < steps[False], (steps, len(bounded))
+    _LOCAL_STEPS.append((seed, len(bounded), int(steps[False]), int(steps[True])))
+
+
+_LOCAL_STEPS = []
