@@ -130,6 +130,10 @@ void pwaf_list_free(char **items, size_t n);
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 #define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1
                                        * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */
+#define PWAF_OPT_LOCAL_WALKS 256u     /* EXPERIMENTAL: a prefilter candidate is walked only from shortly before its first flagged 16-byte
+                                       * chunk until the DFA holds no thread older than the byte after its last one,
+                                       * instead of from its first byte to its last: same verdicts. Off by default: measured on MI355X it
+                                       * saves steps but no time (the 64 walks of a wave advance in lockstep) */
 typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;

@@ -879,12 +879,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
     std::vector<const uint32_t *> chunk_bits_of(e->groups.size(), nullptr);  // filtered passes: this batch's chunk bitmap (set in step 2)
     std::vector<uint32_t> chunk_base_of(e->groups.size(), 0);
+    // PWAF_OPT_LOCAL_WALKS (off by default: it saves steps, not time — DESIGN.md §4.6): prefilter candidates are walked locally
+    bool local_walks = (P.flags & PWAF_OPT_LOCAL_WALKS) != 0;
 #ifdef PWAF_PROFILING
-    // timing experiments (same results): every candidate walked from its first byte to its last, by the lane-independent loop
-    // (PWAF_WHOLE_WALKS) or by the lockstep loop the gap passes use (PWAF_LOCKSTEP_WALKS)
-    static const bool whole_walks = getenv("PWAF_WHOLE_WALKS") != nullptr, lockstep_walks = getenv("PWAF_LOCKSTEP_WALKS") != nullptr;
+    // timing experiments (same results): PWAF_LOCAL_WALKS = the option; PWAF_WHOLE_WALKS = the local kernel, but every candidate walked from its first byte to its last
+    static const bool whole_walks = getenv("PWAF_WHOLE_WALKS") != nullptr, env_local = getenv("PWAF_LOCAL_WALKS") != nullptr;
+    local_walks = local_walks || env_local || whole_walks;
 #else
-    constexpr bool whole_walks = false, lockstep_walks = false;
+    constexpr bool whole_walks = false;
 #endif
     auto list_args = [&](size_t gi, const ListShape &lshape, bool phase_is_local) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
@@ -1009,7 +1011,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
             f.chunk_bits = (uint32_t *)S.cand_sub.p + sub_at;
-            if (!lockstep_walks) {
+            if (local_walks) {
                 chunk_bits_of[gi] = f.chunk_bits;
                 chunk_base_of[gi] = (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u) * (kStreamSlab / 16);
             }

@@ -248,3 +248,42 @@ def test_config5_per_gpu_share_properties_at_6_25M():
     eng.device_status()
     assert (out2.cpu().numpy().view(np.uint32) == got).all()
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_localized_walks_on_the_device(seed):
+    """PWAF_OPT_LOCAL_WALKS: prefilter candidates walked from shortly before their first flagged chunk until the DFA is quiet past
+    the last one, long walks deferred to the waves' queues — the verdicts are the oracle's, tuned or not, on long fields with rule
+    tokens (whole, cut short, case-swapped) at their start, middle and end."""
+    from test_prefilter import _long_requests
+
+    rng = random.Random(9300 + seed)
+    rules = H.lit_rules(rng, rng.randint(3, 50))
+    eng = RuleEngine(rules, {}, flags=_abi.OPT_LOCAL_WALKS | (_abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0))
+    n = rng.choice([64, 700, 3000, 9000])
+    batch = RequestBatch.from_requests(_long_requests(rng, n))
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}")
+    eng.tune(RequestBatch.from_requests(_long_requests(rng, 300)))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, tuned")
+    eng.close()
+
+
+def test_localized_walks_on_the_synthetic_streams():
+    """The 1k-rule set at 200k requests, benign and hostile stream: the engine with localized walks returns what the default engine
+    returns (which the other tests compare with the oracle)."""
+    from synth.pysynth import Workload
+
+    wl = Workload(3)
+    plain = RuleEngine(wl.rules, wl.lists, wl.geoip)
+    local = RuleEngine(wl.rules, wl.lists, wl.geoip, flags=_abi.OPT_LOCAL_WALKS)
+    sample = wl.batch(5_000_000, 20000)
+    plain.tune(sample)
+    local.tune(sample)
+    for adversarial in (False, True):
+        batch = wl.batch(0, 200_000, adversarial=adversarial)
+        a, b = plain.evaluate_batch(batch), local.evaluate_batch(batch)
+        assert np.array_equal(a["action"], b["action"]) and np.array_equal(a["rule_idx"], b["rule_idx"]), adversarial
+        assert len(set(a["action"].tolist())) >= 2
+    plain.close()
+    local.close()
