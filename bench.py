@@ -284,6 +284,12 @@ def main():
         # (PWAF_BENCH_TUNE_ADVERSARIAL: timing experiment — what tables fitted to the hostile stream would buy; never the reported mode)
         eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads, adversarial=bool(os.environ.get("PWAF_BENCH_TUNE_ADVERSARIAL"))))
         t_compile += time.time() - t0
+        if os.environ.get("PWAF_BENCH_RETUNE_ROWS_ADV"):
+            # timing experiment (profiling build): which rows are LDS-resident re-ranked from a HOSTILE sample, prefilters untouched —
+            # what an engine that adapted its table residency to the traffic it sees would reach; never the reported mode
+            os.environ["PWAF_TUNE_ROWS_ONLY"] = "1"
+            eng.tune(wl.batch(world * n + rank * tune_n + tune_n, tune_n, threads=threads, adversarial=True))
+            del os.environ["PWAF_TUNE_ROWS_ONLY"]
 
     phase("headline run")
     elapsed, ktimes, final_counts = R.timed_run(dbatch, args.steps, args.warmup)

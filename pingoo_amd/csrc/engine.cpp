@@ -919,6 +919,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             a.n_quiet = whole_walks ? 0u : d.n_quiet;
             a.has_heads = d.filter.heads.empty() ? 0u : 1u;  // (exactly the passes whose records the host zeroes)
         }
+        a.behind_filter = d.filtered ? 1u : 0u;
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
         a.n = n;
@@ -1942,7 +1943,11 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
     TuneOut T;
     for (const DevGroup &d : e->groups) T.filters.push_back(d.filter);
     if ((rc = tune_host(P, sample, T))) return rc;
-    for (size_t k = 0; k < P.groups.size(); k++) {
+    bool rows_only = false;
+#ifdef PWAF_PROFILING
+    rows_only = getenv("PWAF_TUNE_ROWS_ONLY") != nullptr;  // timing experiment: keep the prefilters, take only the sample's state visits (which rows are LDS-resident)
+#endif
+    for (size_t k = 0; k < P.groups.size() && !rows_only; k++) {
         e->groups[k].filter = T.filters[k];
         if (T.chunks[k]) e->groups[k].chunks = T.chunks[k];
     }

@@ -102,6 +102,7 @@ struct ListScanArgs {
     // the last flagged chunk. Null: whole fields.
     const uint32_t *chunk_bits;
     uint32_t chunk_base, reach, n_quiet;
+    uint32_t behind_filter;    // the list is a bigram prefilter's candidate list (hostile traffic makes it long: lscan_async)
     uint32_t has_heads;        // the filter kernel compared heads for this pass: rec[] holds them (zeroed by the host), the walk merges them
     const uint32_t *req_list;  // the requests to visit and, on the device, how many (req_list null: every request, n_list ignored)
     const uint32_t *n_list;
@@ -330,6 +331,7 @@ int launch_scan(const ScanArgs &a, void *stream);
 struct GatedTable {
     const ListScanArgs *g;  // device
     uint32_t count;
+    uint32_t debug;  // -DPWAF_PROFILING timing experiments only: 1 = never, 2 = always the asynchronous loop for a list (same results)
 };
 int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream);
 // Workgroup shape of the list scan: threads per workgroup, LDS bytes of hot rows per workgroup, workgroups per CU.

@@ -695,6 +695,113 @@ __device__ __forceinline__ void lscan_local(const ListScanArgs &a, const uint16_
     }
 }
 
+// A LONG list (more than an eighth of the batch: hostile traffic — near misses of the rule literals in most requests), walked with the
+// cold steps taken TOGETHER. In the lockstep loop below a group of four steps in which ANY of the 64 lanes meets a cold cell (a row
+// that is not LDS-resident: an L2 round trip) is re-walked step by step by the whole wave, and although a lane spends under a tenth
+// of its steps in cold rows, some lane of the wave does nearly always: measured on the hostile stream of the 1k-rule set, 28 of the
+// 36 groups of a wave's walk take the slow path, and those round trips are 85 % of the scan's 3.6 ms. Here every lane keeps its own
+// position: per iteration a lane whose next four cells are LDS-resident takes them (the wave's cheap iteration), a lane that is not
+// waits — and when half the wave is waiting (or nobody else can move) ONE slow iteration takes the blocked lanes through their
+// group, cold cells from L2, while the others wait: a round trip then serves thirty lanes instead of one.
+template <uint32_t THREADS>
+__device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_t *hot, const unsigned char *cls, uint32_t it, const uint32_t it_end,
+                                            const uint32_t first, const uint32_t n_l, const uint32_t hot_elems) {
+    const uint32_t ncls = a.n_classes, stride = ncls + 3u;
+    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
+    const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
+    auto record_emit = [&](const uint32_t st, Hits &hh) {
+        const uint32_t ei = st * stride + ncls;
+        const uint32_t code = ei < hot_elems ? (uint32_t)hot[ei] : (uint32_t)flat[ei];
+        const uint32_t x = (code & 0x7FFFu) + 1u;
+        bool slow = !(code & 0x8000u) || hh.ovf != kNone;
+        if (!slow) {
+            if (hh.a0 == x || hh.a1 == x) {}
+            else if (hh.a0 == 0) hh.a0 = x;
+            else if (hh.a1 == 0) hh.a1 = x;
+            else slow = true;
+        }
+        if (slow) hh = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, hh);
+    };
+    for (; it < it_end; it++) {
+        const uint32_t li = (it - first) * THREADS + threadIdx.x;
+        bool live = li < n_l;
+        if (live && a.need_in != nullptr) live = ((a.need_in[li] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
+        const uint32_t r = live ? (a.req_list != nullptr ? a.req_list[li] : li) : 0u;
+        if (live && a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31u));
+        uint32_t p = live ? a.off[r] : 0u;           // the next byte to read
+        const uint32_t end = live ? a.off[r + 1] : 0u;
+        uint32_t state = 0, wp = p;                  // wp: where the window in `w` begins (p - wp is a multiple of 4, below 16 after the reload)
+        Hits h{0, 0, kNone};
+        if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
+        u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + wp);
+        u32x4 wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (wp + 16u < end ? wp + 16u : 0u));
+        for (;;) {
+            const bool active = p < end;
+            const unsigned long long am = __ballot(active);
+            if (am == 0) break;
+            if (active && p - wp >= 16u) {  // this lane's window is used up: the prefetched one takes its place, the one after is requested
+                w = wn;
+                wp += 16u;
+                wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (wp + 16u < end ? wp + 16u : 0u));
+            }
+            const uint32_t j = (p - wp) >> 2;
+            const uint32_t wd = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+            const uint32_t cnt = active ? min(4u, end - p) : 0u;
+            uint32_t c[4], t[4], sv[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) c[k] = cls[(wd >> (k * 8)) & 0xFFu];
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));  // (unconditional lookups: see lscan_local)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) c[k] = k < cnt ? c[k] : ncls + 1u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                t[k] = *reinterpret_cast<lds_u16_ptr>((uintptr_t)min(__umul24(k == 0 ? state : sv[k - 1], 2u * stride) + 2u * c[k], 2u * hot_elems));
+                sv[k] = t[k] & 0x7FFFu;
+            }
+            const uint32_t any = t[0] | t[1] | t[2] | t[3], top = max(max(t[0], t[1]), max(t[2], t[3]));
+            const bool blocked = active && top == 0xFFFFu;
+            const unsigned long long bm = __ballot(blocked);
+            const uint32_t n_blocked = (uint32_t)__builtin_popcountll(bm);
+            if (n_blocked < 32u && bm != am) {
+                // the cheap iteration: every lane whose four cells are LDS-resident takes them
+                if (active && !blocked) {
+                    if (any & 0x8000u) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (t[k] & 0x8000u) record_emit(sv[k], h);
+                    }
+                    state = sv[3];
+                    p += 4u;
+                }
+            } else if (blocked) {
+                // the slow iteration: the blocked lanes' group step by step, cold cells from the L2-resident table
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t idx = state * stride + c[k];
+                    uint32_t tg = 0;
+                    if (idx >= hot_elems) tg = flat[idx];
+                    const uint32_t tl = hot[min(idx, hot_elems)];
+                    const uint32_t tt = idx < hot_elems ? tl : tg;
+                    state = tt & 0x7FFFu;
+                    if (tt & 0x8000u) record_emit(state, h);
+                }
+                p += 4u;
+            }
+        }
+        if (live) {
+            if (a.end_off[state + 1] != a.end_off[state]) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);
+            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+            if (a.colmask_local != nullptr) {
+                uint32_t need = 0;
+                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
+                if (a.need_out != nullptr) a.need_out[li] = need;
+                need &= ~a.shared_bits;
+                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+            }
+        }
+    }
+}
+
 // LOCAL: the launch of the passes behind a bigram prefilter (lscan_local); else none is walked locally (one kernel with both loops
 // needs 85 vector registers: the 512-thread shape of the gap passes would lose a third of its waves).
 template <uint32_t THREADS, bool LOCAL>
@@ -745,6 +852,18 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         if (LOCAL) {
             uint32_t *queue = lscan_lds + (hot_bytes + 16u + 768u) / 4 + wave_index() * (2u * kListQueue);  // the wave's deferred walks
             lscan_local<THREADS>(a, hot, cls, reinterpret_cast<const uint16_t *>(cls + 256), queue, it, it_end, first, n_l, hot_elems);
+            it = it_end;
+            continue;
+        }
+        // (the gap passes' lists stay with the lockstep loop: measured 0.25 -> 0.40 ms with this one on the hostile stream — their walks
+        // are short and mostly LDS-resident, and the asynchronous iteration costs more per group)
+#ifdef PWAF_PROFILING
+        const bool long_list = (b.debug & 1u) ? false : (b.debug & 2u) ? true : (a.behind_filter != 0u && (uint64_t)n_l * 8u >= a.n);  // timing experiments: never / always the asynchronous loop (same results)
+#else
+        const bool long_list = a.behind_filter != 0u && (uint64_t)n_l * 8u >= a.n;
+#endif
+        if (long_list) {  // (uniform) a prefilter's candidate list that holds more than an eighth of the batch: lscan_async
+            lscan_async<THREADS>(a, hot, cls, it, it_end, first, n_l, hot_elems);
             it = it_end;
             continue;
         }
@@ -962,7 +1081,11 @@ static const void *lscan_fn(bool wide, bool local) {
 int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream) {
     if (count == 0 || host[0].n == 0) return 0;
     if (count > 256) return (int)hipErrorInvalidValue;
-    GatedTable b{dev, count};
+    GatedTable b{dev, count, 0u};
+#ifdef PWAF_PROFILING
+    static const uint32_t async_mode = getenv("PWAF_LSCAN_ASYNC") ? (uint32_t)atoi(getenv("PWAF_LSCAN_ASYNC")) : 0u;
+    b.debug = async_mode;
+#endif
     hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, shape.threads * kListWalks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
