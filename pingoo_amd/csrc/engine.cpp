@@ -114,7 +114,7 @@ struct Scratch {
     DevBuf res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
-    DevBuf cand_sub, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
+    DevBuf chunk_bits, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
     DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
@@ -142,7 +142,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &cand_sub, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -973,7 +973,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 n_slabs_all += slabs;
                 sub_entries += slabs * (kStreamSlab / 512);  // chunk bitmap words
             }
-        if ((rc = S.cand_sub.reserve((size_t)sub_entries * 4))) return rc;
+        if ((rc = S.chunk_bits.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
         std::vector<FilterArgs> fall;  // every filtered pass, in pass order
         uint32_t fi = 0;
@@ -1011,7 +1011,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.slab0 = col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u;
             const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
-            f.chunk_bits = (uint32_t *)S.cand_sub.p + sub_at;
+            f.chunk_bits = (uint32_t *)S.chunk_bits.p + sub_at;
             if (local_walks) {
                 chunk_bits_of[gi] = f.chunk_bits;
                 chunk_base_of[gi] = (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u) * (kStreamSlab / 16);

@@ -9,7 +9,7 @@
 //   filter_kernel    the launch that streams the request bytes: every string pass whose patterns all have a literal factor sits behind
 //                    a bucketed shift-or BIGRAM PREFILTER. A field's arena is one flat byte stream; per byte one independent lookup of
 //                    a 16 KiB LDS table and two vector ops; the requests overlapping a completed window become CANDIDATES
-//                    (resolve_kernel: hit segments -> bitmap; bitcount / compact_kernel: bitmap -> dense ascending list).
+//                    (resolve_kernel: flagged chunks -> bitmap; bitcount / compact_kernel: bitmap -> dense ascending list).
 //   lscan_kernel     every list-driven pass of a phase in one launch: the candidates of the filtered passes, then the gap passes
 //                    (patterns with wide gaps, visited only by requests whose prefilter factor matched). One listed request per lane
 //                    through the pass's DFA, hot rows in LDS. What a request matched is written as one 4-byte hit record (two atoms
@@ -1605,7 +1605,7 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
     return x;
 }
 
-// resolve_kernel: one wave per slab turns the slab's hit segments into candidate REQUESTS. Request-driven: the flagged 16-byte
+// resolve_kernel: one wave per slab turns the slab's flagged chunks into candidate REQUESTS. Request-driven: the flagged 16-byte
 // chunks of the slab become a bitmap in LDS (8192 bits) with per-word prefix counts, then the wave walks the requests that overlap
 // the slab — 64 per step, offsets read coalesced — and a request is a candidate when a flagged chunk lies within its bytes extended
 // by what a window may reach back (three sampled bigrams) and forward (one byte): two rank queries. Slabs without a hit leave at
