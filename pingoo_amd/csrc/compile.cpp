@@ -1368,6 +1368,16 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
                 if (g.filter.enabled) continue;
             }
             build_group_filter(P.atoms, g, nullptr, g.filter, 1);
+            if (!g.filter.enabled || (P.flags & PWAF_OPT_FILTER_STRIDE2)) continue;
+            // Without a traffic sample the choice of the sampling stride rests on the built-in prior over URL / header text: stride 2
+            // (half the lookups: the pass streams at HBM speed instead of LDS speed) when the model expects it to flag at most two
+            // points more of the requests than stride 1 and under a tenth of them — the rule pwaf_engine_tune applies to measured rates.
+            GroupFilter alt;
+            build_group_filter(P.atoms, g, nullptr, alt, 2);
+#ifdef PWAF_PROFILING
+            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[create] field %d: model rate stride 1 %.4f, stride 2 %s %.4f\n", g.field, g.filter.est_candidate_rate, alt.enabled ? "built" : alt.note.c_str(), alt.est_candidate_rate);
+#endif
+            if (alt.enabled && alt.est_candidate_rate <= g.filter.est_candidate_rate + 0.02 && alt.est_candidate_rate <= 0.10) g.filter = alt;
         }
     // pass order: plain passes, then filtered ones, then the gated gap passes — the hit records of every list-driven pass are
     // then contiguous (one memset per batch)

@@ -2322,6 +2322,8 @@ struct AttrIn {
     uint32_t sstart, slen;  // the short-literal field's value: offset and length
 };
 
+// (__launch_bounds__(256, 7) — 72 registers, 7 waves per SIMD at the price of 3-5 spilled dwords — was measured: 0.229 ms alone against
+// 0.227, nothing.)
 // SMALL: the rule set's membership rows fit 4 ip-set words, 2 country words and one word each of port sets, asn sets and asn
 // comparisons (a 1k-rule set with 124 CIDR lists does): 9 row registers instead of 36.
 template <bool PACKED, bool SMALL>

@@ -28,7 +28,7 @@ from .batch import VERDICT_DTYPE, Request, RequestBatch
 _LIB = None
 # PWAF_LIB_VARIANT=prof loads libpwaf_prof.so, the -DPWAF_PROFILING build with the timing-experiment switches (tools/ only: results may
 # be wrong when a switch is set). Nothing else is ever loaded: there is no fallback of any kind.
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpwaf_prof.so" if os.environ.get("PWAF_LIB_VARIANT") == "prof" else "libpwaf.so")
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"libpwaf_{os.environ['PWAF_LIB_VARIANT']}.so" if os.environ.get("PWAF_LIB_VARIANT") else "libpwaf.so")
 
 
 class PwafError(RuntimeError):

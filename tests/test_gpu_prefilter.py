@@ -287,3 +287,30 @@ def test_localized_walks_on_the_synthetic_streams():
         assert len(set(a["action"].tolist())) >= 2
     plain.close()
     local.close()
+
+
+def test_every_request_a_candidate_at_one_million():
+    """The hostile extreme at size: one million requests, every one a candidate of both filtered passes (near misses and hits mixed,
+    long fields) — the lists are the whole batch, walked by lscan_async. Checked against the engine without prefilters (the
+    streaming scan of every request) on all of it and against the oracle on a prefix."""
+    rng = random.Random(424242)
+    rules = [("a", 'http_request.path.contains("/.env")', [B]), ("b", 'http_request.url.contains("zz9=1") || http_request.url.matches("(?i)union\\\\s+select")', [CAP]),
+             ("c", 'http_request.user_agent.contains("sqlmap")', [B])]
+    pool = []
+    for _ in range(4096):
+        pad = H.rstr(rng, 5, 120, "abcdefxyz/.=-_%0123456789")
+        path = "/" + pad + rng.choice(["/.env", "/.en", "/.envx", "/.e"]) + (H.rstr(rng, 0, 40, "abc/") if rng.random() < 0.5 else "")
+        url = path + "?" + pad + rng.choice(["zz9=1", "zz9=", "zz9", "union select", "UNION  SELECT", "union+select", "unionselect"]) + H.rstr(rng, 0, 60, "abc&=")
+        pool.append(Request(path=path[:250], url=url[:500], host="h", user_agent=rng.choice(["sqlmap/1.7", "sqlma", "Mozilla/5.0 sqlmap", "curl/8"]) + pad[:40]))
+    reqs = [pool[i % 4096] for i in range(1_000_000)]
+    batch = RequestBatch.from_requests(reqs)
+    eng = RuleEngine(rules)
+    plain = RuleEngine(rules, flags=_abi.OPT_NO_PREFILTER)
+    a, counts = eng.evaluate_batch(batch, with_counts=True)
+    b = plain.evaluate_batch(batch)
+    assert np.array_equal(a["action"], b["action"]) and np.array_equal(a["rule_idx"], b["rule_idx"])
+    assert counts.tolist() == np.bincount(a["action"], minlength=4).tolist() and len(set(a["action"].tolist())) >= 3
+    head = batch.slice(0, 4096)
+    H.assert_verdicts_equal(a[:4096], pyoracle.Oracle(rules).evaluate(head), head, "oracle prefix")
+    eng.close()
+    plain.close()

@@ -111,8 +111,11 @@ def test_stride_two_is_taken_where_the_factors_allow_it():
     t = table_walker.Tables(CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2).dump())
     by_field = {g["field"]: g["f_stride"] for g in t.groups if "f_table" in g}
     assert by_field[4] == 2 and by_field[2] == 2  # ("../" still has one sampled bigram per alignment)
+    # without the flag (and without a traffic sample) the built-in prior decides per pass: the User-Agent tokens keep their
+    # selectivity with half the bigrams sampled, the three-byte "../" does not
     t1 = table_walker.Tables(CompiledProgram(rules, {}).dump())
-    assert {g["f_stride"] for g in t1.groups if "f_table" in g} == {1}
+    by_field = {g["field"]: g["f_stride"] for g in t1.groups if "f_table" in g}
+    assert by_field[4] == 2 and by_field[2] == 1
 
 
 def _gated_head_rules():

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-export PWAF_LIB_VARIANT=prof
+export PWAF_LIB_VARIANT=${PWAF_LIB_VARIANT:-prof}
 run() {  # name, env...
   name=$1; shift
   env "$@" timeout 300 python bench.py --steps 6 --warmup 2 --verbose --no-cpu-baseline --no-extra-modes --no-pcie --no-config5 $BENCH_EXTRA > $OUT/$name.json 2> $OUT/$name.err
