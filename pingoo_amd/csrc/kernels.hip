@@ -2578,7 +2578,12 @@ int launch_dir24(const VerdictArgs &a, void *out, void *esc, void *esc_count, vo
 // address lookups: one lane per request at full occupancy (grid-stride; 8 workgroups of 256 per CU)
 int launch_ipres(const VerdictArgs &a, void *stream) {
     if (a.n == 0) return 0;
-    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, 8 * std::max(1u, a.attr_blocks));
+#ifdef PWAF_PROFILING
+    static const uint32_t forced = getenv("PWAF_IPRES_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_IPRES_BLOCKS")) : 0u;
+#else
+    const uint32_t forced = 0;
+#endif
+    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, forced ? forced : 8 * std::max(1u, a.attr_blocks));
     if (a.ipres_packed) hipLaunchKernelGGL(ipres_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(ipres_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
