@@ -90,7 +90,8 @@ struct DevGroup {
     GroupFilter filter;     // the prefilter in use (Program's, or rebuilt from a traffic sample by pwaf_engine_tune)
     DevBuf ftable;
     // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
-    DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list;
+    DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list, delta;
+    uint32_t n_full = 0, n_delta = 0;  // LDS layout of the list scan: rows [0, n_full), then n_delta 8-byte delta records (states n_full ..)
     bool short_lit = false;  // every atom is an anchored literal of <= 8 bytes: evaluated by the attribute kernel, the pass is never walked
     uint32_t n_quiet = 1;    // flat rows [0, n_quiet): the start state and the quiet states
     bool can_skip = false;   // the flat table has an empty state for every byte kind: a walk may start inside a field
@@ -331,7 +332,7 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
 
 // The flat form of a group for lscan_kernel. States are renumbered — start state first, then by visits of the tuning sample
 // (discovery order without one) — so that the rows lscan_kernel stages in LDS are the ones its walks spend their steps in.
-int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t> *visits = nullptr) {
+int build_flat_group(const DfaGroup &g, DevGroup &d, bool wide, const std::vector<uint64_t> *visits = nullptr) {
     const uint32_t S = g.n_states, C = g.n_classes;
     std::vector<uint32_t> order(S), pos(S);
     for (uint32_t s = 0; s < S; s++) order[s] = s;
@@ -342,6 +343,70 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     if (has_quiet) std::stable_partition(order.begin() + 1, order.end(), [&](uint32_t x) { return g.quiet[x] != 0; });
     d.n_quiet = 1;
     if (has_quiet) for (uint32_t s = 1; s < S; s++) d.n_quiet += g.quiet[s] ? 1u : 0u;
+    // DELTA rows. A row that is not LDS-resident costs an L2 round trip per step, and with 64 walks in lockstep some lane is in
+    // such a row in nearly every group of steps once a twentieth of the steps are (hostile traffic: near misses of the rule
+    // literals, deep in the patterns' prefix chains). But such states are the cheap kind: a state deep inside one literal differs
+    // from a shallow state — the one its failure transitions lead back to — in one or two cells. A state within TWO cells of one
+    // of the hottest rows is therefore kept in LDS as an 8-byte record (base row, two exception cells) instead of a row of 100-150
+    // bytes: measured on the 1k-rule set, all of the hostile stream's steps outside the resident rows are in such states. The rows /
+    // records split maximises the sample visits covered (no sample: the states covered).
+    const uint32_t row_bytes = 2u * (C + 3u), budget = list_hot_bytes(list_shape(wide ? 2u : 0u), false);
+    const uint32_t cap_rows = std::min<uint32_t>(S, (budget - 48u) / row_bytes);
+    d.n_full = cap_rows;
+    d.n_delta = 0;
+    std::vector<uint64_t> delta_rec;
+    if (S > cap_rows && cap_rows >= 8 && C <= 255 && d.n_quiet <= cap_rows) {
+        const uint32_t B = std::min<uint32_t>(cap_rows, std::max<uint32_t>(512, d.n_quiet));  // candidate base rows: the hottest ones (the quiet states, which the localized walks test by row number, stay rows)
+        struct Near { uint16_t base; uint8_t n, c[2]; };
+        std::vector<Near> near(S, Near{0, 255, {0, 0}});
+        for (uint32_t q = B; q < S; q++) {
+            const uint32_t s = order[q];
+            const uint16_t *rs = &g.trans[(size_t)s * C];
+            for (uint32_t b = 0; b < B && near[s].n != 0; b++) {
+                const uint16_t *rb = &g.trans[(size_t)order[b] * C];
+                uint32_t nd = 0;
+                uint8_t cc[2] = {0, 0};
+                for (uint32_t c = 0; c < C && nd <= 2; c++)
+                    if (rs[c] != rb[c]) { if (nd < 2) cc[nd] = (uint8_t)c; nd++; }
+                if (nd <= 2 && nd < near[s].n) near[s] = Near{(uint16_t)b, (uint8_t)nd, {cc[0], cc[1]}};
+            }
+        }
+        auto weight = [&](uint32_t s) { return (visits && visits->size() == S ? (double)(*visits)[s] : 0.0) + 1e-3; };
+        double best_score = -1;
+        uint32_t best_n = cap_rows;
+        for (uint32_t n = cap_rows;; n = n >= B + 16 ? n - 16 : B) {
+            const uint64_t space = (uint64_t)budget - (uint64_t)n * row_bytes;
+            uint64_t room = space > 48 ? (space - 48) / 8 : 0;
+            double score = 0;
+            for (uint32_t q = 0; q < n; q++) score += weight(order[q]);
+            for (uint32_t q = n; q < S && room; q++)
+                if (near[order[q]].n <= 2) { score += weight(order[q]); room--; }
+            if (score > best_score) { best_score = score; best_n = n; }
+            if (n == B) break;
+        }
+        // rows [0, n_full), then the records (in visit order, as many as fit), then everything else
+        std::vector<uint32_t> full(order.begin(), order.begin() + best_n), recs, rest;
+        uint64_t room = (uint64_t)budget - (uint64_t)best_n * row_bytes > 48 ? ((uint64_t)budget - (uint64_t)best_n * row_bytes - 48) / 8 : 0;
+        for (uint32_t q = best_n; q < S; q++) {
+            if (near[order[q]].n <= 2 && room) { recs.push_back(order[q]); room--; }
+            else rest.push_back(order[q]);
+        }
+        d.n_full = best_n;
+        d.n_delta = (uint32_t)recs.size();
+        order = full;
+        order.insert(order.end(), recs.begin(), recs.end());
+        order.insert(order.end(), rest.begin(), rest.end());
+        for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
+        auto cell_of = [&](uint32_t t) { return (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u)); };
+        for (uint32_t s : recs) {
+            const Near &nr = near[s];
+            const uint16_t *rs = &g.trans[(size_t)s * C];
+            const uint8_t c1 = nr.n >= 1 ? nr.c[0] : 0, c2 = nr.n >= 2 ? nr.c[1] : c1;
+            // (no exception: both slots repeat the base row's own cell of class 0)
+            const uint16_t t1 = cell_of(rs[c1]), t2 = cell_of(rs[c2]);
+            delta_rec.push_back((uint64_t)nr.base | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 24) | ((uint64_t)t1 << 32) | ((uint64_t)t2 << 48));
+        }
+    }
     for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
     // row = C transition cells (next state | 0x8000 when entering it emits) + one EMIT cell: what entering THIS state emits —
     // 0 = nothing, 0x8000 | local atom = exactly one atom (the common case: settled in registers by the kernel), else 1 + the state's
@@ -385,6 +450,8 @@ int build_flat_group(const DfaGroup &g, DevGroup &d, const std::vector<uint64_t>
     }
     int rc;
     if ((rc = upload(d.flat, flat, 16))) return rc;  // (the LDS staging copies whole 16-byte units)
+    if (delta_rec.empty()) delta_rec.push_back(0);
+    if ((rc = upload(d.delta, delta_rec, 16))) return rc;
     if ((rc = upload(d.flat_classmap, cm))) return rc;
     if ((rc = upload(d.emit_off, emit_off))) return rc;
     if ((rc = upload(d.emit_list, emit_list))) return rc;
@@ -926,7 +993,17 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.flat = (const uint16_t *)d.flat.p;
         a.classmap = (const uint8_t *)d.flat_classmap.p;
         a.n_classes = d.n_classes;
-        a.n_hot = std::min<uint32_t>(d.n_states, list_hot_bytes(lshape, phase_is_local) / (2u * (d.n_classes + 3u)));  // (states are in visit order: the first rows are the hot ones)
+        {
+            // rows [0, n_full) and the delta records behind them, when this launch's LDS share holds the layout the tables were built for
+            const uint32_t row_bytes = 2u * (d.n_classes + 3u), hb = list_hot_bytes(lshape, phase_is_local);
+            if (d.n_delta && (uint64_t)d.n_full * row_bytes + 48u + 8ull * d.n_delta <= hb) {
+                a.n_hot = d.n_full;
+                a.n_delta = d.n_delta;
+                a.delta = (const uint64_t *)d.delta.p;
+            } else {
+                a.n_hot = std::min<uint32_t>(d.n_delta ? d.n_full : d.n_states, (hb - 48u) / row_bytes);  // (states are in visit order: the first rows are the hot ones; 48 bytes stay free for the sentinel cell and lscan_async's dummy record)
+            }
+        }
         a.emit_off = (const uint32_t *)d.emit_off.p;
         a.emit_list = (const uint16_t *)d.emit_list.p;
         a.end_off = (const uint32_t *)d.end_off.p;
@@ -1303,7 +1380,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     std::vector<uint32_t> pass_base;
     for (size_t k = 0; k < P.groups.size(); k++) {
         if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k]))) return dev_fail(rc);
-        if ((rc = build_flat_group(P.groups[k], e->groups[k]))) return dev_fail(rc);
+        if ((rc = build_flat_group(P.groups[k], e->groups[k], P.groups[k].filter.enabled && P.groups[k].filter_cols.empty()))) return dev_fail(rc);
         pass_base.push_back(P.groups[k].atom_base);
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
@@ -1584,7 +1661,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list}) b->release(); }
+    for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list, &g.delta}) b->release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
                       &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
@@ -1955,7 +2032,7 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         if (T.mean_len[f] > 0) e->mean_len[f] = T.mean_len[f];
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &T.visits[k], &T.class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], &T.visits[k]))) return rc;
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &T.visits[k], &T.class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], e->groups[k].filter.enabled && P.groups[k].filter_cols.empty(), &T.visits[k]))) return rc;
     if ((rc = assign_lists(e))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;

@@ -83,6 +83,10 @@ struct ListScanArgs {
     const uint8_t *classmap;  // 256 bytes (+ 512: the empty-state rows, see chunk_bits)
     uint32_t n_classes;
     uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 3) * 2 <= the launch's ListShape::hot_bytes
+    // DELTA records (engine.cpp: build_flat_group): states [n_hot, n_hot + n_delta) live in LDS as 8 bytes each — base row (16 bits), two
+    // exception classes (8 bits each), their two cells (16 bits each); every other class reads the base row's cell. Null: none.
+    const uint64_t *delta;
+    uint32_t n_delta;
     const uint32_t *emit_off;  // [n_states + 1]
     const uint16_t *emit_list;
     const uint32_t *end_off;

@@ -695,6 +695,24 @@ __device__ __forceinline__ void lscan_local(const ListScanArgs &a, const uint16_
     }
 }
 
+// One step of a walk whose state may lie outside the LDS-resident rows: a DELTA record (kernels.h: ListScanArgs::delta — base row and
+// two exception cells, 8 bytes in LDS) or, failing that, the L2-resident flat table. `c` = the byte's class (n_classes + 1: past the
+// field's end, the state stays).
+__device__ __forceinline__ uint32_t list_step_slow(const uint16_t *hot, const PWAF_GLOBAL uint16_t *flat, const uint64_t *delta, const uint32_t state, const uint32_t c,
+                                                   const uint32_t stride, const uint32_t n_hot, const uint32_t n_delta) {
+    if (state < n_hot) return hot[state * stride + c];
+    const uint32_t k = state - n_hot;
+    if (k < n_delta) {
+        if (c + 2u == stride) return state;  // the STAY cell
+        const uint64_t rec = delta[k];
+        const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+        if (c == ((lo >> 16) & 0xFFu)) return hi & 0xFFFFu;
+        if (c == (lo >> 24)) return hi >> 16;
+        return hot[(lo & 0xFFFFu) * stride + c];
+    }
+    return flat[state * stride + c];
+}
+
 // A LONG list (more than an eighth of the batch: hostile traffic — near misses of the rule literals in most requests), walked with the
 // cold steps taken TOGETHER. In the lockstep loop below a group of four steps in which ANY of the 64 lanes meets a cold cell (a row
 // that is not LDS-resident: an L2 round trip) is re-walked step by step by the whole wave, and although a lane spends under a tenth
@@ -704,7 +722,7 @@ __device__ __forceinline__ void lscan_local(const ListScanArgs &a, const uint16_
 // waits — and when half the wave is waiting (or nobody else can move) ONE slow iteration takes the blocked lanes through their
 // group, cold cells from L2, while the others wait: a round trip then serves thirty lanes instead of one.
 template <uint32_t THREADS>
-__device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_t *hot, const unsigned char *cls, uint32_t it, const uint32_t it_end,
+__device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_t *hot, const unsigned char *cls, const uint64_t *delta, uint32_t it, const uint32_t it_end,
                                             const uint32_t first, const uint32_t n_l, const uint32_t hot_elems) {
     const uint32_t ncls = a.n_classes, stride = ncls + 3u;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
@@ -754,6 +772,9 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = k < cnt ? c[k] : ncls + 1u;
 #pragma unroll
+            // (A branch-free step that serves row states and delta-record states alike — record, then the cell of the row or of the
+            // record's base row, then the two exceptions: two dependent LDS reads for every lane — was measured: 4.9 ms against 3.1
+            // for the hostile stream's filtered passes. States without a row in LDS, records included, wait for the slow iteration.)
             for (uint32_t k = 0; k < 4; k++) {
                 t[k] = *reinterpret_cast<lds_u16_ptr>((uintptr_t)min(__umul24(k == 0 ? state : sv[k - 1], 2u * stride) + 2u * c[k], 2u * hot_elems));
                 sv[k] = t[k] & 0x7FFFu;
@@ -777,11 +798,7 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
                 // the slow iteration: the blocked lanes' group step by step, cold cells from the L2-resident table
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t idx = state * stride + c[k];
-                    uint32_t tg = 0;
-                    if (idx >= hot_elems) tg = flat[idx];
-                    const uint32_t tl = hot[min(idx, hot_elems)];
-                    const uint32_t tt = idx < hot_elems ? tl : tg;
+                    const uint32_t tt = list_step_slow(hot, flat, delta, state, c[k], stride, a.n_hot, a.n_delta);
                     state = tt & 0x7FFFu;
                     if (tt & 0x8000u) record_emit(state, h);
                 }
@@ -804,8 +821,9 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
 
 // LOCAL: the launch of the passes behind a bigram prefilter (lscan_local); else none is walked locally (one kernel with both loops
 // needs 85 vector registers: the 512-thread shape of the gap passes would lose a third of its waves).
+// (second bound: waves per SIMD — three 512-thread workgroups per CU need 6, i.e. at most 80 vector registers)
 template <uint32_t THREADS, bool LOCAL>
-__global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint32_t *plan, uint32_t hot_bytes) {
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(GatedTable b, const uint32_t *plan, uint32_t hot_bytes) {
     extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows + 16 bytes for the sentinel cell, then the 256-byte class map and the 512 bytes of empty-state rows
     __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lscan_lds != 0u) __builtin_trap();  // (no static LDS in this kernel: the walks address the hot rows by plain integer offsets)
@@ -826,6 +844,7 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         const ListScanArgs a = load_descriptor(&b.g[ps]);
         const uint32_t ncls = a.n_classes, stride = ncls + 3u;  // row: ncls transitions, the EMIT cell, the STAY cell, the END cell
         const uint32_t hot_elems = a.n_hot * stride;
+        uint64_t *delta_lds = reinterpret_cast<uint64_t *>(lscan_lds) + (hot_elems * 2u + 2u + 15u) / 16u * 2u;  // (16-byte aligned, behind the sentinel cell)
         __syncthreads();  // (every wave is done with the previous pass's rows)
         {
             // 16 bytes per lane and load, four loads in flight (a dword-per-lane loop of dependent load -> store pairs took a dozen L2
@@ -842,6 +861,8 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
                     if (k + q * THREADS < units) dst[k + q * THREADS] = v[q];
             }
             if (threadIdx.x < 192) lscan_lds[(hot_bytes + 16u) / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];  // class map + empty-state rows
+            // the delta records, behind the rows and the sentinel cell (the engine sized rows + 32 + records to fit hot_bytes)
+            for (uint32_t k = threadIdx.x; k < a.n_delta; k += THREADS) delta_lds[k] = a.delta[k];
         }
         __syncthreads();
         // the SENTINEL cell right behind the hot rows (after the barrier: the staging loop's last 16-byte unit may cover it): every
@@ -863,7 +884,7 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
         const bool long_list = a.behind_filter != 0u && (uint64_t)n_l * 8u >= a.n;
 #endif
         if (long_list) {  // (uniform) a prefilter's candidate list that holds more than an eighth of the batch: lscan_async
-            lscan_async<THREADS>(a, hot, cls, it, it_end, first, n_l, hot_elems);
+            lscan_async<THREADS>(a, hot, cls, delta_lds, it, it_end, first, n_l, hot_elems);
             it = it_end;
             continue;
         }
@@ -965,17 +986,9 @@ __global__ __launch_bounds__(THREADS) void lscan_kernel(GatedTable b, const uint
                             // a cold cell: the group step by step for both walks, cold cells from the L2-resident table
 #pragma unroll
                             for (uint32_t k = 0; k < 4; k++) {
-                                uint32_t idx[kListWalks], tg[kListWalks], tl[kListWalks];
 #pragma unroll
                                 for (uint32_t u = 0; u < kListWalks; u++) {
-                                    idx[u] = state[u] * stride + c[u][k];
-                                    tg[u] = 0;
-                                    if (idx[u] >= hot_elems) tg[u] = flat[idx[u]];
-                                    tl[u] = hot[min(idx[u], hot_elems)];
-                                }
-#pragma unroll
-                                for (uint32_t u = 0; u < kListWalks; u++) {
-                                    const uint32_t tt = idx[u] < hot_elems ? tl[u] : tg[u];
+                                    const uint32_t tt = list_step_slow(hot, flat, delta_lds, state[u], c[u][k], stride, a.n_hot, a.n_delta);
                                     state[u] = tt & 0x7FFFu;
                                     if (tt & 0x8000u) record_emit(state[u], h[u]);
                                 }
