@@ -512,6 +512,9 @@ def main():
                 "sample": f"first {sample_n} requests of the same batch, same rules; CPU restatement of the reference's interpreter loop "
                           f"(oracle/), {cores} threads; verdicts {'identical to' if same else 'DIFFERENT from'} the GPU's",
                 "verdicts_match_gpu": same,
+                # (what the figure is and is not: a like-for-like restatement — tree-walking evaluator, Pike-VM regex, linear CIDR
+                # scans — not a tuned CPU engine; the reference's Rust interpreter with the lazy-DFA regex crate is faster per core)
+                "note": "like-for-like port of the reference's per-request rule loop, not a tuned CPU engine: a reported baseline, not the target",
             }
         result["timing_notes"] = {"generate_s": round(t_gen, 2), "compile_upload_tune_s": round(t_compile, 2)}
         print(json.dumps(result))
