@@ -240,3 +240,27 @@ def test_localized_walks_keep_every_verdict(seed):
 
 
 _LOCAL_STEPS = []
+
+
+def test_reach_and_quiet_states_of_a_filtered_pass():
+    """What the localized walks rest on, as the compiler reports it (dump section GLOC): the reach of a pass is the longest distance
+    from a match's first byte to the end of its factor — the literal's length for a plain literal, unbounded as soon as one pattern
+    puts an unbounded repeat before its factor — and the DFA has an empty state for every byte kind plus the quiet successors."""
+    def one(rules):
+        t = table_walker.Tables(CompiledProgram(rules, {}).dump())
+        return [g for g in t.groups if "f_table" in g][0]
+
+    g = one([("a", 'http_request.path.contains("/wp-admin/x")', [H.B]), ("b", 'http_request.path.ends_with(".php5")', [H.B])])
+    assert 5 <= g["f_reach"] <= len("/wp-admin/x")  # (the end of the chosen factor — a prefix of the literal may be the cheaper window)
+    # a bounded repeat before the factor is counted, an unbounded one is not bounded
+    g = one([("a", 'http_request.path.matches("ab[0-9]{1,3}/x9k2q")', [H.B])])
+    assert 7 <= g["f_reach"] <= 2 + 3 + len("/x9k2q")
+    g = one([("a", 'http_request.path.matches("^/api/v[0-9]+/zz9k2")', [H.B])])
+    assert g["f_reach"] in (t_unb := table_walker.Tables.UNBOUNDED, len("/api/v") + 1)  # (either the anchored prefix, bounded, or the rare word behind the repeat)
+    # empty states: one per byte kind in use, all of them quiet, and the start state is none of them
+    g = one([("a", 'http_request.path.matches("\\\\bselect\\\\b.{0,8}from")', [H.B]), ("b", 'http_request.path.contains("union")', [H.B])])
+    empties = [s for s in g["empty_state"] if s != 0xFFFF]
+    assert len(empties) >= 2 and 0 not in empties and all(g["quiet"][s] for s in empties)
+    assert 0 < int(np.sum(g["quiet"])) < g["n_states"]
+    for s in empties:  # what one byte makes of an empty state is quiet too
+        assert all(g["quiet"][int(x)] for x in g["trans"][s])
