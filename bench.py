@@ -167,7 +167,22 @@ def native_batcher_bench(eng, hb):
         return None
 
 
-def config5_leg(dev, threads, steps, verbose):
+def oracle_check(wl, host_prefix, gpu_out, cores):
+    """The CPU oracle on a prefix of a timed batch against the verdicts the GPU wrote for it (the checker, never the thing measured)."""
+    import numpy as np
+
+    from oracle import pyoracle
+
+    t0 = time.perf_counter()
+    cpu_v = pyoracle.Oracle(wl.rules, wl.lists, wl.geoip).evaluate(host_prefix, threads=cores)
+    dt = time.perf_counter() - t0
+    gpu_v = gpu_out[: host_prefix.n].cpu().numpy().view(np.uint32)
+    same = bool((gpu_v[:, 0] == cpu_v["action"]).all() and (gpu_v[:, 1] == cpu_v["rule_idx"]).all())
+    return {"verdicts_match_gpu": same, "oracle_sample": f"first {host_prefix.n} requests of the timed batch, {cores} threads, {dt:.1f} s",
+            "oracle_non_allow_in_sample": int(np.count_nonzero(cpu_v["action"]))}
+
+
+def config5_leg(dev, threads, steps, verbose, check_adversarial=True):
     """BASELINE.json configs[4] on one GPU, short: 4096 rules over 5 + 64 string fields, 1M-request batches (the per-GPU batch of the
     50M-request / 8-GPU configuration is 6.25M: `--config 5 --requests 6250000` times that). Tuned on a benign sample."""
     import torch
@@ -190,11 +205,16 @@ def config5_leg(dev, threads, steps, verbose):
     out.update({"requests_per_s": head["requests_per_s"], "ms_per_step": head["ms_per_step"], "kernel": head["kernel"], "frac": head["frac"],
                 "kernels_ms_per_step": head["kernels_ms_per_step"], "action_counts_allow_block_captcha_bypass": cnt})
     out["latency_ms"] = dict(r.batch_latency(db, 40), batch=n, calls=40)
-    adv = DeviceBatch(wl.batch(0, n, threads=threads, adversarial=True), dev)
+    adv_host = wl.batch(0, n, threads=threads, adversarial=True)
+    adv = DeviceBatch(adv_host, dev)
     el, kt, acnt = r.timed_run(adv, max(2, steps // 2), 1)
     a = r.mode_summary(el, kt, max(2, steps // 2))
     out["adversarial"] = {"requests_per_s": a["requests_per_s"], "ms_per_step": a["ms_per_step"], "frac": a["frac"], "kernels_ms_per_step": a["kernels_ms_per_step"],
-                          "latency_ms": r.batch_latency(adv, 20), "action_counts_allow_block_captcha_bypass": acnt}
+                          "action_counts_allow_block_captcha_bypass": acnt}
+    if check_adversarial:  # (before the latency calls: they write the same output buffer — with the same verdicts)
+        out["adversarial"].update(oracle_check(wl, adv_host.slice(0, min(n, 12_000)), r.outs[0], os.cpu_count() or 1))
+    out["adversarial"]["latency_ms"] = r.batch_latency(adv, 20)
+    del adv_host
     out["adversarial_over_benign"] = a["ms_per_step"] / head["ms_per_step"]
     out["setup_s"] = round(time.time() - t0, 1)
     del adv, db
@@ -243,10 +263,12 @@ def main():
     torch.cuda.set_device(local)
     shard.init_process_group()
     dev = torch.device("cuda", local)
-    # the world size the counters' all-reduce actually sees (1 = no collective ran)
+    # the world size the counters' all-reduce runs over: under torch.distributed.run a process group exists at every world size (1
+    # included) and every step ends in one RCCL all-reduce; started plainly at N = 1 there is none during the timed steps (0 here) and
+    # ONE all-reduce of the final counters runs after them (`rccl_single_rank_check` below)
     ones = torch.ones(1, dtype=torch.int64, device=dev)
     shard.allreduce_counts(ones)
-    rccl_ranks = int(ones.item())
+    rccl_ranks = int(ones.item()) if shard.collective_world() else 0
 
     n = args.requests or DEFAULT_N.get(args.config, 100_000)
     threads = max(1, (os.cpu_count() or 1) // world)
@@ -308,11 +330,16 @@ def main():
         traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * k2 / el, "ms_per_step": 1e3 * el / k2, "host_enqueue_ms_per_step": round(R.issue_ms, 3)}
     if extras and not args.adversarial:
         phase("adversarial run")
-        adv = DeviceBatch(wl.batch(rank * n, n, threads=threads, adversarial=True), dev)
+        adv_host = wl.batch(rank * n, n, threads=threads, adversarial=True)
+        adv = DeviceBatch(adv_host, dev)
         ka = max(2, args.steps // 2)
         el, kt, adv_counts = R.timed_run(adv, ka, 1)
         traffic_modes["adversarial_tuned_on_benign"] = dict(R.mode_summary(el, kt, ka), action_counts_allow_block_captcha_bypass=adv_counts)
-        del adv
+        if rank == 0 and not args.no_cpu_baseline:
+            # the hostile batch's verdicts against the CPU oracle too (only the benign headline was): a bounded prefix
+            phase("adversarial oracle check")
+            traffic_modes["adversarial_tuned_on_benign"].update(oracle_check(wl, adv_host.slice(0, min(n, 60_000)), R.outs[0], os.cpu_count() or 1))
+        del adv, adv_host
     traffic_modes["tuned_benign" if not args.adversarial else "adversarial_tuned_on_benign (headline)"] = head
 
     rules_desc = {3: "1k-rule WAF", 5: "4096-rule bot-protection set, 64 header fields (extension)"}.get(args.config, f"{len(wl.rules)}-rule set")
@@ -483,7 +510,7 @@ def main():
             phase("config 5 leg")
             # (the 10M-request batch and its scratch stay resident: config 5 adds ~6 GB)
             try:
-                result["config5"] = config5_leg(dev, threads, max(4, args.steps), args.verbose)
+                result["config5"] = config5_leg(dev, threads, max(4, args.steps), args.verbose, check_adversarial=not args.no_cpu_baseline)
             except Exception as exc:  # the headline line must survive a failure of the side leg
                 result["config5"] = {"error": repr(exc)}
         # ---- CPU baseline: the oracle (port of the reference's per-request interpreter loop) on host cores ----
@@ -517,8 +544,20 @@ def main():
                 "note": "like-for-like port of the reference's per-request rule loop, not a tuned CPU engine: a reported baseline, not the target",
             }
         result["timing_notes"] = {"generate_s": round(t_gen, 2), "compile_upload_tune_s": round(t_compile, 2)}
+        if world == 1 and shard.collective_world() == 0:
+            # a plain single process: the RCCL wiring exercised once, outside the timed region — a process group of one rank, the final
+            # counters all-reduced (the sum over one rank is the counters themselves)
+            try:
+                shard.init_process_group(always=True)
+                t = torch.tensor(final_counts, dtype=torch.int64, device=dev)
+                shard.allreduce_counts(t)
+                torch.cuda.synchronize(dev)
+                result["rccl_single_rank_check"] = {"world": shard.collective_world(), "counters_unchanged": t.cpu().tolist() == final_counts}
+                torch.distributed.destroy_process_group()
+            except Exception as exc:  # informational: the headline line must survive
+                result["rccl_single_rank_check"] = {"error": repr(exc)}
         print(json.dumps(result))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -6,6 +6,7 @@
 // thread closes a batch when it is full or when its oldest request has waited max_delay_us, runs it through
 // pwaf_evaluate_batch (the same kernels as everything else) and wakes the callers with their verdicts.
 // Plain C++17 on top of the public C ABI: no device code, no access to engine internals.
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -199,17 +200,23 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
                     // Transactional append: every column first gets the CAPACITY it needs — the only step that can throw —
                     // and only then the request's values; a std::bad_alloc can no longer leave the shared batch's columns with
                     // different lengths (every later request of that batch would have been evaluated with shifted offsets).
+                    // (capacity grows GEOMETRICALLY: libstdc++'s reserve(n) allocates exactly n, so asking for size + len per request
+                    // reallocated and copied every column on every append — O(n^2) bytes per batch under the batcher's mutex)
+                    auto grow = [](auto &v, size_t extra) {
+                        const size_t need = v.size() + extra;
+                        if (v.capacity() < need) v.reserve(std::max(need, 2 * v.capacity()));
+                    };
                     for (size_t f = 0; f < n_cols; f++) {
-                        t.data[f].reserve(t.data[f].size() + len[f] + PWAF_ARENA_PAD);
-                        t.offs[f].reserve(t.offs[f].size() + 1);
+                        grow(t.data[f], len[f] + PWAF_ARENA_PAD);
+                        grow(t.offs[f], 1);
                     }
-                    t.ip.reserve(t.ip.size() + 16);
-                    t.v6.reserve(t.v6.size() + 1);
-                    t.flags.reserve(t.flags.size() + 1);
-                    t.port.reserve(t.port.size() + 1);
+                    grow(t.ip, 16);
+                    grow(t.v6, 1);
+                    grow(t.flags, 1);
+                    grow(t.port, 1);
                     if (r->has_geoip) {
-                        t.asn.reserve(t.asn.size() + 1);
-                        t.country.reserve(t.country.size() + 1);
+                        grow(t.asn, 1);
+                        grow(t.country, 1);
                     }
                     for (size_t f = 0; f < n_cols; f++) {
                         t.data[f].insert(t.data[f].end(), (const uint8_t *)ptr[f], (const uint8_t *)ptr[f] + len[f]);

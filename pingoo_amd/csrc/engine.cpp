@@ -1206,9 +1206,11 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ResidualArgs ra{};
         const size_t nc = e->n_fields;
         if ((rc = S.res_cols.reserve(nc * 16))) return rc;
-        std::vector<const void *> ptrs(2 * nc);
-        for (size_t f = 0; f < nc; f++) { ptrs[f] = cols[f].data; ptrs[nc + f] = cols[f].offsets; }
-        HIP_TRY(hipMemcpyAsync(S.res_cols.p, ptrs.data(), nc * 16, hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+        ColPtrChunk ptrs{};  // (travels as the argument of a store launch: stream-ordered, the caller is not blocked — ADVICE r3)
+        ptrs.count = (uint32_t)(2 * nc);
+        for (size_t f = 0; f < nc; f++) { ptrs.p[f] = cols[f].data; ptrs.p[nc + f] = cols[f].offsets; }
+        int he0 = upload_col_ptrs(ptrs, S.res_cols.p, stream);
+        if (he0) return fail(PWAF_E_DEVICE, std::string("column table upload failed: ") + hipGetErrorString((hipError_t)he0));
         ra.data = (const uint8_t *const *)S.res_cols.p;
         ra.off = (const uint32_t *const *)((const char *)S.res_cols.p + nc * 8);
         ra.blob = (const uint8_t *)e->residual_blob.p;

@@ -232,6 +232,13 @@ struct ResidualArgs {
     uint32_t *status;
 };
 int launch_residual(const ResidualArgs &a, void *stream);
+// The batch's string-column pointer table (ResidualArgs::data / off) on its way to device memory: the by-value argument of a store
+// launch, like the pass descriptors (a hipMemcpyAsync from pageable host memory blocks the caller and cannot be captured in a graph).
+struct ColPtrChunk {
+    const void *p[2 * (PWAF_N_FIELDS + kMaxHeaders)];
+    uint32_t count;
+};
+int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream);
 struct CmpAtomDev {
     uint32_t col, c;
 };

@@ -1086,6 +1086,11 @@ int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, 
     return 0;
 }
 
+int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream) {
+    hipLaunchKernelGGL((store_args_kernel<ColPtrChunk, const void *>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, reinterpret_cast<const void **>(dev));
+    return (int)hipGetLastError();
+}
+
 static const void *lscan_fn(bool wide, bool local) {
     return wide ? (local ? reinterpret_cast<const void *>(lscan_kernel<1024, true>) : reinterpret_cast<const void *>(lscan_kernel<1024, false>))
                 : (local ? reinterpret_cast<const void *>(lscan_kernel<512, true>) : reinterpret_cast<const void *>(lscan_kernel<512, false>));

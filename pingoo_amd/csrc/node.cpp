@@ -107,14 +107,17 @@ int pwaf_node_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_lis
         o = *opts;
     }
     pwaf_node *nd = new pwaf_node();
+    bool partial = false;  // PWAF_OPT_LENIENT dropped a rule (PWAF_W_PARTIAL, a positive status: the engine exists)
     for (size_t k = 0; k < n_devices; k++) {
         o.device = devices[k];
         pwaf_engine *e = nullptr;
         int rc = pwaf_engine_create(rules, n_rules, lists, n_lists, geoip, &o, &e, err);  // tables are replicated: tens of MB per device
-        if (rc) {
+        if (rc < 0) {
+            if (e) pwaf_engine_destroy(e);
             pwaf_node_destroy(nd);
             return rc;
         }
+        partial = partial || rc == PWAF_W_PARTIAL;
         nd->engines.push_back(e);
         nd->devices.push_back(devices[k]);
     }
@@ -124,7 +127,7 @@ int pwaf_node_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_lis
         w->th = std::thread([w] { w->run(); });
     }
     *out = nd;
-    return PWAF_OK;
+    return partial ? PWAF_W_PARTIAL : PWAF_OK;
 }
 
 void pwaf_node_destroy(pwaf_node *nd) {

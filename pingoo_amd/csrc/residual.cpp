@@ -32,6 +32,7 @@ struct Info {
     uint32_t seg = 1;     // most rope segments a String in (or being) this value can have
     uint32_t nest = 0;    // deepest list / map nesting
     uint32_t len = 0;     // most items if it is a list
+    uint32_t inner = 0;   // most items of any list / map INSIDE this value (what an index or a member access can bring to the top)
 };
 }  // namespace
 
@@ -155,6 +156,7 @@ struct ResidualBuilder::Impl {
         r.seg = std::max(a.seg, b.seg);
         r.nest = std::max(a.nest, b.nest);
         r.len = std::max(a.len, b.len);
+        r.inner = std::max(a.inner, b.inner);
         return r;
     }
     static void no_ctx(const Info &i, const char *what) {
@@ -236,7 +238,7 @@ struct ResidualBuilder::Impl {
                 no_clist(o, "member access");
                 emit(R_SELECT, 0, add_const(mk(T_STR, (uint32_t)e.text.size(), ((uint64_t)S_CONST << 48) | str_const(e.text))));
                 r = o;
-                r.len = 0;
+                r.len = std::max(o.len, o.inner);  // (a member of a map may be any list nested in it: ADVICE r3 — `{"k": [..]}.k + ..` was charged 0 items)
                 return r;
             }
             case EX_INDEX: {
@@ -254,7 +256,7 @@ struct ResidualBuilder::Impl {
                 pop();
                 r = o;
                 r.clist = false;
-                r.len = o.len;  // (an item of a list of lists: bounded by the outer bound — conservative)
+                r.len = std::max(o.len, o.inner);  // (an item may be any list nested in the receiver, which can be LONGER than the receiver: `[[1, .., 20]][0]`)
                 return r;
             }
             case EX_GCALL: push_err(); return r;  // undeclared function
@@ -270,6 +272,7 @@ struct ResidualBuilder::Impl {
                 }
                 r.nest += 1;
                 if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+                r.inner = std::max(r.inner, r.len);  // (merge() has left the longest item in r.len)
                 r.len = n;
                 r.clist = false;
                 use_heap(n);
@@ -292,6 +295,7 @@ struct ResidualBuilder::Impl {
                 }
                 r.nest += 1;
                 if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+                r.inner = std::max(r.inner, r.len);
                 r.len = n;
                 use_heap(2 * n);
                 emit(R_MKMAP, 0, n);
@@ -434,6 +438,7 @@ struct ResidualBuilder::Impl {
             r.seg = l.seg + rr.seg;
             if (r.seg > kMaxRope) throw Reject{"a concatenation of more than " + std::to_string(kMaxRope) + " strings"};
             r.len = l.len + rr.len;
+            r.inner = std::max(l.inner, rr.inner);
             r.nest = std::max(l.nest, rr.nest);
             use_heap(std::max(r.seg, r.len));
         }

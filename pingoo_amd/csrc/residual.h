@@ -393,7 +393,7 @@ PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
                 bool err = false;
                 for (uint32_t k = 0; k < n; k++) err = err || st[sp - n + k].t == T_ERR;
                 Val v = ERR;
-                if (!err) {
+                if (!err && m.heap_n + n <= kHeap) {  // (the compiler bounds heap use statically; the checks here are the safety net behind it)
                     v = mk(T_LIST, n, kHeapBit | m.heap_n);
                     for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = st[sp - n + k];
                 }
@@ -406,7 +406,7 @@ PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
                 bool err = false;
                 for (uint32_t k = 0; k < 2 * n; k++) err = err || st[sp - 2 * n + k].t == T_ERR || ((k & 1) == 0 && st[sp - 2 * n + k].t != T_STR);
                 Val v = ERR;
-                if (!err) {
+                if (!err && m.heap_n + 2 * n <= kHeap) {
                     const uint32_t base = m.heap_n;
                     uint32_t cnt = 0;
                     for (uint32_t k = 0; k < n; k++) {
@@ -539,6 +539,10 @@ PWAF_HD Val arith(uint32_t op, const Val &l, const Val &r, Machine &m) {
         if (r.a == 0) return l;
         const uint32_t first = m.heap_n;
         uint32_t n = 0;
+        {
+            const uint32_t nl = str_src(l) == S_ROPE ? (uint32_t)((l.p >> 24) & 0xFFu) : 1u, nr = str_src(r) == S_ROPE ? (uint32_t)((r.p >> 24) & 0xFFu) : 1u;
+            if (first + nl + nr > kHeap) return ERR;
+        }
         for (int side = 0; side < 2; side++) {
             const Val &s = side == 0 ? l : r;
             if (str_src(s) == S_ROPE) {
@@ -553,6 +557,7 @@ PWAF_HD Val arith(uint32_t op, const Val &l, const Val &r, Machine &m) {
     }
     if (op == 9 && l.t == T_LIST && r.t == T_LIST) {
         const uint32_t first = m.heap_n;
+        if (first + l.a + r.a > kHeap) return ERR;
         const Val *a = items_of(m, l), *b = items_of(m, r);
         for (uint32_t k = 0; k < l.a; k++) m.heap[m.heap_n++] = a[k];
         for (uint32_t k = 0; k < r.a; k++) m.heap[m.heap_n++] = b[k];

@@ -427,8 +427,9 @@ class NodeEngine:
         err = _abi.CompileError()
         devs = (C.c_int * len(devices))(*devices)
         rc = L.pwaf_node_create(r, nr, l, nl, g, C.byref(o), devs, len(devices), C.byref(h), C.byref(err))
-        if rc != 0:
+        if rc < 0:
             _raise(rc, err.message.decode(errors="replace") or L.pwaf_last_error().decode(errors="replace"), None if err.rule_index == 0xFFFFFFFF else err.rule_index)
+        self.partial = rc == _abi.W_PARTIAL  # PWAF_OPT_LENIENT dropped a rule (see the program's rule status / warnings)
         self._h = h
         e0 = L.pwaf_node_engine(h, 0)
         self.header_names = [L.pwaf_engine_header_name(e0, i).decode() for i in range(L.pwaf_engine_header_count(e0))]
@@ -454,6 +455,17 @@ class NodeEngine:
         c = (C.c_void_p * k)(*[t.data_ptr() for t in counts]) if counts is not None else None
         st = (C.c_void_p * k)(*[int(x) for x in streams]) if streams is not None else None
         rc = lib().pwaf_node_evaluate_device(self._h, arr, o, c, st)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+
+    def allreduce_counts(self, comms, counts, streams=None) -> None:
+        """pwaf_node_allreduce_counts: the per-device int64[4] counter tensors summed in place over RCCL; `comms` = one ncclComm_t
+        (integer handle) per device, e.g. from ncclCommInitAll."""
+        k = len(counts)
+        cm = (C.c_void_p * k)(*[int(x) for x in comms])
+        c = (C.c_void_p * k)(*[t.data_ptr() for t in counts])
+        st = (C.c_void_p * k)(*[int(x) for x in streams]) if streams is not None else None
+        rc = lib().pwaf_node_allreduce_counts(self._h, cm, c, st)
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
 

@@ -29,16 +29,25 @@ def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend: str | None = None):
-    """Initialises torch.distributed from the env when WORLD_SIZE > 1. nccl == RCCL on ROCm."""
+def init_process_group(backend: str | None = None, always: bool = False):
+    """Initialises torch.distributed from the env. nccl == RCCL on ROCm. A process group is created whenever the process was started
+    by torch.distributed.run (RANK is set) — also at world size 1, so that the counters' all-reduce is a collective that really runs —
+    or when `always` asks for one (a plain single process: rank 0 of a world of 1 on a free local port)."""
     import torch
     import torch.distributed as dist
 
     rank, world, local = env_rank()
-    if world == 1 or dist.is_initialized():
+    if dist.is_initialized():
+        return rank, world, local
+    if world == 1 and "RANK" not in os.environ and not always:
         return rank, world, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+
+        with socket.socket() as s:  # (only reached without a launcher: a single process picks its own port)
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
@@ -50,9 +59,17 @@ def init_process_group(backend: str | None = None):
 
 
 def allreduce_counts(counts):
-    """Sums the per-rank action counters (int64 tensor [4] on the rank's device) in place across ranks."""
+    """Sums the per-rank action counters (int64 tensor [4] on the rank's device) in place across ranks: one collective per call
+    whenever a process group exists (world size 1 included: the sum of one rank's counters is those counters)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
+
+
+def collective_world() -> int:
+    """The world size the counters' all-reduce runs over; 0 = no process group, no collective is called."""
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0

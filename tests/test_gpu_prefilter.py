@@ -297,12 +297,12 @@ def test_every_request_a_candidate_at_one_million():
     rules = [("a", 'http_request.path.contains("/.env")', [B]), ("b", 'http_request.url.contains("zz9=1") || http_request.url.matches("(?i)union\\\\s+select")', [CAP]),
              ("c", 'http_request.user_agent.contains("sqlmap")', [B])]
     pool = []
-    for _ in range(4096):
+    for _ in range(32768):
         pad = H.rstr(rng, 5, 120, "abcdefxyz/.=-_%0123456789")
         path = "/" + pad + rng.choice(["/.env", "/.en", "/.envx", "/.e"]) + (H.rstr(rng, 0, 40, "abc/") if rng.random() < 0.5 else "")
         url = path + "?" + pad + rng.choice(["zz9=1", "zz9=", "zz9", "union select", "UNION  SELECT", "union+select", "unionselect"]) + H.rstr(rng, 0, 60, "abc&=")
         pool.append(Request(path=path[:250], url=url[:500], host="h", user_agent=rng.choice(["sqlmap/1.7", "sqlma", "Mozilla/5.0 sqlmap", "curl/8"]) + pad[:40]))
-    reqs = [pool[i % 4096] for i in range(1_000_000)]
+    reqs = [pool[i % 32768] for i in range(1_000_000)]
     batch = RequestBatch.from_requests(reqs)
     eng = RuleEngine(rules)
     plain = RuleEngine(rules, flags=_abi.OPT_NO_PREFILTER)
@@ -310,7 +310,32 @@ def test_every_request_a_candidate_at_one_million():
     b = plain.evaluate_batch(batch)
     assert np.array_equal(a["action"], b["action"]) and np.array_equal(a["rule_idx"], b["rule_idx"])
     assert counts.tolist() == np.bincount(a["action"], minlength=4).tolist() and len(set(a["action"].tolist())) >= 3
-    head = batch.slice(0, 4096)
-    H.assert_verdicts_equal(a[:4096], pyoracle.Oracle(rules).evaluate(head), head, "oracle prefix")
+    # the oracle on 20 000 requests drawn from the WHOLE batch (the first 4 096 are one pass through the pool; positions deep
+    # in the lists, at other arena alignments, are what lscan_async's later work items see)
+    pick = np.sort(np.random.default_rng(7).choice(len(reqs), 20000, replace=False))
+    sample = RequestBatch.from_requests([reqs[int(i)] for i in pick])
+    want = pyoracle.Oracle(rules).evaluate(sample, threads=8)
+    H.assert_verdicts_equal(a[pick], want, sample, "oracle on a random 20k sample")
     eng.close()
     plain.close()
+
+
+def test_config3_adversarial_stream_tuned_on_benign_vs_oracle():
+    """BASELINE.json configs[2] rule set (1024 rules, 200 regex, CIDR lists, GeoIP) on its HOSTILE stream (near misses of the rule
+    literals, maximum-length fields): the engine is tuned on benign traffic — the attacker picks the traffic, not the tuning sample —
+    and its verdicts on 24 000 hostile requests are the oracle's (mirror of the config-5 test above; VERDICT r3 weak #1b)."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
+    hostile = w.batch(250_000, 24000, adversarial=True)
+    want = orc.evaluate(hostile, threads=16)
+    got, counts = eng.evaluate_batch(hostile, with_counts=True)
+    H.assert_verdicts_equal(got, want, hostile, "config 3 adversarial, untuned")
+    eng.tune(w.batch(5_000_000, 32768))
+    got, counts = eng.evaluate_batch(hostile, with_counts=True)
+    H.assert_verdicts_equal(got, want, hostile, "config 3 adversarial, tuned on benign")
+    assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+    assert np.count_nonzero(want["action"]) > 100
+    eng.close()

@@ -335,3 +335,38 @@ def test_dnf_explosion_falls_to_the_interpreter():
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, "DNF explosion")
     assert len(set(want["rule_idx"].tolist())) >= 2
+
+
+def test_heap_use_of_indexed_nested_literals_is_charged_in_full():
+    """`[[1..20]][0] + [[1..20]][0]` — the item an index (or a member access) brings to the top can be LONGER than its
+    receiver, and the concatenation copies it: the compiler charged 44 of the 64 heap slots and the interpreter wrote 82. Now the bound
+    follows the nested lengths: what fits evaluates like the oracle, what does not is refused at compile time — never overrun."""
+    inner = "[" + ", ".join(str(k) for k in range(1, 21)) + "]"
+    rng = random.Random(77)
+    batch = RequestBatch.from_requests([Request(host="h", path="/p", user_agent="ua", remote_port=p) for p in (1, 20, 21, 40)])
+    flags = _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS
+    refused = accepted = 0
+    exprs = [f"([{inner}][0] + [{inner}][0]).contains(client.remote_port)",                    # 20 + 20 + 40 copied = 82 > 64: refused
+             f'({{"k": {inner}}}.k + {{"k": {inner}}}.k).contains(client.remote_port)',         # same through a map member
+             "([[1, 2, 3, 4, 5, 6]][0] + [[20, 21]][0]).contains(client.remote_port)",          # small: runs
+             '({"k": [1, 2, 3]}.k + [[40], [20, 21]][1]).contains(client.remote_port)']
+    for _ in range(60):  # random nestings, indexed and concatenated
+        def lit(depth):
+            if depth == 0 or rng.random() < 0.3:
+                return str(rng.randint(0, 45))
+            return "[" + ", ".join(lit(depth - 1) for _ in range(rng.randint(1, 9))) + "]"
+        a, b = "[" + ", ".join(lit(2) for _ in range(rng.randint(1, 4))) + "]", "[" + ", ".join(lit(2) for _ in range(rng.randint(1, 4))) + "]"
+        exprs.append(f"({a}[0] + {b}[{rng.randint(0, 1)}]).contains(client.remote_port)")
+    for e in exprs:
+        try:
+            m = HostVM([e])
+        except ValueError as why:
+            assert "per request" in str(why), (e, why)
+            refused += 1
+            continue
+        accepted += 1
+        m.bind(batch)
+        orc = pyoracle.Oracle([("r", e, [H.B])], flags=flags)
+        for i in range(batch.n):
+            assert m.eval(0, i) == (orc.execute_rule(0, batch, i) == 1), (e, i)
+    assert refused >= 2 and accepted >= 10, (refused, accepted)

@@ -100,3 +100,34 @@ def test_bench_self_launch_becomes_one_rank_per_gpu(monkeypatch):
     assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
     script = argv.index(os.path.abspath(bench.__file__))
     assert argv[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+
+def _single_rank_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from pingoo_amd import shard
+
+    before = shard.collective_world()
+    shard.init_process_group("gloo")  # what torch.distributed.run --nproc-per-node 1 sets up: a group of one rank
+    t = torch.tensor([5, 6, 7, 8], dtype=torch.int64)
+    shard.allreduce_counts(t)
+    q.put((before, shard.collective_world(), dist.is_initialized(), t.tolist()))
+    dist.destroy_process_group()
+
+
+def test_world_size_one_under_a_launcher_still_runs_the_collective():
+    """with RANK in the environment (torch.distributed.run --nproc-per-node 1) a process group exists and the
+    counters go through dist.all_reduce — `rccl_ranks: 1` then means a collective ran; a plain process has none (collective_world 0)."""
+    from pingoo_amd import shard
+
+    assert shard.collective_world() == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(29900 + (os.getpid() % 90), q))
+    p.start()
+    before, world, inited, vals = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert before == 0 and world == 1 and inited and vals == [5, 6, 7, 8]
