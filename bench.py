@@ -45,6 +45,28 @@ def pct(xs, p):
     return xs[min(len(xs) - 1, int(round(p / 100.0 * (len(xs) - 1))))]
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on the C library's stdout when a communicator is created; the bench's stdout carries ONE JSON line.
+    While this is active file descriptor 1 is stderr (C stdio flushed on the way out)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def self_launch(args_list, n):
     """`python bench.py --gpus N` as a plain command: become N ranks (one per GPU) under torch.distributed.run."""
     with socket.socket() as s:
@@ -261,13 +283,16 @@ def main():
     if local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({torch.cuda.device_count()} visible): --gpus {world} needs {world} GPUs on this node")
     torch.cuda.set_device(local)
-    shard.init_process_group()
     dev = torch.device("cuda", local)
+    with stdout_to_stderr():
+        shard.init_process_group()
     # the world size the counters' all-reduce runs over: under torch.distributed.run a process group exists at every world size (1
     # included) and every step ends in one RCCL all-reduce; started plainly at N = 1 there is none during the timed steps (0 here) and
     # ONE all-reduce of the final counters runs after them (`rccl_single_rank_check` below)
     ones = torch.ones(1, dtype=torch.int64, device=dev)
-    shard.allreduce_counts(ones)
+    with stdout_to_stderr():  # (the first collective creates the communicator)
+        shard.allreduce_counts(ones)
+        torch.cuda.synchronize(dev)
     rccl_ranks = int(ones.item()) if shard.collective_world() else 0
 
     n = args.requests or DEFAULT_N.get(args.config, 100_000)
@@ -548,12 +573,13 @@ def main():
             # a plain single process: the RCCL wiring exercised once, outside the timed region — a process group of one rank, the final
             # counters all-reduced (the sum over one rank is the counters themselves)
             try:
-                shard.init_process_group(always=True)
-                t = torch.tensor(final_counts, dtype=torch.int64, device=dev)
-                shard.allreduce_counts(t)
-                torch.cuda.synchronize(dev)
-                result["rccl_single_rank_check"] = {"world": shard.collective_world(), "counters_unchanged": t.cpu().tolist() == final_counts}
-                torch.distributed.destroy_process_group()
+                with stdout_to_stderr():
+                    shard.init_process_group(always=True)
+                    t = torch.tensor(final_counts, dtype=torch.int64, device=dev)
+                    shard.allreduce_counts(t)
+                    torch.cuda.synchronize(dev)
+                    result["rccl_single_rank_check"] = {"world": shard.collective_world(), "counters_unchanged": t.cpu().tolist() == final_counts}
+                    torch.distributed.destroy_process_group()
             except Exception as exc:  # informational: the headline line must survive
                 result["rccl_single_rank_check"] = {"error": repr(exc)}
         print(json.dumps(result))

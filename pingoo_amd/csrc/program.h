@@ -116,6 +116,39 @@ struct FilterHead {
     uint16_t local;  // local atom id in the pass
 };
 static constexpr uint32_t kUnboundedReach = 0xFFFFFFFFu;
+
+// ---- the CONFIRM tier of a filtered pass (round 4; filter.cpp builds it, confirm.h evaluates it on the host and on the device) ----
+// The bigram filter flags a 16-byte chunk when some position of it completes a WINDOW (<= 4 sampled bigrams) of some factor; a window
+// covers five to eight bytes of a factor that may be sixty long, so traffic made of near misses of the rule literals — what an
+// attacker sends — passes the filter and used to be walked through the pass's DFA, deep into states no LDS copy holds. The confirm
+// tier looks at the flagged position itself: the bigram there selects (by its filter bin) the few factors whose window can END
+// there, and each is compared in full, byte for byte, at the place the window implies. What that decides:
+//   * an atom that IS a literal (contains / starts_with / ends_with / == of a constant: `confirm_literal`) is decided exactly —
+//     it never needs a DFA — and lands in the request's hit record;
+//   * any other atom (a regex) is known NOT to match unless one of its necessary factors was confirmed; only then is the request
+//     walked, through a DFA of the pass's non-literal atoms alone (DfaGroup::rtier), which is a fraction of the full table.
+// Entry e of bin b (head[b] = first | count << 20): the factor `bytes` (len value bytes, len mask bytes — ((text ^ value) & mask) == 0
+// per position, a zero mask where the position is a byte CLASS — then n_cls x {position, class id}) begins d bytes before the
+// flagged position; atom = the local atom it decides (0xFFFF: an R entry — "a regex factor is here: walk").
+struct ConfirmEntry {
+    uint32_t bytes_off;  // into ConfirmTable::bytes (4-byte aligned)
+    uint16_t len, d;
+    uint16_t atom;       // local atom id, or kConfirmWalk
+    uint8_t flags;       // kConfirmAtStart: the factor must begin at the field's first byte; kConfirmAtEnd: it must end at its last
+    uint8_t n_cls;
+};
+static_assert(sizeof(ConfirmEntry) == 12, "ConfirmEntry layout");
+static constexpr uint16_t kConfirmWalk = 0xFFFFu;
+static constexpr uint8_t kConfirmAtStart = 1, kConfirmAtEnd = 2;
+struct ConfirmTable {
+    bool enabled = false;
+    bool has_walk = false;               // some entry is an R entry: the pass keeps a DFA (of its R atoms)
+    std::vector<uint32_t> head;          // kFilterEntries
+    std::vector<ConfirmEntry> entries;   // grouped by bin
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> classes;       // 8 words (256 bits) per class id
+};
+
 struct GroupFilter {
     bool enabled = false;
     std::vector<uint32_t> table;  // kFilterEntries masks: bit 8*j + b = 0 <=> bucket b accepts the bin at window position j
@@ -130,6 +163,7 @@ struct GroupFilter {
     uint32_t reach = kUnboundedReach;
     double est_candidate_rate = 0;  // expected fraction of requests flagged by chance (model or sample)
     std::string note;               // why the pass is not filtered, for stats / warnings
+    ConfirmTable confirm;           // built with the windows it mirrors (every rebuild of the filter rebuilds it)
 };
 struct FilterHints {  // from a traffic sample (pwaf_engine_tune); all optional
     const double *pair_prob = nullptr;             // 65536 entries indexed by fold(b0) | fold(b1) << 8: probability of the (case-folded) bigram in traffic
@@ -166,6 +200,10 @@ struct DfaGroup {
     std::vector<uint32_t> filter_cols;   // their device columns (filled at layout time)
     // Bigram prefilter of an otherwise ungated pass (enabled = the pass only walks the filter's candidates)
     GroupFilter filter;
+    // The DFA of the pass's NON-literal atoms alone (local atom ids are the full group's): what a confirmed candidate is walked
+    // through. Null when every atom is a confirm literal (no walk at all) or none is (the full DFA is the R DFA).
+    std::shared_ptr<DfaGroup> rtier;
+    uint32_t n_confirm_literals = 0;  // atoms of the pass the confirm tier decides without a DFA
 };
 static constexpr uint32_t kMaxDfaStates = 32767;   // 15-bit state ids: bit 15 of a table entry flags "target state emits"
 static constexpr uint32_t kMaxLocalAtoms = 32766;  // 15-bit (+1) atom slots in a hit record
@@ -289,6 +327,8 @@ void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector
 // Builds the bigram prefilter of pass `g` (filter.cpp). `atoms` = Program::atoms. Leaves filter.enabled false (with a note)
 // when some pattern has no usable literal factor.
 void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride = 1);
+// An atom the confirm tier decides by itself: (\A)? literal (\z)? with a literal of 2 .. 64 single bytes.
+bool confirm_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_end);
 // Host model of the filter kernel over one field value: true = candidate. (Used by tune to measure the candidate rate on the
 // sample; the device may flag MORE requests — it also looks at the bytes just past a field's end — never fewer.)
 // `\A literal` / `\A literal \z` with a literal of at most 8 single bytes (kernels.h: ShortAtom)
