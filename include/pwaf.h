@@ -130,6 +130,8 @@ void pwaf_list_free(char **items, size_t n);
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 #define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1
                                        * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */
+#define PWAF_OPT_NO_CONFIRM 512u      /* testing / A-B: no confirm tier — every prefilter candidate is walked through the pass's full DFA
+                                       * (the round-3 path): same verdicts */
 #define PWAF_OPT_LOCAL_WALKS 256u     /* EXPERIMENTAL: a prefilter candidate is walked only from shortly before its first flagged 16-byte
                                        * chunk until the DFA holds no thread older than the byte after its last one,
                                        * instead of from its first byte to its last: same verdicts. Off by default: measured on MI355X it
@@ -370,9 +372,17 @@ typedef struct pwaf_stats {
     uint32_t n_dfa_groups, n_dfa_states_total, max_dfa_states, dfa_table_bytes_total;
     uint32_t n_ip_lists, ipset_trie_nodes, geo_trie_nodes, n_dnf_literals;
     uint32_t n_warnings, n_filtered_groups /* passes behind a bigram prefilter */,
-        n_gated_groups /* gap passes visited only by requests whose prefix factor was found */, reserved[1];
+        n_gated_groups /* gap passes visited only by requests whose prefix factor was found */,
+        n_confirm_literals /* string predicates decided by the confirm tier of their pass's prefilter, without a DFA */;
 } pwaf_stats;
 int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
+/* TEST HOOK (CPU, no device): the bigram prefilter + confirm tier of scan pass `group` over ONE field value placed `arena_offset`
+ * bytes into an arena, as the device evaluates it (csrc/confirm.h is the code both run). Writes the local atom ids of the literal
+ * predicates confirmed (at most cap; possibly repeated), *n_atoms, *flagged (the filter flagged the field) and *walk (a factor of a
+ * non-literal predicate was confirmed: the request is walked through the pass's R-tier DFA). PWAF_E_INVALID_ARG when the pass has
+ * no prefilter. The reference has no counterpart: it evaluates every predicate on every request (pingoo/rules.rs:37-51). */
+int pwaf_program_confirm_field(const pwaf_program *, uint32_t group, const uint8_t *bytes, size_t len, uint32_t arena_offset,
+                               uint16_t *atoms, size_t cap, size_t *n_atoms, int *flagged, int *walk);
 int pwaf_program_stats(const pwaf_program *, pwaf_stats *out);
 
 /* ---- host-side field derivation (what the reference does before building RequestData) ------ */

@@ -23,7 +23,7 @@ RULE_CAPTCHA_ENDPOINT = 0xFFFFFFFD
 RULE_ACTION_BLOCK, RULE_ACTION_CAPTCHA = 1, 2
 
 LIST_STRING, LIST_INT, LIST_IP = 0, 1, 2
-OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER, OPT_STRICT, OPT_FILTER_STRIDE2, OPT_LENIENT, OPT_NO_RESIDUAL, OPT_GLOBAL_VERDICT_TABLES, OPT_LOCAL_WALKS = 1, 2, 4, 8, 16, 32, 64, 128, 256
+OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER, OPT_STRICT, OPT_FILTER_STRIDE2, OPT_LENIENT, OPT_NO_RESIDUAL, OPT_GLOBAL_VERDICT_TABLES, OPT_LOCAL_WALKS, OPT_NO_CONFIRM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 W_PARTIAL = 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CAPTCHA_VERIFIED = 1
@@ -143,7 +143,7 @@ class Stats(C.Structure):
         ("n_rules", C.c_uint32), ("n_atoms", C.c_uint32), ("n_scan_atoms", C.c_uint32), ("n_numeric_atoms", C.c_uint32),
         ("n_dfa_groups", C.c_uint32), ("n_dfa_states_total", C.c_uint32), ("max_dfa_states", C.c_uint32), ("dfa_table_bytes_total", C.c_uint32),
         ("n_ip_lists", C.c_uint32), ("ipset_trie_nodes", C.c_uint32), ("geo_trie_nodes", C.c_uint32), ("n_dnf_literals", C.c_uint32),
-        ("n_warnings", C.c_uint32), ("n_filtered_groups", C.c_uint32), ("n_gated_groups", C.c_uint32), ("reserved", C.c_uint32 * 1),
+        ("n_warnings", C.c_uint32), ("n_filtered_groups", C.c_uint32), ("n_gated_groups", C.c_uint32), ("n_confirm_literals", C.c_uint32),
     ]
 
 

@@ -1231,9 +1231,37 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
             if (cur.size() <= kMaxLocalAtoms && build_dfa(cur, max_states, max_table_bytes, g, derr)) {
                 g.field = (uint8_t)f;
                 g.filter_atoms = cur_filter;
+                g.confirm_off = (P.flags & PWAF_OPT_NO_CONFIRM) != 0;
+                // The R tier (program.h: DfaGroup::rtier): the DFA of the atoms that are NOT plain literals, for the candidates whose
+                // regex factor the confirm tier found. (Gated gap passes sit behind no bigram filter: no tiers.)
+                if (cur_filter.empty() && !(P.flags & (PWAF_OPT_NO_PREFILTER | PWAF_OPT_NO_CONFIRM))) {
+                    std::vector<ScanPattern> rp;
+                    std::vector<uint16_t> rmap;
+                    for (size_t k = 0; k < cur.size(); k++) {
+                        std::string lit;
+                        bool s0, e0;
+                        if (confirm_literal(*cur[k].rx, lit, s0, e0)) continue;
+                        rp.push_back(cur[k]);
+                        rmap.push_back((uint16_t)k);
+                    }
+                    g.n_confirm_literals = (uint32_t)(cur.size() - rp.size());
+                    if (!rp.empty() && rp.size() < cur.size()) {
+                        auto r = std::make_shared<DfaGroup>();
+                        std::string rerr;
+                        if (build_dfa(rp, max_states, max_table_bytes, *r, rerr)) {
+                            for (auto &x : r->emit_list) x = rmap[x];  // local ids of the FULL group
+                            for (auto &x : r->end_list) x = rmap[x];
+                            r->field = (uint8_t)f;
+                            r->atoms = g.atoms;
+                            r->n_local = g.n_local;
+                            g.rtier = r;
+                        }  // (cannot be larger than the full DFA; if it fails anyway the pass keeps the full table for its walks)
+                    }
+                }
                 g.atom_base = next_col;
                 for (size_t k = 0; k < cur.size(); k++) P.atoms[cur[k].atom].id = next_col + (uint32_t)k;
                 next_col += g.n_local;
+                if (g.rtier) g.rtier->atom_base = g.atom_base;
                 P.groups.push_back(std::move(g));
                 continue;
             }
@@ -1486,6 +1514,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         s.max_dfa_states = std::max(s.max_dfa_states, g.n_states);
         s.dfa_table_bytes_total += g.n_states * g.n_classes * 2;
         if (g.filter.enabled) s.n_filtered_groups++;
+        if (g.filter.enabled && g.filter.confirm.enabled) s.n_confirm_literals += g.n_confirm_literals;
         if (!g.filter_atoms.empty()) s.n_gated_groups++;
     }
     s.n_ip_lists = P.n_ip_lists;
@@ -1549,6 +1578,20 @@ std::vector<uint8_t> dump_program(const Program &p) {
             if (!g.class_kind.empty()) memcpy(lw.data() + 12, g.class_kind.data(), g.class_kind.size());
             if (!g.quiet.empty()) memcpy(lw.data() + 12 + g.class_kind.size(), g.quiet.data(), g.quiet.size());
             w.section("GLOC", (uint32_t)gi, lw.data(), lw.size());
+            // confirm tier: [enabled, has_walk, entries, literal atoms of the pass]; the R-tier DFA the confirmed candidates walk
+            const uint32_t ch[4] = {g.filter.confirm.enabled ? 1u : 0u, g.filter.confirm.has_walk ? 1u : 0u, (uint32_t)g.filter.confirm.entries.size(), g.n_confirm_literals};
+            w.section("GCNF", (uint32_t)gi, ch, sizeof ch);
+        }
+        if (g.rtier) {
+            const DfaGroup &r = *g.rtier;
+            const uint32_t rh[2] = {r.n_states, r.n_classes};
+            w.section("RHDR", (uint32_t)gi, rh, sizeof rh);
+            w.section("RCLS", (uint32_t)gi, r.classmap, 256);
+            w.section("RTRN", (uint32_t)gi, r.trans.data(), r.trans.size() * 2);
+            w.section("REMO", (uint32_t)gi, r.emit_off.data(), r.emit_off.size() * 4);
+            w.section("REML", (uint32_t)gi, r.emit_list.data(), r.emit_list.size() * 2);
+            w.section("RENO", (uint32_t)gi, r.end_off.data(), r.end_off.size() * 4);
+            w.section("RENL", (uint32_t)gi, r.end_list.data(), r.end_list.size() * 2);
         }
     }
     {

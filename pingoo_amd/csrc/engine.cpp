@@ -75,6 +75,19 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
     return PWAF_OK;
 }
 
+// flat form of a DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
+struct FlatDev {
+    DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list, delta;
+    uint32_t n_states = 0, n_classes = 0;
+    uint32_t n_full = 0, n_delta = 0;  // LDS layout of the list scan: rows [0, n_full), then n_delta 8-byte delta records (states n_full ..)
+    uint32_t n_quiet = 1;    // flat rows [0, n_quiet): the start state and the quiet states
+    bool can_skip = false;   // the flat table has an empty state for every byte kind: a walk may start inside a field
+    void release() {
+        for (DevBuf *b : {&flat, &flat_classmap, &emit_off, &emit_list, &end_off, &end_list, &delta}) b->release();
+        n_states = 0;
+    }
+};
+
 struct DevGroup {
     DevBuf tab, classmap, special, list_off, list;
     uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base, n_local;
@@ -89,12 +102,14 @@ struct DevGroup {
     bool identity = false;  // a plain pass over a SHORT field (`method`): walked by the list-scan kernel with the identity list
     GroupFilter filter;     // the prefilter in use (Program's, or rebuilt from a traffic sample by pwaf_engine_tune)
     DevBuf ftable;
-    // flat form of the DFA for list-driven walks (lscan_kernel): next state | 0x8000 when entering it emits; lists indexed by state
-    DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list, delta;
-    uint32_t n_full = 0, n_delta = 0;  // LDS layout of the list scan: rows [0, n_full), then n_delta 8-byte delta records (states n_full ..)
+    // flat form of the DFA for list-driven walks (lscan_kernel): of the pass's every atom (fl), and — a pass with a confirm tier and
+    // atoms of both kinds — of its non-literal atoms alone (rt: DfaGroup::rtier), which is what confirmed candidates walk
+    FlatDev fl, rt;
     bool short_lit = false;  // every atom is an anchored literal of <= 8 bytes: evaluated by the attribute kernel, the pass is never walked
-    uint32_t n_quiet = 1;    // flat rows [0, n_quiet): the start state and the quiet states
-    bool can_skip = false;   // the flat table has an empty state for every byte kind: a walk may start inside a field
+    // confirm tier in use (assign_lists uploads it with the filter table): ConfirmTable::head / entries / bytes / classes
+    DevBuf c_head, c_entries, c_bytes, c_classes;
+    bool confirm = false;      // the pass's candidates go through confirm_kernel
+    bool confirm_walk = false; // ... and those with a confirmed regex factor through the DFA (rt if built, else fl)
 };
 
 }  // namespace
@@ -117,6 +132,8 @@ struct Scratch {
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
     DevBuf chunk_bits, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
+    DevBuf walk;                           // per filtered pass with a confirm tier: confirm_kernel's "walk this entry" flags
+    DevBuf args_confirm;                   // ConfirmArgs per pass + the work-item plan
     DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
     DevBuf args_filter, args_list;         // per-pass launch descriptors (kernels.h: FilterTable / GatedTable)
@@ -143,7 +160,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &walk, &args_confirm, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -332,8 +349,10 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
 
 // The flat form of a group for lscan_kernel. States are renumbered — start state first, then by visits of the tuning sample
 // (discovery order without one) — so that the rows lscan_kernel stages in LDS are the ones its walks spend their steps in.
-int build_flat_group(const DfaGroup &g, DevGroup &d, bool wide, const std::vector<uint64_t> *visits = nullptr) {
+int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector<uint64_t> *visits = nullptr) {
     const uint32_t S = g.n_states, C = g.n_classes;
+    d.n_states = S;
+    d.n_classes = C;
     std::vector<uint32_t> order(S), pos(S);
     for (uint32_t s = 0; s < S; s++) order[s] = s;
     if (visits && visits->size() == S) std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
@@ -513,6 +532,7 @@ int assign_lists(pwaf_engine *e) {
         DevGroup &d = e->groups[k];
         d.gate = -1;
         d.filtered = false;
+        d.confirm = d.confirm_walk = false;
         const bool gap = !P.groups[k].filter_cols.empty();
         if (gap) {
             if (e->n_gap >= kGapLists) continue;  // (beyond 32 gap passes the rest simply walk every request)
@@ -524,6 +544,11 @@ int assign_lists(pwaf_engine *e) {
             d.filtered = true;
             e->n_filtered++;
             if ((rc = upload(d.ftable, d.filter.table))) return rc;
+            // the confirm tier built with this filter (program.h: ConfirmTable)
+            const ConfirmTable &ct = d.filter.confirm;
+            d.confirm = ct.enabled && !(P.flags & PWAF_OPT_LOCAL_WALKS);
+            d.confirm_walk = d.confirm && ct.has_walk;
+            if (d.confirm && ((rc = upload(d.c_head, ct.head)) || (rc = upload(d.c_entries, ct.entries)) || (rc = upload(d.c_bytes, ct.bytes)) || (rc = upload(d.c_classes, ct.classes)))) return rc;
         }
     }
     e->n_gated = e->n_gap || e->n_filtered ? kGapLists + e->n_filtered : 0;
@@ -709,6 +734,11 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)S.zero_off.p) col_known[f] = 1;
     if (e->n_gated && (rc = S.gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
     if (e->n_need && (rc = S.need.reserve((size_t)e->n_need * n * 4))) return rc;
+    {
+        uint32_t n_walk = 0;
+        for (const DevGroup &d : e->groups) n_walk += d.confirm_walk ? 1u : 0u;
+        if (n_walk && (rc = S.walk.reserve((size_t)n_walk * n * 4))) return rc;
+    }
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
     // zeroing the hit records themselves would write
     const uint32_t bit_words = 2 * n_groups;
@@ -944,6 +974,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     }
 #endif
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
+    std::vector<const uint32_t *> walk_of(e->groups.size(), nullptr);        // passes with a confirm tier: confirm_kernel's walk flags (set in step 2)
     std::vector<const uint32_t *> chunk_bits_of(e->groups.size(), nullptr);  // filtered passes: this batch's chunk bitmap (set in step 2)
     std::vector<uint32_t> chunk_base_of(e->groups.size(), 0);
     // PWAF_OPT_LOCAL_WALKS (off by default: it saves steps, not time — DESIGN.md §4.6): prefilter candidates are walked locally
@@ -978,36 +1009,43 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 a.shared_bits = d.shared_bits;
             }
         }
-        if (d.filtered && chunk_bits_of[gi] != nullptr) {
+        if (d.confirm) {
+            // the R-tier walk of a pass with a confirm tier: only the entries confirm_kernel flagged, starting from the record it wrote
+            a.need_in = walk_of[gi];
+            a.need_bit = 0;
+            a.merge_rec = 1;
+        }
+        if (d.filtered && chunk_bits_of[gi] != nullptr && !d.confirm) {
             // localized walks: between the candidate's first and last flagged chunk, give or take the filter's reach
             a.chunk_bits = chunk_bits_of[gi];
             a.chunk_base = chunk_base_of[gi];
-            a.reach = d.can_skip && !whole_walks ? d.filter.reach : kUnboundedReach;
-            a.n_quiet = whole_walks ? 0u : d.n_quiet;
+            a.reach = d.fl.can_skip && !whole_walks ? d.filter.reach : kUnboundedReach;
+            a.n_quiet = whole_walks ? 0u : d.fl.n_quiet;
             a.has_heads = d.filter.heads.empty() ? 0u : 1u;  // (exactly the passes whose records the host zeroes)
         }
         a.behind_filter = d.filtered ? 1u : 0u;
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
         a.n = n;
-        a.flat = (const uint16_t *)d.flat.p;
-        a.classmap = (const uint8_t *)d.flat_classmap.p;
-        a.n_classes = d.n_classes;
+        const FlatDev &F = (d.confirm && d.rt.n_states) ? d.rt : d.fl;  // (a confirmed candidate walks the DFA of the pass's non-literal atoms)
+        a.flat = (const uint16_t *)F.flat.p;
+        a.classmap = (const uint8_t *)F.flat_classmap.p;
+        a.n_classes = F.n_classes;
         {
             // rows [0, n_full) and the delta records behind them, when this launch's LDS share holds the layout the tables were built for
-            const uint32_t row_bytes = 2u * (d.n_classes + 3u), hb = list_hot_bytes(lshape, phase_is_local);
-            if (d.n_delta && (uint64_t)d.n_full * row_bytes + 48u + 8ull * d.n_delta <= hb) {
-                a.n_hot = d.n_full;
-                a.n_delta = d.n_delta;
-                a.delta = (const uint64_t *)d.delta.p;
+            const uint32_t row_bytes = 2u * (F.n_classes + 3u), hb = list_hot_bytes(lshape, phase_is_local);
+            if (F.n_delta && (uint64_t)F.n_full * row_bytes + 48u + 8ull * F.n_delta <= hb) {
+                a.n_hot = F.n_full;
+                a.n_delta = F.n_delta;
+                a.delta = (const uint64_t *)F.delta.p;
             } else {
-                a.n_hot = std::min<uint32_t>(d.n_delta ? d.n_full : d.n_states, (hb - 48u) / row_bytes);  // (states are in visit order: the first rows are the hot ones; 48 bytes stay free for the sentinel cell and lscan_async's dummy record)
+                a.n_hot = std::min<uint32_t>(F.n_delta ? F.n_full : F.n_states, (hb - 48u) / row_bytes);  // (states are in visit order: the first rows are the hot ones; 48 bytes stay free for the sentinel cell and lscan_async's dummy record)
             }
         }
-        a.emit_off = (const uint32_t *)d.emit_off.p;
-        a.emit_list = (const uint16_t *)d.emit_list.p;
-        a.end_off = (const uint32_t *)d.end_off.p;
-        a.end_list = (const uint16_t *)d.end_list.p;
+        a.emit_off = (const uint32_t *)F.emit_off.p;
+        a.emit_list = (const uint16_t *)F.emit_list.p;
+        a.end_off = (const uint32_t *)F.end_off.p;
+        a.end_list = (const uint16_t *)F.end_list.p;
         a.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
         a.pool = (PoolEntry *)S.pool.p;
         a.pool_count = (uint32_t *)S.ctrl.p;
@@ -1089,7 +1127,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
             f.chunk_bits = (uint32_t *)S.chunk_bits.p + sub_at;
-            if (local_walks) {
+            if (local_walks && !d.confirm) {
                 chunk_bits_of[gi] = f.chunk_bits;
                 chunk_base_of[gi] = (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u) * (kStreamSlab / 16);
             }
@@ -1135,6 +1173,63 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (!he) he = launch_compact(fall.data(), nf, d_all, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark("resolve+compact", 0xFCu))) return rc;
+        // ---- 2b. confirm tier: what the flagged chunks of every candidate really hold (literal atoms decided; walk flags) ----
+        std::vector<ConfirmArgs> call;
+        uint32_t wi = 0;
+        fi = 0;
+        for (size_t gi = 0; gi < e->groups.size(); gi++) {
+            const DevGroup &d = e->groups[gi];
+            if (!d.filtered) continue;
+            const FilterArgs &f = fall[fi++];
+            if (!d.confirm) continue;
+            ConfirmArgs c{};
+            c.data = f.data;
+            c.off = f.off;
+            c.n = n;
+            c.req_list = f.list;
+            c.n_list = f.list_count;
+            c.chunk_bits = f.chunk_bits;
+            c.chunk_base = f.slab0 * (kStreamSlab / 16);
+            c.mul = f.mul;
+            c.stride = f.stride;
+            c.c_head = (const uint32_t *)d.c_head.p;
+            c.c_entries = (const ConfirmEntry *)d.c_entries.p;
+            c.c_bytes = (const uint8_t *)d.c_bytes.p;
+            c.c_classes = (const uint32_t *)d.c_classes.p;
+            c.has_heads = d.filter.heads.empty() ? 0u : 1u;
+            c.rec = f.rec;
+            c.pool = (PoolEntry *)S.pool.p;
+            c.pool_count = (uint32_t *)S.ctrl.p;
+            c.pool_cap = pool_cap;
+            c.status = status_word;
+            if (e->n_gap && e->owns_factors[gi]) {
+                c.colmask_local = (const uint32_t *)e->colmask.p + d.atom_base;
+                c.n_local = d.n_local;
+                c.gate_lists = (uint32_t *)S.gate_lists.p;
+                c.gate_count = (uint32_t *)S.ctrl.p + 2;
+                if (d.need_slot >= 0) {
+                    c.need_out = (uint32_t *)S.need.p + (size_t)d.need_slot * n;
+                    c.shared_bits = d.shared_bits;
+                }
+            }
+            if (d.confirm_walk) {
+                c.walk = (uint32_t *)S.walk.p + (size_t)wi++ * n;
+                walk_of[gi] = c.walk;
+            }
+            call.push_back(c);
+        }
+        if (!call.empty()) {
+            const uint32_t nc = (uint32_t)call.size();
+            if ((rc = S.args_confirm.reserve((size_t)nc * sizeof(ConfirmArgs) + (nc + 2) * 4))) return rc;
+            ConfirmArgs *d_c = (ConfirmArgs *)S.args_confirm.p;
+            uint32_t *c_plan = (uint32_t *)((char *)S.args_confirm.p + (size_t)nc * sizeof(ConfirmArgs));
+            he = upload_confirm_args(call.data(), nc, d_c, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark(nullptr, 0))) return rc;
+            he = launch_confirm(call.data(), nc, d_c, c_plan, e->n_cus, stream);
+            if (he) return fail(PWAF_E_DEVICE, std::string("confirm kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+            if ((rc = mark("confirm", 0xF8u))) return rc;
+        }
     }
     if ((rc = launch_attr_side())) return rc;  // (no filtered pass: beside the list scans / the verdict kernel's predecessors)
     // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
@@ -1146,6 +1241,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             for (size_t gi = 0; gi < e->groups.size(); gi++) {
                 const DevGroup &d = e->groups[gi];
                 if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
+                if (d.confirm && !d.confirm_walk) continue;  // every atom of the pass is a literal the confirm tier decided: nothing to walk
 #ifdef PWAF_PROFILING
                 static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
                 if (skip_identity && d.identity) continue;
@@ -1382,7 +1478,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     std::vector<uint32_t> pass_base;
     for (size_t k = 0; k < P.groups.size(); k++) {
         if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k]))) return dev_fail(rc);
-        if ((rc = build_flat_group(P.groups[k], e->groups[k], P.groups[k].filter.enabled && P.groups[k].filter_cols.empty()))) return dev_fail(rc);
+        if ((rc = build_flat_group(P.groups[k], e->groups[k].fl, P.groups[k].filter.enabled && P.groups[k].filter_cols.empty()))) return dev_fail(rc);
+        if (P.groups[k].rtier && (rc = build_flat_group(*P.groups[k].rtier, e->groups[k].rt, true))) return dev_fail(rc);
         pass_base.push_back(P.groups[k].atom_base);
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
@@ -1663,7 +1760,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
-    for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.flat, &g.flat_classmap, &g.emit_off, &g.emit_list, &g.end_off, &g.end_list, &g.delta}) b->release(); }
+    for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.c_head, &g.c_entries, &g.c_bytes, &g.c_classes}) b->release(); g.fl.release(); g.rt.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
                       &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
@@ -1688,6 +1785,30 @@ void *pwaf_engine_stream(const pwaf_engine *e) {
 int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
     if (!e || !out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     *out = e->prog.p->stats;
+    // (the prefilters in use are the engine's: pwaf_engine_tune rebuilds them from traffic)
+    out->n_filtered_groups = out->n_confirm_literals = 0;
+    for (size_t k = 0; k < e->groups.size(); k++) {
+        if (e->groups[k].filtered) out->n_filtered_groups++;
+        if (e->groups[k].confirm) out->n_confirm_literals += e->prog.p->groups[k].n_confirm_literals;
+    }
+    return PWAF_OK;
+}
+
+int pwaf_program_confirm_field(const pwaf_program *p, uint32_t group, const uint8_t *bytes, size_t len, uint32_t arena_offset, uint16_t *atoms, size_t cap, size_t *n_atoms,
+                               int *flagged, int *walk) {
+    if (!p || !p->p || group >= p->p->groups.size() || (!bytes && len) || !n_atoms || !flagged || !walk) return fail(PWAF_E_INVALID_ARG, "bad argument");
+    const GroupFilter &f = p->p->groups[group].filter;
+    if (!f.enabled) return fail(PWAF_E_INVALID_ARG, "the pass has no prefilter");
+    if (len > 0x7FFFFFF0u - arena_offset) return fail(PWAF_E_INVALID_ARG, "field too long");
+    std::vector<uint8_t> arena((size_t)arena_offset + len + 2 * PWAF_ARENA_PAD, (uint8_t)'~');  // (what lies around the field must not matter)
+    if (len) memcpy(arena.data() + arena_offset, bytes, len);
+    std::vector<uint16_t> lits;
+    bool fl = false;
+    const bool wk = confirm_field_host(f, arena.data(), arena_offset, arena_offset + (uint32_t)len, lits, &fl);
+    *n_atoms = std::min(cap, lits.size());
+    for (size_t k = 0; k < *n_atoms; k++) atoms[k] = lits[k];
+    *flagged = fl ? 1 : 0;
+    *walk = wk ? 1 : 0;
     return PWAF_OK;
 }
 
@@ -1834,6 +1955,7 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
 namespace {
 struct TuneOut {
     std::vector<std::vector<uint64_t>> visits, class_freq;
+    std::vector<std::vector<uint64_t>> rvisits;  // per pass with an R tier: state visits of the sample's CONFIRMED candidates in that DFA
     std::vector<GroupFilter> filters;  // per pass
     std::vector<double> mean_len;      // per field (0 = the sample does not carry it)
     std::vector<uint32_t> chunks;      // per pass: 16-byte chunks per scan_kernel iteration
@@ -1852,6 +1974,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
     std::vector<std::vector<uint64_t>> &visits = T.visits, &class_freq = T.class_freq;
     std::vector<std::vector<uint64_t>> atom_hits(P.groups.size());
     visits.assign(P.groups.size(), {});
+    T.rvisits.assign(P.groups.size(), {});
     class_freq.assign(P.groups.size(), {});
     if (T.filters.size() != P.groups.size()) return fail(PWAF_E_INVALID_ARG, "tune: filters must be pre-filled with the filters in use");
     T.mean_len.assign(n_fields, 0.0);
@@ -1968,15 +2091,39 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
                 continue;
             }
             // The DFA of a filtered pass only ever walks the filter's candidates, whose states (deep inside pattern prefixes) are
-            // not the ones average traffic visits: its LDS-resident rows are chosen from the candidates' walks alone.
+            // not the ones average traffic visits: its LDS-resident rows are chosen from the candidates' walks alone — with a confirm
+            // tier, from the walks of the candidates in which a regex factor was CONFIRMED, through the DFA they take (the R tier).
             std::vector<uint64_t> &v = visits[k];
             std::fill(v.begin(), v.end(), 0);
+            std::vector<uint64_t> &rv = T.rvisits[k];
+            if (g.rtier) rv.assign(g.rtier->n_states, 0);
+            std::vector<uint8_t> padded;  // (confirm.h reads a few bytes past a factor: the caller's host arena carries no slack)
+            if (gf.confirm.enabled) {
+                padded.assign(data, data + off[n]);
+                padded.resize(padded.size() + 2 * PWAF_ARENA_PAD, 0);
+            }
+            std::vector<uint16_t> lits;
             for (uint32_t i = 0; i < n; i++) {
-                if (!flagged(gf, sc, i)) continue;
+                bool walk;
+                if (gf.confirm.enabled) {
+                    lits.clear();
+                    walk = confirm_field_host(gf, padded.data(), off[i], off[i + 1], lits);
+                } else {
+                    walk = flagged(gf, sc, i);
+                }
+                if (!walk) continue;
                 uint32_t st = 0;
                 for (uint32_t p = off[i]; p < off[i + 1]; p++) {
                     st = g.trans[(size_t)st * g.n_classes + g.classmap[data[p]]];
                     v[st]++;
+                }
+                if (g.rtier) {
+                    const DfaGroup &r = *g.rtier;
+                    uint32_t rs = 0;
+                    for (uint32_t p = off[i]; p < off[i + 1]; p++) {
+                        rs = r.trans[(size_t)rs * r.n_classes + r.classmap[data[p]]];
+                        rv[rs]++;
+                    }
                 }
             }
         }
@@ -2034,7 +2181,10 @@ int pwaf_engine_tune(pwaf_engine *e, const pwaf_batch *sample) {
         if (T.mean_len[f] > 0) e->mean_len[f] = T.mean_len[f];
     HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the tables that are about to be replaced
     for (size_t k = 0; k < P.groups.size(); k++)
-        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &T.visits[k], &T.class_freq[k])) || (rc = build_flat_group(P.groups[k], e->groups[k], e->groups[k].filter.enabled && P.groups[k].filter_cols.empty(), &T.visits[k]))) return rc;
+        if ((rc = build_device_group(P.groups[k], P.lds_hot_budget, e->groups[k], &T.visits[k], &T.class_freq[k])) ||
+            (rc = build_flat_group(P.groups[k], e->groups[k].fl, e->groups[k].filter.enabled && P.groups[k].filter_cols.empty(), &T.visits[k])) ||
+            (P.groups[k].rtier && (rc = build_flat_group(*P.groups[k].rtier, e->groups[k].rt, true, T.rvisits[k].empty() ? nullptr : &T.rvisits[k]))))
+            return rc;
     if ((rc = assign_lists(e))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return PWAF_OK;

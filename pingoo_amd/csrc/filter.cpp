@@ -22,6 +22,7 @@
 #include <map>
 #include <set>
 
+#include "confirm.h"
 #include "program.h"
 
 namespace pwaf {
@@ -321,6 +322,108 @@ struct Window {
 
 }  // namespace
 
+bool confirm_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_end) {
+    return anchored_literal(n, lit, at_start, at_end) && lit.size() >= 2 && lit.size() <= kMaxLen;
+}
+
+namespace {
+// One factor occurrence the confirm tier can verify: the factor string, where its window ends, what it decides.
+struct ConfirmSeed {
+    CStr s;
+    uint32_t d;     // the window's last bigram starts d bytes into the factor
+    uint16_t atom;  // local atom (a confirm literal), or kConfirmWalk
+    uint8_t flags;
+};
+
+// Lays the seeds out as the table confirm.h reads (program.h: ConfirmTable). false: a limit of the encoding was exceeded — the
+// pass then keeps the round-3 path (every candidate walked through the full DFA).
+bool build_confirm_table(std::vector<ConfirmSeed> &seeds, uint32_t mul, ConfirmTable &out) {
+    out = ConfirmTable();
+    // identical (factor, window end, decision) seeds — regexes sharing a factor — once
+    {
+        std::map<std::string, size_t> seen;
+        std::vector<ConfirmSeed> uniq;
+        for (auto &sd : seeds) {
+            std::string key = std::to_string(sd.d) + ":" + std::to_string(sd.atom) + ":" + std::to_string(sd.flags) + ":";
+            for (auto &bs : sd.s) key += bs.to_string();
+            if (seen.emplace(key, uniq.size()).second) uniq.push_back(sd);
+        }
+        seeds.swap(uniq);
+    }
+    std::map<std::string, uint32_t> class_ids;
+    struct Placed { uint32_t bin; ConfirmEntry e; };
+    std::vector<Placed> placed;
+    for (const ConfirmSeed &sd : seeds) {
+        const size_t len = sd.s.size();
+        if (len < 2 || len > kMaxLen || (size_t)sd.d + 2 > len) return false;  // (the window's last bigram lies inside the factor)
+        const size_t l4 = (len + 3) & ~(size_t)3;
+        ConfirmEntry e{};
+        e.bytes_off = (uint32_t)out.bytes.size();
+        e.len = (uint16_t)len;
+        e.d = (uint16_t)sd.d;
+        e.atom = sd.atom;
+        e.flags = sd.flags;
+        std::vector<uint8_t> val(l4, 0), msk(l4, 0), cls;
+        for (size_t j = 0; j < len; j++) {
+            const ByteSet &bs = sd.s[j];
+            const size_t cnt = bs.count();
+            int x = -1, y = -1;
+            for (int b = 0; b < 256; b++)
+                if (bs[(size_t)b]) { if (x < 0) x = b; else if (y < 0) y = b; }
+            if (cnt == 1) {
+                val[j] = (uint8_t)x;
+                msk[j] = 0xFF;
+            } else if (cnt == 2 && ((x ^ y) & ((x ^ y) - 1)) == 0) {  // two bytes one bit apart ((?i) letters): compared under a mask
+                msk[j] = (uint8_t)~(x ^ y);
+                val[j] = (uint8_t)(x & msk[j]);
+            } else {  // a byte class: position + class id after the masks
+                const std::string key = bs.to_string();
+                auto it = class_ids.find(key);
+                if (it == class_ids.end()) {
+                    it = class_ids.emplace(key, (uint32_t)class_ids.size()).first;
+                    for (int w = 0; w < 8; w++) {
+                        uint32_t word = 0;
+                        for (int b = 0; b < 32; b++)
+                            if (bs[(size_t)(w * 32 + b)]) word |= 1u << b;
+                        out.classes.push_back(word);
+                    }
+                }
+                if (it->second > 255 || cls.size() >= 2 * 255) return false;
+                cls.push_back((uint8_t)j);
+                cls.push_back((uint8_t)it->second);
+            }
+        }
+        e.n_cls = (uint8_t)(cls.size() / 2);
+        out.bytes.insert(out.bytes.end(), val.begin(), val.end());
+        out.bytes.insert(out.bytes.end(), msk.begin(), msk.end());
+        out.bytes.insert(out.bytes.end(), cls.begin(), cls.end());
+        while (out.bytes.size() & 3) out.bytes.push_back(0);
+        // the bins the window's LAST bigram can fall into: the entry is listed under each
+        std::vector<uint16_t> pairs;
+        Model::pairs_of(sd.s[sd.d], sd.s[sd.d + 1], pairs);
+        std::set<uint32_t> bins;
+        for (uint16_t pr : pairs) bins.insert(filter_bin((uint8_t)pr, (uint8_t)(pr >> 8), mul));
+        for (uint32_t bn : bins) placed.push_back({bn, e});
+        if (sd.atom == kConfirmWalk) out.has_walk = true;
+    }
+    std::stable_sort(placed.begin(), placed.end(), [](const Placed &a, const Placed &b) { return a.bin < b.bin; });
+    if (placed.size() >= (1u << 20)) return false;
+    out.head.assign(kFilterEntries, 0u);
+    for (size_t k = 0; k < placed.size();) {
+        size_t j = k;
+        while (j < placed.size() && placed[j].bin == placed[k].bin) j++;
+        if (j - k > 4095) return false;
+        out.head[placed[k].bin] = (uint32_t)k | ((uint32_t)(j - k) << 20);
+        k = j;
+    }
+    for (auto &pl : placed) out.entries.push_back(pl.e);
+    for (int pad = 0; pad < 4; pad++) out.bytes.push_back(0);  // (the last entry's dword loads)
+    if (out.classes.empty()) out.classes.assign(8, 0u);
+    out.enabled = true;
+    return true;
+}
+}  // namespace
+
 void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride) {
     out = GroupFilter();
     out.stride = stride;
@@ -381,6 +484,8 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     std::map<std::string, size_t> index;
     std::vector<Window> wins;
     double reach = 0;  // of the pass: the maximum over its patterns' factor sets
+    std::vector<ConfirmSeed> seeds;  // every (factor, alignment) entered into the filter, for the confirm tier
+    const bool l_fits_records = g.atoms.size() < kConfirmWalk;
     for (uint32_t l = 0; l < g.atoms.size(); l++) {
         if (is_head[l]) continue;
         const Atom &at = atoms[g.atoms[l]];
@@ -391,11 +496,25 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             out.heads.clear();
             return;
         }
-        Ext x = extract(m, *at.pattern);
-        Cover f = x.B;
-        f = better(m, f, x.E);
-        f = better(m, f, x.P);
-        f = better(m, f, x.S);
+        // A confirm literal's factor is the literal itself, whole (what the confirm tier compares decides the atom); any other
+        // pattern takes the cheapest necessary factor set.
+        Cover f;
+        std::string c_lit;
+        bool c_start = false, c_end = false;
+        const bool is_lit = confirm_literal(*at.pattern, c_lit, c_start, c_end);
+        if (is_lit) {
+            CStr cs;
+            for (unsigned char ch : c_lit) { ByteSet b1; b1.set(ch); cs.push_back(b1); }
+            f.ok = true;
+            f.s.push_back(std::move(cs));
+            f.reach = (double)c_lit.size();
+        } else {
+            Ext x = extract(m, *at.pattern);
+            f = x.B;
+            f = better(m, f, x.E);
+            f = better(m, f, x.P);
+            f = better(m, f, x.S);
+        }
         if (!std::isfinite(m.score(f))) {
             out.note = "pattern without a literal factor of " +  std::to_string(1 + stride) + " or more bytes: " + at.key.substr(0, 80);
             out.heads.clear();
@@ -423,6 +542,8 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
                 }
 #endif
                 if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
+                seeds.push_back(ConfirmSeed{s, (uint32_t)(st + (k - 1) * stride), is_lit ? (uint16_t)l : kConfirmWalk,
+                                            (uint8_t)(is_lit ? ((c_start ? kConfirmAtStart : 0) | (c_end ? kConfirmAtEnd : 0)) : 0)});
             }
     }
     if (wins.empty() && out.heads.empty()) { out.note = "no patterns"; return; }
@@ -526,6 +647,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     const double len = (hints && hints->mean_len > 0 ? hints->mean_len : 64.0) / stride;
     out.est_candidate_rate = 1.0 - std::pow(std::max(0.0, 1.0 - std::min(1.0, best_fp)), len);
     out.enabled = true;
+    if (l_fits_records && !g.confirm_off) build_confirm_table(seeds, out.mul, out.confirm);  // (failure leaves confirm.enabled false: the round-3 path)
 }
 
 bool short_literal_atom(const RNode &n, std::string &lit, bool &exact) {
@@ -552,6 +674,35 @@ uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n)
         if (memcmp(bytes, h.bytes, h.len) == 0) r |= 1u << k;
     }
     return r;
+}
+
+}  // namespace pwaf
+
+namespace pwaf {
+
+// Host model of filter + confirm tier over the field [fs, fe) of an arena with PWAF_ARENA_PAD readable bytes behind it: the chunks
+// the filter flags for the field's own bytes (the device may flag more — it also sees the neighbours' bytes — which the exact
+// comparison makes irrelevant), then confirm.h over each of them. Appends the confirmed literal atoms (local ids, possibly
+// repeated) to `lits`; returns true when the request must be walked through the DFA (always, for a flagged field of a pass without
+// a confirm table). `flagged` (optional): the filter flagged the field at all.
+bool confirm_field_host(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, std::vector<uint16_t> &lits, bool *flagged) {
+    std::vector<uint32_t> chunks;
+    uint32_t st = f.init;
+    for (uint32_t i = f.stride == 2 ? (fs + 1u) & ~1u : fs; i + 1 < fe; i += f.stride) {
+        st = (st << 8) | f.table[filter_bin(arena[i], arena[i + 1], f.mul)];
+        if (((~st) & 0xFF000000u) && (chunks.empty() || chunks.back() != (i >> 4))) chunks.push_back(i >> 4);
+    }
+    if (flagged) *flagged = !chunks.empty();
+    if (chunks.empty()) return false;
+    if (!f.confirm.enabled) return true;
+    const ConfirmTable &t = f.confirm;
+    const ConfirmView cv{t.head.data(), t.entries.data(), t.bytes.data(), t.classes.data(), f.mul, f.stride};
+    bool walk = false;
+    for (uint32_t c : chunks) {
+        const bool wk = confirm_chunk(cv, arena, fs, fe, c, [&](uint32_t bin) { return t.head[bin]; }, [&](uint32_t atom) { lits.push_back((uint16_t)atom); });
+        walk = walk || wk;
+    }
+    return walk;
 }
 
 }  // namespace pwaf

@@ -116,10 +116,57 @@ struct ListScanArgs {
     // per list entry, the mask of gap passes its hits call for (need_out); a sharing pass skips entries without its bit.
     uint32_t *need_out;        // owner: [list entry] -> gap-pass mask (null: none shares)
     uint32_t shared_bits;      // owner: the gap passes that read need_out (the other bits of a hit's mask are enqueued with atomics)
-    const uint32_t *need_in;   // sharing pass: the owner's masks (null: the list is its own)
-    uint32_t need_bit;
+    const uint32_t *need_in;   // sharing pass: the owner's masks (null: the list is its own). Also the R-tier walk of a pass with a confirm tier:
+    uint32_t need_bit;         //   confirm_kernel's walk flags of the pass's own candidate list (bit 0)
+    // The walk of a pass with a confirm tier: the request's record already holds what the filter heads and the confirm tier found
+    // (literal atoms are not in the R-tier DFA); the walk starts from it, and enqueues only what its own hits add.
+    uint32_t merge_rec;
     uint32_t n_cus;
 };
+
+// ---- confirm tier (program.h: ConfirmTable; confirm.h) ---------------------------------------------------------------------------
+// confirm_kernel: one lane per entry of a filtered pass's candidate list. The lane looks at the flagged chunks inside its request's
+// field: literal atoms confirmed there go into the hit record (complete for this pass unless the request must also be walked), and
+// walk[list entry] says whether a factor of a non-literal atom was confirmed — only those requests are walked, through the R-tier DFA.
+struct ConfirmArgs {
+    const uint8_t *data;
+    const uint32_t *off;
+    uint32_t n;
+    const uint32_t *req_list;   // the pass's candidate list and, on the device, its length
+    const uint32_t *n_list;
+    const uint32_t *chunk_bits; // the pass's chunk bitmap of this batch: bit c - chunk_base = the arena's 16-byte chunk c was flagged
+    uint32_t chunk_base;
+    uint32_t mul, stride;       // of the pass's bigram hash / sampling (GroupFilter)
+    const uint32_t *c_head;     // ConfirmTable on the device
+    const ConfirmEntry *c_entries;
+    const uint8_t *c_bytes;
+    const uint32_t *c_classes;
+    uint32_t has_heads;         // rec[] holds what the filter kernel's head comparisons found (zeroed by the host): merged
+    uint32_t *rec;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t pool_cap;
+    uint32_t *status;
+    const uint32_t *colmask_local;  // a pass that owns prefilter factors of gap passes (else null): see ListScanArgs
+    uint32_t n_local;
+    uint32_t *gate_lists;
+    uint32_t *gate_count;
+    uint32_t *need_out;
+    uint32_t shared_bits;
+    uint32_t *walk;             // [list entry] -> 1: walk the request through the R-tier DFA (null: the pass has no such atoms)
+};
+static constexpr uint32_t kConfirmThreads = 256, kConfirmPerLaunch = 8;
+struct ConfirmBatchArgs {
+    ConfirmArgs c[kConfirmPerLaunch];
+    uint32_t count;
+};
+struct ConfirmTableDev {
+    const ConfirmArgs *c;  // device
+    uint32_t count;
+};
+int upload_confirm_args(const ConfirmArgs *host, uint32_t count, ConfirmArgs *dev, void *stream);
+// `plan`: count + 1 words of device scratch (work-item prefix sums, written on the same stream)
+int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *dev, uint32_t *plan, uint32_t n_cus, void *stream);
 
 // ---- bigram prefilter (program.h: GroupFilter) ------------------------------------------------------------------------------
 // The shift-or state only remembers the last four bigrams, so a field's arena is processed as ONE flat byte stream: a wave takes a

@@ -32,6 +32,7 @@
 #include <mutex>
 #include <set>
 
+#include "confirm.h"
 #include "kernels.h"
 #include "residual.h"
 
@@ -159,6 +160,11 @@ __device__ __noinline__ Walk careful_step(const PWAF_GLOBAL unsigned char *gtab,
         }
     }
     return w;
+}
+// The hit state a walk starts from when the request's record already holds hits (ListScanArgs::merge_rec).
+__device__ __forceinline__ Hits hits_of_record(const uint32_t rv) {
+    if (rv & REC_OVERFLOW) return Hits{0, 0, rv & ~REC_OVERFLOW};
+    return Hits{rv & 0x7FFFu, (rv >> 15) & 0x7FFFu, kNone};
 }
 // The gap passes a finished request's hits call for: OR of the per-atom masks.
 __device__ __noinline__ uint32_t gate_mask(const uint32_t *colmask_local, const PoolEntry *pool, Hits h) {
@@ -750,6 +756,11 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
         const uint32_t end = live ? a.off[r + 1] : 0u;
         uint32_t state = 0, wp = p;                  // wp: where the window in `w` begins (p - wp is a multiple of 4, below 16 after the reload)
         Hits h{0, 0, kNone};
+        uint32_t need_init = 0;  // what the record's hits (filter heads, confirm tier) already enqueued
+        if (live && a.merge_rec) {
+            h = hits_of_record(a.rec[r]);
+            if (a.colmask_local != nullptr && (h.a0 | (h.ovf + 1u)) != 0) need_init = gate_mask(a.colmask_local, a.pool, h);
+        }
         if (live && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
         u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + wp);
         u32x4 wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (wp + 16u < end ? wp + 16u : 0u));
@@ -812,7 +823,7 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
                 uint32_t need = 0;
                 if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
                 if (a.need_out != nullptr) a.need_out[li] = need;
-                need &= ~a.shared_bits;
+                need &= ~(a.shared_bits | need_init);
                 if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
             }
         }
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
             // passes 0.087 -> 0.117 (adversarial 0.24 -> 0.49): a single wave issues an instruction every few cycles at best, so two
             // interleaved chains cost a step twice the issue slots while the list's longest walk — the kernel's critical path on
             // benign traffic — gets no shorter. One walk per lane and as many waves as the LDS copy allows is the better trade.
-            uint32_t li[kListWalks], r[kListWalks], p[kListWalks], end[kListWalks], state[kListWalks];
+            uint32_t li[kListWalks], r[kListWalks], p[kListWalks], end[kListWalks], state[kListWalks], need_init[kListWalks];
             bool live[kListWalks];
             Hits h[kListWalks];
             u32x4 w[kListWalks];
@@ -915,6 +926,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                 end[u] = live[u] ? a.off[r[u] + 1] : 0u;
                 state[u] = 0;
                 h[u] = Hits{0, 0, kNone};
+                need_init[u] = 0;
+                if (live[u] && a.merge_rec) {  // (the walk of a pass with a confirm tier: the record holds the heads' and the literals' hits)
+                    h[u] = hits_of_record(a.rec[r[u]]);
+                    if (a.colmask_local != nullptr && (h[u].a0 | (h[u].ovf + 1u)) != 0) need_init[u] = gate_mask(a.colmask_local, a.pool, h[u]);
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < kListWalks; u++) {
@@ -1022,9 +1038,98 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                     uint32_t need = 0;
                     if ((h[u].a0 | (h[u].ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h[u]);
                     if (a.need_out != nullptr) a.need_out[li[u]] = need;
-                    need &= ~a.shared_bits;
+                    need &= ~(a.shared_bits | need_init[u]);
                     if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r[u], need);
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// confirm tier (confirm.h; program.h: ConfirmTable)
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, uint32_t *plan /* [count + 1] */) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x;
+    uint32_t items = 0;
+    if (t < b.count) {
+        const ConfirmArgs *pa = &b.c[t];
+        items = (min(*pa->n_list, pa->n) + kConfirmThreads - 1) / kConfirmThreads;
+    }
+    part[t] = items;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t < b.count) plan[t] = part[t] - items;
+    if (t == 0) plan[b.count] = part[255];
+}
+
+// One lane per candidate-list entry; a persistent grid over device-computed work items (one workgroup's worth of entries of one pass
+// each), like the list scan: consecutive items are mostly of one pass, whose head table (16 KiB) is staged in LDS once. Per entry:
+// offsets -> the field's words of the chunk bitmap -> per flagged chunk 20 bytes of text, 16 head lookups (LDS), and for the rare
+// bin that lists an entry the full comparison (confirm.h) against the L2-resident byte pool. No DFA, no state: what a near miss
+// costs here is one comparison that fails, whatever the traffic looks like.
+__global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
+    __shared__ uint32_t head[kFilterEntries];
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t total = plan[b.count];
+    const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
+    for (uint32_t it = it0; it < it1;) {
+        uint32_t ps = 0;
+        for (uint32_t lo = 0, hi = b.count; lo + 1 < hi;) {  // the pass of item `it`: the last p with plan[p] <= it (uniform)
+            const uint32_t mid = (lo + hi) >> 1;
+            if (plan[mid] <= it) lo = mid;
+            else hi = mid;
+            ps = lo;
+        }
+        const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
+        const ConfirmArgs a = load_descriptor(&b.c[ps]);
+        __syncthreads();  // (every wave is done with the previous pass's heads)
+        for (uint32_t k = threadIdx.x; k < kFilterEntries; k += kConfirmThreads) head[k] = a.c_head[k];
+        __syncthreads();
+        const ConfirmView cv{nullptr, a.c_entries, a.c_bytes, a.c_classes, a.mul, a.stride};
+        const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
+        const uint32_t n_l = min(*a.n_list, a.n);
+        for (; it < it_end; it++) {
+            const uint32_t li = (it - first) * kConfirmThreads + threadIdx.x;
+            if (li >= n_l) continue;
+            const uint32_t r = a.req_list[li];
+            const uint32_t fs = a.off[r], fe = a.off[r + 1];
+            Hits h{0, 0, kNone};
+            if (a.has_heads) {  // what the filter kernel's head comparisons recorded for this request
+                const uint32_t heads = a.rec[r];
+                h.a0 = heads & 0x7FFFu;
+                h.a1 = (heads >> 15) & 0x7FFFu;
+            }
+            bool walk = false;
+            if (fe >= fs + 2u) {
+                const uint32_t c_lo = (fs >> 4) - a.chunk_base, c_hi = ((fe - 1u) >> 4) - a.chunk_base;
+                for (uint32_t w = c_lo >> 5; w <= (c_hi >> 5); w++) {
+                    uint32_t bits = a.chunk_bits[w];
+                    if (w == (c_lo >> 5)) bits &= ~0u << (c_lo & 31u);
+                    if (w == (c_hi >> 5)) bits &= ~0u >> (31u - (c_hi & 31u));
+                    while (bits) {
+                        const uint32_t c = w * 32u + (uint32_t)__builtin_ctz(bits) + a.chunk_base;
+                        bits &= bits - 1u;
+                        const bool wk = confirm_chunk(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return head[bin]; },
+                                                      [&](const uint32_t atom) { h = record_atom(ctx, atom, h); });
+                        walk = walk || wk;
+                    }
+                }
+            }
+            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+            if (a.walk != nullptr) a.walk[li] = walk ? 1u : 0u;
+            if (a.colmask_local != nullptr) {
+                uint32_t need = 0;
+                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
+                if (a.need_out != nullptr) a.need_out[li] = need;
+                need &= ~a.shared_bits;
+                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
             }
         }
     }
@@ -1084,6 +1189,32 @@ int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, 
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+int upload_confirm_args(const ConfirmArgs *host, uint32_t count, ConfirmArgs *dev, void *stream) {
+    for (uint32_t at = 0; at < count; at += kConfirmPerLaunch) {
+        ConfirmBatchArgs c{};
+        c.count = std::min(kConfirmPerLaunch, count - at);
+        for (uint32_t k = 0; k < c.count; k++) c.c[k] = host[at + k];
+        hipLaunchKernelGGL((store_args_kernel<ConfirmBatchArgs, ConfirmArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *dev, uint32_t *plan, uint32_t n_cus, void *stream) {
+    if (count == 0 || host[0].n == 0) return 0;
+    if (count > 256) return (int)hipErrorInvalidValue;
+    ConfirmTableDev b{dev, count};
+    hipLaunchKernelGGL(confirm_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // persistent grid: 8 workgroups of 256 per CU (16 KiB of LDS each), never more than the items a full batch could produce
+    const uint64_t max_items = (uint64_t)count * ((host[0].n + kConfirmThreads - 1) / kConfirmThreads);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 8u);
+    const uint32_t *cplan = plan;
+    hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
+    return (int)hipGetLastError();
 }
 
 int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream) {

@@ -100,7 +100,12 @@ static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
 // factor such as "../" then owns a single sampled position and floods the candidates. pwaf_engine_tune decides per pass from the sample.)
 static constexpr uint32_t kFilterMul = 0x9E37u;  // default 16-bit multiplier of the bigram hash (v_pk_mul_lo_u16 on the device); a pass picks its own from a
                                                  // few candidates so that its factor windows avoid the bins frequent bigrams fall into (GroupFilter::mul)
-static inline uint32_t filter_bin(uint8_t b0, uint8_t b1, uint32_t mul = kFilterMul) {
+#if defined(__HIPCC__)
+#define PWAF_HOST_DEVICE __host__ __device__
+#else
+#define PWAF_HOST_DEVICE
+#endif
+PWAF_HOST_DEVICE static inline uint32_t filter_bin(uint8_t b0, uint8_t b1, uint32_t mul = kFilterMul) {
     const uint32_t p = (uint32_t)(b0 & 0xDFu) | ((uint32_t)(b1 & 0xDFu) << 8);  // bit 5 cleared: ASCII case folding
     // top 12 bits of the 16-bit product: they mix all 8 bits of the second byte (bits [2, 14) keep only 6 of them, and digits then
     // alias letters: measured 2.6x the candidates on URLs)
@@ -204,6 +209,7 @@ struct DfaGroup {
     // through. Null when every atom is a confirm literal (no walk at all) or none is (the full DFA is the R DFA).
     std::shared_ptr<DfaGroup> rtier;
     uint32_t n_confirm_literals = 0;  // atoms of the pass the confirm tier decides without a DFA
+    bool confirm_off = false;         // PWAF_OPT_NO_CONFIRM: build_group_filter leaves the confirm table out
 };
 static constexpr uint32_t kMaxDfaStates = 32767;   // 15-bit state ids: bit 15 of a table entry flags "target state emits"
 static constexpr uint32_t kMaxLocalAtoms = 32766;  // 15-bit (+1) atom slots in a hit record
@@ -334,6 +340,9 @@ bool confirm_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_
 // `\A literal` / `\A literal \z` with a literal of at most 8 single bytes (kernels.h: ShortAtom)
 bool short_literal_atom(const RNode &n, std::string &lit, bool &exact);
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase = 0);  // phase: offset of the first sampled byte (< stride)
+// Host model of filter + confirm tier over one field [fs, fe) of an arena with PWAF_ARENA_PAD readable bytes behind its end: the literal
+// atoms confirmed (appended to lits), returns "walk the request through the DFA" (filter.cpp; tune and the CPU test hook use it).
+bool confirm_field_host(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, std::vector<uint16_t> &lits, bool *flagged = nullptr);
 // Which heads hold for the field value: bit k = heads[k].
 uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n);
 

@@ -85,6 +85,7 @@ def lib():
     L.pwaf_program_warning.restype = C.c_char_p
     L.pwaf_program_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
     L.pwaf_program_rule_status.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.pwaf_program_confirm_field.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pwaf_engine_create.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
     L.pwaf_engine_destroy.argtypes = [vp]
     L.pwaf_engine_destroy.restype = None
@@ -282,6 +283,16 @@ class CompiledProgram:
         buf = C.create_string_buffer(n)
         lib().pwaf_program_dump(self._h, buf, n)
         return buf.raw
+
+    def confirm_field(self, group: int, data: bytes, arena_offset: int = 0):
+        """TEST HOOK (pwaf_program_confirm_field): prefilter + confirm tier of pass `group` over one field value, run by the very code the
+        device compiles (csrc/confirm.h). Returns (local atoms of the confirmed literal predicates, flagged, walk)."""
+        atoms = (C.c_uint16 * 4096)()
+        n, fl, wk = C.c_size_t(), C.c_int(), C.c_int()
+        rc = lib().pwaf_program_confirm_field(self._h, group, data, len(data), arena_offset, atoms, 4096, C.byref(n), C.byref(fl), C.byref(wk))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return sorted(set(atoms[k] for k in range(n.value))), bool(fl.value), bool(wk.value)
 
     def rule_status(self, i: int) -> Tuple[int, str]:
         """(PWAF_OK, "") or (PWAF_E_UNSUPPORTED, reason): a rule the device compiler cannot take never matches and says so here."""

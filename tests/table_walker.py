@@ -43,7 +43,12 @@ def parse_dump(blob: bytes):
 
 
 class Tables:
-    def __init__(self, blob: bytes):
+    def __init__(self, blob):
+        """`blob`: a program dump, or the CompiledProgram itself (then the confirm tier of its filtered passes is evaluated too,
+        through the program's test hook; from a bare dump a candidate is walked through the pass's full DFA, as PWAF_OPT_NO_CONFIRM does)."""
+        if hasattr(blob, "dump"):
+            self.program = blob
+            blob = blob.dump()
         self.groups = []
         cur = None
         for tag, count, pl in parse_dump(blob):
@@ -80,6 +85,19 @@ class Tables:
                 cur["empty_state"] = struct.unpack_from("<4H", pl, 4)
                 cur["class_kind"] = np.frombuffer(pl, dtype=np.uint8, count=cur["n_classes"], offset=12)
                 cur["quiet"] = np.frombuffer(pl, dtype=np.uint8, count=cur["n_states"], offset=12 + cur["n_classes"])
+            elif tag == "GCNF":
+                cur["confirm"], cur["confirm_walk"], cur["confirm_entries"], cur["confirm_literals"] = struct.unpack("<4I", pl)
+            elif tag == "RHDR":
+                ns, nc = struct.unpack("<2I", pl)
+                cur["rtier"] = dict(n_states=ns, n_classes=nc, atom_base=cur["atom_base"])
+            elif tag == "RCLS":
+                cur["rtier"]["classmap"] = np.frombuffer(pl, dtype=np.uint8)
+            elif tag == "RTRN":
+                cur["rtier"]["trans"] = np.frombuffer(pl, dtype="<u2").reshape(cur["rtier"]["n_states"], cur["rtier"]["n_classes"])
+            elif tag in ("REMO", "RENO"):
+                cur["rtier"]["emit_off" if tag == "REMO" else "end_off"] = np.frombuffer(pl, dtype="<u4")
+            elif tag in ("REML", "RENL"):
+                cur["rtier"]["emit_list" if tag == "REML" else "end_list"] = np.frombuffer(pl, dtype="<u2")
             elif tag == "FCMP":
                 self.fcmp = np.frombuffer(pl, dtype=np.dtype([("col", "<u4"), ("op", "u1"), ("a", "u1"), ("b", "u1"), ("pad", "u1")]))
             elif tag == "HDRS":
@@ -148,7 +166,20 @@ class Tables:
             if data[:len(lit)] == lit and (not exact or len(data) == len(lit)):
                 cols.add(g["atom_base"] + local)
         flags = self.filter_flags(g, data)
-        if flags:
+        if flags and g.get("confirm") and self.program is not None and self.use_confirm:
+            # the confirm tier (run by csrc/confirm.h through the test hook: the code the device compiles): literal atoms decided at the
+            # flagged chunks; the request is walked — through the DFA of the pass's NON-literal atoms — only when a regex factor was confirmed
+            self.n_candidates += 1
+            atoms, flagged, walk = self.program.confirm_field(self.groups.index(g), data, self.arena_offset + self.filter_phase + 16 * self.arena_chunks)  # (filter_phase: the tests' way of saying "one byte further into the arena")
+            assert flagged
+            mine = {g["atom_base"] + a for a in atoms}
+            self.n_confirm_hits += len(mine)
+            if walk:
+                self.n_confirm_walks += 1
+                self.scan_field(g.get("rtier", g), data, mine)
+            cols |= mine
+            walked |= mine
+        elif flags:
             self.n_candidates += 1
             mine = set()
             self.scan_field(g, data, mine, flags if self.use_local_walks else None)
@@ -156,6 +187,11 @@ class Tables:
             walked |= mine
 
     use_filter = True
+    use_confirm = True
+    program = None        # the CompiledProgram the dump came from (the confirm tier runs through its test hook)
+    arena_chunks = 0      # whole 16-byte chunks in front of the field in the hook's arena (tests vary it: chunk-bitmap word boundaries)
+    n_confirm_hits = 0
+    n_confirm_walks = 0
     use_gates = True
     use_local_walks = True
     n_gated_walks = 0

@@ -15,7 +15,7 @@ B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
 
 
 def walk(program: CompiledProgram, batch: RequestBatch):
-    t = Tables(program.dump())
+    t = Tables(program)
     out = np.zeros(batch.n, dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     for i in range(batch.n):
         out[i] = t.evaluate(batch, i)
@@ -158,7 +158,7 @@ def test_dfa_grouping_respects_the_lds_budget_and_keeps_results():
     small = CompiledProgram(rules, max_table_bytes=4096)
     assert big.stats()["n_dfa_groups"] == 1  # one table per field: the literals and the captcha-endpoint prefix share the path table
     assert small.stats()["n_dfa_groups"] > big.stats()["n_dfa_groups"]
-    t = Tables(small.dump())
+    t = Tables(small)
     for g in t.groups:
         assert g["n_states"] * g["n_classes"] * 2 <= 4096
     reqs = [Request(path="/" + "".join(rng.choice(words + ["zz", "/"]) for _ in range(rng.randint(0, 3)))) for _ in range(200)]

@@ -102,7 +102,7 @@ def test_mmdb_table_drives_the_engine_like_the_original_table():
     reqs += [Request(ip="::" + str(ipaddress.IPv4Address(rng.randrange(2 ** 32)))) for _ in range(40)]  # IPv4-compatible IPv6: the ::/96 subtree
     batch = RequestBatch.from_requests(reqs)
     want = pyoracle.Oracle(rules, {}, via_mmdb).evaluate(batch)
-    t = Tables(CompiledProgram(rules, {}, via_mmdb).dump())
+    t = Tables(CompiledProgram(rules, {}, via_mmdb))
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, "mmdb table")
     # IPv4 requests see exactly what the directly built table gives
@@ -167,7 +167,7 @@ rules:
             Request(ip="2001:db8::1")]
     batch = RequestBatch.from_requests(reqs)
     want = pyoracle.Oracle(rules, lists).evaluate(batch)
-    t = Tables(CompiledProgram(rules, lists).dump())
+    t = Tables(CompiledProgram(rules, lists))
     got = [t.evaluate(batch, i) for i in range(batch.n)]
     assert [(int(a), int(r)) for a, r in got] == [(int(v["action"]), int(v["rule_idx"])) for v in want]
     assert [int(a) for a, _ in got] == [1, 2, 1, 0, 1]

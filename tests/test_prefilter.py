@@ -19,7 +19,7 @@ def test_filtered_pipeline_matches_oracle_on_literal_heavy_rules(seed):
     rules = H.lit_rules(rng, rng.randint(3, 40))
     prog = CompiledProgram(rules, {})
     assert prog.stats()["n_filtered_groups"] >= 1, "literal rule sets must end up behind the prefilter"
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     batch = RequestBatch.from_requests(H.lit_requests(rng, 150))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
     for i in range(batch.n):
@@ -32,7 +32,7 @@ def test_filtered_pipeline_matches_oracle_on_literal_heavy_rules(seed):
 def test_filter_has_no_false_negatives_and_heads_are_exact(seed):
     rng = random.Random(9500 + seed)
     rules = H.lit_rules(rng, 30)
-    t = table_walker.Tables(CompiledProgram(rules, {}).dump())
+    t = table_walker.Tables(CompiledProgram(rules, {}))
     batch = RequestBatch.from_requests(H.lit_requests(rng, 300))
     checked = 0
     for g in t.groups:
@@ -67,7 +67,7 @@ def test_synthetic_config3_filters_and_candidate_rates():
 
     w = pysynth.Workload(3)
     prog = CompiledProgram(w.rules, w.lists, w.geoip)
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     filtered = {g["field"] for g in t.groups if "f_table" in g}
     assert filtered == {0, 1, 2, 4}
     b = w.batch(0, 1500)
@@ -85,7 +85,7 @@ def test_stride_two_filters_have_no_false_negatives_at_either_phase(seed):
     rng = random.Random(9900 + seed)
     rules = H.lit_rules(rng, rng.randint(3, 40))
     prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2)
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     strides = {g["f_stride"] for g in t.groups if "f_table" in g}
     batch = RequestBatch.from_requests(H.lit_requests(rng, 200))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
@@ -108,12 +108,12 @@ def test_stride_two_filters_have_no_false_negatives_at_either_phase(seed):
 
 def test_stride_two_is_taken_where_the_factors_allow_it():
     rules = [("ua", 'http_request.user_agent.contains("sqlmap") || http_request.user_agent.contains("nikto/2")', [H.B]), ("p", 'http_request.path.contains("../")', [H.B])]
-    t = table_walker.Tables(CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2).dump())
+    t = table_walker.Tables(CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2))
     by_field = {g["field"]: g["f_stride"] for g in t.groups if "f_table" in g}
     assert by_field[4] == 2 and by_field[2] == 2  # ("../" still has one sampled bigram per alignment)
     # without the flag (and without a traffic sample) the built-in prior decides per pass: the User-Agent tokens keep their
     # selectivity with half the bigrams sampled, the three-byte "../" does not
-    t1 = table_walker.Tables(CompiledProgram(rules, {}).dump())
+    t1 = table_walker.Tables(CompiledProgram(rules, {}))
     by_field = {g["field"]: g["f_stride"] for g in t1.groups if "f_table" in g}
     assert by_field[4] == 2 and by_field[2] == 1
 
@@ -152,7 +152,7 @@ def test_a_prefilter_factor_of_a_gap_pass_is_never_a_filter_head():
     for tuned in (False, True):
         if tuned:
             prog.tune(RequestBatch.from_requests(reqs(500)))
-        t = table_walker.Tables(prog.dump())
+        t = table_walker.Tables(prog)
         gated = [g for g in t.groups if g.get("filter_cols")]
         assert gated, "the state budget must force gated gap passes"
         factor_cols = {c for g in gated for c in g["filter_cols"]}
@@ -175,7 +175,7 @@ def test_tuned_filters_keep_every_verdict(seed):
     rules = H.lit_rules(rng, rng.randint(3, 40))
     prog = CompiledProgram(rules, {}, max_dfa_states=rng.choice([0, 0, 400]))
     prog.tune(RequestBatch.from_requests(H.lit_requests(rng, 400)))
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     batch = RequestBatch.from_requests(H.lit_requests(rng, 120))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
     for phase in (0, 1):
@@ -222,7 +222,7 @@ def test_localized_walks_keep_every_verdict(seed):
     prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0)
     if seed % 2:
         prog.tune(RequestBatch.from_requests(_long_requests(rng, 300)))
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     batch = RequestBatch.from_requests(_long_requests(rng, 100))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
     steps = {}
@@ -247,7 +247,7 @@ def test_reach_and_quiet_states_of_a_filtered_pass():
     from a match's first byte to the end of its factor — the literal's length for a plain literal, unbounded as soon as one pattern
     puts an unbounded repeat before its factor — and the DFA has an empty state for every byte kind plus the quiet successors."""
     def one(rules):
-        t = table_walker.Tables(CompiledProgram(rules, {}).dump())
+        t = table_walker.Tables(CompiledProgram(rules, {}))
         return [g for g in t.groups if "f_table" in g][0]
 
     g = one([("a", 'http_request.path.contains("/wp-admin/x")', [H.B]), ("b", 'http_request.path.ends_with(".php5")', [H.B])])
@@ -264,3 +264,95 @@ def test_reach_and_quiet_states_of_a_filtered_pass():
     assert 0 < int(np.sum(g["quiet"])) < g["n_states"]
     for s in empties:  # what one byte makes of an empty state is quiet too
         assert all(g["quiet"][int(x)] for x in g["trans"][s])
+
+
+def _near_miss_requests(rng, rules_tokens, n):
+    """Fields made of rule tokens whole, cut short by a byte or two, case-swapped and doubled — what hostile traffic looks like."""
+    out = []
+    for _ in range(n):
+        def field(lo, hi):
+            parts = []
+            for _ in range(rng.randint(lo, hi)):
+                tok = rng.choice(rules_tokens)
+                kind = rng.random()
+                if kind < 0.35:
+                    tok = tok[:max(1, len(tok) - rng.randint(1, 2))]      # a near miss: all but the last byte or two
+                elif kind < 0.45:
+                    tok = tok.swapcase()
+                elif kind < 0.55:
+                    tok = tok[1:]                                          # ... or all but the first
+                parts.append(H.rstr(rng, 0, 9, "abcxyz/._-=&0123456789 ") + tok)
+            return "".join(parts) + H.rstr(rng, 0, 6, "abc/")
+        out.append(Request(host=field(0, 2)[:60] or "h", path="/" + field(0, 3)[:120], url="/" + field(0, 4)[:480], user_agent=field(0, 3)[:250] or "ua"))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_confirm_tier_decides_literals_and_walks_only_confirmed_regex_factors(seed):
+    """Round 4: behind the bigram filter a CONFIRM tier compares, at every flagged position, the complete factor whose window can end
+    there (csrc/confirm.h — the code the device compiles, run here through pwaf_program_confirm_field): literal predicates are decided
+    without a DFA, and a request is walked (through the DFA of the pass's non-literal atoms) only when a regex factor was confirmed.
+    Verdicts are the oracle's on traffic made of near misses, at both strides, at every arena alignment, tuned or not; and the
+    tier does what it is for: near misses are confirmed away instead of walked."""
+    rng = random.Random(4100 + seed)
+    toks = [H.lit_token(rng) for _ in range(rng.randint(4, 24))]
+    rules = []
+    for k, tk in enumerate(toks):
+        f = rng.choice(["path", "url", "user_agent", "host"])
+        kind = rng.random()
+        if kind < 0.45:
+            e = f"http_request.{f}.contains({H.q(tk)})"
+        elif kind < 0.55:
+            e = f"http_request.{f}.starts_with({H.q('/' + tk if f in ('path', 'url') else tk)})"
+        elif kind < 0.65:
+            e = f"http_request.{f}.ends_with({H.q(tk)})"
+        elif kind < 0.70:
+            e = f"http_request.{f} == {H.q(tk)}"
+        elif kind < 0.85:
+            e = f"http_request.{f}.matches({H.q('(?i)' + tk[:3] + '[a-z0-9_]*' + tk[3:])})" if len(tk) > 4 else f"http_request.{f}.matches({H.q(tk + '[0-9]+')})"
+        else:
+            e = f"http_request.{f}.matches({H.q(tk + chr(92) + 's+' + toks[(k + 1) % len(toks)])})"
+        if rng.random() < 0.2:
+            e = "!" + e + f" && http_request.{f}.length() > 3"
+        rules.append((f"r{k}", e, [rng.choice([H.B, H.CAP])]))
+    flags = _abi.OPT_FILTER_STRIDE2 if seed % 3 == 1 else 0
+    prog = CompiledProgram(rules, {}, flags=flags)
+    st = prog.stats()
+    if st["n_filtered_groups"] == 0:
+        pytest.skip("no pass of this rule set is filterable")
+    reqs = _near_miss_requests(rng, toks, 120)
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, {}).evaluate(batch)
+    t = table_walker.Tables(prog)
+    plain = table_walker.Tables(CompiledProgram(rules, {}, flags=flags | _abi.OPT_NO_CONFIRM))
+    for tuned in (False, True):
+        if tuned:
+            prog.tune(RequestBatch.from_requests(_near_miss_requests(rng, toks, 200) + H.lit_requests(rng, 200)))
+            t = table_walker.Tables(prog)
+        for i in range(batch.n):
+            t.arena_offset, t.filter_phase = rng.randrange(16), rng.randrange(2)
+            got = t.evaluate(batch, i)
+            assert got == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, tuned, i, rules, [batch.field_bytes(f, i) for f in range(5)])
+    for i in range(batch.n):
+        assert plain.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"]))
+    if st["n_confirm_literals"]:
+        assert t.n_confirm_hits > 0 or not np.count_nonzero(want["action"])
+        assert t.n_confirm_walks < t.n_candidates  # some candidates were settled without a walk
+    assert plain.n_confirm_hits == 0 and all(not g.get("confirm") for g in plain.groups)
+
+
+def test_confirm_tier_on_the_synthetic_hostile_stream():
+    """The 1k-rule set (BASELINE.json configs[2]) on its hostile stream: most candidates of the literal-heavy passes are near misses,
+    which the confirm tier settles without a walk; verdicts are the oracle's."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    prog = CompiledProgram(w.rules, w.lists, w.geoip)
+    st = prog.stats()
+    assert st["n_confirm_literals"] >= 400, st
+    t = table_walker.Tables(prog)
+    b = w.batch(7000, 160, adversarial=True)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(b, threads=8)
+    for i in range(b.n):
+        assert t.evaluate(b, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), i
+    assert t.n_candidates > 100 and t.n_confirm_walks < 0.8 * t.n_candidates, (t.n_candidates, t.n_confirm_walks)

@@ -304,7 +304,7 @@ def test_rule_sets_mixing_column_and_residual_rules_through_the_compiler(seed):
     seen, _ = H.as_the_engine_sees(rules, prog)
     batch = RequestBatch.from_requests(requests(rng, 40))
     want = pyoracle.Oracle(seen, LISTS, flags=flags).evaluate(batch)
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, f"seed {seed}: {[r[1] for r in rules]}")
     test_rule_sets_mixing_column_and_residual_rules_through_the_compiler.n_residual = getattr(test_rule_sets_mixing_column_and_residual_rules_through_the_compiler, "n_residual", 0) + getattr(t, "n_residual", 0)
@@ -331,7 +331,7 @@ def test_dnf_explosion_falls_to_the_interpreter():
         reqs.append(Request(path="/" + "".join(t for t in toks if t[0] == "a") + rng.choice(["", "zz"]), url="/" + "".join(t for t in toks if t[0] == "b"), host="".join(t for t in toks if t[0] == "c"), user_agent="ua"))
     batch = RequestBatch.from_requests(reqs)
     want = pyoracle.Oracle(rules).evaluate(batch)
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, "DNF explosion")
     assert len(set(want["rule_idx"].tolist())) >= 2

@@ -33,7 +33,7 @@ for seed in range(lo, hi):
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
     rules, _ = H.as_the_engine_sees(rules, prog)
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
-    t = Tables(prog.dump())
+    t = Tables(prog)
     t.filter_phase = seed & 1
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     try:

@@ -51,7 +51,7 @@ def main():
     wl = pysynth.Workload(cfg)
     prog = CompiledProgram(wl.rules, wl.lists, wl.geoip, flags=16 if '--stride2' in sys.argv else 0)
     print(prog.stats())
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     b = wl.batch(0, n)
     names = ["host", "url", "path", "method", "user_agent"]
     for gi, g in enumerate(t.groups):
@@ -69,7 +69,7 @@ main()
 def crosscheck():
     wl = pysynth.Workload(3)
     prog = CompiledProgram(wl.rules, wl.lists, wl.geoip)
-    t = table_walker.Tables(prog.dump())
+    t = table_walker.Tables(prog)
     b = wl.batch(0, 3000)
     for g in t.groups:
         if "f_table" not in g:

@@ -57,7 +57,7 @@ for seed in range(lo, hi):
     batch = RequestBatch.from_requests(requests(40))
     rules2, _ = H.as_the_engine_sees(rules, prog)
     want = pyoracle.Oracle(rules2, lists, None, flags=flags).evaluate(batch)
-    t = Tables(prog.dump())
+    t = Tables(prog)
     for local in (False, True):
         t.use_local_walks, t.n_steps = local, 0
         t.arena_offset = rng.randrange(16) if local else 0
