@@ -132,10 +132,6 @@ void pwaf_list_free(char **items, size_t n);
                                        * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */
 #define PWAF_OPT_NO_CONFIRM 512u      /* testing / A-B: no confirm tier — every prefilter candidate is walked through the pass's full DFA
                                        * (the round-3 path): same verdicts */
-#define PWAF_OPT_LOCAL_WALKS 256u     /* EXPERIMENTAL: a prefilter candidate is walked only from shortly before its first flagged 16-byte
-                                       * chunk until the DFA holds no thread older than the byte after its last one,
-                                       * instead of from its first byte to its last: same verdicts. Off by default: measured on MI355X it
-                                       * saves steps but no time (the 64 walks of a wave advance in lockstep) */
 typedef struct pwaf_options {
     uint32_t struct_size; /* sizeof(pwaf_options) */
     uint32_t flags;

@@ -1571,13 +1571,6 @@ std::vector<uint8_t> dump_program(const Program &p) {
             if (!g.filter.heads.empty()) memcpy(fh.data() + 8, g.filter.heads.data(), g.filter.heads.size() * sizeof(FilterHead));
             w.section("GFHD", (uint32_t)gi, fh.data(), fh.size());
             w.section("GFTB", (uint32_t)gi, g.filter.table.data(), g.filter.table.size() * 4);
-            // localized walks: the filter's reach, then the DFA's empty states (4 x u16), class kinds and quiet flags (one byte each)
-            std::vector<uint8_t> lw(4 + 8 + g.class_kind.size() + g.quiet.size());
-            memcpy(lw.data(), &g.filter.reach, 4);
-            memcpy(lw.data() + 4, g.empty_state, 8);
-            if (!g.class_kind.empty()) memcpy(lw.data() + 12, g.class_kind.data(), g.class_kind.size());
-            if (!g.quiet.empty()) memcpy(lw.data() + 12 + g.class_kind.size(), g.quiet.data(), g.quiet.size());
-            w.section("GLOC", (uint32_t)gi, lw.data(), lw.size());
             // confirm tier: [enabled, has_walk, entries, literal atoms of the pass]; the R-tier DFA the confirmed candidates walk
             const uint32_t ch[4] = {g.filter.confirm.enabled ? 1u : 0u, g.filter.confirm.has_walk ? 1u : 0u, (uint32_t)g.filter.confirm.entries.size(), g.n_confirm_literals};
             w.section("GCNF", (uint32_t)gi, ch, sizeof ch);

@@ -362,18 +362,6 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
     DKey k0;
     k0.pk = K_EDGE;
     intern(std::move(k0));
-    // The mid-stream "empty" states: no live thread, previous byte of kind pk. The unanchored search is in exactly this state at a
-    // position where no match is in progress, so a walk may START there in the middle of a field (a list-scan walk begins shortly
-    // before a candidate's first flagged chunk: DESIGN.md §4.4) — they are built whether or not the start state reaches them.
-    int empty_of[4] = {-1, -1, -1, -1};
-    for (uint8_t nk : {K_OTHER, K_WORD, K_NEWLINE}) {
-        bool used = false;
-        for (int c = 0; c < n_cls; c++) if (cls_kind[c] == nk) used = true;
-        if (!used) continue;
-        DKey ke;
-        ke.pk = nk;
-        empty_of[nk] = intern(std::move(ke));
-    }
     std::vector<int> liveA, liveB, pending, rel;
     std::vector<uint16_t> accA, accB, entry_emits;
     for (size_t d = 0; d < ds.size(); d++) {
@@ -491,15 +479,6 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
     out.atoms.clear();
     for (auto &p : pats) out.atoms.push_back(p.atom);
     out.n_local = (uint32_t)pats.size();
-    // quiet states: the empty states and what one byte makes of them — no thread older than the last byte read
-    out.class_kind.assign(cls_kind.begin(), cls_kind.end());
-    out.quiet.assign(S, 0);
-    for (int k = 0; k < 4; k++) {
-        out.empty_state[k] = empty_of[k] >= 0 ? (uint16_t)empty_of[k] : (uint16_t)0xFFFFu;
-        if (empty_of[k] < 0) continue;
-        out.quiet[(size_t)empty_of[k]] = 1;
-        for (int c = 0; c < n_cls; c++) out.quiet[(size_t)ds[(size_t)empty_of[k]].next[c]] = 1;
-    }
     return true;
 }
 

@@ -80,8 +80,6 @@ struct FlatDev {
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list, delta;
     uint32_t n_states = 0, n_classes = 0;
     uint32_t n_full = 0, n_delta = 0;  // LDS layout of the list scan: rows [0, n_full), then n_delta 8-byte delta records (states n_full ..)
-    uint32_t n_quiet = 1;    // flat rows [0, n_quiet): the start state and the quiet states
-    bool can_skip = false;   // the flat table has an empty state for every byte kind: a walk may start inside a field
     void release() {
         for (DevBuf *b : {&flat, &flat_classmap, &emit_off, &emit_list, &end_off, &end_list, &delta}) b->release();
         n_states = 0;
@@ -356,12 +354,6 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
     std::vector<uint32_t> order(S), pos(S);
     for (uint32_t s = 0; s < S; s++) order[s] = s;
     if (visits && visits->size() == S) std::stable_sort(order.begin() + 1, order.end(), [&](uint32_t x, uint32_t y) { return (*visits)[x] > (*visits)[y]; });
-    // The QUIET states (no thread older than one byte: program.h) come right after the start state, so that "row < n_quiet" is the
-    // kernel's test for ending a localized walk; they are where benign text spends its steps anyway.
-    const bool has_quiet = g.quiet.size() == S;
-    if (has_quiet) std::stable_partition(order.begin() + 1, order.end(), [&](uint32_t x) { return g.quiet[x] != 0; });
-    d.n_quiet = 1;
-    if (has_quiet) for (uint32_t s = 1; s < S; s++) d.n_quiet += g.quiet[s] ? 1u : 0u;
     // DELTA rows. A row that is not LDS-resident costs an L2 round trip per step, and with 64 walks in lockstep some lane is in
     // such a row in nearly every group of steps once a twentieth of the steps are (hostile traffic: near misses of the rule
     // literals, deep in the patterns' prefix chains). But such states are the cheap kind: a state deep inside one literal differs
@@ -369,13 +361,13 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
     // of the hottest rows is therefore kept in LDS as an 8-byte record (base row, two exception cells) instead of a row of 100-150
     // bytes: measured on the 1k-rule set, all of the hostile stream's steps outside the resident rows are in such states. The rows /
     // records split maximises the sample visits covered (no sample: the states covered).
-    const uint32_t row_bytes = 2u * (C + 3u), budget = list_hot_bytes(list_shape(wide ? 2u : 0u), false);
+    const uint32_t row_bytes = 2u * (C + 3u), budget = list_hot_bytes(list_shape(wide ? 2u : 0u));
     const uint32_t cap_rows = std::min<uint32_t>(S, (budget - 48u) / row_bytes);
     d.n_full = cap_rows;
     d.n_delta = 0;
     std::vector<uint64_t> delta_rec;
-    if (S > cap_rows && cap_rows >= 8 && C <= 255 && d.n_quiet <= cap_rows) {
-        const uint32_t B = std::min<uint32_t>(cap_rows, std::max<uint32_t>(512, d.n_quiet));  // candidate base rows: the hottest ones (the quiet states, which the localized walks test by row number, stay rows)
+    if (S > cap_rows && cap_rows >= 8 && C <= 255) {
+        const uint32_t B = std::min<uint32_t>(cap_rows, 512u);  // candidate base rows: the hottest ones
         struct Near { uint16_t base; uint8_t n, c[2]; };
         std::vector<Near> near(S, Near{0, 255, {0, 0}});
         for (uint32_t q = B; q < S; q++) {
@@ -453,20 +445,7 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
         end_off.push_back((uint32_t)end_list.size());
     }
-    // class map (256 bytes), then per byte value the row of the empty state a walk takes when it starts right AFTER such a byte
-    // (0xFFFF: the DFA has none — walks start at the field's first byte)
-    std::vector<uint8_t> cm(256 + 512);
-    memcpy(cm.data(), g.classmap, 256);
-    d.can_skip = has_quiet && g.class_kind.size() == C;
-    for (int b = 0; b < 256; b++) {
-        uint16_t row = 0xFFFFu;
-        if (d.can_skip) {
-            const uint16_t es = g.empty_state[g.class_kind[g.classmap[b]] & 3u];
-            if (es != 0xFFFFu) row = (uint16_t)pos[es];
-            else d.can_skip = false;
-        }
-        memcpy(cm.data() + 256 + 2 * b, &row, 2);
-    }
+    std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
     int rc;
     if ((rc = upload(d.flat, flat, 16))) return rc;  // (the LDS staging copies whole 16-byte units)
     if (delta_rec.empty()) delta_rec.push_back(0);
@@ -546,7 +525,7 @@ int assign_lists(pwaf_engine *e) {
             if ((rc = upload(d.ftable, d.filter.table))) return rc;
             // the confirm tier built with this filter (program.h: ConfirmTable)
             const ConfirmTable &ct = d.filter.confirm;
-            d.confirm = ct.enabled && !(P.flags & PWAF_OPT_LOCAL_WALKS);
+            d.confirm = ct.enabled;
             d.confirm_walk = d.confirm && ct.has_walk;
             if (d.confirm && ((rc = upload(d.c_head, ct.head)) || (rc = upload(d.c_entries, ct.entries)) || (rc = upload(d.c_bytes, ct.bytes)) || (rc = upload(d.c_classes, ct.classes)))) return rc;
         }
@@ -975,18 +954,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
 #endif
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
     std::vector<const uint32_t *> walk_of(e->groups.size(), nullptr);        // passes with a confirm tier: confirm_kernel's walk flags (set in step 2)
-    std::vector<const uint32_t *> chunk_bits_of(e->groups.size(), nullptr);  // filtered passes: this batch's chunk bitmap (set in step 2)
-    std::vector<uint32_t> chunk_base_of(e->groups.size(), 0);
-    // PWAF_OPT_LOCAL_WALKS (off by default: it saves steps, not time — DESIGN.md §4.6): prefilter candidates are walked locally
-    bool local_walks = (P.flags & PWAF_OPT_LOCAL_WALKS) != 0;
-#ifdef PWAF_PROFILING
-    // timing experiments (same results): PWAF_LOCAL_WALKS = the option; PWAF_WHOLE_WALKS = the local kernel, but every candidate walked from its first byte to its last
-    static const bool whole_walks = getenv("PWAF_WHOLE_WALKS") != nullptr, env_local = getenv("PWAF_LOCAL_WALKS") != nullptr;
-    local_walks = local_walks || env_local || whole_walks;
-#else
-    constexpr bool whole_walks = false;
-#endif
-    auto list_args = [&](size_t gi, const ListShape &lshape, bool phase_is_local) -> ListScanArgs {
+    auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
@@ -1015,14 +983,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             a.need_bit = 0;
             a.merge_rec = 1;
         }
-        if (d.filtered && chunk_bits_of[gi] != nullptr && !d.confirm) {
-            // localized walks: between the candidate's first and last flagged chunk, give or take the filter's reach
-            a.chunk_bits = chunk_bits_of[gi];
-            a.chunk_base = chunk_base_of[gi];
-            a.reach = d.fl.can_skip && !whole_walks ? d.filter.reach : kUnboundedReach;
-            a.n_quiet = whole_walks ? 0u : d.fl.n_quiet;
-            a.has_heads = d.filter.heads.empty() ? 0u : 1u;  // (exactly the passes whose records the host zeroes)
-        }
         a.behind_filter = d.filtered ? 1u : 0u;
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
@@ -1033,7 +993,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.n_classes = F.n_classes;
         {
             // rows [0, n_full) and the delta records behind them, when this launch's LDS share holds the layout the tables were built for
-            const uint32_t row_bytes = 2u * (F.n_classes + 3u), hb = list_hot_bytes(lshape, phase_is_local);
+            const uint32_t row_bytes = 2u * (F.n_classes + 3u), hb = list_hot_bytes(lshape);
             if (F.n_delta && (uint64_t)F.n_full * row_bytes + 48u + 8ull * F.n_delta <= hb) {
                 a.n_hot = F.n_full;
                 a.n_delta = F.n_delta;
@@ -1127,10 +1087,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             const uint32_t slabs = (uint32_t)(((uint64_t)f.total + kStreamSlab - 1) / kStreamSlab) - f.slab0;
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
             f.chunk_bits = (uint32_t *)S.chunk_bits.p + sub_at;
-            if (local_walks && !d.confirm) {
-                chunk_bits_of[gi] = f.chunk_bits;
-                chunk_base_of[gi] = (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u) * (kStreamSlab / 16);
-            }
             f.sub_count = (uint32_t *)S.cand_cnt.p + cnt_at;
             f.block_count = f.sub_count + slabs;
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
@@ -1235,8 +1191,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
     {
         std::vector<ListScanArgs> la[2];
-        bool phase0_local = false;  // (launch_scan_gated takes the local kernel — less LDS for hot rows — when a pass of the launch has a chunk bitmap)
-        for (size_t gi = 0; gi < e->groups.size(); gi++) phase0_local = phase0_local || (e->groups[gi].filtered && chunk_bits_of[gi] != nullptr);
         for (int phase = 0; phase < 2; phase++)
             for (size_t gi = 0; gi < e->groups.size(); gi++) {
                 const DevGroup &d = e->groups[gi];
@@ -1246,7 +1200,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
                 if (skip_identity && d.identity) continue;
 #endif
-                la[phase].push_back(list_args(gi, lshapes[phase], phase == 0 && phase0_local));
+                la[phase].push_back(list_args(gi, lshapes[phase]));
             }
         const size_t n_desc = la[0].size() + la[1].size();
         if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (n_desc + 2) * 4))) return rc;
@@ -2071,7 +2025,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             if (!g2.enabled) continue;
             g2.est_candidate_rate = sample_rate(g2, sc);
 #ifdef PWAF_PROFILING
-            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads, reach %d), stride 2 %.4f (%zu heads, reach %d), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), (int)gf.reach, g2.est_candidate_rate, g2.heads.size(), (int)g2.reach, mean_len[g.field]);
+            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads), stride 2 %.4f (%zu heads), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.est_candidate_rate, g2.heads.size(), mean_len[g.field]);
 #endif
             const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
             g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);

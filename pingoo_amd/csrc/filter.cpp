@@ -33,23 +33,12 @@ using CStr = std::vector<ByteSet>;  // a "class string": one byte set per positi
 struct Cover {
     bool ok = false;
     std::vector<CStr> s;
-    // Upper bound on (end of the factor occurrence the cover guarantees) - (start of the match), in bytes; INFINITY when the match
-    // may begin arbitrarily far before its factor (`^/api/v[0-9]+/name`: the factor `/name` follows an unbounded repeat). The list
-    // scan uses the pass's maximum: a candidate's walk may start that far before its first flagged chunk (program.h: GroupFilter::reach).
-    double reach = 0;
 };
 // E: every match IS one of these (exact cover); P / S: every match starts / ends with one of these (always known: {""} is trivial);
 // B: every match CONTAINS one of these somewhere (best inner factor set found so far).
 struct Ext {
     Cover E, P, S, B;
-    double maxlen = 0;  // longest match of the node (INFINITY: unbounded)
 };
-
-static double longest(const Cover &c) {
-    size_t l = 0;
-    for (auto &x : c.s) l = std::max(l, x.size());
-    return (double)l;
-}
 
 constexpr size_t kMaxStrs = 24, kMaxLen = 64, kMaxClass = 16;
 
@@ -65,7 +54,6 @@ static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return (uint32_t)(a & 0
 struct Model {
     const double *pairw;  // 65536 probabilities of the case-folded bigrams
     size_t stride;        // sampling stride of the filter being built
-    bool prefer_bounded;  // see better()
     // the distinct folded pairs of two byte sets
     static void pairs_of(const ByteSet &a, const ByteSet &b, std::vector<uint16_t> &out) {
         std::set<uint32_t> ps;
@@ -146,42 +134,22 @@ bool unite(const Cover &a, const Cover &b, Cover &out) {
     out.ok = true;
     out.s = a.s;
     out.s.insert(out.s.end(), b.s.begin(), b.s.end());
-    out.reach = std::max(a.reach, b.reach);
     return true;
 }
 
-// The cheaper cover (expected false positives) — except that, at stride 1, a cover with a BOUNDED reach is preferred to an unbounded
-// one whenever it is selective enough itself (below one expected false window per 10^4 positions): a bounded pass lets the list scan
-// skip the bytes before a candidate's first flagged chunk, which is worth more than the last factor of two in the filter's precision.
-// (Not at stride 2, whose windows sample half the bigrams: measured on the 1k-rule set's path pass, `/api/v[0-9]` and `/wp-admin/`
-// instead of the rare words behind them flag 4.9 % of benign requests instead of 2.1 %.)
-const Cover &better(Model &m, const Cover &a, const Cover &b) {
-    const double sa = m.score(a), sb = m.score(b);
-    const bool fa = std::isfinite(a.reach), fb = std::isfinite(b.reach);
-    if (fa != fb && std::isfinite(sa) && std::isfinite(sb)) {
-        const Cover &bounded = fa ? a : b;
-        if (m.prefer_bounded && (fa ? sa : sb) < 1e-4) return bounded;
-    }
-    return sb < sa ? b : a;
-}
+// The cheaper cover (expected false positives).
+const Cover &better(Model &m, const Cover &a, const Cover &b) { return m.score(b) < m.score(a) ? b : a; }
 
 Ext cat2(Model &m, const Ext &a, const Ext &b) {
     Ext r;
     Cover t;
-    r.maxlen = a.maxlen + b.maxlen;
-    if (cross(a.E, b.E, t, 0)) { r.E = t; r.E.reach = longest(t); }
-    if (a.E.ok && cross(a.E, b.P, t, 1)) { r.P = t; r.P.reach = longest(t); }
+    if (cross(a.E, b.E, t, 0)) r.E = t;
+    if (a.E.ok && cross(a.E, b.P, t, 1)) r.P = t;
     else r.P = a.P;
     if (b.E.ok && cross(a.S, b.E, t, 2)) r.S = t;
     else r.S = b.S;
-    r.S.reach = r.maxlen;  // a suffix ends where the match ends
-    Cover bb = b.B;
-    bb.reach = a.maxlen + b.B.reach;  // b's inner factor, seen from the start of a
-    r.B = better(m, a.B, bb);
-    if (cross(a.S, b.P, t, 1)) {
-        t.reach = a.maxlen + longest(b.P);  // (an upper bound also for the strings cross() cut to their first kMaxLen bytes)
-        r.B = better(m, r.B, t);
-    }
+    r.B = better(m, a.B, b.B);
+    if (cross(a.S, b.P, t, 1)) r.B = better(m, r.B, t);
     if (!std::isfinite(m.score(r.B))) r.B = Cover();
     return r;
 }
@@ -194,15 +162,12 @@ Ext extract(Model &m, const RNode &n) {
             r.E = r.P = r.S = trivial();
             return r;
         case RNode::CLASS:
-            r.maxlen = 1;
             if (n.cls.count() >= 1 && n.cls.count() <= kMaxClass) {
                 r.E.ok = true;
                 r.E.s.push_back({n.cls});
-                r.E.reach = 1;
                 r.P = r.S = r.E;
             } else {
                 r.P = r.S = trivial();
-                r.S.reach = 1;
             }
             return r;
         case RNode::CAT: {
@@ -215,7 +180,6 @@ Ext extract(Model &m, const RNode &n) {
             Cover bset;
             for (auto &k : n.kids) {
                 Ext c = extract(m, *k);
-                r.maxlen = std::max(r.maxlen, c.maxlen);
                 // what a whole alternative guarantees: its best inner factor, or the alternative itself
                 Cover cand = c.B;
                 cand = better(m, cand, c.E);
@@ -237,20 +201,14 @@ Ext extract(Model &m, const RNode &n) {
                 if (b_ok && !unite(bset, cand, t)) b_ok = false;
                 else if (b_ok) bset = t;
             }
-            r.E.reach = longest(r.E);
-            r.P.reach = longest(r.P);
-            r.S.reach = r.maxlen;
             if (b_ok && !first) r.B = bset;
             return r;
         }
         case RNode::REPEAT: {
             const Ext c = extract(m, *n.kids[0]);
-            const double total = n.rmax < 0 ? (c.maxlen > 0 ? INFINITY : 0.0) : (double)n.rmax * c.maxlen;  // (rmax < 0: unbounded)
             if (n.rmin <= 0) {
                 if (n.rmax == 0) r.E = trivial();
                 r.P = r.S = trivial();
-                r.maxlen = total;
-                r.S.reach = total;
                 return r;
             }
             const int copies = std::min(n.rmin, 4);
@@ -260,8 +218,6 @@ Ext extract(Model &m, const RNode &n) {
                 r.E = Cover();  // more may follow the copies taken
                 r.S = c.S;      // ... but the last repetition still ends the match
             }
-            r.maxlen = total;
-            r.S.reach = total;
             return r;
         }
     }
@@ -437,7 +393,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     // smoothed: a bigram the sample never showed is still possible
     std::vector<double> pw(65536);
     for (uint32_t x = 0; x < 65536; x++) pw[x] = pairw0[x] * 0.98 + 0.02 / 65536;
-    Model m{pw.data(), stride, stride == 1};
+    Model m{pw.data(), stride};
 
     if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
     if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
@@ -483,7 +439,6 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     // ---- factors -> windows ----
     std::map<std::string, size_t> index;
     std::vector<Window> wins;
-    double reach = 0;  // of the pass: the maximum over its patterns' factor sets
     std::vector<ConfirmSeed> seeds;  // every (factor, alignment) entered into the filter, for the confirm tier
     const bool l_fits_records = g.atoms.size() < kConfirmWalk;
     for (uint32_t l = 0; l < g.atoms.size(); l++) {
@@ -507,7 +462,6 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             for (unsigned char ch : c_lit) { ByteSet b1; b1.set(ch); cs.push_back(b1); }
             f.ok = true;
             f.s.push_back(std::move(cs));
-            f.reach = (double)c_lit.size();
         } else {
             Ext x = extract(m, *at.pattern);
             f = x.B;
@@ -520,7 +474,6 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             out.heads.clear();
             return;
         }
-        reach = std::max(reach, f.reach);
         for (auto &s : f.s)
             for (size_t al = 0; al < stride; al++) {
                 size_t st, k;
@@ -547,7 +500,6 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
             }
     }
     if (wins.empty() && out.heads.empty()) { out.note = "no patterns"; return; }
-    out.reach = std::isfinite(reach) && reach < 60000.0 ? (uint32_t)reach : kUnboundedReach;
 
     // ---- buckets, once per candidate multiplier of the bigram hash: the one whose bins keep the factor windows away from the
     //      traffic's frequent bigrams wins (a three-byte factor such as "../" owns only two positions: one unlucky collision with a

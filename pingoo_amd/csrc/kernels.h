@@ -80,7 +80,7 @@ struct ListScanArgs {
     const uint32_t *off;
     uint32_t n;
     const uint16_t *flat;
-    const uint8_t *classmap;  // 256 bytes (+ 512: the empty-state rows, see chunk_bits)
+    const uint8_t *classmap;  // 256 bytes
     uint32_t n_classes;
     uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 3) * 2 <= the launch's ListShape::hot_bytes
     // DELTA records (engine.cpp: build_flat_group): states [n_hot, n_hot + n_delta) live in LDS as 8 bytes each — base row (16 bits), two
@@ -100,14 +100,7 @@ struct ListScanArgs {
     uint32_t n_local;
     uint32_t *gate_lists;
     uint32_t *gate_count;
-    // A pass behind a bigram prefilter walks its candidates LOCALLY: chunk_bits = the pass's chunk bitmap of this batch (bit c = the
-    // arena's 16-byte chunk chunk_base + c was flagged); a walk starts `reach` bytes before the field's first flagged chunk, in
-    // the empty state of the byte before (classmap + 256: uint16 row per byte value), and ends once its state is below n_quiet past
-    // the last flagged chunk. Null: whole fields.
-    const uint32_t *chunk_bits;
-    uint32_t chunk_base, reach, n_quiet;
     uint32_t behind_filter;    // the list is a bigram prefilter's candidate list (hostile traffic makes it long: lscan_async)
-    uint32_t has_heads;        // the filter kernel compared heads for this pass: rec[] holds them (zeroed by the host), the walk merges them
     const uint32_t *req_list;  // the requests to visit and, on the device, how many (req_list null: every request, n_list ignored)
     const uint32_t *n_list;
     uint32_t *visited;         // bitmap: set bit r for every visited request (null: not needed — the list IS the pass's bitmap, or all)
@@ -397,8 +390,8 @@ struct ListShape {
     uint32_t threads, hot_bytes, wg_per_cu;
 };
 ListShape list_shape(uint32_t variant);  // 0 = default
-// LDS bytes left for hot rows in a launch of this shape (`local`: every pass is behind a prefilter — the waves' queues of deferred walks take their share)
-uint32_t list_hot_bytes(const ListShape &shape, bool local);
+// LDS bytes for hot rows in a launch of this shape
+uint32_t list_hot_bytes(const ListShape &shape);
 // `plan`: count + 1 words of device scratch (the work-item prefix sums, written by lscan_plan_kernel on the same stream)
 int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream);
 int launch_verdict(const VerdictArgs &a, void *stream);

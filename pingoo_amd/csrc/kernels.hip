@@ -509,198 +509,6 @@ __global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t 
     if (t == 0) plan[b.count] = part[255];
 }
 
-// The candidates of a pass behind a bigram prefilter, walked LOCALLY.
-//
-// kernels.h: ListScanArgs::chunk_bits. A flagged chunk c speaks for matches that begin at or after byte 16 c + 2 - reach (every match
-// holds a factor whose window was flagged where it completed, and begins at most `reach` bytes before that factor's end), so a walk
-// starts one byte before that, in the state a search with no thread alive has after the byte before; and after the last flagged
-// chunk no NEW match can complete its factor, so the walk ends with the last thread that began before byte 16 last + 16 — in a
-// quiet state. A candidate without a flagged chunk inside its own bytes (it was flagged by a neighbour's window) is not walked at
-// all. Near misses of the rule literals, what a hostile stream is made of, then cost a walk of the literal's length instead of the
-// field's.
-//
-// The 64 walks of a wave advance in lockstep, so a wave takes as long as its LONGEST walk — and local walks differ by an order of
-// magnitude (a field flagged at both ends is walked whole). Walks longer than kListLongSpan bytes are therefore DEFERRED: the lane
-// appends its request to the wave's own queue in LDS and sits the item out; whenever 64 have gathered (and once more at the end of
-// the wave's items) they are walked together, long ones among long ones. (Measured on the hostile stream of the 1k-rule set:
-// localized walks alone, in lockstep, changed nothing — 3.6 -> 4.0 ms; lanes that each run through their own sequence of list
-// entries, inputs prefetched piece by piece, were slower still — 4.6 ms, 5.6 ms with whole walks: the per-lane state machine costs
-// more per 16-byte step than the lockstep loop it replaces, and no lane can start a walk more often than its five input stages allow.)
-static constexpr uint32_t kListLongSpan = 128, kListQueue = 128;
-template <uint32_t THREADS>
-__device__ __forceinline__ void lscan_local(const ListScanArgs &a, const uint16_t *hot, const unsigned char *cls, const uint16_t *empt, uint32_t *queue,
-                                            uint32_t it, const uint32_t it_end, const uint32_t first, const uint32_t n_l, const uint32_t hot_elems) {
-    const uint32_t ncls = a.n_classes, stride = ncls + 3u, lane = threadIdx.x & 63u;
-    const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
-    const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
-    auto cell = [&](const uint32_t idx) -> uint32_t { return idx < hot_elems ? (uint32_t)hot[idx] : (uint32_t)flat[idx]; };
-    auto record_emit = [&](const uint32_t st, Hits &hh) {
-        const uint32_t code = cell(st * stride + ncls);
-        const uint32_t x = (code & 0x7FFFu) + 1u;
-        bool slow = !(code & 0x8000u) || hh.ovf != kNone;
-        if (!slow) {
-            if (hh.a0 == x || hh.a1 == x) {}
-            else if (hh.a0 == 0) hh.a0 = x;
-            else if (hh.a1 == 0) hh.a1 = x;
-            else slow = true;
-        }
-        if (slow) hh = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, hh);
-    };
-    uint32_t q_n = 0;  // wave-uniform: deferred requests in the wave's queue
-    // (deferring pays when a wave has several items to get through: with one or two — benign traffic, a few candidates per
-    // thousand requests — the deferred batch is simply a second walk behind the first: measured 0.19 -> 0.24 ms on the 10M-request batch)
-    const bool many = it_end - it >= 4u;
-    // One batch of <= 64 requests per wave, one per lane (`have`): `defer` = long walks go to the queue instead of being walked.
-    auto batch = [&](const bool have, const uint32_t r, const uint32_t li, const bool defer) {
-        uint32_t p = 0, end = 0, state = 0, stop_at = 0xFFFFFFFFu;
-        Hits h{0, 0, kNone};
-        bool live = have, cut = false;
-        if (have) {
-            p = a.off[r];
-            end = a.off[r + 1u];
-            if (a.has_heads) {  // what the filter kernel's head comparisons recorded: a walk that skips the field's first bytes does not see them
-                const uint32_t heads = a.rec[r];
-                h.a0 = heads & 0x7FFFu;
-                h.a1 = (heads >> 15) & 0x7FFFu;
-            }
-            if (a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31u));
-        }
-        bool skipped = false;
-        if (have && end > p && a.chunk_bits != nullptr) {  // (null: a plain pass over a short field that shares the launch — walked whole)
-            const uint32_t c_lo = (p >> 4) - a.chunk_base, c_hi = ((end - 1u) >> 4) - a.chunk_base, w_lo = c_lo >> 5, w_hi = c_hi >> 5;
-            if (w_hi - w_lo <= 2u) {  // (a field of more than ~1 KiB: walked whole)
-                uint32_t bits[3];
-                bits[0] = a.chunk_bits[w_lo];
-                bits[1] = w_hi > w_lo ? a.chunk_bits[w_lo + 1u] : 0u;
-                bits[2] = w_hi > w_lo + 1u ? a.chunk_bits[w_lo + 2u] : 0u;
-                bits[0] &= ~0u << (c_lo & 31u);
-                bits[w_hi - w_lo] &= ~0u >> (31u - (c_hi & 31u));
-                uint32_t f1 = kNone, l1 = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < 3; q++) {
-                    if (bits[q]) {
-                        if (f1 == kNone) f1 = (w_lo + q) * 32u + (uint32_t)__builtin_ctz(bits[q]);
-                        l1 = (w_lo + q) * 32u + 31u - (uint32_t)__builtin_clz(bits[q]);
-                    }
-                }
-                if (f1 == kNone) {
-                    end = p;  // flagged by a neighbour's window only: no pattern of the pass can match inside these bytes
-                    cut = true;
-                } else {
-                    stop_at = 16u * (l1 + a.chunk_base) + 17u;
-                    if (a.reach != kUnboundedReach) {
-                        const uint32_t fpos = 16u * (f1 + a.chunk_base);
-                        const uint32_t p0 = fpos > a.reach + 1u ? fpos - a.reach - 1u : 0u;
-                        if (p0 > p) { p = p0; skipped = true; }
-                    }
-                }
-            }
-        }
-        if (defer) {
-            // the bytes this walk will take at least: to the field's end, or to the byte after the last flagged chunk
-            const uint32_t span = live ? min(end, stop_at) - min(p, end) : 0u;
-            const bool late = live && span > kListLongSpan && a.n_quiet != 0u && many;
-            const unsigned long long lm = __ballot(late);
-            if (lm != 0) {
-                if (late) {
-                    const uint32_t at = q_n + (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull));
-                    queue[at] = r;
-                    queue[kListQueue + at] = li;  // (its list position: the owner's need masks are indexed by it)
-                }
-                q_n += (uint32_t)__builtin_popcountll(lm);
-                if (late) live = false;
-            }
-        }
-        if (!live) { p = 0; end = 0; }
-        if (live && skipped) state = empt[gdata[p - 1u]];
-        if (live && !skipped && a.emit_off[1] != a.emit_off[0]) h = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, 0u, h);
-        u32x4 w = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + p);
-        while (__ballot(p < end) != 0) {
-            const uint32_t pn = p + 16u;
-            const u32x4 wn = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end ? pn : 0u));
-            const uint32_t cnt = p < end ? min(16u, end - p) : 0u;
-#pragma unroll
-            for (uint32_t k0 = 0; k0 < 16; k0 += 4) {
-                const uint32_t wd = k0 == 0 ? w.x : k0 == 4 ? w.y : k0 == 8 ? w.z : w.w;
-                uint32_t c[4], t[4], sv[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) c[k] = cls[(wd >> (k * 8)) & 0xFFu];
-                // (the four class lookups are unconditional: left alone the compiler sinks each under its "k0 + k < cnt" — sixteen
-                // exec-mask branches per window, which doubled the walk's time)
-                asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) c[k] = k0 + k < cnt ? c[k] : ncls + 1u;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    // per step: v_mad_u32_u24 (a 32-bit multiply is quarter rate) -> v_min -> ds_read_u16 -> v_and, all in BYTE offsets
-                    t[k] = *reinterpret_cast<lds_u16_ptr>((uintptr_t)min(__umul24(k == 0 ? state : sv[k - 1], 2u * stride) + 2u * c[k], 2u * hot_elems));  // (the hot rows start at LDS address 0)
-                    sv[k] = t[k] & 0x7FFFu;
-                }
-                const uint32_t any = t[0] | t[1] | t[2] | t[3], top = max(max(t[0], t[1]), max(t[2], t[3]));
-                if (any & 0x8000u) {
-                    if (top == 0xFFFFu) {  // a cold cell: the group step by step, cold cells from the L2-resident table
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) {
-                            const uint32_t tt = cell(state * stride + c[k]);
-                            state = tt & 0x7FFFu;
-                            if (tt & 0x8000u) record_emit(state, h);
-                        }
-                    } else {
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++)
-                            if (t[k] & 0x8000u) record_emit(sv[k], h);
-                        state = sv[3];
-                    }
-                } else {
-                    state = sv[3];
-                }
-            }
-            if (p < end) p = pn;
-            w = wn;
-            if (p >= stop_at && p < end && state < a.n_quiet) {  // past the last flagged chunk with no older thread alive
-                end = p;
-                cut = true;
-            }
-        }
-        if (live) {
-            if (!cut && cell(state * stride + ncls + 2u) != 0u) h = emit_list(a.end_off, a.end_list, a.pool, a.pool_count, a.status, a.pool_cap, state, h);  // (a cut walk did not reach the field's end)
-            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-            if (a.colmask_local != nullptr) {
-                uint32_t need = 0;
-                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
-                if (a.need_out != nullptr) a.need_out[li] = need;
-                need &= ~a.shared_bits;
-                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
-            }
-        }
-    };
-    // the wave's items, and between them — whenever 64 deferred walks have gathered, and once more at the end — a batch from the queue
-    for (;;) {
-        const bool from_queue = q_n >= 64u || (it >= it_end && q_n != 0u);  // (wave-uniform)
-        if (!from_queue && it >= it_end) break;
-        bool have;
-        uint32_t r, li;
-        if (from_queue) {
-            const uint32_t take = min(q_n, 64u), rest = q_n - take;
-            have = lane < take;
-            r = have ? queue[lane] : 0u;
-            li = have ? queue[kListQueue + lane] : 0u;
-            // (close the gap: the entries behind the ones taken move to the front)
-            const uint32_t mv_r = lane < rest ? queue[take + lane] : 0u, mv_l = lane < rest ? queue[kListQueue + take + lane] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < rest) { queue[lane] = mv_r; queue[kListQueue + lane] = mv_l; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            q_n = rest;
-        } else {
-            li = (it - first) * THREADS + threadIdx.x;
-            have = li < n_l;
-            r = have ? (a.req_list != nullptr ? a.req_list[li] : li) : 0u;
-            it++;
-        }
-        batch(have, r, li, !from_queue);
-    }
-}
-
 // One step of a walk whose state may lie outside the LDS-resident rows: a DELTA record (kernels.h: ListScanArgs::delta — base row and
 // two exception cells, 8 bytes in LDS) or, failing that, the L2-resident flat table. `c` = the byte's class (n_classes + 1: past the
 // field's end, the state stays).
@@ -779,7 +587,7 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
             uint32_t c[4], t[4], sv[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = cls[(wd >> (k * 8)) & 0xFFu];
-            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));  // (unconditional lookups: see lscan_local)
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));  // (the four class lookups stay unconditional: left alone the compiler sinks each under its "k < cnt" — sixteen exec-mask branches per window, which doubled the walk's time)
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = k < cnt ? c[k] : ncls + 1u;
 #pragma unroll
@@ -830,12 +638,10 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
     }
 }
 
-// LOCAL: the launch of the passes behind a bigram prefilter (lscan_local); else none is walked locally (one kernel with both loops
-// needs 85 vector registers: the 512-thread shape of the gap passes would lose a third of its waves).
-// (second bound: waves per SIMD — three 512-thread workgroups per CU need 6, i.e. at most 80 vector registers)
-template <uint32_t THREADS, bool LOCAL>
+// (waves per SIMD: three 512-thread workgroups per CU need 6, i.e. at most 80 vector registers)
+template <uint32_t THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(GatedTable b, const uint32_t *plan, uint32_t hot_bytes) {
-    extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows + 16 bytes for the sentinel cell, then the 256-byte class map and the 512 bytes of empty-state rows
+    extern __shared__ uint32_t lscan_lds[];  // [hot_bytes / 4] hot rows + 16 bytes for the sentinel cell, then the 256-byte class map
     __builtin_amdgcn_s_setprio(3);  // on the critical path, beside the attribute kernel's background waves
     if ((uint32_t)(uintptr_t)(PWAF_LDS unsigned char *)lscan_lds != 0u) __builtin_trap();  // (no static LDS in this kernel: the walks address the hot rows by plain integer offsets)
     const uint32_t total = plan[b.count];
@@ -871,7 +677,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                 for (uint32_t q = 0; q < 4; q++)
                     if (k + q * THREADS < units) dst[k + q * THREADS] = v[q];
             }
-            if (threadIdx.x < 192) lscan_lds[(hot_bytes + 16u) / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];  // class map + empty-state rows
+            if (threadIdx.x < 64) lscan_lds[(hot_bytes + 16u) / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(a.classmap)[threadIdx.x];  // class map
             // the delta records, behind the rows and the sentinel cell (the engine sized rows + 32 + records to fit hot_bytes)
             for (uint32_t k = threadIdx.x; k < a.n_delta; k += THREADS) delta_lds[k] = a.delta[k];
         }
@@ -881,12 +687,6 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
         if (threadIdx.x == 0) reinterpret_cast<uint16_t *>(lscan_lds)[hot_elems] = 0xFFFFu;
         __syncthreads();
         const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
-        if (LOCAL) {
-            uint32_t *queue = lscan_lds + (hot_bytes + 16u + 768u) / 4 + wave_index() * (2u * kListQueue);  // the wave's deferred walks
-            lscan_local<THREADS>(a, hot, cls, reinterpret_cast<const uint16_t *>(cls + 256), queue, it, it_end, first, n_l, hot_elems);
-            it = it_end;
-            continue;
-        }
         // (the gap passes' lists stay with the lockstep loop: measured 0.25 -> 0.40 ms with this one on the hostile stream — their walks
         // are short and mostly LDS-resident, and the asynchronous iteration costs more per group)
 #ifdef PWAF_PROFILING
@@ -1222,10 +1022,7 @@ int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream) {
     return (int)hipGetLastError();
 }
 
-static const void *lscan_fn(bool wide, bool local) {
-    return wide ? (local ? reinterpret_cast<const void *>(lscan_kernel<1024, true>) : reinterpret_cast<const void *>(lscan_kernel<1024, false>))
-                : (local ? reinterpret_cast<const void *>(lscan_kernel<512, true>) : reinterpret_cast<const void *>(lscan_kernel<512, false>));
-}
+static const void *lscan_fn(bool wide) { return wide ? reinterpret_cast<const void *>(lscan_kernel<1024>) : reinterpret_cast<const void *>(lscan_kernel<512>); }
 
 int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanArgs *dev, uint32_t *plan, const ListShape &shape, void *stream) {
     if (count == 0 || host[0].n == 0) return 0;
@@ -1243,18 +1040,16 @@ int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanAr
     const uint64_t max_items = (uint64_t)count * ((host[0].n + shape.threads * kListWalks - 1) / (shape.threads * kListWalks));
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, host[0].n_cus) * shape.wg_per_cu);
     const uint32_t *cplan = plan;
-    bool local = false;  // the launch holds a pass behind a prefilter (the filtered phase: such passes, and plain passes over short fields)
-    for (uint32_t k = 0; k < count; k++) local = local || host[k].chunk_bits != nullptr;
-    uint32_t hot_bytes = list_hot_bytes(shape, local);  // (the local kernel's waves each keep a queue of deferred walks behind the rows)
+    uint32_t hot_bytes = list_hot_bytes(shape);
     void *args[] = {&b, &cplan, &hot_bytes};
-    const void *fn = lscan_fn(shape.threads == 1024, local);
-    e = hipLaunchKernel(fn, dim3(blocks), dim3(shape.threads), args, shape.hot_bytes + 16 + 768, (hipStream_t)stream);
+    const void *fn = lscan_fn(shape.threads == 1024);
+    e = hipLaunchKernel(fn, dim3(blocks), dim3(shape.threads), args, shape.hot_bytes + 16 + 256, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
 // LDS budget of the list scan: 160 KiB per CU shared by wg_per_cu workgroups. Default 3 x (48 KiB, 512 threads) = 24 waves per CU;
 // PWAF_LIST_SHAPE (profiling builds) tries the others.
-uint32_t list_hot_bytes(const ListShape &shape, bool local) { return shape.hot_bytes - (local ? (shape.threads / 64u) * (2u * kListQueue * 4u) : 0u); }
+uint32_t list_hot_bytes(const ListShape &shape) { return shape.hot_bytes; }
 
 ListShape list_shape(uint32_t variant) {
     switch (variant) {
@@ -2819,7 +2614,7 @@ int configure_kernels(int device) {
                          reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64>),
                          reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
                          reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
-                         lscan_fn(false, false), lscan_fn(false, true), lscan_fn(true, false), lscan_fn(true, true)};
+                         lscan_fn(false), lscan_fn(true)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerGroup);
         if (e != hipSuccess) return (int)e;

@@ -120,7 +120,6 @@ struct FilterHead {
     uint8_t exact;   // 1: field == literal, 0: field starts with literal
     uint16_t local;  // local atom id in the pass
 };
-static constexpr uint32_t kUnboundedReach = 0xFFFFFFFFu;
 
 // ---- the CONFIRM tier of a filtered pass (round 4; filter.cpp builds it, confirm.h evaluates it on the host and on the device) ----
 // The bigram filter flags a 16-byte chunk when some position of it completes a WINDOW (<= 4 sampled bigrams) of some factor; a window
@@ -161,11 +160,6 @@ struct GroupFilter {
     uint32_t mul = kFilterMul;    // multiplier of the bigram hash chosen for this pass
     uint32_t stride = 1;          // bigrams are sampled at every stride-th byte of the arena stream (1 or 2); factors are entered once per alignment
     std::vector<FilterHead> heads;
-    // How far before the END of its factor a match of any pattern of the pass can begin, in bytes (kUnboundedReach: some pattern puts
-    // an unbounded repeat before its factor). A flagged chunk c therefore only speaks for matches that begin at or after byte
-    // 16 c + 2 - reach of the arena: the list scan starts a candidate's walk there instead of at the field's first byte
-    // (DESIGN.md §4.4), and ends it once the DFA holds no thread older than the byte after the last flagged chunk.
-    uint32_t reach = kUnboundedReach;
     double est_candidate_rate = 0;  // expected fraction of requests flagged by chance (model or sample)
     std::string note;               // why the pass is not filtered, for stats / warnings
     ConfirmTable confirm;           // built with the windows it mirrors (every rebuild of the filter rebuilds it)
@@ -190,11 +184,6 @@ struct DfaGroup {
     std::vector<uint16_t> emit_list;     // LOCAL atom ids (column = atom_base + local)
     std::vector<uint32_t> end_off;       // n_states + 1
     std::vector<uint16_t> end_list;      // LOCAL atom ids true if the field ends in this state
-    // Walks that begin or end inside a field (the list scan of a bounded prefilter pass): empty_state[kind] = the state of a search
-    // with no thread alive after a byte of that kind (1 other, 2 word, 3 newline — only the kinds the patterns' assertions tell
-    // apart exist; 0xFFFF: none), class_kind = a byte class's kind, quiet[s] = 1 when s holds no thread older than one byte.
-    uint16_t empty_state[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-    std::vector<uint8_t> class_kind, quiet;
     uint32_t atom_base = 0;              // first device column of this group
     uint32_t n_local = 0;                // columns owned by this group (= atoms.size())
     std::vector<uint32_t> atoms;         // indices into Program::atoms, local id order

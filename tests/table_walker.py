@@ -80,11 +80,6 @@ class Tables:
                 cur["f_table"] = np.frombuffer(pl, dtype="<u4")
             elif tag == "GFLT":
                 cur["filter_cols"] = [int(x) for x in np.frombuffer(pl, dtype="<u4")]
-            elif tag == "GLOC":
-                cur["f_reach"] = struct.unpack_from("<I", pl, 0)[0]
-                cur["empty_state"] = struct.unpack_from("<4H", pl, 4)
-                cur["class_kind"] = np.frombuffer(pl, dtype=np.uint8, count=cur["n_classes"], offset=12)
-                cur["quiet"] = np.frombuffer(pl, dtype=np.uint8, count=cur["n_states"], offset=12 + cur["n_classes"])
             elif tag == "GCNF":
                 cur["confirm"], cur["confirm_walk"], cur["confirm_entries"], cur["confirm_literals"] = struct.unpack("<4I", pl)
             elif tag == "RHDR":
@@ -161,7 +156,7 @@ class Tables:
             cols |= mine
             walked |= mine
             return
-        # heads are compared by the filter kernel for every request (a localized walk may not pass the field's first bytes)
+        # heads are compared by the filter kernel for every request
         for lit, exact, local in g["f_heads"]:
             if data[:len(lit)] == lit and (not exact or len(data) == len(lit)):
                 cols.add(g["atom_base"] + local)
@@ -182,7 +177,7 @@ class Tables:
         elif flags:
             self.n_candidates += 1
             mine = set()
-            self.scan_field(g, data, mine, flags if self.use_local_walks else None)
+            self.scan_field(g, data, mine)
             cols |= mine
             walked |= mine
 
@@ -193,39 +188,25 @@ class Tables:
     n_confirm_hits = 0
     n_confirm_walks = 0
     use_gates = True
-    use_local_walks = True
     n_gated_walks = 0
     filter_phase = 0  # offset of the first sampled byte of a field (the device: parity of the field's arena offset, stride-2 passes)
     arena_offset = 0  # where the field starts in its arena, modulo 16 (chunk boundaries) — tests vary it
     n_candidates = 0
-    n_steps = 0       # DFA steps taken by filtered passes (what localized walks save)
-    UNBOUNDED = 0xFFFFFFFF
+    n_steps = 0       # DFA steps taken by filtered passes
 
-    def scan_field(self, g: dict, data: bytes, cols: set, flags=None):
-        """Walks one field through group g's DFA, adding the device column ids that hold. With `flags` (the flagged arena chunks of
-        a prefilter candidate) the walk is LOCALIZED as lscan_kernel's: it starts `reach` bytes before the first flagged chunk, in
-        the empty state of the byte before, and ends once no thread older than the byte after the last flagged chunk is alive."""
-        st, start, stop_at = 0, 0, None  # states are in BFS order from the start state
-        if flags and "quiet" in g:
-            o = self.arena_offset
-            stop_at = 16 * max(flags) + 17 - o  # field-relative position from which a quiet state ends the walk
-            if g["f_reach"] != self.UNBOUNDED:
-                start = max(0, 16 * min(flags) - g["f_reach"] - 1 - o)
-                if start > 0:
-                    st = int(g["empty_state"][int(g["class_kind"][g["classmap"][data[start - 1]]])])
-                    assert st != 0xFFFF
+    def scan_field(self, g: dict, data: bytes, cols: set):
+        """Walks one field through group g's DFA (the pass's, or its R tier's), adding the device column ids that hold."""
+        st = 0  # states are in BFS order from the start state
 
         def emit(s):
             for a in g["emit_list"][g["emit_off"][s]:g["emit_off"][s + 1]]:
                 cols.add(g["atom_base"] + int(a))
         emit(st)
         cm, tr = g["classmap"], g["trans"]
-        for j in range(start, len(data)):
+        for j in range(len(data)):
             st = int(tr[st, cm[data[j]]])
             emit(st)
             self.n_steps += 1
-            if stop_at is not None and j + 1 >= stop_at and g["quiet"][st] and j + 1 < len(data):
-                return  # (no end-of-field emits: the field has not ended)
         for a in g["end_list"][g["end_off"][st]:g["end_off"][st + 1]]:
             cols.add(g["atom_base"] + int(a))
 

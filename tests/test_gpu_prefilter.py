@@ -251,42 +251,48 @@ def test_config5_per_gpu_share_properties_at_6_25M():
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_localized_walks_on_the_device(seed):
-    """PWAF_OPT_LOCAL_WALKS: prefilter candidates walked from shortly before their first flagged chunk until the DFA is quiet past
-    the last one, long walks deferred to the waves' queues — the verdicts are the oracle's, tuned or not, on long fields with rule
-    tokens (whole, cut short, case-swapped) at their start, middle and end."""
+def test_confirm_tier_on_long_fields_on_the_device(seed):
+    """confirm_kernel + the R-tier walk on long fields with rule tokens (whole, cut short, case-swapped) at their start, middle and
+    end — several flagged chunks per candidate, chunk-bitmap words straddled — against the oracle, tuned or not, at both strides;
+    and the engine without a confirm tier (PWAF_OPT_NO_CONFIRM: every candidate through the full DFA) returns the same."""
     from test_prefilter import _long_requests
 
     rng = random.Random(9300 + seed)
     rules = H.lit_rules(rng, rng.randint(3, 50))
-    eng = RuleEngine(rules, {}, flags=_abi.OPT_LOCAL_WALKS | (_abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0))
+    flags = _abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0
+    eng = RuleEngine(rules, {}, flags=flags)
     n = rng.choice([64, 700, 3000, 9000])
     batch = RequestBatch.from_requests(_long_requests(rng, n))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}")
     eng.tune(RequestBatch.from_requests(_long_requests(rng, 300)))
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"seed {seed}, tuned")
+    plain = RuleEngine(rules, {}, flags=flags | _abi.OPT_NO_CONFIRM)
+    H.assert_verdicts_equal(plain.evaluate_batch(batch), want, batch, f"seed {seed}, no confirm tier")
+    assert plain.stats()["n_confirm_literals"] == 0
     eng.close()
+    plain.close()
 
 
-def test_localized_walks_on_the_synthetic_streams():
-    """The 1k-rule set at 200k requests, benign and hostile stream: the engine with localized walks returns what the default engine
-    returns (which the other tests compare with the oracle)."""
+def test_confirm_tier_on_the_synthetic_streams_against_the_full_dfa_walk():
+    """The 1k-rule set at 200k requests, benign and hostile stream: the engine with the confirm tier returns what the engine that walks
+    every candidate through the full DFA returns (both are compared with the oracle at smaller sizes by the other tests)."""
     from synth.pysynth import Workload
 
     wl = Workload(3)
-    plain = RuleEngine(wl.rules, wl.lists, wl.geoip)
-    local = RuleEngine(wl.rules, wl.lists, wl.geoip, flags=_abi.OPT_LOCAL_WALKS)
+    conf = RuleEngine(wl.rules, wl.lists, wl.geoip)
+    plain = RuleEngine(wl.rules, wl.lists, wl.geoip, flags=_abi.OPT_NO_CONFIRM)
+    assert conf.stats()["n_confirm_literals"] >= 400 and plain.stats()["n_confirm_literals"] == 0
     sample = wl.batch(5_000_000, 20000)
+    conf.tune(sample)
     plain.tune(sample)
-    local.tune(sample)
     for adversarial in (False, True):
         batch = wl.batch(0, 200_000, adversarial=adversarial)
-        a, b = plain.evaluate_batch(batch), local.evaluate_batch(batch)
+        a, b = plain.evaluate_batch(batch), conf.evaluate_batch(batch)
         assert np.array_equal(a["action"], b["action"]) and np.array_equal(a["rule_idx"], b["rule_idx"]), adversarial
         assert len(set(a["action"].tolist())) >= 2
     plain.close()
-    local.close()
+    conf.close()
 
 
 def test_every_request_a_candidate_at_one_million():

@@ -212,58 +212,27 @@ def _long_requests(rng, n):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_localized_walks_keep_every_verdict(seed):
-    """A candidate of a bounded prefilter pass is walked from `reach` bytes before its first flagged chunk (in the empty state of the
-    byte before) until no thread older than the byte after its last flagged chunk is alive (table_walker.scan_field = lscan_kernel's
-    rule, at its most aggressive). Verdicts equal the oracle's at every alignment of the field in its arena, tuned or not, and the
-    walks are shorter."""
+def test_long_fields_at_every_arena_alignment(seed):
+    """Long fields with rule tokens at their start, middle and end: the candidates' flagged chunks are looked at by the confirm tier
+    (and, where a regex factor is confirmed, walked) at every alignment of the field in its arena, tuned or not; verdicts equal the
+    oracle's, and the engine without a confirm tier (PWAF_OPT_NO_CONFIRM) agrees."""
     rng = random.Random(9100 + seed)
     rules = H.lit_rules(rng, rng.randint(3, 30))
-    prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0)
+    flags = _abi.OPT_FILTER_STRIDE2 if seed % 3 == 2 else 0
+    prog = CompiledProgram(rules, {}, flags=flags)
     if seed % 2:
         prog.tune(RequestBatch.from_requests(_long_requests(rng, 300)))
     t = table_walker.Tables(prog)
+    plain = table_walker.Tables(CompiledProgram(rules, {}, flags=flags | _abi.OPT_NO_CONFIRM))
     batch = RequestBatch.from_requests(_long_requests(rng, 100))
     want = pyoracle.Oracle(rules, {}).evaluate(batch)
-    steps = {}
-    for local in (False, True):
-        t.use_local_walks, t.n_steps = local, 0
-        for off in ([0] if not local else rng.sample(range(16), 4)):
-            t.arena_offset = off
-            for i in range(batch.n):
-                assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, local, off, i, [batch.field_bytes(f, i) for f in range(5)])
-        steps[local] = t.n_steps / (4 if local else 1)
-    bounded = [g for g in t.groups if g.get("f_reach", t.UNBOUNDED) != t.UNBOUNDED]
-    if bounded and steps[False] > 2000:
-        assert steps[True] < steps[False], (steps, len(bounded))
-    _LOCAL_STEPS.append((seed, len(bounded), int(steps[False]), int(steps[True])))
-
-
-_LOCAL_STEPS = []
-
-
-def test_reach_and_quiet_states_of_a_filtered_pass():
-    """What the localized walks rest on, as the compiler reports it (dump section GLOC): the reach of a pass is the longest distance
-    from a match's first byte to the end of its factor — the literal's length for a plain literal, unbounded as soon as one pattern
-    puts an unbounded repeat before its factor — and the DFA has an empty state for every byte kind plus the quiet successors."""
-    def one(rules):
-        t = table_walker.Tables(CompiledProgram(rules, {}))
-        return [g for g in t.groups if "f_table" in g][0]
-
-    g = one([("a", 'http_request.path.contains("/wp-admin/x")', [H.B]), ("b", 'http_request.path.ends_with(".php5")', [H.B])])
-    assert 5 <= g["f_reach"] <= len("/wp-admin/x")  # (the end of the chosen factor — a prefix of the literal may be the cheaper window)
-    # a bounded repeat before the factor is counted, an unbounded one is not bounded
-    g = one([("a", 'http_request.path.matches("ab[0-9]{1,3}/x9k2q")', [H.B])])
-    assert 7 <= g["f_reach"] <= 2 + 3 + len("/x9k2q")
-    g = one([("a", 'http_request.path.matches("^/api/v[0-9]+/zz9k2")', [H.B])])
-    assert g["f_reach"] in (t_unb := table_walker.Tables.UNBOUNDED, len("/api/v") + 1)  # (either the anchored prefix, bounded, or the rare word behind the repeat)
-    # empty states: one per byte kind in use, all of them quiet, and the start state is none of them
-    g = one([("a", 'http_request.path.matches("\\\\bselect\\\\b.{0,8}from")', [H.B]), ("b", 'http_request.path.contains("union")', [H.B])])
-    empties = [s for s in g["empty_state"] if s != 0xFFFF]
-    assert len(empties) >= 2 and 0 not in empties and all(g["quiet"][s] for s in empties)
-    assert 0 < int(np.sum(g["quiet"])) < g["n_states"]
-    for s in empties:  # what one byte makes of an empty state is quiet too
-        assert all(g["quiet"][int(x)] for x in g["trans"][s])
+    for off in rng.sample(range(16), 4):
+        t.arena_offset = plain.arena_offset = off
+        for i in range(batch.n):
+            assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (seed, off, i, [batch.field_bytes(f, i) for f in range(5)])
+            if off == 0:
+                assert plain.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"]))
+    assert t.n_candidates > 0
 
 
 def _near_miss_requests(rng, rules_tokens, n):
