@@ -28,7 +28,9 @@ struct ConfirmView {  // plain pointers: host tables or device tables
 
 PWAF_HD uint32_t confirm_load32(const uint8_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(p);  // (gfx950 global loads need no alignment)
+    // (every table and arena of this tier lives in global memory: a GLOBAL load, at any byte address — gfx950 needs no alignment —
+    // instead of the FLAT load a generic pointer gets)
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t __attribute__((aligned(1))) *>((uintptr_t)p);
 #else
     uint32_t v;
     memcpy(&v, p, 4);
@@ -37,23 +39,36 @@ PWAF_HD uint32_t confirm_load32(const uint8_t *p) {
 }
 
 // One entry against the text: does the factor occur with its window's last bigram at arena position i, inside the field [fs, fe)?
-PWAF_HD bool confirm_entry(const ConfirmView &cv, const ConfirmEntry &e, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t i) {
+// 0 = no, 1 = yes and it decides a literal atom (e.atom), 2 = yes and it is a factor of a non-literal atom (walk).
+// OUT OF LINE on the device: the caller's loop over a chunk's positions stays a few dozen instructions (the first version inlined this
+// — and the hit record's overflow path — into a 16-fold unrolled loop: 8 400 instructions, ~50 KiB of code that no instruction cache
+// holds next to seven other workgroups' — measured 0.5 ms per WORK ITEM, 11.8 ms for the hostile stream's candidates).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+    uint32_t
+    confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
+                  const uint32_t i) {
+    const ConfirmEntry e = entries[index];
     const uint32_t len = e.len, d = e.d;
-    if (i < fs + d) return false;
+    if (i < fs + d) return 0;
     const uint32_t q = i - d;
-    if (q + len > fe) return false;
-    if ((e.flags & kConfirmAtStart) && q != fs) return false;
-    if ((e.flags & kConfirmAtEnd) && q + len != fe) return false;
+    if (q + len > fe) return 0;
+    if ((e.flags & kConfirmAtStart) && q != fs) return 0;
+    if ((e.flags & kConfirmAtEnd) && q + len != fe) return 0;
     const uint32_t l4 = (len + 3u) & ~3u;
-    const uint8_t *val = cv.bytes + e.bytes_off, *msk = val + l4;
+    const uint8_t *val = bytes + e.bytes_off, *msk = val + l4;
     for (uint32_t w = 0; w < l4; w += 4)  // (reads up to 3 bytes past the factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero)
-        if ((confirm_load32(data + q + w) ^ confirm_load32(val + w)) & confirm_load32(msk + w)) return false;
+        if ((confirm_load32(data + q + w) ^ confirm_load32(val + w)) & confirm_load32(msk + w)) return 0;
     const uint8_t *cls = msk + l4;
     for (uint32_t k = 0; k < e.n_cls; k++) {
-        const uint32_t t = data[q + cls[2 * k]];
-        if (!((cv.classes[(uint32_t)cls[2 * k + 1] * 8u + (t >> 5)] >> (t & 31u)) & 1u)) return false;
+        const uint32_t pc = confirm_load32(cls + 2u * k);  // {position, class id} (the pool is padded: the load may run 2 bytes over)
+        const uint32_t t = confirm_load32(data + q + (pc & 0xFFu)) & 0xFFu;
+        if (!((classes[((pc >> 8) & 0xFFu) * 8u + (t >> 5)] >> (t & 31u)) & 1u)) return 0;
     }
-    return true;
+    return e.atom == kConfirmWalk ? 2u : 1u;
 }
 
 // The flagged 16-byte arena chunk c against the field [fs, fe) of one request: hit(atom) for every literal atom confirmed at a
@@ -63,25 +78,28 @@ template <class HeadAt, class Hit>
 PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, HeadAt &&head_at, Hit &&hit) {
     if (fe < fs + 2u) return false;
     const uint32_t base = c * 16u;
-    // the chunk's bytes and the byte after it (second half of its last bigram)
-    uint32_t w[5];
-#pragma unroll
-    for (uint32_t k = 0; k < 5; k++) w[k] = confirm_load32(data + base + 4u * k);
+    // the chunk's bytes and the byte after it (second half of its last bigram) travel through a 64-bit window that moves one byte per
+    // position: no register is indexed by the position, and the loop is NOT unrolled (see confirm_entry)
+    uint32_t lo = confirm_load32(data + base), hi = confirm_load32(data + base + 4u);
+    uint32_t n0 = confirm_load32(data + base + 8u), n1 = confirm_load32(data + base + 12u), n2 = confirm_load32(data + base + 16u);
     bool walk = false;
-#pragma unroll
+#pragma unroll 1
     for (uint32_t k = 0; k < 16; k++) {
         const uint32_t i = base + k;
+        const uint32_t b0 = lo & 0xFFu, b1 = (lo >> 8) & 0xFFu;
+        lo = (lo >> 8) | (hi << 24);
+        hi >>= 8;
+        if ((k & 3u) == 3u) { hi = n0; n0 = n1; n1 = n2; }
         if (i < fs || i + 1u >= fe) continue;        // both bytes of the bigram inside the field
         if (cv.stride == 2u && (i & 1u)) continue;  // (bigrams are sampled at the even bytes of the arena)
-        const uint32_t b0 = (w[k >> 2] >> (8u * (k & 3u))) & 0xFFu, b1 = (w[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xFFu;
         const uint32_t hd = head_at(filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul));
         if (hd == 0u) continue;
         const uint32_t first = hd & 0xFFFFFu, cnt = hd >> 20;
+#pragma unroll 1
         for (uint32_t j = 0; j < cnt; j++) {
-            const ConfirmEntry e = cv.entries[first + j];
-            if (!confirm_entry(cv, e, data, fs, fe, i)) continue;
-            if (e.atom == kConfirmWalk) walk = true;
-            else hit((uint32_t)e.atom);
+            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, i);
+            if (res == 2u) walk = true;
+            else if (res == 1u) hit((uint32_t)cv.entries[first + j].atom);
         }
     }
     return walk;
