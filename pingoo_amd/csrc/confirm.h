@@ -24,6 +24,7 @@ struct ConfirmView {  // plain pointers: host tables or device tables
     const uint8_t *bytes;
     const uint32_t *classes;
     uint32_t mul, stride;
+    uint32_t init;  // the filter's state of a stream with no history (GroupFilter::init)
 };
 
 PWAF_HD uint32_t confirm_load32(const uint8_t *p) {
@@ -73,31 +74,53 @@ inline
 
 // The flagged 16-byte arena chunk c against the field [fs, fe) of one request: hit(atom) for every literal atom confirmed at a
 // position of the chunk; returns true when a factor of a non-literal atom was confirmed (the request must be walked).
-// head_at(bin) reads the table's head word (the device keeps the heads in LDS).
-template <class HeadAt, class Hit>
-PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, HeadAt &&head_at, Hit &&hit) {
+// tab_at(bin) / head_at(bin) read the pass's filter table and the confirm table's head word (the device keeps both in LDS).
+//
+// Two phases, because the 64 requests of a wave run this in lockstep:
+//   A  the filter's own shift-or automaton over the chunk (warmed up with the sampled bigrams of the 8 bytes before it: the state it
+//      had on the device) names the positions where a window really COMPLETED — one or two of the sixteen, as a bit mask. Registers
+//      and LDS only.
+//   B  each lane takes ITS next such position: head word -> the entries whose window can end with that bigram -> the full comparison.
+// (The first version looked up the head word of every position and compared on the spot: a fifth of all bins list an entry, so with
+// 64 lanes every one of the 16 iterations found SOME lane with work and paid the comparison's memory round trips — 1 400 load
+// instructions and 0.6 ms per wave, counters in profiles/r4_confirm_v1_counters.txt.)
+template <class TabAt, class HeadAt, class Hit>
+PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at, HeadAt &&head_at, Hit &&hit) {
     if (fe < fs + 2u) return false;
     const uint32_t base = c * 16u;
-    // the chunk's bytes and the byte after it (second half of its last bigram) travel through a 64-bit window that moves one byte per
-    // position: no register is indexed by the position, and the loop is NOT unrolled (see confirm_entry)
-    uint32_t lo = confirm_load32(data + base), hi = confirm_load32(data + base + 4u);
-    uint32_t n0 = confirm_load32(data + base + 8u), n1 = confirm_load32(data + base + 12u), n2 = confirm_load32(data + base + 16u);
-    bool walk = false;
+    const bool pre = base >= 8u;  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
+    const uint32_t w0 = confirm_load32(data + base), w1 = confirm_load32(data + base + 4u), w2 = confirm_load32(data + base + 8u), w3 = confirm_load32(data + base + 12u),
+                   w4 = confirm_load32(data + base + 16u);
+    // ---- A: bytes [base - 8, base + 17) through a 64-bit window that moves one byte per step (no register is indexed by the position)
+    uint32_t lo = pre ? confirm_load32(data + base - 8u) : 0u, hi = pre ? confirm_load32(data + base - 4u) : 0u;
+    uint32_t n0 = w0, n1 = w1, n2 = w2, n3 = w3, n4 = w4;
+    uint32_t st = cv.init, mask = 0;
 #pragma unroll 1
-    for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t i = base + k;
+    for (uint32_t t = 0; t < 24; t++) {
         const uint32_t b0 = lo & 0xFFu, b1 = (lo >> 8) & 0xFFu;
         lo = (lo >> 8) | (hi << 24);
         hi >>= 8;
-        if ((k & 3u) == 3u) { hi = n0; n0 = n1; n1 = n2; }
-        if (i < fs || i + 1u >= fe) continue;        // both bytes of the bigram inside the field
+        if ((t & 3u) == 3u) { hi = n0; n0 = n1; n1 = n2; n2 = n3; n3 = n4; }
+        if (t < 8u && !pre) continue;               // (the arena's first chunk: the stream starts in the init state)
+        const uint32_t i = base + t - 8u;
         if (cv.stride == 2u && (i & 1u)) continue;  // (bigrams are sampled at the even bytes of the arena)
-        const uint32_t hd = head_at(filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul));
+        st = (st << 8) | tab_at(filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul));
+        if (t >= 8u && ((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) mask |= 1u << (t - 8u);  // a window completed here, both bytes inside the field
+    }
+    // ---- B: the completed windows, one per iteration
+    bool walk = false;
+    while (mask) {
+        const uint32_t k = (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        const uint32_t q = k >> 2;
+        const uint32_t a = q == 0u ? w0 : q == 1u ? w1 : q == 2u ? w2 : w3, b = q == 0u ? w1 : q == 1u ? w2 : q == 2u ? w3 : w4;
+        const uint32_t two = (uint32_t)((((uint64_t)b << 32) | a) >> (8u * (k & 3u)));
+        const uint32_t hd = head_at(filter_bin((uint8_t)(two & 0xFFu), (uint8_t)((two >> 8) & 0xFFu), cv.mul));
         if (hd == 0u) continue;
         const uint32_t first = hd & 0xFFFFFu, cnt = hd >> 20;
 #pragma unroll 1
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, i);
+            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, base + k);
             if (res == 2u) walk = true;
             else if (res == 1u) hit((uint32_t)cv.entries[first + j].atom);
         }

@@ -1148,6 +1148,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.chunk_base = f.slab0 * (kStreamSlab / 16);
             c.mul = f.mul;
             c.stride = f.stride;
+            c.init = f.init;
+            c.ftable = f.table;
             c.c_head = (const uint32_t *)d.c_head.p;
             c.c_entries = (const ConfirmEntry *)d.c_entries.p;
             c.c_bytes = (const uint8_t *)d.c_bytes.p;

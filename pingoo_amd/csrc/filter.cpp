@@ -648,10 +648,11 @@ bool confirm_field_host(const GroupFilter &f, const uint8_t *arena, uint32_t fs,
     if (chunks.empty()) return false;
     if (!f.confirm.enabled) return true;
     const ConfirmTable &t = f.confirm;
-    const ConfirmView cv{t.head.data(), t.entries.data(), t.bytes.data(), t.classes.data(), f.mul, f.stride};
+    const ConfirmView cv{t.head.data(), t.entries.data(), t.bytes.data(), t.classes.data(), f.mul, f.stride, f.init};
     bool walk = false;
     for (uint32_t c : chunks) {
-        const bool wk = confirm_chunk(cv, arena, fs, fe, c, [&](uint32_t bin) { return t.head[bin]; }, [&](uint32_t atom) { lits.push_back((uint16_t)atom); });
+        const bool wk = confirm_chunk(cv, arena, fs, fe, c, [&](uint32_t bin) { return f.table[bin]; }, [&](uint32_t bin) { return t.head[bin]; },
+                                      [&](uint32_t atom) { lits.push_back((uint16_t)atom); });
         walk = walk || wk;
     }
     return walk;

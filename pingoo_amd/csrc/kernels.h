@@ -129,7 +129,8 @@ struct ConfirmArgs {
     const uint32_t *n_list;
     const uint32_t *chunk_bits; // the pass's chunk bitmap of this batch: bit c - chunk_base = the arena's 16-byte chunk c was flagged
     uint32_t chunk_base;
-    uint32_t mul, stride;       // of the pass's bigram hash / sampling (GroupFilter)
+    uint32_t mul, stride, init; // of the pass's bigram hash / sampling / automaton (GroupFilter)
+    const uint32_t *ftable;     // the pass's filter table (kFilterEntries masks)
     const uint32_t *c_head;     // ConfirmTable on the device
     const ConfirmEntry *c_entries;
     const uint8_t *c_bytes;

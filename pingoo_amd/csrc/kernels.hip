@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
 // bin that lists an entry the full comparison (confirm.h) against the L2-resident byte pool. No DFA, no state: what a near miss
 // costs here is one comparison that fails, whatever the traffic looks like.
 __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
-    __shared__ uint32_t head[kFilterEntries];
+    __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __builtin_amdgcn_s_setprio(3);
     const uint32_t total = plan[b.count];
     const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
@@ -890,9 +890,20 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
         const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
         const ConfirmArgs a = load_descriptor(&b.c[ps]);
         __syncthreads();  // (every wave is done with the previous pass's heads)
-        for (uint32_t k = threadIdx.x; k < kFilterEntries; k += kConfirmThreads) head[k] = a.c_head[k];
+        {
+            // 16 bytes per lane and load, all of a thread's loads in flight before the first store (two 16 KiB tables)
+            const uint4 *sh = reinterpret_cast<const uint4 *>(a.c_head), *sf = reinterpret_cast<const uint4 *>(a.ftable);
+            uint4 vh[kFilterEntries / 4 / kConfirmThreads], vf[kFilterEntries / 4 / kConfirmThreads];
+#pragma unroll
+            for (uint32_t q = 0; q < kFilterEntries / 4 / kConfirmThreads; q++) { vh[q] = sh[q * kConfirmThreads + threadIdx.x]; vf[q] = sf[q * kConfirmThreads + threadIdx.x]; }
+#pragma unroll
+            for (uint32_t q = 0; q < kFilterEntries / 4 / kConfirmThreads; q++) {
+                reinterpret_cast<uint4 *>(head)[q * kConfirmThreads + threadIdx.x] = vh[q];
+                reinterpret_cast<uint4 *>(ftab)[q * kConfirmThreads + threadIdx.x] = vf[q];
+            }
+        }
         __syncthreads();
-        const ConfirmView cv{nullptr, a.c_entries, a.c_bytes, a.c_classes, a.mul, a.stride};
+        const ConfirmView cv{nullptr, a.c_entries, a.c_bytes, a.c_classes, a.mul, a.stride, a.init};
         const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
         const uint32_t n_l = min(*a.n_list, a.n);
         for (; it < it_end; it++) {
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
                     while (bits) {
                         const uint32_t c = w * 32u + (uint32_t)__builtin_ctz(bits) + a.chunk_base;
                         bits &= bits - 1u;
-                        const bool wk = confirm_chunk(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return head[bin]; },
+                        const bool wk = confirm_chunk(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return ftab[bin]; }, [&](const uint32_t bin) { return head[bin]; },
                                                       [&](const uint32_t atom) { h = record_atom(ctx, atom, h); });
                         walk = walk || wk;
                     }
@@ -1009,9 +1020,9 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     hipLaunchKernelGGL(confirm_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // persistent grid: 8 workgroups of 256 per CU (16 KiB of LDS each), never more than the items a full batch could produce
+    // persistent grid: 5 workgroups of 256 per CU (32 KiB of LDS each), never more than the items a full batch could produce
     const uint64_t max_items = (uint64_t)count * ((host[0].n + kConfirmThreads - 1) / kConfirmThreads);
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 8u);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 5u);
     const uint32_t *cplan = plan;
     hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
     return (int)hipGetLastError();

@@ -11,7 +11,7 @@ for d in sorted(glob.glob(f"{root}/pmc_*/p_counter_collection.csv")):
     for r in csv.DictReader(open(d)):
         if "pwaf" in r["Kernel_Name"]:
             data[(int(r["Dispatch_Id"]), r["Kernel_Name"].replace("void ", "")[:28])][r["Counter_Name"]] = float(r["Counter_Value"])
-rows = sorted(data.items())[-13:]
+rows = sorted(data.items())[-26:]
 cols = sorted({c for _, v in rows for c in v})
 print("dispatch kernel " + " ".join(c.replace("SQ_", "") for c in cols))
 for (did, k), v in rows:
