@@ -40,16 +40,17 @@ PWAF_HD uint32_t confirm_load32(const uint8_t *p) {
 }
 
 // One entry against the text: does the factor occur with its window's last bigram at arena position i, inside the field [fs, fe)?
-// 0 = no, 1 = yes and it decides a literal atom (e.atom), 2 = yes and it is a factor of a non-literal atom (walk).
+// 0 = no, 1 | atom << 8 = yes and it decides that literal atom, 2 = yes and it is a factor of a non-literal atom (walk).
 // OUT OF LINE on the device: the caller's loop over a chunk's positions stays a few dozen instructions (the first version inlined this
 // — and the hit record's overflow path — into a 16-fold unrolled loop: 8 400 instructions, ~50 KiB of code that no instruction cache
 // holds next to seven other workgroups' — measured 0.5 ms per WORK ITEM, 11.8 ms for the hostile stream's candidates).
+#if defined(__HIPCC__)
+__host__ __device__
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__
-#else
-inline
+__attribute__((noinline))
 #endif
-    uint32_t
+#endif
+inline uint32_t
     confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
                   const uint32_t i) {
     const ConfirmEntry e = entries[index];
@@ -69,32 +70,32 @@ inline
         const uint32_t t = confirm_load32(data + q + (pc & 0xFFu)) & 0xFFu;
         if (!((classes[((pc >> 8) & 0xFFu) * 8u + (t >> 5)] >> (t & 31u)) & 1u)) return 0;
     }
-    return e.atom == kConfirmWalk ? 2u : 1u;
+    return e.atom == kConfirmWalk ? 2u : (1u | ((uint32_t)e.atom << 8));
 }
 
-// The flagged 16-byte arena chunk c against the field [fs, fe) of one request: hit(atom) for every literal atom confirmed at a
-// position of the chunk; returns true when a factor of a non-literal atom was confirmed (the request must be walked).
-// tab_at(bin) / head_at(bin) read the pass's filter table and the confirm table's head word (the device keeps both in LDS).
-//
-// Two phases, because the 64 requests of a wave run this in lockstep:
-//   A  the filter's own shift-or automaton over the chunk (warmed up with the sampled bigrams of the 8 bytes before it: the state it
-//      had on the device) names the positions where a window really COMPLETED — one or two of the sixteen, as a bit mask. Registers
-//      and LDS only.
-//   B  each lane takes ITS next such position: head word -> the entries whose window can end with that bigram -> the full comparison.
-// (The first version looked up the head word of every position and compared on the spot: a fifth of all bins list an entry, so with
-// 64 lanes every one of the 16 iterations found SOME lane with work and paid the comparison's memory round trips — 1 400 load
-// instructions and 0.6 ms per wave, counters in profiles/r4_confirm_v1_counters.txt.)
-template <class TabAt, class HeadAt, class Hit>
-PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at, HeadAt &&head_at, Hit &&hit) {
-    if (fe < fs + 2u) return false;
+// A flagged 16-byte arena chunk as the confirm tier sees it: the positions where a window of the pass's filter really COMPLETED inside
+// the field [fs, fe) (bit k = chunk byte k) and, for the first four of them in ascending order, the filter bin of the bigram there
+// (12 bits each, 16 apart: a dynamic shift of one 64-bit register — selecting the bytes again by position made the compiler park the
+// chunk in scratch memory).
+struct ConfirmChunk {
+    uint32_t mask;
+    uint64_t bins;
+};
+// The filter's own shift-or automaton over the chunk, warmed up with the sampled bigrams of the 8 bytes before it (the state it had on
+// the device: four pushes determine it): one or two of the sixteen positions survive. Registers and tab_at(bin) — the pass's filter
+// table, which the device keeps in LDS — only. A match of any pattern holds a factor whose window completes at one of these
+// positions, inside the field (what lies before the factor cannot matter: a bucket only tests its last kmin bigrams).
+template <class TabAt>
+PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
     const uint32_t base = c * 16u;
     const bool pre = base >= 8u;  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
-    const uint32_t w0 = confirm_load32(data + base), w1 = confirm_load32(data + base + 4u), w2 = confirm_load32(data + base + 8u), w3 = confirm_load32(data + base + 12u),
-                   w4 = confirm_load32(data + base + 16u);
-    // ---- A: bytes [base - 8, base + 17) through a 64-bit window that moves one byte per step (no register is indexed by the position)
+    // bytes [base - 8, base + 17) through a 64-bit window that moves one byte per step (no register is indexed by the position; the
+    // loop is NOT unrolled: this code sits inside the kernel's per-lane state machine)
     uint32_t lo = pre ? confirm_load32(data + base - 8u) : 0u, hi = pre ? confirm_load32(data + base - 4u) : 0u;
-    uint32_t n0 = w0, n1 = w1, n2 = w2, n3 = w3, n4 = w4;
-    uint32_t st = cv.init, mask = 0;
+    uint32_t n0 = confirm_load32(data + base), n1 = confirm_load32(data + base + 4u), n2 = confirm_load32(data + base + 8u), n3 = confirm_load32(data + base + 12u),
+             n4 = confirm_load32(data + base + 16u);
+    uint32_t st = cv.init, mask = 0, found = 0;
+    uint64_t bins = 0;
 #pragma unroll 1
     for (uint32_t t = 0; t < 24; t++) {
         const uint32_t b0 = lo & 0xFFu, b1 = (lo >> 8) & 0xFFu;
@@ -104,25 +105,46 @@ PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uin
         if (t < 8u && !pre) continue;               // (the arena's first chunk: the stream starts in the init state)
         const uint32_t i = base + t - 8u;
         if (cv.stride == 2u && (i & 1u)) continue;  // (bigrams are sampled at the even bytes of the arena)
-        st = (st << 8) | tab_at(filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul));
-        if (t >= 8u && ((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) mask |= 1u << (t - 8u);  // a window completed here, both bytes inside the field
+        const uint32_t bin = filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul);
+        st = (st << 8) | tab_at(bin);
+        if (t >= 8u && ((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) {  // a window completed here, both bytes inside the field
+            mask |= 1u << (t - 8u);
+            if (found < 4u) bins |= (uint64_t)bin << (16u * found);
+            found++;
+        }
     }
-    // ---- B: the completed windows, one per iteration
+    ConfirmChunk r;
+    r.mask = fe < fs + 2u ? 0u : mask;
+    r.bins = bins;
+    return r;
+}
+// filter bin of the bigram of the chunk's idx-th completed window (ascending positions), which sits at arena position pos
+PWAF_HD uint32_t confirm_bin_of(const ConfirmChunk &ch, const uint32_t idx, const uint8_t *data, const uint32_t pos, const uint32_t mul) {
+    if (idx < 4u) return (uint32_t)(ch.bins >> (16u * idx)) & 0xFFFu;
+    const uint32_t two = confirm_load32(data + pos);  // (more than four windows completed in one chunk: rare)
+    return filter_bin((uint8_t)(two & 0xFFu), (uint8_t)((two >> 8) & 0xFFu), mul);
+}
+
+// The flagged chunk c against the field [fs, fe) of one request, start to end: hit(atom) for every literal atom confirmed at a position
+// of the chunk; returns true when a factor of a non-literal atom was confirmed (the request must be walked). head_at(bin) reads the
+// confirm table's head word. (The host's form — tune, the CPU test hook. The device kernel runs the same three steps — windows, head
+// word, entry comparison — as a per-lane state machine, so that the 64 requests of a wave each take THEIR next comparison per
+// iteration instead of the wave taking the product of the nested loops' longest trips: kernels.hip, confirm_kernel.)
+template <class TabAt, class HeadAt, class Hit>
+PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at, HeadAt &&head_at, Hit &&hit) {
+    const ConfirmChunk ch = confirm_windows(cv, data, fs, fe, c, tab_at);
+    uint32_t mask = ch.mask, idx = 0;
     bool walk = false;
     while (mask) {
         const uint32_t k = (uint32_t)__builtin_ctz(mask);
         mask &= mask - 1u;
-        const uint32_t q = k >> 2;
-        const uint32_t a = q == 0u ? w0 : q == 1u ? w1 : q == 2u ? w2 : w3, b = q == 0u ? w1 : q == 1u ? w2 : q == 2u ? w3 : w4;
-        const uint32_t two = (uint32_t)((((uint64_t)b << 32) | a) >> (8u * (k & 3u)));
-        const uint32_t hd = head_at(filter_bin((uint8_t)(two & 0xFFu), (uint8_t)((two >> 8) & 0xFFu), cv.mul));
+        const uint32_t hd = head_at(confirm_bin_of(ch, idx++, data, c * 16u + k, cv.mul));
         if (hd == 0u) continue;
         const uint32_t first = hd & 0xFFFFFu, cnt = hd >> 20;
-#pragma unroll 1
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, base + k);
+            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, c * 16u + k);
             if (res == 2u) walk = true;
-            else if (res == 1u) hit((uint32_t)cv.entries[first + j].atom);
+            else if (res & 1u) hit(res >> 8);
         }
     }
     return walk;

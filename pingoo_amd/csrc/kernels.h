@@ -149,7 +149,7 @@ struct ConfirmArgs {
     uint32_t shared_bits;
     uint32_t *walk;             // [list entry] -> 1: walk the request through the R-tier DFA (null: the pass has no such atoms)
 };
-static constexpr uint32_t kConfirmThreads = 256, kConfirmPerLaunch = 8;
+static constexpr uint32_t kConfirmThreads = 512, kConfirmPerLaunch = 8;
 struct ConfirmBatchArgs {
     ConfirmArgs c[kConfirmPerLaunch];
     uint32_t count;

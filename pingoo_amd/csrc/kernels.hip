@@ -870,10 +870,16 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
 }
 
 // One lane per candidate-list entry; a persistent grid over device-computed work items (one workgroup's worth of entries of one pass
-// each), like the list scan: consecutive items are mostly of one pass, whose head table (16 KiB) is staged in LDS once. Per entry:
-// offsets -> the field's words of the chunk bitmap -> per flagged chunk 20 bytes of text, 16 head lookups (LDS), and for the rare
-// bin that lists an entry the full comparison (confirm.h) against the L2-resident byte pool. No DFA, no state: what a near miss
-// costs here is one comparison that fails, whatever the traffic looks like.
+// each), like the list scan: consecutive items are mostly of one pass, whose filter table and confirm head table (16 KiB each) are
+// staged in LDS once.
+//
+// A lane's work is a chain: offsets -> the field's words of the chunk bitmap -> per flagged chunk its text and the filter's automaton
+// over it (confirm_windows: which positions completed a window) -> per such position the head word -> per listed entry the full
+// comparison against the L2-resident byte pool (confirm_entry). Written as nested loops the 64 lanes of a wave take the PRODUCT of
+// each level's longest trip (measured: ~28 comparisons per wave where a lane needs one or two, every one a chain of memory round
+// trips — 0.42 ms for the benign candidates of a 10M-request batch, 5.7 ms for the hostile stream's). So the lane is a small state
+// machine and the wave's loop has two steps: lanes that are out of windows fetch their next flagged chunk, lanes that hold an entry
+// compare it. Every lane takes ITS next comparison per iteration: the wave runs as long as its longest lane, not the product.
 __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __builtin_amdgcn_s_setprio(3);
@@ -887,17 +893,18 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
             else hi = mid;
             ps = lo;
         }
-        const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
+        const uint32_t first_item = plan[ps], it_end = min(it1, plan[ps + 1]);
         const ConfirmArgs a = load_descriptor(&b.c[ps]);
-        __syncthreads();  // (every wave is done with the previous pass's heads)
+        __syncthreads();  // (every wave is done with the previous pass's tables)
         {
             // 16 bytes per lane and load, all of a thread's loads in flight before the first store (two 16 KiB tables)
             const uint4 *sh = reinterpret_cast<const uint4 *>(a.c_head), *sf = reinterpret_cast<const uint4 *>(a.ftable);
-            uint4 vh[kFilterEntries / 4 / kConfirmThreads], vf[kFilterEntries / 4 / kConfirmThreads];
+            constexpr uint32_t kPer = kFilterEntries / 4 / kConfirmThreads;
+            uint4 vh[kPer], vf[kPer];
 #pragma unroll
-            for (uint32_t q = 0; q < kFilterEntries / 4 / kConfirmThreads; q++) { vh[q] = sh[q * kConfirmThreads + threadIdx.x]; vf[q] = sf[q * kConfirmThreads + threadIdx.x]; }
+            for (uint32_t q = 0; q < kPer; q++) { vh[q] = sh[q * kConfirmThreads + threadIdx.x]; vf[q] = sf[q * kConfirmThreads + threadIdx.x]; }
 #pragma unroll
-            for (uint32_t q = 0; q < kFilterEntries / 4 / kConfirmThreads; q++) {
+            for (uint32_t q = 0; q < kPer; q++) {
                 reinterpret_cast<uint4 *>(head)[q * kConfirmThreads + threadIdx.x] = vh[q];
                 reinterpret_cast<uint4 *>(ftab)[q * kConfirmThreads + threadIdx.x] = vf[q];
             }
@@ -907,32 +914,63 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
         const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
         const uint32_t n_l = min(*a.n_list, a.n);
         for (; it < it_end; it++) {
-            const uint32_t li = (it - first) * kConfirmThreads + threadIdx.x;
-            if (li >= n_l) continue;
-            const uint32_t r = a.req_list[li];
-            const uint32_t fs = a.off[r], fe = a.off[r + 1];
+            const uint32_t li = (it - first_item) * kConfirmThreads + threadIdx.x;
+            const bool live = li < n_l;
+            const uint32_t r = live ? a.req_list[li] : 0u;
+            const uint32_t fs = live ? a.off[r] : 0u, fe = live ? a.off[r + 1] : 0u;
             Hits h{0, 0, kNone};
-            if (a.has_heads) {  // what the filter kernel's head comparisons recorded for this request
-                const uint32_t heads = a.rec[r];
-                h.a0 = heads & 0x7FFFu;
-                h.a1 = (heads >> 15) & 0x7FFFu;
-            }
+            if (live && a.has_heads) h = hits_of_record(a.rec[r]);  // what the filter kernel's head comparisons recorded for this request
             bool walk = false;
-            if (fe >= fs + 2u) {
-                const uint32_t c_lo = (fs >> 4) - a.chunk_base, c_hi = ((fe - 1u) >> 4) - a.chunk_base;
-                for (uint32_t w = c_lo >> 5; w <= (c_hi >> 5); w++) {
+            const bool any_bytes = live && fe >= fs + 2u;
+            const uint32_t c_lo = any_bytes ? (fs >> 4) - a.chunk_base : 1u, c_hi = any_bytes ? ((fe - 1u) >> 4) - a.chunk_base : 0u;
+            // the field's words of the chunk bitmap, three at a time (a field of up to ~1 KiB has at most three)
+            for (uint32_t seg = c_lo >> 5;; seg += 3u) {
+                const bool seg_live = any_bytes && seg <= (c_hi >> 5);
+                if (__ballot(seg_live) == 0) break;
+                auto bitmap_word = [&](const uint32_t w) -> uint32_t {
+                    if (!seg_live || w > (c_hi >> 5)) return 0u;
                     uint32_t bits = a.chunk_bits[w];
                     if (w == (c_lo >> 5)) bits &= ~0u << (c_lo & 31u);
                     if (w == (c_hi >> 5)) bits &= ~0u >> (31u - (c_hi & 31u));
-                    while (bits) {
-                        const uint32_t c = w * 32u + (uint32_t)__builtin_ctz(bits) + a.chunk_base;
-                        bits &= bits - 1u;
-                        const bool wk = confirm_chunk(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return ftab[bin]; }, [&](const uint32_t bin) { return head[bin]; },
-                                                      [&](const uint32_t atom) { h = record_atom(ctx, atom, h); });
-                        walk = walk || wk;
+                    return bits;
+                };
+                uint32_t bw0 = bitmap_word(seg), bw1 = bitmap_word(seg + 1u), bw2 = bitmap_word(seg + 2u);
+                uint32_t mask = 0, cnt = 0, j = 0, e0 = 0, pos = 0, cbase = 0, widx = 0;
+                ConfirmChunk ch{0u, 0ull};
+                for (;;) {
+                    if (__ballot(j < cnt || mask != 0u || (bw0 | bw1 | bw2) != 0u) == 0) break;
+                    // step 1: a lane that is out of windows takes its next flagged chunk (text loads + the filter's automaton over it)
+                    if (j >= cnt && mask == 0u && (bw0 | bw1 | bw2) != 0u) {
+                        uint32_t rel;
+                        if (bw0) { rel = (uint32_t)__builtin_ctz(bw0); bw0 &= bw0 - 1u; }
+                        else if (bw1) { rel = 32u + (uint32_t)__builtin_ctz(bw1); bw1 &= bw1 - 1u; }
+                        else { rel = 64u + (uint32_t)__builtin_ctz(bw2); bw2 &= bw2 - 1u; }
+                        const uint32_t c = seg * 32u + rel + a.chunk_base;
+                        ch = confirm_windows(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return ftab[bin]; });
+                        mask = ch.mask;
+                        cbase = c * 16u;
+                        widx = 0;
+                    }
+                    // ... and a lane that is out of entries its next window that lists some (LDS only)
+                    while (j >= cnt && mask != 0u) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(mask);
+                        mask &= mask - 1u;
+                        pos = cbase + k;
+                        const uint32_t hd = head[confirm_bin_of(ch, widx++, a.data, pos, a.mul)];
+                        e0 = hd & 0xFFFFFu;
+                        cnt = hd >> 20;
+                        j = 0;
+                    }
+                    // step 2: one comparison per lane that holds an entry
+                    if (j < cnt) {
+                        const uint32_t res = confirm_entry(a.c_entries, a.c_bytes, a.c_classes, e0 + j, a.data, fs, fe, pos);
+                        j++;
+                        if (res == 2u) walk = true;
+                        else if (res & 1u) h = record_atom(ctx, res >> 8, h);
                     }
                 }
             }
+            if (!live) continue;
             a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
             if (a.walk != nullptr) a.walk[li] = walk ? 1u : 0u;
             if (a.colmask_local != nullptr) {
@@ -1020,9 +1058,9 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     hipLaunchKernelGGL(confirm_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // persistent grid: 5 workgroups of 256 per CU (32 KiB of LDS each), never more than the items a full batch could produce
+    // persistent grid: 4 workgroups of 512 per CU (32 KiB of LDS each: 32 waves per CU), never more than the items a full batch could produce
     const uint64_t max_items = (uint64_t)count * ((host[0].n + kConfirmThreads - 1) / kConfirmThreads);
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 5u);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 4u);
     const uint32_t *cplan = plan;
     hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
     return (int)hipGetLastError();
