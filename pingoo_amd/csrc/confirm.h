@@ -27,11 +27,19 @@ struct ConfirmView {  // plain pointers: host tables or device tables
     uint32_t init;  // the filter's state of a stream with no history (GroupFilter::init)
 };
 
-PWAF_HD uint32_t confirm_load32(const uint8_t *p) {
+PWAF_HD uint32_t confirm_load32(const uint8_t *p) {  // request TEXT: an arena in global memory
 #if defined(__HIP_DEVICE_COMPILE__)
-    // (every table and arena of this tier lives in global memory: a GLOBAL load, at any byte address — gfx950 needs no alignment —
-    // instead of the FLAT load a generic pointer gets)
+    // (a GLOBAL load, at any byte address — gfx950 needs no alignment — instead of the FLAT load a generic pointer gets)
     return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t __attribute__((aligned(1))) *>((uintptr_t)p);
+#else
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+#endif
+}
+PWAF_HD uint32_t confirm_table32(const uint8_t *p) {  // the tier's TABLES (4-byte aligned): global memory, or the kernel's LDS copy (a generic pointer)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const uint32_t *>(p);
 #else
     uint32_t v;
     memcpy(&v, p, 4);
@@ -63,12 +71,16 @@ inline uint32_t
     const uint32_t l4 = (len + 3u) & ~3u;
     const uint8_t *val = bytes + e.bytes_off, *msk = val + l4;
     for (uint32_t w = 0; w < l4; w += 4)  // (reads up to 3 bytes past the factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero)
-        if ((confirm_load32(data + q + w) ^ confirm_load32(val + w)) & confirm_load32(msk + w)) return 0;
+        if ((confirm_load32(data + q + w) ^ confirm_table32(val + w)) & confirm_table32(msk + w)) return 0;
     const uint8_t *cls = msk + l4;
-    for (uint32_t k = 0; k < e.n_cls; k++) {
-        const uint32_t pc = confirm_load32(cls + 2u * k);  // {position, class id} (the pool is padded: the load may run 2 bytes over)
+    for (uint32_t k = 0; k < e.n_cls; k += 2) {
+        const uint32_t pc = confirm_table32(cls + 2u * k);  // two {position, class id} pairs (the pool is padded to whole dwords)
         const uint32_t t = confirm_load32(data + q + (pc & 0xFFu)) & 0xFFu;
         if (!((classes[((pc >> 8) & 0xFFu) * 8u + (t >> 5)] >> (t & 31u)) & 1u)) return 0;
+        if (k + 1u < e.n_cls) {
+            const uint32_t t2 = confirm_load32(data + q + ((pc >> 16) & 0xFFu)) & 0xFFu;
+            if (!((classes[(pc >> 24) * 8u + (t2 >> 5)] >> (t2 & 31u)) & 1u)) return 0;
+        }
     }
     return e.atom == kConfirmWalk ? 2u : (1u | ((uint32_t)e.atom << 8));
 }

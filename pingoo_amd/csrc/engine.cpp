@@ -1154,6 +1154,9 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.c_entries = (const ConfirmEntry *)d.c_entries.p;
             c.c_bytes = (const uint8_t *)d.c_bytes.p;
             c.c_classes = (const uint32_t *)d.c_classes.p;
+            c.n_entries = (uint32_t)d.filter.confirm.entries.size();
+            c.n_bytes = (uint32_t)d.filter.confirm.bytes.size() & ~3u;
+            c.n_class_words = (uint32_t)d.filter.confirm.classes.size();
             c.has_heads = d.filter.heads.empty() ? 0u : 1u;
             c.rec = f.rec;
             c.pool = (PoolEntry *)S.pool.p;

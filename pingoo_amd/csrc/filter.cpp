@@ -374,6 +374,7 @@ bool build_confirm_table(std::vector<ConfirmSeed> &seeds, uint32_t mul, ConfirmT
     }
     for (auto &pl : placed) out.entries.push_back(pl.e);
     for (int pad = 0; pad < 4; pad++) out.bytes.push_back(0);  // (the last entry's dword loads)
+    while (out.bytes.size() & 3) out.bytes.push_back(0);
     if (out.classes.empty()) out.classes.assign(8, 0u);
     out.enabled = true;
     return true;

@@ -135,6 +135,7 @@ struct ConfirmArgs {
     const ConfirmEntry *c_entries;
     const uint8_t *c_bytes;
     const uint32_t *c_classes;
+    uint32_t n_entries, n_bytes, n_class_words;  // table sizes (bytes: a multiple of 4): a pass whose entries + bytes + classes fit the launch's LDS pool is compared from LDS
     uint32_t has_heads;         // rec[] holds what the filter kernel's head comparisons found (zeroed by the host): merged
     uint32_t *rec;
     PoolEntry *pool;
@@ -149,7 +150,8 @@ struct ConfirmArgs {
     uint32_t shared_bits;
     uint32_t *walk;             // [list entry] -> 1: walk the request through the R-tier DFA (null: the pass has no such atoms)
 };
-static constexpr uint32_t kConfirmThreads = 512, kConfirmPerLaunch = 8;
+static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 8;
+static constexpr uint32_t kConfirmPoolBytes = 44 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
 struct ConfirmBatchArgs {
     ConfirmArgs c[kConfirmPerLaunch];
     uint32_t count;

@@ -880,8 +880,13 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
 // trips — 0.42 ms for the benign candidates of a 10M-request batch, 5.7 ms for the hostile stream's). So the lane is a small state
 // machine and the wave's loop has two steps: lanes that are out of windows fetch their next flagged chunk, lanes that hold an entry
 // compare it. Every lane takes ITS next comparison per iteration: the wave runs as long as its longest lane, not the product.
-__global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
+//
+// The comparison's tables — entries, value / mask bytes, classes: a few dozen KiB per pass — are staged in LDS next to the two 16 KiB
+// lookup tables whenever they fit (kConfirmPoolBytes): of a comparison's chain of round trips (entry -> bytes + text -> class) only the
+// request text is then a trip to memory. A pass whose tables do not fit reads them from the L2-resident originals.
+__global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
+    __shared__ uint32_t pool[kConfirmPoolBytes / 4];                 // entries | bytes | classes of the pass (when they fit)
     __builtin_amdgcn_s_setprio(3);
     const uint32_t total = plan[b.count];
     const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
@@ -909,8 +914,23 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
                 reinterpret_cast<uint4 *>(ftab)[q * kConfirmThreads + threadIdx.x] = vf[q];
             }
         }
+        // the comparison tables: LDS when they fit (generic pointers: the same comparison code reads either copy)
+        const uint32_t e_words = a.n_entries * 3u, b_words = a.n_bytes / 4u, c_words = a.n_class_words;
+        const bool in_lds = (uint64_t)e_words + b_words + c_words <= kConfirmPoolBytes / 4;
+        const ConfirmEntry *t_entries = a.c_entries;
+        const uint8_t *t_bytes = a.c_bytes;
+        const uint32_t *t_classes = a.c_classes;
+        if (in_lds) {
+            const uint32_t *se = reinterpret_cast<const uint32_t *>(a.c_entries), *sb = reinterpret_cast<const uint32_t *>(a.c_bytes);
+            for (uint32_t k = threadIdx.x; k < e_words; k += kConfirmThreads) pool[k] = se[k];
+            for (uint32_t k = threadIdx.x; k < b_words; k += kConfirmThreads) pool[e_words + k] = sb[k];
+            for (uint32_t k = threadIdx.x; k < c_words; k += kConfirmThreads) pool[e_words + b_words + k] = a.c_classes[k];
+            t_entries = reinterpret_cast<const ConfirmEntry *>(pool);
+            t_bytes = reinterpret_cast<const uint8_t *>(pool + e_words);
+            t_classes = pool + e_words + b_words;
+        }
         __syncthreads();
-        const ConfirmView cv{nullptr, a.c_entries, a.c_bytes, a.c_classes, a.mul, a.stride, a.init};
+        const ConfirmView cv{nullptr, t_entries, t_bytes, t_classes, a.mul, a.stride, a.init};
         const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
         const uint32_t n_l = min(*a.n_list, a.n);
         for (; it < it_end; it++) {
@@ -963,7 +983,7 @@ __global__ __launch_bounds__(kConfirmThreads) void confirm_kernel(ConfirmTableDe
                     }
                     // step 2: one comparison per lane that holds an entry
                     if (j < cnt) {
-                        const uint32_t res = confirm_entry(a.c_entries, a.c_bytes, a.c_classes, e0 + j, a.data, fs, fe, pos);
+                        const uint32_t res = confirm_entry(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
                         j++;
                         if (res == 2u) walk = true;
                         else if (res & 1u) h = record_atom(ctx, res >> 8, h);
@@ -1058,9 +1078,9 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     hipLaunchKernelGGL(confirm_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // persistent grid: 4 workgroups of 512 per CU (32 KiB of LDS each: 32 waves per CU), never more than the items a full batch could produce
+    // persistent grid: 2 workgroups of 1024 per CU (76 KiB of LDS each: 32 waves per CU), never more than the items a full batch could produce
     const uint64_t max_items = (uint64_t)count * ((host[0].n + kConfirmThreads - 1) / kConfirmThreads);
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 4u);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 2u);
     const uint32_t *cplan = plan;
     hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
     return (int)hipGetLastError();
