@@ -130,7 +130,8 @@ struct Scratch {
     DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
     DevBuf chunk_bits, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
-    DevBuf walk;                           // per filtered pass with a confirm tier: confirm_kernel's "walk this entry" flags
+    DevBuf pairs;                          // per filtered pass with a confirm tier: resolve_kernel's (request, flagged chunk) pairs
+    DevBuf walk_bits;                      // ... and the "already on the walk list" bitmaps
     DevBuf args_confirm;                   // ConfirmArgs per pass + the work-item plan
     DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
@@ -158,7 +159,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &walk, &args_confirm, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &pairs, &walk_bits, &args_confirm, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (auto &b : stage_field_data) b.release();
@@ -539,7 +540,10 @@ int assign_lists(pwaf_engine *e) {
     for (auto &d : e->groups) { d.share_owner = -1; d.shared_bits = 0; d.need_slot = -1; d.visit_slot = -1; d.identity = false; }
     for (size_t k = 0; k < P.groups.size(); k++) {
         DevGroup &d = e->groups[k];
-        if (d.gate >= 0 && !d.filtered) d.visit_slot = (int)e->n_visit++;
+        if (d.gate >= 0 && !d.filtered) {
+            d.visit_slot = d.gate;  // (a gap pass's visited bitmap is indexed by its list slot: enqueueing sets the bit)
+            e->n_visit = std::max(e->n_visit, (uint32_t)d.gate + 1u);
+        }
         // a plain pass over a field of a few bytes: the streaming DFA kernel's per-request machinery costs more than the walk itself
         const double ml = P.groups[k].field < e->mean_len.size() ? e->mean_len[P.groups[k].field] : 0.0;
         if (d.gate < 0 && (P.groups[k].field == PWAF_FIELD_METHOD ? (ml == 0 || ml < 12) : (ml > 0 && ml < 12))) d.identity = true;
@@ -590,7 +594,7 @@ int assign_lists(pwaf_engine *e) {
             if (o < 0 || (owner >= 0 && o != owner)) single = false;
             owner = o;
         }
-        if (!single || owner < 0 || !e->groups[owner].filtered) continue;
+        if (!single || owner < 0 || !e->groups[owner].filtered || e->groups[owner].confirm) continue;  // (an owner with a confirm tier has no candidate list to share: it enqueues)
         d.share_owner = owner;
         e->groups[owner].shared_bits |= 1u << d.gate;
         if (e->groups[owner].need_slot < 0) e->groups[owner].need_slot = (int)e->n_need++;
@@ -675,7 +679,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const uint32_t pair_stride = std::max(1u, e->n_bit_atoms + e->n_cmp_atoms + e->n_short);
     if ((rc = S.attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
-    const size_t ctrl_words = 2 + (size_t)std::max(kGapLists, e->n_gated);  // [0] pool allocator, [1] status word, then one length per list slot
+    const size_t n_slots = (size_t)std::max(kGapLists, e->n_gated);
+    const size_t ctrl_words = 2 + n_slots + e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count per filtered pass
     if ((rc = S.ctrl.reserve(4 * ctrl_words))) return rc;
     HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, 4 * ctrl_words, stream));
     // string columns by field id: the five fixed fields, then one column per header name the rule set mentions (EXTENSION); a header
@@ -713,11 +718,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)S.zero_off.p) col_known[f] = 1;
     if (e->n_gated && (rc = S.gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
     if (e->n_need && (rc = S.need.reserve((size_t)e->n_need * n * 4))) return rc;
-    {
-        uint32_t n_walk = 0;
-        for (const DevGroup &d : e->groups) n_walk += d.confirm_walk ? 1u : 0u;
-        if (n_walk && (rc = S.walk.reserve((size_t)n_walk * n * 4))) return rc;
-    }
+
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
     // zeroing the hit records themselves would write
     const uint32_t bit_words = 2 * n_groups;
@@ -801,8 +802,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.cand_bits = (const uint32_t *)S.cand_bits.p;
     v.visit_bits = (const uint32_t *)S.visit_bits.p;
     v.bit_words = bit_words;
-    for (size_t k = 0; k < e->groups.size(); k++)  // a pass with heads writes records outside its candidate list too: zeroed, read densely
-        if (e->groups[k].filtered && !e->groups[k].filter.heads.empty()) HIP_TRY(hipMemsetAsync((uint32_t *)S.rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
+    for (size_t k = 0; k < e->groups.size(); k++)  // a pass with heads writes records outside its candidate list too: zeroed, read densely; a confirm tier MERGES hits into zeroed records
+        if (e->groups[k].filtered && (!e->groups[k].filter.heads.empty() || e->groups[k].confirm)) HIP_TRY(hipMemsetAsync((uint32_t *)S.rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
     v.n_hlen = (uint32_t)e->hlen_fields.size();
     for (size_t k = 0; k < e->hlen_fields.size(); k++) v.hoff[k] = cols[e->hlen_fields[k]].offsets;
     v.gpairs = (uint4 *)S.attr.p;
@@ -953,7 +954,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     }
 #endif
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
-    std::vector<const uint32_t *> walk_of(e->groups.size(), nullptr);        // passes with a confirm tier: confirm_kernel's walk flags (set in step 2)
     auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
@@ -972,17 +972,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             a.n_local = d.n_local;
             a.gate_lists = (uint32_t *)S.gate_lists.p;
             a.gate_count = (uint32_t *)S.ctrl.p + 2;
+            a.enq_bits = (uint32_t *)S.visit_bits.p;  // (a gap pass's visited bitmap, indexed by its list slot: set when the request is enqueued)
+            a.enq_words = bit_words;
             if (d.need_slot >= 0) {
                 a.need_out = (uint32_t *)S.need.p + (size_t)d.need_slot * n;
                 a.shared_bits = d.shared_bits;
             }
         }
-        if (d.confirm) {
-            // the R-tier walk of a pass with a confirm tier: only the entries confirm_kernel flagged, starting from the record it wrote
-            a.need_in = walk_of[gi];
-            a.need_bit = 0;
-            a.merge_rec = 1;
-        }
+        if (d.confirm) a.merge_rec = 1;  // the R-tier walk of a pass with a confirm tier: its list is confirm_kernel's walk list, the walk starts from the record it merged
         a.behind_filter = d.filtered ? 1u : 0u;
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
@@ -1053,7 +1050,22 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         std::vector<FilterArgs> fall;  // every filtered pass, in pass order
         uint32_t fi = 0;
         uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
-        uint64_t sub_at = 0, cnt_at = 0;
+        uint64_t sub_at = 0, cnt_at = 0, pair_at = 0;
+        {
+            uint64_t pair_bytes = 0;
+            uint32_t n_conf = 0;
+            for (const DevGroup &d : e->groups)
+                if (d.filtered && d.confirm) {
+                    const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab - (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u);
+                    pair_bytes += std::min<uint64_t>(0xFFFFFFF0u, slabs * (kStreamSlab / 16) + n + 64) * sizeof(uint2);
+                    n_conf++;
+                }
+            if (pair_bytes && (rc = S.pairs.reserve((size_t)pair_bytes))) return rc;
+            if (n_conf) {
+                if ((rc = S.walk_bits.reserve((size_t)n_conf * bit_words * 4))) return rc;
+                HIP_TRY(hipMemsetAsync(S.walk_bits.p, 0, (size_t)n_conf * bit_words * 4, stream));
+            }
+        }
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
             if (!d.filtered) continue;
@@ -1092,6 +1104,13 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
             f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
+            if (d.confirm) {
+                // (request, flagged chunk) pairs: at most one per chunk of the arena plus one per request (a chunk that straddles two requests counts for both)
+                f.pair_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, (uint64_t)slabs * (kStreamSlab / 16) + n + 64);
+                f.pairs = (uint2 *)((char *)S.pairs.p + pair_at);
+                f.pair_count = (uint32_t *)S.ctrl.p + 2 + n_slots + fi;
+                pair_at += (uint64_t)f.pair_cap * sizeof(uint2);
+            }
             f.first_block = 0;
             sub_at += (uint64_t)slabs * (kStreamSlab / 512);
             cnt_at += slabs + n_cblocks;
@@ -1142,10 +1161,9 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.data = f.data;
             c.off = f.off;
             c.n = n;
-            c.req_list = f.list;
-            c.n_list = f.list_count;
-            c.chunk_bits = f.chunk_bits;
-            c.chunk_base = f.slab0 * (kStreamSlab / 16);
+            c.pairs = f.pairs;
+            c.pair_count = f.pair_count;
+            c.pair_cap = f.pair_cap;
             c.mul = f.mul;
             c.stride = f.stride;
             c.init = f.init;
@@ -1157,8 +1175,13 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.n_entries = (uint32_t)d.filter.confirm.entries.size();
             c.n_bytes = (uint32_t)d.filter.confirm.bytes.size() & ~3u;
             c.n_class_words = (uint32_t)d.filter.confirm.classes.size();
-            c.has_heads = d.filter.heads.empty() ? 0u : 1u;
             c.rec = f.rec;
+            c.valid_bits = f.bitmap;
+            c.walk_bits = (uint32_t *)S.walk_bits.p + (size_t)wi++ * bit_words;
+            if (d.confirm_walk) {
+                c.walk_list = f.list;
+                c.walk_count = f.list_count;
+            }
             c.pool = (PoolEntry *)S.pool.p;
             c.pool_count = (uint32_t *)S.ctrl.p;
             c.pool_cap = pool_cap;
@@ -1168,14 +1191,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 c.n_local = d.n_local;
                 c.gate_lists = (uint32_t *)S.gate_lists.p;
                 c.gate_count = (uint32_t *)S.ctrl.p + 2;
-                if (d.need_slot >= 0) {
-                    c.need_out = (uint32_t *)S.need.p + (size_t)d.need_slot * n;
-                    c.shared_bits = d.shared_bits;
-                }
-            }
-            if (d.confirm_walk) {
-                c.walk = (uint32_t *)S.walk.p + (size_t)wi++ * n;
-                walk_of[gi] = c.walk;
+                c.enq_bits = (uint32_t *)S.visit_bits.p;
+                c.enq_words = bit_words;
             }
             call.push_back(c);
         }

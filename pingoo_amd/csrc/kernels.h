@@ -100,6 +100,8 @@ struct ListScanArgs {
     uint32_t n_local;
     uint32_t *gate_lists;
     uint32_t *gate_count;
+    uint32_t *enq_bits;        // [gap list slot][enq_words]: a request is appended to a gap pass's list ONCE (the list holds n entries) — this is also that pass's "record valid" bitmap
+    uint32_t enq_words;
     uint32_t behind_filter;    // the list is a bigram prefilter's candidate list (hostile traffic makes it long: lscan_async)
     const uint32_t *req_list;  // the requests to visit and, on the device, how many (req_list null: every request, n_list ignored)
     const uint32_t *n_list;
@@ -109,8 +111,8 @@ struct ListScanArgs {
     // per list entry, the mask of gap passes its hits call for (need_out); a sharing pass skips entries without its bit.
     uint32_t *need_out;        // owner: [list entry] -> gap-pass mask (null: none shares)
     uint32_t shared_bits;      // owner: the gap passes that read need_out (the other bits of a hit's mask are enqueued with atomics)
-    const uint32_t *need_in;   // sharing pass: the owner's masks (null: the list is its own). Also the R-tier walk of a pass with a confirm tier:
-    uint32_t need_bit;         //   confirm_kernel's walk flags of the pass's own candidate list (bit 0)
+    const uint32_t *need_in;   // sharing pass: the owner's masks (null: the list is its own)
+    uint32_t need_bit;
     // The walk of a pass with a confirm tier: the request's record already holds what the filter heads and the confirm tier found
     // (literal atoms are not in the R-tier DFA); the walk starts from it, and enqueues only what its own hits add.
     uint32_t merge_rec;
@@ -118,17 +120,18 @@ struct ListScanArgs {
 };
 
 // ---- confirm tier (program.h: ConfirmTable; confirm.h) ---------------------------------------------------------------------------
-// confirm_kernel: one lane per entry of a filtered pass's candidate list. The lane looks at the flagged chunks inside its request's
-// field: literal atoms confirmed there go into the hit record (complete for this pass unless the request must also be walked), and
-// walk[list entry] says whether a factor of a non-literal atom was confirmed — only those requests are walked, through the R-tier DFA.
+// confirm_kernel: one lane per (request, flagged chunk) pair of a filtered pass (resolve_kernel lists them). The lane runs the filter's
+// automaton over its chunk, compares the entries of the windows that completed there, and only acts when something is confirmed
+// (rare: most pairs are chance hits of the bigram hash, or near misses): a literal atom is merged into the request's hit record
+// (compare-and-swap: another chunk of the same request may be merging too), a factor of a non-literal atom puts the request on the
+// pass's walk list (once: walk_bits) for the R-tier DFA.
 struct ConfirmArgs {
     const uint8_t *data;
     const uint32_t *off;
     uint32_t n;
-    const uint32_t *req_list;   // the pass's candidate list and, on the device, its length
-    const uint32_t *n_list;
-    const uint32_t *chunk_bits; // the pass's chunk bitmap of this batch: bit c - chunk_base = the arena's 16-byte chunk c was flagged
-    uint32_t chunk_base;
+    const uint2 *pairs;         // {request, arena chunk}
+    const uint32_t *pair_count; // on the device
+    uint32_t pair_cap;
     uint32_t mul, stride, init; // of the pass's bigram hash / sampling / automaton (GroupFilter)
     const uint32_t *ftable;     // the pass's filter table (kFilterEntries masks)
     const uint32_t *c_head;     // ConfirmTable on the device
@@ -136,8 +139,11 @@ struct ConfirmArgs {
     const uint8_t *c_bytes;
     const uint32_t *c_classes;
     uint32_t n_entries, n_bytes, n_class_words;  // table sizes (bytes: a multiple of 4): a pass whose entries + bytes + classes fit the launch's LDS pool is compared from LDS
-    uint32_t has_heads;         // rec[] holds what the filter kernel's head comparisons found (zeroed by the host): merged
-    uint32_t *rec;
+    uint32_t *rec;              // the pass's hit records, ZEROED by the host per batch (hits are merged in)
+    uint32_t *valid_bits;       // bit r: record r holds something (the verdict kernel reads no other record of the pass)
+    uint32_t *walk_bits;        // bit r: request r is on the walk list
+    uint32_t *walk_list;        // requests to walk through the R-tier DFA, and how many (null: the pass has no non-literal atom)
+    uint32_t *walk_count;
     PoolEntry *pool;
     uint32_t *pool_count;
     uint32_t pool_cap;
@@ -146,9 +152,8 @@ struct ConfirmArgs {
     uint32_t n_local;
     uint32_t *gate_lists;
     uint32_t *gate_count;
-    uint32_t *need_out;
-    uint32_t shared_bits;
-    uint32_t *walk;             // [list entry] -> 1: walk the request through the R-tier DFA (null: the pass has no such atoms)
+    uint32_t *enq_bits;
+    uint32_t enq_words;
 };
 static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 8;
 static constexpr uint32_t kConfirmPoolBytes = 44 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
@@ -203,6 +208,11 @@ struct FilterArgs {
     uint32_t *block_count;    // [(words + kCompactWords - 1) / kCompactWords]: candidates per compact workgroup
     uint32_t *list;           // n: dense candidate list
     uint32_t *list_count;     // its length
+    // A pass with a confirm tier: resolve_kernel writes no candidate bitmap but the (request, flagged chunk) PAIRS of the pass — one per
+    // flagged chunk inside a request's own bytes — for confirm_kernel to take one lane each (null: the pass has no confirm tier)
+    uint2 *pairs;
+    uint32_t *pair_count;
+    uint32_t pair_cap;
     uint32_t first_block;     // first workgroup of this pass in the fused filter launch
     uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration
 };

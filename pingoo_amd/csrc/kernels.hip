@@ -189,6 +189,19 @@ __device__ __noinline__ void enqueue_mask(uint32_t *gate_lists, uint32_t *gate_c
         gate_lists[(size_t)g * n + atomicAdd(&gate_count[g], 1u)] = r;
     }
 }
+// ... once per request and gap pass when the pass's enqueue bitmap is given (a list holds n entries; several chunks of one request — or
+// its confirm tier and its walk — may all find a factor).
+__device__ __noinline__ void enqueue_mask_once(uint32_t *gate_lists, uint32_t *gate_count, uint32_t n, uint32_t r, uint32_t need, uint32_t *enq_bits, uint32_t enq_words) {
+    while (need) {
+        const uint32_t g = (uint32_t)__builtin_ctz(need);
+        need &= need - 1;
+        if (enq_bits != nullptr) {
+            const uint32_t bit = 1u << (r & 31u);
+            if (atomicOr(&enq_bits[(size_t)g * enq_words + (r >> 5)], bit) & bit) continue;
+        }
+        gate_lists[(size_t)g * n + atomicAdd(&gate_count[g], 1u)] = r;
+    }
+}
 __device__ __forceinline__ void enqueue_gated(const uint32_t *colmask_local, const PoolEntry *pool, uint32_t *gate_lists, uint32_t *gate_count, uint32_t n,
                                               uint32_t r, Hits h) {
     enqueue_mask(gate_lists, gate_count, n, r, gate_mask(colmask_local, pool, h));
@@ -632,7 +645,7 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
                 if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
                 if (a.need_out != nullptr) a.need_out[li] = need;
                 need &= ~(a.shared_bits | need_init);
-                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+                if (need) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, r, need, a.enq_bits, a.enq_words);
             }
         }
     }
@@ -839,7 +852,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                     if ((h[u].a0 | (h[u].ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h[u]);
                     if (a.need_out != nullptr) a.need_out[li[u]] = need;
                     need &= ~(a.shared_bits | need_init[u]);
-                    if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r[u], need);
+                    if (need) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, r[u], need, a.enq_bits, a.enq_words);
                 }
             }
         }
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
     uint32_t items = 0;
     if (t < b.count) {
         const ConfirmArgs *pa = &b.c[t];
-        items = (min(*pa->n_list, pa->n) + kConfirmThreads - 1) / kConfirmThreads;
+        items = (min(*pa->pair_count, pa->pair_cap) + kConfirmThreads - 1) / kConfirmThreads;
     }
     part[t] = items;
     __syncthreads();
@@ -869,21 +882,33 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
     if (t == 0) plan[b.count] = part[255];
 }
 
-// One lane per candidate-list entry; a persistent grid over device-computed work items (one workgroup's worth of entries of one pass
-// each), like the list scan: consecutive items are mostly of one pass, whose filter table and confirm head table (16 KiB each) are
-// staged in LDS once.
+// A literal atom confirmed for request r, merged into its hit record: several lanes (other flagged chunks of the same request) may be
+// merging at once, so the record is republished with a compare-and-swap (an overflow chain grows like a lock-free stack: the new
+// entry points at the old head before the record names it).
+__device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, uint32_t *status, uint32_t pool_cap, uint32_t *rec, uint32_t atom) {
+    const SlowCtx ctx{nullptr, nullptr, pool, pool_count, status, pool_cap};
+    uint32_t old = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const Hits h = record_atom(ctx, atom, hits_of_record(old));
+        const uint32_t upd = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
+        if (upd == old) return;
+        const uint32_t seen = atomicCAS(rec, old, upd);
+        if (seen == old) return;
+        old = seen;
+    }
+}
+
+// One lane per (request, flagged chunk) pair; a persistent grid over device-computed work items (one workgroup's worth of pairs of
+// one pass each), like the list scan: consecutive items are mostly of one pass, whose tables are staged in LDS once — the filter
+// table and the confirm head table (16 KiB each) and, when they fit kConfirmPoolBytes, the comparison tables (entries, value / mask
+// bytes, classes); a pass whose tables do not fit reads them from the L2-resident originals through the same (generic) pointers.
 //
-// A lane's work is a chain: offsets -> the field's words of the chunk bitmap -> per flagged chunk its text and the filter's automaton
-// over it (confirm_windows: which positions completed a window) -> per such position the head word -> per listed entry the full
-// comparison against the L2-resident byte pool (confirm_entry). Written as nested loops the 64 lanes of a wave take the PRODUCT of
-// each level's longest trip (measured: ~28 comparisons per wave where a lane needs one or two, every one a chain of memory round
-// trips — 0.42 ms for the benign candidates of a 10M-request batch, 5.7 ms for the hostile stream's). So the lane is a small state
-// machine and the wave's loop has two steps: lanes that are out of windows fetch their next flagged chunk, lanes that hold an entry
-// compare it. Every lane takes ITS next comparison per iteration: the wave runs as long as its longest lane, not the product.
-//
-// The comparison's tables — entries, value / mask bytes, classes: a few dozen KiB per pass — are staged in LDS next to the two 16 KiB
-// lookup tables whenever they fit (kConfirmPoolBytes): of a comparison's chain of round trips (entry -> bytes + text -> class) only the
-// request text is then a trip to memory. A pass whose tables do not fit reads them from the L2-resident originals.
+// Why pairs. A request-per-lane version (this round's first) looped over the request's flagged chunks, their completed windows and
+// the windows' entries: 64 lanes in lockstep take the PRODUCT of each level's longest trip, every trip a chain of memory round
+// trips, and a wave is as slow as its unluckiest request — measured 0.32 - 0.64 ms for the ~350k benign candidates of a 10M-request
+// batch and 4 - 13 ms for the hostile stream's 11M (profiles/r4_confirm_v1_*). A pair is one chunk of text and the one or two
+// windows that completed in it: the same small amount of work in every lane, and nothing to do afterwards unless something was
+// confirmed.
 __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __shared__ uint32_t pool[kConfirmPoolBytes / 4];                 // entries | bytes | classes of the pass (when they fit)
@@ -902,7 +927,7 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
         const ConfirmArgs a = load_descriptor(&b.c[ps]);
         __syncthreads();  // (every wave is done with the previous pass's tables)
         {
-            // 16 bytes per lane and load, all of a thread's loads in flight before the first store (two 16 KiB tables)
+            // 16 bytes per lane and load (two 16 KiB tables)
             const uint4 *sh = reinterpret_cast<const uint4 *>(a.c_head), *sf = reinterpret_cast<const uint4 *>(a.ftable);
             constexpr uint32_t kPer = kFilterEntries / 4 / kConfirmThreads;
             uint4 vh[kPer], vf[kPer];
@@ -931,74 +956,59 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
         }
         __syncthreads();
         const ConfirmView cv{nullptr, t_entries, t_bytes, t_classes, a.mul, a.stride, a.init};
-        const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
-        const uint32_t n_l = min(*a.n_list, a.n);
+        const uint32_t n_p = min(*a.pair_count, a.pair_cap);
         for (; it < it_end; it++) {
             const uint32_t li = (it - first_item) * kConfirmThreads + threadIdx.x;
-            const bool live = li < n_l;
-            const uint32_t r = live ? a.req_list[li] : 0u;
+            const bool live = li < n_p;
+            const uint2 pr = live ? a.pairs[li] : make_uint2(0u, 0u);
+            const uint32_t r = pr.x;
             const uint32_t fs = live ? a.off[r] : 0u, fe = live ? a.off[r + 1] : 0u;
-            Hits h{0, 0, kNone};
-            if (live && a.has_heads) h = hits_of_record(a.rec[r]);  // what the filter kernel's head comparisons recorded for this request
+            ConfirmChunk ch{0u, 0ull};
+            if (live) ch = confirm_windows(cv, a.data, fs, fe, pr.y, [&](const uint32_t bin) { return ftab[bin]; });
+            // the completed windows' entries, one comparison per lane and iteration (a lane advances to ITS next entry: the wave runs
+            // as long as its longest lane, not the product of the two loops' longest trips)
+            uint32_t mask = ch.mask, cnt = 0, j = 0, e0 = 0, pos = 0, widx = 0;
+            uint32_t hit0 = kNone, hit1 = kNone;  // literal atoms confirmed in this chunk (a third one is merged on the spot)
+            uint32_t need = 0;                    // the gap passes those atoms call for
             bool walk = false;
-            const bool any_bytes = live && fe >= fs + 2u;
-            const uint32_t c_lo = any_bytes ? (fs >> 4) - a.chunk_base : 1u, c_hi = any_bytes ? ((fe - 1u) >> 4) - a.chunk_base : 0u;
-            // the field's words of the chunk bitmap, three at a time (a field of up to ~1 KiB has at most three)
-            for (uint32_t seg = c_lo >> 5;; seg += 3u) {
-                const bool seg_live = any_bytes && seg <= (c_hi >> 5);
-                if (__ballot(seg_live) == 0) break;
-                auto bitmap_word = [&](const uint32_t w) -> uint32_t {
-                    if (!seg_live || w > (c_hi >> 5)) return 0u;
-                    uint32_t bits = a.chunk_bits[w];
-                    if (w == (c_lo >> 5)) bits &= ~0u << (c_lo & 31u);
-                    if (w == (c_hi >> 5)) bits &= ~0u >> (31u - (c_hi & 31u));
-                    return bits;
-                };
-                uint32_t bw0 = bitmap_word(seg), bw1 = bitmap_word(seg + 1u), bw2 = bitmap_word(seg + 2u);
-                uint32_t mask = 0, cnt = 0, j = 0, e0 = 0, pos = 0, cbase = 0, widx = 0;
-                ConfirmChunk ch{0u, 0ull};
-                for (;;) {
-                    if (__ballot(j < cnt || mask != 0u || (bw0 | bw1 | bw2) != 0u) == 0) break;
-                    // step 1: a lane that is out of windows takes its next flagged chunk (text loads + the filter's automaton over it)
-                    if (j >= cnt && mask == 0u && (bw0 | bw1 | bw2) != 0u) {
-                        uint32_t rel;
-                        if (bw0) { rel = (uint32_t)__builtin_ctz(bw0); bw0 &= bw0 - 1u; }
-                        else if (bw1) { rel = 32u + (uint32_t)__builtin_ctz(bw1); bw1 &= bw1 - 1u; }
-                        else { rel = 64u + (uint32_t)__builtin_ctz(bw2); bw2 &= bw2 - 1u; }
-                        const uint32_t c = seg * 32u + rel + a.chunk_base;
-                        ch = confirm_windows(cv, a.data, fs, fe, c, [&](const uint32_t bin) { return ftab[bin]; });
-                        mask = ch.mask;
-                        cbase = c * 16u;
-                        widx = 0;
-                    }
-                    // ... and a lane that is out of entries its next window that lists some (LDS only)
-                    while (j >= cnt && mask != 0u) {
-                        const uint32_t k = (uint32_t)__builtin_ctz(mask);
-                        mask &= mask - 1u;
-                        pos = cbase + k;
-                        const uint32_t hd = head[confirm_bin_of(ch, widx++, a.data, pos, a.mul)];
-                        e0 = hd & 0xFFFFFu;
-                        cnt = hd >> 20;
-                        j = 0;
-                    }
-                    // step 2: one comparison per lane that holds an entry
-                    if (j < cnt) {
-                        const uint32_t res = confirm_entry(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
-                        j++;
-                        if (res == 2u) walk = true;
-                        else if (res & 1u) h = record_atom(ctx, res >> 8, h);
+            for (;;) {
+                if (__ballot(j < cnt || mask != 0u) == 0) break;
+                while (j >= cnt && mask != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    pos = pr.y * 16u + k;
+                    const uint32_t hd = head[confirm_bin_of(ch, widx++, a.data, pos, a.mul)];
+                    e0 = hd & 0xFFFFFu;
+                    cnt = hd >> 20;
+                    j = 0;
+                }
+                if (j < cnt) {
+                    const uint32_t res = confirm_entry(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
+                    j++;
+                    if (res == 2u) {
+                        walk = true;
+                    } else if (res & 1u) {
+                        const uint32_t atom = res >> 8;
+                        if (a.colmask_local != nullptr) need |= a.colmask_local[atom];
+                        if (hit0 == kNone || hit0 == atom) hit0 = atom;
+                        else if (hit1 == kNone || hit1 == atom) hit1 = atom;
+                        else merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, atom);
                     }
                 }
             }
-            if (!live) continue;
-            a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-            if (a.walk != nullptr) a.walk[li] = walk ? 1u : 0u;
-            if (a.colmask_local != nullptr) {
-                uint32_t need = 0;
-                if ((h.a0 | (h.ovf + 1u)) != 0) need = gate_mask(a.colmask_local, a.pool, h);
-                if (a.need_out != nullptr) a.need_out[li] = need;
-                need &= ~a.shared_bits;
-                if (need) enqueue_mask(a.gate_lists, a.gate_count, a.n, r, need);
+            // Nothing confirmed (the common case by far): the lane is done and has written nothing.
+            if (hit0 != kNone) {
+                merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit0);
+                if (hit1 != kNone) merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit1);
+                atomicOr(&a.valid_bits[r >> 5], 1u << (r & 31u));
+                if (need) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, r, need, a.enq_bits, a.enq_words);
+            }
+            if (walk && a.walk_list != nullptr) {
+                const uint32_t bit = 1u << (r & 31u);
+                if (!(atomicOr(&a.walk_bits[r >> 5], bit) & bit)) {
+                    a.walk_list[atomicAdd(a.walk_count, 1u)] = r;
+                    atomicOr(&a.valid_bits[r >> 5], bit);
+                }
             }
         }
     }
@@ -1079,7 +1089,8 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     // persistent grid: 2 workgroups of 1024 per CU (76 KiB of LDS each: 32 waves per CU), never more than the items a full batch could produce
-    const uint64_t max_items = (uint64_t)count * ((host[0].n + kConfirmThreads - 1) / kConfirmThreads);
+    uint64_t max_items = 0;
+    for (uint32_t k = 0; k < count; k++) max_items += ((uint64_t)host[k].pair_cap + kConfirmThreads - 1) / kConfirmThreads;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 2u);
     const uint32_t *cplan = plan;
     hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
@@ -1697,6 +1708,41 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             const uint32_t r2 = r + 64;
             s_n = e_n = 0xFFFFFFFFu;
             if (r2 < a.n) { s_n = a.off[r2]; e_n = a.off[r2 + 1]; }
+        }
+        if (a.pairs != nullptr) {
+            // A pass with a confirm tier: no candidate bitmap — the (request, flagged chunk) pairs of the flagged chunks that lie inside
+            // the request's OWN bytes (a window completes inside the factor it belongs to), in this slab. Counted with two rank queries,
+            // placed with a wave prefix sum and ONE atomic per 64 requests, written from the slab's bitmap in LDS.
+            uint32_t cnt_p = 0, x0 = 0, x1 = 0;
+            if (live && e >= s + 2u) {
+                const uint32_t f_lo = s >> 4, f_hi = (e - 1u) >> 4;
+                if (f_hi >= c_first && f_lo < c_first + kChunks) {
+                    x0 = f_lo > c_first ? f_lo - c_first : 0u;
+                    x1 = min(f_hi - c_first, kChunks - 1u);
+                    cnt_p = rank_of(x1 + 1u) - rank_of(x0);
+                }
+            }
+            const uint32_t incl = wave_scan_add(cnt_p), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tot != 0) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(a.pair_count, tot);
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + incl - cnt_p;
+                if (cnt_p != 0) {
+                    for (uint32_t w = x0 >> 5; w <= (x1 >> 5); w++) {
+                        uint32_t bw = bits[w];
+                        if (w == (x0 >> 5)) bw &= ~0u << (x0 & 31u);
+                        if (w == (x1 >> 5)) bw &= ~0u >> (31u - (x1 & 31u));
+                        while (bw) {
+                            const uint32_t c = c_first + w * 32u + (uint32_t)__builtin_ctz(bw);
+                            bw &= bw - 1u;
+                            if (at < a.pair_cap) a.pairs[at] = make_uint2(r, c);
+                            at++;
+                        }
+                    }
+                }
+            }
+            if (__ballot(live && (uint64_t)s >= b1 + 16) != 0) break;  // (offsets ascend: nothing further overlaps)
+            continue;
         }
         bool mark = false;
         if (live && (uint64_t)s < b1 + 16) {
