@@ -37,9 +37,14 @@ PWAF_HD uint32_t confirm_load32(const uint8_t *p) {  // request TEXT: an arena i
     return v;
 #endif
 }
-PWAF_HD uint32_t confirm_table32(const uint8_t *p) {  // the tier's TABLES (4-byte aligned): global memory, or the kernel's LDS copy (a generic pointer)
+// The tier's TABLES (4-byte aligned words). SPACE says where they live for the device: 1 = global memory, 3 = the kernel's LDS copy (the
+// generic pointer's low half is the LDS address: a ds_read instead of the FLAT load a generic pointer gets — a FLAT load that hits LDS
+// still takes the texture path's latency); the host ignores it.
+template <int SPACE>
+PWAF_HD uint32_t confirm_table32(const uint8_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return *reinterpret_cast<const uint32_t *>(p);
+    if (SPACE == 3) return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)(uintptr_t)p);
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((uintptr_t)p);
 #else
     uint32_t v;
     memcpy(&v, p, 4);
@@ -49,9 +54,9 @@ PWAF_HD uint32_t confirm_table32(const uint8_t *p) {  // the tier's TABLES (4-by
 
 // One entry against the text: does the factor occur with its window's last bigram at arena position i, inside the field [fs, fe)?
 // 0 = no, 1 | atom << 8 = yes and it decides that literal atom, 2 = yes and it is a factor of a non-literal atom (walk).
-// OUT OF LINE on the device: the caller's loop over a chunk's positions stays a few dozen instructions (the first version inlined this
-// — and the hit record's overflow path — into a 16-fold unrolled loop: 8 400 instructions, ~50 KiB of code that no instruction cache
-// holds next to seven other workgroups' — measured 0.5 ms per WORK ITEM, 11.8 ms for the hostile stream's candidates).
+// Out of line on the device (the kernel's per-lane loop stays a few dozen instructions). The chain of dependent accesses is what a
+// comparison costs, so it is kept short: the entry's three words together, then per 4 bytes of the factor value, mask and text together.
+template <int SPACE>
 #if defined(__HIPCC__)
 __host__ __device__
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -61,28 +66,30 @@ __attribute__((noinline))
 inline uint32_t
     confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
                   const uint32_t i) {
-    const ConfirmEntry e = entries[index];
-    const uint32_t len = e.len, d = e.d;
+    const uint8_t *ep = reinterpret_cast<const uint8_t *>(entries) + (size_t)index * sizeof(ConfirmEntry);
+    const uint32_t e_off = confirm_table32<SPACE>(ep), e_ld = confirm_table32<SPACE>(ep + 4), e_af = confirm_table32<SPACE>(ep + 8);
+    const uint32_t len = e_ld & 0xFFFFu, d = e_ld >> 16, atom = e_af & 0xFFFFu, flags = (e_af >> 16) & 0xFFu, n_cls = e_af >> 24;
     if (i < fs + d) return 0;
     const uint32_t q = i - d;
     if (q + len > fe) return 0;
-    if ((e.flags & kConfirmAtStart) && q != fs) return 0;
-    if ((e.flags & kConfirmAtEnd) && q + len != fe) return 0;
+    if ((flags & kConfirmAtStart) && q != fs) return 0;
+    if ((flags & kConfirmAtEnd) && q + len != fe) return 0;
     const uint32_t l4 = (len + 3u) & ~3u;
-    const uint8_t *val = bytes + e.bytes_off, *msk = val + l4;
+    const uint8_t *val = bytes + e_off, *msk = val + l4;
     for (uint32_t w = 0; w < l4; w += 4)  // (reads up to 3 bytes past the factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero)
-        if ((confirm_load32(data + q + w) ^ confirm_table32(val + w)) & confirm_table32(msk + w)) return 0;
+        if ((confirm_load32(data + q + w) ^ confirm_table32<SPACE>(val + w)) & confirm_table32<SPACE>(msk + w)) return 0;
     const uint8_t *cls = msk + l4;
-    for (uint32_t k = 0; k < e.n_cls; k += 2) {
-        const uint32_t pc = confirm_table32(cls + 2u * k);  // two {position, class id} pairs (the pool is padded to whole dwords)
+    const uint8_t *cw = reinterpret_cast<const uint8_t *>(classes);
+    for (uint32_t k = 0; k < n_cls; k += 2) {
+        const uint32_t pc = confirm_table32<SPACE>(cls + 2u * k);  // two {position, class id} pairs (the pool is padded to whole dwords)
         const uint32_t t = confirm_load32(data + q + (pc & 0xFFu)) & 0xFFu;
-        if (!((classes[((pc >> 8) & 0xFFu) * 8u + (t >> 5)] >> (t & 31u)) & 1u)) return 0;
-        if (k + 1u < e.n_cls) {
+        if (!((confirm_table32<SPACE>(cw + 4u * (((pc >> 8) & 0xFFu) * 8u + (t >> 5))) >> (t & 31u)) & 1u)) return 0;
+        if (k + 1u < n_cls) {
             const uint32_t t2 = confirm_load32(data + q + ((pc >> 16) & 0xFFu)) & 0xFFu;
-            if (!((classes[(pc >> 24) * 8u + (t2 >> 5)] >> (t2 & 31u)) & 1u)) return 0;
+            if (!((confirm_table32<SPACE>(cw + 4u * ((pc >> 24) * 8u + (t2 >> 5))) >> (t2 & 31u)) & 1u)) return 0;
         }
     }
-    return e.atom == kConfirmWalk ? 2u : (1u | ((uint32_t)e.atom << 8));
+    return atom == kConfirmWalk ? 2u : (1u | (atom << 8));
 }
 
 // A flagged 16-byte arena chunk as the confirm tier sees it: the positions where a window of the pass's filter really COMPLETED inside
@@ -154,7 +161,7 @@ PWAF_HD bool confirm_chunk(const ConfirmView &cv, const uint8_t *data, const uin
         if (hd == 0u) continue;
         const uint32_t first = hd & 0xFFFFFu, cnt = hd >> 20;
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t res = confirm_entry(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, c * 16u + k);
+            const uint32_t res = confirm_entry<1>(cv.entries, cv.bytes, cv.classes, first + j, data, fs, fe, c * 16u + k);
             if (res == 2u) walk = true;
             else if (res & 1u) hit(res >> 8);
         }

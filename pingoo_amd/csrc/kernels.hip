@@ -567,8 +567,8 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
         }
         if (slow) hh = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, hh);
     };
-    for (; it < it_end; it++) {
-        const uint32_t li = (it - first) * THREADS + threadIdx.x;
+    for (it += wave_index(); it < it_end; it += THREADS / 64u) {  // (work items are one wave's worth of entries: this wave's)
+        const uint32_t li = (it - first) * 64u + (threadIdx.x & 63u);
         bool live = li < n_l;
         if (live && a.need_in != nullptr) live = ((a.need_in[li] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
         const uint32_t r = live ? (a.req_list != nullptr ? a.req_list[li] : li) : 0u;
@@ -714,7 +714,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
         }
         const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
         const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
-        for (; it < it_end; it++) {
+        // A work item is ONE WAVE's worth of list entries (round 4; it used to be a workgroup's: a short list — the few requests whose
+        // regex factor the confirm tier found, a gap pass's requests — then sat in a handful of full waves on a handful of CUs, every
+        // wave as slow as the unluckiest of its 64 walks, while the rest of the chip idled: 0.07 -> 0.6 ms when the lists became dense).
+        for (uint32_t iw = it + wave_index(); iw < it_end; iw += THREADS / 64u) {
             // kListWalks listed requests per lane, walked in lockstep. Measured with 2 (round 3), in the hope that a lane's two cold cells
             // travelling to L2 together would help hostile traffic (near misses of the rule literals drive most walks deep into states
             // that are not LDS-resident): adversarial filtered passes 3.87 -> 3.41 ms, but benign 0.143 -> 0.204 ms and the gap
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
             u32x4 w[kListWalks];
 #pragma unroll
             for (uint32_t u = 0; u < kListWalks; u++) {
-                li[u] = ((it - first) * kListWalks + u) * THREADS + threadIdx.x;
+                li[u] = ((iw - first) * kListWalks + u) * 64u + (threadIdx.x & 63u);
                 live[u] = li[u] < n_l;
                 if (live[u] && a.need_in != nullptr) live[u] = ((a.need_in[li[u]] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
                 r[u] = live[u] ? (a.req_list != nullptr ? a.req_list[li[u]] : li[u]) : 0u;
@@ -856,6 +859,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                 }
             }
         }
+        it = it_end;
     }
 }
 
@@ -889,9 +893,11 @@ __device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, u
     const SlowCtx ctx{nullptr, nullptr, pool, pool_count, status, pool_cap};
     uint32_t old = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
+        __threadfence();  // (acquire: a chain this record names was written by another lane — possibly on another XCD — before it published the head)
         const Hits h = record_atom(ctx, atom, hits_of_record(old));
         const uint32_t upd = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
         if (upd == old) return;
+        __threadfence();  // (release: the pool entries pushed above are visible before the record that names them)
         const uint32_t seen = atomicCAS(rec, old, upd);
         if (seen == old) return;
         old = seen;
@@ -983,7 +989,8 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
                     j = 0;
                 }
                 if (j < cnt) {
-                    const uint32_t res = confirm_entry(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
+                    const uint32_t res = in_lds ? confirm_entry<3>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos)
+                                                : confirm_entry<1>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
                     j++;
                     if (res == 2u) {
                         walk = true;
@@ -1112,12 +1119,12 @@ int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanAr
     static const uint32_t async_mode = getenv("PWAF_LSCAN_ASYNC") ? (uint32_t)atoi(getenv("PWAF_LSCAN_ASYNC")) : 0u;
     b.debug = async_mode;
 #endif
-    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, shape.threads * kListWalks);
+    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, 64u * kListWalks);  // (a work item = one wave's worth of entries)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     // persistent grid: what the chip holds at this LDS size (the work items are split evenly over it), never more than the items
     // a full batch could produce
-    const uint64_t max_items = (uint64_t)count * ((host[0].n + shape.threads * kListWalks - 1) / (shape.threads * kListWalks));
+    const uint64_t max_items = (uint64_t)count * ((host[0].n + 64u * kListWalks - 1) / (64u * kListWalks));
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, host[0].n_cus) * shape.wg_per_cu);
     const uint32_t *cplan = plan;
     uint32_t hot_bytes = list_hot_bytes(shape);
@@ -1694,6 +1701,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         hi = nh;
     }
     const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
+    // A pass with a confirm tier walks its requests TWICE: once to count the slab's pairs — ONE atomic per slab then reserves their
+    // place in the pass's pair list (an atomic per 64 requests, 115k returned same-address atomics per pass and batch, took 2.8 ms) —
+    // and once to write them (the second walk's offsets come from L2).
+    uint32_t pair_total = 0, pair_at = 0;  // wave-uniform
+    for (uint32_t phase = a.pairs != nullptr ? 0u : 1u; phase < 2u; phase++) {
+    if (phase == 1u && a.pairs != nullptr) {
+        if (pair_total == 0) return;
+        uint32_t at0 = 0;
+        if (lane == 0) at0 = atomicAdd(a.pair_count, pair_total);
+        pair_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+    }
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
     uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
     {
@@ -1723,10 +1741,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
                 }
             }
             const uint32_t incl = wave_scan_add(cnt_p), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (tot != 0) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(a.pair_count, tot);
-                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + incl - cnt_p;
+            if (phase == 0u) {
+                pair_total += tot;
+            } else if (tot != 0) {
+                uint32_t at = pair_at + incl - cnt_p;
+                pair_at += tot;
                 if (cnt_p != 0) {
                     for (uint32_t w = x0 >> 5; w <= (x1 >> 5); w++) {
                         uint32_t bw = bits[w];
@@ -1763,6 +1782,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         }
         if (__ballot(live && (uint64_t)s >= b1 + 16) != 0) break;  // (offsets ascend: nothing further overlaps)
     }
+    }  // phases
 }
 
 // compact_kernel: a workgroup turns kCompactWords bitmap words into its part of the ascending request list. Each wave owns 512
