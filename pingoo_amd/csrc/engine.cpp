@@ -1225,7 +1225,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 la[phase].push_back(list_args(gi, lshapes[phase]));
             }
         const size_t n_desc = la[0].size() + la[1].size();
-        if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (n_desc + 2) * 4))) return rc;
+        if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (2 * n_desc + 4) * 4))) return rc;
         ListScanArgs *d_at = (ListScanArgs *)S.args_list.p;
         uint32_t *plan_at = (uint32_t *)((char *)S.args_list.p + (n_desc + 1) * sizeof(ListScanArgs));  // work-item prefix sums, one set per phase
         for (int phase = 0; phase < 2; phase++) {
@@ -1235,7 +1235,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc = mark(nullptr, 0))) return rc;
             he = launch_scan_gated(la[phase].data(), cnt, d_at, plan_at, lshapes[phase], stream);
-            plan_at += cnt + 1;
+            plan_at += 2 * cnt + 1;  // (prefix sums, then the entries per work item of every pass)
             if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             char nm[48];
             snprintf(nm, sizeof nm, "lscan_x%u", cnt);

@@ -501,14 +501,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 // [total * b / G, total * (b + 1) / G) — consecutive items are mostly of one pass, whose hot rows are staged once. (Round 2 launched
 // ceil(n / 512) x passes workgroups, nearly all of which found their list exhausted: 53k launches-and-exits for the 69 filtered
 // passes of the 4096-rule set.)
-__global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t *plan /* [count + 1] */, uint32_t threads) {
+// A work item is one WAVE's share of a list: `epi` entries (a power of two up to 64, per pass: plan[count + 1 + pass]). A long list
+// packs 64 walks into a wave; a SHORT one — the few requests whose regex factor the confirm tier found, a gap pass's requests — is
+// spread one or a few walks per wave over the waves the launch has: the 64 walks of a wave advance in lockstep and every emit or cold
+// cell of one lane sends the whole wave through the slow path of its group of steps, so a wave of 64 true hits (what a dense walk list
+// is made of) crawls while the rest of the chip idles (measured: 0.07 -> 0.5 ms for ~10k walks when the lists became dense).
+__global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t *plan /* [2 count + 1] */, uint32_t n_waves) {
     __shared__ uint32_t part[256];
     const uint32_t t = threadIdx.x;
     uint32_t items = 0;
     if (t < b.count) {
         const ListScanArgs *pa = &b.g[t];
         const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
-        items = (n_l + threads - 1) / threads;  // (`threads` = entries per work item: the workgroup's lanes x kListWalks)
+        uint32_t epi = 1;
+        while (epi < 64u * kListWalks && (n_l + epi - 1) / epi > n_waves) epi <<= 1;
+        items = (n_l + epi - 1) / epi;
+        plan[b.count + 1 + t] = epi;
     }
     part[t] = items;
     __syncthreads();
@@ -550,7 +558,7 @@ __device__ __forceinline__ uint32_t list_step_slow(const uint16_t *hot, const PW
 // group, cold cells from L2, while the others wait: a round trip then serves thirty lanes instead of one.
 template <uint32_t THREADS>
 __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_t *hot, const unsigned char *cls, const uint64_t *delta, uint32_t it, const uint32_t it_end,
-                                            const uint32_t first, const uint32_t n_l, const uint32_t hot_elems) {
+                                            const uint32_t first, const uint32_t n_l, const uint32_t hot_elems, const uint32_t epi) {
     const uint32_t ncls = a.n_classes, stride = ncls + 3u;
     const PWAF_GLOBAL unsigned char *gdata = (const PWAF_GLOBAL unsigned char *)a.data;
     const PWAF_GLOBAL uint16_t *flat = (const PWAF_GLOBAL uint16_t *)a.flat;
@@ -567,9 +575,9 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
         }
         if (slow) hh = emit_list(a.emit_off, a.emit_list, a.pool, a.pool_count, a.status, a.pool_cap, st, hh);
     };
-    for (it += wave_index(); it < it_end; it += THREADS / 64u) {  // (work items are one wave's worth of entries: this wave's)
-        const uint32_t li = (it - first) * 64u + (threadIdx.x & 63u);
-        bool live = li < n_l;
+    for (it += wave_index(); it < it_end; it += THREADS / 64u) {  // (work items are one wave's share of the list: this wave's)
+        const uint32_t li = (it - first) * epi + (threadIdx.x & 63u);
+        bool live = (threadIdx.x & 63u) < epi && li < n_l;
         if (live && a.need_in != nullptr) live = ((a.need_in[li] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
         const uint32_t r = live ? (a.req_list != nullptr ? a.req_list[li] : li) : 0u;
         if (live && a.visited != nullptr) atomicOr(&a.visited[r >> 5], 1u << (r & 31u));
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
             else hi = mid;
             ps = lo;
         }
-        const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]);
+        const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]), epi = plan[b.count + 1 + ps];
         const ListScanArgs a = load_descriptor(&b.g[ps]);
         const uint32_t ncls = a.n_classes, stride = ncls + 3u;  // row: ncls transitions, the EMIT cell, the STAY cell, the END cell
         const uint32_t hot_elems = a.n_hot * stride;
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
         const bool long_list = a.behind_filter != 0u && (uint64_t)n_l * 8u >= a.n;
 #endif
         if (long_list) {  // (uniform) a prefilter's candidate list that holds more than an eighth of the batch: lscan_async
-            lscan_async<THREADS>(a, hot, cls, delta_lds, it, it_end, first, n_l, hot_elems);
+            lscan_async<THREADS>(a, hot, cls, delta_lds, it, it_end, first, n_l, hot_elems, epi);
             it = it_end;
             continue;
         }
@@ -730,8 +738,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
             u32x4 w[kListWalks];
 #pragma unroll
             for (uint32_t u = 0; u < kListWalks; u++) {
-                li[u] = ((iw - first) * kListWalks + u) * 64u + (threadIdx.x & 63u);
-                live[u] = li[u] < n_l;
+                li[u] = (iw - first) * epi + u * 64u + (threadIdx.x & 63u);
+                live[u] = (threadIdx.x & 63u) + u * 64u < epi && li[u] < n_l;
                 if (live[u] && a.need_in != nullptr) live[u] = ((a.need_in[li[u]] >> a.need_bit) & 1u) != 0;  // (a sharing gap pass: none of its factors fired here)
                 r[u] = live[u] ? (a.req_list != nullptr ? a.req_list[li[u]] : li[u]) : 0u;
             }
@@ -886,18 +894,44 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
     if (t == 0) plan[b.count] = part[255];
 }
 
-// A literal atom confirmed for request r, merged into its hit record: several lanes (other flagged chunks of the same request) may be
-// merging at once, so the record is republished with a compare-and-swap (an overflow chain grows like a lock-free stack: the new
-// entry points at the old head before the record names it).
+// A literal atom confirmed for request r, merged into its hit record. Several lanes — other flagged chunks of the same request, in other
+// workgroups on other XCDs — may be merging at once, so every access to the shared words is a read-modify-write atomic (performed at
+// the device's coherence point; a returned atomic has completed when its value arrives, which orders an overflow entry's words before
+// the compare-and-swap that publishes it): no fences — an agent-scope fence writes back and invalidates the whole L2, and two per hit
+// took this kernel from 0.3 to 1.5 ms and its neighbours with it. An overflow chain grows like a lock-free stack (entries allocated for
+// an attempt that lost its compare-and-swap are leaked: rare, and the pool is sized per batch).
 __device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, uint32_t *status, uint32_t pool_cap, uint32_t *rec, uint32_t atom) {
-    const SlowCtx ctx{nullptr, nullptr, pool, pool_count, status, pool_cap};
-    uint32_t old = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto rmw_read = [](uint32_t *p) { return atomicOr(p, 0u); };
+    auto publish = [&](uint32_t idx, uint32_t at, uint32_t next) {
+        const uint32_t t0 = atomicExch(&pool[idx].atom, at), t1 = atomicExch(&pool[idx].next, next);
+        asm volatile("" ::"v"(t0), "v"(t1));  // (both have been performed before anything below is issued)
+    };
+    uint32_t old = rmw_read(rec);
     for (;;) {
-        __threadfence();  // (acquire: a chain this record names was written by another lane — possibly on another XCD — before it published the head)
-        const Hits h = record_atom(ctx, atom, hits_of_record(old));
-        const uint32_t upd = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-        if (upd == old) return;
-        __threadfence();  // (release: the pool entries pushed above are visible before the record that names them)
+        uint32_t upd;
+        const uint32_t x = atom + 1u;
+        if (!(old & REC_OVERFLOW)) {
+            const uint32_t a0 = old & 0x7FFFu, a1 = (old >> 15) & 0x7FFFu;
+            if (a0 == x || a1 == x) return;
+            if (a0 == 0u) upd = old | x;
+            else if (a1 == 0u) upd = old | (x << 15);
+            else {  // a third atom: the record becomes a chain of all three
+                const uint32_t idx = atomicAdd(pool_count, 3u);
+                if (idx + 3u > pool_cap) { atomicOr(status, 1u); return; }  // (the host runs the batch again with the pool the allocator asked for)
+                publish(idx, a0 - 1u, kNone);
+                publish(idx + 1u, a1 - 1u, idx);
+                publish(idx + 2u, atom, idx + 1u);
+                upd = REC_OVERFLOW | (idx + 2u);
+            }
+        } else {
+            const uint32_t head = old & ~REC_OVERFLOW;
+            for (uint32_t i = head; i != kNone; i = rmw_read(&pool[i].next))
+                if (rmw_read(&pool[i].atom) == atom) return;
+            const uint32_t idx = atomicAdd(pool_count, 1u);
+            if (idx >= pool_cap) { atomicOr(status, 1u); return; }
+            publish(idx, atom, head);
+            upd = REC_OVERFLOW | idx;
+        }
         const uint32_t seen = atomicCAS(rec, old, upd);
         if (seen == old) return;
         old = seen;
@@ -1119,13 +1153,11 @@ int launch_scan_gated(const ListScanArgs *host, uint32_t count, const ListScanAr
     static const uint32_t async_mode = getenv("PWAF_LSCAN_ASYNC") ? (uint32_t)atoi(getenv("PWAF_LSCAN_ASYNC")) : 0u;
     b.debug = async_mode;
 #endif
-    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, 64u * kListWalks);  // (a work item = one wave's worth of entries)
+    // persistent grid: what the chip holds at this LDS size (the work items are split evenly over it)
+    const uint32_t blocks = std::max(1u, host[0].n_cus) * shape.wg_per_cu;
+    hipLaunchKernelGGL(lscan_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan, blocks * (shape.threads / 64u));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // persistent grid: what the chip holds at this LDS size (the work items are split evenly over it), never more than the items
-    // a full batch could produce
-    const uint64_t max_items = (uint64_t)count * ((host[0].n + 64u * kListWalks - 1) / (64u * kListWalks));
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, host[0].n_cus) * shape.wg_per_cu);
     const uint32_t *cplan = plan;
     uint32_t hot_bytes = list_hot_bytes(shape);
     void *args[] = {&b, &cplan, &hot_bytes};
