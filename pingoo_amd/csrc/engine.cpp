@@ -594,7 +594,9 @@ int assign_lists(pwaf_engine *e) {
             if (o < 0 || (owner >= 0 && o != owner)) single = false;
             owner = o;
         }
-        if (!single || owner < 0 || !e->groups[owner].filtered || e->groups[owner].confirm) continue;  // (an owner with a confirm tier has no candidate list to share: it enqueues)
+        // (an owner with a confirm tier shares its WALK list — a literal hit that calls for a sharing gap pass sends the request through the
+        // walk — unless it never walks: then it enqueues)
+        if (!single || owner < 0 || !e->groups[owner].filtered || (e->groups[owner].confirm && !e->groups[owner].confirm_walk)) continue;
         d.share_owner = owner;
         e->groups[owner].shared_bits |= 1u << d.gate;
         if (e->groups[owner].need_slot < 0) e->groups[owner].need_slot = (int)e->n_need++;
@@ -1193,6 +1195,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 c.gate_count = (uint32_t *)S.ctrl.p + 2;
                 c.enq_bits = (uint32_t *)S.visit_bits.p;
                 c.enq_words = bit_words;
+                c.shared_bits = d.shared_bits;
             }
             call.push_back(c);
         }
@@ -1313,6 +1316,23 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     int he = launch_verdict(v, stream);
     if (he) return fail(PWAF_E_DEVICE, std::string("verdict kernel launch failed: ") + hipGetErrorString((hipError_t)he));
     if ((rc = mark("verdict", 0xFFu))) return rc;
+#ifdef PWAF_PROFILING
+    {
+        static const bool dump_counts = getenv("PWAF_DUMP_COUNTS") != nullptr;  // debugging aid: the device-side list lengths of this batch
+        if (dump_counts) {
+            std::vector<uint32_t> cw(ctrl_words);
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(cw.data(), S.ctrl.p, 4 * ctrl_words, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pwaf] n %u pool %u status %u |", n, cw[0], cw[1]);
+            for (size_t k = 0; k < e->groups.size(); k++) {
+                const DevGroup &d = e->groups[k];
+                if (d.gate >= 0) fprintf(stderr, " pass %zu field %u %s list %u", k, d.field, d.filtered ? (d.confirm ? "confirm" : "filtered") : "gap", cw[2 + (size_t)d.gate]);
+            }
+            for (uint32_t k = 0; k < e->n_filtered; k++) fprintf(stderr, " pairs[%u] %u", k, cw[2 + n_slots + k]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     e->n_timed = ev_i;
     return PWAF_OK;
 }

@@ -952,6 +952,7 @@ __device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, u
 __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __shared__ uint32_t pool[kConfirmPoolBytes / 4];                 // entries | bytes | classes of the pass (when they fit)
+    __shared__ uint32_t app_cnt, app_base;                           // the workgroup's walk-list appends of one work item
     __builtin_amdgcn_s_setprio(3);
     const uint32_t total = plan[b.count];
     const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
@@ -1042,15 +1043,28 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
                 merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit0);
                 if (hit1 != kNone) merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit1);
                 atomicOr(&a.valid_bits[r >> 5], 1u << (r & 31u));
+                // gap passes that SHARE this pass's walk list learn of the request through the walk (its epilogue writes the need mask
+                // of the list entry: no atomics); the others are enqueued here
+                if (need & a.shared_bits) walk = true;
+                need &= ~a.shared_bits;
                 if (need) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, r, need, a.enq_bits, a.enq_words);
             }
+            // The walk list: a request is appended once (walk_bits), and the workgroup's appends of this item share ONE atomic on the
+            // list's length (a returned same-address atomic per request is what DESIGN.md 4.1 measured at 0.5 ms per batch).
+            bool append = false;
             if (walk && a.walk_list != nullptr) {
                 const uint32_t bit = 1u << (r & 31u);
-                if (!(atomicOr(&a.walk_bits[r >> 5], bit) & bit)) {
-                    a.walk_list[atomicAdd(a.walk_count, 1u)] = r;
-                    atomicOr(&a.valid_bits[r >> 5], bit);
-                }
+                append = !(atomicOr(&a.walk_bits[r >> 5], bit) & bit);
+                if (append) atomicOr(&a.valid_bits[r >> 5], bit);
             }
+            if (threadIdx.x == 0) app_cnt = 0;
+            __syncthreads();
+            uint32_t slot = 0;
+            if (append) slot = atomicAdd(&app_cnt, 1u);
+            __syncthreads();
+            if (threadIdx.x == 0 && app_cnt != 0) app_base = atomicAdd(a.walk_count, app_cnt);
+            __syncthreads();
+            if (append) a.walk_list[app_base + slot] = r;
         }
     }
 }
