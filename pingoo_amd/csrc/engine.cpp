@@ -1147,7 +1147,9 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if ((rc = launch_attr_side())) return rc;
         if ((rc = mark(nullptr, 0))) return rc;
         he = launch_resolve(fall.data(), nf, d_all, stream);
-        if (!he) he = launch_compact(fall.data(), nf, d_all, stream);
+        bool any_list = false;  // (a pass with a confirm tier has no candidate bitmap to turn into a list: its flagged chunks are the work list)
+        for (const DevGroup &d : e->groups) any_list = any_list || (d.filtered && !d.confirm);
+        if (!he && any_list) he = launch_compact(fall.data(), nf, d_all, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark("resolve+compact", 0xFCu))) return rc;
         // ---- 2b. confirm tier: what the flagged chunks of every candidate really hold (literal atoms decided; walk flags) ----

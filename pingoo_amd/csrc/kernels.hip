@@ -1002,23 +1002,48 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
             const uint32_t li = (it - first_item) * kConfirmThreads + threadIdx.x;
             const bool live = li < n_p;
             const uint2 pr = live ? a.pairs[li] : make_uint2(0u, 0u);
-            const uint32_t r = pr.x;
-            const uint32_t fs = live ? a.off[r] : 0u, fe = live ? a.off[r + 1] : 0u;
+            uint32_t r = pr.x;  // the request that owns the chunk's first byte; a chunk that holds a field boundary also speaks for the next one(s)
+            uint32_t fs = live ? a.off[r] : 0u, fe = live ? a.off[r + 1] : 0u;
             ConfirmChunk ch{0u, 0ull};
-            if (live) ch = confirm_windows(cv, a.data, fs, fe, pr.y, [&](const uint32_t bin) { return ftab[bin]; });
+            if (live) ch = confirm_windows(cv, a.data, 0u, 0xFFFFFFFFu, pr.y, [&](const uint32_t bin) { return ftab[bin]; });  // (every window of the chunk: whose field it lies in is settled below)
             // the completed windows' entries, one comparison per lane and iteration (a lane advances to ITS next entry: the wave runs
             // as long as its longest lane, not the product of the two loops' longest trips)
             uint32_t mask = ch.mask, cnt = 0, j = 0, e0 = 0, pos = 0, widx = 0;
-            uint32_t hit0 = kNone, hit1 = kNone;  // literal atoms confirmed in this chunk (a third one is merged on the spot)
-            uint32_t need = 0;                    // the gap passes those atoms call for
-            bool walk = false;
+            bool walk = false;  // of request r (the one the lane is at)
+            auto settle = [&](const uint32_t rq, const uint32_t need_lits, const bool wk, const bool aggregated) -> bool {
+                // what the comparisons found for request rq: gap passes its literal hits call for, the walk list. Returns "append rq to
+                // the walk list through the workgroup's aggregated atomic" (the lane's LAST request); an earlier request of the same
+                // chunk (rare: the chunk holds a field boundary) is appended directly.
+                bool w2 = wk;
+                if (need_lits & a.shared_bits) w2 = true;  // a gap pass that shares the walk list learns of the request through the walk
+                const uint32_t direct = need_lits & ~a.shared_bits;
+                if (direct) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, rq, direct, a.enq_bits, a.enq_words);
+                if (!w2 || a.walk_list == nullptr) return false;
+                const uint32_t bit = 1u << (rq & 31u);
+                if (atomicOr(&a.walk_bits[rq >> 5], bit) & bit) return false;  // already listed
+                atomicOr(&a.valid_bits[rq >> 5], bit);
+                if (aggregated) return true;
+                a.walk_list[atomicAdd(a.walk_count, 1u)] = rq;
+                return false;
+            };
+            uint32_t need = 0;  // gap passes the literal hits of request r call for
             for (;;) {
                 if (__ballot(j < cnt || mask != 0u) == 0) break;
                 while (j >= cnt && mask != 0u) {
                     const uint32_t k = (uint32_t)__builtin_ctz(mask);
                     mask &= mask - 1u;
                     pos = pr.y * 16u + k;
-                    const uint32_t hd = head[confirm_bin_of(ch, widx++, a.data, pos, a.mul)];
+                    const uint32_t bin = confirm_bin_of(ch, widx++, a.data, pos, a.mul);
+                    while (pos >= fe && r + 1u < a.n) {  // the window lies in a later field of the chunk
+                        settle(r, need, walk, false);
+                        need = 0;
+                        walk = false;
+                        r++;
+                        fs = fe;
+                        fe = a.off[r + 1];
+                    }
+                    if (pos + 1u >= fe) continue;  // the bigram crosses the field's end (or lies in the arena's slack)
+                    const uint32_t hd = head[bin];
                     e0 = hd & 0xFFFFFu;
                     cnt = hd >> 20;
                     j = 0;
@@ -1031,32 +1056,16 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
                         walk = true;
                     } else if (res & 1u) {
                         const uint32_t atom = res >> 8;
+                        merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, atom);
+                        atomicOr(&a.valid_bits[r >> 5], 1u << (r & 31u));
                         if (a.colmask_local != nullptr) need |= a.colmask_local[atom];
-                        if (hit0 == kNone || hit0 == atom) hit0 = atom;
-                        else if (hit1 == kNone || hit1 == atom) hit1 = atom;
-                        else merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, atom);
                     }
                 }
             }
             // Nothing confirmed (the common case by far): the lane is done and has written nothing.
-            if (hit0 != kNone) {
-                merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit0);
-                if (hit1 != kNone) merge_atom(a.pool, a.pool_count, a.status, a.pool_cap, a.rec + r, hit1);
-                atomicOr(&a.valid_bits[r >> 5], 1u << (r & 31u));
-                // gap passes that SHARE this pass's walk list learn of the request through the walk (its epilogue writes the need mask
-                // of the list entry: no atomics); the others are enqueued here
-                if (need & a.shared_bits) walk = true;
-                need &= ~a.shared_bits;
-                if (need) enqueue_mask_once(a.gate_lists, a.gate_count, a.n, r, need, a.enq_bits, a.enq_words);
-            }
-            // The walk list: a request is appended once (walk_bits), and the workgroup's appends of this item share ONE atomic on the
-            // list's length (a returned same-address atomic per request is what DESIGN.md 4.1 measured at 0.5 ms per batch).
-            bool append = false;
-            if (walk && a.walk_list != nullptr) {
-                const uint32_t bit = 1u << (r & 31u);
-                append = !(atomicOr(&a.walk_bits[r >> 5], bit) & bit);
-                if (append) atomicOr(&a.valid_bits[r >> 5], bit);
-            }
+            const bool append = live && settle(r, need, walk, true);
+            // The walk list: the workgroup's appends of this item share ONE atomic on the list's length (a returned same-address atomic
+            // per request is what DESIGN.md 4.1 measured at 0.5 ms per batch).
             if (threadIdx.x == 0) app_cnt = 0;
             __syncthreads();
             uint32_t slot = 0;
@@ -1747,17 +1756,16 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         hi = nh;
     }
     const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
-    // A pass with a confirm tier walks its requests TWICE: once to count the slab's pairs — ONE atomic per slab then reserves their
-    // place in the pass's pair list (an atomic per 64 requests, 115k returned same-address atomics per pass and batch, took 2.8 ms) —
-    // and once to write them (the second walk's offsets come from L2).
-    uint32_t pair_total = 0, pair_at = 0;  // wave-uniform
-    for (uint32_t phase = a.pairs != nullptr ? 0u : 1u; phase < 2u; phase++) {
-    if (phase == 1u && a.pairs != nullptr) {
-        if (pair_total == 0) return;
-        uint32_t at0 = 0;
-        if (lane == 0) at0 = atomicAdd(a.pair_count, pair_total);
-        pair_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+    // A pass with a confirm tier lists its flagged chunks instead of marking candidates: every flagged chunk of the slab becomes ONE pair
+    // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — its
+    // length is the slab's flag count, which filter_kernel left in sub_count: one atomic per slab — and a chunk's place in it is its rank
+    // among the slab's flagged chunks (the prefix counts above): no scan, no second walk.
+    uint32_t pair_base = 0;
+    if (a.pairs != nullptr) {
+        if (lane == 0) pair_base = atomicAdd(a.pair_count, cnt);
+        pair_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_base);
     }
+    {
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
     uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
     {
@@ -1774,39 +1782,26 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             if (r2 < a.n) { s_n = a.off[r2]; e_n = a.off[r2 + 1]; }
         }
         if (a.pairs != nullptr) {
-            // A pass with a confirm tier: no candidate bitmap — the (request, flagged chunk) pairs of the flagged chunks that lie inside
-            // the request's OWN bytes (a window completes inside the factor it belongs to), in this slab. Counted with two rank queries,
-            // placed with a wave prefix sum and ONE atomic per 64 requests, written from the slab's bitmap in LDS.
-            uint32_t cnt_p = 0, x0 = 0, x1 = 0;
-            if (live && e >= s + 2u) {
-                const uint32_t f_lo = s >> 4, f_hi = (e - 1u) >> 4;
-                if (f_hi >= c_first && f_lo < c_first + kChunks) {
-                    x0 = f_lo > c_first ? f_lo - c_first : 0u;
-                    x1 = min(f_hi - c_first, kChunks - 1u);
-                    cnt_p = rank_of(x1 + 1u) - rank_of(x0);
-                }
-            }
-            const uint32_t incl = wave_scan_add(cnt_p), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (phase == 0u) {
-                pair_total += tot;
-            } else if (tot != 0) {
-                uint32_t at = pair_at + incl - cnt_p;
-                pair_at += tot;
-                if (cnt_p != 0) {
+            // the flagged chunks whose first byte lies in this request (clipped to the slab)
+            if (live && e > s) {
+                const uint32_t f_lo = (s + 15u) >> 4, f_hi = (e - 1u) >> 4;
+                if (f_lo <= f_hi && f_hi >= c_first && f_lo < c_first + kChunks) {
+                    const uint32_t x0 = f_lo > c_first ? f_lo - c_first : 0u, x1 = min(f_hi - c_first, kChunks - 1u);
                     for (uint32_t w = x0 >> 5; w <= (x1 >> 5); w++) {
-                        uint32_t bw = bits[w];
+                        const uint32_t word = bits[w];
+                        uint32_t bw = word;
                         if (w == (x0 >> 5)) bw &= ~0u << (x0 & 31u);
                         if (w == (x1 >> 5)) bw &= ~0u >> (31u - (x1 & 31u));
                         while (bw) {
-                            const uint32_t c = c_first + w * 32u + (uint32_t)__builtin_ctz(bw);
+                            const uint32_t bit = (uint32_t)__builtin_ctz(bw);
                             bw &= bw - 1u;
-                            if (at < a.pair_cap) a.pairs[at] = make_uint2(r, c);
-                            at++;
+                            const uint32_t at = pair_base + rank[w] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u));
+                            if (at < a.pair_cap) a.pairs[at] = make_uint2(r, c_first + w * 32u + bit);
                         }
                     }
                 }
             }
-            if (__ballot(live && (uint64_t)s >= b1 + 16) != 0) break;  // (offsets ascend: nothing further overlaps)
+            if (__ballot(live && (uint64_t)s >= b1) != 0) break;  // (offsets ascend: no later request owns a byte of this slab)
             continue;
         }
         bool mark = false;
@@ -1828,7 +1823,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         }
         if (__ballot(live && (uint64_t)s >= b1 + 16) != 0) break;  // (offsets ascend: nothing further overlaps)
     }
-    }  // phases
+    }
 }
 
 // compact_kernel: a workgroup turns kCompactWords bitmap words into its part of the ascending request list. Each wave owns 512
