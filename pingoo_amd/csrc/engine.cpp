@@ -1048,7 +1048,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 sub_entries += slabs * (kStreamSlab / 512);  // chunk bitmap words
             }
         if ((rc = S.chunk_bits.reserve((size_t)sub_entries * 4))) return rc;
-        if ((rc = S.cand_cnt.reserve((size_t)(n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;
+        if ((rc = S.cand_cnt.reserve((size_t)(2 * n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;  // per pass: flag counts per slab, pair-list starts per slab, candidates per compact workgroup
         std::vector<FilterArgs> fall;  // every filtered pass, in pass order
         uint32_t fi = 0;
         uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
@@ -1102,7 +1102,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.rec = (uint32_t *)S.rec.p + gi * (size_t)n;
             f.chunk_bits = (uint32_t *)S.chunk_bits.p + sub_at;
             f.sub_count = (uint32_t *)S.cand_cnt.p + cnt_at;
-            f.block_count = f.sub_count + slabs;
+            f.pair_base = f.sub_count + slabs;
+            f.block_count = f.pair_base + slabs;
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
             f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
@@ -1115,7 +1116,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             }
             f.first_block = 0;
             sub_at += (uint64_t)slabs * (kStreamSlab / 512);
-            cnt_at += slabs + n_cblocks;
+            cnt_at += 2 * slabs + n_cblocks;
             alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
         }

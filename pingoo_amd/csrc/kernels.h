@@ -214,6 +214,7 @@ struct FilterArgs {
     uint2 *pairs;
     uint32_t *pair_count;
     uint32_t pair_cap;
+    uint32_t *pair_base;      // [slabs]: where each slab's pairs begin in the list (pair_scan_kernel: exclusive prefix sums of sub_count)
     uint32_t first_block;     // first workgroup of this pass in the fused filter launch
     uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration
 };

@@ -1499,6 +1499,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterMix M) 
 }
 
 __global__ void resolve_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
+__global__ void pair_scan_kernel(FilterTable B);
 
 // bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
 // (kCompactWords bitmap words each), then every workgroup sums the counts before it (a few hundred values) and writes its part.
@@ -1548,6 +1549,12 @@ int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev
     if (count == 0 || max_slabs == 0) return 0;
     FilterTable t{dev, count};
     void *args[] = {&t};
+    bool any_pairs = false;
+    for (uint32_t k = 0; k < count; k++) any_pairs = any_pairs || host[k].pairs != nullptr;
+    if (any_pairs) {
+        hipError_t e0 = hipLaunchKernel(reinterpret_cast<const void *>(pair_scan_kernel), dim3(count), dim3(1024), args, 0, (hipStream_t)stream);
+        if (e0 != hipSuccess) return (int)e0;
+    }
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
@@ -1691,6 +1698,32 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
     return x;
 }
 
+// pair_scan_kernel: one workgroup per pass with a confirm tier — exclusive prefix sums of the slabs' flag counts = where each slab's
+// pairs begin in the pass's pair list, and the list's length.
+__global__ __launch_bounds__(1024) void pair_scan_kernel(FilterTable B) {
+    __shared__ uint32_t part[1024];
+    const FilterArgs a = load_descriptor(&B.f[blockIdx.x]);
+    if (a.pairs == nullptr) return;
+    const uint32_t slabs = (uint32_t)(((uint64_t)a.total + kStreamSlab - 1) / kStreamSlab) - a.slab0, t = threadIdx.x;
+    const uint32_t per = (slabs + 1023u) / 1024u, k0 = t * per, k1 = min(slabs, k0 + per);
+    uint32_t sum = 0;
+    for (uint32_t k = k0; k < k1; k++) sum += a.sub_count[k];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t at = part[t] - sum;
+    for (uint32_t k = k0; k < k1; k++) {
+        a.pair_base[k] = at;
+        at += a.sub_count[k];
+    }
+    if (t == 1023) *a.pair_count = part[1023];
+}
+
 // resolve_kernel: one wave per slab turns the slab's flagged chunks into candidate REQUESTS. Request-driven: the flagged 16-byte
 // chunks of the slab become a bitmap in LDS (8192 bits) with per-word prefix counts, then the wave walks the requests that overlap
 // the slab — 64 per step, offsets read coalesced — and a request is a candidate when a flagged chunk lies within its bytes extended
@@ -1757,14 +1790,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     }
     const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
     // A pass with a confirm tier lists its flagged chunks instead of marking candidates: every flagged chunk of the slab becomes ONE pair
-    // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — its
-    // length is the slab's flag count, which filter_kernel left in sub_count: one atomic per slab — and a chunk's place in it is its rank
-    // among the slab's flagged chunks (the prefix counts above): no scan, no second walk.
-    uint32_t pair_base = 0;
-    if (a.pairs != nullptr) {
-        if (lane == 0) pair_base = atomicAdd(a.pair_count, cnt);
-        pair_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_base);
-    }
+    // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — it begins
+    // at the sum of the earlier slabs' flag counts, which filter_kernel left in sub_count (pair_scan_kernel: an atomic per slab on the
+    // list's length, ~20k returned same-address atomics per batch, held every wave up for its turn) — and a chunk's place in it is its
+    // rank among the slab's flagged chunks (the prefix counts above): no second walk.
+    const uint32_t pair_base = a.pairs != nullptr ? a.pair_base[rel] : 0u;
     {
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
     uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
