@@ -54,14 +54,11 @@ PWAF_HD uint32_t confirm_table32(const uint8_t *p) {
 
 // One entry against the text: does the factor occur with its window's last bigram at arena position i, inside the field [fs, fe)?
 // 0 = no, 1 | atom << 8 = yes and it decides that literal atom, 2 = yes and it is a factor of a non-literal atom (walk).
-// Out of line on the device (the kernel's per-lane loop stays a few dozen instructions). The chain of dependent accesses is what a
-// comparison costs, so it is kept short: the entry's three words together, then per 4 bytes of the factor value, mask and text together.
+// The chain of dependent accesses is what a comparison costs, so it is kept short: the entry's three words together, then value, mask
+// and text of up to 16 bytes of the factor together.
 template <int SPACE>
 #if defined(__HIPCC__)
 __host__ __device__
-#if defined(__HIP_DEVICE_COMPILE__)
-__attribute__((noinline))
-#endif
 #endif
 inline uint32_t
     confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
@@ -76,8 +73,16 @@ inline uint32_t
     if ((flags & kConfirmAtEnd) && q + len != fe) return 0;
     const uint32_t l4 = (len + 3u) & ~3u;
     const uint8_t *val = bytes + e_off, *msk = val + l4;
-    for (uint32_t w = 0; w < l4; w += 4)  // (reads up to 3 bytes past the factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero)
-        if ((confirm_load32(data + q + w) ^ confirm_table32<SPACE>(val + w)) & confirm_table32<SPACE>(msk + w)) return 0;
+    // four words (16 bytes: most factors whole) per round of loads — text, value and mask of all four are in flight together, so a
+    // mismatch in the factor's last bytes (a near miss) costs one trip to the text, not one per word. (Reads up to 3 bytes past the
+    // factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero.)
+    for (uint32_t w = 0; w < l4; w += 16) {
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 16; u += 4)
+            if (w + u < l4) diff |= (confirm_load32(data + q + w + u) ^ confirm_table32<SPACE>(val + w + u)) & confirm_table32<SPACE>(msk + w + u);
+        if (diff) return 0;
+    }
     const uint8_t *cls = msk + l4;
     const uint8_t *cw = reinterpret_cast<const uint8_t *>(classes);
     for (uint32_t k = 0; k < n_cls; k += 2) {
@@ -108,25 +113,27 @@ template <class TabAt>
 PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
     const uint32_t base = c * 16u;
     const bool pre = base >= 8u;  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
-    // bytes [base - 8, base + 17) through a 64-bit window that moves one byte per step (no register is indexed by the position; the
-    // loop is NOT unrolled: this code sits inside the kernel's per-lane state machine)
-    uint32_t lo = pre ? confirm_load32(data + base - 8u) : 0u, hi = pre ? confirm_load32(data + base - 4u) : 0u;
-    uint32_t n0 = confirm_load32(data + base), n1 = confirm_load32(data + base + 4u), n2 = confirm_load32(data + base + 8u), n3 = confirm_load32(data + base + 12u),
-             n4 = confirm_load32(data + base + 16u);
+    // bytes [base - 8, base + 20): seven words, every position at a fixed place in them (the 24 steps are unrolled: no register is
+    // indexed by the position and nothing moves between steps)
+    uint32_t w[7];
+    w[0] = pre ? confirm_load32(data + base - 8u) : 0u;
+    w[1] = pre ? confirm_load32(data + base - 4u) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) w[2 + k] = confirm_load32(data + base + 4u * k);
     uint32_t st = cv.init, mask = 0, found = 0;
     uint64_t bins = 0;
-#pragma unroll 1
+#pragma unroll
     for (uint32_t t = 0; t < 24; t++) {
-        const uint32_t b0 = lo & 0xFFu, b1 = (lo >> 8) & 0xFFu;
-        lo = (lo >> 8) | (hi << 24);
-        hi >>= 8;
-        if ((t & 3u) == 3u) { hi = n0; n0 = n1; n1 = n2; n2 = n3; n3 = n4; }
-        if (t < 8u && !pre) continue;               // (the arena's first chunk: the stream starts in the init state)
-        const uint32_t i = base + t - 8u;
-        if (cv.stride == 2u && (i & 1u)) continue;  // (bigrams are sampled at the even bytes of the arena)
+        if (cv.stride == 2u && (t & 1u)) continue;  // (bigrams are sampled at the even bytes of the arena; chunks start at even addresses)
+        const uint32_t lo = w[t >> 2] >> (8u * (t & 3u)), b0 = lo & 0xFFu, b1 = (t & 3u) == 3u ? w[(t >> 2) + 1] & 0xFFu : (lo >> 8) & 0xFFu;
         const uint32_t bin = filter_bin((uint8_t)b0, (uint8_t)b1, cv.mul);
+        if (t < 8u) {
+            if (pre) st = (st << 8) | tab_at(bin);  // (the arena's first chunk: the stream starts in the init state)
+            continue;
+        }
         st = (st << 8) | tab_at(bin);
-        if (t >= 8u && ((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) {  // a window completed here, both bytes inside the field
+        const uint32_t i = base + t - 8u;
+        if (((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) {  // a window completed here, both bytes inside the field
             mask |= 1u << (t - 8u);
             if (found < 4u) bins |= (uint64_t)bin << (16u * found);
             found++;

@@ -157,7 +157,7 @@ struct ConfirmArgs {
     uint32_t shared_bits;       // gap passes that share this pass's walk list (ListScanArgs::need_out): a literal hit that calls for one sends the request through the walk
 };
 static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 8;
-static constexpr uint32_t kConfirmPoolBytes = 44 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
+static constexpr uint32_t kConfirmPoolBytes = 40 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
 struct ConfirmBatchArgs {
     ConfirmArgs c[kConfirmPerLaunch];
     uint32_t count;

@@ -952,8 +952,10 @@ __device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, u
 __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __shared__ uint32_t pool[kConfirmPoolBytes / 4];                 // entries | bytes | classes of the pass (when they fit)
-    __shared__ uint32_t app_cnt, app_base;                           // the workgroup's walk-list appends of one work item
+    constexpr uint32_t kConfirmQueue = 1024;
+    __shared__ uint32_t app_cnt, app_base, app_queue[kConfirmQueue];  // the workgroup's walk-list appends of the current pass
     __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) app_cnt = 0;
     const uint32_t total = plan[b.count];
     const uint32_t it0 = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), it1 = (uint32_t)((uint64_t)total * (blockIdx.x + 1) / gridDim.x);
     for (uint32_t it = it0; it < it1;) {
@@ -1064,16 +1066,23 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
             }
             // Nothing confirmed (the common case by far): the lane is done and has written nothing.
             const bool append = live && settle(r, need, walk, true);
-            // The walk list: the workgroup's appends of this item share ONE atomic on the list's length (a returned same-address atomic
-            // per request is what DESIGN.md 4.1 measured at 0.5 ms per batch).
+            // The walk list: the lane parks the request in the workgroup's LDS queue (an LDS atomic, no barrier); the queue is flushed with
+            // ONE atomic on the list's length when the workgroup is done with the pass (a returned same-address atomic per request is
+            // what DESIGN.md 4.1 measured at 0.5 ms per batch; a barrier per work item cost the 16 waves their independence).
+            if (append) {
+                const uint32_t slot = atomicAdd(&app_cnt, 1u);
+                if (slot < kConfirmQueue) app_queue[slot] = r;
+                else a.walk_list[atomicAdd(a.walk_count, 1u)] = r;  // (queue full: directly — rare)
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t queued = min(app_cnt, kConfirmQueue);
+            if (threadIdx.x == 0 && queued != 0) app_base = atomicAdd(a.walk_count, queued);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < queued; k += kConfirmThreads) a.walk_list[app_base + k] = app_queue[k];
+            __syncthreads();
             if (threadIdx.x == 0) app_cnt = 0;
-            __syncthreads();
-            uint32_t slot = 0;
-            if (append) slot = atomicAdd(&app_cnt, 1u);
-            __syncthreads();
-            if (threadIdx.x == 0 && app_cnt != 0) app_base = atomicAdd(a.walk_count, app_cnt);
-            __syncthreads();
-            if (append) a.walk_list[app_base + slot] = r;
         }
     }
 }
