@@ -37,6 +37,34 @@ PWAF_HD uint32_t confirm_load32(const uint8_t *p) {  // request TEXT: an arena i
     return v;
 #endif
 }
+// 16 / 8 bytes of request text at once: a scattered load instruction costs the texture addresser a cycle per lane whatever its width
+// (DESIGN.md 6.1 found the streaming kernel bound by exactly that), so the chunk's 28 bytes are three instructions, not seven.
+struct ConfirmText4 { uint32_t x, y, z, w; };
+PWAF_HD ConfirmText4 confirm_load128(const uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef u4 u4_u __attribute__((aligned(1)));
+    const u4 v = *reinterpret_cast<const __attribute__((address_space(1))) u4_u *>((uintptr_t)p);
+    return ConfirmText4{v.x, v.y, v.z, v.w};
+#else
+    ConfirmText4 v;
+    memcpy(&v, p, 16);
+    return v;
+#endif
+}
+PWAF_HD void confirm_load64(const uint8_t *p, uint32_t &lo, uint32_t &hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    typedef u2 u2_u __attribute__((aligned(1)));
+    const u2 v = *reinterpret_cast<const __attribute__((address_space(1))) u2_u *>((uintptr_t)p);
+    lo = v.x;
+    hi = v.y;
+#else
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+#endif
+}
+
 // The tier's TABLES (4-byte aligned words). SPACE says where they live for the device: 1 = global memory, 3 = the kernel's LDS copy (the
 // generic pointer's low half is the LDS address: a ds_read instead of the FLAT load a generic pointer gets — a FLAT load that hits LDS
 // still takes the texture path's latency); the host ignores it.
@@ -77,10 +105,12 @@ inline uint32_t
     // mismatch in the factor's last bytes (a near miss) costs one trip to the text, not one per word. (Reads up to 3 bytes past the
     // factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero.)
     for (uint32_t w = 0; w < l4; w += 16) {
+        const ConfirmText4 t4 = confirm_load128(data + q + w);  // (may read up to 15 bytes past the factor: PWAF_ARENA_PAD)
+        const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
         uint32_t diff = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 16; u += 4)
-            if (w + u < l4) diff |= (confirm_load32(data + q + w + u) ^ confirm_table32<SPACE>(val + w + u)) & confirm_table32<SPACE>(msk + w + u);
+        for (uint32_t u = 0; u < 4; u++)
+            if (w + 4u * u < l4) diff |= (tw[u] ^ confirm_table32<SPACE>(val + w + 4u * u)) & confirm_table32<SPACE>(msk + w + 4u * u);
         if (diff) return 0;
     }
     const uint8_t *cls = msk + l4;
@@ -115,11 +145,13 @@ PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data,
     const bool pre = base >= 8u;  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
     // bytes [base - 8, base + 20): seven words, every position at a fixed place in them (the 24 steps are unrolled: no register is
     // indexed by the position and nothing moves between steps)
-    uint32_t w[7];
-    w[0] = pre ? confirm_load32(data + base - 8u) : 0u;
-    w[1] = pre ? confirm_load32(data + base - 4u) : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 5; k++) w[2 + k] = confirm_load32(data + base + 4u * k);
+    uint32_t w[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (pre) confirm_load64(data + base - 8u, w[0], w[1]);
+    {
+        const ConfirmText4 t4 = confirm_load128(data + base);
+        w[2] = t4.x; w[3] = t4.y; w[4] = t4.z; w[5] = t4.w;
+    }
+    w[6] = confirm_load32(data + base + 16u);
     uint32_t st = cv.init, mask = 0, found = 0;
     uint64_t bins = 0;
 #pragma unroll

@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
             const bool live = li < n_p;
             const uint2 pr = live ? a.pairs[li] : make_uint2(0u, 0u);
             uint32_t r = pr.x;  // the request that owns the chunk's first byte; a chunk that holds a field boundary also speaks for the next one(s)
-            uint32_t fs = live ? a.off[r] : 0u, fe = live ? a.off[r + 1] : 0u;
+            uint32_t fs = 0u, fe = 0u;
+            if (live) confirm_load64(reinterpret_cast<const uint8_t *>(a.off + r), fs, fe);  // (the request's two offsets: one scattered load)
             ConfirmChunk ch{0u, 0ull};
             if (live) ch = confirm_windows(cv, a.data, 0u, 0xFFFFFFFFu, pr.y, [&](const uint32_t bin) { return ftab[bin]; });  // (every window of the chunk: whose field it lies in is settled below)
             // the completed windows' entries, one comparison per lane and iteration (a lane advances to ITS next entry: the wave runs
