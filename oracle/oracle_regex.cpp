@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <bitset>
 #include <cstring>
+#include <functional>
 
 namespace oracle {
 
@@ -79,6 +80,69 @@ struct Parser {
         a->k = Ast::Assert;
         a->ak = k;
         return a;
+    }
+
+    // \p{..} / \pX / \P{..} / \p{^..}: Unicode general categories over ASCII text (the reference's fields are ASCII by construction:
+    // http_listener.rs:159-165 keeps only visible ASCII, http::Uri is ASCII) — regex-syntax folds the class under (?i) first, then
+    // negates it. pos is at the 'p' / 'P'. Returns false after fail() for anything but a general category (or Latin / ASCII / Any).
+    bool unicode_property(ByteSet &s, bool fold_case) {
+        bool negated = peek() == 'P';
+        pos++;
+        std::string nm;
+        if (!eof() && peek() == '{') {
+            size_t end = p.find('}', pos);
+            if (end == std::string::npos) { fail("unterminated \\p{"); return false; }
+            nm = p.substr(pos + 1, end - pos - 1);
+            pos = end + 1;
+        } else if (!eof()) {
+            nm = std::string(1, peek());
+            pos++;
+        } else {
+            fail("incomplete \\p");
+            return false;
+        }
+        if (!nm.empty() && nm[0] == '^') { negated = !negated; nm = nm.substr(1); }
+        std::string k;
+        for (char ch : nm) if (ch != '_' && ch != '-' && ch != ' ') k.push_back((char)std::tolower((unsigned char)ch));
+        auto is = [&](std::initializer_list<const char *> names) { for (const char *n : names) if (k == n) return true; return false; };
+        auto upper = [](int c) { return c >= 'A' && c <= 'Z'; };
+        auto lower = [](int c) { return c >= 'a' && c <= 'z'; };
+        auto in = [](int c, const char *set) { return c != 0 && std::strchr(set, c) != nullptr; };
+        std::function<bool(int)> pred;
+        if (is({"l", "letter", "alphabetic", "alpha", "latin", "latn", "lc", "casedletter"})) pred = [&](int c) { return upper(c) || lower(c); };
+        else if (is({"lu", "uppercaseletter", "uppercase", "upper"})) pred = upper;
+        else if (is({"ll", "lowercaseletter", "lowercase", "lower"})) pred = lower;
+        else if (is({"n", "number", "nd", "decimalnumber", "digit"})) pred = [](int c) { return c >= '0' && c <= '9'; };
+        else if (is({"p", "punctuation", "punct"})) pred = [&](int c) { return in(c, "!\"#%&'()*,-./:;?@[\\]_{}"); };
+        else if (is({"pc", "connectorpunctuation"})) pred = [](int c) { return c == '_'; };
+        else if (is({"pd", "dashpunctuation"})) pred = [](int c) { return c == '-'; };
+        else if (is({"ps", "openpunctuation"})) pred = [&](int c) { return in(c, "([{"); };
+        else if (is({"pe", "closepunctuation"})) pred = [&](int c) { return in(c, ")]}"); };
+        else if (is({"po", "otherpunctuation"})) pred = [&](int c) { return in(c, "!\"#%&'*,./:;?@\\"); };
+        else if (is({"s", "symbol"})) pred = [&](int c) { return in(c, "$+<=>^`|~"); };
+        else if (is({"sc", "currencysymbol"})) pred = [](int c) { return c == '$'; };
+        else if (is({"sm", "mathsymbol"})) pred = [&](int c) { return in(c, "+<=>|~"); };
+        else if (is({"sk", "modifiersymbol"})) pred = [&](int c) { return in(c, "^`"); };
+        else if (is({"z", "separator", "zs", "spaceseparator"})) pred = [](int c) { return c == ' '; };
+        else if (is({"cc", "control", "cntrl", "c", "other"})) pred = [](int c) { return c < 0x20 || c == 0x7F; };
+        else if (is({"ascii"})) pred = [](int c) { return c < 0x80; };
+        else if (is({"any"})) pred = [](int) { return true; };
+        else if (is({"lt", "titlecaseletter", "lm", "modifierletter", "lo", "otherletter", "m", "mark", "mn", "mc", "me", "nl", "letternumber", "no", "othernumber", "pi",
+                     "initialpunctuation", "pf", "finalpunctuation", "so", "othersymbol", "zl", "lineseparator", "zp", "paragraphseparator", "cf", "format", "cs", "surrogate",
+                     "co", "privateuse", "cn", "unassigned"}))
+            pred = [](int) { return false; };  // categories without an ASCII member
+        else { fail("unsupported: Unicode property \\p{" + nm + "} (only general categories, ASCII-restricted)"); return false; }
+        ByteSet t;
+        for (int c = 0; c < 256; c++)
+            if ((k == "any" || c < 0x80) && pred(c)) t.set((size_t)c);
+        if (fold_case)
+            for (int c = 'a'; c <= 'z'; c++) {
+                if (t.test((size_t)c)) t.set((size_t)(c - 32));
+                if (t.test((size_t)(c - 32))) t.set((size_t)c);
+            }
+        if (negated) t = ~t;
+        s |= t;
+        return true;
     }
 
     static void perl_class(char c, ByteSet &s) {
@@ -217,7 +281,7 @@ struct Parser {
                 if (eof()) { fail("incomplete escape"); return nullptr; }
                 char e = peek();
                 if (strchr("dDwWsS", e)) { pos++; perl_class(e, s); continue; }
-                if (e == 'p' || e == 'P') { fail("unsupported: Unicode class \\p"); return nullptr; }
+                if (e == 'p' || e == 'P') { if (!unicode_property(s, f.i)) return nullptr; continue; }
                 if (e == 'b') { pos++; lo = 0x08; }  // inside a class \b is backspace
                 else { lo = escape_byte(); if (lo < 0) return nullptr; }
             } else {
@@ -344,7 +408,11 @@ struct Parser {
             if (e == 'z') { pos++; return mk_assert(AKind::EndText); }
             if (e == 'b') { pos++; return mk_assert(AKind::WordB); }
             if (e == 'B') { pos++; return mk_assert(AKind::NotWordB); }
-            if (e == 'p' || e == 'P') { fail("unsupported: Unicode class \\p"); return nullptr; }
+            if (e == 'p' || e == 'P') {
+                ByteSet s;
+                if (!unicode_property(s, f.i)) return nullptr;
+                return mk_set(s);
+            }
             if (e >= '0' && e <= '9') { fail("backreferences are not supported"); return nullptr; }
             int b = escape_byte();
             if (b < 0) return nullptr;

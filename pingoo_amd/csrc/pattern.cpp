@@ -148,6 +148,59 @@ struct RxParser {
             }
         }
     }
+    // \p{Name} / \pX / \P{Name} / \p{^Name}: Unicode general categories (and the script Latin), RESTRICTED TO ASCII — the reference's fields
+    // are ASCII by construction (HeaderValue::to_str, http::Uri), where \p{L} is [A-Za-z], \p{N} is [0-9] and so on; under (?i) a cased
+    // category takes its other case too (the regex crate folds classes). i points at the 'p' / 'P'. Other property names: unsupported.
+    bool unicode_class(ByteSet &out, bool icase) {
+        const bool neg_outer = p[i] == 'P';
+        i++;
+        std::string name;
+        if (i < p.size() && p[i] == '{') {
+            const size_t close = p.find('}', i);
+            if (close == std::string::npos) return invalid("unterminated \\p{");
+            name = p.substr(i + 1, close - i - 1);
+            i = close + 1;
+        } else if (i < p.size()) {
+            name = std::string(1, p[i++]);
+        } else {
+            return invalid("incomplete \\p");
+        }
+        bool neg = neg_outer;
+        if (!name.empty() && name[0] == '^') { neg = !neg; name.erase(0, 1); }
+        std::string key;
+        for (char ch : name)
+            if (ch != '_' && ch != ' ' && ch != '-') key += (char)tolower((unsigned char)ch);
+        struct Cat { const char *names; const char *ranges; };  // names separated by '|', ranges as byte pairs
+        static const Cat cats[] = {
+            {"l|letter|alphabetic|alpha|latin|latn|lc|casedletter", "AZaz"}, {"lu|uppercaseletter|uppercase|upper", "AZ"}, {"ll|lowercaseletter|lowercase|lower", "az"},
+            {"n|number|nd|decimalnumber|digit", "09"}, {"p|punctuation|punct", "!#%*,/:;?@[]__{{}}"}, {"pc|connectorpunctuation", "__"}, {"pd|dashpunctuation", "--"},
+            {"ps|openpunctuation", "(([[{{"}, {"pe|closepunctuation", "))]]}}"}, {"po|otherpunctuation", "!#%'**,,./:;?@\\\\"}, {"s|symbol", "$$++<>^^``||~~"},
+            {"sc|currencysymbol", "$$"}, {"sm|mathsymbol", "++<>||~~"}, {"sk|modifiersymbol", "^^``"}, {"z|separator|zs|spaceseparator", "  "},
+            {"cc|control|cntrl|c|other", "\x01\x1f\x7f\x7f"}, {"ascii", "\x01\x7f"}, {"any", "\x01\xff"},
+            {"lt|titlecaseletter|lm|modifierletter|lo|otherletter|m|mark|mn|mc|me|nl|letternumber|no|othernumber|pi|initialpunctuation|pf|finalpunctuation|so|othersymbol|zl|lineseparator|zp|paragraphseparator|cf|format|cs|surrogate|co|privateuse|cn|unassigned", ""},
+        };
+        const Cat *hit = nullptr;
+        for (const Cat &c : cats) {
+            const char *q = c.names;
+            while (*q && !hit) {
+                const char *e = strchr(q, '|');
+                const size_t len = e ? (size_t)(e - q) : strlen(q);
+                if (len == key.size() && !memcmp(q, key.data(), len)) hit = &c;
+                q += len + (e ? 1 : 0);
+            }
+            if (hit) break;
+        }
+        if (!hit) return unsupported("Unicode property \\p{" + name + "} (only general categories, ASCII-restricted)");
+        ByteSet t;
+        for (const char *r = hit->ranges; r[0]; r += 2)
+            for (int c = (unsigned char)r[0]; c <= (unsigned char)r[1]; c++) t.set((size_t)c);
+        if (key == "cc" || key == "control" || key == "cntrl" || key == "c" || key == "other" || key == "ascii" || key == "any") t.set(0);  // NUL cannot sit in the range string
+        if (key == "p" || key == "punctuation" || key == "punct") for (char c : std::string("\"&'()-.\\")) t.set((size_t)(unsigned char)c);
+        if (icase) fold(t);
+        if (neg) t.flip();
+        out |= t;
+        return true;
+    }
     static void shorthand(char k, ByteSet &out) {
         ByteSet t;
         char lower = (char)(k | 0x20);
@@ -239,7 +292,7 @@ struct RxParser {
                 if (i >= p.size()) return invalid("incomplete escape");
                 char e = p[i];
                 if (strchr("dDwWsS", e)) { shorthand(e, s); i++; continue; }
-                if (e == 'p' || e == 'P') return unsupported("Unicode class \\p");
+                if (e == 'p' || e == 'P') { if (!unicode_class(s, fl.icase)) return false; continue; }  // (the crate folds, then negates, per item)
                 if (e == 'b') { lo = 8; i++; }
                 else { lo = one_byte_escape(); if (lo < 0) return false; }
             } else {
@@ -451,7 +504,7 @@ struct RxParser {
                     if (e == 'z') { i++; push(rx_assert(A_TEXT_END)); break; }
                     if (e == 'b') { i++; push(rx_assert(A_WORD_B)); break; }
                     if (e == 'B') { i++; push(rx_assert(A_NOT_WORD_B)); break; }
-                    if (e == 'p' || e == 'P') { unsupported("Unicode class \\p"); break; }
+                    if (e == 'p' || e == 'P') { ByteSet s; if (unicode_class(s, fl.icase)) push(rx_class(s)); break; }
                     if (e >= '0' && e <= '9') { invalid("backreferences are not supported"); break; }
                     int b = one_byte_escape();
                     if (b < 0) break;

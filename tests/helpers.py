@@ -59,6 +59,8 @@ def rregex(rng: random.Random, depth=0) -> str:
     if k <= 1:
         return rng.choice(["a", "b", "/", "\\.", "ab", "ba", "a/b", "."])
     if k == 2:
+        if rng.random() < 0.2:  # Unicode general categories (ASCII-restricted in both the oracle and the device compiler)
+            return rng.choice(["\\p{L}", "\\pL", "\\P{L}", "\\p{Lu}", "\\p{Ll}", "\\p{N}", "\\p{Nd}", "\\P{N}", "\\p{P}", "\\p{^P}", "[\\p{L}/]", "[^\\p{N}a]", "\\p{S}", "\\p{Zs}", "[\\P{Lu}b]"])
         return rng.choice(["[ab]", "[^a]", "[a-b/]", "\\w", "\\W", "\\d", "\\s", "[[:alpha:]]", "[^/.]", "\\S"])
     if k == 3:
         return rng.choice(["^", "$", "\\b", "\\B", "\\A", "\\z"]) if rng.random() < 0.5 else "a"

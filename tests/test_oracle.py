@@ -169,11 +169,12 @@ def test_regex_matches_cpython_re():
 
 
 def test_regex_syntax_errors_and_unsupported():
-    for pat in ["(", ")", "a{2", "a{,3}", "*a", "a**b{", "[a", "\\", "\\q", "(?z)", "(?P<>a)", "a{3,2}", "[b-a]", "(?=a)", "(?<!a)", "\\1", "\\p{L}", "[[:bogus:]]", "(?x)a b", "[a&&b]", "\\xZZ",
+    for pat in ["(", ")", "a{2", "a{,3}", "*a", "a**b{", "[a", "\\", "\\q", "(?z)", "(?P<>a)", "a{3,2}", "[b-a]", "(?=a)", "(?<!a)", "\\1", "\\p{Greek}", "\\p{", "[[:bogus:]]", "(?x)a b", "[a&&b]", "\\xZZ",
                 "\\x{110000}"]:
         with pytest.raises(pyoracle.OracleError):
             pyoracle.regex_is_match(pat, b"a")
     assert pyoracle.regex_is_match("[[:alpha:]]+[[:digit:]]", b"..ab1")
+    assert pyoracle.regex_is_match("^\\p{L}+\\p{N}$", b"ab1") and not pyoracle.regex_is_match("^\\P{L}$", b"a")  # general categories, over ASCII
     assert pyoracle.regex_is_match("(?i)union\\s+select", b"x UnIoN \t SELECT y")
     assert not pyoracle.regex_is_match("^$", b"a") and pyoracle.regex_is_match("^$", b"") and pyoracle.regex_is_match("a*", b"")
     assert pyoracle.regex_is_match("a$", b"a") and not pyoracle.regex_is_match("a$", b"a\n")  # Rust `$` is not Perl's
