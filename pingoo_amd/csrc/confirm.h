@@ -139,19 +139,27 @@ struct ConfirmChunk {
 // the device: four pushes determine it): one or two of the sixteen positions survive. Registers and tab_at(bin) — the pass's filter
 // table, which the device keeps in LDS — only. A match of any pattern holds a factor whose window completes at one of these
 // positions, inside the field (what lies before the factor cannot matter: a bucket only tests its last kmin bigrams).
-template <class TabAt>
-PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
+// bytes [16 c - 8, 16 c + 20) of the arena: the chunk, the 8 bytes before it (zeros for the arena's first chunk) and the 4 behind it
+struct ConfirmBytes {
+    uint32_t w[7];
+};
+PWAF_HD ConfirmBytes confirm_chunk_bytes(const uint8_t *data, const uint32_t c) {
     const uint32_t base = c * 16u;
-    const bool pre = base >= 8u;  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
-    // bytes [base - 8, base + 20): seven words, every position at a fixed place in them (the 24 steps are unrolled: no register is
-    // indexed by the position and nothing moves between steps)
-    uint32_t w[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (pre) confirm_load64(data + base - 8u, w[0], w[1]);
-    {
-        const ConfirmText4 t4 = confirm_load128(data + base);
-        w[2] = t4.x; w[3] = t4.y; w[4] = t4.z; w[5] = t4.w;
-    }
-    w[6] = confirm_load32(data + base + 16u);
+    ConfirmBytes t;
+    t.w[0] = t.w[1] = 0u;
+    if (base >= 8u) confirm_load64(data + base - 8u, t.w[0], t.w[1]);  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
+    const ConfirmText4 t4 = confirm_load128(data + base);
+    t.w[2] = t4.x; t.w[3] = t4.y; t.w[4] = t4.z; t.w[5] = t4.w;
+    t.w[6] = confirm_load32(data + base + 16u);
+    return t;
+}
+template <class TabAt>
+PWAF_HD ConfirmChunk confirm_windows_of(const ConfirmView &cv, const ConfirmBytes &tb, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
+    const uint32_t base = c * 16u;
+    const bool pre = base >= 8u;
+    // seven words, every position at a fixed place in them (the 24 steps are unrolled: no register is indexed by the position and
+    // nothing moves between steps)
+    const uint32_t *w = tb.w;
     uint32_t st = cv.init, mask = 0, found = 0;
     uint64_t bins = 0;
 #pragma unroll
@@ -175,6 +183,10 @@ PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data,
     r.mask = fe < fs + 2u ? 0u : mask;
     r.bins = bins;
     return r;
+}
+template <class TabAt>
+PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
+    return confirm_windows_of(cv, confirm_chunk_bytes(data, c), fs, fe, c, tab_at);
 }
 // filter bin of the bigram of the chunk's idx-th completed window (ascending positions), which sits at arena position pos
 PWAF_HD uint32_t confirm_bin_of(const ConfirmChunk &ch, const uint32_t idx, const uint8_t *data, const uint32_t pos, const uint32_t mul) {

@@ -1000,15 +1000,34 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
         __syncthreads();
         const ConfirmView cv{nullptr, t_entries, t_bytes, t_classes, a.mul, a.stride, a.init};
         const uint32_t n_p = min(*a.pair_count, a.pair_cap);
+        // A lane's chain of dependent loads — pair -> the request's offsets, the chunk's text — is issued one work item AHEAD: the
+        // next item's offsets and text (and the pair of the one after) travel while this item's windows are compared. (The kernel is
+        // bound by those round trips, not by instructions: 65 % of its wave cycles were waits with everything issued on demand.)
+        auto pair_of = [&](const uint32_t item) -> uint2 {
+            const uint32_t k = (item - first_item) * kConfirmThreads + threadIdx.x;
+            return (item < it_end && k < n_p) ? a.pairs[k] : make_uint2(kNone, 0u);  // (kNone: no pair for this lane)
+        };
+        uint2 pr_next = pair_of(it), pr_after = pair_of(it + 1u);
+        uint32_t fs_next = 0u, fe_next = 0u;
+        ConfirmBytes tb_next{};
+        if (pr_next.x != kNone) {
+            confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);  // (the request's two offsets: one scattered load)
+            tb_next = confirm_chunk_bytes(a.data, pr_next.y);
+        }
         for (; it < it_end; it++) {
-            const uint32_t li = (it - first_item) * kConfirmThreads + threadIdx.x;
-            const bool live = li < n_p;
-            const uint2 pr = live ? a.pairs[li] : make_uint2(0u, 0u);
-            uint32_t r = pr.x;  // the request that owns the chunk's first byte; a chunk that holds a field boundary also speaks for the next one(s)
-            uint32_t fs = 0u, fe = 0u;
-            if (live) confirm_load64(reinterpret_cast<const uint8_t *>(a.off + r), fs, fe);  // (the request's two offsets: one scattered load)
+            const uint2 pr = pr_next;
+            const bool live = pr.x != kNone;
+            uint32_t r = live ? pr.x : 0u;  // the request that owns the chunk's first byte; a chunk that holds a field boundary also speaks for the next one(s)
+            uint32_t fs = fs_next, fe = fe_next;
+            const ConfirmBytes tb = tb_next;
+            pr_next = pr_after;
+            if (pr_next.x != kNone) {
+                confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);
+                tb_next = confirm_chunk_bytes(a.data, pr_next.y);
+            }
+            pr_after = pair_of(it + 2u);
             ConfirmChunk ch{0u, 0ull};
-            if (live) ch = confirm_windows(cv, a.data, 0u, 0xFFFFFFFFu, pr.y, [&](const uint32_t bin) { return ftab[bin]; });  // (every window of the chunk: whose field it lies in is settled below)
+            if (live) ch = confirm_windows_of(cv, tb, 0u, 0xFFFFFFFFu, pr.y, [&](const uint32_t bin) { return ftab[bin]; });  // (every window of the chunk: whose field it lies in is settled below)
             // the completed windows' entries, one comparison per lane and iteration (a lane advances to ITS next entry: the wave runs
             // as long as its longest lane, not the product of the two loops' longest trips)
             uint32_t mask = ch.mask, cnt = 0, j = 0, e0 = 0, pos = 0, widx = 0;
