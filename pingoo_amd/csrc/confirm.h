@@ -104,8 +104,10 @@ inline uint32_t
     // four words (16 bytes: most factors whole) per round of loads — text, value and mask of all four are in flight together, so a
     // mismatch in the factor's last bytes (a near miss) costs one trip to the text, not one per word. (Reads up to 3 bytes past the
     // factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero.)
+    ConfirmText4 first{0u, 0u, 0u, 0u};  // the factor's first 16 bytes of text: class positions inside them need no load of their own
     for (uint32_t w = 0; w < l4; w += 16) {
         const ConfirmText4 t4 = confirm_load128(data + q + w);  // (may read up to 15 bytes past the factor: PWAF_ARENA_PAD)
+        if (w == 0u) first = t4;
         const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
         uint32_t diff = 0;
 #pragma unroll
@@ -115,12 +117,19 @@ inline uint32_t
     }
     const uint8_t *cls = msk + l4;
     const uint8_t *cw = reinterpret_cast<const uint8_t *>(classes);
+    auto text_byte = [&](const uint32_t at) -> uint32_t {
+        if (at < 16u) {
+            const uint32_t word = at < 4u ? first.x : at < 8u ? first.y : at < 12u ? first.z : first.w;
+            return (word >> (8u * (at & 3u))) & 0xFFu;
+        }
+        return confirm_load32(data + q + at) & 0xFFu;
+    };
     for (uint32_t k = 0; k < n_cls; k += 2) {
         const uint32_t pc = confirm_table32<SPACE>(cls + 2u * k);  // two {position, class id} pairs (the pool is padded to whole dwords)
-        const uint32_t t = confirm_load32(data + q + (pc & 0xFFu)) & 0xFFu;
+        const uint32_t t = text_byte(pc & 0xFFu);
         if (!((confirm_table32<SPACE>(cw + 4u * (((pc >> 8) & 0xFFu) * 8u + (t >> 5))) >> (t & 31u)) & 1u)) return 0;
         if (k + 1u < n_cls) {
-            const uint32_t t2 = confirm_load32(data + q + ((pc >> 16) & 0xFFu)) & 0xFFu;
+            const uint32_t t2 = text_byte((pc >> 16) & 0xFFu);
             if (!((confirm_table32<SPACE>(cw + 4u * ((pc >> 24) * 8u + (t2 >> 5))) >> (t2 & 31u)) & 1u)) return 0;
         }
     }
@@ -143,14 +152,20 @@ struct ConfirmChunk {
 struct ConfirmBytes {
     uint32_t w[7];
 };
-PWAF_HD ConfirmBytes confirm_chunk_bytes(const uint8_t *data, const uint32_t c) {
+PWAF_HD ConfirmBytes confirm_chunk_bytes(const uint8_t *data, const uint32_t c, const uint32_t readable /* arena bytes + PWAF_ARENA_PAD */) {
     const uint32_t base = c * 16u;
     ConfirmBytes t;
-    t.w[0] = t.w[1] = 0u;
-    if (base >= 8u) confirm_load64(data + base - 8u, t.w[0], t.w[1]);  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it)
-    const ConfirmText4 t4 = confirm_load128(data + base);
-    t.w[2] = t4.x; t.w[3] = t4.y; t.w[4] = t4.z; t.w[5] = t4.w;
-    t.w[6] = confirm_load32(data + base + 16u);
+    if (base >= 8u && base + 24u <= readable) {  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it) two 16-byte loads: [base - 8, base + 24)
+        const ConfirmText4 lo = confirm_load128(data + base - 8u), hi = confirm_load128(data + base + 8u);
+        t.w[0] = lo.x; t.w[1] = lo.y; t.w[2] = lo.z; t.w[3] = lo.w;
+        t.w[4] = hi.x; t.w[5] = hi.y; t.w[6] = hi.z;
+    } else {
+        const ConfirmText4 t4 = confirm_load128(data + base);
+        t.w[0] = t.w[1] = 0u;
+        if (base >= 8u) confirm_load64(data + base - 8u, t.w[0], t.w[1]);
+        t.w[2] = t4.x; t.w[3] = t4.y; t.w[4] = t4.z; t.w[5] = t4.w;
+        t.w[6] = confirm_load32(data + base + 16u);
+    }
     return t;
 }
 template <class TabAt>
@@ -186,7 +201,7 @@ PWAF_HD ConfirmChunk confirm_windows_of(const ConfirmView &cv, const ConfirmByte
 }
 template <class TabAt>
 PWAF_HD ConfirmChunk confirm_windows(const ConfirmView &cv, const uint8_t *data, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
-    return confirm_windows_of(cv, confirm_chunk_bytes(data, c), fs, fe, c, tab_at);
+    return confirm_windows_of(cv, confirm_chunk_bytes(data, c, c * 16u + 20u), fs, fe, c, tab_at);  // (the host's arenas: only what the narrow form reads)
 }
 // filter bin of the bigram of the chunk's idx-th completed window (ascending positions), which sits at arena position pos
 PWAF_HD uint32_t confirm_bin_of(const ConfirmChunk &ch, const uint32_t idx, const uint8_t *data, const uint32_t pos, const uint32_t mul) {

@@ -1166,6 +1166,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.data = f.data;
             c.off = f.off;
             c.n = n;
+            c.total = f.total;
             c.pairs = f.pairs;
             c.pair_count = f.pair_count;
             c.pair_cap = f.pair_cap;

@@ -129,6 +129,7 @@ struct ConfirmArgs {
     const uint8_t *data;
     const uint32_t *off;
     uint32_t n;
+    uint32_t total;             // bytes in the arena (readable: total + PWAF_ARENA_PAD)
     const uint2 *pairs;         // {request, arena chunk}
     const uint32_t *pair_count; // on the device
     uint32_t pair_cap;

@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
         ConfirmBytes tb_next{};
         if (pr_next.x != kNone) {
             confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);  // (the request's two offsets: one scattered load)
-            tb_next = confirm_chunk_bytes(a.data, pr_next.y);
+            tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
         }
         for (; it < it_end; it++) {
             const uint2 pr = pr_next;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
             pr_next = pr_after;
             if (pr_next.x != kNone) {
                 confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);
-                tb_next = confirm_chunk_bytes(a.data, pr_next.y);
+                tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
             }
             pr_after = pair_of(it + 2u);
             ConfirmChunk ch{0u, 0ull};
