@@ -955,6 +955,17 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         list_variant[1] = forced_shape >> 4;
     }
 #endif
+    {
+        // With a confirm tier on every filtered pass the phase-0 lists are short walk lists: the small workgroup shape (512 threads,
+        // 48 KiB) starts on whatever wave slots the attribute kernels leave free — the 1024-thread / 144 KiB shape had to wait for a whole
+        // free CU (measured: 0.04 ms alone, 0.17 ms beside the side stream).
+        bool all_confirm = e->n_filtered != 0;
+        for (const DevGroup &d : e->groups) all_confirm = all_confirm && (!d.filtered || d.confirm);
+#ifdef PWAF_PROFILING
+        if (!getenv("PWAF_LIST_SHAPE"))
+#endif
+        if (all_confirm) list_variant[0] = 0;
+    }
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
     auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
