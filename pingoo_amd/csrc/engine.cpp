@@ -804,8 +804,17 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.cand_bits = (const uint32_t *)S.cand_bits.p;
     v.visit_bits = (const uint32_t *)S.visit_bits.p;
     v.bit_words = bit_words;
-    for (size_t k = 0; k < e->groups.size(); k++)  // a pass with heads writes records outside its candidate list too: zeroed, read densely; a confirm tier MERGES hits into zeroed records
-        if (e->groups[k].filtered && (!e->groups[k].filter.heads.empty() || e->groups[k].confirm)) HIP_TRY(hipMemsetAsync((uint32_t *)S.rec.p + k * (size_t)n, 0, (size_t)n * 4, stream));
+    // A pass with heads writes records outside its candidate list too (zeroed, read densely); a confirm tier MERGES hits into zeroed
+    // records. Passes are laid out so that the filtered ones are neighbours: runs of passes to zero take ONE memset each (69 memsets of
+    // 4 MB were 0.3 ms of the 4096-rule set's 1.4 ms step).
+    for (size_t k = 0; k < e->groups.size();) {
+        auto zeroed = [&](size_t q) { return e->groups[q].filtered && (!e->groups[q].filter.heads.empty() || e->groups[q].confirm); };
+        if (!zeroed(k)) { k++; continue; }
+        size_t k1 = k;
+        while (k1 < e->groups.size() && zeroed(k1)) k1++;
+        HIP_TRY(hipMemsetAsync((uint32_t *)S.rec.p + k * (size_t)n, 0, (k1 - k) * (size_t)n * 4, stream));
+        k = k1;
+    }
     v.n_hlen = (uint32_t)e->hlen_fields.size();
     for (size_t k = 0; k < e->hlen_fields.size(); k++) v.hoff[k] = cols[e->hlen_fields[k]].offsets;
     v.gpairs = (uint4 *)S.attr.p;
