@@ -157,7 +157,7 @@ struct ConfirmArgs {
     uint32_t enq_words;
     uint32_t shared_bits;       // gap passes that share this pass's walk list (ListScanArgs::need_out): a literal hit that calls for one sends the request through the walk
 };
-static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 8;
+static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 16;
 static constexpr uint32_t kConfirmPoolBytes = 40 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
 struct ConfirmBatchArgs {
     ConfirmArgs c[kConfirmPerLaunch];
@@ -186,7 +186,7 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
 static constexpr uint32_t kStreamSlab = 128 * 1024;   // bytes per wave
 static constexpr uint32_t kStreamIter = 4096;          // bytes per iteration of a wave: four rows of 64 lanes x 16 bytes
 static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup
-static constexpr uint32_t kMaxFiltersPerLaunch = 8;
+static constexpr uint32_t kMaxFiltersPerLaunch = 16;  // descriptors per store launch (16 x 232 bytes of kernel arguments)
 static constexpr uint32_t kCompactWords = 2048;       // bitmap words per compact workgroup (65536 requests)
 struct FilterArgs {
     const uint8_t *data;
@@ -389,7 +389,7 @@ struct VerdictArgs {
 };
 
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
-static constexpr uint32_t kGatedPerLaunch = 8;
+static constexpr uint32_t kGatedPerLaunch = 16;
 struct GatedArgs {
     ListScanArgs g[kGatedPerLaunch];
     uint32_t count;
@@ -422,3 +422,7 @@ struct VerdictShape {
 VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false);
 
 }  // namespace pwaf
+
+namespace pwaf {
+static_assert(sizeof(FilterBatchArgs) <= 4064 && sizeof(GatedArgs) <= 4064 && sizeof(ConfirmBatchArgs) <= 4064, "a descriptor chunk travels as one launch's kernel arguments");
+}
