@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) and micro-batcher measurements")
     ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--residual", type=int, default=0, help="also time the same workload with K extra rules that only the per-request residual interpreter can evaluate "
+                                                            "(arithmetic on lengths / ports, concatenation, lists of request values, orderings between fields): `residual` object")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: step i is issued on stream i mod INFLIGHT (pwaf_evaluate_device is re-entrant: every call takes "
                                                             "its own scratch context), so one batch's small latency-bound kernels run under the next batch's streaming kernels")
     args = ap.parse_args()
@@ -531,6 +533,31 @@ def main():
             nb = native_batcher_bench(eng, hb)
             if nb is not None:
                 result["batcher"] = nb
+        if world == 1 and args.residual > 0:
+            # the residual path: K rules no column form exists for, appended to the rule set — what a9's "any expression"
+            # costs per batch on top of the column pipeline (it had never been timed)
+            phase("residual rules")
+            kinds = ["http_request.path.length() + 1 > http_request.url.length() && client.remote_port % 2 == 0",
+                     '(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && http_request.path + "x" == "/qx"',
+                     '[http_request.host, "zz"].contains(http_request.path)',
+                     'http_request.host < http_request.path && http_request.path < "c"',
+                     "client.remote_port * 2 == 4242 && http_request.url.length() - http_request.path.length() > 300",
+                     '(http_request.path.starts_with("/a") ? http_request.host : http_request.url).ends_with("!")',
+                     "client.remote_port % 7 == 3 && client.remote_port / 7 == 1234",
+                     '{"k": http_request.method}.k == "TRACE"']
+            extra = [(f"residual_{k}", kinds[k % len(kinds)] + (f" && client.remote_port != {k}" if k >= len(kinds) else ""), [1]) for k in range(args.residual)]
+            eng_r = RuleEngine(list(wl.rules) + extra, wl.lists, wl.geoip, **opts)
+            n_res = sum("residual interpreter" in w for w in eng_r.program.warnings())
+            if tune_n:
+                eng_r.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
+            Rr = Runner(eng_r, n, dev, world, 1)
+            el, kt, cnt_r = Rr.timed_run(dbatch, args.steps, 1)
+            sm = Rr.mode_summary(el, kt, args.steps)
+            result["residual"] = {"extra_rules": args.residual, "rules_on_the_interpreter": n_res, "ms_per_step": sm["ms_per_step"], "requests_per_s": sm["requests_per_s"],
+                                  "residual_kernel_ms_per_step": sm["kernels_ms_per_step"].get("residual", 0.0), "delta_ms_vs_headline": sm["ms_per_step"] - 1000.0 * elapsed / args.steps,
+                                  "kernels_ms_per_step": sm["kernels_ms_per_step"], "action_counts_allow_block_captcha_bypass": cnt_r}
+            eng_r.close()
+            del Rr
         if world == 1 and args.config == 3 and not args.no_config5 and extras:
             phase("config 5 leg")
             # (the 10M-request batch and its scratch stay resident: config 5 adds ~6 GB)

@@ -372,6 +372,13 @@ typedef struct pwaf_stats {
         n_confirm_literals /* string predicates decided by the confirm tier of their pass's prefilter, without a DFA */;
 } pwaf_stats;
 int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
+/* Execution-error visibility (the reference logs every rule whose execution errs and treats it as "no match": pingoo/rules.rs:41-45).
+ * Here an error is a no-match too; errors the compiler can see — unknown names, type errors, invalid patterns: nearly all of them,
+ * the context's schema being fixed — are reported ONCE at creation (pwaf_program_warning: "can never match"). What remains are
+ * run-time errors of rules on the per-request interpreter (checked arithmetic: overflow, division by zero; an index computed from a
+ * request value): counted on the device. counts[i] = requests, over every batch this engine has evaluated, for which caller rule i
+ * ended in an execution error. Waits for the device. */
+int pwaf_engine_rule_errors(pwaf_engine *, uint64_t *counts, size_t n_rules);
 /* TEST HOOK (CPU, no device): the bigram prefilter + confirm tier of scan pass `group` over ONE field value placed `arena_offset`
  * bytes into an arena, as the device evaluates it (csrc/confirm.h is the code both run). Writes the local atom ids of the literal
  * predicates confirmed (at most cap; possibly repeated), *n_atoms, *flagged (the filter flagged the field) and *walk (a factor of a

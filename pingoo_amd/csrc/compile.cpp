@@ -1106,6 +1106,8 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         std::string rwhy;
         const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_field(name); }, rwhy);
         if (idx < 0) { why = col_why + "; and the residual interpreter cannot take it either: " + rwhy; return -1; }
+        if (P.residual_rule.size() <= (size_t)idx) P.residual_rule.resize((size_t)idx + 1, 0xFFFFFFFFu);
+        P.residual_rule[(size_t)idx] = (uint32_t)k;
         Atom a;
         a.kind = ATOM_RESIDUAL;
         a.ref = (uint32_t)idx;

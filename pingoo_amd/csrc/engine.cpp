@@ -193,6 +193,7 @@ struct pwaf_engine {
     DevBuf ip_root4, ip_root6, ip_nodes, geo_root4, geo_root6, geo_nodes, geo_recs;
     std::mutex mu;  // guards the context ring and table rebuilds (pwaf_engine_tune)
     std::mutex prof_mu;  // while profiling is on, calls enqueue one at a time: the event / timing tables below are per engine
+    DevBuf residual_errors;  // per residual rule: requests whose evaluation ended in an execution error (accumulated; pwaf_engine_rule_errors)
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
     DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
@@ -1330,6 +1331,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ra.pool_count = (uint32_t *)S.ctrl.p;
         ra.pool_cap = pool_cap;
         ra.status = status_word;
+        ra.rule_errors = (unsigned long long *)e->residual_errors.p;
         if ((rc = mark(nullptr, 0))) return rc;
         int he2 = launch_residual(ra, stream);
         if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
@@ -1714,6 +1716,10 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     }
     if (P.n_residual) {
         UP(residual_blob, P.residual_blob)
+        {
+            const std::vector<unsigned long long> zero(P.n_residual, 0ull);
+            UP(residual_errors, zero)
+        }
         if (P.has_geo && P.residual_needs_geo) {
             // client.asn / client.country VALUES (the class trie above only keeps which predicates hold): the trie with record leaves
             const std::vector<uint32_t> leaf0(65536, TRIE_LEAF);  // record 0 = the default {0, "XX"}
@@ -1782,7 +1788,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.c_head, &g.c_entries, &g.c_bytes, &g.c_classes}) b->release(); g.fl.release(); g.rt.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
-                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
     for (auto &c : e->ctx) c->release();
@@ -1811,6 +1817,20 @@ int pwaf_engine_stats(const pwaf_engine *e, pwaf_stats *out) {
         if (e->groups[k].filtered) out->n_filtered_groups++;
         if (e->groups[k].confirm) out->n_confirm_literals += e->prog.p->groups[k].n_confirm_literals;
     }
+    return PWAF_OK;
+}
+
+int pwaf_engine_rule_errors(pwaf_engine *e, uint64_t *counts, size_t n_rules) {
+    if (!e || (!counts && n_rules)) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    const Program &P = *e->prog.p;
+    for (size_t k = 0; k < n_rules; k++) counts[k] = 0;
+    if (P.n_residual == 0) return PWAF_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());  // (the counters of every batch enqueued so far)
+    std::vector<unsigned long long> dev(P.n_residual);
+    HIP_TRY(hipMemcpy(dev.data(), e->residual_errors.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dev.size() && k < P.residual_rule.size(); k++)
+        if (P.residual_rule[k] < n_rules) counts[P.residual_rule[k]] += dev[k];
     return PWAF_OK;
 }
 

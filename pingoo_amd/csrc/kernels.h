@@ -286,6 +286,7 @@ struct ResidualArgs {
     uint32_t *pool_count;
     uint32_t pool_cap;
     uint32_t *status;
+    unsigned long long *rule_errors;  // [n_rules], accumulated over the engine's batches: requests for which the rule's evaluation ended in an error
 };
 int launch_residual(const ResidualArgs &a, void *stream);
 // The batch's string-column pointer table (ResidualArgs::data / off) on its way to device memory: the by-value argument of a store

@@ -1678,8 +1678,14 @@ __global__ __launch_bounds__(128) void residual_kernel(ResidualArgs a) {
         m.q.asn = asn;
         m.q.country = country;
         Hits h{0, 0, kNone};
-        for (uint32_t k = 0; k < a.n_rules; k++)
-            if (rvm::run_rule(m, k)) h = record_atom(ctx, k, h);
+        for (uint32_t k = 0; k < a.n_rules; k++) {
+            const uint32_t res = rvm::run_rule(m, k);
+            if (res == 1u) h = record_atom(ctx, k, h);
+            // execution errors are COUNTED per rule (the reference logs each one, pingoo/rules.rs:41-45; here: pwaf_engine_rule_errors):
+            // one atomic per wave and rule that saw any
+            const unsigned long long em = __ballot(res == 2u);
+            if (em != 0 && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(em)) atomicAdd(&a.rule_errors[k], (unsigned long long)__builtin_popcountll(em));
+        }
         a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
     }
 }

@@ -265,6 +265,7 @@ struct Program {
     std::vector<uint8_t> residual_blob;  // rvm::Header + sections (empty: none)
     uint32_t n_residual = 0, residual_base = 0;
     bool residual_needs_geo = false;     // some residual rule reads client.asn / client.country
+    std::vector<uint32_t> residual_rule; // per residual rule: the caller's rule index (execution-error counters are reported per caller rule)
     std::vector<int64_t> int_pool;
     std::vector<uint32_t> country_lut_words;  // 22 words per lut
     std::vector<DevRule> rules;               // pseudo rules first, then the caller's rules with an effect

@@ -337,7 +337,9 @@ PWAF_HD Val arith(uint32_t op /* B_ADD.. */, const Val &l, const Val &r, Machine
 
 // ---- the interpreter: one rule, one request ---------------------------------------------------------------------------------------------
 // BinOp numbering of frontend.h: B_OR 0, B_AND 1, B_EQ 2, B_NE 3, B_LT 4, B_LE 5, B_GT 6, B_GE 7, B_IN 8, B_ADD 9, B_SUB 10, B_MUL 11, B_DIV 12, B_MOD 13
-PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
+// 1 = the rule's program ends in Bool(true) (the rule matches), 2 = it ends in an execution ERROR (what the reference logs with warn!
+// and treats as "no match": pingoo/rules.rs:41-45), 0 = anything else (false, or a non-Bool value: no match, no error).
+PWAF_HD_NOINLINE uint32_t run_rule(Machine &m, uint32_t rule) {
     const Ins *code = section<Ins>(m, m.h->code);
     const Val *consts = section<Val>(m, m.h->consts);
     uint32_t pc = section<uint32_t>(m, m.h->rules)[rule];
@@ -348,7 +350,7 @@ PWAF_HD_NOINLINE bool run_rule(Machine &m, uint32_t rule) {
     for (;;) {
         const Ins in = code[pc++];
         switch (in.op) {
-            case R_END: return sp == 1 && st[0].t == T_BOOL && st[0].p == 1;
+            case R_END: return sp != 1 ? 0u : st[0].t == T_ERR ? 2u : (st[0].t == T_BOOL && st[0].p == 1) ? 1u : 0u;
             case R_CONST: st[sp++] = consts[in.b]; break;
             case R_FIELD: st[sp++] = mk(T_STR, m.q.off[in.b][m.q.r + 1] - m.q.off[in.b][m.q.r], (uint64_t)in.b << 48); break;
             case R_COUNTRY: st[sp++] = mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); break;

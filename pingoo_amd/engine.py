@@ -86,6 +86,7 @@ def lib():
     L.pwaf_program_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
     L.pwaf_program_rule_status.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
     L.pwaf_program_confirm_field.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pwaf_engine_rule_errors.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     L.pwaf_engine_create.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
     L.pwaf_engine_destroy.argtypes = [vp]
     L.pwaf_engine_destroy.restype = None
@@ -355,6 +356,15 @@ class RuleEngine:
     @property
     def program(self) -> CompiledProgram:
         return CompiledProgram._borrow(lib().pwaf_engine_program(self._h))
+
+    def rule_errors(self, n_rules: int) -> List[int]:
+        """Per caller rule: requests (over every batch so far) for which the rule's evaluation ended in an execution error — what the
+        reference logs per occurrence (pingoo/rules.rs:41-45). Static errors are creation-time warnings instead."""
+        arr = (C.c_uint64 * n_rules)()
+        rc = lib().pwaf_engine_rule_errors(self._h, arr, n_rules)
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        return list(arr)
 
     def stats(self) -> dict:
         s = _abi.Stats()

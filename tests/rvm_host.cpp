@@ -93,6 +93,6 @@ int rvmh_eval(void *hv, uint32_t rule, const uint8_t *const *data, const uint32_
     m.q.asn = asn;
     m.q.country = country;
     m.heap_n = 0;
-    return rvm::run_rule(m, rule) ? 1 : 0;
+    return (int)rvm::run_rule(m, rule);  // 1 match, 2 execution error, 0 otherwise
 }
 }

@@ -65,3 +65,28 @@ def test_residual_known_answers_and_dnf_explosion_on_the_device():
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "residual rules on the device")
     assert len(set(want["rule_idx"].tolist())) >= 6
     eng.close()
+
+
+def test_execution_errors_are_counted_per_rule():
+    """The reference logs every rule whose execution errs (pingoo/rules.rs:41-45: warn!, no match). Run-time errors only arise on the
+    per-request interpreter (checked arithmetic, computed indexes): the device counts them per caller rule, across batches, and the
+    counts equal the oracle's."""
+    rules = [("div", "client.remote_port / (client.remote_port - 80) == 1", [B]),            # division by zero for port 80
+             ("ovf", "9223372036854775807 + client.remote_port > 0", [B]),                   # overflow unless the port is 0
+             ("idx", '[http_request.host, http_request.path][client.remote_port - 80] == "h"', [B]),  # index out of range unless the port is 80 or 81
+             ("fine", "http_request.path.length() + 1 > http_request.url.length()", [CAP]),
+             ("col", 'http_request.path == "/x"', [B])]
+    eng = RuleEngine(rules)
+    orc = pyoracle.Oracle(rules, flags=0)
+    rng = random.Random(8)
+    reqs = [Request(host="h", path=rng.choice(["/x", "/y"]), url="/y?z=1", user_agent="ua", remote_port=rng.choice([0, 80, 81, 82, 443])) for _ in range(4000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = orc.evaluate(batch)
+    for rounds in (1, 2):
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "errors are no-matches")
+        errs = eng.rule_errors(len(rules))
+        # the oracle's view: a rule errs for a request when execute_rule says 3 (only for requests that REACH it is what a sequential
+        # host would log; the device evaluates every residual rule for every request, so the count is over all requests)
+        expect = [sum(orc.execute_rule(k, batch, i) == 3 for i in range(batch.n)) * rounds for k in range(len(rules))]
+        assert errs == expect and errs[0] > 0 and errs[1] > 0 and errs[2] > 0 and errs[3] == 0 and errs[4] == 0, (errs, expect)
+    eng.close()

@@ -92,12 +92,16 @@ class HostVM:
         self._off = (C.c_void_p * len(cols))(*[o.ctypes.data for _, o in cols])
         self._batch = batch
 
-    def eval(self, rule: int, i: int, asn=None, country=None) -> bool:
+    def eval3(self, rule: int, i: int, asn=None, country=None) -> int:
+        """1 = the rule matches (Bool(true)), 2 = its evaluation ends in an execution error, 0 = anything else."""
         b = self._batch
         if asn is None:
             asn = int(b.asn[i]) if b.asn is not None else 0
             country = int(b.country[i]) if b.country is not None else int.from_bytes(b"XX", "little")
-        return bool(vm().rvmh_eval(self._h, rule, self._data, self._off, i, b.ip[i].ctypes.data, int(b.ip_is_v6[i]), int(b.port[i]), asn, country))
+        return int(vm().rvmh_eval(self._h, rule, self._data, self._off, i, b.ip[i].ctypes.data, int(b.ip_is_v6[i]), int(b.port[i]), asn, country))
+
+    def eval(self, rule: int, i: int, asn=None, country=None) -> bool:
+        return self.eval3(rule, i, asn, country) == 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -252,7 +256,10 @@ def test_every_expression_of_the_general_fuzzer_runs_in_the_interpreter(seed):
         orc = pyoracle.Oracle([("r", e, [H.B])], lists, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
         m.bind(batch)
         for i in range(batch.n):
-            assert m.eval(0, i) == (orc.execute_rule(0, batch, i) == 1), (seed, e, i, [batch.field_bytes(f, i) for f in range(5)])
+            want3 = orc.execute_rule(0, batch, i)  # 1 true, 0 false, 2 non-Bool, 3 error
+            got3 = m.eval3(0, i)
+            assert (got3 == 1) == (want3 == 1), (seed, e, i, [batch.field_bytes(f, i) for f in range(5)])
+            assert (got3 == 2) == (want3 == 3), ("execution errors are counted per rule: the interpreter and the oracle must agree on them", seed, e, i, got3, want3)
 
 
 def test_residual_known_answers():
