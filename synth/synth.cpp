@@ -160,7 +160,7 @@ static void gen_header(const Config &c, uint64_t idx, int k, std::string &out) {
     if (!r.chance(0.7)) return;  // header absent = empty string
     out = c.header_vals[r.below(400)];
     if (r.chance(0.004)) out += ";" + c.rare[r.below(3000)];  // a rare word now and then (rules target them)
-    if (c.mode == 1 && !c.literals.empty() && r.chance(0.25)) {
+    if ((c.mode & 1) && !c.literals.empty() && r.chance(0.25)) {
         // adversarial: a near miss of a rule literal on this very header (or of any literal): all but its last one or two bytes
         for (int tries = 0; tries < 4; tries++) {
             const auto &lit = c.literals[r.below((uint32_t)c.literals.size())];
@@ -236,7 +236,7 @@ static void gen_request(const Config &c, uint64_t idx, Req &q) {
     else if (ur < 0.002) q.ua = std::string(256 + r.below(40), 'A');
     else if (ur < 0.004) q.ua = c.rare_uas[r.below(64)];
     else q.ua = c.uas[r.below(200)];
-    if (c.mode == 1 && !c.literals.empty()) {
+    if ((c.mode & 1) && !c.literals.empty()) {
         // adversarial stream (BASELINE.json configs[4]): near misses of the rule literals (everything but the last byte or two), long
         // runs that keep regex states busy, User-Agent / path / url at their maximum lengths
         auto near_miss = [&](int field) -> std::string {
@@ -260,6 +260,12 @@ static void gen_request(const Config &c, uint64_t idx, Req &q) {
         if (q.ua.size() > 255) q.ua.resize(255);
         if (q.host.size() > 64) q.host.resize(64);
         while (!q.path.empty() && q.path.back() == '/') q.path.pop_back();
+    }
+    // mode bit 1: the url as an HTTP/2 listener hands it over — Display(Uri) of a Uri rebuilt from :scheme / :authority / :path is the
+    // ABSOLUTE form (pingoo/serde_utils.rs:16-18); `path` is unaffected
+    if (c.mode & 2) {
+        q.url = "https://" + q.host + q.url;
+        if (q.url.size() > 600) q.url.resize(600);
     }
     // client
     memset(q.ip, 0, 16);
@@ -498,7 +504,7 @@ static Config *make_config(int id, uint64_t seed) {
 extern "C" {
 
 void *synth_create(int config_id, uint64_t seed) { return make_config(config_id, seed); }
-// 0 = benign stream, 1 = adversarial stream (near misses of the rule literals, maximum-length fields, regex-state-heavy inputs)
+// bit 0: adversarial stream (near misses of the rule literals, maximum-length fields, regex-state-heavy inputs); bit 1: absolute-form urls (HTTP/2)
 void synth_set_mode(void *h, int mode) { ((Config *)h)->mode = mode; }
 int synth_header_count(void *h) { return ((Config *)h)->n_headers; }
 const char *synth_header_name(void *h, int k) { return ((Config *)h)->header_names[(size_t)k].c_str(); }

@@ -60,8 +60,33 @@ META = (b"\xAB\xCD\xEFMaxMind.com"
 
 MMDB = TREE + SEPARATOR + DATA + META
 
+
+# ---- the same tree with 28- and 32-bit records (round 4: geoip.rs:57 reads whatever record size the file declares; the fixture above
+#      only pinned 24). "Binary Search Tree Section":
+#        28 bits: a node is 7 bytes — left[23..0] (3 bytes), one byte holding left[27..24] in its HIGH nibble and right[27..24] in its
+#                 LOW nibble, right[23..0] (3 bytes);
+#        32 bits: a node is 8 bytes — left and right, 4 bytes each, big endian.
+def node28(left: int, right: int) -> bytes:
+    return rec24(left & 0xFFFFFF) + bytes([((left >> 24) & 0xF) << 4 | ((right >> 24) & 0xF)]) + rec24(right & 0xFFFFFF)
+
+
+def node32(left: int, right: int) -> bytes:
+    return left.to_bytes(4, "big") + right.to_bytes(4, "big")
+
+
+NODES = [(1, PTR_A), (NO_DATA, 2), (PTR_B, PTR_C)]
+TREE28 = b"".join(node28(l, r) for l, r in NODES)
+TREE32 = b"".join(node32(l, r) for l, r in NODES)
+assert len(TREE28) == NODE_COUNT * 7 and len(TREE32) == NODE_COUNT * 8
+assert TREE28[:7] == bytes([0, 0, 1, 0x00, 0, 0, PTR_A]) and TREE32[:8] == bytes([0, 0, 0, 1, 0, 0, 0, PTR_A])
+assert META.endswith(b"\x4Brecord_size" b"\xA1\x18")
+MMDB28 = TREE28 + SEPARATOR + DATA + META[:-1] + b"\x1C"  # record_size = 28
+MMDB32 = TREE32 + SEPARATOR + DATA + META[:-1] + b"\x20"  # record_size = 32
+FIXTURES = {"handmade_v4.mmdb": MMDB, "handmade_v4_rs28.mmdb": MMDB28, "handmade_v4_rs32.mmdb": MMDB32}
+
 if __name__ == "__main__":
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "handmade_v4.mmdb")
-    with open(out, "wb") as f:
-        f.write(MMDB)
-    print(out, len(MMDB), "bytes")
+    for name, blob in FIXTURES.items():
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
+        with open(out, "wb") as f:
+            f.write(blob)
+        print(out, len(blob), "bytes")

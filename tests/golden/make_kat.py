@@ -136,6 +136,20 @@ CASES = [
         requests=[req(host="api.example.com"), req(host="www.example.com"), req(host="api")],
         expect=[[BLOCK, 0], [ALLOW, NONE], [ALLOW, NONE]],
     ),
+    dict(
+        name="K13_absolute_form_url_on_http2",
+        source="pingoo/serde_utils.rs:16-18: `url` serialises Display(Uri). An HTTP/1 request line carries the origin form (/p?q); an HTTP/2 "
+               "request's Uri is rebuilt from :scheme, :authority and :path, so its Display is the ABSOLUTE form (https://host/p?q). A rule "
+               "that anchors on the url's first bytes therefore behaves differently per protocol, while `path` (uri.path(), "
+               "http_utils.rs:114-116) is the same in both: the engine takes whatever the host derived, it does not normalise",
+        rules=[["url_prefix", 'http_request.url.starts_with("/admin")', [B]], ["path_prefix", 'http_request.path.starts_with("/admin")', [CAP]],
+               ["url_contains", 'http_request.url.contains("/admin?")', [B]]],
+        requests=[req(url="/admin/x?y=1", path="/admin/x"),                               # h1: origin form -> the url rule decides
+                  req(url="https://example.com/admin/x?y=1", path="/admin/x"),             # h2: absolute form -> only the path rule sees a prefix
+                  req(url="https://example.com/admin?y=1", path="/admin", captcha_verified=True),  # h2, verified client: captcha skipped, the contains rule blocks
+                  req(url="https://example.com/public", path="/public")],
+        expect=[[BLOCK, 0], [CAPTCHA, 1], [BLOCK, 2], [ALLOW, NONE]],
+    ),
 ]
 
 # Field-derivation vectors (what the listener does BEFORE building RequestData). Inputs are raw header bytes as

@@ -250,3 +250,19 @@ def test_missing_library_or_device_is_loud(monkeypatch):
         eng.evaluate_batch(bad)
     assert ei.value.code == _abi.E_BATCH
     eng.close()
+
+
+def test_absolute_form_urls_http2_stream_on_the_device():
+    """The 1k-rule set on 30 000 requests whose `url` is the absolute form an HTTP/2 listener derives (pingoo/serde_utils.rs:16-18:
+    Display(Uri)): longer URL fields that begin with scheme and host — HIP engine vs oracle, untuned and tuned on origin-form traffic."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    batch = w.batch(700_000, 30_000, absolute_url=True)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=16)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "absolute-form urls, untuned")
+    eng.tune(w.batch(5_000_000, 16384))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "absolute-form urls, tuned on origin-form traffic")
+    assert np.count_nonzero(want["action"]) > 100
+    eng.close()

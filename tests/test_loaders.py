@@ -219,17 +219,19 @@ def zstd_compress(data: bytes) -> bytes:
     return buf.raw[:n]
 
 
-def test_mmdb_reader_against_a_hand_assembled_file():
-    """tests/golden/handmade_v4.mmdb was written byte by byte from the public MaxMind DB spec (tests/golden/make_handmade_mmdb.py cites
-    the section per field), not by the repo's own writer: 128.0.0.0/1 -> AS64500 FR, 64.0.0.0/3 -> AS15169 US, 96.0.0.0/3 -> a record
-    whose country fails validation (-> the default record), 0.0.0.0/2 -> no data."""
+@pytest.mark.parametrize("name", ["handmade_v4.mmdb", "handmade_v4_rs28.mmdb", "handmade_v4_rs32.mmdb"])
+def test_mmdb_reader_against_a_hand_assembled_file(name):
+    """tests/golden/handmade_v4*.mmdb were written byte by byte from the public MaxMind DB spec (tests/golden/make_handmade_mmdb.py cites
+    the section per field), not by the repo's own writer — with 24-, 28- and 32-bit search-tree records (geoip.rs:57 reads whatever
+    the file declares): 128.0.0.0/1 -> AS64500 FR, 64.0.0.0/3 -> AS15169 US, 96.0.0.0/3 -> a record whose country fails validation
+    (-> the default record), 0.0.0.0/2 -> no data."""
     here = os.path.dirname(os.path.abspath(__file__))
-    blob = open(os.path.join(here, "golden", "handmade_v4.mmdb"), "rb").read()
+    blob = open(os.path.join(here, "golden", name), "rb").read()
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_handmade_mmdb", os.path.join(here, "golden", "make_handmade_mmdb.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert blob == mod.MMDB, "the committed fixture is not what the script assembles"
+    assert blob == mod.FIXTURES[name], "the committed fixture is not what the script assembles"
     got = table_set(geoip_from_mmdb(blob))
     assert got == {(bytes([128, 0, 0, 0]), 1, 0, 64500, b"FR"), (bytes([64, 0, 0, 0]), 3, 0, 15169, b"US"), (bytes([96, 0, 0, 0]), 3, 0, 0, b"XX")}
     # and through the oracle's longest-prefix lookup: addresses inside / outside the three networks
