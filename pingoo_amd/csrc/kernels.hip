@@ -1640,13 +1640,7 @@ int launch_fcmp(const FcmpArgs &a, void *stream) {
 
 // residual_kernel: the rules no column form exists for (residual.h), interpreted with one lane per request. The interpreter's value
 // stack and heap live in the lane's private memory: this is the slow path by design (a rule set without such rules never launches it).
-struct ResidualLdsStack {  // slot i of lane t at [i][t]: neighbouring lanes, neighbouring banks
-    rvm::Val *base;
-    __device__ __forceinline__ rvm::Val &at(uint32_t i) { return base[i * 128u]; }
-};
 __global__ __launch_bounds__(128) void residual_kernel(ResidualArgs a) {
-    __shared__ rvm::Val stack_lds[rvm::kStack * 128];  // the lanes' value stacks (48 KiB per workgroup): see rvm::run_rule_on
-    ResidualLdsStack st{stack_lds + threadIdx.x};
     const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
     rvm::Machine m;
     m.blob = a.blob;
@@ -1685,7 +1679,7 @@ __global__ __launch_bounds__(128) void residual_kernel(ResidualArgs a) {
         m.q.country = country;
         Hits h{0, 0, kNone};
         for (uint32_t k = 0; k < a.n_rules; k++) {
-            const uint32_t res = rvm::run_rule_on(m, k, st);
+            const uint32_t res = rvm::run_rule(m, k);
             if (res == 1u) h = record_atom(ctx, k, h);
             // execution errors are COUNTED per rule (the reference logs each one, pingoo/rules.rs:41-45; here: pwaf_engine_rule_errors):
             // one atomic per wave and rule that saw any

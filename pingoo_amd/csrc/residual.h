@@ -339,87 +339,80 @@ PWAF_HD Val arith(uint32_t op /* B_ADD.. */, const Val &l, const Val &r, Machine
 // BinOp numbering of frontend.h: B_OR 0, B_AND 1, B_EQ 2, B_NE 3, B_LT 4, B_LE 5, B_GT 6, B_GE 7, B_IN 8, B_ADD 9, B_SUB 10, B_MUL 11, B_DIV 12, B_MOD 13
 // 1 = the rule's program ends in Bool(true) (the rule matches), 2 = it ends in an execution ERROR (what the reference logs with warn!
 // and treats as "no match": pingoo/rules.rs:41-45), 0 = anything else (false, or a non-Bool value: no match, no error).
-// The value stack lives where the caller puts it (ST::at(i)): the host test build and the default device form keep it in the lane's
-// private memory; residual_kernel keeps it in LDS — a private-memory access is a trip through the vector memory path (~1 us under
-// load) and the interpreter makes several per instruction: measured 29 us per rule and request, 17 ms for 8 rules x 10M requests.
-struct PrivateStack {
-    Val v[kStack];
-    PWAF_HD Val &at(uint32_t i) { return v[i]; }
-};
-template <class ST>
-PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
+PWAF_HD_NOINLINE uint32_t run_rule(Machine &m, uint32_t rule) {
     const Ins *code = section<Ins>(m, m.h->code);
     const Val *consts = section<Val>(m, m.h->consts);
     uint32_t pc = section<uint32_t>(m, m.h->rules)[rule];
+    Val st[kStack];
     uint32_t sp = 0;
     m.heap_n = 0;
     const Val ERR = mk(T_ERR);
     for (;;) {
         const Ins in = code[pc++];
         switch (in.op) {
-            case R_END: return sp != 1 ? 0u : st.at(0).t == T_ERR ? 2u : (st.at(0).t == T_BOOL && st.at(0).p == 1) ? 1u : 0u;
-            case R_CONST: st.at(sp++) = consts[in.b]; break;
-            case R_FIELD: st.at(sp++) = mk(T_STR, m.q.off[in.b][m.q.r + 1] - m.q.off[in.b][m.q.r], (uint64_t)in.b << 48); break;
-            case R_COUNTRY: st.at(sp++) = mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); break;
-            case R_PORT: st.at(sp++) = mk_int((int64_t)m.q.port); break;
-            case R_ASN: st.at(sp++) = mk_int((int64_t)m.q.asn); break;
-            case R_IP: st.at(sp++) = mk(T_IP); break;
-            case R_CLIST: st.at(sp++) = mk(T_CLIST, in.b); break;
+            case R_END: return sp != 1 ? 0u : st[0].t == T_ERR ? 2u : (st[0].t == T_BOOL && st[0].p == 1) ? 1u : 0u;
+            case R_CONST: st[sp++] = consts[in.b]; break;
+            case R_FIELD: st[sp++] = mk(T_STR, m.q.off[in.b][m.q.r + 1] - m.q.off[in.b][m.q.r], (uint64_t)in.b << 48); break;
+            case R_COUNTRY: st[sp++] = mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); break;
+            case R_PORT: st[sp++] = mk_int((int64_t)m.q.port); break;
+            case R_ASN: st[sp++] = mk_int((int64_t)m.q.asn); break;
+            case R_IP: st[sp++] = mk(T_IP); break;
+            case R_CLIST: st[sp++] = mk(T_CLIST, in.b); break;
             case R_NOT: {
-                Val &x = st.at(sp - 1);
+                Val &x = st[sp - 1];
                 if (x.t == T_ERR) break;
                 x = x.t == T_BOOL ? mk_bool(x.p == 0) : ERR;
                 break;
             }
             case R_NEG: {
-                Val &x = st.at(sp - 1);
+                Val &x = st[sp - 1];
                 if (x.t == T_INT) x = (int64_t)x.p == INT64_MIN ? ERR : mk_int(-(int64_t)x.p);
                 else if (x.t == T_FLT) x = mk_flt(-as_flt(x));
                 else x = ERR;
                 break;
             }
             case R_AND_L: case R_OR_L: {
-                const Val l = st.at(--sp);
-                if (l.t == T_ERR || l.t != T_BOOL) { st.at(sp++) = ERR; pc = in.b; break; }
-                if ((in.op == R_OR_L) == (l.p != 0)) { st.at(sp++) = l; pc = in.b; }  // decided by the left operand
+                const Val l = st[--sp];
+                if (l.t == T_ERR || l.t != T_BOOL) { st[sp++] = ERR; pc = in.b; break; }
+                if ((in.op == R_OR_L) == (l.p != 0)) { st[sp++] = l; pc = in.b; }  // decided by the left operand
                 break;
             }
             case R_BOOL_CHK: {
-                Val &x = st.at(sp - 1);
+                Val &x = st[sp - 1];
                 if (x.t != T_BOOL) x = ERR;
                 break;
             }
             case R_COND: {
-                const Val c = st.at(--sp);
-                if (c.t != T_BOOL) { st.at(sp++) = ERR; pc = code[in.b - 1].b; break; }  // (the instruction before the else branch is the then-branch's R_JMP to the end)
+                const Val c = st[--sp];
+                if (c.t != T_BOOL) { st[sp++] = ERR; pc = code[in.b - 1].b; break; }  // (the instruction before the else branch is the then-branch's R_JMP to the end)
                 if (c.p == 0) pc = in.b;
                 break;
             }
             case R_JMP: pc = in.b; break;
-            case R_FAIL: sp -= in.b; st.at(sp++) = ERR; break;
+            case R_FAIL: sp -= in.b; st[sp++] = ERR; break;
             case R_MKLIST: {
                 const uint32_t n = in.b;
                 bool err = false;
-                for (uint32_t k = 0; k < n; k++) err = err || st.at(sp - n + k).t == T_ERR;
+                for (uint32_t k = 0; k < n; k++) err = err || st[sp - n + k].t == T_ERR;
                 Val v = ERR;
                 if (!err && m.heap_n + n <= kHeap) {  // (the compiler bounds heap use statically; the checks here are the safety net behind it)
                     v = mk(T_LIST, n, kHeapBit | m.heap_n);
-                    for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = st.at(sp - n + k);
+                    for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = st[sp - n + k];
                 }
                 sp -= n;
-                st.at(sp++) = v;
+                st[sp++] = v;
                 break;
             }
             case R_MKMAP: {
                 const uint32_t n = in.b;
                 bool err = false;
-                for (uint32_t k = 0; k < 2 * n; k++) err = err || st.at(sp - 2 * n + k).t == T_ERR || ((k & 1) == 0 && st.at(sp - 2 * n + k).t != T_STR);
+                for (uint32_t k = 0; k < 2 * n; k++) err = err || st[sp - 2 * n + k].t == T_ERR || ((k & 1) == 0 && st[sp - 2 * n + k].t != T_STR);
                 Val v = ERR;
                 if (!err && m.heap_n + 2 * n <= kHeap) {
                     const uint32_t base = m.heap_n;
                     uint32_t cnt = 0;
                     for (uint32_t k = 0; k < n; k++) {
-                        const Val &key = st.at(sp - 2 * n + 2 * k), &val = st.at(sp - 2 * n + 2 * k + 1);
+                        const Val &key = st[sp - 2 * n + 2 * k], &val = st[sp - 2 * n + 2 * k + 1];
                         bool dup = false;
                         for (uint32_t j = 0; j < cnt && !dup; j++)
                             if (m.heap[base + 2 * j].a == key.a && str_eq_at(m, m.heap[base + 2 * j], 0, key)) { m.heap[base + 2 * j + 1] = val; dup = true; }
@@ -429,11 +422,11 @@ PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
                     v = mk(T_MAP, cnt, kHeapBit | base);
                 }
                 sp -= 2 * n;
-                st.at(sp++) = v;
+                st[sp++] = v;
                 break;
             }
             case R_INDEX: {
-                const Val i = st.at(--sp), o = st.at(--sp);
+                const Val i = st[--sp], o = st[--sp];
                 Val v = ERR;
                 if (o.t == T_ERR || i.t == T_ERR) {}
                 else if (o.t == T_MAP) { if (i.t == T_STR) { Val out; if (map_has(m, o, i, &out)) v = out; } }
@@ -446,11 +439,11 @@ PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
                         else v = mk(T_NET, 0, d.first + i.p);
                     }
                 }
-                st.at(sp++) = v;
+                st[sp++] = v;
                 break;
             }
             case R_SELECT: {
-                Val &o = st.at(sp - 1);
+                Val &o = st[sp - 1];
                 if (o.t == T_ERR) break;
                 Val out = ERR;
                 if (o.t == T_MAP) { Val got; if (map_has(m, o, consts[in.b], &got)) out = got; }
@@ -460,11 +453,11 @@ PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
             case R_CALL: {
                 const uint32_t argc = in.b >> 12, aux = in.b & 0xFFFu;
                 bool err = false;
-                for (uint32_t k = 0; k <= argc; k++) err = err || st.at(sp - 1 - argc + k).t == T_ERR;
-                const Val recv = st.at(sp - 1 - argc), arg = argc ? st.at(sp - argc) : ERR;
+                for (uint32_t k = 0; k <= argc; k++) err = err || st[sp - 1 - argc + k].t == T_ERR;
+                const Val recv = st[sp - 1 - argc], arg = argc ? st[sp - argc] : ERR;
                 sp -= argc + 1;
                 Val v = ERR;
-                if (err) { st.at(sp++) = v; break; }
+                if (err) { st[sp++] = v; break; }
                 switch (in.a) {
                     case FN_CONTAINS:
                         if (argc != 1) break;
@@ -488,13 +481,13 @@ PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
                         break;
                     default: break;
                 }
-                st.at(sp++) = v;
+                st[sp++] = v;
                 break;
             }
             case R_BIN: {
-                const Val r = st.at(--sp), l = st.at(--sp);
+                const Val r = st[--sp], l = st[--sp];
                 Val v = ERR;
-                if (l.t == T_ERR || r.t == T_ERR) { st.at(sp++) = v; break; }
+                if (l.t == T_ERR || r.t == T_ERR) { st[sp++] = v; break; }
                 switch (in.a) {
                     case 2: v = mk_bool(val_eq(m, l, r)); break;
                     case 3: v = mk_bool(!val_eq(m, l, r)); break;
@@ -509,16 +502,12 @@ PWAF_HD_NOINLINE uint32_t run_rule_on(Machine &m, uint32_t rule, ST &st) {
                         break;
                     default: v = arith(in.a, l, r, m); break;
                 }
-                st.at(sp++) = v;
+                st[sp++] = v;
                 break;
             }
             default: return false;
         }
     }
-}
-PWAF_HD_NOINLINE uint32_t run_rule(Machine &m, uint32_t rule) {
-    PrivateStack st;
-    return run_rule_on(m, rule, st);
 }
 
 PWAF_HD Val arith(uint32_t op, const Val &l, const Val &r, Machine &m) {
