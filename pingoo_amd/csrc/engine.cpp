@@ -805,11 +805,11 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.cand_bits = (const uint32_t *)S.cand_bits.p;
     v.visit_bits = (const uint32_t *)S.visit_bits.p;
     v.bit_words = bit_words;
-    // A pass with heads writes records outside its candidate list too (zeroed, read densely); a confirm tier MERGES hits into zeroed
-    // records. Passes are laid out so that the filtered ones are neighbours: runs of passes to zero take ONE memset each (69 memsets of
-    // 4 MB were 0.3 ms of the 4096-rule set's 1.4 ms step).
+    // A pass with heads writes records outside its candidate list too: zeroed here, read densely. (A confirm tier MERGES hits into zeroed
+    // records: resolve_kernel zeroes the records of the requests that have a flagged chunk — the only ones a hit can land in.) Passes are
+    // laid out so that the filtered ones are neighbours: runs of passes to zero take ONE memset each.
     for (size_t k = 0; k < e->groups.size();) {
-        auto zeroed = [&](size_t q) { return e->groups[q].filtered && (!e->groups[q].filter.heads.empty() || e->groups[q].confirm); };
+        auto zeroed = [&](size_t q) { return e->groups[q].filtered && !e->groups[q].filter.heads.empty(); };
         if (!zeroed(k)) { k++; continue; }
         size_t k1 = k;
         while (k1 < e->groups.size() && zeroed(k1)) k1++;

@@ -1847,6 +1847,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             if (r2 < a.n) { s_n = a.off[r2]; e_n = a.off[r2 + 1]; }
         }
         if (a.pairs != nullptr) {
+            // A request with a flagged chunk among its own gets its hit record ZEROED here (confirm_kernel merges hits into it; the verdict
+            // kernel only reads records whose valid bit a hit or a walk set — which implies a flagged chunk): one store per such request
+            // instead of a memset of the pass's every record (69 passes x 4 MB per batch of the 4096-rule set). A pass with filter
+            // heads keeps the host's memset: its records are written outside the flagged requests too.
+            if (a.n_heads == 0 && live && e > s) {
+                const uint32_t g_lo = s >> 4, g_hi = (e - 1u) >> 4;
+                if (g_hi >= c_first && g_lo < c_first + kChunks) {
+                    const uint32_t y0 = g_lo > c_first ? g_lo - c_first : 0u, y1 = min(g_hi - c_first, kChunks - 1u);
+                    if (rank_of(y1 + 1u) != rank_of(y0)) a.rec[r] = 0u;
+                }
+            }
             // the flagged chunks whose first byte lies in this request (clipped to the slab)
             if (live && e > s) {
                 const uint32_t f_lo = (s + 15u) >> 4, f_hi = (e - 1u) >> 4;
