@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define PWAF_ABI_VERSION 2u /* 2: pwaf_batch carries header columns; strict rule compilation by default (PWAF_OPT_LENIENT, PWAF_W_PARTIAL);
-                            * residual rules; pwaf_request carries header values; pwaf_node_evaluate_device; pwaf_program_tune */
+#define PWAF_ABI_VERSION 3u /* 2: pwaf_batch carries header columns; strict rule compilation by default (PWAF_OPT_LENIENT, PWAF_W_PARTIAL);
+                            * residual rules; pwaf_request carries header values; pwaf_node_evaluate_device; pwaf_program_tune
+                            * 3: page-locked host memory for batch columns (pwaf_host_alloc / _register); no struct changed */
 
 /* ---- status codes ------------------------------------------------------------------ */
 #define PWAF_OK 0
@@ -280,6 +281,16 @@ void *pwaf_engine_stream(const pwaf_engine *); /* hipStream_t the synchronous en
  * before the call returns: PWAF_E_NOMEM is only reported when that does not help. */
 int pwaf_evaluate_batch(pwaf_engine *, const pwaf_batch *in, pwaf_verdict *out, pwaf_counts *counts);
 
+/* Page-locked host memory for the columns of HOST batches (ABI 3). Where the reference's listener has the request's bytes when the
+ * rule loop runs (http_listener.rs:206-219) is host memory; a host that parses into arenas from pwaf_host_alloc (or registers its own
+ * with pwaf_host_register) lets pwaf_evaluate_batch's copies run at the link's speed: the copy engine reads such memory directly and
+ * the calling thread validates the batch meanwhile. Pageable columns still work (the runtime stages them: slower). Small host batches
+ * (under 1 MiB: the micro-batcher's) are packed into one page-locked block inside the engine whatever the caller's memory is. */
+int pwaf_host_alloc(size_t bytes, void **out);
+void pwaf_host_free(void *);
+int pwaf_host_register(void *p, size_t bytes);
+int pwaf_host_unregister(void *p);
+
 /* Asynchronous device-resident evaluation on a caller-supplied HIP stream (hipStream_t as void*, passed through
  * unchanged: NULL is HIP's default stream; pwaf_engine_stream() returns the engine's own non-blocking stream). All pointers (batch columns, out, counts, match_idx, n_matches)
  * are device pointers. `match_idx`/`n_matches` (nullable) receive the compacted indices of
@@ -342,8 +353,9 @@ void pwaf_node_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t 
 /* ---- deadline micro-batcher ------------------------------------------------------ */
 /* The reference evaluates rules once per request on the tokio worker that owns the connection (http_listener.rs:196-264); a
  * drop-in RuleEngine::evaluate(Request) -> Action keeps that call shape. The batcher gathers concurrent callers: each call blocks
- * until its batch — closed when it holds max_batch requests or its oldest request has waited max_delay_us — has gone through
- * pwaf_evaluate_batch. Thread-safe; one dispatcher thread per batcher. Destroy it before the engine. */
+ * until its batch — closed when it holds max_batch requests, when its oldest request has waited max_delay_us, or (early close) when
+ * every caller currently inside the call is already waiting in a batch and the oldest has waited max_delay_us / 8: callers block, so
+ * nobody else can join before somebody is answered — has gone through pwaf_evaluate_batch. Thread-safe; one dispatcher thread per batcher. Destroy it before the engine. */
 typedef struct pwaf_batcher pwaf_batcher;
 int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_delay_us, pwaf_batcher **out);
 int pwaf_batcher_evaluate(pwaf_batcher *, const pwaf_request *req, pwaf_verdict *out);

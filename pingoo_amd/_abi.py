@@ -5,7 +5,7 @@ Kept in one place so the product wrapper (pingoo_amd.engine) and the test-side o
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 E_INVALID_ARG = -1

@@ -166,6 +166,38 @@ class RequestBatch:
         assert not self.headers, "tile(): header columns are not supported"
         return RequestBatch(datas, offs, rep(self.ip), rep(self.ip_is_v6), rep(self.port), rep(self.flags), rep(self.asn), rep(self.country))
 
+    def _arrays(self):
+        out = list(self.data) + list(self.offsets) + [self.ip, self.ip_is_v6, self.port, self.flags]
+        out += [a for a in (self.asn, self.country) if a is not None]
+        for d, o in self.headers.values():
+            out += [d, o]
+        return [a for a in out if a.nbytes]
+
+    def page_lock(self) -> "RequestBatch":
+        """Registers every column with the HIP runtime (pwaf_host_register): the copy engine then reads the arrays where they are.
+        What a host that parses requests into pwaf_host_alloc arenas gets without this call. Undo with page_unlock()."""
+        from . import engine
+
+        L = engine.lib()
+        done = getattr(self, "_locked", [])
+        for a in self._arrays():
+            if any(a is b for b in done):
+                continue
+            rc = L.pwaf_host_register(a.ctypes.data, a.nbytes)
+            if rc != 0:
+                raise RuntimeError("pwaf_host_register failed: " + L.pwaf_last_error().decode(errors="replace"))
+            done.append(a)
+        self._locked = done
+        return self
+
+    def page_unlock(self) -> None:
+        from . import engine
+
+        L = engine.lib()
+        for a in getattr(self, "_locked", []):
+            L.pwaf_host_unregister(a.ctypes.data)
+        self._locked = []
+
     def algorithmic_bytes(self) -> int:
         """sum(field bytes) + 4*(5+1) offset bytes + 22 B numerics + 8 B verdict per request
         (+6 B when GeoIP is precomputed on the host)."""

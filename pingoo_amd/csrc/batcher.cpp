@@ -41,7 +41,7 @@ struct Slot {  // a batch being filled (struct of arrays, exactly the pwaf_batch
     std::vector<uint16_t> port, country;
     std::vector<uint32_t> asn;
     uint32_t n = 0;
-    Clock::time_point deadline;
+    Clock::time_point deadline, first;  // first: when the batch's oldest request arrived
     std::shared_ptr<Generation> gen = std::make_shared<Generation>();
     void reset(size_t n_cols) {
         data.assign(n_cols, {});
@@ -65,6 +65,12 @@ struct pwaf_batcher {
     bool stop = false;
     uint64_t n_batches = 0, n_requests = 0;
     uint32_t active = 0;  // callers inside pwaf_batcher_evaluate: destroy waits for them
+    uint32_t in_flight = 0;  // requests of the batches being evaluated right now
+    // Early close: callers BLOCK in pwaf_batcher_evaluate, so once every caller inside the call sits in a slot or in a batch under
+    // evaluation, nobody else can join until somebody is answered — waiting out the deadline then only adds latency. Such a batch is
+    // closed after a short gather window (an eighth of the deadline: woken callers re-enter over a few tens of microseconds), a batch
+    // that others may still join at its deadline, as before.
+    std::chrono::microseconds grace{0};
     // two dispatchers: while one waits for its batch on the device, the other closes and submits the next one (the engine's per-call
     // contexts let their copies and kernels overlap)
     std::thread worker[2];
@@ -76,10 +82,13 @@ struct pwaf_batcher {
             int due = -1;
             Clock::time_point wake = Clock::time_point::max();
             const auto now = Clock::now();
+            const bool all_here = slot[0].n + slot[1].n + in_flight >= active;
             for (int s = 0; s < 2; s++) {
                 if (slot[s].n == 0) continue;
-                if (slot[s].n >= max_batch || slot[s].deadline <= now || stop) { due = s; break; }
-                if (slot[s].deadline < wake) wake = slot[s].deadline;
+                Clock::time_point close_at = slot[s].deadline;
+                if (all_here) close_at = std::min(close_at, slot[s].first + grace);
+                if (slot[s].n >= max_batch || close_at <= now || stop) { due = s; break; }
+                if (close_at < wake) wake = close_at;
             }
             if (due < 0) {
                 if (stop) return;
@@ -90,6 +99,7 @@ struct pwaf_batcher {
             Slot b = std::move(slot[due]);
             slot[due] = Slot();
             slot[due].reset(n_cols);
+            in_flight += b.n;
             lk.unlock();
             // evaluate outside the lock: callers keep filling the next batch meanwhile
             pwaf_batch pb{};
@@ -137,6 +147,7 @@ struct pwaf_batcher {
             b.gen->done = true;
             n_batches++;
             n_requests += b.n;
+            in_flight -= b.n;
             cv_done.notify_all();
         }
     }
@@ -151,6 +162,7 @@ int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_de
     b->engine = engine;
     b->max_batch = max_batch;
     b->max_delay = std::chrono::microseconds(max_delay_us);
+    b->grace = std::chrono::microseconds(max_delay_us / 8);
     b->n_cols = PWAF_N_FIELDS + (size_t)pwaf_engine_header_count(engine);
     b->slot[0].reset(b->n_cols);
     b->slot[1].reset(b->n_cols);
@@ -232,8 +244,11 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
                     }
                     idx = t.n++;
                     gen = t.gen;
-                    if (idx == 0) t.deadline = Clock::now() + b->max_delay;
-                    if (idx == 0 || t.n >= b->max_batch) b->cv_work.notify_one();
+                    if (idx == 0) {
+                        t.first = Clock::now();
+                        t.deadline = t.first + b->max_delay;
+                    }
+                    b->cv_work.notify_one();  // (every arrival can complete the "everyone is here" condition)
                     b->cv_done.wait(lk, [&] { return gen->done; });
                 }
             }
@@ -242,6 +257,7 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
             emsg = std::string("micro-batcher: ") + ex.what();
         }
         b->active--;
+        if (b->slot[0].n + b->slot[1].n) b->cv_work.notify_one();  // (a caller leaving can complete the "everyone is here" condition)
         if (b->active == 0) b->cv_done.notify_all();
     }
     if (rc != PWAF_OK) return fail(rc, emsg);

@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,6 +62,28 @@ struct DevBuf {
     }
     void release() {
         if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Page-locked host memory the device reads / writes directly: staging of small host batches, status words on their way back.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return PWAF_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+        if (e != hipSuccess) return fail(PWAF_E_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
+        cap = want;
+        return PWAF_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
     }
@@ -125,19 +149,37 @@ struct Scratch {
     bool last_own = false;       // ... which was the context's own stream (a host batch)
     DevBuf status;            // one sticky word: bit 0 = some batch on this context exhausted the overflow pool (cleared when reported)
     uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
-    DevBuf res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
+    struct View { void *p = nullptr; };  // a part of zero_block / args (not owned)
+    View res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
-    DevBuf rec, pool, ctrl /* [0] pool allocator, [1] status word, then one length per list slot */, gate_lists, attr;
-    DevBuf chunk_bits, cand_cnt, cand_bits;  // filter_kernel's chunk bitmaps and per-slab counts; candidate bitmaps
+    DevBuf rec, pool, gate_lists, attr;
+    // What a batch needs ZEROED lives in one block (one memset per batch instead of four): the control words ([0] pool allocator, [1]
+    // status word, then one length per list slot and one pair count per filtered pass), the candidate bitmaps of the filtered passes,
+    // the visited bitmaps of the gap passes and the walk bitmaps of the confirm tier.
+    DevBuf zero_block;
+    View ctrl, cand_bits, visit_bits, walk_bits;
+    DevBuf chunk_bits, cand_cnt;  // filter_kernel's chunk bitmaps and per-slab counts
     DevBuf need;                           // per sharing owner: gap-pass mask of every entry of its candidate list
     DevBuf pairs;                          // per filtered pass with a confirm tier: resolve_kernel's (request, flagged chunk) pairs
-    DevBuf walk_bits;                      // ... and the "already on the walk list" bitmaps
-    DevBuf args_confirm;                   // ConfirmArgs per pass + the work-item plan
-    DevBuf visit_bits;                     // per gap pass: visited bitmap
     DevBuf zero_off;                       // n + 1 zero offsets: the column of a header the batch does not carry
-    DevBuf args_filter, args_list;         // per-pass launch descriptors (kernels.h: FilterTable / GatedTable)
+    // Launch descriptors of a batch (kernels.h: FilterArgs / ConfirmArgs / ListScanArgs per pass, the residual kernel's column pointers):
+    // built on the host before the first launch and uploaded ONCE — the host writes them into a page-locked slot and one copy launch
+    // on the batch's stream moves them to `args` (stream-ordered like the by-value store launches it replaces: a 4096-rule set over 64
+    // header fields took 22 of those per batch). A slot is rewritten only after the copy launch that read it has run (its event);
+    // with kArgSlots slots a caller can be that many batches ahead of the device before it has to wait.
+    static constexpr uint32_t kArgSlots = 8;
+    DevBuf args;
+    PinBuf arg_slot[kArgSlots];
+    hipEvent_t arg_ev[kArgSlots] = {};
+    bool arg_pending[kArgSlots] = {};
+    uint32_t arg_next = 0;
     std::vector<DevBuf> stage_field_data, stage_field_off;  // n_fields each
     DevBuf stage_ip, stage_v6, stage_port, stage_flags, stage_asn, stage_country, stage_out, stage_counts;
+    // A SMALL host batch (the micro-batcher's, pwaf_evaluate_one's) travels as ONE block: every column packed into page-locked memory,
+    // one asynchronous copy in, one out (pwaf_evaluate_batch). pin_status: the status words on their way back (never a pageable target:
+    // a device-to-host copy into pageable memory is a blocking staged copy).
+    PinBuf pin_in, pin_out, pin_status;
+    DevBuf packed;
     // Streams and events are created on first use: every HIP stream takes a share of the few hardware queues of its priority
     // class, and a context (or its own stream) a caller never uses must not cost the caller's streams their concurrency (measured:
     // three idle contexts' streams made two caller streams share one queue — no overlap between two batches in flight).
@@ -154,16 +196,23 @@ struct Scratch {
             if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess)
                 return fail(PWAF_E_DEVICE, "hipStreamCreate / hipEventCreate failed");
+            for (hipEvent_t &ev : arg_ev)
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(PWAF_E_DEVICE, "hipEventCreate failed");
         }
         if (own_stream && !stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail(PWAF_E_DEVICE, "hipStreamCreate failed");
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &res_cols, &ipres, &rec, &pool, &ctrl, &gate_lists, &attr, &chunk_bits, &cand_cnt, &cand_bits, &need, &pairs, &walk_bits, &args_confirm, &visit_bits, &zero_off, &args_filter, &args_list, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &ipres, &rec, &pool, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
+        for (PinBuf &b : arg_slot) b.release();
+        for (hipEvent_t ev : arg_ev)
+            if (ev) (void)hipEventDestroy(ev);
         for (auto &b : stage_field_data) b.release();
         for (auto &b : stage_field_off) b.release();
+        packed.release();
+        for (PinBuf *b : {&pin_in, &pin_out, &pin_status}) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         if (side) (void)hipStreamDestroy(side);
         for (hipEvent_t ev : {ev_fork, ev_join, done})
@@ -684,8 +733,24 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     const size_t n_slots = (size_t)std::max(kGapLists, e->n_gated);
     const size_t ctrl_words = 2 + n_slots + e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count per filtered pass
-    if ((rc = S.ctrl.reserve(4 * ctrl_words))) return rc;
-    HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, 4 * ctrl_words, stream));
+    // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
+    // zeroing the hit records themselves would write. They share ONE zeroed block with the control words and the confirm tier's walk bitmaps.
+    const uint32_t bit_words = 2 * n_groups;
+    uint32_t n_conf = 0;
+    for (const DevGroup &d : e->groups) n_conf += (d.filtered && d.confirm) ? 1u : 0u;
+    {
+        size_t zb = 0;
+        auto part = [&](size_t bytes) { const size_t at = zb; zb = (zb + bytes + 255) & ~(size_t)255; return at; };
+        const size_t z_ctrl = part(4 * ctrl_words), z_cand = part((size_t)e->n_filtered * bit_words * 4), z_visit = part((size_t)e->n_visit * bit_words * 4),
+                     z_walk = part((size_t)n_conf * bit_words * 4);
+        if ((rc = S.zero_block.reserve(zb))) return rc;
+        HIP_TRY(hipMemsetAsync(S.zero_block.p, 0, zb, stream));
+        char *const zbase = (char *)S.zero_block.p;
+        S.ctrl.p = zbase + z_ctrl;
+        S.cand_bits.p = zbase + z_cand;
+        S.visit_bits.p = zbase + z_visit;
+        S.walk_bits.p = zbase + z_walk;
+    }
     // string columns by field id: the five fixed fields, then one column per header name the rule set mentions (EXTENSION); a header
     // the batch does not carry reads as the empty string for every request
     std::vector<pwaf_strcol> cols(e->n_fields);
@@ -721,18 +786,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (col_bytes[f] != 0 || cols[f].data == (const uint8_t *)S.zero_off.p) col_known[f] = 1;
     if (e->n_gated && (rc = S.gate_lists.reserve((size_t)e->n_gated * n * 4))) return rc;
     if (e->n_need && (rc = S.need.reserve((size_t)e->n_need * n * 4))) return rc;
-
-    // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
-    // zeroing the hit records themselves would write
-    const uint32_t bit_words = 2 * n_groups;
-    if (e->n_filtered) {
-        if ((rc = S.cand_bits.reserve((size_t)e->n_filtered * bit_words * 4))) return rc;
-        HIP_TRY(hipMemsetAsync(S.cand_bits.p, 0, (size_t)e->n_filtered * bit_words * 4, stream));
-    }
-    if (e->n_visit) {
-        if ((rc = S.visit_bits.reserve((size_t)e->n_visit * bit_words * 4))) return rc;
-        HIP_TRY(hipMemsetAsync(S.visit_bits.p, 0, (size_t)e->n_visit * bit_words * 4, stream));
-    }
 
     // Profiling: HIP events on the launch stream. On the main stream the event that ends one kernel also starts the next
     // (half the events; the few microseconds of launch gap or memset in between are charged to the later kernel).
@@ -1047,11 +1100,16 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark(nm, (uint64_t)col_bytes[d.field] + 4ull * (n + 1)))) return rc;  // algorithmic bytes: the field's bytes + its offsets (0 bytes when the arena size is unknown)
     }
-    // ---- 2. bigram prefilters of every filtered pass in one launch (the arenas as flat byte streams), hit segments -> candidate
-    //         bitmaps, bitmaps -> dense request lists ----
+    // ---- 2. the descriptors of every launch of the batch (prefilter, resolve, confirm tier, list scans, residual kernel): built here,
+    //         uploaded ONCE ----
+    std::vector<uint32_t> &totals = col_bytes;
+    std::vector<FilterArgs> fall;        // every filtered pass, in pass order
+    std::vector<FilterArgs> by_stride[2];
+    std::vector<ConfirmArgs> call;
+    std::vector<ListScanArgs> la[2];
+    uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
     if (e->n_filtered) {
         // arena sizes: a host batch's offsets were read while staging; a device batch says so itself or is asked (one small copy)
-        std::vector<uint32_t> &totals = col_bytes;
         bool ask = false;
         for (const DevGroup &d : e->groups)
             if (d.filtered && !col_known[d.field]) ask = true;
@@ -1070,24 +1128,16 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             }
         if ((rc = S.chunk_bits.reserve((size_t)sub_entries * 4))) return rc;
         if ((rc = S.cand_cnt.reserve((size_t)(2 * n_slabs_all + (uint64_t)e->n_filtered * n_cblocks) * 4))) return rc;  // per pass: flag counts per slab, pair-list starts per slab, candidates per compact workgroup
-        std::vector<FilterArgs> fall;  // every filtered pass, in pass order
         uint32_t fi = 0;
-        uint64_t alg_bytes[3] = {0, 0, 0};  // per sampling stride
         uint64_t sub_at = 0, cnt_at = 0, pair_at = 0;
         {
             uint64_t pair_bytes = 0;
-            uint32_t n_conf = 0;
             for (const DevGroup &d : e->groups)
                 if (d.filtered && d.confirm) {
                     const uint64_t slabs = ((uint64_t)totals[d.field] + kStreamSlab - 1) / kStreamSlab - (col_begin ? (*col_begin)[d.field] / kStreamSlab : 0u);
                     pair_bytes += std::min<uint64_t>(0xFFFFFFF0u, slabs * (kStreamSlab / 16) + n + 64) * sizeof(uint2);
-                    n_conf++;
                 }
             if (pair_bytes && (rc = S.pairs.reserve((size_t)pair_bytes))) return rc;
-            if (n_conf) {
-                if ((rc = S.walk_bits.reserve((size_t)n_conf * bit_words * 4))) return rc;
-                HIP_TRY(hipMemsetAsync(S.walk_bits.p, 0, (size_t)n_conf * bit_words * 4, stream));
-            }
         }
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
@@ -1141,41 +1191,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             alg_bytes[f.stride == 2 ? 2 : 1] += (uint64_t)f.total + 4ull * (n + 1);
             fi++;
         }
-        // descriptor tables in device memory: [all passes] [stride-1 passes, first_block numbered] [stride-2 passes, numbered from 0 again]
-        const uint32_t nf = (uint32_t)fall.size();
-        if ((rc = S.args_filter.reserve((size_t)3 * nf * sizeof(FilterArgs)))) return rc;
-        FilterArgs *d_all = (FilterArgs *)S.args_filter.p;
-        int he = upload_filter_args(fall.data(), nf, d_all, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-        std::vector<FilterArgs> by_stride[2];
+        // the fused filter launch takes the stride-1 passes and the stride-2 passes as two tables, first_block numbered within each
         for (const FilterArgs &f : fall) {
             std::vector<FilterArgs> &sub = by_stride[f.stride == 2 ? 1 : 0];
             const uint32_t block = sub.empty() ? 0u : sub.back().first_block + ((uint32_t)(((uint64_t)sub.back().total + kStreamSlab - 1) / kStreamSlab) - sub.back().slab0 + kFilterWaves - 1) / kFilterWaves;
             sub.push_back(f);
             sub.back().first_block = block;
         }
-        FilterArgs *d_s1 = d_all + nf, *d_s2 = d_s1 + by_stride[0].size();
-        if (!by_stride[0].empty() && (he = upload_filter_args(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-        if (!by_stride[1].empty() && (he = upload_filter_args(by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream))) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-        if ((rc = mark(nullptr, 0))) return rc;
-        he = launch_filter(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        // algorithmic bytes: every streamed arena once + its offsets. The mark's name tells the bench which strides the launch mixed.
-        if ((rc = mark(by_stride[1].empty() ? "filter_s1" : by_stride[0].empty() ? "filter_s2" : "filter_mix", alg_bytes[1] + alg_bytes[2]))) return rc;
-#ifdef PWAF_PROFILING
-        static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
-        if (!attr_after_compact)
-#endif
-        if ((rc = launch_attr_side())) return rc;
-        if ((rc = mark(nullptr, 0))) return rc;
-        he = launch_resolve(fall.data(), nf, d_all, stream);
-        bool any_list = false;  // (a pass with a confirm tier has no candidate bitmap to turn into a list: its flagged chunks are the work list)
-        for (const DevGroup &d : e->groups) any_list = any_list || (d.filtered && !d.confirm);
-        if (!he && any_list) he = launch_compact(fall.data(), nf, d_all, stream);
-        if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
-        if ((rc = mark("resolve+compact", 0xFCu))) return rc;
-        // ---- 2b. confirm tier: what the flagged chunks of every candidate really hold (literal atoms decided; walk flags) ----
-        std::vector<ConfirmArgs> call;
+        // confirm tier: what the flagged chunks of every candidate really hold (literal atoms decided; walk flags)
         uint32_t wi = 0;
         fi = 0;
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
@@ -1224,51 +1247,114 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             }
             call.push_back(c);
         }
-        if (!call.empty()) {
-            const uint32_t nc = (uint32_t)call.size();
-            if ((rc = S.args_confirm.reserve((size_t)nc * sizeof(ConfirmArgs) + (nc + 2) * 4))) return rc;
-            ConfirmArgs *d_c = (ConfirmArgs *)S.args_confirm.p;
-            uint32_t *c_plan = (uint32_t *)((char *)S.args_confirm.p + (size_t)nc * sizeof(ConfirmArgs));
-            he = upload_confirm_args(call.data(), nc, d_c, stream);
+    }
+    // list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes
+    for (int phase = 0; phase < 2; phase++)
+        for (size_t gi = 0; gi < e->groups.size(); gi++) {
+            const DevGroup &d = e->groups[gi];
+            if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
+            if (d.confirm && !d.confirm_walk) continue;  // every atom of the pass is a literal the confirm tier decided: nothing to walk
+#ifdef PWAF_PROFILING
+            static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
+            if (skip_identity && d.identity) continue;
+#endif
+            la[phase].push_back(list_args(gi, lshapes[phase]));
+        }
+    ColPtrChunk ptrs{};  // residual kernel: the batch's string columns as arrays of pointers
+    if (P.n_residual) {
+        const size_t nc = e->n_fields;
+        ptrs.count = (uint32_t)(2 * nc);
+        for (size_t f = 0; f < nc; f++) { ptrs.p[f] = cols[f].data; ptrs.p[nc + f] = cols[f].offsets; }
+    }
+    // device layout of `args`: [all filtered passes] [stride-1 passes] [stride-2 passes] [confirm passes] [list passes of phase 0] [of
+    // phase 1] [column pointers] — the uploaded part — then the work-item plans the plan kernels write (confirm: count + 2 words; list
+    // scans: per phase 2 * count + 1)
+    const uint32_t nf = (uint32_t)fall.size(), nc_conf = (uint32_t)call.size();
+    const FilterArgs *d_all = nullptr, *d_s1 = nullptr, *d_s2 = nullptr;
+    const ConfirmArgs *d_c = nullptr;
+    const ListScanArgs *d_la[2] = {nullptr, nullptr};
+    uint32_t *c_plan = nullptr, *l_plan = nullptr;
+    {
+        size_t ab = 0;
+        auto part = [&](size_t bytes) { const size_t at = ab; ab = (ab + bytes + 255) & ~(size_t)255; return at; };
+        const size_t a_all = part((size_t)nf * sizeof(FilterArgs)), a_s1 = part(by_stride[0].size() * sizeof(FilterArgs)), a_s2 = part(by_stride[1].size() * sizeof(FilterArgs)),
+                     a_c = part((size_t)nc_conf * sizeof(ConfirmArgs)), a_l0 = part((la[0].size() + 1) * sizeof(ListScanArgs)), a_l1 = part((la[1].size() + 1) * sizeof(ListScanArgs)),
+                     a_ptrs = part((size_t)ptrs.count * sizeof(void *));
+        const size_t up_bytes = ab;
+        const size_t a_cplan = part(((size_t)nc_conf + 2) * 4), a_lplan = part((2 * (la[0].size() + la[1].size()) + 4) * 4);
+        if ((rc = S.args.reserve(ab))) return rc;
+        char *const abase = (char *)S.args.p;
+        d_all = (const FilterArgs *)(abase + a_all);
+        d_s1 = (const FilterArgs *)(abase + a_s1);
+        d_s2 = (const FilterArgs *)(abase + a_s2);
+        d_c = (const ConfirmArgs *)(abase + a_c);
+        d_la[0] = (const ListScanArgs *)(abase + a_l0);
+        d_la[1] = (const ListScanArgs *)(abase + a_l1);
+        S.res_cols.p = abase + a_ptrs;
+        c_plan = (uint32_t *)(abase + a_cplan);
+        l_plan = (uint32_t *)(abase + a_lplan);
+        if (up_bytes) {
+            const uint32_t slot = S.arg_next++ % Scratch::kArgSlots;
+            if (S.arg_pending[slot]) HIP_TRY(hipEventSynchronize(S.arg_ev[slot]));  // (the copy launch that read this slot last has run: returns at once unless the caller is kArgSlots batches ahead)
+            if ((rc = S.arg_slot[slot].reserve(up_bytes))) return rc;
+            char *const hb = (char *)S.arg_slot[slot].p;
+            auto put = [&](size_t at, const void *src, size_t bytes) { if (bytes) memcpy(hb + at, src, bytes); };
+            put(a_all, fall.data(), (size_t)nf * sizeof(FilterArgs));
+            put(a_s1, by_stride[0].data(), by_stride[0].size() * sizeof(FilterArgs));
+            put(a_s2, by_stride[1].data(), by_stride[1].size() * sizeof(FilterArgs));
+            put(a_c, call.data(), (size_t)nc_conf * sizeof(ConfirmArgs));
+            put(a_l0, la[0].data(), la[0].size() * sizeof(ListScanArgs));
+            put(a_l1, la[1].data(), la[1].size() * sizeof(ListScanArgs));
+            put(a_ptrs, ptrs.p, (size_t)ptrs.count * sizeof(void *));
+            int he = upload_args_block(hb, S.args.p, up_bytes, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
+            HIP_TRY(hipEventRecord(S.arg_ev[slot], stream));
+            S.arg_pending[slot] = true;
+        }
+    }
+    // ---- 2a. bigram prefilters of every filtered pass in one launch (the arenas as flat byte streams), hit segments -> candidate
+    //          bitmaps / pair lists ----
+    if (e->n_filtered) {
+        int he;
+        if ((rc = mark(nullptr, 0))) return rc;
+        he = launch_filter(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        // algorithmic bytes: every streamed arena once + its offsets. The mark's name tells the bench which strides the launch mixed.
+        if ((rc = mark(by_stride[1].empty() ? "filter_s1" : by_stride[0].empty() ? "filter_s2" : "filter_mix", alg_bytes[1] + alg_bytes[2]))) return rc;
+#ifdef PWAF_PROFILING
+        static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
+        if (!attr_after_compact)
+#endif
+        if ((rc = launch_attr_side())) return rc;
+        if ((rc = mark(nullptr, 0))) return rc;
+        he = launch_resolve(fall.data(), nf, d_all, stream);
+        bool any_list = false;  // (a pass with a confirm tier has no candidate bitmap to turn into a list: its flagged chunks are the work list)
+        for (const DevGroup &d : e->groups) any_list = any_list || (d.filtered && !d.confirm);
+        if (!he && any_list) he = launch_compact(fall.data(), nf, d_all, stream);
+        if (he) return fail(PWAF_E_DEVICE, std::string("resolve / compact kernel launch failed: ") + hipGetErrorString((hipError_t)he));
+        if ((rc = mark("resolve+compact", 0xFCu))) return rc;
+        // ---- 2b. confirm tier ----
+        if (!call.empty()) {
             if ((rc = mark(nullptr, 0))) return rc;
-            he = launch_confirm(call.data(), nc, d_c, c_plan, e->n_cus, stream);
+            he = launch_confirm(call.data(), nc_conf, d_c, c_plan, e->n_cus, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("confirm kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc = mark("confirm", 0xF8u))) return rc;
         }
     }
     if ((rc = launch_attr_side())) return rc;  // (no filtered pass: beside the list scans / the verdict kernel's predecessors)
-    // ---- 3. list-driven DFA passes: first those behind a prefilter (they may feed the gap passes' lists), then the gap passes ----
+    // ---- 3. list-driven DFA passes ----
     {
-        std::vector<ListScanArgs> la[2];
-        for (int phase = 0; phase < 2; phase++)
-            for (size_t gi = 0; gi < e->groups.size(); gi++) {
-                const DevGroup &d = e->groups[gi];
-                if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
-                if (d.confirm && !d.confirm_walk) continue;  // every atom of the pass is a literal the confirm tier decided: nothing to walk
-#ifdef PWAF_PROFILING
-                static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
-                if (skip_identity && d.identity) continue;
-#endif
-                la[phase].push_back(list_args(gi, lshapes[phase]));
-            }
-        const size_t n_desc = la[0].size() + la[1].size();
-        if ((rc = S.args_list.reserve((n_desc + 1) * sizeof(ListScanArgs) + (2 * n_desc + 4) * 4))) return rc;
-        ListScanArgs *d_at = (ListScanArgs *)S.args_list.p;
-        uint32_t *plan_at = (uint32_t *)((char *)S.args_list.p + (n_desc + 1) * sizeof(ListScanArgs));  // work-item prefix sums, one set per phase
+        uint32_t *plan_at = l_plan;  // work-item prefix sums, one set per phase
         for (int phase = 0; phase < 2; phase++) {
             const uint32_t cnt = (uint32_t)la[phase].size();
             if (!cnt) continue;
-            int he = upload_list_args(la[phase].data(), cnt, d_at, stream);
-            if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
             if ((rc = mark(nullptr, 0))) return rc;
-            he = launch_scan_gated(la[phase].data(), cnt, d_at, plan_at, lshapes[phase], stream);
+            int he = launch_scan_gated(la[phase].data(), cnt, d_la[phase], plan_at, lshapes[phase], stream);
             plan_at += 2 * cnt + 1;  // (prefix sums, then the entries per work item of every pass)
             if (he) return fail(PWAF_E_DEVICE, std::string("gated scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
             char nm[48];
             snprintf(nm, sizeof nm, "lscan_x%u", cnt);
             if ((rc = mark(nm, 0xFDu))) return rc;
-            d_at += cnt;
         }
     }
     if (!P.fcmp.empty()) {
@@ -1305,12 +1391,6 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         // rules the column compiler could not take: interpreted per request (residual.h), results = the hit records of the last pseudo pass
         ResidualArgs ra{};
         const size_t nc = e->n_fields;
-        if ((rc = S.res_cols.reserve(nc * 16))) return rc;
-        ColPtrChunk ptrs{};  // (travels as the argument of a store launch: stream-ordered, the caller is not blocked — ADVICE r3)
-        ptrs.count = (uint32_t)(2 * nc);
-        for (size_t f = 0; f < nc; f++) { ptrs.p[f] = cols[f].data; ptrs.p[nc + f] = cols[f].offsets; }
-        int he0 = upload_col_ptrs(ptrs, S.res_cols.p, stream);
-        if (he0) return fail(PWAF_E_DEVICE, std::string("column table upload failed: ") + hipGetErrorString((hipError_t)he0));
         ra.data = (const uint8_t *const *)S.res_cols.p;
         ra.off = (const uint32_t *const *)((const char *)S.res_cols.p + nc * 8);
         ra.blob = (const uint8_t *)e->residual_blob.p;
@@ -1890,19 +1970,32 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
     if ((rc = S.ensure(true))) return rc;
     hipStream_t s = S.stream;
     if (must_wait) HIP_TRY(hipStreamWaitEvent(s, S.done, 0));
-    // runs the pipeline and waits; a batch that exhausted the overflow pool is run again with a pool of the size it asked for
-    auto run_checked = [&](const pwaf_batch &db, pwaf_verdict *d_out, pwaf_counts *d_counts, bool known, const std::vector<uint32_t> *begins = nullptr) -> int {
+    // Runs the pipeline and waits ONCE: the status words travel back (into page-locked memory) behind the batch, together with whatever
+    // `after` enqueues (the host batch's verdicts). A batch that exhausted the overflow pool is run again with a pool of the size it
+    // asked for. `counts_zero`: the first attempt's counters arrive zeroed (they are part of a staged block).
+    if ((rc = S.pin_status.reserve(16))) return rc;
+    volatile uint32_t *const st = (volatile uint32_t *)S.pin_status.p;
+    auto run_checked = [&](const pwaf_batch &db, pwaf_verdict *d_out, pwaf_counts *d_counts, bool known, const std::vector<uint32_t> *begins, const std::function<int()> &after,
+                           bool counts_zero) -> int {
         for (int attempt = 0;; attempt++) {
-            if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
+            if (d_counts && !(counts_zero && attempt == 0)) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
             int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins, true);
             S.used = true;
             S.last = s;
             S.last_own = true;
+            if (r) {
+                (void)hipEventRecord(S.done, s);
+                (void)hipStreamSynchronize(s);  // (whatever was enqueued may still read the caller's buffers)
+                return r;
+            }
+            HIP_TRY(hipMemcpyAsync((void *)&st[0], (uint32_t *)S.status.p + 1, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync((void *)&st[1], S.ctrl.p, 4, hipMemcpyDeviceToHost, s));  // overflow entries the batch asked for
+            if (after && (r = after())) {
+                (void)hipEventRecord(S.done, s);
+                (void)hipStreamSynchronize(s);
+                return r;
+            }
             HIP_TRY(hipEventRecord(S.done, s));
-            if (r) return r;
-            uint32_t st[2] = {0, 0};
-            HIP_TRY(hipMemcpyAsync(&st[0], (uint32_t *)S.status.p + 1, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(&st[1], S.ctrl.p, 4, hipMemcpyDeviceToHost, s));  // overflow entries the batch asked for
             HIP_TRY(hipStreamSynchronize(s));
             if (!st[0]) return PWAF_OK;
             HIP_TRY(hipMemsetAsync((uint32_t *)S.status.p + 1, 0, 4, s));
@@ -1910,8 +2003,9 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
             S.pool_entries = (uint64_t)st[1] + st[1] / 4 + 1024;
         }
     };
-    if (in->memory == PWAF_MEM_DEVICE) return run_checked(*in, out, counts, false);
-    // HOST batch: validate what a device cannot report, stage, run, copy back
+    if (in->memory == PWAF_MEM_DEVICE) return run_checked(*in, out, counts, false, nullptr, nullptr, false);
+    // HOST batch: stage, validate what a device cannot report (while the copies are in flight, when the caller's memory is page-locked:
+    // pwaf_host_alloc / pwaf_host_register), run, copy back
     const uint32_t n = in->n;
     // host view of every string column by field id (five fields + the header columns the batch carries; the others read as "")
     const uint32_t n_hdr_in = in->headers ? std::min<uint32_t>(in->n_headers, e->n_fields - PWAF_N_FIELDS) : 0u;
@@ -1920,25 +2014,122 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         const uint32_t k = f - PWAF_N_FIELDS;
         return (k < n_hdr_in && in->headers[k].data && in->headers[k].offsets) ? &in->headers[k] : nullptr;
     };
+    auto validate = [&]() -> int {
+        for (uint32_t f = 0; f < e->n_fields; f++) {
+            const pwaf_strcol *c = host_col(f);
+            if (!c) continue;
+            const uint32_t *o = c->offsets;
+            uint32_t bad = 0;
+            for (uint32_t i = 0; i < n; i++) bad |= (uint32_t)(o[i + 1] < o[i]);  // (branch-free: the loop vectorizes)
+            if (bad) return fail(PWAF_E_BATCH, "field offsets are not monotone");
+        }
+        if (in->country) {
+            uint32_t bad = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t c0 = (in->country[i] & 0xFFu) - 'A', c1 = ((uint32_t)in->country[i] >> 8) - 'A';
+                bad |= (uint32_t)(c0 > 25u) | (uint32_t)(c1 > 25u);
+            }
+            if (bad) return fail(PWAF_E_BATCH, "country is not two letters A-Z (pingoo/geoip.rs:128-142)");
+        }
+        return PWAF_OK;
+    };
+    // the ends must be ordered before any size is computed from them (the full check follows)
     for (uint32_t f = 0; f < e->n_fields; f++) {
         const pwaf_strcol *c = host_col(f);
-        if (!c) continue;
-        const uint32_t *o = c->offsets;
-        for (uint32_t i = 0; i < n; i++)
-            if (o[i + 1] < o[i]) return fail(PWAF_E_BATCH, "field offsets are not monotone");
-    }
-    if (in->country) {
-        for (uint32_t i = 0; i < n; i++) {
-            uint8_t c0 = (uint8_t)(in->country[i] & 0xFF), c1 = (uint8_t)(in->country[i] >> 8);
-            if (c0 < 'A' || c0 > 'Z' || c1 < 'A' || c1 > 'Z') return fail(PWAF_E_BATCH, "country is not two letters A-Z (pingoo/geoip.rs:128-142)");
-        }
+        if (c && c->offsets[n] < c->offsets[0]) return fail(PWAF_E_BATCH, "field offsets are not monotone");
     }
     pwaf_batch db = *in;
     db.memory = PWAF_MEM_DEVICE;
-    if (S.stage_field_data.size() < e->n_fields) { S.stage_field_data.resize(e->n_fields); S.stage_field_off.resize(e->n_fields); }
     std::vector<pwaf_strcol> hdr_cols(e->n_fields - PWAF_N_FIELDS, pwaf_strcol{nullptr, nullptr});
     std::vector<uint32_t> hdr_bytes(e->n_fields - PWAF_N_FIELDS, 0);
     std::vector<uint32_t> col_begin(e->n_fields, 0);
+    auto set_col = [&](uint32_t f, const uint8_t *d_data, const uint32_t *d_off, uint32_t hi) {
+        const pwaf_strcol dc{d_data, d_off};
+        if (f < PWAF_N_FIELDS) {
+            db.field[f] = dc;
+            db.field_bytes[f] = hi;
+        } else {
+            hdr_cols[f - PWAF_N_FIELDS] = dc;
+            hdr_bytes[f - PWAF_N_FIELDS] = hi;
+        }
+    };
+    auto finish_headers = [&]() {
+        db.headers = hdr_cols.empty() ? nullptr : hdr_cols.data();
+        db.header_bytes = hdr_bytes.empty() ? nullptr : hdr_bytes.data();
+        db.n_headers = (uint32_t)hdr_cols.size();
+    };
+
+    // ---- small batches: ONE packed block ----
+    // [offsets + arena of every column] [ip] [v6] [port] [flags] [asn] [country] [counters] | [verdicts], each 256-byte aligned. The
+    // micro-batcher's batches and pwaf_evaluate_one's single requests paid ~25 small copies from pageable memory (each a blocking staged
+    // copy) and two waits per batch; now: memcpy into page-locked memory, one copy in, one out, one wait.
+    static constexpr size_t kPackMax = 1u << 20;
+    size_t need = 0;
+    auto take = [&](size_t bytes) { const size_t at = need; need = (need + bytes + 255) & ~(size_t)255; return at; };
+    bool packable = true;
+    std::vector<size_t> at_off(e->n_fields, 0), at_data(e->n_fields, 0);
+    for (uint32_t f = 0; f < e->n_fields && packable; f++) {
+        const pwaf_strcol *c = host_col(f);
+        if (!c) continue;
+        if (c->offsets[0] != 0) { packable = false; break; }  // (a slab view of a larger arena keeps its positions: the column-by-column path)
+        at_off[f] = take((size_t)(n + 1) * 4);
+        at_data[f] = take((size_t)c->offsets[n] + PWAF_ARENA_PAD);
+        if (need > kPackMax) packable = false;
+    }
+    const size_t at_ip = take((size_t)n * 16), at_v6 = take(n), at_port = take((size_t)n * 2), at_flags = take(n);
+    const size_t at_asn = in->asn ? take((size_t)n * 4) : 0, at_cc = in->asn ? take((size_t)n * 2) : 0;
+    const size_t at_counts = take(sizeof(pwaf_counts));  // (arrive zeroed with the inputs, return with the verdicts)
+    const size_t in_bytes = need;
+    const size_t at_out = take((size_t)n * sizeof(pwaf_verdict));
+    static const bool no_pack = getenv("PWAF_NO_PACKED_STAGING") != nullptr;  // A/B: the column-by-column path for every batch
+    if (packable && need <= kPackMax && !no_pack) {
+        if ((rc = validate())) return rc;
+        if ((rc = S.pin_in.reserve(in_bytes)) || (rc = S.pin_out.reserve(need - at_counts)) || (rc = S.packed.reserve(need))) return rc;
+        uint8_t *const h = (uint8_t *)S.pin_in.p;
+        const uint8_t *const d = (const uint8_t *)S.packed.p;
+        for (uint32_t f = 0; f < e->n_fields; f++) {
+            const pwaf_strcol *c = host_col(f);
+            if (!c) continue;
+            const uint32_t hi = c->offsets[n];
+            memcpy(h + at_off[f], c->offsets, (size_t)(n + 1) * 4);
+            if (hi) memcpy(h + at_data[f], c->data, hi);
+            memset(h + at_data[f] + hi, 0, PWAF_ARENA_PAD);
+            set_col(f, d + at_data[f], (const uint32_t *)(d + at_off[f]), hi);
+        }
+        finish_headers();
+        memcpy(h + at_ip, in->ip, (size_t)n * 16);
+        memcpy(h + at_v6, in->ip_is_v6, n);
+        memcpy(h + at_port, in->port, (size_t)n * 2);
+        memcpy(h + at_flags, in->flags, n);
+        db.ip = d + at_ip;
+        db.ip_is_v6 = d + at_v6;
+        db.port = (const uint16_t *)(d + at_port);
+        db.flags = d + at_flags;
+        if (in->asn) {
+            memcpy(h + at_asn, in->asn, (size_t)n * 4);
+            memcpy(h + at_cc, in->country, (size_t)n * 2);
+            db.asn = (const uint32_t *)(d + at_asn);
+            db.country = (const uint16_t *)(d + at_cc);
+        }
+        memset(h + at_counts, 0, sizeof(pwaf_counts));
+        HIP_TRY(hipMemcpyAsync(S.packed.p, h, in_bytes, hipMemcpyHostToDevice, s));
+        pwaf_verdict *const d_out = (pwaf_verdict *)((char *)S.packed.p + at_out);
+        pwaf_counts *const d_counts = (pwaf_counts *)((char *)S.packed.p + at_counts);
+        const size_t back = need - at_counts;
+        rc = run_checked(db, d_out, d_counts, true, &col_begin, [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(S.pin_out.p, d_counts, back, hipMemcpyDeviceToHost, s));
+            return PWAF_OK;
+        }, true);
+        if (rc) return rc;
+        memcpy(out, (const char *)S.pin_out.p + (at_out - at_counts), (size_t)n * sizeof(pwaf_verdict));
+        if (counts) memcpy(counts, S.pin_out.p, sizeof(pwaf_counts));
+        return PWAF_OK;
+    }
+
+    // ---- large batches: column by column, straight from the caller's buffers (page-locked ones are read by the copy engine while this
+    //      thread goes on: pwaf_host_alloc / pwaf_host_register) ----
+    if (S.stage_field_data.size() < e->n_fields) { S.stage_field_data.resize(e->n_fields); S.stage_field_off.resize(e->n_fields); }
+    auto bail = [&](int code) { (void)hipStreamSynchronize(s); return code; };  // (copies in flight read the caller's buffers)
     for (uint32_t f = 0; f < e->n_fields; f++) {
         const pwaf_strcol *c = host_col(f);
         if (!c) continue;
@@ -1947,23 +2138,14 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         col_begin[f] = (uint32_t)lo;
         // offsets are used unchanged on the device: the arena keeps its positions, but only the batch's own bytes [off[0], off[n]) travel
         // (a slab view of a larger batch — pwaf_node_evaluate_batch — does not re-send what lies before it)
-        if ((rc = S.stage_field_data[f].reserve(hi + PWAF_ARENA_PAD))) return rc;
-        if ((rc = S.stage_field_off[f].reserve((size_t)(n + 1) * 4))) return rc;
+        if ((rc = S.stage_field_data[f].reserve(hi + PWAF_ARENA_PAD))) return bail(rc);
+        if ((rc = S.stage_field_off[f].reserve((size_t)(n + 1) * 4))) return bail(rc);
         if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)S.stage_field_data[f].p + lo, c->data + lo, hi - lo, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync((char *)S.stage_field_data[f].p + hi, 0, PWAF_ARENA_PAD, s));
         HIP_TRY(hipMemcpyAsync(S.stage_field_off[f].p, o, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
-        const pwaf_strcol dc{(const uint8_t *)S.stage_field_data[f].p, (const uint32_t *)S.stage_field_off[f].p};
-        if (f < PWAF_N_FIELDS) {
-            db.field[f] = dc;
-            db.field_bytes[f] = (uint32_t)hi;
-        } else {
-            hdr_cols[f - PWAF_N_FIELDS] = dc;
-            hdr_bytes[f - PWAF_N_FIELDS] = (uint32_t)hi;
-        }
+        set_col(f, (const uint8_t *)S.stage_field_data[f].p, (const uint32_t *)S.stage_field_off[f].p, (uint32_t)hi);
     }
-    db.headers = hdr_cols.empty() ? nullptr : hdr_cols.data();
-    db.header_bytes = hdr_bytes.empty() ? nullptr : hdr_bytes.data();
-    db.n_headers = (uint32_t)hdr_cols.size();
+    finish_headers();
     auto stage = [&](DevBuf &b, const void *src, size_t bytes, const void **dst) -> int {
         int r = b.reserve(bytes);
         if (r) return r;
@@ -1971,21 +2153,44 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
         *dst = b.p;
         return PWAF_OK;
     };
-    if ((rc = stage(S.stage_ip, in->ip, (size_t)n * 16, (const void **)&db.ip))) return rc;
-    if ((rc = stage(S.stage_v6, in->ip_is_v6, n, (const void **)&db.ip_is_v6))) return rc;
-    if ((rc = stage(S.stage_port, in->port, (size_t)n * 2, (const void **)&db.port))) return rc;
-    if ((rc = stage(S.stage_flags, in->flags, n, (const void **)&db.flags))) return rc;
+    if ((rc = stage(S.stage_ip, in->ip, (size_t)n * 16, (const void **)&db.ip))) return bail(rc);
+    if ((rc = stage(S.stage_v6, in->ip_is_v6, n, (const void **)&db.ip_is_v6))) return bail(rc);
+    if ((rc = stage(S.stage_port, in->port, (size_t)n * 2, (const void **)&db.port))) return bail(rc);
+    if ((rc = stage(S.stage_flags, in->flags, n, (const void **)&db.flags))) return bail(rc);
     if (in->asn) {
-        if ((rc = stage(S.stage_asn, in->asn, (size_t)n * 4, (const void **)&db.asn))) return rc;
-        if ((rc = stage(S.stage_country, in->country, (size_t)n * 2, (const void **)&db.country))) return rc;
+        if ((rc = stage(S.stage_asn, in->asn, (size_t)n * 4, (const void **)&db.asn))) return bail(rc);
+        if ((rc = stage(S.stage_country, in->country, (size_t)n * 2, (const void **)&db.country))) return bail(rc);
     }
-    if ((rc = S.stage_out.reserve((size_t)n * sizeof(pwaf_verdict)))) return rc;
-    if ((rc = S.stage_counts.reserve(sizeof(pwaf_counts)))) return rc;
-    rc = run_checked(db, (pwaf_verdict *)S.stage_out.p, (pwaf_counts *)S.stage_counts.p, true, &col_begin);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, S.stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
-    if (counts) HIP_TRY(hipMemcpyAsync(counts, S.stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = S.stage_out.reserve((size_t)n * sizeof(pwaf_verdict)))) return bail(rc);
+    if ((rc = S.stage_counts.reserve(sizeof(pwaf_counts)))) return bail(rc);
+    if ((rc = validate())) return bail(rc);
+    return run_checked(db, (pwaf_verdict *)S.stage_out.p, (pwaf_counts *)S.stage_counts.p, true, &col_begin, [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(out, S.stage_out.p, (size_t)n * sizeof(pwaf_verdict), hipMemcpyDeviceToHost, s));
+        if (counts) HIP_TRY(hipMemcpyAsync(counts, S.stage_counts.p, sizeof(pwaf_counts), hipMemcpyDeviceToHost, s));
+        return PWAF_OK;
+    }, false);
+}
+
+// Page-locked host memory for batch columns: the copy engine reads it directly (no staging copy inside the runtime, the calling thread
+// goes on while the copy runs). A listener that parses requests into such arenas hands pwaf_evaluate_batch its bytes at PCIe speed.
+int pwaf_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    hipError_t he = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+    if (he != hipSuccess) { *out = nullptr; return fail(PWAF_E_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(he)); }
+    return PWAF_OK;
+}
+void pwaf_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+int pwaf_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return PWAF_OK;
+}
+int pwaf_host_unregister(void *p) {
+    if (!p) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipHostUnregister(p));
     return PWAF_OK;
 }
 

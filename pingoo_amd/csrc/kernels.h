@@ -157,17 +157,12 @@ struct ConfirmArgs {
     uint32_t enq_words;
     uint32_t shared_bits;       // gap passes that share this pass's walk list (ListScanArgs::need_out): a literal hit that calls for one sends the request through the walk
 };
-static constexpr uint32_t kConfirmThreads = 1024, kConfirmPerLaunch = 16;
+static constexpr uint32_t kConfirmThreads = 1024;
 static constexpr uint32_t kConfirmPoolBytes = 40 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
-struct ConfirmBatchArgs {
-    ConfirmArgs c[kConfirmPerLaunch];
-    uint32_t count;
-};
 struct ConfirmTableDev {
     const ConfirmArgs *c;  // device
     uint32_t count;
 };
-int upload_confirm_args(const ConfirmArgs *host, uint32_t count, ConfirmArgs *dev, void *stream);
 // `plan`: count + 1 words of device scratch (work-item prefix sums, written on the same stream)
 int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *dev, uint32_t *plan, uint32_t n_cus, void *stream);
 
@@ -186,7 +181,6 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
 static constexpr uint32_t kStreamSlab = 128 * 1024;   // bytes per wave
 static constexpr uint32_t kStreamIter = 4096;          // bytes per iteration of a wave: four rows of 64 lanes x 16 bytes
 static constexpr uint32_t kFilterWaves = 4;           // waves (slabs) per workgroup
-static constexpr uint32_t kMaxFiltersPerLaunch = 16;  // descriptors per store launch (16 x 232 bytes of kernel arguments)
 static constexpr uint32_t kCompactWords = 2048;       // bitmap words per compact workgroup (65536 requests)
 struct FilterArgs {
     const uint8_t *data;
@@ -220,12 +214,10 @@ struct FilterArgs {
     uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration
 };
 // The descriptors of all passes of a launch live in DEVICE memory (a 4096-rule set over 64 header fields has ~70 filtered passes:
-// 15 KB of descriptors, kernel arguments hold 8). They get there as the by-value arguments of small store launches on the same
-// stream — stream-ordered, and no staging buffer that a later batch could overwrite before an asynchronous copy has run.
-struct FilterBatchArgs {  // a chunk of descriptors on its way to the device
-    FilterArgs f[kMaxFiltersPerLaunch];
-    uint32_t count;
-};
+// 15 KB of descriptors, kernel arguments hold 8). The host builds the descriptors of EVERY launch of a batch before the first one, writes
+// them into a page-locked slot and one copy launch on the batch's stream moves the block (engine.cpp: Scratch::args): stream-ordered,
+// one launch per batch whatever the number of passes.
+int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *stream);
 struct FilterTable {
     const FilterArgs *f;  // device
     uint32_t count;
@@ -234,7 +226,6 @@ struct FilterMix {  // the fused filter launch: the stride-1 passes and the stri
     const FilterArgs *f1, *f2;  // device
     uint32_t count1, count2, blocks1, blocks2;
 };
-int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, void *stream);
 // `host` = the same `count` descriptors as `dev` (launch geometry). launch_filter: ONE launch, the passes of stride 1 and of stride 2
 // as two tables (either may be empty), first_block numbered within each by the caller.
 int launch_filter(const FilterArgs *host1, uint32_t count1, const FilterArgs *dev1, const FilterArgs *host2, uint32_t count2, const FilterArgs *dev2, void *stream);
@@ -289,13 +280,11 @@ struct ResidualArgs {
     unsigned long long *rule_errors;  // [n_rules], accumulated over the engine's batches: requests for which the rule's evaluation ended in an error
 };
 int launch_residual(const ResidualArgs &a, void *stream);
-// The batch's string-column pointer table (ResidualArgs::data / off) on its way to device memory: the by-value argument of a store
-// launch, like the pass descriptors (a hipMemcpyAsync from pageable host memory blocks the caller and cannot be captured in a graph).
+// The batch's string-column pointer table (ResidualArgs::data / off): part of the batch's descriptor block.
 struct ColPtrChunk {
     const void *p[2 * (PWAF_N_FIELDS + kMaxHeaders)];
     uint32_t count;
 };
-int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream);
 struct CmpAtomDev {
     uint32_t col, c;
 };
@@ -390,18 +379,12 @@ struct VerdictArgs {
 };
 
 // Launchers (hipStream_t passed as void*). Return hipError_t as int.
-static constexpr uint32_t kGatedPerLaunch = 16;
-struct GatedArgs {
-    ListScanArgs g[kGatedPerLaunch];
-    uint32_t count;
-};
 int launch_scan(const ScanArgs &a, void *stream);
 struct GatedTable {
     const ListScanArgs *g;  // device
     uint32_t count;
     uint32_t debug;  // -DPWAF_PROFILING timing experiments only: 1 = never, 2 = always the asynchronous loop for a list (same results)
 };
-int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream);
 // Workgroup shape of the list scan: threads per workgroup, LDS bytes of hot rows per workgroup, workgroups per CU.
 struct ListShape {
     uint32_t threads, hot_bytes, wg_per_cu;
@@ -423,7 +406,3 @@ struct VerdictShape {
 VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false);
 
 }  // namespace pwaf
-
-namespace pwaf {
-static_assert(sizeof(FilterBatchArgs) <= 4064 && sizeof(GatedArgs) <= 4064 && sizeof(ConfirmBatchArgs) <= 4064, "a descriptor chunk travels as one launch's kernel arguments");
-}

@@ -1132,48 +1132,18 @@ int launch_scan(const ScanArgs &a, void *stream) {
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
-// Descriptor chunks to device memory: the chunk is the launch's by-value argument, every thread stores a few of its words.
-template <class CHUNK, class T>
-__global__ __launch_bounds__(256) void store_args_kernel(CHUNK c, T *dst) {
-    typedef uint32_t __attribute__((may_alias)) word_t;
-    const uint32_t words = c.count * (uint32_t)(sizeof(T) / 4);
-    const word_t *src = reinterpret_cast<const word_t *>(&c);
-    for (uint32_t i = threadIdx.x; i < words; i += 256) reinterpret_cast<word_t *>(dst)[i] = src[i];
+// The batch's launch descriptors, host to device in ONE launch: `src` is page-locked host memory (device-visible: the lanes read it
+// over the link, 16 bytes each), `dst` device memory; both 16-byte aligned, bytes rounded up to 16 by the caller's 256-byte parts.
+__global__ __launch_bounds__(256) void copy_args_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
 }
-int upload_list_args(const ListScanArgs *host, uint32_t count, ListScanArgs *dev, void *stream) {
-    for (uint32_t at = 0; at < count; at += kGatedPerLaunch) {
-        GatedArgs c{};
-        c.count = std::min(kGatedPerLaunch, count - at);
-        for (uint32_t k = 0; k < c.count; k++) c.g[k] = host[at + k];
-        hipLaunchKernelGGL((store_args_kernel<GatedArgs, ListScanArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
-int upload_filter_args(const FilterArgs *host, uint32_t count, FilterArgs *dev, void *stream) {
-    for (uint32_t at = 0; at < count; at += kMaxFiltersPerLaunch) {
-        FilterBatchArgs c{};
-        c.count = std::min(kMaxFiltersPerLaunch, count - at);
-        for (uint32_t k = 0; k < c.count; k++) c.f[k] = host[at + k];
-        hipLaunchKernelGGL((store_args_kernel<FilterBatchArgs, FilterArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
+int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *stream) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (n16 == 0) return 0;
+    hipLaunchKernelGGL(copy_args_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 64u)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)host_pinned, (uint4 *)dev, n16);
+    return (int)hipGetLastError();
 }
 
-int upload_confirm_args(const ConfirmArgs *host, uint32_t count, ConfirmArgs *dev, void *stream) {
-    for (uint32_t at = 0; at < count; at += kConfirmPerLaunch) {
-        ConfirmBatchArgs c{};
-        c.count = std::min(kConfirmPerLaunch, count - at);
-        for (uint32_t k = 0; k < c.count; k++) c.c[k] = host[at + k];
-        hipLaunchKernelGGL((store_args_kernel<ConfirmBatchArgs, ConfirmArgs>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, dev + at);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
 int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *dev, uint32_t *plan, uint32_t n_cus, void *stream) {
     if (count == 0 || host[0].n == 0) return 0;
     if (count > 256) return (int)hipErrorInvalidValue;
@@ -1187,11 +1157,6 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 2u);
     const uint32_t *cplan = plan;
     hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
-    return (int)hipGetLastError();
-}
-
-int upload_col_ptrs(const ColPtrChunk &c, void *dev, void *stream) {
-    hipLaunchKernelGGL((store_args_kernel<ColPtrChunk, const void *>), dim3(1), dim3(256), 0, (hipStream_t)stream, c, reinterpret_cast<const void **>(dev));
     return (int)hipGetLastError();
 }
 

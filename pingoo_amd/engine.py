@@ -103,6 +103,11 @@ def lib():
     L.pwaf_engine_stream.restype = vp
     L.pwaf_evaluate_batch.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp]
     L.pwaf_evaluate_device.argtypes = [vp, C.POINTER(_abi.Batch), vp, vp, vp, vp, vp]
+    L.pwaf_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.pwaf_host_free.argtypes = [vp]
+    L.pwaf_host_free.restype = None
+    L.pwaf_host_register.argtypes = [vp, C.c_size_t]
+    L.pwaf_host_unregister.argtypes = [vp]
     L.pwaf_evaluate_one.argtypes = [vp, C.POINTER(_abi.Request), C.POINTER(_abi.Verdict)]
     L.pwaf_engine_device_status.argtypes = [vp]
     L.pwaf_engine_set_profiling.argtypes = [vp, C.c_int]
