@@ -554,7 +554,8 @@ def main():
             el, kt, cnt_r = Rr.timed_run(dbatch, args.steps, 1)
             sm = Rr.mode_summary(el, kt, args.steps)
             result["residual"] = {"extra_rules": args.residual, "rules_on_the_interpreter": n_res, "ms_per_step": sm["ms_per_step"], "requests_per_s": sm["requests_per_s"],
-                                  "residual_kernel_ms_per_step": sm["kernels_ms_per_step"].get("residual", 0.0), "delta_ms_vs_headline": sm["ms_per_step"] - 1000.0 * elapsed / args.steps,
+                                  "mode": {0: "none", 1: "interpreted", 2: "specialized (hiprtc)"}[eng_r.residual_mode],
+                                  "residual_kernel_ms_per_step": sum(v for k, v in sm["kernels_ms_per_step"].items() if k.startswith("residual")), "delta_ms_vs_headline": sm["ms_per_step"] - 1000.0 * elapsed / args.steps,
                                   "kernels_ms_per_step": sm["kernels_ms_per_step"], "action_counts_allow_block_captcha_bypass": cnt_r}
             eng_r.close()
             del Rr

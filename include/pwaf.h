@@ -128,6 +128,8 @@ void pwaf_list_free(char **items, size_t n);
                                        * rule is a fail-open hole */
 #define PWAF_OPT_GLOBAL_VERDICT_TABLES 128u /* testing: the verdict kernel variant for programs whose tables do not fit LDS (same verdicts) */
 #define PWAF_OPT_NO_RESIDUAL 64u      /* do not use the per-request residual interpreter (testing / benchmarking the column path alone) */
+#define PWAF_OPT_NO_RESIDUAL_JIT 1024u /* residual rules are INTERPRETED per request (residual_kernel) instead of running as the specialized
+                                       * device program compiled by hiprtc when the engine is created (the default): same verdicts */
 #define PWAF_OPT_NO_PREFILTER 4u      /* every scan pass walks its DFA over every request (no bigram prefilter): same verdicts */
 #define PWAF_OPT_FILTER_STRIDE2 16u   /* prefilters sample every second byte wherever a pass's patterns allow it (default: stride 1
                                        * until pwaf_engine_tune decides per pass from the traffic sample): same verdicts */
@@ -391,6 +393,18 @@ int pwaf_engine_stats(const pwaf_engine *, pwaf_stats *out);
  * request value): counted on the device. counts[i] = requests, over every batch this engine has evaluated, for which caller rule i
  * ended in an execution error. Waits for the device. */
 int pwaf_engine_rule_errors(pwaf_engine *, uint64_t *counts, size_t n_rules);
+/* How the engine evaluates the rules outside the column compiler's subset (the reference: Program::execute on every request,
+ * pingoo/rules.rs:37-51): 0 = the rule set has none, 1 = interpreted per request on the device (residual_kernel),
+ * 2 = SPECIALIZED — the rules' stack programs translated to straight-line device code and compiled for this device by hiprtc at
+ * creation (csrc/residual_jit.cpp, rtc.cpp). When 1 was not asked for (PWAF_OPT_NO_RESIDUAL_JIT), a program warning says why. */
+int pwaf_engine_residual_mode(const pwaf_engine *);
+/* Inspection / test hooks of the specialized form (CPU, no device). _source: kind 0 = the rule functions alone (portable C++ over
+ * csrc/residual.h: the CPU suite compiles them with g++ and fuzzes them against the oracle), kind 1 = the whole device program as
+ * handed to hiprtc. Returns the text's length (0: the program has no residual rules, or they cannot be specialized); copies at most
+ * cap - 1 bytes + NUL. _compile: runs hiprtc for `arch` ("gfx950"); returns the code object's size, or a negative PWAF_E_* with the
+ * compiler's log in err. */
+size_t pwaf_program_residual_source(const pwaf_program *, int kind, char *buf, size_t cap);
+long pwaf_program_residual_compile(const pwaf_program *, const char *arch, char *err, size_t err_len);
 /* TEST HOOK (CPU, no device): the bigram prefilter + confirm tier of scan pass `group` over ONE field value placed `arena_offset`
  * bytes into an arena, as the device evaluates it (csrc/confirm.h is the code both run). Writes the local atom ids of the literal
  * predicates confirmed (at most cap; possibly repeated), *n_atoms, *flagged (the filter flagged the field) and *walk (a factor of a

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpwaf.so")
-SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "filter.cpp", "residual.cpp", "compile.cpp", "loaders.cpp", "batcher.cpp", "node.cpp", "engine.cpp", "kernels.hip"]
+SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "filter.cpp", "residual.cpp", "residual_jit.cpp", "rtc.cpp", "compile.cpp", "loaders.cpp", "batcher.cpp", "node.cpp", "engine.cpp", "kernels.hip"]
 HEADERS = ["frontend.h", "program.h", "kernels.h", "residual.h", "confirm.h", os.path.join("..", "..", "include", "pwaf.h")]
 
 
@@ -22,6 +22,21 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (needed to build pingoo_amd/libpwaf.so)")
+
+
+EMBED = os.path.join(CSRC, "residual_h.inc")
+
+
+def embed() -> str:
+    """csrc/residual_h.inc: residual.h as one raw string literal. residual_jit.cpp puts it in front of the specialized residual
+    program it hands to hiprtc when an engine is created (the device has no include path to find the header in)."""
+    text = open(os.path.join(CSRC, "residual.h")).read()
+    assert ')RVMH"' not in text
+    out = 'R"RVMH(' + text + ')RVMH"\n'
+    if not os.path.exists(EMBED) or open(EMBED).read() != out:
+        with open(EMBED, "w") as f:
+            f.write(out)
+    return EMBED
 
 
 def is_stale(lib: str = LIB) -> bool:
@@ -36,6 +51,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     lib = LIB if not variant else os.path.join(HERE, f"libpwaf_{variant}.so")
     if not force and not is_stale(lib):
         return lib
+    embed()
     objs = []
     objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
@@ -53,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), *(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)):
             continue
         cmd = [cc, *common, "-c", path, "-o", obj]
-        if src.endswith(".hip") or src == "engine.cpp":
+        if src.endswith(".hip") or src in ("engine.cpp", "rtc.cpp"):
             cmd[1:1] = ["-x", "hip", "--offload-arch=gfx950"]
         else:
             # host-only translation units (no HIP headers): plain C++

@@ -153,6 +153,7 @@ struct Scratch {
     View res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, gate_lists, attr;
+    DevBuf res_words;  // specialized residual program: [2][words][n] match / error bits per (request, rule)
     // What a batch needs ZEROED lives in one block (one memset per batch instead of four): the control words ([0] pool allocator, [1]
     // status word, then one length per list slot and one pair count per filtered pass), the candidate bitmaps of the filtered passes,
     // the visited bitmaps of the gap passes and the walk bitmaps of the confirm tier.
@@ -203,7 +204,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &ipres, &rec, &pool, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &ipres, &rec, &res_words, &pool, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (PinBuf &b : arg_slot) b.release();
@@ -243,6 +244,7 @@ struct pwaf_engine {
     std::mutex mu;  // guards the context ring and table rebuilds (pwaf_engine_tune)
     std::mutex prof_mu;  // while profiling is on, calls enqueue one at a time: the event / timing tables below are per engine
     DevBuf residual_errors;  // per residual rule: requests whose evaluation ended in an execution error (accumulated; pwaf_engine_rule_errors)
+    JitKernel residual_jit;  // the specialized residual program (residual_jit.cpp + rtc.cpp); function == nullptr: the rules are interpreted
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
     DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
@@ -1413,9 +1415,41 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ra.status = status_word;
         ra.rule_errors = (unsigned long long *)e->residual_errors.p;
         if ((rc = mark(nullptr, 0))) return rc;
-        int he2 = launch_residual(ra, stream);
-        if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
-        if ((rc = mark("residual", 0xF9u))) return rc;
+        if (e->residual_jit.function) {
+            // the SPECIALIZED form: the same programs as straight-line device code (compiled at creation), then the result bits -> records
+            const size_t words = (P.n_residual + 31u) / 32u;
+            if ((rc = S.res_words.reserve(2 * words * (size_t)n * 4))) return rc;
+            ResidualJitArgs ja{};
+            ja.data = ra.data;
+            ja.off = ra.off;
+            ja.blob = ra.blob;
+            ja.n = n;
+            ja.n_rules = P.n_residual;
+            ja.ip = ra.ip;
+            ja.ip_is_v6 = ra.ip_is_v6;
+            ja.port = ra.port;
+            ja.asn = ra.asn;
+            ja.country = ra.country;
+            ja.has_geo = ra.has_geo;
+            ja.geo_root4 = ra.geo_root4;
+            ja.geo_root6 = ra.geo_root6;
+            ja.geo_nodes = ra.geo_nodes;
+            ja.geo_recs = ra.geo_recs;
+            ja.match_words = (uint32_t *)S.res_words.p;
+            ja.err_words = (uint32_t *)S.res_words.p + words * (size_t)n;
+            int hj = launch_residual_jit(e->residual_jit, ja, e->n_cus, stream);
+            if (hj) return fail(PWAF_E_DEVICE, std::string("specialized residual kernel launch failed: ") + hipGetErrorString((hipError_t)hj));
+            if ((rc = mark("residual_jit", 0xF9u))) return rc;
+            if ((rc = mark(nullptr, 0))) return rc;
+            ResidualPackArgs pa{n, P.n_residual, ja.match_words, ja.err_words, ra.rec, ra.pool, ra.pool_count, ra.pool_cap, ra.status, ra.rule_errors};
+            hj = launch_residual_pack(pa, stream);
+            if (hj) return fail(PWAF_E_DEVICE, std::string("residual pack kernel launch failed: ") + hipGetErrorString((hipError_t)hj));
+            if ((rc = mark("residual_pack", 0xF9u))) return rc;
+        } else {
+            int he2 = launch_residual(ra, stream);
+            if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
+            if ((rc = mark("residual", 0xF9u))) return rc;
+        }
     }
     if (placement >= 2) HIP_TRY(hipStreamWaitEvent(stream, S.ev_join, 0));  // (the attribute kernel ran on the side stream)
     if ((rc = mark(nullptr, 0))) return rc;
@@ -1800,6 +1834,19 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             const std::vector<unsigned long long> zero(P.n_residual, 0ull);
             UP(residual_errors, zero)
         }
+        if (!(opts && (opts->flags & PWAF_OPT_NO_RESIDUAL_JIT))) {
+            // The specialized form: translate, compile for this device, load. Any failure leaves the interpreter in charge (same verdicts)
+            // and says so in the program's warnings.
+            std::string text, why;
+            std::vector<char> code;
+            hipDeviceProp_t prop;
+            bool ok = P.n_residual <= kMaxJitRules;
+            if (!ok) why = "more than " + std::to_string(kMaxJitRules) + " residual rules";
+            ok = ok && rvm_jit_program(P.residual_blob.data(), P.residual_blob.size(), text, why);
+            if (ok && hipGetDeviceProperties(&prop, e->device) != hipSuccess) { ok = false; why = "hipGetDeviceProperties failed"; }
+            ok = ok && rtc_compile(text, prop.gcnArchName, code, why) && jit_load(code, e->residual_jit, why);
+            if (!ok) e->prog.p->warnings.push_back("residual rules are interpreted per request, not specialized: " + why);
+        }
         if (P.has_geo && P.residual_needs_geo) {
             // client.asn / client.country VALUES (the class trie above only keeps which predicates hold): the trie with record leaves
             const std::vector<uint32_t> leaf0(65536, TRIE_LEAF);  // record 0 = the default {0, "XX"}
@@ -1871,9 +1918,43 @@ void pwaf_engine_destroy(pwaf_engine *e) {
                       &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
+    jit_release(e->residual_jit);
     for (auto &c : e->ctx) c->release();
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     delete e;
+}
+
+int pwaf_engine_residual_mode(const pwaf_engine *e) {
+    if (!e || e->prog.p->n_residual == 0) return 0;
+    return e->residual_jit.function ? 2 : 1;
+}
+size_t pwaf_program_residual_source(const pwaf_program *p, int kind, char *buf, size_t cap) {
+    if (!p || p->p->n_residual == 0) return 0;
+    std::string text, why;
+    const std::vector<uint8_t> &blob = p->p->residual_blob;
+    if (!(kind == 0 ? rvm_specialize(blob.data(), blob.size(), text, why) : rvm_jit_program(blob.data(), blob.size(), text, why))) {
+        (void)fail(PWAF_E_UNSUPPORTED, why);
+        return 0;
+    }
+    if (buf && cap) {
+        const size_t k = std::min(cap - 1, text.size());
+        memcpy(buf, text.data(), k);
+        buf[k] = '\0';
+    }
+    return text.size();
+}
+long pwaf_program_residual_compile(const pwaf_program *p, const char *arch, char *err, size_t err_len) {
+    if (err && err_len) err[0] = '\0';
+    if (!p || !arch) return fail(PWAF_E_INVALID_ARG, "NULL argument");
+    if (p->p->n_residual == 0) return 0;
+    std::string text, why;
+    std::vector<char> code;
+    const std::vector<uint8_t> &blob = p->p->residual_blob;
+    if (!rvm_jit_program(blob.data(), blob.size(), text, why) || !rtc_compile(text, arch, code, why)) {
+        if (err && err_len) snprintf(err, err_len, "%s", why.c_str());
+        return fail(PWAF_E_UNSUPPORTED, why);
+    }
+    return (long)code.size();
 }
 
 const pwaf_program *pwaf_engine_program(const pwaf_engine *e) { return e ? &e->prog : nullptr; }

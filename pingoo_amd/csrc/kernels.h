@@ -1,6 +1,8 @@
 // kernels.h — argument blocks and launch entry points of the gfx950 kernels (kernels.hip).
 #pragma once
 #include <cstdint>
+#include <string>
+#include <vector>
 
 #include "program.h"
 
@@ -280,6 +282,47 @@ struct ResidualArgs {
     unsigned long long *rule_errors;  // [n_rules], accumulated over the engine's batches: requests for which the rule's evaluation ended in an error
 };
 int launch_residual(const ResidualArgs &a, void *stream);
+// The SPECIALIZED form (residual_jit.cpp: the same programs as straight-line device code, compiled by hiprtc when the engine is created —
+// rtc.cpp): rvm_jit_kernel evaluates every rule for every request and writes one match bit and one error bit per (request, rule) —
+// match_words[w * n + r] bit k = rule 32 w + k — which residual_pack_kernel turns into the pseudo pass's hit records and the per-rule
+// error counters. (The struct is mirrored in the generated program's text: plain pointers and words only.)
+struct ResidualJitArgs {
+    const uint8_t *const *data;
+    const uint32_t *const *off;
+    const uint8_t *blob;
+    uint32_t n, n_rules;
+    const uint8_t *ip;
+    const uint8_t *ip_is_v6;
+    const uint16_t *port;
+    const uint32_t *asn;
+    const uint16_t *country;
+    uint32_t has_geo, pad;
+    const uint32_t *geo_root4, *geo_root6, *geo_nodes;
+    const GeoRec *geo_recs;
+    uint32_t *match_words;
+    uint32_t *err_words;
+};
+struct JitKernel {
+    void *module = nullptr, *function = nullptr;  // hipModule_t / hipFunction_t
+};
+static constexpr uint32_t kMaxJitRules = 256;  // (result words per request: 2 x ceil(rules / 32))
+bool rvm_specialize(const uint8_t *blob, size_t len, std::string &out, std::string &why);   // residual_jit.cpp
+bool rvm_jit_program(const uint8_t *blob, size_t len, std::string &out, std::string &why);
+bool rtc_compile(const std::string &source, const std::string &arch, std::vector<char> &code, std::string &why);  // rtc.cpp
+bool jit_load(const std::vector<char> &code, JitKernel &out, std::string &why);
+void jit_release(JitKernel &k);
+int launch_residual_jit(const JitKernel &k, const ResidualJitArgs &a, uint32_t n_cus, void *stream);
+struct ResidualPackArgs {
+    uint32_t n, n_rules;
+    const uint32_t *match_words, *err_words;
+    uint32_t *rec;
+    PoolEntry *pool;
+    uint32_t *pool_count;
+    uint32_t pool_cap;
+    uint32_t *status;
+    unsigned long long *rule_errors;
+};
+int launch_residual_pack(const ResidualPackArgs &a, void *stream);
 // The batch's string-column pointer table (ResidualArgs::data / off): part of the batch's descriptor block.
 struct ColPtrChunk {
     const void *p[2 * (PWAF_N_FIELDS + kMaxHeaders)];

@@ -17,7 +17,22 @@
 // have to be compiled per request), a literal pattern whose DFA exceeds the residual budget, dynamic keys into the context maps
 // (http_request[...] / client[...] / lists[...] with a computed key), nesting / stack / heap beyond the limits below.
 #pragma once
+#if !defined(__HIPCC_RTC__)
+#include <cstddef>
 #include <cstdint>
+#else  // hiprtc (the specialized form, residual_jit.cpp): no host include path to rely on — the compiler's own type macros
+typedef __UINT8_TYPE__ uint8_t;
+typedef __UINT16_TYPE__ uint16_t;
+typedef __UINT32_TYPE__ uint32_t;
+typedef __UINT64_TYPE__ uint64_t;
+typedef __INT8_TYPE__ int8_t;
+typedef __INT16_TYPE__ int16_t;
+typedef __INT32_TYPE__ int32_t;
+typedef __INT64_TYPE__ int64_t;
+typedef __SIZE_TYPE__ size_t;
+#define INT64_MIN (-__INT64_MAX__ - 1)
+#define INT64_MAX __INT64_MAX__
+#endif
 
 #if defined(__HIPCC__)
 #define PWAF_HD __host__ __device__ __forceinline__
@@ -25,6 +40,14 @@
 #else
 #define PWAF_HD inline
 #define PWAF_HD_NOINLINE inline
+#endif
+// The string helpers: out of line in the interpreter (one copy, called from a dozen places of a program that is decoded at run time);
+// in line in the SPECIALIZED form (residual_jit.cpp, compiled by hiprtc), where the source of nearly every string — which field, a
+// constant, a rope — is a literal at the call site and the dispatch inside them folds away.
+#if defined(__HIPCC_RTC__)
+#define PWAF_HD_STR PWAF_HD
+#else
+#define PWAF_HD_STR PWAF_HD_NOINLINE
 #endif
 
 namespace pwaf {
@@ -152,7 +175,7 @@ PWAF_HD const uint8_t *flat_ptr(const Machine &m, const Val &s, uint8_t (&inl)[8
     return nullptr;
 }
 // Byte i of any string (ropes: a walk over the segments — residual rules are rare, clarity over speed).
-PWAF_HD_NOINLINE uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
+PWAF_HD_STR uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
     uint8_t inl[8];
     if (str_src(s) != S_ROPE) return flat_ptr(m, s, inl)[i];
     const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = (uint32_t)((s.p >> 24) & 0xFFu);
@@ -163,7 +186,7 @@ PWAF_HD_NOINLINE uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
     }
     return 0;
 }
-PWAF_HD_NOINLINE bool str_eq_at(const Machine &m, const Val &h, uint32_t at, const Val &n) {  // h[at, at + n.a) == n (caller checks the bounds)
+PWAF_HD_STR bool str_eq_at(const Machine &m, const Val &h, uint32_t at, const Val &n) {  // h[at, at + n.a) == n (caller checks the bounds)
     uint8_t i1[8], i2[8];
     const uint8_t *ph = str_src(h) != S_ROPE ? flat_ptr(m, h, i1) : nullptr, *pn = str_src(n) != S_ROPE ? flat_ptr(m, n, i2) : nullptr;
     if (ph && pn) {
@@ -252,7 +275,20 @@ template <>
 struct Eq<-1> {
     static PWAF_HD bool eq(const Machine &, const Val &, const Val &) { return false; }  // unreachable: nesting is bounded at compile time
 };
-PWAF_HD bool val_eq(const Machine &m, const Val &a, const Val &b) { return Eq<(int)kMaxNest>::eq(m, a, b); }
+PWAF_HD bool val_eq(const Machine &m, const Val &a, const Val &b) {
+    // scalars in line (the same answers as the general comparison above): in the specialized form one operand's type is usually known
+    // at compile time, and the out-of-line general comparison — with the registers it needs — is then never referenced
+    if (a.t == T_INT && b.t == T_FLT) return (double)(int64_t)a.p == as_flt(b);
+    if (a.t == T_FLT && b.t == T_INT) return as_flt(a) == (double)(int64_t)b.p;
+    if (a.t != b.t) return false;
+    switch (b.t) {
+        case T_NULL: case T_IP: return true;
+        case T_BOOL: case T_INT: return a.p == b.p;
+        case T_FLT: return as_flt(a) == as_flt(b);
+        case T_STR: return a.a == b.a && str_eq_at(m, a, 0, b);
+        default: return Eq<(int)kMaxNest>::eq(m, a, b);  // networks, lists, maps
+    }
+}
 
 // -1 / 0 / 1, or 2 when not comparable (D5)
 PWAF_HD int val_cmp(const Machine &m, const Val &a, const Val &b) {
@@ -268,7 +304,7 @@ PWAF_HD int val_cmp(const Machine &m, const Val &a, const Val &b) {
 }
 
 // list.contains(x) / x in list (D10, D12: a network item contains an Ip by CIDR containment)
-PWAF_HD_NOINLINE bool list_contains(const Machine &m, const Val &l, const Val &x) {
+PWAF_HD_STR bool list_contains(const Machine &m, const Val &l, const Val &x) {
     if (l.t == T_LIST) {
         const Val *it = items_of(m, l);
         const NetItem *nets = section<NetItem>(m, m.h->nets);
@@ -320,25 +356,155 @@ PWAF_HD bool map_has(const Machine &m, const Val &mp, const Val &key, Val *out) 
     return false;
 }
 
-PWAF_HD_NOINLINE bool regex_match(const Machine &m, uint32_t id, const Val &s) {
+PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
     const RegexDesc &d = section<RegexDesc>(m, m.h->regexes)[id];
     const uint16_t *trans = section<uint16_t>(m, d.trans);
     const uint8_t *cm = m.blob + d.classmap, *fl = m.blob + d.flags;
+    const uint32_t nc = d.n_classes;
     uint32_t st = 0;
     if (fl[0] & 1u) return true;
-    for (uint32_t i = 0; i < s.a; i++) {
-        st = trans[st * d.n_classes + cm[str_byte(m, s, i)]];
-        if (fl[st] & 1u) return true;
+    // segment by segment (a flat string is its own only segment): the bytes of a segment are consecutive in memory
+    const bool rope = str_src(s) == S_ROPE;
+    const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = rope ? (uint32_t)((s.p >> 24) & 0xFFu) : 1u;
+    for (uint32_t k = 0; k < nseg; k++) {
+        const Val sg = rope ? m.heap[first + k] : s;
+        uint8_t inl[8];
+        const uint8_t *p = flat_ptr(m, sg, inl);
+        for (uint32_t i = 0; i < sg.a; i++) {
+            st = trans[st * nc + cm[p[i]]];
+            if (fl[st] & 1u) return true;
+        }
     }
     return (fl[st] & 2u) != 0;
 }
 
 PWAF_HD Val arith(uint32_t op /* B_ADD.. */, const Val &l, const Val &r, Machine &m);
 
-// ---- the interpreter: one rule, one request ---------------------------------------------------------------------------------------------
+// ---- the operations of the stack program ------------------------------------------------------------------------------------------------
+// One function per instruction, shared by the interpreter below (run_rule: decodes the program per request) and by the SPECIALIZED form
+// of a rule set (residual_jit.cpp: the same program translated instruction by instruction into straight-line calls of these functions
+// with the stack slots as local variables and the constants as literals, compiled for the device when the engine is created).
 // BinOp numbering of frontend.h: B_OR 0, B_AND 1, B_EQ 2, B_NE 3, B_LT 4, B_LE 5, B_GT 6, B_GE 7, B_IN 8, B_ADD 9, B_SUB 10, B_MUL 11, B_DIV 12, B_MOD 13
+PWAF_HD Val op_field(const Machine &m, uint32_t f) { return mk(T_STR, m.q.off[f][m.q.r + 1] - m.q.off[f][m.q.r], (uint64_t)f << 48); }
+PWAF_HD Val op_country(const Machine &m) { return mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); }
+PWAF_HD Val op_port(const Machine &m) { return mk_int((int64_t)m.q.port); }
+PWAF_HD Val op_asn(const Machine &m) { return mk_int((int64_t)m.q.asn); }
+PWAF_HD Val op_not(const Val &x) {
+    if (x.t == T_ERR) return x;
+    return x.t == T_BOOL ? mk_bool(x.p == 0) : mk(T_ERR);
+}
+PWAF_HD Val op_neg(const Val &x) {
+    if (x.t == T_INT) return (int64_t)x.p == INT64_MIN ? mk(T_ERR) : mk_int(-(int64_t)x.p);
+    if (x.t == T_FLT) return mk_flt(-as_flt(x));
+    return mk(T_ERR);
+}
+// The left operand of && (is_or false) / || (true), popped: true = it decides (`out` = the result: the operand itself, or an error when
+// it is not a Bool) and the right operand is skipped; false = the right operand is evaluated and IS the result (after op_bool_chk).
+PWAF_HD bool op_logic_left(bool is_or, const Val &l, Val &out) {
+    if (l.t != T_BOOL) { out = mk(T_ERR); return true; }
+    if (is_or == (l.p != 0)) { out = l; return true; }
+    return false;
+}
+PWAF_HD Val op_bool_chk(const Val &x) { return x.t == T_BOOL ? x : mk(T_ERR); }  // the right operand of && / || must be a Bool (an error stays an error)
+PWAF_HD uint32_t op_cond(const Val &c) { return c.t != T_BOOL ? 2u : c.p == 0 ? 1u : 0u; }  // 0: then branch, 1: else branch, 2: not a Bool (the conditional is an error)
+PWAF_HD Val op_mklist(Machine &m, const Val *items, uint32_t n) {
+    bool err = false;
+    for (uint32_t k = 0; k < n; k++) err = err || items[k].t == T_ERR;
+    if (err || m.heap_n + n > kHeap) return mk(T_ERR);  // (the compiler bounds heap use statically; the check here is the safety net behind it)
+    const Val v = mk(T_LIST, n, kHeapBit | m.heap_n);
+    for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = items[k];
+    return v;
+}
+PWAF_HD Val op_mkmap(Machine &m, const Val *kv /* key, value, key, value ... */, uint32_t n) {
+    bool err = false;
+    for (uint32_t k = 0; k < 2 * n; k++) err = err || kv[k].t == T_ERR || ((k & 1) == 0 && kv[k].t != T_STR);
+    if (err || m.heap_n + 2 * n > kHeap) return mk(T_ERR);
+    const uint32_t base = m.heap_n;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const Val &key = kv[2 * k], &val = kv[2 * k + 1];
+        bool dup = false;
+        for (uint32_t j = 0; j < cnt && !dup; j++)
+            if (m.heap[base + 2 * j].a == key.a && str_eq_at(m, m.heap[base + 2 * j], 0, key)) { m.heap[base + 2 * j + 1] = val; dup = true; }  // later duplicates win
+        if (!dup) { m.heap[base + 2 * cnt] = key; m.heap[base + 2 * cnt + 1] = val; cnt++; }
+    }
+    m.heap_n = base + 2 * cnt;
+    return mk(T_MAP, cnt, kHeapBit | base);
+}
+PWAF_HD Val op_index(const Machine &m, const Val &o, const Val &i) {
+    Val v = mk(T_ERR);
+    if (o.t == T_ERR || i.t == T_ERR) {}
+    else if (o.t == T_MAP) { if (i.t == T_STR) { Val out; if (map_has(m, o, i, &out)) v = out; } }
+    else if (o.t == T_LIST) { if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < o.a) v = items_of(m, o)[i.p]; }
+    else if (o.t == T_CLIST) {
+        const ListDesc &d = section<ListDesc>(m, m.h->lists)[o.a];
+        if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < d.n) {
+            if (d.type == 0) { const uint32_t *sp2 = section<uint32_t>(m, m.h->lstr) + 2 * (size_t)(d.first + i.p); v = mk(T_STR, sp2[1], ((uint64_t)S_CONST << 48) | sp2[0]); }
+            else if (d.type == 1) v = mk_int(section<int64_t>(m, m.h->lints)[d.first + i.p]);
+            else v = mk(T_NET, 0, d.first + i.p);
+        }
+    }
+    return v;
+}
+PWAF_HD Val op_select(const Machine &m, const Val &o, const Val &key) {
+    if (o.t == T_ERR) return o;
+    Val got;
+    if (o.t == T_MAP && map_has(m, o, key, &got)) return got;
+    return mk(T_ERR);
+}
+// recv.fn(arg): argc is 0 (length) or 1 (the compiler turns every other arity into R_FAIL); `arg` is ignored when argc == 0
+PWAF_HD Val op_call(const Machine &m, uint32_t fn, uint32_t argc, uint32_t aux, const Val &recv, const Val &arg) {
+    Val v = mk(T_ERR);
+    if (recv.t == T_ERR || (argc && arg.t == T_ERR)) return v;
+    switch (fn) {
+        case FN_CONTAINS:
+            if (argc != 1) break;
+            if (recv.t == T_STR) { if (arg.t == T_STR) v = mk_bool(str_find(m, recv, arg)); }
+            else if (recv.t == T_LIST || recv.t == T_CLIST) v = mk_bool(list_contains(m, recv, arg));
+            else if (recv.t == T_MAP) { if (arg.t == T_STR) v = mk_bool(map_has(m, recv, arg, nullptr)); }
+            break;
+        case FN_STARTS: case FN_ENDS:
+            if (argc != 1 || recv.t != T_STR || arg.t != T_STR) break;
+            if (arg.a > recv.a) v = mk_bool(false);
+            else v = mk_bool(str_eq_at(m, recv, fn == FN_STARTS ? 0u : recv.a - arg.a, arg));
+            break;
+        case FN_LENGTH:
+            if (argc != 0) break;
+            if (recv.t == T_STR || recv.t == T_LIST || recv.t == T_MAP) v = mk_int((int64_t)recv.a);
+            else if (recv.t == T_CLIST) v = mk_int((int64_t)section<ListDesc>(m, m.h->lists)[recv.a].n);
+            break;
+        case FN_MATCHES:
+            if (argc != 1 || recv.t != T_STR || arg.t != T_STR || aux == 0xFFFu) break;  // (an invalid pattern is an execution error)
+            v = mk_bool(regex_match(m, aux, recv));
+            break;
+        default: break;
+    }
+    return v;
+}
+PWAF_HD Val op_bin(Machine &m, uint32_t op, const Val &l, const Val &r) {
+    Val v = mk(T_ERR);
+    if (l.t == T_ERR || r.t == T_ERR) return v;
+    switch (op) {
+        case 2: v = mk_bool(val_eq(m, l, r)); break;
+        case 3: v = mk_bool(!val_eq(m, l, r)); break;
+        case 4: case 5: case 6: case 7: {
+            const int c = val_cmp(m, l, r);
+            if (c != 2) v = mk_bool(op == 4 ? c < 0 : op == 5 ? c <= 0 : op == 6 ? c > 0 : c >= 0);
+            break;
+        }
+        case 8:
+            if (r.t == T_LIST || r.t == T_CLIST) v = mk_bool(list_contains(m, r, l));
+            else if (r.t == T_MAP && l.t == T_STR) v = mk_bool(map_has(m, r, l, nullptr));
+            break;
+        default: v = arith(op, l, r, m); break;
+    }
+    return v;
+}
 // 1 = the rule's program ends in Bool(true) (the rule matches), 2 = it ends in an execution ERROR (what the reference logs with warn!
 // and treats as "no match": pingoo/rules.rs:41-45), 0 = anything else (false, or a non-Bool value: no match, no error).
+PWAF_HD uint32_t rule_result(const Val &top) { return top.t == T_ERR ? 2u : (top.t == T_BOOL && top.p == 1) ? 1u : 0u; }
+
+// ---- the interpreter: one rule, one request ---------------------------------------------------------------------------------------------
 PWAF_HD_NOINLINE uint32_t run_rule(Machine &m, uint32_t rule) {
     const Ins *code = section<Ins>(m, m.h->code);
     const Val *consts = section<Val>(m, m.h->consts);
@@ -346,163 +512,64 @@ PWAF_HD_NOINLINE uint32_t run_rule(Machine &m, uint32_t rule) {
     Val st[kStack];
     uint32_t sp = 0;
     m.heap_n = 0;
-    const Val ERR = mk(T_ERR);
     for (;;) {
         const Ins in = code[pc++];
         switch (in.op) {
-            case R_END: return sp != 1 ? 0u : st[0].t == T_ERR ? 2u : (st[0].t == T_BOOL && st[0].p == 1) ? 1u : 0u;
+            case R_END: return sp != 1 ? 0u : rule_result(st[0]);
             case R_CONST: st[sp++] = consts[in.b]; break;
-            case R_FIELD: st[sp++] = mk(T_STR, m.q.off[in.b][m.q.r + 1] - m.q.off[in.b][m.q.r], (uint64_t)in.b << 48); break;
-            case R_COUNTRY: st[sp++] = mk(T_STR, 2, ((uint64_t)S_INLINE << 48) | (m.q.country & 0xFFFFu)); break;
-            case R_PORT: st[sp++] = mk_int((int64_t)m.q.port); break;
-            case R_ASN: st[sp++] = mk_int((int64_t)m.q.asn); break;
+            case R_FIELD: st[sp++] = op_field(m, in.b); break;
+            case R_COUNTRY: st[sp++] = op_country(m); break;
+            case R_PORT: st[sp++] = op_port(m); break;
+            case R_ASN: st[sp++] = op_asn(m); break;
             case R_IP: st[sp++] = mk(T_IP); break;
             case R_CLIST: st[sp++] = mk(T_CLIST, in.b); break;
-            case R_NOT: {
-                Val &x = st[sp - 1];
-                if (x.t == T_ERR) break;
-                x = x.t == T_BOOL ? mk_bool(x.p == 0) : ERR;
-                break;
-            }
-            case R_NEG: {
-                Val &x = st[sp - 1];
-                if (x.t == T_INT) x = (int64_t)x.p == INT64_MIN ? ERR : mk_int(-(int64_t)x.p);
-                else if (x.t == T_FLT) x = mk_flt(-as_flt(x));
-                else x = ERR;
-                break;
-            }
+            case R_NOT: st[sp - 1] = op_not(st[sp - 1]); break;
+            case R_NEG: st[sp - 1] = op_neg(st[sp - 1]); break;
             case R_AND_L: case R_OR_L: {
                 const Val l = st[--sp];
-                if (l.t == T_ERR || l.t != T_BOOL) { st[sp++] = ERR; pc = in.b; break; }
-                if ((in.op == R_OR_L) == (l.p != 0)) { st[sp++] = l; pc = in.b; }  // decided by the left operand
+                Val out;
+                if (op_logic_left(in.op == R_OR_L, l, out)) { st[sp++] = out; pc = in.b; }  // decided by the left operand
                 break;
             }
-            case R_BOOL_CHK: {
-                Val &x = st[sp - 1];
-                if (x.t != T_BOOL) x = ERR;
-                break;
-            }
+            case R_BOOL_CHK: st[sp - 1] = op_bool_chk(st[sp - 1]); break;
             case R_COND: {
-                const Val c = st[--sp];
-                if (c.t != T_BOOL) { st[sp++] = ERR; pc = code[in.b - 1].b; break; }  // (the instruction before the else branch is the then-branch's R_JMP to the end)
-                if (c.p == 0) pc = in.b;
+                const uint32_t c = op_cond(st[--sp]);
+                if (c == 2u) { st[sp++] = mk(T_ERR); pc = code[in.b - 1].b; }  // (the instruction before the else branch is the then-branch's R_JMP to the end)
+                else if (c == 1u) pc = in.b;
                 break;
             }
             case R_JMP: pc = in.b; break;
-            case R_FAIL: sp -= in.b; st[sp++] = ERR; break;
+            case R_FAIL: sp -= in.b; st[sp++] = mk(T_ERR); break;
             case R_MKLIST: {
                 const uint32_t n = in.b;
-                bool err = false;
-                for (uint32_t k = 0; k < n; k++) err = err || st[sp - n + k].t == T_ERR;
-                Val v = ERR;
-                if (!err && m.heap_n + n <= kHeap) {  // (the compiler bounds heap use statically; the checks here are the safety net behind it)
-                    v = mk(T_LIST, n, kHeapBit | m.heap_n);
-                    for (uint32_t k = 0; k < n; k++) m.heap[m.heap_n++] = st[sp - n + k];
-                }
+                const Val v = op_mklist(m, &st[sp - n], n);
                 sp -= n;
                 st[sp++] = v;
                 break;
             }
             case R_MKMAP: {
                 const uint32_t n = in.b;
-                bool err = false;
-                for (uint32_t k = 0; k < 2 * n; k++) err = err || st[sp - 2 * n + k].t == T_ERR || ((k & 1) == 0 && st[sp - 2 * n + k].t != T_STR);
-                Val v = ERR;
-                if (!err && m.heap_n + 2 * n <= kHeap) {
-                    const uint32_t base = m.heap_n;
-                    uint32_t cnt = 0;
-                    for (uint32_t k = 0; k < n; k++) {
-                        const Val &key = st[sp - 2 * n + 2 * k], &val = st[sp - 2 * n + 2 * k + 1];
-                        bool dup = false;
-                        for (uint32_t j = 0; j < cnt && !dup; j++)
-                            if (m.heap[base + 2 * j].a == key.a && str_eq_at(m, m.heap[base + 2 * j], 0, key)) { m.heap[base + 2 * j + 1] = val; dup = true; }
-                        if (!dup) { m.heap[base + 2 * cnt] = key; m.heap[base + 2 * cnt + 1] = val; cnt++; }
-                    }
-                    m.heap_n = base + 2 * cnt;
-                    v = mk(T_MAP, cnt, kHeapBit | base);
-                }
+                const Val v = op_mkmap(m, &st[sp - 2 * n], n);
                 sp -= 2 * n;
                 st[sp++] = v;
                 break;
             }
             case R_INDEX: {
                 const Val i = st[--sp], o = st[--sp];
-                Val v = ERR;
-                if (o.t == T_ERR || i.t == T_ERR) {}
-                else if (o.t == T_MAP) { if (i.t == T_STR) { Val out; if (map_has(m, o, i, &out)) v = out; } }
-                else if (o.t == T_LIST) { if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < o.a) v = items_of(m, o)[i.p]; }
-                else if (o.t == T_CLIST) {
-                    const ListDesc &d = section<ListDesc>(m, m.h->lists)[o.a];
-                    if (i.t == T_INT && (int64_t)i.p >= 0 && i.p < d.n) {
-                        if (d.type == 0) { const uint32_t *sp2 = section<uint32_t>(m, m.h->lstr) + 2 * (size_t)(d.first + i.p); v = mk(T_STR, sp2[1], ((uint64_t)S_CONST << 48) | sp2[0]); }
-                        else if (d.type == 1) v = mk_int(section<int64_t>(m, m.h->lints)[d.first + i.p]);
-                        else v = mk(T_NET, 0, d.first + i.p);
-                    }
-                }
-                st[sp++] = v;
+                st[sp++] = op_index(m, o, i);
                 break;
             }
-            case R_SELECT: {
-                Val &o = st[sp - 1];
-                if (o.t == T_ERR) break;
-                Val out = ERR;
-                if (o.t == T_MAP) { Val got; if (map_has(m, o, consts[in.b], &got)) out = got; }
-                o = out;
-                break;
-            }
+            case R_SELECT: st[sp - 1] = op_select(m, st[sp - 1], consts[in.b]); break;
             case R_CALL: {
                 const uint32_t argc = in.b >> 12, aux = in.b & 0xFFFu;
-                bool err = false;
-                for (uint32_t k = 0; k <= argc; k++) err = err || st[sp - 1 - argc + k].t == T_ERR;
-                const Val recv = st[sp - 1 - argc], arg = argc ? st[sp - argc] : ERR;
+                const Val recv = st[sp - 1 - argc], arg = argc ? st[sp - argc] : mk(T_ERR);
                 sp -= argc + 1;
-                Val v = ERR;
-                if (err) { st[sp++] = v; break; }
-                switch (in.a) {
-                    case FN_CONTAINS:
-                        if (argc != 1) break;
-                        if (recv.t == T_STR) { if (arg.t == T_STR) v = mk_bool(str_find(m, recv, arg)); }
-                        else if (recv.t == T_LIST || recv.t == T_CLIST) v = mk_bool(list_contains(m, recv, arg));
-                        else if (recv.t == T_MAP) { if (arg.t == T_STR) v = mk_bool(map_has(m, recv, arg, nullptr)); }
-                        break;
-                    case FN_STARTS: case FN_ENDS:
-                        if (argc != 1 || recv.t != T_STR || arg.t != T_STR) break;
-                        if (arg.a > recv.a) v = mk_bool(false);
-                        else v = mk_bool(str_eq_at(m, recv, in.a == FN_STARTS ? 0u : recv.a - arg.a, arg));
-                        break;
-                    case FN_LENGTH:
-                        if (argc != 0) break;
-                        if (recv.t == T_STR || recv.t == T_LIST || recv.t == T_MAP) v = mk_int((int64_t)recv.a);
-                        else if (recv.t == T_CLIST) v = mk_int((int64_t)section<ListDesc>(m, m.h->lists)[recv.a].n);
-                        break;
-                    case FN_MATCHES:
-                        if (argc != 1 || recv.t != T_STR || arg.t != T_STR || aux == 0xFFFu) break;  // (an invalid pattern is an execution error)
-                        v = mk_bool(regex_match(m, aux, recv));
-                        break;
-                    default: break;
-                }
-                st[sp++] = v;
+                st[sp++] = op_call(m, in.a, argc, aux, recv, arg);
                 break;
             }
             case R_BIN: {
                 const Val r = st[--sp], l = st[--sp];
-                Val v = ERR;
-                if (l.t == T_ERR || r.t == T_ERR) { st[sp++] = v; break; }
-                switch (in.a) {
-                    case 2: v = mk_bool(val_eq(m, l, r)); break;
-                    case 3: v = mk_bool(!val_eq(m, l, r)); break;
-                    case 4: case 5: case 6: case 7: {
-                        const int c = val_cmp(m, l, r);
-                        if (c != 2) v = mk_bool(in.a == 4 ? c < 0 : in.a == 5 ? c <= 0 : in.a == 6 ? c > 0 : c >= 0);
-                        break;
-                    }
-                    case 8:
-                        if (r.t == T_LIST || r.t == T_CLIST) v = mk_bool(list_contains(m, r, l));
-                        else if (r.t == T_MAP && l.t == T_STR) v = mk_bool(map_has(m, r, l, nullptr));
-                        break;
-                    default: v = arith(in.a, l, r, m); break;
-                }
-                st[sp++] = v;
+                st[sp++] = op_bin(m, in.a, l, r);
                 break;
             }
             default: return false;

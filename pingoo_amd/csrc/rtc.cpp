@@ -1,0 +1,110 @@
+// rtc.cpp — run-time compilation of the specialized residual program (residual_jit.cpp) for the device an engine runs on.
+//
+// hiprtc is loaded on first use (dlopen: a host without it keeps working — such an engine interprets its residual rules with
+// residual_kernel, and says so in its warnings). The code object is loaded as a HIP module owned by the engine.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace pwaf {
+
+namespace {
+struct Rtc {
+    void *lib = nullptr;
+    int (*create)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*compile)(void *, int, const char **) = nullptr;
+    int (*log_size)(void *, size_t *) = nullptr;
+    int (*log)(void *, char *) = nullptr;
+    int (*code_size)(void *, size_t *) = nullptr;
+    int (*code)(void *, char *) = nullptr;
+    int (*destroy)(void **) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rtc &rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.why = std::string("libhiprtc.so cannot be loaded: ") + dlerror(); return; }
+        auto sym = [&](const char *n) { return dlsym(r.lib, n); };
+        r.create = (decltype(r.create))sym("hiprtcCreateProgram");
+        r.compile = (decltype(r.compile))sym("hiprtcCompileProgram");
+        r.log_size = (decltype(r.log_size))sym("hiprtcGetProgramLogSize");
+        r.log = (decltype(r.log))sym("hiprtcGetProgramLog");
+        r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
+        r.code = (decltype(r.code))sym("hiprtcGetCode");
+        r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+        r.ok = r.create && r.compile && r.log_size && r.log && r.code_size && r.code && r.destroy;
+        if (!r.ok) r.why = "libhiprtc.so lacks an entry point";
+    });
+    return r;
+}
+}  // namespace
+
+// Compiles `source` for `arch` ("gfx950"; a target id's feature suffix is dropped: the code object then runs under any setting).
+// No device is needed (the CPU suite checks that the generated program of its fuzz rules compiles for gfx950).
+bool rtc_compile(const std::string &source, const std::string &arch, std::vector<char> &code, std::string &why) {
+    Rtc &r = rtc();
+    if (!r.ok) { why = r.why; return false; }
+    void *prog = nullptr;
+    if (r.create(&prog, source.c_str(), "pwaf_residual.hip", 0, nullptr, nullptr) != 0) { why = "hiprtcCreateProgram failed"; return false; }
+    const std::string a = "--offload-arch=" + arch.substr(0, arch.find(':'));
+    const char *opts[] = {a.c_str(), "-O3", "-std=c++17", "-Wno-pragma-once-outside-header"};
+    const int rc = r.compile(prog, 4, opts);
+    if (rc != 0) {
+        size_t n = 0;
+        r.log_size(prog, &n);
+        std::string log(n + 1, '\0');
+        if (n) r.log(prog, &log[0]);
+        why = "hiprtc could not compile the specialized residual program: " + log.substr(0, 2000);
+        r.destroy(&prog);
+        return false;
+    }
+    size_t n = 0;
+    if (r.code_size(prog, &n) != 0 || n == 0) { why = "hiprtcGetCodeSize failed"; r.destroy(&prog); return false; }
+    code.resize(n);
+    const int rc2 = r.code(prog, code.data());
+    r.destroy(&prog);
+    if (rc2 != 0) { why = "hiprtcGetCode failed"; return false; }
+    return true;
+}
+
+bool jit_load(const std::vector<char> &code, JitKernel &out, std::string &why) {
+    hipModule_t mod = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, code.data());
+    if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
+    hipFunction_t fn = nullptr;
+    e = hipModuleGetFunction(&fn, mod, "rvm_jit_kernel");
+    if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); (void)hipModuleUnload(mod); return false; }
+    out.module = mod;
+    out.function = fn;
+    return true;
+}
+
+void jit_release(JitKernel &k) {
+    if (k.module) (void)hipModuleUnload((hipModule_t)k.module);
+    k.module = k.function = nullptr;
+}
+
+int launch_residual_jit(const JitKernel &k, const ResidualJitArgs &a, uint32_t n_cus, void *stream) {
+    if (a.n == 0 || a.n_rules == 0) return 0;
+    ResidualJitArgs args = a;
+    size_t size = sizeof args;
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, std::max(1u, n_cus) * 8u);
+    return (int)hipModuleLaunchKernel((hipFunction_t)k.function, blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+}
+
+}  // namespace pwaf

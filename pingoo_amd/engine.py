@@ -87,6 +87,11 @@ def lib():
     L.pwaf_program_rule_status.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
     L.pwaf_program_confirm_field.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pwaf_engine_rule_errors.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
+    L.pwaf_engine_residual_mode.argtypes = [vp]
+    L.pwaf_program_residual_source.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    L.pwaf_program_residual_source.restype = C.c_size_t
+    L.pwaf_program_residual_compile.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.pwaf_program_residual_compile.restype = C.c_long
     L.pwaf_engine_create.argtypes = create_args + [C.POINTER(vp), C.POINTER(_abi.CompileError)]
     L.pwaf_engine_destroy.argtypes = [vp]
     L.pwaf_engine_destroy.restype = None
@@ -300,6 +305,24 @@ class CompiledProgram:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
         return sorted(set(atoms[k] for k in range(n.value))), bool(fl.value), bool(wk.value)
 
+    def residual_source(self, kind: int = 1) -> str:
+        """Inspection hook: the specialized form of the residual rules (csrc/residual_jit.cpp). kind 0 = the rule functions alone,
+        1 = the whole device program as handed to hiprtc at engine creation. "" when the rule set has no residual rules."""
+        n = lib().pwaf_program_residual_source(self._h, kind, None, 0)
+        if n == 0:
+            return ""
+        buf = C.create_string_buffer(n + 1)
+        lib().pwaf_program_residual_source(self._h, kind, buf, n + 1)
+        return buf.value.decode()
+
+    def residual_compile(self, arch: str = "gfx950") -> int:
+        """Inspection hook: compiles that program with hiprtc for `arch` (no device needed); the code object's size (0: no residual rules)."""
+        err = C.create_string_buffer(4000)
+        rc = lib().pwaf_program_residual_compile(self._h, arch.encode(), err, 4000)
+        if rc < 0:
+            _raise(int(rc), err.value.decode(errors="replace"))
+        return int(rc)
+
     def rule_status(self, i: int) -> Tuple[int, str]:
         """(PWAF_OK, "") or (PWAF_E_UNSUPPORTED, reason): a rule the device compiler cannot take never matches and says so here."""
         buf = C.create_string_buffer(300)
@@ -361,6 +384,12 @@ class RuleEngine:
     @property
     def program(self) -> CompiledProgram:
         return CompiledProgram._borrow(lib().pwaf_engine_program(self._h))
+
+    @property
+    def residual_mode(self) -> int:
+        """0: no residual rules; 1: interpreted per request (residual_kernel); 2: specialized — compiled for this device by hiprtc when
+        the engine was created (csrc/residual_jit.cpp). With 1 and no OPT_NO_RESIDUAL_JIT, a program warning says why."""
+        return int(lib().pwaf_engine_residual_mode(self._h))
 
     def rule_errors(self, n_rules: int) -> List[int]:
         """Per caller rule: requests (over every batch so far) for which the rule's evaluation ended in an execution error — what the

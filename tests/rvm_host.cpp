@@ -9,6 +9,10 @@
 #include "../pingoo_amd/csrc/program.h"
 #include "../pingoo_amd/csrc/residual.h"
 
+namespace pwaf {
+bool rvm_specialize(const uint8_t *blob, size_t len, std::string &out, std::string &why);  // residual_jit.cpp
+}
+
 using namespace pwaf;
 
 struct Handle {
@@ -74,6 +78,16 @@ void *rvmh_from_blob(const uint8_t *blob, size_t len) {
     h->n_rules = reinterpret_cast<const rvm::Header *>(h->blob.data())->n_rules;
     return h;
 }
+// The SPECIALIZED form of the handle's rules (csrc/residual_jit.cpp: the rule functions as portable C++ over residual.h), for
+// tests/test_residual_jit.py to compile with g++ and run beside the interpreter. Returns the text's length (0 + why on failure).
+size_t rvmh_specialize(void *hv, char *buf, size_t cap, char *why, size_t why_len) {
+    Handle *h = (Handle *)hv;
+    std::string text, reason;
+    if (!rvm_specialize(h->blob.data(), h->blob.size(), text, reason)) { snprintf(why, why_len, "%s", reason.c_str()); return 0; }
+    if (buf && cap) { const size_t k = text.size() < cap - 1 ? text.size() : cap - 1; memcpy(buf, text.data(), k); buf[k] = 0; }
+    return text.size();
+}
+const uint8_t *rvmh_blob(void *hv, size_t *len) { Handle *h = (Handle *)hv; *len = h->blob.size(); return h->blob.data(); }
 void rvmh_free(void *h) { delete (Handle *)h; }
 size_t rvmh_header_count(void *h) { return ((Handle *)h)->header_names.size(); }
 const char *rvmh_header_name(void *h, size_t k) { return ((Handle *)h)->header_names[k].c_str(); }

@@ -1,6 +1,7 @@
-"""The residual interpreter on the device (residual_kernel, through the C ABI): rules the column compiler cannot take are evaluated per
-request by the stack interpreter of residual.h and land in a pseudo pass of the verdict kernel. Verdicts must be the oracle's —
-whichever path evaluates a rule."""
+"""The residual rules on the device (through the C ABI): rules the column compiler cannot take are lowered to stack programs
+(residual.h) and evaluated per request — by default as the SPECIALIZED program hiprtc compiled for the device when the engine was
+created (residual_jit.cpp; pwaf_engine_residual_mode == 2), with PWAF_OPT_NO_RESIDUAL_JIT by the interpreter kernel (mode 1) — and
+land in a pseudo pass of the verdict kernel. Verdicts must be the oracle's — whichever path evaluates a rule."""
 import random
 
 import numpy as np
@@ -16,8 +17,16 @@ pytestmark = pytest.mark.gpu
 B, CAP = _abi.RULE_ACTION_BLOCK, _abi.RULE_ACTION_CAPTCHA
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_mixed_rule_sets_on_the_device(seed):
+JIT = {"specialized": 0, "interpreted": _abi.OPT_NO_RESIDUAL_JIT}
+
+
+def check_mode(eng, how):
+    n_res = sum("residual interpreter" in w for w in eng.program.warnings())
+    assert eng.residual_mode == (0 if n_res == 0 else 2 if how == "specialized" else 1), (how, eng.residual_mode, eng.program.warnings())
+
+
+@pytest.mark.parametrize("seed,how", [(s, "specialized") for s in range(16)] + [(s, "interpreted") for s in range(0, 16, 3)])
+def test_mixed_rule_sets_on_the_device(seed, how):
     rng = random.Random(717100 + seed)
     rules = []
     for k in range(rng.randint(2, 12)):
@@ -29,7 +38,8 @@ def test_mixed_rule_sets_on_the_device(seed):
         rules.append((f"r{k}", e, H.fuzz_actions(rng)))
     geo = H.fuzz_geoip(rng) if seed % 2 else None
     flags = rng.choice([0, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
-    eng = RuleEngine(rules, TR.LISTS, geo, flags=flags | _abi.OPT_LENIENT)
+    eng = RuleEngine(rules, TR.LISTS, geo, flags=flags | _abi.OPT_LENIENT | JIT[how])
+    check_mode(eng, how)
     seen, _ = H.as_the_engine_sees(rules, eng.program)
     n = rng.choice([1, 64, 65, 300, 1000])
     reqs = TR.requests(rng, n)
@@ -44,7 +54,8 @@ def test_mixed_rule_sets_on_the_device(seed):
     eng.close()
 
 
-def test_residual_known_answers_and_dnf_explosion_on_the_device():
+@pytest.mark.parametrize("how", list(JIT))
+def test_residual_known_answers_and_dnf_explosion_on_the_device(how):
     rules = [("arith", "http_request.path.length() + 1 > http_request.url.length() && client.remote_port % 2 == 0", [B]),
              ("concat", '(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && http_request.path + "x" == "/qx"', [CAP]),
              ("list", '[http_request.host, "zz"].contains(http_request.path)', [B]),
@@ -53,7 +64,8 @@ def test_residual_known_answers_and_dnf_explosion_on_the_device():
              ("cond", '(http_request.path.starts_with("/a") ? http_request.host : http_request.url).ends_with("!")', [B]),
              ("big", " && ".join(f'(http_request.path.contains("a{k}") || http_request.url.contains("b{k}") || http_request.host.contains("c{k}"))' for k in range(8)), [CAP]),
              ("plain", 'http_request.path.contains("plain")', [B])]
-    eng = RuleEngine(rules)
+    eng = RuleEngine(rules, flags=JIT[how])
+    check_mode(eng, how)
     assert not eng.partial and sum("residual interpreter" in w for w in eng.program.warnings()) == 7
     rng = random.Random(5)
     words = ["/q", "a", "b", "zz", "ab:", "x!", "/a!", "FR", "plain", "a0a1a2a3a4a5a6a7", "b0", "c1c2", "/abc", ""]
@@ -67,7 +79,8 @@ def test_residual_known_answers_and_dnf_explosion_on_the_device():
     eng.close()
 
 
-def test_execution_errors_are_counted_per_rule():
+@pytest.mark.parametrize("how", list(JIT))
+def test_execution_errors_are_counted_per_rule(how):
     """The reference logs every rule whose execution errs (pingoo/rules.rs:41-45: warn!, no match). Run-time errors only arise on the
     per-request interpreter (checked arithmetic, computed indexes): the device counts them per caller rule, across batches, and the
     counts equal the oracle's."""
@@ -76,7 +89,8 @@ def test_execution_errors_are_counted_per_rule():
              ("idx", '[http_request.host, http_request.path][client.remote_port - 80] == "h"', [B]),  # index out of range unless the port is 80 or 81
              ("fine", "http_request.path.length() + 1 > http_request.url.length()", [CAP]),
              ("col", 'http_request.path == "/x"', [B])]
-    eng = RuleEngine(rules)
+    eng = RuleEngine(rules, flags=JIT[how])
+    check_mode(eng, how)
     orc = pyoracle.Oracle(rules, flags=0)
     rng = random.Random(8)
     reqs = [Request(host="h", path=rng.choice(["/x", "/y"]), url="/y?z=1", user_agent="ua", remote_port=rng.choice([0, 80, 81, 82, 443])) for _ in range(4000)]

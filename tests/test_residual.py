@@ -22,12 +22,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "pingoo_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "librvm_host.so")
-SRCS = [os.path.join(HERE, "rvm_host.cpp")] + [os.path.join(CSRC, f) for f in ("residual.cpp", "frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp")]
+SRCS = [os.path.join(HERE, "rvm_host.cpp")] + [os.path.join(CSRC, f) for f in ("residual.cpp", "residual_jit.cpp", "frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp")]
 DEPS = SRCS + [os.path.join(CSRC, f) for f in ("residual.h", "program.h", "frontend.h")]
 
 
 def build_host_vm() -> str:
     os.makedirs(BUILD, exist_ok=True)
+    from pingoo_amd.build import embed
+    embed()  # (csrc/residual_h.inc: residual_jit.cpp carries residual.h as text)
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", os.path.join(HERE, "..", "include"), *SRCS, "-o", LIB]
         subprocess.run(cmd, check=True)
@@ -50,6 +52,8 @@ def vm():
         L.rvmh_header_count.argtypes = [C.c_void_p]
         L.rvmh_header_name.restype = C.c_char_p
         L.rvmh_header_name.argtypes = [C.c_void_p, C.c_size_t]
+        L.rvmh_specialize.restype = C.c_size_t
+        L.rvmh_specialize.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.rvmh_eval.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         _L = L
     return _L
@@ -76,6 +80,16 @@ class HostVM:
         self._h = vm().rvmh_from_blob(blob, len(blob))
         self.header_names = list(header_names)
         return self
+
+    def specialized_source(self) -> str:
+        """The rules as straight-line C++ over residual.h (csrc/residual_jit.cpp)."""
+        why = C.create_string_buffer(400)
+        n = vm().rvmh_specialize(self._h, None, 0, why, 400)
+        if n == 0:
+            raise ValueError(why.value.decode(errors="replace"))
+        buf = C.create_string_buffer(n + 1)
+        vm().rvmh_specialize(self._h, buf, n + 1, why, 400)
+        return buf.value.decode()
 
     def __del__(self):
         if getattr(self, "_h", None):
