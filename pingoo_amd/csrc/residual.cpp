@@ -136,8 +136,23 @@ struct ResidualBuilder::Impl {
             std::vector<uint8_t> tab(g.trans.size() * 2 + 256 + g.n_states);
             memcpy(tab.data(), g.trans.data(), g.trans.size() * 2);
             memcpy(tab.data() + g.trans.size() * 2, g.classmap, 256);
+            uint8_t *fl = tab.data() + g.trans.size() * 2 + 256;
             for (uint32_t s = 0; s < g.n_states; s++)
-                tab[g.trans.size() * 2 + 256 + s] = (uint8_t)((g.emit_off[s + 1] != g.emit_off[s] ? 1 : 0) | (g.end_off[s + 1] != g.end_off[s] ? 2 : 0));
+                fl[s] = (uint8_t)((g.emit_off[s + 1] != g.emit_off[s] ? 1 : 0) | (g.end_off[s + 1] != g.end_off[s] ? 2 : 0));
+            // bit 2: DEAD — no deciding or accepting state can be reached from here (an anchored pattern that already failed): the walk
+            // stops with "no match" instead of reading the rest of the string
+            std::vector<uint8_t> alive(g.n_states, 0);
+            for (uint32_t s = 0; s < g.n_states; s++) alive[s] = fl[s] != 0;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (uint32_t s = 0; s < g.n_states; s++) {
+                    if (alive[s]) continue;
+                    for (uint32_t c = 0; c < g.n_classes && !alive[s]; c++)
+                        if (alive[g.trans[(size_t)s * g.n_classes + c]]) alive[s] = 1, changed = true;
+                }
+            }
+            for (uint32_t s = 0; s < g.n_states; s++)
+                if (!alive[s]) fl[s] |= 4u;
             RegexDesc d{};
             d.n_classes = g.n_classes;
             d.trans = (uint32_t)g.trans.size() * 2;  // (sizes for now: resolved to blob offsets in blob())

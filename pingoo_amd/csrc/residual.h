@@ -109,7 +109,7 @@ struct ListDesc {     // one configured list
 struct RegexDesc {    // one literal `matches` pattern compiled to a DFA (a single-pattern DfaGroup, see program.h)
     uint32_t trans;   // byte offset in the blob of uint16 trans[n_states][n_classes]
     uint32_t classmap;  // ... of 256 class bytes
-    uint32_t flags;   // ... of n_states bytes: bit 0 = entering the state is a match, bit 1 = ending the haystack in it is a match
+    uint32_t flags;   // ... of n_states bytes: bit 0 = entering the state is a match, bit 1 = ending the haystack in it is a match, bit 2 = dead (neither can be reached any more)
     uint32_t n_classes;
 };
 // The whole residual program of a rule set is ONE blob (uploaded as is): header, then sections at the header's byte offsets.
@@ -363,6 +363,7 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
     const uint32_t nc = d.n_classes;
     uint32_t st = 0;
     if (fl[0] & 1u) return true;
+    if (fl[0] & 4u) return false;
     // segment by segment (a flat string is its own only segment): the bytes of a segment are consecutive in memory
     const bool rope = str_src(s) == S_ROPE;
     const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = rope ? (uint32_t)((s.p >> 24) & 0xFFu) : 1u;
@@ -372,7 +373,9 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
         const uint8_t *p = flat_ptr(m, sg, inl);
         for (uint32_t i = 0; i < sg.a; i++) {
             st = trans[st * nc + cm[p[i]]];
-            if (fl[st] & 1u) return true;
+            const uint32_t f = fl[st];
+            if (f & 1u) return true;
+            if (f & 4u) return false;  // dead state (residual.cpp): nothing the rest of the string holds can make it match
         }
     }
     return (fl[st] & 2u) != 0;
