@@ -55,6 +55,7 @@ struct ResidualBuilder::Impl {
     const std::vector<ResidualList> *host_lists = nullptr;
     std::function<int(const std::string &)> header_field;
     uint32_t depth = 0, max_depth = 0, heap = 0;
+    uint32_t heap_items = 0;  // the largest heap bound over the accepted rules (Header::heap_items)
 
     uint32_t str_const(const std::string &s) {
         const uint32_t off = (uint32_t)strpool.size();
@@ -153,6 +154,13 @@ struct ResidualBuilder::Impl {
             }
             for (uint32_t s = 0; s < g.n_states; s++)
                 if (!alive[s]) fl[s] |= 4u;
+            // ... and both facts about the TARGET state ride in the table entry (states < 8192: bits 15 and 14 are free), so a step of the
+            // walk is one table load (regex_match of residual.h)
+            uint16_t *tr = reinterpret_cast<uint16_t *>(tab.data());
+            for (size_t k = 0; k < g.trans.size(); k++) {
+                const uint16_t to = g.trans[k];
+                tr[k] = (uint16_t)(to | ((fl[to] & 1u) ? 0x8000u : 0u) | ((fl[to] & 4u) ? 0x4000u : 0u));
+            }
             RegexDesc d{};
             d.n_classes = g.n_classes;
             d.trans = (uint32_t)g.trans.size() * 2;  // (sizes for now: resolved to blob offsets in blob())
@@ -483,6 +491,7 @@ int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualL
         if (top.ctx) m.push_err();  // a map is not Bool(true)
         m.emit(R_END);
         m.entries.push_back(entry);
+        m.heap_items = std::max(m.heap_items, m.heap);
         return (int)m.entries.size() - 1;
     } catch (Reject &rj) {
         why = rj.why;
@@ -526,7 +535,9 @@ std::vector<uint8_t> ResidualBuilder::blob() const {
     }
     h.regexes = put(rd.data(), rd.size() * sizeof(RegexDesc), 4);
     h.needs_geo = m.needs_geo ? 1u : 0u;
+    h.heap_items = m.heap_items;
     align(16);
+    out.resize(out.size() + 16);  // (strings are read eight bytes at a time: residual.h load8)
     h.total_bytes = (uint32_t)out.size();
     memcpy(out.data(), &h, sizeof h);
     return out;

@@ -90,10 +90,13 @@ bool translate_rule(const Header &h, const uint8_t *blob, uint32_t rule, std::st
     }
     // pass 2: text
     std::string s;
-    s += "PWAF_RVM_RULE uint32_t rvm_rule_" + std::to_string(rule) + "(Machine &m) {\n";
+    // (a heap of its own per rule: a rule that reads its heap through an index the compiler cannot resolve then keeps ITS heap in
+    // scratch memory, not every rule's — the others' stay in registers)
+    s += "PWAF_RVM_RULE uint32_t rvm_rule_" + std::to_string(rule) + "(const Machine &m0) {\n";
+    s += "    Machine m;\n    m.blob = m0.blob;\n    m.h = m0.h;\n    m.q = m0.q;\n    m.heap_n = 0;\n";
     s += "    Val ";
     for (int k = 0; k < std::max(1, max_depth); k++) s += (k ? ", " : "") + slot(k);
-    s += ";\n    m.heap_n = 0;\n";
+    s += ";\n";
     int d = 0;
     for (uint32_t pc = entry; pc <= end; pc++) {
         const Ins in = code[pc];
@@ -173,7 +176,7 @@ bool rvm_specialize(const uint8_t *blob, size_t len, std::string &out, std::stri
     std::string s = "namespace pwaf {\nnamespace rvm {\n";
     for (uint32_t k = 0; k < h.n_rules; k++)
         if (!translate_rule(h, blob, k, s, why)) return false;
-    s += "PWAF_RVM_RULE uint32_t rvm_rule_dispatch(Machine &m, uint32_t k) {\n    switch (k) {\n";
+    s += "PWAF_RVM_RULE uint32_t rvm_rule_dispatch(const Machine &m, uint32_t k) {\n    switch (k) {\n";
     for (uint32_t k = 0; k < h.n_rules; k++) s += "        case " + std::to_string(k) + ": return rvm_rule_" + std::to_string(k) + "(m);\n";
     s += "        default: return 0u;\n    }\n}\n}  // namespace rvm\n}  // namespace pwaf\n";
     out += s;
@@ -189,6 +192,7 @@ bool rvm_jit_program(const uint8_t *blob, size_t len, std::string &out, std::str
     memcpy(&h, blob, sizeof h);
     std::string s;
     s += "#define PWAF_RVM_RULE static __device__\n";
+    s += "#define PWAF_RVM_HEAP " + std::to_string(std::max(1u, std::min(h.heap_items, 64u))) + "\n";
     s += kResidualHeaderText;
     s += "\n";
     if (!rvm_specialize(blob, len, s, why)) return false;
@@ -218,7 +222,7 @@ extern "C" __global__ __launch_bounds__(256) void rvm_jit_kernel(RvmJitArgs a) {
     m.q.data = a.data;
     m.q.off = a.off;
     m.heap_n = 0;
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < a.n; r += gridDim.x * 256u) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += gridDim.x * blockDim.x) {
         m.q.r = r;
         m.q.ip = a.ip + (size_t)r * 16;
         m.q.v6 = a.ip_is_v6[r];

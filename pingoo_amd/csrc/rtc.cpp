@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -103,8 +104,15 @@ int launch_residual_jit(const JitKernel &k, const ResidualJitArgs &a, uint32_t n
     ResidualJitArgs args = a;
     size_t size = sizeof args;
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    const uint32_t blocks = std::min<uint32_t>((a.n + 255) / 256, std::max(1u, n_cus) * 8u);
-    return (int)hipModuleLaunchKernel((hipFunction_t)k.function, blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+    // one workgroup per 256 requests: the groups are short and uneven (a rule that walks a string next to seven that compare two
+    // integers), the dispatcher balances them; a grid capped at the occupancy ran a third of its second round on an idle chip
+    (void)n_cus;
+    uint32_t wg = 256, blocks = (a.n + 255) / 256;
+#ifdef PWAF_PROFILING
+    if (const char *w = getenv("PWAF_JIT_WG")) { wg = (uint32_t)atoi(w); blocks = (a.n + wg - 1) / wg; }              // timing experiments
+    if (const char *c = getenv("PWAF_JIT_CAP")) blocks = std::min<uint32_t>(blocks, std::max(1u, n_cus) * (uint32_t)atoi(c));
+#endif
+    return (int)hipModuleLaunchKernel((hipFunction_t)k.function, blocks, 1, 1, wg, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
 }
 
 }  // namespace pwaf
