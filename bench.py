@@ -508,6 +508,22 @@ def main():
                                         "sample": f"{m} requests from host memory, synchronous pwaf_evaluate_batch (H2D of ~{hb.algorithmic_bytes() / m:.0f} B/request, kernels, D2H of 8 B/request), median of {len(lat)} calls",
                                         "latency_ms": {"p50": 1e3 * pct(lat, 50), "p99": 1e3 * pct(lat, 99)},
                                         "verdicts_match_device_resident_run": bool((hv["action"] == gv[:, 0]).all() and (hv["rule_idx"] == gv[:, 1]).all())}
+            # the same call on PAGE-LOCKED columns and result array (pwaf_host_register / pwaf_host_alloc: what a listener that parses
+            # requests into such arenas hands over): the copy engine reads the caller's bytes directly, validation runs under the copies
+            from pingoo_amd.engine import PinnedVerdicts
+            pv = PinnedVerdicts(m)
+            hb.pin()
+            eng.evaluate_batch(hb, out=pv.array)
+            lat_p = []
+            for _ in range(6 if args.config != 5 else 12):
+                t0 = time.perf_counter()
+                eng.evaluate_batch(hb, out=pv.array)
+                lat_p.append(time.perf_counter() - t0)
+            result["pcie_inclusive"]["page_locked"] = {"value": m / pct(lat_p, 50), "unit": "requests/s", "latency_ms": {"p50": 1e3 * pct(lat_p, 50), "p99": 1e3 * pct(lat_p, 99)},
+                                                       "gb_per_s_in": hb.algorithmic_bytes() / pct(lat_p, 50) / 1e9,
+                                                       "verdicts_match_device_resident_run": bool((pv.array["action"] == gv[:, 0]).all() and (pv.array["rule_idx"] == gv[:, 1]).all())}
+            hb.unpin()
+            pv.free()
             if "latency_ms" in result:
                 result["latency_ms"]["host_batch_pcie_inclusive"] = result["pcie_inclusive"]["latency_ms"]
             # the same host batches from several caller threads at once: the engine's per-call contexts (scratch, staging buffers,

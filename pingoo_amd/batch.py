@@ -198,6 +198,42 @@ class RequestBatch:
             L.pwaf_host_unregister(a.ctypes.data)
         self._locked = []
 
+    def _arrays(self):
+        arrs = list(self.data) + list(self.offsets) + [self.ip, self.ip_is_v6, self.port, self.flags]
+        if self.asn is not None:
+            arrs += [self.asn, self.country]
+        for hd, ho in self.headers.values():
+            arrs += [hd, ho]
+        return arrs
+
+    def pin(self) -> "RequestBatch":
+        """Page-locks every column (pwaf_host_register): the copy engine then reads the caller's bytes directly — no staging copy inside
+        the runtime, and pwaf_evaluate_batch validates the offsets while the copies are in flight. What a listener that parses requests
+        into pwaf_host_alloc'd arenas gets without this step. Undo with unpin() before the arrays are freed."""
+        from .engine import _raise, lib  # (engine imports this module)
+
+        if getattr(self, "_pinned", None):
+            return self
+        done = []
+        for a in self._arrays():
+            if a.nbytes == 0:
+                continue
+            rc = lib().pwaf_host_register(a.ctypes.data, a.nbytes)
+            if rc != 0:
+                for q in done:
+                    lib().pwaf_host_unregister(q.ctypes.data)
+                _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+            done.append(a)
+        self._pinned = done
+        return self
+
+    def unpin(self) -> None:
+        from .engine import lib
+
+        for a in getattr(self, "_pinned", None) or []:
+            lib().pwaf_host_unregister(a.ctypes.data)
+        self._pinned = None
+
     def algorithmic_bytes(self) -> int:
         """sum(field bytes) + 4*(5+1) offset bytes + 22 B numerics + 8 B verdict per request
         (+6 B when GeoIP is precomputed on the host)."""

@@ -153,7 +153,7 @@ struct Scratch {
     View res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, gate_lists, attr;
-    DevBuf res_words;  // specialized residual program: [2][words][n] match / error bits per (request, rule)
+    DevBuf res_words;  // specialized residual program: [words][n] match bits per (request, rule)
     // What a batch needs ZEROED lives in one block (one memset per batch instead of four): the control words ([0] pool allocator, [1]
     // status word, then one length per list slot and one pair count per filtered pass), the candidate bitmaps of the filtered passes,
     // the visited bitmaps of the gap passes and the walk bitmaps of the confirm tier.
@@ -658,7 +658,8 @@ int assign_lists(pwaf_engine *e) {
         std::vector<PassInfo> pt(e->groups.size() + 2);
         pt[e->groups.size()] = PassInfo{P.fcmp_base, 0u};  // the pseudo pass of the field-against-field atoms (dense records)
         // ... and the one of the residual rules (right after it, or in its place when there are no such atoms)
-        pt[e->groups.size() + (P.fcmp.empty() ? 0u : 1u)] = PassInfo{P.residual_base, 0u};
+        // (dense records from the interpreter kernel; none when the specialized program runs: the verdict kernel reads its result words)
+        pt[e->groups.size() + (P.fcmp.empty() ? 0u : 1u)] = PassInfo{P.residual_base, e->residual_jit.function ? (3u << 24) : 0u};
         uint32_t fi = 0;
         for (size_t k = 0; k < e->groups.size(); k++) {
             const DevGroup &d = e->groups[k];
@@ -857,6 +858,12 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.n_passes = n_passes;
     v.rec = (const uint32_t *)S.rec.p;
     v.passes = (const PassInfo *)e->pass_table.p;
+    if (P.n_residual && e->residual_jit.function) {
+        v.res_words = (P.n_residual + 31u) / 32u;
+        v.res_base = P.residual_base;
+        if ((rc = S.res_words.reserve((size_t)v.res_words * n * 4))) return rc;
+        v.res_match = (const uint32_t *)S.res_words.p;
+    }
     v.cand_bits = (const uint32_t *)S.cand_bits.p;
     v.visit_bits = (const uint32_t *)S.visit_bits.p;
     v.bit_words = bit_words;
@@ -1416,9 +1423,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ra.rule_errors = (unsigned long long *)e->residual_errors.p;
         if ((rc = mark(nullptr, 0))) return rc;
         if (e->residual_jit.function) {
-            // the SPECIALIZED form: the same programs as straight-line device code (compiled at creation), then the result bits -> records
-            const size_t words = (P.n_residual + 31u) / 32u;
-            if ((rc = S.res_words.reserve(2 * words * (size_t)n * 4))) return rc;
+            // the SPECIALIZED form: the same programs as straight-line device code (compiled at creation); the verdict kernel reads the result words
             ResidualJitArgs ja{};
             ja.data = ra.data;
             ja.off = ra.off;
@@ -1436,15 +1441,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             ja.geo_nodes = ra.geo_nodes;
             ja.geo_recs = ra.geo_recs;
             ja.match_words = (uint32_t *)S.res_words.p;
-            ja.err_words = (uint32_t *)S.res_words.p + words * (size_t)n;
+            ja.rule_errors = ra.rule_errors;
             int hj = launch_residual_jit(e->residual_jit, ja, e->n_cus, stream);
             if (hj) return fail(PWAF_E_DEVICE, std::string("specialized residual kernel launch failed: ") + hipGetErrorString((hipError_t)hj));
             if ((rc = mark("residual_jit", 0xF9u))) return rc;
-            if ((rc = mark(nullptr, 0))) return rc;
-            ResidualPackArgs pa{n, P.n_residual, ja.match_words, ja.err_words, ra.rec, ra.pool, ra.pool_count, ra.pool_cap, ra.status, ra.rule_errors};
-            hj = launch_residual_pack(pa, stream);
-            if (hj) return fail(PWAF_E_DEVICE, std::string("residual pack kernel launch failed: ") + hipGetErrorString((hipError_t)hj));
-            if ((rc = mark("residual_pack", 0xF9u))) return rc;
         } else {
             int he2 = launch_residual(ra, stream);
             if (he2) return fail(PWAF_E_DEVICE, std::string("residual kernel launch failed: ") + hipGetErrorString((hipError_t)he2));
@@ -1620,6 +1620,19 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     }
     if ((rc = upload(e->pass_base, pass_base))) return dev_fail(rc);
     for (size_t k = 0; k < P.groups.size(); k++) e->groups[k].filter = P.groups[k].filter;
+    if (P.n_residual && !(opts && (opts->flags & PWAF_OPT_NO_RESIDUAL_JIT))) {
+        // The SPECIALIZED form of the residual rules (before the pass table is built: their pseudo pass then has no records): translate,
+        // compile for this device, load. Any failure leaves the interpreter in charge (same verdicts) and says so in the program's warnings.
+        std::string text, why;
+        std::vector<char> code;
+        hipDeviceProp_t prop;
+        bool ok = P.n_residual <= kMaxJitRules;
+        if (!ok) why = "more than " + std::to_string(kMaxJitRules) + " residual rules";
+        ok = ok && rvm_jit_program(P.residual_blob.data(), P.residual_blob.size(), text, why);
+        if (ok && hipGetDeviceProperties(&prop, e->device) != hipSuccess) { ok = false; why = "hipGetDeviceProperties failed"; }
+        ok = ok && rtc_compile(text, prop.gcnArchName, code, why) && jit_load(code, e->residual_jit, why);
+        if (!ok) e->prog.p->warnings.push_back("residual rules are interpreted per request, not specialized: " + why);
+    }
     if ((rc = assign_lists(e.get()))) return dev_fail(rc);
 #define UP(buf, vec)                                     \
     if ((rc = upload(e->buf, vec))) return dev_fail(rc);
@@ -1833,19 +1846,6 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         {
             const std::vector<unsigned long long> zero(P.n_residual, 0ull);
             UP(residual_errors, zero)
-        }
-        if (!(opts && (opts->flags & PWAF_OPT_NO_RESIDUAL_JIT))) {
-            // The specialized form: translate, compile for this device, load. Any failure leaves the interpreter in charge (same verdicts)
-            // and says so in the program's warnings.
-            std::string text, why;
-            std::vector<char> code;
-            hipDeviceProp_t prop;
-            bool ok = P.n_residual <= kMaxJitRules;
-            if (!ok) why = "more than " + std::to_string(kMaxJitRules) + " residual rules";
-            ok = ok && rvm_jit_program(P.residual_blob.data(), P.residual_blob.size(), text, why);
-            if (ok && hipGetDeviceProperties(&prop, e->device) != hipSuccess) { ok = false; why = "hipGetDeviceProperties failed"; }
-            ok = ok && rtc_compile(text, prop.gcnArchName, code, why) && jit_load(code, e->residual_jit, why);
-            if (!ok) e->prog.p->warnings.push_back("residual rules are interpreted per request, not specialized: " + why);
         }
         if (P.has_geo && P.residual_needs_geo) {
             // client.asn / client.country VALUES (the class trie above only keeps which predicates hold): the trie with record leaves

@@ -283,9 +283,9 @@ struct ResidualArgs {
 };
 int launch_residual(const ResidualArgs &a, void *stream);
 // The SPECIALIZED form (residual_jit.cpp: the same programs as straight-line device code, compiled by hiprtc when the engine is created —
-// rtc.cpp): rvm_jit_kernel evaluates every rule for every request and writes one match bit and one error bit per (request, rule) —
-// match_words[w * n + r] bit k = rule 32 w + k — which residual_pack_kernel turns into the pseudo pass's hit records and the per-rule
-// error counters. (The struct is mirrored in the generated program's text: plain pointers and words only.)
+// rtc.cpp): rvm_jit_kernel evaluates every rule for every request and writes one match bit per (request, rule) — match_words[w * n + r]
+// bit k = rule 32 w + k — which the verdict kernel reads in place of the pseudo pass's hit records (VerdictArgs::res_match), and counts
+// execution errors per rule. (The struct is mirrored in the generated program's text: plain pointers and words only.)
 struct ResidualJitArgs {
     const uint8_t *const *data;
     const uint32_t *const *off;
@@ -300,29 +300,18 @@ struct ResidualJitArgs {
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
     const GeoRec *geo_recs;
     uint32_t *match_words;
-    uint32_t *err_words;
+    unsigned long long *rule_errors;
 };
 struct JitKernel {
     void *module = nullptr, *function = nullptr;  // hipModule_t / hipFunction_t
 };
-static constexpr uint32_t kMaxJitRules = 256;  // (result words per request: 2 x ceil(rules / 32))
+static constexpr uint32_t kMaxJitRules = 256;  // (result words per request: ceil(rules / 32))
 bool rvm_specialize(const uint8_t *blob, size_t len, std::string &out, std::string &why);   // residual_jit.cpp
 bool rvm_jit_program(const uint8_t *blob, size_t len, std::string &out, std::string &why);
 bool rtc_compile(const std::string &source, const std::string &arch, std::vector<char> &code, std::string &why);  // rtc.cpp
 bool jit_load(const std::vector<char> &code, JitKernel &out, std::string &why);
 void jit_release(JitKernel &k);
 int launch_residual_jit(const JitKernel &k, const ResidualJitArgs &a, uint32_t n_cus, void *stream);
-struct ResidualPackArgs {
-    uint32_t n, n_rules;
-    const uint32_t *match_words, *err_words;
-    uint32_t *rec;
-    PoolEntry *pool;
-    uint32_t *pool_count;
-    uint32_t pool_cap;
-    uint32_t *status;
-    unsigned long long *rule_errors;
-};
-int launch_residual_pack(const ResidualPackArgs &a, void *stream);
 // The batch's string-column pointer table (ResidualArgs::data / off): part of the batch's descriptor block.
 struct ColPtrChunk {
     const void *p[2 * (PWAF_N_FIELDS + kMaxHeaders)];
@@ -358,6 +347,10 @@ struct VerdictArgs {
     // matched": no memset of 4 bytes per request and pass, no read of them here). kind 0 = the pass writes (or the host zeroes)
     // every record; 1 = bitmap `slot` of cand_bits (a filter's candidates); 2 = bitmap `slot` of visit_bits (a gap pass).
     const PassInfo *passes;
+    // the residual rules' results when their specialized program ran (ResidualJitArgs::match_words; their pseudo pass then has no
+    // records: kind 3): res_words words per request, bit k of word w = column res_base + 32 w + k
+    const uint32_t *res_match;
+    uint32_t res_words, res_base;
     const uint32_t *cand_bits, *visit_bits;
     uint32_t bit_words;  // words per bitmap (2 per 64-request group)
     // EXTENSION: header columns whose length is compared (comparison variable 7 + k)

@@ -1661,38 +1661,6 @@ int launch_residual(const ResidualArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
-// residual_pack_kernel: the specialized residual program's result words (ResidualJitArgs) -> hit records of the pseudo pass, and the
-// per-rule execution-error counters (the reference logs each erring rule, pingoo/rules.rs:41-45): one atomic per wave and rule that saw any.
-__global__ __launch_bounds__(256) void residual_pack_kernel(ResidualPackArgs a) {
-    const SlowCtx ctx{nullptr, nullptr, a.pool, a.pool_count, a.status, a.pool_cap};
-    const uint32_t words = (a.n_rules + 31u) / 32u;
-    const uint32_t n_up = (a.n + 63u) & ~63u;  // (whole waves: the ballots below need every lane of a wave in the loop)
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n_up; r += gridDim.x * 256u) {
-        const bool in = r < a.n;
-        Hits h{0, 0, kNone};
-        for (uint32_t w = 0; w < words; w++) {
-            uint32_t mt = in ? a.match_words[(size_t)w * a.n + r] : 0u;
-            for (; mt; mt &= mt - 1u) h = record_atom(ctx, 32u * w + (uint32_t)__builtin_ctz(mt), h);
-            const uint32_t er = in ? a.err_words[(size_t)w * a.n + r] : 0u;
-            if (__ballot(er != 0u) == 0ull) continue;
-            uint32_t any = er;
-            for (uint32_t d = 1; d < 64u; d <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)d, 64);
-            for (; any; any &= any - 1u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(any);
-                const unsigned long long em = __ballot(((er >> k) & 1u) != 0u);
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(em)) atomicAdd(&a.rule_errors[32u * w + k], (unsigned long long)__builtin_popcountll(em));
-            }
-        }
-        if (in) a.rec[r] = h.ovf != kNone ? (REC_OVERFLOW | h.ovf) : (h.a0 | (h.a1 << 15));
-    }
-}
-
-int launch_residual_pack(const ResidualPackArgs &a, void *stream) {
-    if (a.n == 0 || a.n_rules == 0) return 0;
-    hipLaunchKernelGGL(residual_pack_kernel, dim3(std::min<uint32_t>((a.n + 255) / 256, 4096u)), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-}
-
 // -------------------------------------------------------------------------------------------------
 // verdict
 // -------------------------------------------------------------------------------------------------
@@ -2041,6 +2009,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         unsigned long long rest[kBitRegs];  // wave-uniform: non-empty passes that got no slot (fetched inside the group: rare)
         uint32_t flags, n_pairs;
         uint4 pair0;
+        uint32_t res0;  // the first result word of the specialized residual program (VerdictArgs::res_match)
     };
     // group-invariant, per lane: the bitmap and first column of "my" pass in each register
     const uint32_t *my_bits[kBitRegs];
@@ -2098,6 +2067,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         const uint32_t gg = min(g, a.n_groups - 1);
         in.n_pairs = a.ghdr[gg];
         in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];  // (the buffer is padded: reading past the group's count is harmless)
+        in.res0 = (a.res_words && valid) ? a.res_match[i] : 0u;
     };
     for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;  // the column file starts clean; afterwards groups clean up after themselves
     for (uint32_t k = lane; k < colw; k += 64) colnz[k] = 0;
@@ -2186,6 +2156,25 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.bits.w[r], l);
                     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
                     mark_hits((valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u, base);
+                }
+            }
+        }
+
+        // 2b. residual rules evaluated by their specialized program: one result word per request and 32 rules, transposed here into the
+        //     rules' column words (a ballot per rule that matched anybody in the group)
+        for (uint32_t w = 0; w < a.res_words; w++) {
+            const uint32_t mw = w == 0 ? cur.res0 : (valid ? a.res_match[(size_t)w * a.n + i] : 0u);
+            if (__ballot(mw != 0u) == 0ull) continue;
+            uint32_t any = mw;
+            for (uint32_t d = 1; d < 64u; d <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)d, 64);
+            any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+            for (; any; any &= any - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(any);
+                const unsigned long long who = __ballot(((mw >> k) & 1u) != 0u);
+                if (lane == 0) {
+                    const uint32_t c = a.res_base + 32u * w + k;
+                    atomicOr(&col[c], who);
+                    atomicOr(&colnz[c >> 5], 1u << (c & 31));
                 }
             }
         }

@@ -184,8 +184,8 @@ bool rvm_specialize(const uint8_t *blob, size_t len, std::string &out, std::stri
 }
 
 // The whole device program: residual.h, the rule functions, and the kernel that runs every rule for every request of a batch —
-// one lane per request, results as one match bit and one error bit per (request, rule): match_words[w * n + r] bit k = rule 32 w + k.
-// (residual_pack_kernel of kernels.hip turns the words into the hit records of the pseudo pass and the per-rule error counters.)
+// one lane per request, results as one match bit per (request, rule): match_words[w * n + r] bit k = rule 32 w + k, which the verdict
+// kernel reads in place of hit records (VerdictArgs::res_match); execution errors are counted per rule as they happen.
 bool rvm_jit_program(const uint8_t *blob, size_t len, std::string &out, std::string &why) {
     Header h;
     if (len < sizeof h) { why = "residual program image too short"; return false; }
@@ -212,7 +212,7 @@ struct RvmJitArgs {
     const uint32_t *geo_root4, *geo_root6, *geo_nodes;
     const uint2 *geo_recs;  // {asn, country (two bytes, memory order) | pad << 16}
     uint32_t *match_words;
-    uint32_t *err_words;
+    unsigned long long *rule_errors;
 };
 extern "C" __global__ __launch_bounds__(256) void rvm_jit_kernel(RvmJitArgs a) {
     using namespace pwaf::rvm;
@@ -253,6 +253,9 @@ extern "C" __global__ __launch_bounds__(256) void rvm_jit_kernel(RvmJitArgs a) {
         m.q.asn = asn;
         m.q.country = country;
 )KRN";
+    // Per 32 rules one result word per request (bit k = rule 32 w + k matched: the verdict kernel turns the words of a 64-request group
+    // into its column bitmasks); execution errors (the reference logs each, pingoo/rules.rs:41-45) are counted per rule: one atomic per
+    // wave and rule that saw any.
     const uint32_t words = (h.n_rules + 31) / 32;
     for (uint32_t w = 0; w < words; w++) {
         s += "        {\n            uint32_t mt = 0, er = 0, res;\n";
@@ -260,7 +263,13 @@ extern "C" __global__ __launch_bounds__(256) void rvm_jit_kernel(RvmJitArgs a) {
             const std::string bit = std::to_string(k & 31u);
             s += "            res = rvm_rule_" + std::to_string(k) + "(m); mt |= (uint32_t)(res == 1u) << " + bit + "; er |= (uint32_t)(res == 2u) << " + bit + ";\n";
         }
-        s += "            a.match_words[(size_t)" + std::to_string(w) + " * a.n + r] = mt;\n            a.err_words[(size_t)" + std::to_string(w) + " * a.n + r] = er;\n        }\n";
+        s += "            a.match_words[(size_t)" + std::to_string(w) + " * a.n + r] = mt;\n";
+        s += "            if (__builtin_amdgcn_ballot_w64(er != 0u) != 0ull) {\n"
+             "                for (uint32_t k = 0; k < 32u; k++) {\n"
+             "                    const unsigned long long em = __builtin_amdgcn_ballot_w64(((er >> k) & 1u) != 0u);\n"
+             "                    if (em != 0ull && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(em))\n"
+             "                        __hip_atomic_fetch_add(&a.rule_errors[" + std::to_string(32 * w) + "u + k], (unsigned long long)__builtin_popcountll(em), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+             "                }\n            }\n        }\n";
     }
     s += "    }\n}\n";
     out = std::move(s);

@@ -406,9 +406,12 @@ class RuleEngine:
         return {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k != "reserved"}
 
     # ---- evaluation -------------------------------------------------------------------------------
-    def evaluate_batch(self, batch: RequestBatch, with_counts: bool = False):
-        """Host batch in, numpy VERDICT_DTYPE array out (and the 4 action counters when asked)."""
-        out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
+    def evaluate_batch(self, batch: RequestBatch, with_counts: bool = False, out: Optional[np.ndarray] = None):
+        """Host batch in, numpy VERDICT_DTYPE array out (and the 4 action counters when asked). `out`: a caller-owned result array
+        (e.g. page-locked: PinnedVerdicts(n).array) instead of a fresh one per call."""
+        if out is None:
+            out = np.zeros(batch.n, dtype=VERDICT_DTYPE)
+        assert out.dtype == VERDICT_DTYPE and len(out) >= batch.n and out.flags["C_CONTIGUOUS"]
         counts = _abi.Counts()
         st = batch.as_struct(self.header_names)
         rc = lib().pwaf_evaluate_batch(self._h, C.byref(st), out.ctypes.data, C.addressof(counts))
@@ -542,6 +545,26 @@ class NodeEngine:
 
     def __del__(self):
         self.close()
+
+
+class PinnedVerdicts:
+    """A page-locked verdict array (pwaf_host_alloc) for RuleEngine.evaluate_batch(out=...): the device-to-host copy of the results
+    lands in it directly. `.array` is the numpy view; free() releases the memory (the view must not be used afterwards)."""
+
+    def __init__(self, n: int):
+        p = C.c_void_p()
+        nbytes = max(1, n) * VERDICT_DTYPE.itemsize
+        rc = lib().pwaf_host_alloc(nbytes, C.byref(p))
+        if rc != 0:
+            _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
+        self._p = p
+        self.array = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=VERDICT_DTYPE, count=n)
+
+    def free(self) -> None:
+        if self._p:
+            self.array = None
+            lib().pwaf_host_free(self._p)
+            self._p = None
 
 
 def node_shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:

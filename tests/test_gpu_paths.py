@@ -428,3 +428,33 @@ def test_lenient_node_keeps_its_engines_when_a_rule_is_refused():
     got = node.evaluate_batch(batch)
     assert got["action"].tolist() == [1, 0] * 100 and set(got["rule_idx"][::2].tolist()) == {1}
     node.close()
+
+
+def test_host_batches_small_and_large_pageable_and_page_locked():
+    """pwaf_evaluate_batch's two staging paths (one packed page-locked block for small batches, column by column for large ones), from
+    pageable memory and from page-locked columns (pwaf_host_register) into a page-locked result array (pwaf_host_alloc): the same
+    verdicts as the oracle either way, and the same engine serves all of them in turn."""
+    from pingoo_amd.engine import PinnedVerdicts
+    rng = random.Random(99)
+    lists = H.fuzz_lists(rng)
+    rules = [(f"r{k}", H.rexpr(rng, lists), H.fuzz_actions(rng)) for k in range(12)]
+    eng = RuleEngine(rules, lists, flags=_abi.OPT_LENIENT)
+    seen, _ = H.as_the_engine_sees(rules, eng.program)
+    orc = pyoracle.Oracle(seen, lists)
+    pool = H.fuzz_requests(rng, 700, with_geo=True)
+    for n in (1, 300, 60000):  # (60000 requests exceed the 1 MiB packed block: the column-by-column path)
+        batch = RequestBatch.from_requests([pool[i % len(pool)] for i in range(n)])
+        want = orc.evaluate(batch, threads=8)
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"pageable, n={n}")
+        pv = PinnedVerdicts(n)
+        batch.pin()
+        try:
+            got, counts = eng.evaluate_batch(batch, with_counts=True, out=pv.array)
+            assert got is pv.array
+            H.assert_verdicts_equal(got, want, batch, f"page-locked, n={n}")
+            assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+            H.assert_verdicts_equal(eng.evaluate_batch(batch, out=pv.array), want, batch, f"page-locked again, n={n}")
+        finally:
+            batch.unpin()
+            pv.free()
+    eng.close()
