@@ -262,8 +262,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) and micro-batcher measurements")
     ap.add_argument("--verbose", action="store_true", help="per-kernel timings on stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--residual", type=int, default=0, help="also time the same workload with K extra rules that only the per-request residual interpreter can evaluate "
-                                                            "(arithmetic on lengths / ports, concatenation, lists of request values, orderings between fields): `residual` object")
+    ap.add_argument("--residual", type=int, default=None, help="also time the same workload with K extra rules outside the column compiler's subset (arithmetic on lengths / ports, "
+                                                            "concatenation, lists of request values, orderings between fields), evaluated by their specialized device program "
+                                                            "(DESIGN.md 3.5): `residual` object. Default: 8 in the full run, none with --no-extra-modes; 0 skips the leg")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: step i is issued on stream i mod INFLIGHT (pwaf_evaluate_device is re-entrant: every call takes "
                                                             "its own scratch context), so one batch's small latency-bound kernels run under the next batch's streaming kernels")
     args = ap.parse_args()
@@ -508,22 +509,6 @@ def main():
                                         "sample": f"{m} requests from host memory, synchronous pwaf_evaluate_batch (H2D of ~{hb.algorithmic_bytes() / m:.0f} B/request, kernels, D2H of 8 B/request), median of {len(lat)} calls",
                                         "latency_ms": {"p50": 1e3 * pct(lat, 50), "p99": 1e3 * pct(lat, 99)},
                                         "verdicts_match_device_resident_run": bool((hv["action"] == gv[:, 0]).all() and (hv["rule_idx"] == gv[:, 1]).all())}
-            # the same call on PAGE-LOCKED columns and result array (pwaf_host_register / pwaf_host_alloc: what a listener that parses
-            # requests into such arenas hands over): the copy engine reads the caller's bytes directly, validation runs under the copies
-            from pingoo_amd.engine import PinnedVerdicts
-            pv = PinnedVerdicts(m)
-            hb.pin()
-            eng.evaluate_batch(hb, out=pv.array)
-            lat_p = []
-            for _ in range(6 if args.config != 5 else 12):
-                t0 = time.perf_counter()
-                eng.evaluate_batch(hb, out=pv.array)
-                lat_p.append(time.perf_counter() - t0)
-            result["pcie_inclusive"]["page_locked"] = {"value": m / pct(lat_p, 50), "unit": "requests/s", "latency_ms": {"p50": 1e3 * pct(lat_p, 50), "p99": 1e3 * pct(lat_p, 99)},
-                                                       "gb_per_s_in": hb.algorithmic_bytes() / pct(lat_p, 50) / 1e9,
-                                                       "verdicts_match_device_resident_run": bool((pv.array["action"] == gv[:, 0]).all() and (pv.array["rule_idx"] == gv[:, 1]).all())}
-            hb.unpin()
-            pv.free()
             if "latency_ms" in result:
                 result["latency_ms"]["host_batch_pcie_inclusive"] = result["pcie_inclusive"]["latency_ms"]
             # the same host batches from several caller threads at once: the engine's per-call contexts (scratch, staging buffers,
@@ -549,6 +534,25 @@ def main():
             nb = native_batcher_bench(eng, hb)
             if nb is not None:
                 result["batcher"] = nb
+            # (last of the host-side legs: registering and unregistering 300 MB of the process's memory perturbs what runs after it)
+            # the same call on PAGE-LOCKED columns and result array (pwaf_host_register / pwaf_host_alloc: what a listener that parses
+            # requests into such arenas hands over): the copy engine reads the caller's bytes directly, validation runs under the copies
+            from pingoo_amd.engine import PinnedVerdicts
+            pv = PinnedVerdicts(m)
+            hb.pin()
+            eng.evaluate_batch(hb, out=pv.array)
+            lat_p = []
+            for _ in range(6 if args.config != 5 else 12):
+                t0 = time.perf_counter()
+                eng.evaluate_batch(hb, out=pv.array)
+                lat_p.append(time.perf_counter() - t0)
+            result["pcie_inclusive"]["page_locked"] = {"value": m / pct(lat_p, 50), "unit": "requests/s", "latency_ms": {"p50": 1e3 * pct(lat_p, 50), "p99": 1e3 * pct(lat_p, 99)},
+                                                       "gb_per_s_in": hb.algorithmic_bytes() / pct(lat_p, 50) / 1e9,
+                                                       "verdicts_match_device_resident_run": bool((pv.array["action"] == gv[:, 0]).all() and (pv.array["rule_idx"] == gv[:, 1]).all())}
+            hb.unpin()
+            pv.free()
+        if args.residual is None:
+            args.residual = 8 if (extras and args.config == 3) else 0
         if world == 1 and args.residual > 0:
             # the residual path: K rules no column form exists for, appended to the rule set — what a9's "any expression"
             # costs per batch on top of the column pipeline (it had never been timed)

@@ -56,12 +56,30 @@ Rtc &rtc() {
 
 // Compiles `source` for `arch` ("gfx950"; a target id's feature suffix is dropped: the code object then runs under any setting).
 // No device is needed (the CPU suite checks that the generated program of its fuzz rules compiles for gfx950).
-bool rtc_compile(const std::string &source, const std::string &arch, std::vector<char> &code, std::string &why) {
+namespace {
+// Code objects by (program text, architecture): the engines of a node (pwaf_node_create: one per device, the same rule set) and a
+// re-created engine compile once per process.
+struct Compiled {
+    std::string source, arch;
+    std::vector<char> code;
+};
+std::mutex g_cache_mu;
+std::vector<Compiled> g_cache;  // (a handful of rule sets per process: a linear scan)
+constexpr size_t kCacheEntries = 8;
+}  // namespace
+
+bool rtc_compile(const std::string &source, const std::string &arch_id, std::vector<char> &code, std::string &why) {
+    const std::string arch = arch_id.substr(0, arch_id.find(':'));
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (const Compiled &c : g_cache)
+            if (c.arch == arch && c.source == source) { code = c.code; return true; }
+    }
     Rtc &r = rtc();
     if (!r.ok) { why = r.why; return false; }
     void *prog = nullptr;
     if (r.create(&prog, source.c_str(), "pwaf_residual.hip", 0, nullptr, nullptr) != 0) { why = "hiprtcCreateProgram failed"; return false; }
-    const std::string a = "--offload-arch=" + arch.substr(0, arch.find(':'));
+    const std::string a = "--offload-arch=" + arch;
     const char *opts[] = {a.c_str(), "-O3", "-std=c++17", "-Wno-pragma-once-outside-header"};
     const int rc = r.compile(prog, 4, opts);
     if (rc != 0) {
@@ -79,6 +97,11 @@ bool rtc_compile(const std::string &source, const std::string &arch, std::vector
     const int rc2 = r.code(prog, code.data());
     r.destroy(&prog);
     if (rc2 != 0) { why = "hiprtcGetCode failed"; return false; }
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_cache.size() >= kCacheEntries) g_cache.erase(g_cache.begin());
+        g_cache.push_back(Compiled{source, arch, code});
+    }
     return true;
 }
 
