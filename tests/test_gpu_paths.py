@@ -146,8 +146,12 @@ def test_node_api_two_engines_from_one_thread_and_concurrent_device_calls():
 
     w = pysynth.Workload(0)  # tiny mixed config incl. header fields
     batch = w.batch(0, 20001)
-    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(batch, threads=8)
-    node = NodeEngine(w.rules, w.lists, w.geoip, devices=[0, 0])
+    # (+ two rules outside the column compiler's subset: every replica runs their specialized program, compiled once per process)
+    rules = list(w.rules) + [("res_a", "http_request.path.length() * 2 > http_request.url.length() + 3 && client.remote_port % 5 == 0", [B]),
+                             ("res_b", '(http_request.method + " " + http_request.path).starts_with("POST /a")', [CAP])]
+    want = pyoracle.Oracle(rules, w.lists, w.geoip).evaluate(batch, threads=8)
+    assert len({int(x) for x in want["rule_idx"]} & {len(rules) - 2, len(rules) - 1}) >= 1, "the residual rules never decide a request: weak test"
+    node = NodeEngine(rules, w.lists, w.geoip, devices=[0, 0])
     assert node.n_devices == 2
     got, counts = node.evaluate_batch(batch, with_counts=True)
     H.assert_verdicts_equal(got, want, batch, "node, 2 replicas")
@@ -173,7 +177,7 @@ def test_node_api_two_engines_from_one_thread_and_concurrent_device_calls():
     assert (cnts_d[0] + cnts_d[1]).cpu().tolist() == np.bincount(want["action"], minlength=4).tolist()
     node.close()
 
-    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    eng = RuleEngine(rules, w.lists, w.geoip)
     halves = [batch.slice(0, 10000), batch.slice(10000, 20001)]
     dbs = [DeviceBatch(h) for h in halves]
     outs, errs = [None, None], []
