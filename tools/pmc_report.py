@@ -9,7 +9,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 data = collections.defaultdict(dict)
 for d in sorted(glob.glob(f"{root}/pmc_*/p_counter_collection.csv")):
     for r in csv.DictReader(open(d)):
-        if "pwaf" in r["Kernel_Name"]:
+        if "pwaf" in r["Kernel_Name"] or "rvm_jit" in r["Kernel_Name"]:  # (rvm_jit_kernel: the specialized residual program, extern "C")
             data[(int(r["Dispatch_Id"]), r["Kernel_Name"].replace("void ", "")[:28])][r["Counter_Name"]] = float(r["Counter_Value"])
 rows = sorted(data.items())[-26:]
 cols = sorted({c for _, v in rows for c in v})

@@ -19,7 +19,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     for path in glob.glob(f"{root}/pmc_{cname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            if "pwaf::" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+            if ("pwaf::" in r["Kernel_Name"] or "rvm_jit" in r["Kernel_Name"]) and r["Counter_Name"] == cname:
                 per[r["Kernel_Name"].split("(")[0].replace("void ", "")][cname].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 out = {"commit": os.environ.get("PWAF_COMMIT", "?"), "unit": "bytes per launch, last pipeline pass of the trace",
        "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B; consistent with filter_kernel's known input bytes)", "kernels": {}}

@@ -16,7 +16,7 @@ def main():
         print(f"{name[:60]:<60} {calls:>6} {total / 1e3:>12.3f} {avg:>12.3f} {pct:>7.2f}")
     print()
     print("# per-launch detail of the product kernels (last pipeline pass in the trace)")
-    rows = list(c.execute("select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count from kernels where name like '%pwaf::%' order by start"))
+    rows = list(c.execute("select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count from kernels where name like '%pwaf::%' or name like '%rvm_jit%' order by start"))
     last_verdict = max(i for i, r in enumerate(rows) if "verdict" in r[0])
     prev = max([i for i, r in enumerate(rows[:last_verdict]) if "verdict" in r[0]] + [-1])
     print(f"{'kernel':<40} {'dur_us':>10} {'grid':>9} {'wg':>5} {'lds_B':>8} {'vgpr':>5} {'sgpr':>5}")
