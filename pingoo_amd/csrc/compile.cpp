@@ -1112,7 +1112,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         a.kind = ATOM_RESIDUAL;
         a.ref = (uint32_t)idx;
         a.key = "R" + std::to_string(idx);
-        P.warnings.push_back("rule #" + std::to_string(k) + " is evaluated by the per-request residual interpreter (slow path): " + col_why);
+        P.warnings.push_back("rule #" + std::to_string(k) + " has no column form and is lowered to a residual program (compiled for the device when an engine is created, else run by the per-request residual interpreter): " + col_why);
         return rc.intern_atom(std::move(a));
     };
     for (size_t k = 0; k < in.n_rules; k++) {
