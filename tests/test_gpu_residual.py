@@ -104,3 +104,34 @@ def test_execution_errors_are_counted_per_rule(how):
         expect = [sum(orc.execute_rule(k, batch, i) == 3 for i in range(batch.n)) * rounds for k in range(len(rules))]
         assert errs == expect and errs[0] > 0 and errs[1] > 0 and errs[2] > 0 and errs[3] == 0 and errs[4] == 0, (errs, expect)
     eng.close()
+
+
+@pytest.mark.parametrize("how", list(JIT))
+def test_more_than_32_residual_rules(how):
+    """The specialized program writes one result word per request and 32 rules; the verdict kernel reads the first word one group ahead
+    and the others in the group: 70 residual rules = three words, some rules erring at run time (counted per rule), batch sizes around
+    the 64-request group."""
+    rules = []
+    for k in range(70):
+        if k % 9 == 4:
+            e = f"{k} / (client.remote_port % 3 - 1) >= 0 && client.remote_port % 70 == {k}"  # divides by zero for a third of the ports: an execution error
+        elif k % 2:
+            e = f"client.remote_port % 70 == {k} && http_request.path.length() + {k} > http_request.url.length()"
+        else:
+            e = f'(http_request.path + "{k}").ends_with("{k % 10}") && client.remote_port % 70 == {k}'
+        rules.append((f"r{k}", e, [B] if k % 3 else [CAP]))
+    eng = RuleEngine(rules, flags=JIT[how] | _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    check_mode(eng, how)
+    orc = pyoracle.Oracle(rules, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    rng = random.Random(70)
+    total_err = [0] * len(rules)
+    for n in (1, 63, 64, 65, 1000):
+        reqs = [Request(host="h", path="/" + "p" * rng.randint(0, 12), url="/" + "u" * rng.randint(0, 40), user_agent="ua", remote_port=rng.randint(0, 20000)) for _ in range(n)]
+        batch = RequestBatch.from_requests(reqs)
+        want = orc.evaluate(batch)
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"70 residual rules, n={n}")
+        for k in range(len(rules)):
+            total_err[k] += sum(orc.execute_rule(k, batch, i) == 3 for i in range(n))
+    assert len(set(want["rule_idx"].tolist())) > 20  # rules of every word decide requests
+    assert eng.rule_errors(len(rules)) == total_err and sum(total_err) > 0
+    eng.close()
