@@ -50,5 +50,7 @@ def test_no_data_race_under_thread_sanitizer():
     exe = build("batcher_stub_tsan", "-O1", "-g", "-fsanitize=thread", "-DPWAF_BATCHER_SYSTEM_CLOCK")
     for args in ((32, 60, 200), (12, 60, 200, 3)):
         r, out = run(exe, *args, timeout=600)
+        if "unexpected memory mapping" in r.stderr:  # (the sanitizer runtime cannot start under this kernel's address-space layout: nothing was tested)
+            pytest.skip("ThreadSanitizer cannot run here: " + r.stderr.strip().splitlines()[0])
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0 and out["bad"] == 0, (r.returncode, out)
