@@ -48,13 +48,27 @@ extern "C" int spec_eval(const uint8_t *blob, uint32_t rule, const uint8_t *cons
 """
 
 
+def heap_items_of(m) -> int:
+    """Header::heap_items of the program image (residual.h): the compiler's bound on what any rule puts on its lane's heap."""
+    n = C.c_size_t(0)
+    TR.vm().rvmh_blob.restype = C.c_void_p
+    TR.vm().rvmh_blob.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    p = TR.vm().rvmh_blob(m._h, C.byref(n))
+    words = (C.c_uint32 * 16).from_address(p)
+    assert words[0] == 0x314D5652 and words[12] == n.value, "Header layout (residual.h) changed"
+    return int(words[13])
+
+
 def build_specialized(m: "TR.HostVM", tag: str):
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(BUILD, f"spec_{tag}.cpp")
     lib = os.path.join(BUILD, f"libspec_{tag}.so")
     with open(src, "w") as f:
         f.write(HARNESS % m.specialized_source())
-    subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"), src, "-o", lib], check=True)
+    # the heap exactly as large as the device program's (residual_jit.cpp defines PWAF_RVM_HEAP the same way): a bound that is too
+    # small shows up here as an execution error the interpreter (64 items) does not report
+    heap = max(1, min(heap_items_of(m), 64))
+    subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", f"-DPWAF_RVM_HEAP={heap}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"), src, "-o", lib], check=True)
     L = C.CDLL(lib)
     L.spec_eval.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     return L
