@@ -1917,7 +1917,6 @@ __global__ __launch_bounds__(256) void compact_kernel(FilterTable B) {
     if (blockIdx.x == n_blocks - 1 && tid == 255) *a.list_count = pos0;
 }
 
-static constexpr uint32_t kBitColEntries = 24 * 32;  // (source word, bit) -> column table, shared by the block in LDS
 
 __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
     const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
@@ -2366,7 +2365,6 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 //     /24 and oversized ids escape to an 8-byte side table and continue in the 8-bit trie nodes;
 //   * a group's inputs are requested TWO groups ahead and its DIR-24 / root entries ONE group ahead, so the long-latency loads of the
 //     next groups are in flight while the current group's rows are transposed (few waves per CU: nothing else hides them).
-static constexpr uint32_t kMaxRowWords = kSrcWords;  // ip-set, country, port-set, asn-set, asn-comparison words per request
 static constexpr uint32_t DIR_ESCAPE = 0x80000000u;
 
 // ipres_kernel (round 3): the address lookups of the attribute path as a kernel of their own — one lane per request, ~20 registers,

@@ -54,6 +54,10 @@ def test_error_paths_do_not_need_a_gpu():
     assert L.pwaf_node_evaluate_device(None, None, None, None, None) == _abi.E_INVALID_ARG
     assert L.pwaf_node_synchronize(None) == _abi.E_INVALID_ARG and L.pwaf_node_allreduce_counts(None, None, None, None) == _abi.E_INVALID_ARG
     assert L.pwaf_evaluate_batch(None, None, None, None) == _abi.E_INVALID_ARG
+    # round 4: the residual-program hooks and the page-locked memory entry points
+    assert L.pwaf_engine_residual_mode(None) == 0 and L.pwaf_program_residual_source(None, 1, None, 0) == 0
+    assert L.pwaf_program_residual_compile(None, b"gfx950", None, 0) == _abi.E_INVALID_ARG
+    assert L.pwaf_host_alloc(16, None) == _abi.E_INVALID_ARG and L.pwaf_host_register(None, 16) == _abi.E_INVALID_ARG and L.pwaf_host_unregister(None) == _abi.E_INVALID_ARG
     assert b"NULL" in L.pwaf_last_error()
     with pytest.raises(engine.ExpressionIsNotValid):
         engine.compile_expression("a ==")
