@@ -228,6 +228,43 @@ struct ResidualBuilder::Impl {
         return false;
     }
 
+    // A context map as a real Map VALUE, built per request: what a COMPUTED key needs (`client[http_request.method]`,
+    // `http_request.host in lists`): the key sets of http_request / client / lists are closed, so the map is a literal of this compiler's
+    // own making and the generic Map operations answer — a key that is not a String is an execution error, an absent one an error
+    // for [] and false for `in` / contains, exactly as for any map. keys_only: the values are never read (membership tests).
+    // Not offered: the headers map (it holds the names the WHOLE rule set mentions — later rules add to it), and http_request[computed]
+    // (its "headers" entry is that map).
+    void gen_ctx_map(int ctx, bool keys_only, Info &r) {
+        static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
+        uint32_t n = 0;
+        auto key = [&](const std::string &k) { push_str(k); n++; };
+        if (ctx == 1) {
+            if (!keys_only) throw Reject{"http_request indexed with a computed key (its headers entry is a map of the rule set's header names)"};
+            for (auto f : kFields) { key(f); push_bool(true); }
+            key("headers"); push_bool(true);
+        } else if (ctx == 2) {
+            key("ip"); if (keys_only) push_bool(true); else { emit(R_IP); push(); }
+            key("remote_port"); if (keys_only) push_bool(true); else { emit(R_PORT); push(); }
+            key("asn"); if (keys_only) push_bool(true); else { needs_geo = true; emit(R_ASN); push(); }
+            key("country"); if (keys_only) push_bool(true); else { needs_geo = true; emit(R_COUNTRY); push(); }
+        } else if (ctx == 3) {
+            std::set<std::string> seen;  // (names are distinct in the set the host hands over; like select_ctx, the first of a name counts)
+            for (size_t k = 0; k < host_lists->size(); k++) {
+                const std::string &name = (*host_lists)[k].name;
+                if (!seen.insert(name).second) continue;
+                key(name);
+                if (keys_only) push_bool(true);
+                else { emit(R_CLIST, 0, list_id(k)); push(); r.clist = true; r.len = std::max(r.len, (uint32_t)(*host_lists)[k].size()); }
+            }
+        } else {
+            throw Reject{"the headers map with a computed key (it holds the names the whole rule set mentions)"};
+        }
+        use_heap(2 * n);
+        emit(R_MKMAP, 0, n);
+        pop((int)(2 * n));
+        push();
+    }
+
     // does the node denote a context object? (decided from the syntax alone: nothing is emitted)
     int ctx_of(int ni) const {
         const Ex &e = syn->nodes[(size_t)ni];
@@ -270,7 +307,16 @@ struct ResidualBuilder::Impl {
                     const Ex &ix = syn->nodes[(size_t)e.kids[1]];
                     if (ix.kind == EX_STR) return select_ctx(o.ctx, ix.text);
                     if (ix.kind == EX_INT || ix.kind == EX_FLOAT || ix.kind == EX_BOOL || ix.kind == EX_NULL) { push_err(); return r; }  // map keys are Strings
-                    throw Reject{"a context map indexed with a computed key"};
+                    // a computed key: the map as a value, then the generic index (client / lists: closed key sets)
+                    Info mr;
+                    gen_ctx_map(o.ctx, false, mr);
+                    Info ki = gen(e.kids[1]);
+                    no_ctx(ki, "as an index");
+                    no_clist(ki, "as an index");
+                    emit(R_INDEX);
+                    pop();
+                    r = mr;
+                    return r;
                 }
                 Info i = gen(e.kids[1]);
                 no_ctx(i, "as an index");
@@ -372,7 +418,15 @@ struct ResidualBuilder::Impl {
                 const Ex &k = syn->nodes[(size_t)e.kids[1]];
                 if (k.kind == EX_STR) { push_bool(ctx_has(recv.ctx, k.text)); return r; }
                 if (k.kind == EX_INT || k.kind == EX_FLOAT || k.kind == EX_BOOL || k.kind == EX_NULL) { push_err(); return r; }
-                throw Reject{"contains() on a context map with a computed key"};
+                // a computed key: the map's key set as a value, then the generic contains
+                Info mr;
+                gen_ctx_map(recv.ctx, true, mr);
+                Info ka = gen(e.kids[1]);
+                if (ka.ctx) throw Reject{"a context map used as a function argument"};
+                if (ka.clist) throw Reject{"a configured list used as a function argument"};
+                emit(R_CALL, FN_CONTAINS, (uint32_t)(1u << 12));
+                pop();
+                return r;
             }
             if (f == "length" && argc == 0) {
                 if (recv.ctx == 1) { push_int(6); return r; }  // host, url, path, method, user_agent + the headers map (extension)
@@ -441,7 +495,15 @@ struct ResidualBuilder::Impl {
                 const Ex &k = syn->nodes[(size_t)e.kids[0]];
                 if (k.kind == EX_STR) { push_bool(ctx_has(rc, k.text)); return r; }
                 if (k.kind == EX_INT || k.kind == EX_FLOAT || k.kind == EX_BOOL || k.kind == EX_NULL) { push_err(); return r; }
-                throw Reject{"`in` on a context map with a computed key"};
+                // a computed key: evaluate it, then the map's key set as a value and the generic `in`
+                Info kl = gen(e.kids[0]);
+                if (kl.ctx) throw Reject{"a context map on the left of `in`"};
+                no_clist(kl, "on the left of `in`");
+                Info mr;
+                gen_ctx_map(rc, true, mr);
+                emit(R_BIN, (uint8_t)B_IN);
+                pop();
+                return r;
             }
             Info l = gen(e.kids[0]);
             if (l.ctx) throw Reject{"a context map on the left of `in`"};

@@ -14,8 +14,9 @@
 // evaluation entry point.
 //
 // Not covered (such a rule stays PWAF_E_UNSUPPORTED): `matches` with a pattern that is not a String literal (the regex would
-// have to be compiled per request), a literal pattern whose DFA exceeds the residual budget, dynamic keys into the context maps
-// (http_request[...] / client[...] / lists[...] with a computed key), nesting / stack / heap beyond the limits below.
+// have to be compiled per request), a literal pattern whose DFA exceeds the residual budget, http_request[...] and the headers map
+// with a computed key (client[k], lists[k] and membership of a computed key in http_request / client / lists are taken: the compiler
+// builds the closed key set as a Map value, residual.cpp: gen_ctx_map), nesting / stack / heap beyond the limits below.
 #pragma once
 #if !defined(__HIPCC_RTC__)
 #include <cstddef>
