@@ -1918,7 +1918,13 @@ void pwaf_engine_destroy(pwaf_engine *e) {
                       &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
-    jit_release(e->residual_jit);
+    if (e->residual_jit.module) {  // (a module belongs to the device it was loaded on)
+        int cur = -1;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        (void)hipSetDevice(e->device);
+        jit_release(e->residual_jit);
+        if (have) (void)hipSetDevice(cur);
+    }
     for (auto &c : e->ctx) c->release();
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     delete e;
