@@ -2357,7 +2357,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             const uint8_t *data = c->data;
             const uint32_t *off = c->offsets;
             for (uint32_t i = 0; i < n; i++)
-                for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[(data[p] & 0xDFu) | ((uint32_t)(data[p + 1] & 0xDFu) << 8)]++; tot++; }
+                for (uint32_t p = off[i]; p + 1 < off[i + 1]; p++) { cnt[filter_fold(data[p]) | (filter_fold(data[p + 1]) << 8)]++; tot++; }
             if (tot)
                 for (uint32_t b = 0; b < 65536; b++) pair_prob[f][b] = (double)cnt[b] / (double)tot;
             mean_len[f] = (double)(off[n] - off[0]) / (double)n;

@@ -49,7 +49,7 @@ Cover trivial() {
     return c;
 }
 
-static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return (uint32_t)(a & 0xDFu) | ((uint32_t)(b & 0xDFu) << 8); }
+static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return filter_fold(a) | (filter_fold(b) << 8); }  // (program.h: the fold filter_bin applies)
 
 struct Model {
     const double *pairw;  // 65536 probabilities of the case-folded bigrams

@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
         return *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (p < total ? p : 0u));
     };
     auto dword_at = [&](const uint32_t p) {  // (wave-uniform address)
-        return *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + p) & 0xDFDFDFDFu;
+        return filter_fold4(*reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + p));
     };
     // LDS byte offset of a bin = (16-bit product >> 4) * 4, for the two products of one v_pk_mul_lo_u16: ONE mask for both halves,
     // then one SDWA shift per half (v_lshrrev_b32 reading WORD_0 / WORD_1 zero-extended) — three instructions per two lookups where
@@ -1388,11 +1388,11 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
         unsigned long long hm[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t x0 = w[q].x & 0xDFDFDFDFu, x1 = w[q].y & 0xDFDFDFDFu, x2 = w[q].z & 0xDFDFDFDFu, x3 = w[q].w & 0xDFDFDFDFu;
+            const uint32_t x0 = filter_fold4(w[q].x), x1 = filter_fold4(w[q].y), x2 = filter_fold4(w[q].z), x3 = filter_fold4(w[q].w);  // (program.h: letters lose their case, nothing below 0x40 moves)
             uint32_t st, seen = 0xFFFFFFFFu, tail;
             if (STRIDE == 1) {
                 // lane 63's next dword: lane 0 of the next row (row 0 already holds the NEXT iteration's chunk; the slab's last row: `after`)
-                const uint32_t first_next = (q == 3 && !more) ? after : (__builtin_amdgcn_readfirstlane(w[(q + 1) & 3].x) & 0xDFDFDFDFu);
+                const uint32_t first_next = (q == 3 && !more) ? after : filter_fold4(__builtin_amdgcn_readfirstlane(w[(q + 1) & 3].x));
                 const uint32_t x4 = (uint32_t)__builtin_amdgcn_update_dpp((int)first_next, (int)x0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
                 uint32_t m[16];
                 {

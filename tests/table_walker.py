@@ -123,7 +123,8 @@ class Tables:
 
     @staticmethod
     def filter_bin(b0: int, b1: int, mul: int) -> int:
-        return ((((b0 & 0xDF) | ((b1 & 0xDF) << 8)) * mul) & 0xFFFF) >> 4
+        f0, f1 = b0 & ~((b0 >> 1) & 0x20), b1 & ~((b1 >> 1) & 0x20)  # program.h: filter_fold (bit 5 cleared where bit 6 is set)
+        return (((f0 | (f1 << 8)) * mul) & 0xFFFF) >> 4
 
     def filter_flags(self, g: dict, data: bytes):
         """The bigram prefilter of a pass exactly as filter_kernel applies it to the bytes of ONE field value that starts

@@ -15,7 +15,8 @@ import table_walker
 def candidates(g, data, off):
     STRIDE = int(g.get("f_stride", 1))
     """numpy model of filter_kernel over one field arena (bigrams sampled every STRIDE bytes from each field's start): bool per request"""
-    d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
+    d = data[: off[-1] + 1].astype(np.uint32)
+    d = d & ~((d >> 1) & 0x20)  # program.h: filter_fold
     p = d[:-1] | (d[1:] << 8)
     bins = ((p * int(g["f_mul"])) & 0xFFFF) >> 4
     m = g["f_table"][bins].astype(np.uint64)

@@ -18,7 +18,8 @@ from synth import pysynth  # noqa: E402
 def hits(g, data, off):
     """windows completed at every arena position (bool array) under pass g's filter"""
     stride = int(g.get("f_stride", 1))
-    d = data[: off[-1] + 1].astype(np.uint32) & 0xDF
+    d = data[: off[-1] + 1].astype(np.uint32)
+    d = d & ~((d >> 1) & 0x20)  # program.h: filter_fold
     p = d[:-1] | (d[1:] << 8)
     bins = ((p * int(g["f_mul"])) & 0xFFFF) >> 4
     m = g["f_table"][bins].astype(np.uint64)
