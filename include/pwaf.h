@@ -357,7 +357,7 @@ void pwaf_node_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t 
  * drop-in RuleEngine::evaluate(Request) -> Action keeps that call shape. The batcher gathers concurrent callers: each call blocks
  * until its batch — closed when it holds max_batch requests, when its oldest request has waited max_delay_us, or (early close) when
  * every caller currently inside the call is already waiting in a batch and the oldest has waited max_delay_us / 8: callers block, so
- * nobody else can join before somebody is answered — has gone through pwaf_evaluate_batch. Thread-safe; one dispatcher thread per batcher. Destroy it before the engine. */
+ * nobody else can join before somebody is answered — has gone through pwaf_evaluate_batch. Thread-safe; two dispatcher threads per batcher (one gathers and submits the next batch while the other waits for its own on the device). Destroy it before the engine. */
 typedef struct pwaf_batcher pwaf_batcher;
 int pwaf_batcher_create(pwaf_engine *engine, uint32_t max_batch, uint32_t max_delay_us, pwaf_batcher **out);
 int pwaf_batcher_evaluate(pwaf_batcher *, const pwaf_request *req, pwaf_verdict *out);
@@ -396,8 +396,10 @@ int pwaf_engine_rule_errors(pwaf_engine *, uint64_t *counts, size_t n_rules);
 /* How the engine evaluates the rules outside the column compiler's subset (the reference: Program::execute on every request,
  * pingoo/rules.rs:37-51): 0 = the rule set has none, 1 = interpreted per request on the device (residual_kernel),
  * 2 = SPECIALIZED — the rules' stack programs translated to straight-line device code and compiled for this device by hiprtc at
- * creation (csrc/residual_jit.cpp, rtc.cpp). When 1 was not asked for (PWAF_OPT_NO_RESIDUAL_JIT), a program warning says why. */
+ * creation (csrc/residual_jit.cpp, rtc.cpp). When 1 was not asked for (PWAF_OPT_NO_RESIDUAL_JIT), pwaf_engine_residual_fallback
+ * says why ("" otherwise; the string lives as long as the engine): no libhiprtc.so on the host, a compile error, too many rules. */
 int pwaf_engine_residual_mode(const pwaf_engine *);
+const char *pwaf_engine_residual_fallback(const pwaf_engine *);
 /* Inspection / test hooks of the specialized form (CPU, no device). _source: kind 0 = the rule functions alone (portable C++ over
  * csrc/residual.h: the CPU suite compiles them with g++ and fuzzes them against the oracle), kind 1 = the whole device program as
  * handed to hiprtc. Returns the text's length (0: the program has no residual rules, or they cannot be specialized); copies at most

@@ -167,44 +167,12 @@ class RequestBatch:
         return RequestBatch(datas, offs, rep(self.ip), rep(self.ip_is_v6), rep(self.port), rep(self.flags), rep(self.asn), rep(self.country))
 
     def _arrays(self):
-        out = list(self.data) + list(self.offsets) + [self.ip, self.ip_is_v6, self.port, self.flags]
-        out += [a for a in (self.asn, self.country) if a is not None]
-        for d, o in self.headers.values():
-            out += [d, o]
-        return [a for a in out if a.nbytes]
-
-    def page_lock(self) -> "RequestBatch":
-        """Registers every column with the HIP runtime (pwaf_host_register): the copy engine then reads the arrays where they are.
-        What a host that parses requests into pwaf_host_alloc arenas gets without this call. Undo with page_unlock()."""
-        from . import engine
-
-        L = engine.lib()
-        done = getattr(self, "_locked", [])
-        for a in self._arrays():
-            if any(a is b for b in done):
-                continue
-            rc = L.pwaf_host_register(a.ctypes.data, a.nbytes)
-            if rc != 0:
-                raise RuntimeError("pwaf_host_register failed: " + L.pwaf_last_error().decode(errors="replace"))
-            done.append(a)
-        self._locked = done
-        return self
-
-    def page_unlock(self) -> None:
-        from . import engine
-
-        L = engine.lib()
-        for a in getattr(self, "_locked", []):
-            L.pwaf_host_unregister(a.ctypes.data)
-        self._locked = []
-
-    def _arrays(self):
         arrs = list(self.data) + list(self.offsets) + [self.ip, self.ip_is_v6, self.port, self.flags]
         if self.asn is not None:
             arrs += [self.asn, self.country]
         for hd, ho in self.headers.values():
             arrs += [hd, ho]
-        return arrs
+        return [a for a in arrs if a.nbytes]  # (pwaf_host_register refuses zero bytes: an all-empty header column has nothing to lock)
 
     def pin(self) -> "RequestBatch":
         """Page-locks every column (pwaf_host_register): the copy engine then reads the caller's bytes directly — no staging copy inside
@@ -216,8 +184,6 @@ class RequestBatch:
             return self
         done = []
         for a in self._arrays():
-            if a.nbytes == 0:
-                continue
             rc = lib().pwaf_host_register(a.ctypes.data, a.nbytes)
             if rc != 0:
                 for q in done:
@@ -233,6 +199,21 @@ class RequestBatch:
         for a in getattr(self, "_pinned", None) or []:
             lib().pwaf_host_unregister(a.ctypes.data)
         self._pinned = None
+
+    def view(self, lo: int, hi: int) -> "RequestBatch":
+        """Requests [lo, hi) as a SLAB VIEW: the same arenas, offsets[lo : hi + 1] unchanged (absolute positions, offsets[0] != 0 in
+        general) — what pwaf_node_evaluate_batch hands each device's engine (csrc/node.cpp) and what a caller that splits one parsed
+        buffer passes. `slice()` is the re-based copy."""
+        headers = {name: (d, o[lo:hi + 1]) for name, (d, o) in self.headers.items()}
+        v = RequestBatch.__new__(RequestBatch)
+        v.n = hi - lo
+        v.headers = {name: (d, np.ascontiguousarray(o)) for name, (d, o) in headers.items()}
+        v.data = list(self.data)
+        v.offsets = [np.ascontiguousarray(o[lo:hi + 1]) for o in self.offsets]
+        v.ip, v.ip_is_v6, v.port, v.flags = self.ip[lo:hi], self.ip_is_v6[lo:hi], self.port[lo:hi], self.flags[lo:hi]
+        v.asn = None if self.asn is None else self.asn[lo:hi]
+        v.country = None if self.country is None else self.country[lo:hi]
+        return v
 
     def algorithmic_bytes(self) -> int:
         """sum(field bytes) + 4*(5+1) offset bytes + 22 B numerics + 8 B verdict per request

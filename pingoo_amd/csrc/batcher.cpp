@@ -126,9 +126,19 @@ struct pwaf_batcher {
                 else cv_work.wait_until(lk, wake);
                 continue;
             }
+            // the batch leaves its slot and a fresh one takes its place. Building the fresh slot allocates (columns, its Generation): done
+            // FIRST and inside a try, so that a std::bad_alloc leaves the gathered batch where it is and is tried again — nothing may
+            // escape a worker thread (std::terminate: ADVICE r4)
+            std::unique_ptr<Slot> fresh;
+            try {
+                fresh.reset(new Slot());
+                fresh->reset(n_cols);
+            } catch (const std::exception &) {
+                cv_work.wait_for(lk, std::chrono::milliseconds(1));
+                continue;
+            }
             Slot b = std::move(slot[due]);
-            slot[due] = Slot();
-            slot[due].reset(n_cols);
+            slot[due] = std::move(*fresh);
             in_flight += b.n;
             lk.unlock();
             // evaluate outside the lock: callers keep filling the next batch meanwhile
@@ -223,10 +233,16 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
     uint32_t idx = 0;
     int rc = PWAF_OK;
     std::string emsg;
+    // Counted BEFORE the mutex is touched and until nothing of *b is touched any more, on every way out: pwaf_batcher_destroy waits
+    // for `inside` to reach zero before it deletes the object (a caller blocked on the mutex used to be invisible to it).
+    struct Inside {
+        std::atomic<uint32_t> &c;
+        explicit Inside(std::atomic<uint32_t> &x) : c(x) { c.fetch_add(1, std::memory_order_acq_rel); }
+        ~Inside() { c.fetch_sub(1, std::memory_order_acq_rel); }
+    } inside_guard(b->inside);
     {
         std::unique_lock<std::mutex> lk(b->mu);
         if (b->stop) return fail(PWAF_E_INVALID_ARG, "batcher is shutting down");
-        b->inside.fetch_add(1, std::memory_order_acq_rel);
         b->active.fetch_add(1, std::memory_order_acq_rel);
         try {
             // a full slot the dispatcher has not picked up yet: wait for it to be taken
@@ -301,8 +317,7 @@ int pwaf_batcher_evaluate(pwaf_batcher *b, const pwaf_request *r, pwaf_verdict *
         else emsg = gen->error;
     }
     b->active.fetch_sub(1, std::memory_order_acq_rel);
-    b->cv_work.notify_one();  // (a caller leaving can complete the "everyone is here" condition of the batch being gathered)
-    b->inside.fetch_sub(1, std::memory_order_acq_rel);  // (nothing of *b is touched after this)
+    b->cv_work.notify_one();  // (a caller leaving can complete the "everyone is here" condition of the batch being gathered; nothing of *b is touched after this but the guard's counter)
     if (status != PWAF_OK) return fail(status, emsg);
     return PWAF_OK;
 }

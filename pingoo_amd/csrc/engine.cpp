@@ -244,6 +244,7 @@ struct pwaf_engine {
     std::mutex mu;  // guards the context ring and table rebuilds (pwaf_engine_tune)
     std::mutex prof_mu;  // while profiling is on, calls enqueue one at a time: the event / timing tables below are per engine
     DevBuf residual_errors;  // per residual rule: requests whose evaluation ended in an execution error (accumulated; pwaf_engine_rule_errors)
+    std::string residual_note;  // why the residual rules are interpreted although specialization was asked for (pwaf_engine_residual_fallback)
     JitKernel residual_jit;  // the specialized residual program (residual_jit.cpp + rtc.cpp); function == nullptr: the rules are interpreted
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
     DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
@@ -1622,7 +1623,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
     for (size_t k = 0; k < P.groups.size(); k++) e->groups[k].filter = P.groups[k].filter;
     if (P.n_residual && !(opts && (opts->flags & PWAF_OPT_NO_RESIDUAL_JIT))) {
         // The SPECIALIZED form of the residual rules (before the pass table is built: their pseudo pass then has no records): translate,
-        // compile for this device, load. Any failure leaves the interpreter in charge (same verdicts) and says so in the program's warnings.
+        // compile for this device, load. Any failure leaves the interpreter in charge (same verdicts) and says so: pwaf_engine_residual_fallback.
         std::string text, why;
         std::vector<char> code;
         hipDeviceProp_t prop;
@@ -1631,7 +1632,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         ok = ok && rvm_jit_program(P.residual_blob.data(), P.residual_blob.size(), text, why);
         if (ok && hipGetDeviceProperties(&prop, e->device) != hipSuccess) { ok = false; why = "hipGetDeviceProperties failed"; }
         ok = ok && rtc_compile(text, prop.gcnArchName, code, why) && jit_load(code, e->residual_jit, why);
-        if (!ok) e->prog.p->warnings.push_back("residual rules are interpreted per request, not specialized: " + why);
+        if (!ok) e->residual_note = "residual rules are interpreted per request, not specialized: " + why;  // (the ENGINE's: this device, this hiprtc — not the program's)
     }
     if ((rc = assign_lists(e.get()))) return dev_fail(rc);
 #define UP(buf, vec)                                     \
@@ -1934,6 +1935,7 @@ int pwaf_engine_residual_mode(const pwaf_engine *e) {
     if (!e || e->prog.p->n_residual == 0) return 0;
     return e->residual_jit.function ? 2 : 1;
 }
+const char *pwaf_engine_residual_fallback(const pwaf_engine *e) { return e ? e->residual_note.c_str() : ""; }
 size_t pwaf_program_residual_source(const pwaf_program *p, int kind, char *buf, size_t cap) {
     if (!p || p->p->n_residual == 0) return 0;
     std::string text, why;

@@ -1230,6 +1230,12 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
     const uint64_t base64 = (uint64_t)slab * kStreamSlab;
     if (base64 >= a.total) return;
     const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
+    // The batch's own bytes are [off[0], total): a slab view of a larger arena (a rank's share of a node batch, engine.cpp: col_begin) keeps
+    // absolute positions, and what lies before off[0] — another view's requests, stale staging bytes — must not flag a chunk: a chunk
+    // that no request owns has no pair (resolve_kernel), and its slot of the pair list would be read unwritten. The chunk that HOLDS
+    // off[0] counts (its later bytes are the first request's): chunks are flagged from (off[0] & ~15) on. One unsigned compare, as before.
+    const uint32_t lo16 = __builtin_amdgcn_readfirstlane(a.off[0]) & ~15u, span = total - lo16;
+    const uint32_t lane_at = 16u * lane - lo16;
     unsigned long long *my_bits = reinterpret_cast<unsigned long long *>(a.chunk_bits) + (size_t)rel * (kStreamSlab / 1024);  // one 64-bit word per row
     uint32_t n_hit = 0;  // wave-uniform: flagged chunks of the slab
     const uint32_t mul2 = a.mul | (a.mul << 16);
@@ -1431,7 +1437,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
                 for (int i = 0; i < 8; i++) { push(st, m[i]); seen &= st; }
             }
             carry = __builtin_amdgcn_readlane(tail, 63);
-            const bool hit = ((~seen) & 0xFF000000u) != 0 && b + kRow * q + 16u * lane < total;
+            const bool hit = ((~seen) & 0xFF000000u) != 0 && b + kRow * q + lane_at < span;  // (inside [off[0] & ~15, total), wrapping below it)
             hm[q] = __ballot(hit);  // bit l = the row's chunk l: the row's word of the pass's chunk bitmap as it is
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1795,6 +1801,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     // list's length, ~20k returned same-address atomics per batch, held every wave up for its turn) — and a chunk's place in it is its
     // rank among the slab's flagged chunks (the prefix counts above): no second walk.
     const uint32_t pair_base = a.pairs != nullptr ? a.pair_base[rel] : 0u;
+    const uint32_t begin = __builtin_amdgcn_readfirstlane(a.off[0]);  // != 0: a slab view of a larger arena
     {
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
     uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
@@ -1823,9 +1830,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
                     if (rank_of(y1 + 1u) != rank_of(y0)) a.rec[r] = 0u;
                 }
             }
-            // the flagged chunks whose first byte lies in this request (clipped to the slab)
+            // the flagged chunks whose first byte lies in this request (clipped to the slab). The chunk that holds off[0] when off[0] is
+            // not a multiple of 16 (a slab view) begins before every request: it belongs to the first request that has bytes, which is
+            // the one with s == off[0] < e (it used to have no owner, and a factor completing in the view's first bytes was
+            // never confirmed).
             if (live && e > s) {
-                const uint32_t f_lo = (s + 15u) >> 4, f_hi = (e - 1u) >> 4;
+                const uint32_t f_lo = s == begin ? s >> 4 : (s + 15u) >> 4, f_hi = (e - 1u) >> 4;
                 if (f_lo <= f_hi && f_hi >= c_first && f_lo < c_first + kChunks) {
                     const uint32_t x0 = f_lo > c_first ? f_lo - c_first : 0u, x1 = min(f_hi - c_first, kChunks - 1u);
                     for (uint32_t w = x0 >> 5; w <= (x1 >> 5); w++) {

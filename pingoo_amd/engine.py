@@ -88,6 +88,8 @@ def lib():
     L.pwaf_program_confirm_field.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint16), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pwaf_engine_rule_errors.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     L.pwaf_engine_residual_mode.argtypes = [vp]
+    L.pwaf_engine_residual_fallback.argtypes = [vp]
+    L.pwaf_engine_residual_fallback.restype = C.c_char_p
     L.pwaf_program_residual_source.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     L.pwaf_program_residual_source.restype = C.c_size_t
     L.pwaf_program_residual_compile.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
@@ -388,8 +390,12 @@ class RuleEngine:
     @property
     def residual_mode(self) -> int:
         """0: no residual rules; 1: interpreted per request (residual_kernel); 2: specialized — compiled for this device by hiprtc when
-        the engine was created (csrc/residual_jit.cpp). With 1 and no OPT_NO_RESIDUAL_JIT, a program warning says why."""
+        the engine was created (csrc/residual_jit.cpp). With 1 and no OPT_NO_RESIDUAL_JIT, `residual_fallback` says why."""
         return int(lib().pwaf_engine_residual_mode(self._h))
+
+    @property
+    def residual_fallback(self) -> str:
+        return (lib().pwaf_engine_residual_fallback(self._h) or b"").decode(errors="replace")
 
     def rule_errors(self, n_rules: int) -> List[int]:
         """Per caller rule: requests (over every batch so far) for which the rule's evaluation ended in an execution error — what the

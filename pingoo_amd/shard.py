@@ -43,11 +43,15 @@ def init_process_group(backend: str | None = None, always: bool = False):
         return rank, world, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in os.environ:
-        import socket
+        if world == 1:
+            import socket
 
-        with socket.socket() as s:  # (only reached without a launcher: a single process picks its own port)
-            s.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            with socket.socket() as s:  # (a single process without a launcher picks its own free port)
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        else:
+            # ranks started by hand (RANK / WORLD_SIZE set, no launcher) must agree on ONE port: a random one per rank never meets
+            os.environ["MASTER_PORT"] = "29517"  # 
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":

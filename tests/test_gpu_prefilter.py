@@ -345,3 +345,42 @@ def test_config3_adversarial_stream_tuned_on_benign_vs_oracle():
     assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
     assert np.count_nonzero(want["action"]) > 100
     eng.close()
+
+
+def test_slab_view_whose_first_bytes_complete_a_window():
+    """a batch that is a SLAB VIEW of a larger arena (offsets[0] != 0: a rank's share in pwaf_node_evaluate_batch, a
+    caller splitting one parsed buffer). The 16-byte chunk that holds offsets[0] begins BEFORE the view's first request; resolve_kernel
+    gave it no owner, so a literal completing inside the view's first < 16 bytes was never confirmed (fail-open), and chunks flagged in
+    the bytes before offsets[0] left unwritten slots in the pair list. Every view start 1..40 (all residues mod 16) with the literal at
+    every offset 0..14 of the first request, bytes BEFORE the view that would flag on their own, through pwaf_evaluate_batch and through
+    a two-replica node whose second share starts off 16-byte alignment."""
+    from pingoo_amd.engine import NodeEngine
+
+    rules = [("env", 'http_request.path.contains("/.env")', [B]), ("tail", 'http_request.url.ends_with("x9k2")', [CAP]),
+             ("sqli", 'http_request.url.matches("(?i)union\\\\s+select")', [B]), ("wp", 'http_request.path.starts_with("/wp-admin")', [CAP])]
+    eng = RuleEngine(rules)
+    orc = pyoracle.Oracle(rules)
+    assert eng.stats()["n_filtered_groups"] >= 2
+    for lead in range(1, 41):
+        for at in (0, 1, 5, 9, 14):
+            reqs = [Request(path="/.env" + "p" * (lead - 5) if lead >= 5 else "/" * lead, url="union select x9k2"[: max(lead, 1)].ljust(lead, "u"), host="h")]  # the bytes before the view
+            reqs += [Request(path="q" * at + "/.env", url="z" * at + "UNION  select" + "x9k2", host="h"), Request(path="", url="", host="h"),
+                     Request(path="/wp-admin/x", url="/wp-admin/x?a=1", host="h"), Request(path="/index.html", url="/index.html?x9k2", host="h")]
+            reqs += [Request(path="/a/b" * (k % 7), url="/a/b?c=" + "d" * k, host="h") for k in range(60)]
+            batch = RequestBatch.from_requests(reqs)
+            assert int(batch.offsets[2][1]) == lead
+            view = batch.view(1, batch.n)
+            want = orc.evaluate(batch.slice(1, batch.n))
+            assert want["action"][0] == B and want["rule_idx"][0] == 0
+            H.assert_verdicts_equal(eng.evaluate_batch(view), want, batch.slice(1, batch.n), f"view at byte {lead}, literal at {at}")
+    # the node's shares: 64-aligned request counts, arbitrary byte positions; the second share begins with the literal
+    reqs = [Request(path="/x" * (k % 5) + "/i", url="/x?k=%d" % k, host="h") for k in range(64)]
+    reqs += [Request(path="/.env", url="/.env", host="h")] + [Request(path="/y/%d" % k, url="/y?union+select", host="h") for k in range(63)]
+    batch = RequestBatch.from_requests(reqs)
+    assert int(batch.offsets[2][64]) % 16 != 0
+    node = NodeEngine(rules, devices=[0, 0])
+    want = orc.evaluate(batch)
+    assert want["action"][64] == B
+    H.assert_verdicts_equal(node.evaluate_batch(batch), want, batch, "node, second share off alignment")
+    node.close()
+    eng.close()
