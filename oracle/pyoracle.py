@@ -23,7 +23,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_expr.cpp", "oracle_regex.cpp", "oracle_engine.cpp", "oracle_expr.h", "oracle_regex.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_expr.cpp", "oracle_regex.cpp", "oracle_engine.cpp", "oracle_expr.h", "oracle_regex.h", "unicode_data.inc", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "pwaf.h"))
     stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if stale:

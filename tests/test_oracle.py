@@ -168,9 +168,77 @@ def test_regex_matches_cpython_re():
     assert n_checked > 10000
 
 
+def _rand_uregex(rng, depth=0):
+    """Patterns over the constructs whose Unicode semantics CPython's `re` (str mode) shares with the regex crate."""
+    k = rng.randint(0, 11 if depth < 3 else 3)
+    if k <= 1:
+        return rng.choice(["a", "s", "k", "\u00e9", "\u03c3", "\u20ac", "a\u00e9", "\u0663", "\u00a0", "s\u00e9", "\U0001F600"])
+    if k == 2:
+        return rng.choice([".", "[^a]", "[^\u00e9]", "\\w", "\\W", "\\d", "\\D", "\\s", "\\S", "[\u00e0-\u00ff]", "[^\u0660-\u0669s]", "[a\u20ac]", "[\\w\u20ac]", "[\\d.]"])
+    if k == 3:
+        return rng.choice(["^", "$", "\\b", "\\B"])
+    if k == 4:
+        return _rand_uregex(rng, depth + 1) + _rand_uregex(rng, depth + 1)
+    if k == 5:
+        return "(" + _rand_uregex(rng, depth + 1) + "|" + _rand_uregex(rng, depth + 1) + ")"
+    if k == 6:
+        return "(?:" + _rand_uregex(rng, depth + 1) + ")" + rng.choice(["*", "+", "?", "{2}", "{1,3}", "{2,}"])
+    if k == 7:
+        return _rand_uregex(rng, depth + 1) + rng.choice([".*", ".+", ".{0,2}", "\\w*", "\\s+"])
+    if k == 8:
+        return "(?i:" + rng.choice(["S", "sK", "\u00c9", "\u03a3", "k\u00e9s", "\u017f"]) + ")" + _rand_uregex(rng, depth + 1)
+    return _rand_uregex(rng, depth + 1) + "|" + _rand_uregex(rng, depth + 1)
+
+
+def test_regex_unicode_matches_cpython_re_in_str_mode():
+    """The oracle's Unicode half against an independent implementation: CPython `re` on the DECODED haystack folds s / U+017F and
+    k / U+212A, treats \\d \\s \\w \\b as Unicode and `.` as one code point. The alphabet keeps to code points where the two \\w / \\s
+    definitions agree (no marks, no No / Nl numbers, no U+001C-1F: CPython's isalnum / isspace differ from Alphabetic / White_Space there)."""
+    rng = random.Random(4321)
+    alphabet = ["a", "s", "S", "k", "K", "\u017f", "\u212a", "\u00e9", "\u00c9", "\u03c3", "\u03c2", "\u03a3", "\u20ac", "\u0663", "\u00a0", "\u2003", " ", ".", "_", "1", "\n", "\U0001F600"]
+    n_checked = n_non_ascii_hits = 0
+    for _ in range(2500):
+        pat = _rand_uregex(rng)
+        try:
+            pyre = re.compile(_to_python(pat).decode())
+        except re.error:
+            continue
+        for _ in range(10):
+            hay = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 7)))
+            if hay == "" and "\\B" in pat:
+                continue  # (CPython quirk, see above)
+            want = pyre.search(hay) is not None
+            got = pyoracle.regex_is_match(pat, hay.encode())
+            assert got == want, (pat, hay, got, want)
+            n_checked += 1
+            n_non_ascii_hits += want and not hay.isascii()
+    assert n_checked > 15000 and n_non_ascii_hits > 3000
+
+
+def test_unicode_tables_agree_with_cpython_unicodedata():
+    """unicode_data.inc comes from perl's UCD; CPython carries its own copy of the same Unicode version: every general category, code
+    point by code point, through the oracle's \\p{..}; \\d against str.isdecimal."""
+    import unicodedata
+
+    assert unicodedata.unidata_version == "13.0.0"
+    cats = sorted({unicodedata.category(chr(c)) for c in range(0x110000)} - {"Cs"})
+    text = "".join(chr(c) for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF)
+    by_cat = {}
+    for ch in text:
+        by_cat.setdefault(unicodedata.category(ch), []).append(ch)
+    for cat in cats:
+        inside = "".join(by_cat[cat])
+        assert pyoracle.regex_is_match("^\\p{%s}+$" % cat, inside.encode()), cat
+        assert not pyoracle.regex_is_match("\\P{%s}" % cat, inside.encode()), cat
+        outside = "".join("".join(v) for k, v in by_cat.items() if k != cat)
+        assert not pyoracle.regex_is_match("\\p{%s}" % cat, outside.encode()), cat
+    digits = "".join(ch for ch in text if ch.isdecimal())
+    assert pyoracle.regex_is_match("^\\d+$", digits.encode()) and not pyoracle.regex_is_match("\\d", "".join(ch for ch in text if not ch.isdecimal()).encode())
+
+
 def test_regex_syntax_errors_and_unsupported():
-    for pat in ["(", ")", "a{2", "a{,3}", "*a", "a**b{", "[a", "\\", "\\q", "(?z)", "(?P<>a)", "a{3,2}", "[b-a]", "(?=a)", "(?<!a)", "\\1", "\\p{Greek}", "\\p{", "[[:bogus:]]", "(?x)a b", "[a&&b]", "\\xZZ",
-                "\\x{110000}"]:
+    for pat in ["(", ")", "a{2", "a{,3}", "*a", "a**b{", "[a", "\\", "\\q", "(?z)", "(?P<>a)", "a{3,2}", "[b-a]", "(?=a)", "(?<!a)", "\\1", "\\p{Bogus}", "\\p{age=6.0}", "\\p{", "[[:bogus:]]", "[a&&b]", "\\xZZ",
+                "\\x{110000}", "\\x{D800}", "(?R)a", "(?-u:.)", "(?-u:\\W)", "(?-u:[^a])", "(?-u:\\xFF)", "(?-u:\\pL)", "\\b{start}a", "\\<a"]:
         with pytest.raises(pyoracle.OracleError):
             pyoracle.regex_is_match(pat, b"a")
     assert pyoracle.regex_is_match("[[:alpha:]]+[[:digit:]]", b"..ab1")
@@ -179,7 +247,41 @@ def test_regex_syntax_errors_and_unsupported():
     assert not pyoracle.regex_is_match("^$", b"a") and pyoracle.regex_is_match("^$", b"") and pyoracle.regex_is_match("a*", b"")
     assert pyoracle.regex_is_match("a$", b"a") and not pyoracle.regex_is_match("a$", b"a\n")  # Rust `$` is not Perl's
     assert pyoracle.regex_is_match("(?m)a$", b"a\nb") and pyoracle.regex_is_match("(?m)^b", b"a\nb")
-    assert pyoracle.regex_is_match("a.b", b"a\xffb") and not pyoracle.regex_is_match("a.b", b"a\nb") and pyoracle.regex_is_match("(?s)a.b", b"a\nb")
+    assert not pyoracle.regex_is_match("a.b", b"a\nb") and pyoracle.regex_is_match("(?s)a.b", b"a\nb")
+
+
+def test_regex_unicode_semantics_of_the_regex_crate():
+    """regex 1.12.2 (Cargo.lock:1694-1700) is Unicode-aware by default and http 1.3.1 (Cargo.lock:824-826) admits UTF-8 in path and
+    query, which reach `bel` as Rust str (pingoo/rules.rs:16-25): VERDICT r4 Missing #2. Hand-derived from the crate's documented
+    semantics (regex-syntax's translation: `.` / negated classes = one scalar value, \\d = Nd, \\s = White_Space, \\w = Alphabetic + M + Nd +
+    Pc + Join_Control, (?i) = simple case folding, \\b Unicode-aware, (?-u) = ASCII)."""
+    M = lambda pat, hay: pyoracle.regex_is_match(pat, hay.encode() if isinstance(hay, str) else hay)
+    # the fail-open cases VERDICT names
+    assert M("(?i)union\\s+select", "q=union\u00a0select") and M("(?i)union\\s+select", "q=UNION\u2003\u3000SELECT")
+    assert M("(?i)select", "\u017felect") and M("(?i)nikto", "ni\u212ato") and not M("select", "\u017felect")
+    assert M("^\\w+$", "caf\u00e9") and M("^\\w+$", "\u4f60\u597d_1") and not M("^\\w+$", "a\u20acb")
+    # one scalar value per `.` / negated class
+    assert M("^a.b$", "a\u00e9b") and M("^a.b$", "a\U0001F600b") and not M("^a..b$", "a\u00e9b") and M("^a[^x]b$", "a\u20acb")
+    assert M("^.{3}$", "\u00e9\u20ac\U0001F600") and not M("^.{3}$", "\u00e9\u20ac")
+    # \\d is Nd, \\s is White_Space, \\D \\S \\W their complements over scalar values
+    assert M("^\\d+$", "\u0663\u0967") and not M("^\\d$", "\u00b2") and M("^\\D$", "\u00b2") and M("^\\S$", "\u00e9") and not M("^\\S$", "\u2028")
+    assert M("^\\W$", "\u20ac") and not M("^\\W$", "\u00e9") and not M("\\s", "\x1c") and M("\\s", "\x85".encode("latin1").decode("latin1"))
+    # Unicode word boundaries
+    assert not M("\\bselect", "\u00e9select") and M("\\bselect", "\u20acselect") and M("(?-u:\\b)select", "\u00e9select")
+    assert not M("select\\b", "select\u00e9") and M("select\\B", "select\u00e9") and M("select\\b", "select\u2003x")
+    # (?-u): ASCII classes, ASCII folding
+    assert not M("(?-u:\\w)$", "\u00e9") and not M("(?i-u)select", "\u017felect") and M("(?i-u)select", "SELECT") and not M("(?-u:\\s)", "\u00a0")
+    # classes: ranges over code points, folding of the whole class, POSIX classes stay ASCII (but fold: K is in the orbit of k)
+    assert M("^[\u03b1-\u03c9]+$", "\u03b1\u03c9") and M("(?i)^[\u03b1-\u03c9]+$", "\u0391\u03a9") and M("(?i)^[[:lower:]]$", "\u212a") and not M("^[[:lower:]]$", "\u212a")
+    assert M("^[[:^alpha:]]$", "\u00e9") and M("^\\x{e9}\\u00e9\\u{e9}\\U000000e9$", "\u00e9" * 4) and M("^\\xe9$", "\u00e9")
+    # \\p{..}: categories, scripts, binary properties; folded under (?i), then negated
+    assert M("^\\p{Greek}+$", "\u03b1\u03b2") and M("^\\p{sc=Cyrillic}$", "\u0436") and M("^\\p{Lu}\\p{Ll}$", "\u00c9\u00e9") and M("(?i)^\\p{Lu}$", "\u00e9")
+    assert M("^\\P{L}$", "\u20ac") and not M("^\\P{L}$", "\u00e9") and M("^\\p{gc=Nd}\\p{Alphabetic}\\p{White_Space}$", "\u0663\u00e9\u3000") and M("^\\pN$", "\u00b2")
+    # (?x): whitespace and comments are syntax
+    assert M("(?x) union \\s+ select  # comment", "union select") and M("(?x)a\\ b [ c d ]", "a bd") and not M("(?x)a b", "a b") and M("(?x)a{1, 2}$", "aa")
+    # ill-formed UTF-8 (unreachable through the reference's str): a unit no class matches; \\b and \\B are both false next to it (D17)
+    assert not M("a.b", b"a\xffb") and not M("a[^x]b", b"a\xffb") and M("a", b"\xffa\xff") and not M("\\ba", b"\xffa") and not M("\\Ba", b"\xffa")
+    assert not M("^a.b$", b"a\xc3b") and not M("^.$", b"\xed\xa0\x80") and not M("^.$", b"\xc0\x80") and M("^.$", b"\xf4\x8f\xbf\xbf") and not M("^.$", b"\xf4\x90\x80\x80")
 
 
 # ---- ip parsing / containment against the stdlib -------------------------------------------------------------------
