@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpwaf.so")
 SOURCES = ["frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp", "filter.cpp", "residual.cpp", "residual_jit.cpp", "rtc.cpp", "compile.cpp", "loaders.cpp", "batcher.cpp", "node.cpp", "engine.cpp", "kernels.hip"]
-HEADERS = ["frontend.h", "program.h", "kernels.h", "residual.h", "confirm.h", os.path.join("..", "..", "include", "pwaf.h")]
+HEADERS = ["frontend.h", "program.h", "kernels.h", "residual.h", "confirm.h", "unicode_data.inc", os.path.join("..", "..", "include", "pwaf.h")]
 
 
 def hipcc() -> str:

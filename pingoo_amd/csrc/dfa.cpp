@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <unordered_map>
 
 #include "program.h"
@@ -28,14 +29,17 @@ namespace pwaf {
 
 namespace {
 
-enum : uint8_t { N_EPS, N_BYTE, N_ASSERT, N_ACCEPT };
+// N_SCALAR: consumes one SCALAR VALUE of a set with members beyond ASCII (RNode::UCLASS); exists only while a pattern is being built —
+// lower_scalars() replaces every one by the UTF-8 byte sequences of its set before the subset construction sees the automaton.
+enum : uint8_t { N_EPS, N_BYTE, N_ASSERT, N_ACCEPT, N_SCALAR };
 struct NState {
     uint8_t type;
     AssertKind ak;
     int out = -1, out2 = -1;
-    int cls = -1;   // N_BYTE: distinct class-set id
+    int cls = -1;   // N_BYTE: distinct class-set id; N_SCALAR: index into Nfa::usets
     int atom = -1;  // N_ACCEPT: local atom id
 };
+static inline bool is_word_assert(AssertKind a) { return a == A_WORD_B || a == A_NOT_WORD_B || a == A_WORD_B_ASCII || a == A_NOT_WORD_B_ASCII; }
 
 enum : uint8_t { K_EDGE = 0 /* START as prev, END as next */, K_OTHER = 1, K_WORD = 2, K_NEWLINE = 3 };
 
@@ -44,7 +48,9 @@ struct Nfa {
     std::vector<ByteSet> sets;
     std::map<std::string, int> set_ids;
     std::vector<int> entries;  // per-pattern entry states
-    bool uses_word = false, uses_line = false;
+    std::vector<CpSet> usets;  // N_SCALAR sets
+    bool uses_word = false /* (never set any more: eliminate_word_asserts rewrites \\b \\B away) */, uses_line = false;
+    bool pattern_has_word = false;  // the pattern being built holds a \\b / \\B
     size_t cap = 0;
     bool overflow = false;
     // Counted repetitions of ONE byte class (`.{0,40}`, `[^>]{0,64}`, `\s{1,8}`) unroll into a chain of optional
@@ -86,6 +92,13 @@ struct Nfa {
                 s.out = next;
                 return add(s);
             }
+            case RNode::UCLASS: {
+                NState s{N_SCALAR, A_TEXT_START};
+                s.cls = (int)usets.size();
+                usets.push_back(n.ucls);
+                s.out = next;
+                return add(s);
+            }
             case RNode::CAT: {
                 int cur = next;
                 for (size_t k = n.kids.size(); k-- > 0;) cur = build(*n.kids[k], cur);
@@ -117,7 +130,7 @@ struct Nfa {
                     }
                 } else {
                     cur = next;
-                    bool chain = k.k == RNode::CLASS && n.rmax - n.rmin >= 2;
+                    bool chain = (k.k == RNode::CLASS || k.k == RNode::UCLASS) && n.rmax - n.rmin >= 2;
                     int id = chain ? n_chains++ : -1;
                     for (int c = n.rmin; c < n.rmax; c++) {
                         NState opt{N_EPS, A_TEXT_START};
@@ -137,7 +150,7 @@ struct Nfa {
             case RNode::ASSERT: {
                 NState s{N_ASSERT, n.ak};
                 s.out = next;
-                if (n.ak == A_WORD_B || n.ak == A_NOT_WORD_B) uses_word = true;
+                if (is_word_assert(n.ak)) pattern_has_word = true;
                 if (n.ak == A_LINE_START || n.ak == A_LINE_END) uses_line = true;
                 return add(s);
             }
@@ -145,6 +158,276 @@ struct Nfa {
         return next;
     }
 };
+
+
+// ---- \b and \B, Unicode-aware, without look-around in the subset construction ---------------------------------------------------
+// The regex crate's \b looks at the SCALAR VALUES on both sides (is the previous one a word character? is the next one?). A byte DFA
+// cannot look a whole multi-byte scalar ahead, so the assertion is compiled away per pattern, as a product of its NFA with
+//   last = what the thread consumed last (nothing known / a non-word scalar / a word scalar [/ an ASCII word character, when the
+//          pattern also holds (?-u:\b)]), and
+//   need = what the next scalar must be (a set of those kinds, or the end of the text):
+// a \b turns `last` into a `need`; a consuming state under a `need` keeps the members of its set that satisfy it; an accept under a
+// `need` first consumes one scalar of a permitted kind (or asserts \z) — reporting a match one scalar late is the same match for a
+// boolean. What precedes the FIRST scalar a thread consumes is known by consuming it: when a \b can be reached before anything was
+// consumed the pattern gets a prelude (\A | one scalar of either kind) — the search is unanchored, so a thread starting one scalar
+// earlier is the same search. Next to a byte that is not part of a well-formed sequence both \b and \B are false: such
+// a byte is never consumed, so it is the `last = unknown` of a thread that starts behind it and it satisfies no `need`.
+struct WordElim {
+    Nfa &nfa;
+    size_t lo, hi;  // the pattern's states: [lo, hi) of the NFA as built
+    CpSet P[3];     // the kinds: 0 = no word character, 1 = word character [beyond ASCII when kind 2 exists], 2 = ASCII word character
+    bool has_uni = false, has_ascii = false;
+    std::vector<uint8_t> reach;  // [s - lo]: a word assertion can be reached from s
+    std::map<std::tuple<int, int, int>, int> memo;
+    std::map<std::tuple<int, int, int>, int> chains;
+    struct Item { int id, s, last, need; };
+    std::vector<Item> work;
+    bool unknown_last_met = false;
+    static constexpr int ANY = 15, END = 8;
+
+    WordElim(Nfa &n, size_t lo_, size_t hi_) : nfa(n), lo(lo_), hi(hi_) {
+        for (size_t s = lo; s < hi; s++)
+            if (nfa.st[s].type == N_ASSERT) {
+                const AssertKind a = nfa.st[s].ak;
+                if (a == A_WORD_B || a == A_NOT_WORD_B) has_uni = true;
+                if (a == A_WORD_B_ASCII || a == A_NOT_WORD_B_ASCII) has_ascii = true;
+            }
+        const CpSet &wu = unicode_word_set(true), &wa = unicode_word_set(false);
+        P[0] = cp_complement(has_uni ? wu : wa);
+        if (has_uni) P[1] = has_ascii ? cp_intersect(wu, cp_complement(wa)) : wu;
+        if (has_ascii) P[2] = wa;
+        // which states can reach a word assertion (backwards over the pattern's edges, to a fixpoint)
+        reach.assign(hi - lo, 0);
+        for (bool grew = true; grew;) {
+            grew = false;
+            for (size_t s = lo; s < hi; s++) {
+                if (reach[s - lo]) continue;
+                const NState &n2 = nfa.st[s];
+                bool r = n2.type == N_ASSERT && is_word_assert(n2.ak);
+                for (int t : {n2.out, n2.out2})
+                    if (t >= (int)lo && t < (int)hi && reach[(size_t)t - lo]) r = true;
+                if (r) { reach[s - lo] = 1; grew = true; }
+            }
+        }
+    }
+    bool reaches(int s) const { return s >= (int)lo && s < (int)hi && reach[(size_t)s - lo]; }
+    int mask_word(AssertKind a) const { return (a == A_WORD_B || a == A_NOT_WORD_B) ? 6 : 4; }  // kinds that are word characters to this assertion
+    CpSet set_of(const NState &n2) const {
+        if (n2.type == N_SCALAR) return nfa.usets[(size_t)n2.cls];
+        CpSet o;
+        const ByteSet &b = nfa.sets[(size_t)n2.cls];
+        for (uint32_t c = 0; c < 128; c++)
+            if (b[c]) o.push_back({c, c});
+        cp_canon(o);
+        return o;
+    }
+    int consume(const CpSet &set, int out) {  // a state that consumes one scalar of `set`
+        bool beyond = false;
+        ByteSet b;
+        for (auto &r : set) {
+            for (uint32_t c = r.first; c <= std::min<uint32_t>(r.second, 127); c++) b.set(c);
+            if (r.second > 127) beyond = true;
+        }
+        NState s{beyond ? N_SCALAR : N_BYTE, A_TEXT_START};
+        if (beyond) { s.cls = (int)nfa.usets.size(); nfa.usets.push_back(set); }
+        else s.cls = nfa.set_id(b);
+        s.out = out;
+        return nfa.add(s);
+    }
+    int alt_of(const std::vector<int> &heads) {  // -1: no alternative is left
+        int cur = -1;
+        for (size_t k = heads.size(); k-- > 0;) {
+            if (cur < 0) { cur = heads[k]; continue; }
+            NState e{N_EPS, A_TEXT_START};
+            e.out = heads[k];
+            e.out2 = cur;
+            cur = nfa.add(e);
+        }
+        return cur;
+    }
+    int chain_of(int c, int last, int need) {
+        auto it = chains.find({c, last, need});
+        if (it == chains.end()) it = chains.emplace(std::make_tuple(c, last, need), nfa.n_chains++).first;
+        return it->second;
+    }
+    // the product state (s, last, need): -1 = dead
+    int get(int s, int last, int need) {
+        if (s < 0) return -1;
+        if (need == ANY && !reaches(s)) return s;  // nothing ahead depends on `last`: the pattern's own states go on
+        const NState n2 = nfa.st[(size_t)s];
+        if (n2.type == N_ASSERT && is_word_assert(n2.ak)) {
+            if (last == 0) { unknown_last_met = true; return -1; }
+            const int mw = mask_word(n2.ak);
+            const bool prev_word = (mw >> (last - 1)) & 1;
+            const bool boundary = n2.ak == A_WORD_B || n2.ak == A_WORD_B_ASCII;
+            const bool next_word = boundary ? !prev_word : prev_word;
+            const int nn = need & (next_word ? mw : (ANY & ~mw));
+            return nn ? get(n2.out, last, nn) : -1;
+        }
+        auto key = std::make_tuple(s, last, need);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        NState ph{N_EPS, A_TEXT_START};
+        const int id = nfa.add(ph);
+        memo.emplace(key, id);
+        work.push_back({id, s, last, need});
+        return id;
+    }
+    void drain() {
+        while (!work.empty() && !nfa.overflow) {
+            const Item w = work.back();
+            work.pop_back();
+            const NState n2 = nfa.st[(size_t)w.s];
+            NState r{N_EPS, A_TEXT_START};
+            switch (n2.type) {
+                case N_EPS:
+                    r.out = get(n2.out, w.last, w.need);
+                    r.out2 = get(n2.out2, w.last, w.need);
+                    break;
+                case N_ASSERT:  // (\A \z ^ $: the subset construction decides them on bytes)
+                    r.type = N_ASSERT;
+                    r.ak = n2.ak;
+                    r.out = get(n2.out, w.last, w.need);
+                    if (r.out < 0) r = NState{N_EPS, A_TEXT_START};
+                    break;
+                case N_BYTE:
+                case N_SCALAR: {
+                    CpSet set = set_of(n2);
+                    if (w.need != ANY) {
+                        CpSet allowed;
+                        for (int k = 0; k < 3; k++)
+                            if ((w.need >> k) & 1) allowed.insert(allowed.end(), P[k].begin(), P[k].end());
+                        cp_canon(allowed);
+                        set = cp_intersect(set, allowed);
+                    }
+                    std::vector<int> heads;
+                    if (!reaches(n2.out)) {
+                        if (!set.empty()) heads.push_back(consume(set, n2.out));
+                    } else {
+                        for (int k = 0; k < 3; k++) {
+                            const CpSet part = cp_intersect(set, P[k]);
+                            if (part.empty()) continue;
+                            const int t = get(n2.out, k + 1, ANY);
+                            if (t >= 0) heads.push_back(consume(part, t));
+                        }
+                    }
+                    r.out = alt_of(heads);
+                    break;
+                }
+                case N_ACCEPT: {  // under a need: one more scalar of a permitted kind, or the end of the text
+                    std::vector<int> heads;
+                    for (int k = 0; k < 3; k++)
+                        if (((w.need >> k) & 1) && !P[k].empty()) heads.push_back(consume(P[k], w.s));
+                    if (w.need & END) {
+                        NState e{N_ASSERT, A_TEXT_END};
+                        e.out = w.s;
+                        heads.push_back(nfa.add(e));
+                    }
+                    r.out = alt_of(heads);
+                    break;
+                }
+            }
+            nfa.st[(size_t)w.id] = r;
+            // counted-class chains keep their pruning, each (last, need) variant as a chain of its own
+            if ((size_t)w.s < nfa.chain_id.size() && nfa.chain_id[(size_t)w.s] >= 0) nfa.tag(w.id, chain_of(nfa.chain_id[(size_t)w.s], w.last, w.need), nfa.chain_rank[(size_t)w.s]);
+            if ((size_t)w.s < nfa.chain_tail.size() && !nfa.chain_tail[(size_t)w.s].empty()) {
+                std::vector<int> tails;
+                for (int c : nfa.chain_tail[(size_t)w.s]) tails.push_back(chain_of(c, w.last, w.need));
+                if ((size_t)w.id >= nfa.chain_tail.size()) nfa.chain_tail.resize(nfa.st.size());
+                nfa.chain_tail[(size_t)w.id] = tails;
+            }
+        }
+    }
+    int run(int entry) {
+        const int plain = get(entry, 0, ANY);
+        drain();
+        if (!unknown_last_met) return plain;
+        std::vector<int> heads;
+        if (plain >= 0) heads.push_back(plain);
+        {
+            const int t = get(entry, 1, ANY);  // the start of the text counts as "no word character before"
+            drain();
+            if (t >= 0) {
+                NState e{N_ASSERT, A_TEXT_START};
+                e.out = t;
+                heads.push_back(nfa.add(e));
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            if (P[k].empty()) continue;
+            const int t = get(entry, k + 1, ANY);
+            drain();
+            if (t >= 0) heads.push_back(consume(P[k], t));
+        }
+        const int e = alt_of(heads);
+        if (e >= 0) return e;
+        NState dead{N_EPS, A_TEXT_START};
+        return nfa.add(dead);
+    }
+};
+
+// Every N_SCALAR state becomes the alternatives of its set: one byte state for the ASCII members, a chain of byte-range states per
+// UTF-8 sequence of the others (suffixes shared), joined by epsilon states; the state keeps its number (it may be a chain's tail).
+static std::vector<uint8_t> reachable_states(const Nfa &nfa) {
+    std::vector<uint8_t> seen(nfa.st.size(), 0);
+    std::vector<int> stack(nfa.entries.begin(), nfa.entries.end());
+    while (!stack.empty()) {
+        const int s = stack.back();
+        stack.pop_back();
+        if (s < 0 || seen[(size_t)s]) continue;
+        seen[(size_t)s] = 1;
+        stack.push_back(nfa.st[(size_t)s].out);
+        stack.push_back(nfa.st[(size_t)s].out2);
+    }
+    return seen;
+}
+static void lower_scalars(Nfa &nfa) {
+    const size_t n0 = nfa.st.size();
+    const std::vector<uint8_t> live = reachable_states(nfa);  // (what eliminate_word_asserts replaced is still there, unreachable)
+    for (size_t s = 0; s < n0 && !nfa.overflow; s++) {
+        if (nfa.st[s].type != N_SCALAR || !live[s]) continue;
+        const CpSet set = nfa.usets[(size_t)nfa.st[s].cls];
+        const int out = nfa.st[s].out;
+        std::vector<int> heads;
+        ByteSet ascii;
+        for (auto &r : set)
+            for (uint32_t c = r.first; c <= std::min<uint32_t>(r.second, 127); c++) ascii.set(c);
+        auto byte_state = [&](const ByteSet &b, int to) {
+            NState x{N_BYTE, A_TEXT_START};
+            x.cls = nfa.set_id(b);
+            x.out = to;
+            return nfa.add(x);
+        };
+        if (ascii.any()) heads.push_back(byte_state(ascii, out));
+        std::vector<std::vector<std::pair<uint8_t, uint8_t>>> seqs;
+        utf8_sequences(set, seqs);
+        std::map<std::tuple<int, int, int>, int> shared;  // (lo, hi, to) -> state
+        for (auto &seq : seqs) {
+            int cur = out;
+            for (size_t j = seq.size(); j-- > 0;) {
+                auto key = std::make_tuple((int)seq[j].first, (int)seq[j].second, cur);
+                auto it = shared.find(key);
+                if (it == shared.end()) {
+                    ByteSet b;
+                    for (int c = seq[j].first; c <= seq[j].second; c++) b.set((size_t)c);
+                    it = shared.emplace(key, byte_state(b, cur)).first;
+                }
+                cur = it->second;
+            }
+            if (std::find(heads.begin(), heads.end(), cur) == heads.end()) heads.push_back(cur);
+        }
+        NState e{N_EPS, A_TEXT_START};
+        int cur = -1;
+        for (size_t k = heads.size(); k-- > 1;) {
+            NState x{N_EPS, A_TEXT_START};
+            x.out = heads[k];
+            x.out2 = cur;
+            cur = nfa.add(x);
+        }
+        if (!heads.empty()) { e.out = heads[0]; e.out2 = cur; }
+        nfa.st[s] = e;
+    }
+}
 
 static inline bool needs_next(AssertKind a) { return a == A_TEXT_END || a == A_LINE_END || a == A_WORD_B || a == A_NOT_WORD_B; }
 static inline bool holds(AssertKind a, uint8_t pk, uint8_t nk) {
@@ -156,6 +439,7 @@ static inline bool holds(AssertKind a, uint8_t pk, uint8_t nk) {
         case A_LINE_END: return nk == K_EDGE || nk == K_NEWLINE;
         case A_WORD_B: return (pk == K_WORD) != (nk == K_WORD);
         case A_NOT_WORD_B: return (pk == K_WORD) == (nk == K_WORD);
+        default: break;  // (word assertions never reach the subset construction: eliminate_word_asserts)
     }
     return false;
 }
@@ -243,11 +527,25 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         acc.atom = (int)k;
         int a = nfa.add(acc);
         size_t before = nfa.st.size();
-        nfa.entries.push_back(nfa.build(*pats[k].rx, a));
+        nfa.pattern_has_word = false;
+        int entry = nfa.build(*pats[k].rx, a);
+        if (nfa.pattern_has_word && !nfa.overflow) {
+            nfa.chain_id.resize(nfa.st.size(), -1);
+            nfa.chain_rank.resize(nfa.st.size(), 0);
+            nfa.chain_tail.resize(nfa.st.size());
+            WordElim we(nfa, (size_t)a, nfa.st.size());
+            entry = we.run(entry);
+        }
+        nfa.entries.push_back(entry);
         if (nfa.overflow || nfa.st.size() - before > 20000) {
             err = "pattern too large (more than 20000 NFA states)";
             return false;
         }
+    }
+    lower_scalars(nfa);
+    if (nfa.overflow) {
+        err = "pattern set too large (NFA state limit)";
+        return false;
     }
     nfa.chain_id.resize(nfa.st.size(), -1);
     nfa.chain_rank.resize(nfa.st.size(), 0);
@@ -269,7 +567,16 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
             if (it == first.end()) it = first.emplace(k, n_cls++).first;
             cls_of[b] = it->second;
         }
-        for (const ByteSet &s : nfa.sets) {
+        // (only the sets of states a pattern can reach: what the word-assertion rewrite left behind must not split byte classes)
+        std::vector<uint8_t> set_used(nfa.sets.size(), 0);
+        {
+            const std::vector<uint8_t> live = reachable_states(nfa);
+            for (size_t q = 0; q < nfa.st.size(); q++)
+                if (live[q] && nfa.st[q].type == N_BYTE) set_used[(size_t)nfa.st[q].cls] = 1;
+        }
+        for (size_t si = 0; si < nfa.sets.size(); si++) {
+            if (!set_used[si]) continue;
+            const ByteSet &s = nfa.sets[si];
             std::map<std::pair<int, bool>, int> split;
             int next_id = 0;
             std::vector<int> nc(256);
@@ -484,7 +791,7 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
 
 // `.*`, `[^>]+`, and counted gaps wide enough to multiply states with the other patterns of a table (`.{0,40}`)
 static bool is_wide_gap(const RNode &n) {
-    return n.k == RNode::REPEAT && (n.rmax < 0 || n.rmax - n.rmin >= 8) && n.kids[0]->k == RNode::CLASS && n.kids[0]->cls.count() >= 64;
+    return n.k == RNode::REPEAT && (n.rmax < 0 || n.rmax - n.rmin >= 8) && (n.kids[0]->k == RNode::CLASS || n.kids[0]->k == RNode::UCLASS) && n.kids[0]->cls.count() >= 64;
 }
 
 bool has_wide_gap(const RNode &n) {
@@ -496,7 +803,7 @@ bool has_wide_gap(const RNode &n) {
 static bool rx_nullable(const RNode &n) {
     switch (n.k) {
         case RNode::EMPTY: case RNode::ASSERT: return true;
-        case RNode::CLASS: return false;
+        case RNode::CLASS: case RNode::UCLASS: return false;
         case RNode::CAT: for (auto &k : n.kids) if (!rx_nullable(*k)) return false; return true;
         case RNode::ALT: for (auto &k : n.kids) if (rx_nullable(*k)) return true; return false;
         case RNode::REPEAT: return n.rmin == 0 || rx_nullable(*n.kids[0]);
@@ -508,6 +815,7 @@ uint32_t rx_min_len(const RNode &n) {
     switch (n.k) {
         case RNode::EMPTY: case RNode::ASSERT: return 0;
         case RNode::CLASS: return 1;
+        case RNode::UCLASS: return n.cls.any() ? 1 : 2;  // (bytes: a scalar beyond ASCII takes at least two)
         case RNode::CAT: { uint32_t s = 0; for (auto &k : n.kids) s += rx_min_len(*k); return s; }
         case RNode::ALT: { uint32_t m = 0xFFFFFFFFu; for (auto &k : n.kids) m = std::min(m, rx_min_len(*k)); return m == 0xFFFFFFFFu ? 0 : m; }
         case RNode::REPEAT: return (uint32_t)n.rmin * rx_min_len(*n.kids[0]);

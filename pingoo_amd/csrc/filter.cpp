@@ -170,6 +170,34 @@ Ext extract(Model &m, const RNode &n) {
                 r.P = r.S = trivial();
             }
             return r;
+        case RNode::UCLASS: {
+            // One scalar value of a set with members beyond ASCII (`.`, \s, (?i)s = s | S | U+017F ...): one class string per
+            // encoded LENGTH — the ASCII members, and per length 2..4 the union of the sequences' byte ranges position by position
+            // (a superset of the encodings: a cover may over-approximate, it must not miss). A position with more than kMaxClass
+            // bytes makes the class wide: it then only breaks factors, as `.` always did.
+            std::vector<std::vector<std::pair<uint8_t, uint8_t>>> seqs;
+            utf8_sequences(n.ucls, seqs);
+            CStr by_len[5];
+            for (auto &q : seqs) {
+                CStr &c = by_len[q.size()];
+                c.resize(q.size());
+                for (size_t j = 0; j < q.size(); j++)
+                    for (int b = q[j].first; b <= q[j].second; b++) c[j].set((size_t)b);
+            }
+            bool wide = n.cls.count() > kMaxClass;
+            for (int L = 2; L <= 4; L++)
+                for (auto &bs : by_len[L]) wide = wide || bs.count() > kMaxClass;
+            if (wide) {
+                r.P = r.S = trivial();
+                return r;
+            }
+            r.E.ok = true;
+            if (n.cls.any()) r.E.s.push_back({n.cls});
+            for (int L = 2; L <= 4; L++)
+                if (!by_len[L].empty()) r.E.s.push_back(by_len[L]);
+            r.P = r.S = r.E;
+            return r;
+        }
         case RNode::CAT: {
             r.E = r.P = r.S = trivial();
             for (auto &k : n.kids) r = cat2(m, r, extract(m, *k));

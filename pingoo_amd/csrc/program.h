@@ -21,19 +21,33 @@ namespace pwaf {
 // ---- regex / literal patterns ------------------------------------------------------------------
 using ByteSet = std::bitset<256>;
 
-enum AssertKind : uint8_t { A_TEXT_START, A_TEXT_END, A_LINE_START, A_LINE_END, A_WORD_B, A_NOT_WORD_B };
+// A_WORD_B / A_NOT_WORD_B: the crate's Unicode-aware \b \B (the default); the _ASCII forms: under (?-u)
+enum AssertKind : uint8_t { A_TEXT_START, A_TEXT_END, A_LINE_START, A_LINE_END, A_WORD_B, A_NOT_WORD_B, A_WORD_B_ASCII, A_NOT_WORD_B_ASCII };
+using CpRange = std::pair<uint32_t, uint32_t>;
+using CpSet = std::vector<CpRange>;  // scalar values: sorted, disjoint, non-adjacent ranges
 
 struct RNode;
 using RNodeP = std::shared_ptr<RNode>;
 struct RNode {
-    enum K : uint8_t { EMPTY, CLASS, CAT, ALT, REPEAT, ASSERT } k = EMPTY;
+    // CLASS: one BYTE of a set (literal bytes of contains / == / ..., and every regex class within ASCII). UCLASS: one SCALAR VALUE of
+    // a set with members beyond ASCII — `.`, negated classes, \w \d \s \p{..}, (?i)s (= s, S, U+017F) — as the regex crate matches
+    // a Rust str (regex 1.12.2 is Unicode-aware by default, Cargo.lock:1694-1700; url / path may carry UTF-8, http 1.3.1): `ucls` holds
+    // the whole set (ASCII members too), `cls` its ASCII members; dfa.cpp lowers it to UTF-8 byte sequences.
+    enum K : uint8_t { EMPTY, CLASS, CAT, ALT, REPEAT, ASSERT, UCLASS } k = EMPTY;
     ByteSet cls;
+    CpSet ucls;
     std::vector<RNodeP> kids;
     int rmin = 0, rmax = -1;  // REPEAT; rmax < 0 = unbounded
     AssertKind ak = A_TEXT_START;
 };
 RNodeP rx_empty();
 RNodeP rx_class(const ByteSet &s);
+void cp_canon(CpSet &s);  // sorts, merges, drops the surrogates
+CpSet cp_complement(const CpSet &s);
+CpSet cp_intersect(const CpSet &a, const CpSet &b);
+RNodeP rx_scalars(const CpSet &s);  // CLASS when the set lies within ASCII, else UCLASS
+void utf8_sequences(const CpSet &s, std::vector<std::vector<std::pair<uint8_t, uint8_t>>> &out);  // the non-ASCII part of `s` as sequences of byte ranges
+const CpSet &unicode_word_set(bool unicode);  // \w: Alphabetic + M + Nd + Pc + Join_Control (regex-syntax), or [0-9A-Za-z_]
 RNodeP rx_byte(uint8_t c);
 RNodeP rx_literal(const std::string &bytes);
 RNodeP rx_cat(std::vector<RNodeP> kids);
