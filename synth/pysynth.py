@@ -87,11 +87,12 @@ class Workload:
             lib().synth_destroy(self._h)
             self._h = None
 
-    def batch(self, start: int, n: int, threads: int = DEFAULT_THREADS, adversarial: bool = False, absolute_url: bool = False) -> RequestBatch:
+    def batch(self, start: int, n: int, threads: int = DEFAULT_THREADS, adversarial: bool = False, absolute_url: bool = False, utf8: bool = False) -> RequestBatch:
         """Requests [start, start + n) of the seeded stream. adversarial: the hostile variant of the same stream (near misses of
         the rule literals, maximum-length fields, regex-state-heavy inputs: BASELINE.json configs[4]). absolute_url: `url` in the
-        absolute form an HTTP/2 listener derives (https://host/path?query: pingoo/serde_utils.rs:16-18) instead of the origin form."""
-        lib().synth_set_mode(self._h, (1 if adversarial else 0) | (2 if absolute_url else 0))
+        absolute form an HTTP/2 listener derives (https://host/path?query: pingoo/serde_utils.rs:16-18) instead of the origin form. utf8: url / path with UTF-8 in them
+        (http 1.3.1 admits it) incl. the evasions only Unicode regex semantics catch (U+00A0 for a blank, U+017F for s)."""
+        lib().synth_set_mode(self._h, (1 if adversarial else 0) | (2 if absolute_url else 0) | (4 if utf8 else 0))
         sizes = (C.c_uint64 * 5)()
         lib().synth_sizes(self._h, start, n, sizes, threads)
         for s in sizes:

@@ -150,6 +150,27 @@ CASES = [
                   req(url="https://example.com/public", path="/public")],
         expect=[[BLOCK, 0], [CAPTCHA, 1], [BLOCK, 2], [ALLOW, NONE]],
     ),
+    dict(
+        name="K14_unicode_regex_semantics_on_url_and_path",
+        source="pingoo/rules.rs:16-25 + serde_utils.rs:16-18: url = Display(Uri) and path = uri.path() reach bel as Rust str; http 1.3.1 "
+               "(Cargo.lock:824-826) admits UTF-8 in path and query; regex 1.12.2 (Cargo.lock:1694-1700) is Unicode-aware by default: \\s is "
+               "White_Space (U+00A0, U+2003 ...), (?i) is simple case folding (s ~ U+017F, k ~ U+212A), \\w is Alphabetic + M + Nd + Pc + "
+               "Join_Control, `.` is one scalar value, \\b looks at scalar values. Round 4 matched bytes with ASCII classes: these requests "
+               "were Allowed (fail-open). Expectations written from the crate's documented semantics, not computed",
+        rules=[["sqli", 'http_request.url.matches("(?i)union\\\\s+select")', [B]], ["word", 'http_request.path.matches("^/\\\\w+$")', [CAP]],
+               ["dot", 'http_request.path.matches("^/a.b$")', [B]], ["edge", 'http_request.url.matches("\\\\bdrop\\\\b")', [B]],
+               ["len", "http_request.path.length() == 6", [CAP]]],
+        requests=[req(url="/?q=union\u00a0select", path=""),              # U+00A0 is \\s: Block
+                  req(url="/?q=UNION\u2003\u017fELECT", path=""),        # U+2003 is \\s, U+017F folds to s: Block
+                  req(url="/?q=union\u200bselect", path=""),              # U+200B (zero width space) is NOT White_Space: Allow
+                  req(url="/caf\u00e9", path="/caf\u00e9"),               # e-acute is \\w: Captcha by `word` (rule 1) — and its length() is 6 BYTES (D13)
+                  req(url="/a\u20acb", path="/a\u20acb"),                 # the euro sign is one scalar value for `.`: Block by `dot` (not \\w: `word` does not fire)
+                  req(url="/a\u20ac\u20acb", path="/a\u20ac\u20acb"),   # two scalar values: `dot` does not match
+                  req(url="/?x=\u00e9drop", path=""),                      # e-acute is a word character: no boundary before `drop`: Allow
+                  req(url="/?x=\u20acdrop\u00a0", path=""),               # the euro sign and U+00A0 are not: Block by `edge`
+                  req(url="/ab\u00e9", path="/ab\u00e9", captcha_verified=True)],  # 5 bytes: `len` does not fire; `word` is a captcha rule, skipped for a verified client
+        expect=[[BLOCK, 0], [BLOCK, 0], [ALLOW, NONE], [CAPTCHA, 1], [BLOCK, 2], [ALLOW, NONE], [ALLOW, NONE], [BLOCK, 3], [ALLOW, NONE]],
+    ),
 ]
 
 # Field-derivation vectors (what the listener does BEFORE building RequestData). Inputs are raw header bytes as

@@ -41,6 +41,10 @@ def assert_verdicts_equal(got, want, batch=None, what=""):
 # fuzzer: small alphabets so that predicates actually fire
 # ---------------------------------------------------------------------------------------------------------
 ALPHA = "ab/."
+# url / path / host values with UTF-8 in them (http 1.3.1 admits it in path and query, the regex crate matches scalar values): two- and
+# three-byte sequences next to the ASCII alphabet, members of \w (e-acute), of \s (U+00A0), of neither (the euro sign), and the two
+# code points whose simple case folding reaches ASCII (U+017F ~ s, U+212A ~ k)
+UALPHA = "ab/.sk\u00e9\u20ac\u00a0\u017f\u212a"
 FIELDS = ["host", "url", "path", "method", "user_agent"]
 COUNTRIES = ["XX", "FR", "US", "CN", "DE", "AA", "ZZ"]
 
@@ -57,10 +61,11 @@ def rregex(rng: random.Random, depth=0) -> str:
     """Random pattern over the syntax both the oracle and the device compiler support."""
     k = rng.randint(0, 13 if depth < 3 else 4)
     if k <= 1:
-        return rng.choice(["a", "b", "/", "\\.", "ab", "ba", "a/b", "."])
+        return rng.choice(["a", "b", "/", "\\.", "ab", "ba", "a/b", ".", "\u00e9", "a\u20ac", "s"])
     if k == 2:
-        if rng.random() < 0.2:  # Unicode general categories (ASCII-restricted in both the oracle and the device compiler)
-            return rng.choice(["\\p{L}", "\\pL", "\\P{L}", "\\p{Lu}", "\\p{Ll}", "\\p{N}", "\\p{Nd}", "\\P{N}", "\\p{P}", "\\p{^P}", "[\\p{L}/]", "[^\\p{N}a]", "\\p{S}", "\\p{Zs}", "[\\P{Lu}b]"])
+        if rng.random() < 0.2:  # Unicode general categories
+            return rng.choice(["\\p{L}", "\\pL", "\\P{L}", "\\p{Lu}", "\\p{Ll}", "\\p{N}", "\\p{Nd}", "\\P{N}", "\\p{P}", "\\p{^P}", "[\\p{L}/]", "[^\\p{N}a]", "\\p{S}", "\\p{Zs}", "[\\P{Lu}b]",
+                               "[^\u00e9]", "[\u00e0-\u00ff]", "(?-u:\\w)", "(?-u:\\b)"])
         return rng.choice(["[ab]", "[^a]", "[a-b/]", "\\w", "\\W", "\\d", "\\s", "[[:alpha:]]", "[^/.]", "\\S"])
     if k == 3:
         return rng.choice(["^", "$", "\\b", "\\B", "\\A", "\\z"]) if rng.random() < 0.5 else "a"
@@ -77,7 +82,7 @@ def rregex(rng: random.Random, depth=0) -> str:
     if k == 9:
         return rregex(rng, depth + 1) + "$"
     if k == 10:
-        return "(?i)" + rng.choice(["A", "aB", "[A-B]/"]) + rregex(rng, depth + 1)
+        return "(?i)" + rng.choice(["A", "aB", "[A-B]/", "S", "Ks", "\u00c9", "[r-t]"]) + rregex(rng, depth + 1)
     if k == 11:
         return "(" + rregex(rng, depth + 1) + ")" + rregex(rng, depth + 1)
     if k == 12:
@@ -183,7 +188,8 @@ def fuzz_lists(rng: random.Random):
 def fuzz_requests(rng: random.Random, n: int, with_geo: bool):
     reqs = []
     for _ in range(n):
-        path = rstr(rng, 0, 8)
+        alpha = UALPHA if rng.random() < 0.3 else ALPHA
+        path = rstr(rng, 0, 8, alpha)
         if rng.random() < 0.1:
             path = "/__pingoo/captcha" + path
         ua = rstr(rng, 0, 8, "abM/ ") if rng.random() < 0.9 else rng.choice(["", "x" * 255, "x" * 256, "x" * 290])
@@ -194,7 +200,7 @@ def fuzz_requests(rng: random.Random, n: int, with_geo: bool):
         kw = {}
         if with_geo:
             kw = dict(asn=rng.choice([0, 1, 2, 3, 64512, 4294967295]), country=rng.choice(COUNTRIES))
-        reqs.append(Request(host=rstr(rng, 0, 6), url=path + rstr(rng, 0, 4), path=path, method=rng.choice(["GET", "POST", "a", ""]), user_agent=ua, ip=ip,
+        reqs.append(Request(host=rstr(rng, 0, 6, alpha), url=path + rstr(rng, 0, 4, alpha), path=path, method=rng.choice(["GET", "POST", "a", ""]), user_agent=ua, ip=ip,
                             remote_port=rng.choice([0, 1, 2, 3, 80, 443, 65535, rng.randint(0, 65535)]), captcha_verified=rng.random() < 0.3, **kw))
     return reqs
 

@@ -269,3 +269,33 @@ def test_absolute_form_urls_http2_stream_on_the_device():
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "absolute-form urls, tuned on origin-form traffic")
     assert np.count_nonzero(want["action"]) > 100
     eng.close()
+
+
+def test_utf8_stream_unicode_regex_semantics_on_the_device():
+    """VERDICT r4 missing #2: url / path are Rust str that may hold UTF-8 (http 1.3.1, Cargo.lock:824-826) and regex 1.12.2 matches
+    SCALAR VALUES with Unicode classes (Cargo.lock:1694-1700). The 1k-rule set on 40 000 requests of the UTF-8 stream (segments in other
+    scripts, `union<U+00A0>select`, U+017F for s, e-acute / euro signs around rule words) — HIP engine vs oracle, untuned and tuned on
+    ASCII traffic; the hostile variant of the same stream; and the hand-derived known answers of K14 through the C ABI."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
+    batch = w.batch(800_000, 40_000, utf8=True)
+    want = orc.evaluate(batch, threads=16)
+    plain = orc.evaluate(w.batch(800_000, 40_000), threads=16)
+    assert np.count_nonzero(want["action"]) > np.count_nonzero(plain["action"]) + 1000  # the matches only Unicode semantics give
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "utf-8 stream, untuned")
+    eng.tune(w.batch(5_000_000, 16384))
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "utf-8 stream, tuned on ASCII traffic")
+    hostile = w.batch(800_000, 20_000, utf8=True, adversarial=True)
+    H.assert_verdicts_equal(eng.evaluate_batch(hostile), orc.evaluate(hostile, threads=16), hostile, "utf-8 stream, hostile")
+    eng.close()
+    for c in H.load_kat()["cases"]:
+        if not c["name"].startswith("K14"):
+            continue
+        rules, lists, kb, expect = H.kat_case_inputs(c)
+        e2 = RuleEngine(rules, lists)
+        got = e2.evaluate_batch(kb)
+        assert [(int(a), int(r)) for a, r in zip(got["action"], got["rule_idx"])] == [(int(a), int(r)) for a, r in expect], c["name"]
+        e2.close()
