@@ -253,7 +253,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, help="synthetic config id (BASELINE.json configs[id-1]); default 3")
-    ap.add_argument("--requests", type=int, default=0, help="requests per GPU (default: the config's batch size)")
+    ap.add_argument("--requests", type=int, default=0, help="requests per batch (default: the config's batch size): per GPU with --scaling weak, of the ONE batch all GPUs share with --scaling strong")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default when --gpus > 1): BASELINE configs[3] as written — ONE batch of --requests requests, split over the GPUs by shard_bounds "
+                         "(64-aligned contiguous slabs); weak (default at one GPU): --requests requests PER GPU")
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--adversarial", action="store_true", help="time the adversarial variant of the stream as the HEADLINE batch (the tuning sample stays benign)")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the untuned and adversarial side runs (traffic_modes)")
@@ -298,7 +301,16 @@ def main():
         torch.cuda.synchronize(dev)
     rccl_ranks = int(ones.item()) if shard.collective_world() else 0
 
-    n = args.requests or DEFAULT_N.get(args.config, 100_000)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    n_arg = args.requests or DEFAULT_N.get(args.config, 100_000)
+    if scaling == "strong":  # one batch, split: rank r takes its 64-aligned slab of it (pingoo_amd/shard.py = pwaf_node_shard_bounds)
+        total = n_arg
+        first, last = shard.shard_bounds(total, rank, world)
+        n = last - first
+    else:
+        n, total, first = n_arg, n_arg * world, rank * n_arg
+    if n == 0:
+        raise SystemExit(f"rank {rank}: an empty slab ({total} requests over {world} GPUs)")
     threads = max(1, (os.cpu_count() or 1) // world)
     extras = world == 1 and not args.no_extra_modes and not os.environ.get("PWAF_BENCH_NO_TUNE")
 
@@ -308,7 +320,7 @@ def main():
 
     t0 = time.time()
     wl = pysynth.Workload(args.config)
-    batch = wl.batch(rank * n, n, threads=threads, adversarial=args.adversarial)  # this rank's slab of the global seeded request stream
+    batch = wl.batch(first, n, threads=threads, adversarial=args.adversarial)  # this rank's slab of the global seeded request stream
     t_gen = time.time() - t0
     t0 = time.time()
     opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
@@ -332,18 +344,18 @@ def main():
         phase("tune")
         t0 = time.time()
         # (PWAF_BENCH_TUNE_ADVERSARIAL: timing experiment — what tables fitted to the hostile stream would buy; never the reported mode)
-        eng.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads, adversarial=bool(os.environ.get("PWAF_BENCH_TUNE_ADVERSARIAL"))))
+        eng.tune(wl.batch(total + rank * tune_n, tune_n, threads=threads, adversarial=bool(os.environ.get("PWAF_BENCH_TUNE_ADVERSARIAL"))))
         t_compile += time.time() - t0
         if os.environ.get("PWAF_BENCH_RETUNE_ROWS_ADV"):
             # timing experiment (profiling build): which rows are LDS-resident re-ranked from a HOSTILE sample, prefilters untouched —
             # what an engine that adapted its table residency to the traffic it sees would reach; never the reported mode
             os.environ["PWAF_TUNE_ROWS_ONLY"] = "1"
-            eng.tune(wl.batch(world * n + rank * tune_n + tune_n, tune_n, threads=threads, adversarial=True))
+            eng.tune(wl.batch(total + world * tune_n + rank * tune_n, tune_n, threads=threads, adversarial=True))
             del os.environ["PWAF_TUNE_ROWS_ONLY"]
 
     phase("headline run")
     elapsed, ktimes, final_counts = R.timed_run(dbatch, args.steps, args.warmup)
-    value = n * world * args.steps / elapsed
+    value = total * args.steps / elapsed
     head = R.mode_summary(elapsed, ktimes, args.steps)
     head["host_enqueue_ms_per_step"] = round(R.issue_ms, 3)
     headline_out = R.outs[0][: min(n, 1_000_000)].clone()  # verdicts of the headline batch (the side runs below overwrite the buffer)
@@ -355,10 +367,10 @@ def main():
         phase("two batches in flight")
         k2 = max(4, args.steps)
         el, kt, _ = R.timed_run(dbatch, k2, 2, inflight=2)
-        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": n * world * k2 / el, "ms_per_step": 1e3 * el / k2, "host_enqueue_ms_per_step": round(R.issue_ms, 3)}
+        traffic_modes["tuned_benign_two_batches_in_flight"] = {"requests_per_s": total * k2 / el, "ms_per_step": 1e3 * el / k2, "host_enqueue_ms_per_step": round(R.issue_ms, 3)}
     if extras and not args.adversarial:
         phase("adversarial run")
-        adv_host = wl.batch(rank * n, n, threads=threads, adversarial=True)
+        adv_host = wl.batch(first, n, threads=threads, adversarial=True)
         adv = DeviceBatch(adv_host, dev)
         ka = max(2, args.steps // 2)
         el, kt, adv_counts = R.timed_run(adv, ka, 1)
@@ -380,13 +392,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
+        "requests_total": total,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "rccl_ranks": rccl_ranks,
         "config": {
-            "workload": f"BASELINE.json configs[{args.config - 1}]: {n} requests/GPU x {len(wl.rules)} rules "
+            "workload": f"BASELINE.json configs[{args.config - 1 if world == 1 or args.config != 3 else 3}]: "
+                        + (f"{n} requests/GPU" if scaling == "weak" else f"ONE batch of {total} requests split over {world} GPU(s) ({n} on rank 0)") + f" x {len(wl.rules)} rules "
                         f"({stats['n_scan_atoms']} string/regex predicates in {stats['n_dfa_groups']} DFA passes, {stats['n_filtered_groups']} of them behind a bigram prefilter, "
                         f"{stats['n_ip_lists']} CIDR lists, {0 if wl.geoip is None else len(wl.geoip)} GeoIP prefixes, {len(eng.header_names)} header fields), "
                         f"seed 0x50494E47^{args.config}, {'adversarial' if args.adversarial else 'benign'} stream",
@@ -569,7 +583,7 @@ def main():
             eng_r = RuleEngine(list(wl.rules) + extra, wl.lists, wl.geoip, **opts)
             n_res = sum("residual interpreter" in w for w in eng_r.program.warnings())
             if tune_n:
-                eng_r.tune(wl.batch(world * n + rank * tune_n, tune_n, threads=threads))
+                eng_r.tune(wl.batch(total + rank * tune_n, tune_n, threads=threads))
             Rr = Runner(eng_r, n, dev, world, 1)
             el, kt, cnt_r = Rr.timed_run(dbatch, args.steps, 1)
             sm = Rr.mode_summary(el, kt, args.steps)

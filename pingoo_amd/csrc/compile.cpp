@@ -1559,6 +1559,12 @@ std::vector<uint8_t> dump_program(const Program &p) {
         uint32_t gh[8] = {g.field, g.n_states, g.n_classes, 0, 0, g.atom_base, g.n_local, (uint32_t)g.atoms.size()};
         w.section("GHDR", (uint32_t)gi, gh, sizeof gh);
         w.section("GCLS", (uint32_t)gi, g.classmap, 256);
+        if (g.umap.on()) {  // scalar mode: the device image of the scalar-value -> class map ([ill class] in the section's count field's place: first byte)
+            std::vector<uint8_t> img = scalar_map_image(g.umap);
+            img.insert(img.begin(), 8, 0);
+            img[0] = g.umap.ill_class;
+            w.section("GUMP", (uint32_t)gi, img.data(), img.size());
+        }
         w.section("GTRN", (uint32_t)gi, g.trans.data(), g.trans.size() * 2);
         w.section("GEMO", (uint32_t)gi, g.emit_off.data(), g.emit_off.size() * 4);
         w.section("GEML", (uint32_t)gi, g.emit_list.data(), g.emit_list.size() * 2);
@@ -1582,6 +1588,12 @@ std::vector<uint8_t> dump_program(const Program &p) {
             const uint32_t rh[2] = {r.n_states, r.n_classes};
             w.section("RHDR", (uint32_t)gi, rh, sizeof rh);
             w.section("RCLS", (uint32_t)gi, r.classmap, 256);
+            if (r.umap.on()) {
+                std::vector<uint8_t> img = scalar_map_image(r.umap);
+                img.insert(img.begin(), 8, 0);
+                img[0] = r.umap.ill_class;
+                w.section("RUMP", (uint32_t)gi, img.data(), img.size());
+            }
             w.section("RTRN", (uint32_t)gi, r.trans.data(), r.trans.size() * 2);
             w.section("REMO", (uint32_t)gi, r.emit_off.data(), r.emit_off.size() * 4);
             w.section("REML", (uint32_t)gi, r.emit_list.data(), r.emit_list.size() * 2);

@@ -24,33 +24,107 @@
 #include <unordered_map>
 
 #include "program.h"
+#include "utf8.h"
 
 namespace pwaf {
 
 namespace {
 
-// N_SCALAR: consumes one SCALAR VALUE of a set with members beyond ASCII (RNode::UCLASS); exists only while a pattern is being built —
-// lower_scalars() replaces every one by the UTF-8 byte sequences of its set before the subset construction sees the automaton.
-enum : uint8_t { N_EPS, N_BYTE, N_ASSERT, N_ACCEPT, N_SCALAR };
+// The automaton's ALPHABET. A table whose patterns are all made of bytes (literals, ASCII classes) reads bytes: symbols 0..255, as
+// in rounds 1-4. As soon as a pattern of the table holds a class with members beyond ASCII (RNode::UCLASS: `.`, [^x], \\w \\s \\d,
+// \\p{..}, (?i)s ...) the table is in SCALAR MODE: the text is read one scalar value at a time — an ASCII byte is its own symbol; a
+// scalar beyond ASCII is ONE symbol, the ATOM (symbol 256 + k) of the partition of the non-ASCII scalar values that the table's sets
+// (and, when a \\b is there, the word characters) induce; continuation bytes are skipped, a byte that begins no well-formed sequence
+// is the atom ILL that no class holds. The walkers decode at the lead byte (rare: csrc/utf8.h) and look the atom's class up in a
+// two-stage table (DfaGroup::umap); everything else — tables, kernels, the bigram filter over raw bytes — is what it was for ASCII
+// traffic. (The round's first version compiled every class into UTF-8 byte automata instead: exact too, but \\w alone is a 300-state
+// decoder that every context of a pattern needs a copy of — 19 gap passes instead of 6 for the 1k-rule set, rows of 140 byte classes,
+// 6.0 -> 5.2 G requests/s on traffic that holds no byte above 0x7F at all.)
+using SymSet = std::bitset<512>;
+static constexpr int kAtom0 = 256, kMaxAtoms = 240, kAtomIll = 0;  // atom 0 = a byte outside every well-formed sequence
+enum : uint8_t { N_EPS, N_BYTE, N_ASSERT, N_ACCEPT };
 struct NState {
     uint8_t type;
     AssertKind ak;
     int out = -1, out2 = -1;
-    int cls = -1;   // N_BYTE: distinct class-set id; N_SCALAR: index into Nfa::usets
+    int cls = -1;   // N_BYTE: distinct symbol-set id
     int atom = -1;  // N_ACCEPT: local atom id
 };
 static inline bool is_word_assert(AssertKind a) { return a == A_WORD_B || a == A_NOT_WORD_B || a == A_WORD_B_ASCII || a == A_NOT_WORD_B_ASCII; }
 
-enum : uint8_t { K_EDGE = 0 /* START as prev, END as next */, K_OTHER = 1, K_WORD = 2, K_NEWLINE = 3 };
+// kinds of a symbol (what assertions ask of the previous / next one): K_WORD = an ASCII word character, K_UWORD = a word character
+// beyond ASCII (a word character to \\b, none to (?-u:\\b)), K_ILL = an ill-formed byte (\\b and \\B are both false next to it: D17)
+enum : uint8_t { K_EDGE = 0 /* START as prev, END as next */, K_OTHER = 1, K_WORD = 2, K_NEWLINE = 3, K_UWORD = 4, K_ILL = 5, K_COUNT = 6 };
+
+// The partition of the scalar values beyond ASCII into atoms (scalar mode).
+struct ScalarAlphabet {
+    bool on = false;
+    std::vector<uint32_t> starts;  // elementary intervals [starts[i], starts[i + 1]) over [0x80, 0x110000)
+    std::vector<uint16_t> atom;    // ... and the atom each belongs to (>= 1; 0 is ILL)
+    std::vector<uint8_t> word;     // per atom: a \\w scalar (meaningful when the table holds a Unicode \\b)
+    int n_atoms = 1;
+    std::vector<CpSet> sets;       // the distinct non-ASCII parts that were partitioned
+    void build(const std::vector<CpSet> &all, bool with_words) {
+        on = true;
+        auto beyond_ascii = [](const CpSet &x) {
+            CpSet t;
+            for (auto &r : x)
+                if (r.second >= 0x80) t.push_back({std::max<uint32_t>(r.first, 0x80), r.second});
+            return t;
+        };
+        auto intern = [&](const CpSet &t) -> int {
+            if (t.empty()) return -1;
+            auto it = std::find(sets.begin(), sets.end(), t);
+            if (it == sets.end()) { sets.push_back(t); return (int)sets.size() - 1; }
+            return (int)(it - sets.begin());
+        };
+        for (auto &x : all) intern(beyond_ascii(x));
+        const int words = with_words ? intern(beyond_ascii(unicode_word_set(true))) : -1;
+        std::vector<uint32_t> cuts{0x80, 0x110000};
+        for (auto &x : sets)
+            for (auto &r : x) { cuts.push_back(r.first); cuts.push_back(r.second + 1); }
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        std::map<std::vector<bool>, int> ids;
+        auto in = [](const CpSet &x, uint32_t c) {
+            auto it = std::upper_bound(x.begin(), x.end(), CpRange{c, 0xFFFFFFFFu});
+            return it != x.begin() && (it - 1)->second >= c;
+        };
+        word.assign(1, 0);
+        for (size_t i = 0; i + 1 < cuts.size(); i++) {
+            std::vector<bool> sig(sets.size());
+            for (size_t k = 0; k < sets.size(); k++) sig[k] = in(sets[k], cuts[i]);
+            auto it = ids.find(sig);
+            if (it == ids.end()) {
+                it = ids.emplace(sig, n_atoms++).first;
+                word.push_back(words >= 0 && sig[(size_t)words]);
+            }
+            if (!atom.empty() && atom.back() == it->second) continue;  // (the same atom goes on)
+            starts.push_back(cuts[i]);
+            atom.push_back((uint16_t)it->second);
+        }
+        starts.push_back(0x110000);
+    }
+    int atom_of(uint32_t cp) const { return atom[(size_t)(std::upper_bound(starts.begin(), starts.end(), cp) - starts.begin()) - 1]; }
+    SymSet symbols(const RNode &n) const {  // a UCLASS as a set of symbols: its ASCII members and the atoms it holds (an atom lies inside a set or outside it)
+        SymSet o;
+        for (int c = 0; c < 128; c++) o[(size_t)c] = n.cls[(size_t)c];
+        for (auto &r : n.ucls) {
+            if (r.second < 0x80) continue;
+            size_t i = (size_t)(std::upper_bound(starts.begin(), starts.end(), std::max<uint32_t>(r.first, 0x80)) - starts.begin()) - 1;
+            for (; i + 1 < starts.size() && starts[i] <= r.second; i++) o.set((size_t)(kAtom0 + atom[i]));
+        }
+        return o;
+    }
+};
 
 struct Nfa {
     std::vector<NState> st;
-    std::vector<ByteSet> sets;
+    std::vector<SymSet> sets;
     std::map<std::string, int> set_ids;
     std::vector<int> entries;  // per-pattern entry states
-    std::vector<CpSet> usets;  // N_SCALAR sets
-    bool uses_word = false /* (never set any more: eliminate_word_asserts rewrites \\b \\B away) */, uses_line = false;
-    bool pattern_has_word = false;  // the pattern being built holds a \\b / \\B
+    const ScalarAlphabet *alpha = nullptr;
+    bool uses_word = false, uses_uword = false, uses_line = false;
     size_t cap = 0;
     bool overflow = false;
     // Counted repetitions of ONE byte class (`.{0,40}`, `[^>]{0,64}`, `\s{1,8}`) unroll into a chain of optional
@@ -72,7 +146,7 @@ struct Nfa {
         st.push_back(s);
         return (int)st.size() - 1;
     }
-    int set_id(const ByteSet &b) {
+    int set_id(const SymSet &b) {
         std::string k = b.to_string();
         auto it = set_ids.find(k);
         if (it != set_ids.end()) return it->second;
@@ -88,14 +162,16 @@ struct Nfa {
             case RNode::EMPTY: return next;
             case RNode::CLASS: {
                 NState s{N_BYTE, A_TEXT_START};
-                s.cls = set_id(n.cls);
+                SymSet b;
+                // (scalar mode reads no raw byte above 0x7F: what is left of a byte class up there — a literal that is not UTF-8 — matches nothing)
+                for (int c = 0; c < (alpha->on ? 128 : 256); c++) b[(size_t)c] = n.cls[(size_t)c];
+                s.cls = set_id(b);
                 s.out = next;
                 return add(s);
             }
             case RNode::UCLASS: {
-                NState s{N_SCALAR, A_TEXT_START};
-                s.cls = (int)usets.size();
-                usets.push_back(n.ucls);
+                NState s{N_BYTE, A_TEXT_START};
+                s.cls = set_id(alpha->symbols(n));
                 s.out = next;
                 return add(s);
             }
@@ -150,7 +226,8 @@ struct Nfa {
             case RNode::ASSERT: {
                 NState s{N_ASSERT, n.ak};
                 s.out = next;
-                if (is_word_assert(n.ak)) pattern_has_word = true;
+                if (is_word_assert(n.ak)) uses_word = true;
+                if (n.ak == A_WORD_B || n.ak == A_NOT_WORD_B) uses_uword = true;
                 if (n.ak == A_LINE_START || n.ak == A_LINE_END) uses_line = true;
                 return add(s);
             }
@@ -160,276 +237,7 @@ struct Nfa {
 };
 
 
-// ---- \b and \B, Unicode-aware, without look-around in the subset construction ---------------------------------------------------
-// The regex crate's \b looks at the SCALAR VALUES on both sides (is the previous one a word character? is the next one?). A byte DFA
-// cannot look a whole multi-byte scalar ahead, so the assertion is compiled away per pattern, as a product of its NFA with
-//   last = what the thread consumed last (nothing known / a non-word scalar / a word scalar [/ an ASCII word character, when the
-//          pattern also holds (?-u:\b)]), and
-//   need = what the next scalar must be (a set of those kinds, or the end of the text):
-// a \b turns `last` into a `need`; a consuming state under a `need` keeps the members of its set that satisfy it; an accept under a
-// `need` first consumes one scalar of a permitted kind (or asserts \z) — reporting a match one scalar late is the same match for a
-// boolean. What precedes the FIRST scalar a thread consumes is known by consuming it: when a \b can be reached before anything was
-// consumed the pattern gets a prelude (\A | one scalar of either kind) — the search is unanchored, so a thread starting one scalar
-// earlier is the same search. Next to a byte that is not part of a well-formed sequence both \b and \B are false: such
-// a byte is never consumed, so it is the `last = unknown` of a thread that starts behind it and it satisfies no `need`.
-struct WordElim {
-    Nfa &nfa;
-    size_t lo, hi;  // the pattern's states: [lo, hi) of the NFA as built
-    CpSet P[3];     // the kinds: 0 = no word character, 1 = word character [beyond ASCII when kind 2 exists], 2 = ASCII word character
-    bool has_uni = false, has_ascii = false;
-    std::vector<uint8_t> reach;  // [s - lo]: a word assertion can be reached from s
-    std::map<std::tuple<int, int, int>, int> memo;
-    std::map<std::tuple<int, int, int>, int> chains;
-    struct Item { int id, s, last, need; };
-    std::vector<Item> work;
-    bool unknown_last_met = false;
-    static constexpr int ANY = 15, END = 8;
-
-    WordElim(Nfa &n, size_t lo_, size_t hi_) : nfa(n), lo(lo_), hi(hi_) {
-        for (size_t s = lo; s < hi; s++)
-            if (nfa.st[s].type == N_ASSERT) {
-                const AssertKind a = nfa.st[s].ak;
-                if (a == A_WORD_B || a == A_NOT_WORD_B) has_uni = true;
-                if (a == A_WORD_B_ASCII || a == A_NOT_WORD_B_ASCII) has_ascii = true;
-            }
-        const CpSet &wu = unicode_word_set(true), &wa = unicode_word_set(false);
-        P[0] = cp_complement(has_uni ? wu : wa);
-        if (has_uni) P[1] = has_ascii ? cp_intersect(wu, cp_complement(wa)) : wu;
-        if (has_ascii) P[2] = wa;
-        // which states can reach a word assertion (backwards over the pattern's edges, to a fixpoint)
-        reach.assign(hi - lo, 0);
-        for (bool grew = true; grew;) {
-            grew = false;
-            for (size_t s = lo; s < hi; s++) {
-                if (reach[s - lo]) continue;
-                const NState &n2 = nfa.st[s];
-                bool r = n2.type == N_ASSERT && is_word_assert(n2.ak);
-                for (int t : {n2.out, n2.out2})
-                    if (t >= (int)lo && t < (int)hi && reach[(size_t)t - lo]) r = true;
-                if (r) { reach[s - lo] = 1; grew = true; }
-            }
-        }
-    }
-    bool reaches(int s) const { return s >= (int)lo && s < (int)hi && reach[(size_t)s - lo]; }
-    int mask_word(AssertKind a) const { return (a == A_WORD_B || a == A_NOT_WORD_B) ? 6 : 4; }  // kinds that are word characters to this assertion
-    CpSet set_of(const NState &n2) const {
-        if (n2.type == N_SCALAR) return nfa.usets[(size_t)n2.cls];
-        CpSet o;
-        const ByteSet &b = nfa.sets[(size_t)n2.cls];
-        for (uint32_t c = 0; c < 128; c++)
-            if (b[c]) o.push_back({c, c});
-        cp_canon(o);
-        return o;
-    }
-    int consume(const CpSet &set, int out) {  // a state that consumes one scalar of `set`
-        bool beyond = false;
-        ByteSet b;
-        for (auto &r : set) {
-            for (uint32_t c = r.first; c <= std::min<uint32_t>(r.second, 127); c++) b.set(c);
-            if (r.second > 127) beyond = true;
-        }
-        NState s{beyond ? N_SCALAR : N_BYTE, A_TEXT_START};
-        if (beyond) { s.cls = (int)nfa.usets.size(); nfa.usets.push_back(set); }
-        else s.cls = nfa.set_id(b);
-        s.out = out;
-        return nfa.add(s);
-    }
-    int alt_of(const std::vector<int> &heads) {  // -1: no alternative is left
-        int cur = -1;
-        for (size_t k = heads.size(); k-- > 0;) {
-            if (cur < 0) { cur = heads[k]; continue; }
-            NState e{N_EPS, A_TEXT_START};
-            e.out = heads[k];
-            e.out2 = cur;
-            cur = nfa.add(e);
-        }
-        return cur;
-    }
-    int chain_of(int c, int last, int need) {
-        auto it = chains.find({c, last, need});
-        if (it == chains.end()) it = chains.emplace(std::make_tuple(c, last, need), nfa.n_chains++).first;
-        return it->second;
-    }
-    // the product state (s, last, need): -1 = dead
-    int get(int s, int last, int need) {
-        if (s < 0) return -1;
-        if (need == ANY && !reaches(s)) return s;  // nothing ahead depends on `last`: the pattern's own states go on
-        const NState n2 = nfa.st[(size_t)s];
-        if (n2.type == N_ASSERT && is_word_assert(n2.ak)) {
-            if (last == 0) { unknown_last_met = true; return -1; }
-            const int mw = mask_word(n2.ak);
-            const bool prev_word = (mw >> (last - 1)) & 1;
-            const bool boundary = n2.ak == A_WORD_B || n2.ak == A_WORD_B_ASCII;
-            const bool next_word = boundary ? !prev_word : prev_word;
-            const int nn = need & (next_word ? mw : (ANY & ~mw));
-            return nn ? get(n2.out, last, nn) : -1;
-        }
-        auto key = std::make_tuple(s, last, need);
-        auto it = memo.find(key);
-        if (it != memo.end()) return it->second;
-        NState ph{N_EPS, A_TEXT_START};
-        const int id = nfa.add(ph);
-        memo.emplace(key, id);
-        work.push_back({id, s, last, need});
-        return id;
-    }
-    void drain() {
-        while (!work.empty() && !nfa.overflow) {
-            const Item w = work.back();
-            work.pop_back();
-            const NState n2 = nfa.st[(size_t)w.s];
-            NState r{N_EPS, A_TEXT_START};
-            switch (n2.type) {
-                case N_EPS:
-                    r.out = get(n2.out, w.last, w.need);
-                    r.out2 = get(n2.out2, w.last, w.need);
-                    break;
-                case N_ASSERT:  // (\A \z ^ $: the subset construction decides them on bytes)
-                    r.type = N_ASSERT;
-                    r.ak = n2.ak;
-                    r.out = get(n2.out, w.last, w.need);
-                    if (r.out < 0) r = NState{N_EPS, A_TEXT_START};
-                    break;
-                case N_BYTE:
-                case N_SCALAR: {
-                    CpSet set = set_of(n2);
-                    if (w.need != ANY) {
-                        CpSet allowed;
-                        for (int k = 0; k < 3; k++)
-                            if ((w.need >> k) & 1) allowed.insert(allowed.end(), P[k].begin(), P[k].end());
-                        cp_canon(allowed);
-                        set = cp_intersect(set, allowed);
-                    }
-                    std::vector<int> heads;
-                    if (!reaches(n2.out)) {
-                        if (!set.empty()) heads.push_back(consume(set, n2.out));
-                    } else {
-                        for (int k = 0; k < 3; k++) {
-                            const CpSet part = cp_intersect(set, P[k]);
-                            if (part.empty()) continue;
-                            const int t = get(n2.out, k + 1, ANY);
-                            if (t >= 0) heads.push_back(consume(part, t));
-                        }
-                    }
-                    r.out = alt_of(heads);
-                    break;
-                }
-                case N_ACCEPT: {  // under a need: one more scalar of a permitted kind, or the end of the text
-                    std::vector<int> heads;
-                    for (int k = 0; k < 3; k++)
-                        if (((w.need >> k) & 1) && !P[k].empty()) heads.push_back(consume(P[k], w.s));
-                    if (w.need & END) {
-                        NState e{N_ASSERT, A_TEXT_END};
-                        e.out = w.s;
-                        heads.push_back(nfa.add(e));
-                    }
-                    r.out = alt_of(heads);
-                    break;
-                }
-            }
-            nfa.st[(size_t)w.id] = r;
-            // counted-class chains keep their pruning, each (last, need) variant as a chain of its own
-            if ((size_t)w.s < nfa.chain_id.size() && nfa.chain_id[(size_t)w.s] >= 0) nfa.tag(w.id, chain_of(nfa.chain_id[(size_t)w.s], w.last, w.need), nfa.chain_rank[(size_t)w.s]);
-            if ((size_t)w.s < nfa.chain_tail.size() && !nfa.chain_tail[(size_t)w.s].empty()) {
-                std::vector<int> tails;
-                for (int c : nfa.chain_tail[(size_t)w.s]) tails.push_back(chain_of(c, w.last, w.need));
-                if ((size_t)w.id >= nfa.chain_tail.size()) nfa.chain_tail.resize(nfa.st.size());
-                nfa.chain_tail[(size_t)w.id] = tails;
-            }
-        }
-    }
-    int run(int entry) {
-        const int plain = get(entry, 0, ANY);
-        drain();
-        if (!unknown_last_met) return plain;
-        std::vector<int> heads;
-        if (plain >= 0) heads.push_back(plain);
-        {
-            const int t = get(entry, 1, ANY);  // the start of the text counts as "no word character before"
-            drain();
-            if (t >= 0) {
-                NState e{N_ASSERT, A_TEXT_START};
-                e.out = t;
-                heads.push_back(nfa.add(e));
-            }
-        }
-        for (int k = 0; k < 3; k++) {
-            if (P[k].empty()) continue;
-            const int t = get(entry, k + 1, ANY);
-            drain();
-            if (t >= 0) heads.push_back(consume(P[k], t));
-        }
-        const int e = alt_of(heads);
-        if (e >= 0) return e;
-        NState dead{N_EPS, A_TEXT_START};
-        return nfa.add(dead);
-    }
-};
-
-// Every N_SCALAR state becomes the alternatives of its set: one byte state for the ASCII members, a chain of byte-range states per
-// UTF-8 sequence of the others (suffixes shared), joined by epsilon states; the state keeps its number (it may be a chain's tail).
-static std::vector<uint8_t> reachable_states(const Nfa &nfa) {
-    std::vector<uint8_t> seen(nfa.st.size(), 0);
-    std::vector<int> stack(nfa.entries.begin(), nfa.entries.end());
-    while (!stack.empty()) {
-        const int s = stack.back();
-        stack.pop_back();
-        if (s < 0 || seen[(size_t)s]) continue;
-        seen[(size_t)s] = 1;
-        stack.push_back(nfa.st[(size_t)s].out);
-        stack.push_back(nfa.st[(size_t)s].out2);
-    }
-    return seen;
-}
-static void lower_scalars(Nfa &nfa) {
-    const size_t n0 = nfa.st.size();
-    const std::vector<uint8_t> live = reachable_states(nfa);  // (what eliminate_word_asserts replaced is still there, unreachable)
-    for (size_t s = 0; s < n0 && !nfa.overflow; s++) {
-        if (nfa.st[s].type != N_SCALAR || !live[s]) continue;
-        const CpSet set = nfa.usets[(size_t)nfa.st[s].cls];
-        const int out = nfa.st[s].out;
-        std::vector<int> heads;
-        ByteSet ascii;
-        for (auto &r : set)
-            for (uint32_t c = r.first; c <= std::min<uint32_t>(r.second, 127); c++) ascii.set(c);
-        auto byte_state = [&](const ByteSet &b, int to) {
-            NState x{N_BYTE, A_TEXT_START};
-            x.cls = nfa.set_id(b);
-            x.out = to;
-            return nfa.add(x);
-        };
-        if (ascii.any()) heads.push_back(byte_state(ascii, out));
-        std::vector<std::vector<std::pair<uint8_t, uint8_t>>> seqs;
-        utf8_sequences(set, seqs);
-        std::map<std::tuple<int, int, int>, int> shared;  // (lo, hi, to) -> state
-        for (auto &seq : seqs) {
-            int cur = out;
-            for (size_t j = seq.size(); j-- > 0;) {
-                auto key = std::make_tuple((int)seq[j].first, (int)seq[j].second, cur);
-                auto it = shared.find(key);
-                if (it == shared.end()) {
-                    ByteSet b;
-                    for (int c = seq[j].first; c <= seq[j].second; c++) b.set((size_t)c);
-                    it = shared.emplace(key, byte_state(b, cur)).first;
-                }
-                cur = it->second;
-            }
-            if (std::find(heads.begin(), heads.end(), cur) == heads.end()) heads.push_back(cur);
-        }
-        NState e{N_EPS, A_TEXT_START};
-        int cur = -1;
-        for (size_t k = heads.size(); k-- > 1;) {
-            NState x{N_EPS, A_TEXT_START};
-            x.out = heads[k];
-            x.out2 = cur;
-            cur = nfa.add(x);
-        }
-        if (!heads.empty()) { e.out = heads[0]; e.out2 = cur; }
-        nfa.st[s] = e;
-    }
-}
-
-static inline bool needs_next(AssertKind a) { return a == A_TEXT_END || a == A_LINE_END || a == A_WORD_B || a == A_NOT_WORD_B; }
+static inline bool needs_next(AssertKind a) { return a == A_TEXT_END || a == A_LINE_END || is_word_assert(a); }
 static inline bool holds(AssertKind a, uint8_t pk, uint8_t nk) {
     // pk: K_EDGE = start of text; nk: K_EDGE = end of text
     switch (a) {
@@ -437,9 +245,17 @@ static inline bool holds(AssertKind a, uint8_t pk, uint8_t nk) {
         case A_TEXT_END: return nk == K_EDGE;
         case A_LINE_START: return pk == K_EDGE || pk == K_NEWLINE;
         case A_LINE_END: return nk == K_EDGE || nk == K_NEWLINE;
-        case A_WORD_B: return (pk == K_WORD) != (nk == K_WORD);
-        case A_NOT_WORD_B: return (pk == K_WORD) == (nk == K_WORD);
-        default: break;  // (word assertions never reach the subset construction: eliminate_word_asserts)
+        // \\b \\B: the regex crate's Unicode-aware assertions look at SCALAR VALUES — the symbols of a table in scalar mode; under (?-u)
+        // only ASCII word characters count. Next to an ill-formed byte neither holds.
+        case A_WORD_B: case A_NOT_WORD_B: {
+            if (pk == K_ILL || nk == K_ILL) return false;
+            const bool pw = pk == K_WORD || pk == K_UWORD, nw = nk == K_WORD || nk == K_UWORD;
+            return (pw != nw) == (a == A_WORD_B);
+        }
+        case A_WORD_B_ASCII: case A_NOT_WORD_B_ASCII: {
+            if (pk == K_ILL || nk == K_ILL) return false;
+            return ((pk == K_WORD) != (nk == K_WORD)) == (a == A_WORD_B_ASCII);
+        }
     }
     return false;
 }
@@ -519,85 +335,150 @@ struct Builder {
 
 }  // namespace
 
+// Scalar mode reads scalar values, so the byte literals of contains / starts_with / == ... (rx_literal: one CLASS per byte) are turned
+// into scalars too: a run of single-byte classes that spells one well-formed sequence becomes the UCLASS of that scalar. (A byte above
+// 0x7F that is part of no such run — a literal that is not UTF-8: no Rust str can hold it — matches nothing in scalar mode.)
+static RNodeP scalarize(const RNodeP &n) {
+    if (!n) return n;
+    if (n->k == RNode::CAT) {
+        auto single = [](const RNodeP &x) -> int { return (x->k == RNode::CLASS && x->cls.count() == 1) ? (int)x->cls._Find_first() : -1; };
+        std::vector<RNodeP> kids;
+        for (size_t i = 0; i < n->kids.size();) {
+            const int b0 = single(n->kids[i]);
+            const int len = b0 >= 0xF0 ? 4 : b0 >= 0xE0 ? 3 : b0 >= 0xC2 ? 2 : 0;
+            bool done = false;
+            if (len && i + (size_t)len <= n->kids.size()) {
+                uint32_t v = (uint32_t)b0 & (0x7Fu >> len);
+                bool ok = true;
+                for (int k = 1; k < len && ok; k++) {
+                    const int b = single(n->kids[i + (size_t)k]);
+                    ok = b >= 0x80 && b <= 0xBF;
+                    v = (v << 6) | ((uint32_t)b & 0x3Fu);
+                }
+                if (ok && !((len == 3 && v < 0x800) || (len == 4 && v < 0x10000) || v > 0x10FFFF || (v >= 0xD800 && v <= 0xDFFF))) {
+                    kids.push_back(rx_scalars(CpSet{{v, v}}));
+                    i += (size_t)len;
+                    done = true;
+                }
+            }
+            if (!done) kids.push_back(scalarize(n->kids[i++]));
+        }
+        auto o = std::make_shared<RNode>(*n);
+        o->kids = std::move(kids);
+        return o;
+    }
+    if (n->kids.empty()) return n;
+    auto o = std::make_shared<RNode>(*n);
+    for (auto &k : o->kids) k = scalarize(k);
+    return o;
+}
+static void collect_uclasses(const RNode &n, std::vector<CpSet> &out, bool &uword) {
+    if (n.k == RNode::UCLASS) out.push_back(n.ucls);
+    if (n.k == RNode::ASSERT && (n.ak == A_WORD_B || n.ak == A_NOT_WORD_B)) uword = true;
+    for (auto &k : n.kids) collect_uclasses(*k, out, uword);
+}
+static bool has_uclass(const RNode &n) {  // ... or a Unicode-aware \\b / \\B: both ask what a SCALAR VALUE is
+    if (n.k == RNode::UCLASS || (n.k == RNode::ASSERT && (n.ak == A_WORD_B || n.ak == A_NOT_WORD_B))) return true;
+    for (auto &k : n.kids) if (has_uclass(*k)) return true;
+    return false;
+}
+static bool has_high_single_bytes(const RNode &n) {  // a literal byte above 0x7F (what scalarize() would turn into a scalar)
+    if (n.k == RNode::CLASS && n.cls.count() == 1 && n.cls._Find_first() >= 0x80) return true;
+    for (auto &k : n.kids) if (has_high_single_bytes(*k)) return true;
+    return false;
+}
+
 bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32_t max_table_bytes, DfaGroup &out, std::string &err) {
     Nfa nfa;
     nfa.cap = 400000;
+    // ---- the alphabet: bytes, or (a class beyond ASCII somewhere) scalar values ----
+    ScalarAlphabet alpha;
+    std::vector<RNodeP> rxs;
+    {
+        bool scalar = false;
+        for (auto &p : pats) scalar = scalar || has_uclass(*p.rx);
+        for (auto &p : pats) rxs.push_back(scalar && has_high_single_bytes(*p.rx) ? scalarize(p.rx) : p.rx);
+        if (scalar) {
+            std::vector<CpSet> sets;
+            bool uword = false;
+            for (auto &r : rxs) collect_uclasses(*r, sets, uword);
+            alpha.build(sets, uword);
+            if (alpha.n_atoms > kMaxAtoms) {
+                err = "too many distinct classes of non-ASCII scalar values in one table";
+                return false;
+            }
+        }
+    }
+    nfa.alpha = &alpha;
     for (size_t k = 0; k < pats.size(); k++) {
         NState acc{N_ACCEPT, A_TEXT_START};
         acc.atom = (int)k;
         int a = nfa.add(acc);
         size_t before = nfa.st.size();
-        nfa.pattern_has_word = false;
-        int entry = nfa.build(*pats[k].rx, a);
-        if (nfa.pattern_has_word && !nfa.overflow) {
-            nfa.chain_id.resize(nfa.st.size(), -1);
-            nfa.chain_rank.resize(nfa.st.size(), 0);
-            nfa.chain_tail.resize(nfa.st.size());
-            WordElim we(nfa, (size_t)a, nfa.st.size());
-            entry = we.run(entry);
-        }
-        nfa.entries.push_back(entry);
+        nfa.entries.push_back(nfa.build(*rxs[k], a));
         if (nfa.overflow || nfa.st.size() - before > 20000) {
             err = "pattern too large (more than 20000 NFA states)";
             return false;
         }
     }
-    lower_scalars(nfa);
-    if (nfa.overflow) {
-        err = "pattern set too large (NFA state limit)";
-        return false;
-    }
     nfa.chain_id.resize(nfa.st.size(), -1);
     nfa.chain_rank.resize(nfa.st.size(), 0);
     nfa.chain_tail.resize(nfa.st.size());
-    // ---- byte classes: bytes are equivalent when no class set and no assertion kind tells them apart ----
+    // ---- symbol classes: symbols are equivalent when no set and no assertion kind tells them apart ----
+    // symbols: 0..255 the bytes; scalar mode: kAtom0 + k the atoms (bytes 0x80..0xBF are then continuation bytes — skipped: the
+    // class CONT, whose transitions all stay — and bytes 0xC0..0xFF lead bytes, which the walkers replace by the scalar's atom)
+    const int n_sym = alpha.on ? kAtom0 + alpha.n_atoms : 256;
     auto kind_of = [&](int b) -> uint8_t {
+        if (b >= kAtom0) {
+            if (b - kAtom0 == kAtomIll) return nfa.uses_word ? K_ILL : K_OTHER;
+            return (nfa.uses_uword && alpha.word[(size_t)(b - kAtom0)]) ? K_UWORD : K_OTHER;
+        }
         bool w = (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_';
         if (nfa.uses_word && w) return K_WORD;
         if (nfa.uses_line && b == '\n') return K_NEWLINE;
         return K_OTHER;
     };
-    std::vector<int> cls_of(256);
+    std::vector<int> cls_of((size_t)n_sym);
     int n_cls = 0;
     {
-        std::map<int, int> first;
-        for (int b = 0; b < 256; b++) {
-            int k = kind_of(b);
-            auto it = first.find(k);
-            if (it == first.end()) it = first.emplace(k, n_cls++).first;
-            cls_of[b] = it->second;
-        }
-        // (only the sets of states a pattern can reach: what the word-assertion rewrite left behind must not split byte classes)
-        std::vector<uint8_t> set_used(nfa.sets.size(), 0);
-        {
-            const std::vector<uint8_t> live = reachable_states(nfa);
-            for (size_t q = 0; q < nfa.st.size(); q++)
-                if (live[q] && nfa.st[q].type == N_BYTE) set_used[(size_t)nfa.st[q].cls] = 1;
+        // the first split: kind, and in scalar mode what a symbol IS (an ASCII byte, a continuation byte, a lead byte, an atom) — the
+        // walkers treat these differently, so no class may mix them
+        auto role = [&](int b) { return !alpha.on ? 0 : b >= kAtom0 ? 3 : b >= 0xC0 ? 2 : b >= 0x80 ? 1 : 0; };
+        std::map<std::pair<int, int>, int> first;
+        for (int b = 0; b < n_sym; b++) {
+            auto key = std::make_pair((int)kind_of(b), role(b));
+            auto it = first.find(key);
+            if (it == first.end()) it = first.emplace(key, n_cls++).first;
+            cls_of[(size_t)b] = it->second;
         }
         for (size_t si = 0; si < nfa.sets.size(); si++) {
-            if (!set_used[si]) continue;
-            const ByteSet &s = nfa.sets[si];
+            const SymSet &s = nfa.sets[si];
             std::map<std::pair<int, bool>, int> split;
             int next_id = 0;
-            std::vector<int> nc(256);
-            for (int b = 0; b < 256; b++) {
-                auto key = std::make_pair(cls_of[b], (bool)s[b]);
+            std::vector<int> nc((size_t)n_sym);
+            for (int b = 0; b < n_sym; b++) {
+                auto key = std::make_pair(cls_of[(size_t)b], (bool)s[(size_t)b]);
                 auto it = split.find(key);
                 if (it == split.end()) it = split.emplace(key, next_id++).first;
-                nc[b] = it->second;
+                nc[(size_t)b] = it->second;
             }
             cls_of = nc;
             n_cls = next_id;
         }
     }
-    std::vector<int> rep(n_cls, -1);  // representative byte per class
-    for (int b = 0; b < 256; b++) if (rep[cls_of[b]] < 0) rep[cls_of[b]] = b;
+    std::vector<int> rep((size_t)n_cls, -1);  // representative symbol per class
+    for (int b = 0; b < n_sym; b++) if (rep[(size_t)cls_of[(size_t)b]] < 0) rep[(size_t)cls_of[(size_t)b]] = b;
+    // classes of the continuation / lead BYTES of scalar mode: no transition of theirs is ever computed — they stay
+    std::vector<uint8_t> cls_stays((size_t)n_cls, 0);
+    if (alpha.on)
+        for (int c = 0; c < n_cls; c++) cls_stays[(size_t)c] = rep[(size_t)c] >= 0x80 && rep[(size_t)c] < kAtom0;
     // set membership per class
-    std::vector<std::vector<uint8_t>> set_has(nfa.sets.size(), std::vector<uint8_t>(n_cls));
+    std::vector<std::vector<uint8_t>> set_has(nfa.sets.size(), std::vector<uint8_t>((size_t)n_cls));
     for (size_t s = 0; s < nfa.sets.size(); s++)
-        for (int c = 0; c < n_cls; c++) set_has[s][c] = nfa.sets[s][rep[c]];
-    std::vector<uint8_t> cls_kind(n_cls);
-    for (int c = 0; c < n_cls; c++) cls_kind[c] = kind_of(rep[c]);
+        for (int c = 0; c < n_cls; c++) set_has[s][(size_t)c] = nfa.sets[s][(size_t)rep[(size_t)c]];
+    std::vector<uint8_t> cls_kind((size_t)n_cls);
+    for (int c = 0; c < n_cls; c++) cls_kind[(size_t)c] = kind_of(rep[(size_t)c]);
+    if (n_cls > 250) { err = "more than 250 symbol classes in one table"; return false; }
 
     if ((uint64_t)n_cls * 2 > max_table_bytes) { err = "LDS table budget too small"; return false; }
     uint32_t state_cap = std::min<uint64_t>(max_states, (uint64_t)max_table_bytes / (2ull * n_cls));
@@ -611,12 +492,12 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         std::vector<uint8_t> in;  // visited in phase A
         std::vector<int> liveA, pending;
         std::vector<uint16_t> accA;
-        std::vector<int> liveB[4];      // extra live states released under next-kind nk
-        std::vector<uint16_t> accB[4];  // accepts released under nk
+        std::vector<int> liveB[K_COUNT];      // extra live states released under next-kind nk
+        std::vector<uint16_t> accB[K_COUNT];  // accepts released under nk
         std::vector<std::vector<int>> move;  // per class: sorted targets of liveA ∪ liveB[kind(c)]
         bool ready = false;
     };
-    Root roots[4];
+    Root roots[K_COUNT];
     auto get_root = [&](uint8_t pk) -> Root & {
         Root &r = roots[pk];
         if (r.ready) return r;
@@ -625,7 +506,7 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         bl.stamp++;
         bl.closure(nfa.entries, pk, false, 0, r.liveA, r.accA, &r.pending);
         for (size_t s = 0; s < nfa.st.size(); s++) r.in[s] = bl.mark[s] == bl.stamp;
-        for (uint8_t nk = 0; nk < 4; nk++) {
+        for (uint8_t nk = 0; nk < K_COUNT; nk++) {
             std::vector<int> rel;
             for (int s : r.pending)
                 if (holds(nfa.st[s].ak, pk, nk)) rel.push_back(nfa.st[s].out);
@@ -713,7 +594,7 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         entry_emits.insert(entry_emits.end(), key.delayed.begin(), key.delayed.end());
         uniq16(entry_emits);
         ds[d].emits = entry_emits;
-        ds[d].next.assign(n_cls, 0);
+        ds[d].next.assign(n_cls, (int)d);  // (the classes that stay — continuation and lead bytes of scalar mode — keep this)
         // phase B for next-kind nk: release this state's own pending assertions (the root's are precomputed)
         auto phaseB = [&](uint8_t nk) {
             liveB.clear();
@@ -736,16 +617,16 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
         };
         phaseB(K_EDGE);
         ds[d].end_emits = accB;
-        for (uint8_t nk : {K_OTHER, K_WORD, K_NEWLINE}) {
+        for (uint8_t nk : {K_OTHER, K_WORD, K_NEWLINE, K_UWORD, K_ILL}) {
             bool used = false;
-            for (int c = 0; c < n_cls; c++) if (cls_kind[c] == nk) used = true;
+            for (int c = 0; c < n_cls; c++) if (cls_kind[c] == nk && !cls_stays[(size_t)c]) used = true;
             if (!used) continue;
             // phase B marks must not leak between next-kinds: restart from the phase-A marks
             bl.stamp++;
             for (int s : liveA) bl.mark[s] = bl.stamp;
             phaseB(nk);
             for (int c = 0; c < n_cls; c++) {
-                if (cls_kind[c] != nk) continue;
+                if (cls_kind[c] != nk || cls_stays[(size_t)c]) continue;
                 DKey nkey;
                 nkey.pk = nk;
                 nkey.delayed = accB;
@@ -769,7 +650,35 @@ bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32
     uint32_t S = (uint32_t)ds.size();
     out.n_states = S;
     out.n_classes = (uint32_t)n_cls;
-    for (int b = 0; b < 256; b++) out.classmap[b] = (uint8_t)cls_of[b];
+    for (int b = 0; b < 256; b++) out.classmap[b] = (uint8_t)cls_of[(size_t)b];
+    out.class_stays.assign(cls_stays.begin(), cls_stays.end());
+    out.umap = ScalarMap();
+    if (alpha.on) {
+        // scalar value -> class, two stages of 128 (equal blocks shared): what a walker looks up at a lead byte
+        ScalarMap &m = out.umap;
+        m.ill_class = (uint8_t)cls_of[(size_t)(kAtom0 + kAtomIll)];
+        m.stage1.assign(kScalarBlocks, 0);
+        std::map<std::vector<uint8_t>, uint16_t> blocks;
+        std::vector<uint8_t> blk(128);
+        size_t iv = 0;
+        for (uint32_t bi = 0; bi < kScalarBlocks; bi++) {
+            for (uint32_t k = 0; k < 128; k++) {
+                const uint32_t cp = bi * 128 + k;
+                uint8_t c = m.ill_class;  // (ASCII is never looked up; surrogates are never decoded)
+                if (cp >= 0x80 && !(cp >= 0xD800 && cp <= 0xDFFF)) {
+                    while (alpha.starts[iv + 1] <= cp) iv++;
+                    c = (uint8_t)cls_of[(size_t)(kAtom0 + alpha.atom[iv])];
+                }
+                blk[k] = c;
+            }
+            auto it = blocks.find(blk);
+            if (it == blocks.end()) {
+                it = blocks.emplace(blk, (uint16_t)(m.stage2.size() / 128)).first;
+                m.stage2.insert(m.stage2.end(), blk.begin(), blk.end());
+            }
+            m.stage1[bi] = it->second;
+        }
+    }
     out.trans.assign((size_t)S * n_cls, 0);
     out.emit_off.assign(1, 0);
     out.emit_list.clear();
@@ -838,6 +747,30 @@ RNodeP gap_prefilter(const RNodeP &rx) {
     return x;
 }
 
+// the device image of a ScalarMap (what utf8_class reads): stage 1, then stage 2
+std::vector<uint8_t> scalar_map_image(const ScalarMap &m) {
+    std::vector<uint8_t> img;
+    if (!m.on()) return img;
+    img.resize(kUmapStage2 + m.stage2.size());
+    memcpy(img.data(), m.stage1.data(), kUmapStage2);
+    memcpy(img.data() + kUmapStage2, m.stage2.data(), m.stage2.size());
+    return img;
+}
+uint32_t dfa_class_at(const DfaGroup &g, const uint8_t *bytes, size_t i, size_t n) {
+    const uint32_t b = bytes[i];
+    if (b < 0xC0u || !g.umap.on()) return g.classmap[b];
+    uint32_t next = 0;
+    for (size_t k = 1; k < 4 && i + k < n; k++) next |= (uint32_t)bytes[i + k] << (8 * (k - 1));
+    // (a walk that looks classes up often builds the image once; this is the simple form for the test hooks)
+    const uint32_t len = b >= 0xF0u ? 4u : b >= 0xE0u ? 3u : 2u;
+    if (b < 0xC2u || b > 0xF4u || n - i < len) return g.umap.ill_class;
+    const uint32_t c1 = next & 0xFFu, c2 = (next >> 8) & 0xFFu, c3 = (next >> 16) & 0xFFu;
+    if ((c1 & 0xC0u) != 0x80u || (len > 2u && (c2 & 0xC0u) != 0x80u) || (len > 3u && (c3 & 0xC0u) != 0x80u)) return g.umap.ill_class;
+    uint32_t cp = len == 2u ? ((b & 0x1Fu) << 6) | (c1 & 0x3Fu) : len == 3u ? ((b & 0x0Fu) << 12) | ((c1 & 0x3Fu) << 6) | (c2 & 0x3Fu) : ((b & 0x07u) << 18) | ((c1 & 0x3Fu) << 12) | ((c2 & 0x3Fu) << 6) | (c3 & 0x3Fu);
+    if ((len == 3u && (cp < 0x800u || (cp >= 0xD800u && cp <= 0xDFFFu))) || (len == 4u && (cp < 0x10000u || cp > 0x10FFFFu))) return g.umap.ill_class;
+    return g.umap.stage2[(size_t)g.umap.stage1[cp >> 7] * 128 + (cp & 127u)];
+}
+
 void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector<uint16_t> &out_atoms) {
     uint32_t s = 0;
     auto emit = [&](uint32_t st) {
@@ -845,8 +778,9 @@ void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector
     };
     emit(s);
     for (size_t i = 0; i < n; i++) {
-        s = g.trans[(size_t)s * g.n_classes + g.classmap[bytes[i]]];
-        emit(s);
+        const uint32_t before = s;
+        s = g.trans[(size_t)s * g.n_classes + dfa_class_at(g, bytes, i, n)];
+        if (s != before || !g.class_stays[dfa_class_at(g, bytes, i, n)]) emit(s);
     }
     for (uint32_t k = g.end_off[s]; k < g.end_off[s + 1]; k++) out_atoms.push_back(g.end_list[k]);
     std::sort(out_atoms.begin(), out_atoms.end());

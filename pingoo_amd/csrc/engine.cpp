@@ -103,6 +103,8 @@ int upload(DevBuf &b, const std::vector<T> &v, size_t pad_bytes = 0) {
 struct FlatDev {
     DevBuf flat, flat_classmap, emit_off, emit_list, end_off, end_list, delta;
     uint32_t n_states = 0, n_classes = 0;
+    bool scalar_mode = false;  // the table reads scalar values (dfa.cpp): the class image holds the scalar map behind the byte map
+    uint32_t ill_class = 0;
     uint32_t n_full = 0, n_delta = 0;  // LDS layout of the list scan: rows [0, n_full), then n_delta 8-byte delta records (states n_full ..)
     void release() {
         for (DevBuf *b : {&flat, &flat_classmap, &emit_off, &emit_list, &end_off, &end_list, &delta}) b->release();
@@ -113,6 +115,8 @@ struct FlatDev {
 struct DevGroup {
     DevBuf tab, classmap, special, list_off, list;
     uint32_t n_states, stride, n_classes, n_hot, start_emit, emit_base, special_base, atom_base, n_local;
+    bool scalar_mode = false;
+    uint32_t ill_class = 0;
     uint8_t field;
     uint32_t chunks = 1;  // 16-byte chunks per scan iteration (2 for fields whose sampled mean length is >= 48 bytes)
     int gate = -1;  // >= 0: list-driven pass (behind a bigram prefilter, or gated by prefilter factors): index of its request list
@@ -283,6 +287,26 @@ void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
     g_last_error = src.message;
 }
 
+// A table's class lookups on the device: the 256-byte class map of the BYTES, 16 bytes of padding, then — scalar mode — the image of the
+// scalar-value map (csrc/utf8.h; classes renumbered like the byte map when the table permutes its columns).
+static constexpr size_t kUmapAt = 272;
+std::vector<uint8_t> class_image(const DfaGroup &g, const std::vector<uint32_t> *cpos, uint32_t &ill_class) {
+    std::vector<uint8_t> img(kUmapAt, 0);
+    for (int b = 0; b < 256; b++) img[(size_t)b] = (uint8_t)(cpos ? (*cpos)[g.classmap[b]] : g.classmap[b]);
+    ill_class = 0;
+    if (g.umap.on()) {
+        ScalarMap m = g.umap;
+        if (cpos) {
+            for (auto &c : m.stage2) c = (uint8_t)(*cpos)[c];
+            m.ill_class = (uint8_t)(*cpos)[m.ill_class];
+        }
+        ill_class = m.ill_class;
+        const std::vector<uint8_t> u = scalar_map_image(m);
+        img.insert(img.end(), u.begin(), u.end());
+    }
+    return img;
+}
+
 // Builds the device form of one DFA group: see the cell encoding in kernels.h. `visits` (optional, one count per state) is a
 // traffic profile from pwaf_engine_tune: the LDS-resident ("hot") rows are then the most visited states instead of the
 // shallowest ones. The result of a scan never depends on which rows are hot.
@@ -390,8 +414,8 @@ int build_device_group(const DfaGroup &g, uint32_t lds_hot_budget, DevGroup &d, 
     d.field = g.field;
     int rc;
     if ((rc = upload(d.tab, tab, 16))) return rc;
-    std::vector<uint8_t> cm(256);
-    for (int b = 0; b < 256; b++) cm[b] = (uint8_t)cpos[g.classmap[b]];
+    const std::vector<uint8_t> cm = class_image(g, &cpos, d.ill_class);
+    d.scalar_mode = g.umap.on();
     if ((rc = upload(d.classmap, cm))) return rc;
     if ((rc = upload(d.special, special))) return rc;
     if ((rc = upload(d.list_off, list_off))) return rc;
@@ -462,13 +486,14 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
         order.insert(order.end(), recs.begin(), recs.end());
         order.insert(order.end(), rest.begin(), rest.end());
         for (uint32_t q = 0; q < S; q++) pos[order[q]] = q;
-        auto cell_of = [&](uint32_t t) { return (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u)); };
+        // (a class that STAYS — a continuation byte of scalar mode — enters nothing: its cell, the state itself, carries no emit flag)
+        auto cell_of = [&](uint32_t t, uint32_t c) { return (uint16_t)(pos[t] | ((g.emit_off[(size_t)t + 1] != g.emit_off[t] && !(c < g.class_stays.size() && g.class_stays[c])) ? 0x8000u : 0u)); };
         for (uint32_t s : recs) {
             const Near &nr = near[s];
             const uint16_t *rs = &g.trans[(size_t)s * C];
             const uint8_t c1 = nr.n >= 1 ? nr.c[0] : 0, c2 = nr.n >= 2 ? nr.c[1] : c1;
             // (no exception: both slots repeat the base row's own cell of class 0)
-            const uint16_t t1 = cell_of(rs[c1]), t2 = cell_of(rs[c2]);
+            const uint16_t t1 = cell_of(rs[c1], c1), t2 = cell_of(rs[c2], c2);
             delta_rec.push_back((uint64_t)nr.base | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 24) | ((uint64_t)t1 << 32) | ((uint64_t)t2 << 48));
         }
     }
@@ -488,7 +513,8 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
         const uint32_t s = order[q];
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t t = g.trans[(size_t)s * C + c];
-            flat[(size_t)q * stride + c] = (uint16_t)(pos[t] | (g.emit_off[(size_t)t + 1] != g.emit_off[t] ? 0x8000u : 0u));
+            const bool stays = c < g.class_stays.size() && g.class_stays[c];  // (a continuation byte of scalar mode: the state itself, entering nothing)
+            flat[(size_t)q * stride + c] = (uint16_t)(pos[t] | ((g.emit_off[(size_t)t + 1] != g.emit_off[t] && !stays) ? 0x8000u : 0u));
         }
         const uint32_t ne = g.emit_off[(size_t)s + 1] - g.emit_off[s];
         flat[(size_t)q * stride + C] = ne == 0 ? (uint16_t)0 : (ne == 1 && g.emit_list[g.emit_off[s]] < 0x7FFFu) ? (uint16_t)(0x8000u | g.emit_list[g.emit_off[s]]) : (uint16_t)1;
@@ -499,7 +525,8 @@ int build_flat_group(const DfaGroup &g, FlatDev &d, bool wide, const std::vector
         end_list.insert(end_list.end(), g.end_list.begin() + g.end_off[s], g.end_list.begin() + g.end_off[(size_t)s + 1]);
         end_off.push_back((uint32_t)end_list.size());
     }
-    std::vector<uint8_t> cm(g.classmap, g.classmap + 256);
+    const std::vector<uint8_t> cm = class_image(g, nullptr, d.ill_class);
+    d.scalar_mode = g.umap.on();
     int rc;
     if ((rc = upload(d.flat, flat, 16))) return rc;  // (the LDS staging copies whole 16-byte units)
     if (delta_rec.empty()) delta_rec.push_back(0);
@@ -1000,6 +1027,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.n = n;
         a.tab = (const uint16_t *)d.tab.p;
         a.classmap = (const uint8_t *)d.classmap.p;
+        a.umap = d.scalar_mode ? (const uint8_t *)d.classmap.p + kUmapAt : nullptr;
+        a.ill_class = d.ill_class;
         a.special = (const SpecialCell *)d.special.p;
         a.list_off = (const uint32_t *)d.list_off.p;
         a.list = (const uint16_t *)d.list.p;
@@ -1073,6 +1102,8 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         const FlatDev &F = (d.confirm && d.rt.n_states) ? d.rt : d.fl;  // (a confirmed candidate walks the DFA of the pass's non-literal atoms)
         a.flat = (const uint16_t *)F.flat.p;
         a.classmap = (const uint8_t *)F.flat_classmap.p;
+        a.umap = F.scalar_mode ? (const uint8_t *)F.flat_classmap.p + kUmapAt : nullptr;
+        a.ill_class = F.ill_class;
         a.n_classes = F.n_classes;
         {
             // rows [0, n_full) and the delta records behind them, when this launch's LDS share holds the layout the tables were built for
@@ -2335,7 +2366,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             uint32_t s = 0;
             note(g.emit_off, g.emit_list, s);
             for (uint32_t p = off[i]; p < off[i + 1]; p++) {
-                const uint32_t cl = g.classmap[data[p]];
+                const uint32_t cl = dfa_class_at(g, data + off[i], p - off[i], off[i + 1] - off[i]);  // (scalar mode: the scalar's class at a lead byte)
                 cf[cl]++;
                 s = g.trans[(size_t)s * g.n_classes + cl];
                 v[s]++;
@@ -2448,14 +2479,14 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
                 if (!walk) continue;
                 uint32_t st = 0;
                 for (uint32_t p = off[i]; p < off[i + 1]; p++) {
-                    st = g.trans[(size_t)st * g.n_classes + g.classmap[data[p]]];
+                    st = g.trans[(size_t)st * g.n_classes + dfa_class_at(g, data + off[i], p - off[i], off[i + 1] - off[i])];
                     v[st]++;
                 }
                 if (g.rtier) {
                     const DfaGroup &r = *g.rtier;
                     uint32_t rs = 0;
                     for (uint32_t p = off[i]; p < off[i + 1]; p++) {
-                        rs = r.trans[(size_t)rs * r.n_classes + r.classmap[data[p]]];
+                        rs = r.trans[(size_t)rs * r.n_classes + dfa_class_at(r, data + off[i], p - off[i], off[i + 1] - off[i])];
                         rv[rs]++;
                     }
                 }

@@ -46,6 +46,8 @@ struct ScanArgs {
     uint32_t n;
     const uint16_t *tab;      // full table (all rows), padded to 16 bytes
     const uint8_t *classmap;  // 256 bytes
+    const uint8_t *umap;      // scalar mode (dfa.cpp): the scalar-value -> class map a lead byte is looked up in (csrc/utf8.h); null: the table reads bytes
+    uint32_t ill_class;       // ... and the class of a byte that begins no well-formed sequence
     const SpecialCell *special;
     const uint32_t *list_off; // shared by end- and emit-lists
     const uint16_t *list;     // local atom ids
@@ -83,6 +85,8 @@ struct ListScanArgs {
     uint32_t n;
     const uint16_t *flat;
     const uint8_t *classmap;  // 256 bytes
+    const uint8_t *umap;      // scalar mode: see ScanArgs
+    uint32_t ill_class;
     uint32_t n_classes;
     uint32_t n_hot;            // rows staged in LDS: n_hot * (n_classes + 3) * 2 <= the launch's ListShape::hot_bytes
     // DELTA records (engine.cpp: build_flat_group): states [n_hot, n_hot + n_delta) live in LDS as 8 bytes each — base row (16 bits), two

@@ -33,6 +33,7 @@
 #include <set>
 
 #include "confirm.h"
+#include "utf8.h"
 #include "kernels.h"
 #include "residual.h"
 
@@ -215,6 +216,19 @@ __device__ __forceinline__ void enqueue_gated(const uint32_t *colmask_local, con
 // and every branch on it would be an exec-mask branch).
 __device__ __forceinline__ uint32_t wave_index() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Scalar mode of a table (dfa.cpp, utf8.h): does a 16-byte window hold a LEAD byte (>= 0xC0: bits 7 and 6 set)? Asked once per window
+// and wave (ASCII traffic: never), so that the class fix-up below costs the common case ten vector instructions per 16 bytes.
+__device__ __forceinline__ bool window_has_lead(const u32x4 w) {
+    const uint32_t m = (w.x & (w.x << 1)) | (w.y & (w.y << 1)) | (w.z & (w.z << 1)) | (w.w & (w.w << 1));
+    return (m & 0x80808080u) != 0u;
+}
+// The class of the scalar value whose lead byte b0 sits at arena position `at` of a field that ends at `end` (rare path: one unaligned
+// load of the three bytes behind it, two dependent table loads).
+__device__ __noinline__ uint32_t lead_class(const uint8_t *umap, const uint32_t ill_class, const PWAF_GLOBAL unsigned char *gdata, const uint32_t b0, const uint32_t at, const uint32_t end) {
+    const uint32_t next = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + at + 1u);  // (PWAF_ARENA_PAD covers the read behind the arena's end)
+    return utf8_class(umap, ill_class, b0, next, end - at);
+}
+
 template <class T>
 __device__ __forceinline__ T load_descriptor(const T *p) {
     static_assert(sizeof(T) % 4 == 0, "descriptor size");
@@ -378,6 +392,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             // byte classes do not depend on the state: all 16 lookups are issued before the dependent chain starts
             const uint32_t c = WIDE ? *reinterpret_cast<lds_u32_ptr>((uintptr_t)(byte << 2)) : (uint32_t)*reinterpret_cast<lds_u8_ptr>((uintptr_t)byte);
             c2[k] = (uint32_t)k < cnt ? c : stay2;  // past the end: the STAY cell
+        }
+        if (a.umap != nullptr && __ballot(cnt != 0u && window_has_lead(w[q])) != 0ull) {  // scalar mode, a lead byte in somebody's chunk (rare)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                if (byte >= 0xC0u && (uint32_t)k < cnt) c2[k] = 2u * lead_class(a.umap, a.ill_class, gdata, byte, p + 16u * (uint32_t)q + (uint32_t)k, end);
+            }
         }
         // The 16 steps run in groups of 4 with ONE check per group: inside a group every lane chains lookup to lookup
         // (v_lshl_add + ds_read_u16, nothing else on the dependent path), treating whatever it reads as the next row. Only if
@@ -609,6 +630,13 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = cls[(wd >> (k * 8)) & 0xFFu];
             asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));  // (the four class lookups stay unconditional: left alone the compiler sinks each under its "k < cnt" — sixteen exec-mask branches per window, which doubled the walk's time)
+            if (a.umap != nullptr && __ballot(active && ((wd & (wd << 1)) & 0x80808080u) != 0u) != 0ull) {  // scalar mode, a lead byte somewhere (rare): the scalar's class
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t byte = (wd >> (k * 8)) & 0xFFu;
+                    if (byte >= 0xC0u && k < cnt) c[k] = lead_class(a.umap, a.ill_class, gdata, byte, p + k, end);
+                }
+            }
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = k < cnt ? c[k] : ncls + 1u;
 #pragma unroll
@@ -789,12 +817,15 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                 if (!more) break;
                 u32x4 wn[kListWalks];
                 uint32_t cnt[kListWalks];
+                bool lead_here = false;  // scalar mode: some walk's window holds a lead byte (wave-uniform after the ballot)
 #pragma unroll
                 for (uint32_t u = 0; u < kListWalks; u++) {
                     const uint32_t pn = p[u] + 16u;
                     wn[u] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end[u] ? pn : 0u));
                     cnt[u] = p[u] < end[u] ? min(16u, end[u] - p[u]) : 0u;
+                    if (a.umap != nullptr) lead_here = lead_here || (cnt[u] != 0u && window_has_lead(w[u]));
                 }
+                const bool fix_classes = a.umap != nullptr && __ballot(lead_here) != 0ull;
 #pragma unroll
                 for (uint32_t k0 = 0; k0 < 16; k0 += 4) {
                     uint32_t c[kListWalks][4], t[kListWalks][4], sv[kListWalks][4];
@@ -805,6 +836,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                         for (uint32_t k = 0; k < 4; k++) {
                             const uint32_t cl = cls[(wd >> (k * 8)) & 0xFFu];
                             c[u][k] = k0 + k < cnt[u] ? cl : ncls + 1u;
+                        }
+                        if (fix_classes) {  // (uniform, rare) a lead byte reads as the class of the scalar value it begins; its continuation bytes stay
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t byte = (wd >> (k * 8)) & 0xFFu;
+                                if (byte >= 0xC0u && k0 + k < cnt[u]) c[u][k] = lead_class(a.umap, a.ill_class, gdata, byte, p[u] + k0 + k, end[u]);
+                            }
                         }
                     }
 #pragma unroll
@@ -1930,7 +1968,7 @@ __global__ __launch_bounds__(256) void compact_kernel(FilterTable B) {
 
 __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uint32_t n_rules) {
     const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
-    return ((n_cols * 8 + 64 * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;  // columns, fire words, bitmaps, candidates
+    return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;  // columns, bitmaps, candidates (also: the list of non-zero columns)
 }
 
 // LDS-resident copies of the small read-mostly program tables (LT = true): trigger lists, rule headers and DNF literals are
@@ -1965,8 +2003,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     const uint32_t wave_bytes = verdict_wave_lds(a.n_cols, a.n_rules);
     unsigned char *mine = lds + (size_t)wave * wave_bytes;
     unsigned long long *col = reinterpret_cast<unsigned long long *>(mine);
-    unsigned long long *fbuf = col + a.n_cols;  // per round: candidate j's 64-request match word
-    uint32_t *colnz = reinterpret_cast<uint32_t *>(fbuf + 64);
+    uint32_t *colnz = reinterpret_cast<uint32_t *>(col + a.n_cols);
     uint32_t *rulebm = colnz + colw;
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
     unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
@@ -2202,15 +2239,45 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
         // 4. candidate rules: a rule can only match some request of this group if one of its terms has a non-zero positive
         //    column (trigger lists, one chosen literal per term) or consists of negations only (always_rules).
-        for (uint32_t wv = lane; wv < colw && !(dbg_skip & 8u); wv += 64) {
-            uint32_t nz = colnz[wv];
-            while (nz) {
-                const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
-                nz &= nz - 1;
-                const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
-                for (uint32_t k = kb; k < ke; k++) {
-                    const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
-                    atomicOr(&rulebm[r >> 5], 1u << (r & 31));
+        //    The non-zero columns are first LISTED (a prefix sum over the bitmap words' popcounts: the candidate array is free until
+        //    the compaction below), then one lane takes one column. (Round 4 gave a lane a whole bitmap word: the ~60 attribute columns
+        //    of a group sit in a handful of neighbouring words, so a few lanes walked eight to sixteen columns one after the other,
+        //    each a chain of three dependent LDS reads, while the other sixty waited.)
+        if (!(dbg_skip & 8u)) {
+            uint32_t n_nz = 0;
+            for (uint32_t wb = 0; wb < colw; wb += 64) {
+                uint32_t nz = wb + lane < colw ? colnz[wb + lane] : 0u;
+                const uint32_t pc = (uint32_t)__builtin_popcount(nz), incl = wave_scan_add(pc);
+                uint32_t pos = n_nz + incl - pc;
+                while (nz) {
+                    if (pos < a.n_rules) cand[pos] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(nz));  // (a column file fits LDS: n_cols < 20480)
+                    pos++;
+                    nz &= nz - 1;
+                }
+                n_nz += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (n_nz <= a.n_rules) {
+                for (uint32_t j = lane; j < n_nz; j += 64) {
+                    const uint32_t c = cand[j];
+                    const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
+                    for (uint32_t k = kb; k < ke; k++) {
+                        const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
+                        atomicOr(&rulebm[r >> 5], 1u << (r & 31));
+                    }
+                }
+            } else {  // (more non-zero columns than the list holds: word by word)
+                for (uint32_t wv = lane; wv < colw; wv += 64) {
+                    uint32_t nz = colnz[wv];
+                    while (nz) {
+                        const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
+                        nz &= nz - 1;
+                        const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
+                        for (uint32_t k = kb; k < ke; k++) {
+                            const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
+                            atomicOr(&rulebm[r >> 5], 1u << (r & 31));
+                        }
+                    }
                 }
             }
         }
@@ -2276,41 +2343,37 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                 fire = acc_or & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
             }
             if (dbg_skip & 256u) fire = 0;
-            fbuf[lane] = fire;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (__ballot(fire != 0) != 0 && !(dbg_skip & 128u)) {
-                const uint32_t cnt = min(64u, n_cand - base);
-                uint32_t first = kNone;
-                for (uint32_t j = 0; j < cnt; j += 4) {
-                    unsigned long long w4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) w4[q] = fbuf[min(j + (uint32_t)q, 63u)];  // same address in every lane: a broadcast read
-#pragma unroll
-                    for (int q = 3; q >= 0; q--)
-                        if (j + (uint32_t)q < cnt && (w4[q] & mybit)) first = first < j + (uint32_t)q ? first : j + (uint32_t)q;
-                    if (__ballot(undecided && first == kNone) == 0) break;  // every open request of the group has met its rule
-                }
-                if (undecided && first != kNone) {
-                    undecided = false;
-                    const uint32_t jc = cand[base + first];
-                    uint32_t eff_u, eff_v;
-                    if (LT) {
-                        const uint32_t y = l_rules[jc].y;
-                        eff_u = (y >> 16) & 0xFFu;
-                        eff_v = y >> 24;
-                        const uint32_t pi = l_pub[jc];
-                        my_rule = pi >= 0xFFF0u ? 0xFFFF0000u | pi : pi;
-                    } else {
-                        const DevRule dr = a.rules[jc];
-                        eff_u = dr.eff_unverified;
-                        eff_v = dr.eff_verified;
-                        my_rule = dr.public_idx;
-                    }
-                    my_action = (verified_mask & mybit) ? eff_v : eff_u;
-                }
-                pending = __ballot(undecided);
+            // first match wins: the candidates that fire for ANYBODY (a few per group: most candidates' terms stay false) are taken in
+            // rule order, each word broadcast from its lane — a request's rule is the first word that holds its bit. (Round 4 parked
+            // all 64 words in LDS and every request lane read them back, sixteen rounds of four broadcast reads per 64 candidates.)
+            unsigned long long firing = (dbg_skip & 128u) ? 0ull : __ballot(fire != 0);
+            uint32_t first = kNone;
+            while (firing != 0 && pending != 0) {
+                const int j = __builtin_ctzll(firing);
+                firing &= firing - 1;
+                const unsigned long long fj = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fire >> 32), j) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fire, j)) & pending;
+                if (fj & mybit) first = (uint32_t)j;
+                pending &= ~fj;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (undecided && first != kNone) {
+                undecided = false;
+                const uint32_t jc = cand[base + first];
+                uint32_t eff_u, eff_v;
+                if (LT) {
+                    const uint32_t y = l_rules[jc].y;
+                    eff_u = (y >> 16) & 0xFFu;
+                    eff_v = y >> 24;
+                    const uint32_t pi = l_pub[jc];
+                    my_rule = pi >= 0xFFF0u ? 0xFFFF0000u | pi : pi;
+                } else {
+                    const DevRule dr = a.rules[jc];
+                    eff_u = dr.eff_unverified;
+                    eff_v = dr.eff_verified;
+                    my_rule = dr.public_idx;
+                }
+                my_action = (verified_mask & mybit) ? eff_v : eff_u;
+            }
         }
 
         if (dbg_skip & 64u) my_rule = n_cand;  // profiling aid: report the candidate count instead of the deciding rule

@@ -195,10 +195,21 @@ struct FilterHints {  // from a traffic sample (pwaf_engine_tune); all optional
 // One multi-pattern DFA = one scan pass over one field. States are numbered in BFS order from the start
 // state (id 0), so low ids are the shallow, frequently visited states: the device keeps rows [0, n_hot)
 // in LDS and reads colder rows from the L2-resident global copy.
+// Scalar mode of a table (dfa.cpp): the class of a scalar value beyond ASCII, looked up at its lead byte — stage1[cp >> 7] names a
+// block of 128 classes in stage2 (equal blocks shared: a few KiB even when \\w is in the table). Empty: the table reads bytes.
+static constexpr uint32_t kScalarBlocks = 0x110000 >> 7;
+struct ScalarMap {
+    std::vector<uint16_t> stage1;
+    std::vector<uint8_t> stage2;
+    uint8_t ill_class = 0;  // a byte that begins no well-formed sequence
+    bool on() const { return !stage1.empty(); }
+};
 struct DfaGroup {
     uint8_t field = 0;
     uint32_t n_states = 0, n_classes = 0;
-    uint8_t classmap[256] = {0};
+    uint8_t classmap[256] = {0};          // class of a BYTE (scalar mode: 0x80..0xBF continuation bytes — a class that stays — and 0xC0..0xFF lead bytes, which the walkers replace by umap's class of the scalar)
+    ScalarMap umap;
+    std::vector<uint8_t> class_stays;    // per class: every transition stays where it is and emits nothing (continuation / lead bytes of scalar mode)
     std::vector<uint16_t> trans;         // n_states * n_classes, row-major; state 0 = start
     std::vector<uint32_t> emit_off;      // n_states + 1 offsets into emit_list (columns set on ENTERING the state)
     std::vector<uint16_t> emit_list;     // LOCAL atom ids (column = atom_base + local)
@@ -327,6 +338,9 @@ struct ScanPattern {
     uint32_t atom;  // index into Program::atoms
 };
 // Builds one DFA for `pats` (local ids = positions in pats). Returns false when the state limit is exceeded.
+// class of the symbol that begins at bytes[i] (csrc/utf8.h: scalar mode decodes at a lead byte)
+std::vector<uint8_t> scalar_map_image(const ScalarMap &m);  // [stage1 u16 x kScalarBlocks][stage2]: what csrc/utf8.h reads
+uint32_t dfa_class_at(const DfaGroup &g, const uint8_t *bytes, size_t i, size_t n);
 bool build_dfa(const std::vector<ScanPattern> &pats, uint32_t max_states, uint32_t max_table_bytes, DfaGroup &out, std::string &err);
 // true when the pattern has an unbounded repetition of a wide byte class (".*", "[^x]*", ...): such patterns multiply DFA
 // states with each other (each adds an independent "prefix seen" bit), so the grouping heuristic isolates them.

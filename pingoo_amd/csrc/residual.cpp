@@ -134,7 +134,10 @@ struct ResidualBuilder::Impl {
             std::string e2;
             if (!build_dfa(one, 8192, 2u << 20, g, e2)) throw Reject{"matches(): the pattern's DFA exceeds the residual interpreter's budget: " + e2};
             if (regexes.size() >= 0xFFE) throw Reject{"too many regex literals in residual programs"};
-            std::vector<uint8_t> tab(g.trans.size() * 2 + 256 + g.n_states);
+            const std::vector<uint8_t> uimg = scalar_map_image(g.umap);  // (empty: the table reads bytes)
+            const size_t uat = (g.trans.size() * 2 + 256 + g.n_states + 3) & ~(size_t)3;
+            std::vector<uint8_t> tab(uat + uimg.size());
+            if (!uimg.empty()) memcpy(tab.data() + uat, uimg.data(), uimg.size());
             memcpy(tab.data(), g.trans.data(), g.trans.size() * 2);
             memcpy(tab.data() + g.trans.size() * 2, g.classmap, 256);
             uint8_t *fl = tab.data() + g.trans.size() * 2 + 256;
@@ -165,6 +168,8 @@ struct ResidualBuilder::Impl {
             d.n_classes = g.n_classes;
             d.trans = (uint32_t)g.trans.size() * 2;  // (sizes for now: resolved to blob offsets in blob())
             d.flags = g.n_states;
+            d.umap = uimg.empty() ? 0u : (uint32_t)uat;  // (relative to the table: resolved in blob())
+            d.ill_class = g.umap.ill_class;
             regexes.push_back(d);
             regex_tabs.push_back(std::move(tab));
             id = (uint32_t)regexes.size() - 1;
@@ -593,6 +598,7 @@ std::vector<uint8_t> ResidualBuilder::blob() const {
         rd[k].trans = at;
         rd[k].classmap = at + trans_bytes;
         rd[k].flags = at + trans_bytes + 256;
+        if (rd[k].umap) rd[k].umap += at;
         (void)n_states;
     }
     h.regexes = put(rd.data(), rd.size() * sizeof(RegexDesc), 4);

@@ -122,6 +122,8 @@ struct RegexDesc {    // one literal `matches` pattern compiled to a DFA (a sing
     uint32_t classmap;  // ... of 256 class bytes
     uint32_t flags;   // ... of n_states bytes: bit 0 = entering the state is a match, bit 1 = ending the haystack in it is a match, bit 2 = dead (neither can be reached any more)
     uint32_t n_classes;
+    uint32_t umap;    // SCALAR MODE (dfa.cpp): byte offset of the scalar-value -> class map ([stage1 u16 x 8704][stage2]: csrc/utf8.h), 0 = the table reads bytes
+    uint32_t ill_class;  // ... and the class of a byte that begins no well-formed sequence
 };
 // The whole residual program of a rule set is ONE blob (uploaded as is): header, then sections at the header's byte offsets.
 struct Header {
@@ -405,13 +407,20 @@ PWAF_HD bool map_has(const Machine &m, const Val &mp, const Val &key, Val *out) 
 PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
     // Table entries (residual.cpp): next state | 0x8000 when entering it decides the match | 0x4000 when it is dead (nothing the rest
     // of the string holds can make the pattern match: an anchored pattern that has failed) — one table load per byte.
+    // SCALAR MODE (a class beyond ASCII in the pattern: the regex crate matches scalar values, Cargo.lock:1694-1700): a byte below 0x80
+    // is its own symbol, a well-formed sequence is ONE symbol — its scalar's class from the two-stage map — taken when its last byte
+    // arrives (the string may be a rope: the sequence may straddle two segments), a lead byte that the next byte does not continue is
+    // the ill-formed class and that byte is then read on its own; a continuation byte that continues nothing is skipped, as the table
+    // walkers of kernels.hip do (utf8.h decodes at the lead byte there: the same symbols in the same order).
     const RegexDesc &d = section<RegexDesc>(m, m.h->regexes)[id];
     const uint16_t *trans = section<uint16_t>(m, d.trans);
     const uint8_t *cm = m.blob + d.classmap, *fl = m.blob + d.flags;
+    const uint8_t *um = d.umap ? m.blob + d.umap : nullptr;
     const uint32_t nc = d.n_classes;
     uint32_t st = 0;
     if (fl[0] & 1u) return true;
     if (fl[0] & 4u) return false;
+    uint32_t pend = 0, need = 0, cp = 0;  // scalar mode: bytes of the open sequence still to come, its length, the bits so far
     // segment by segment (a flat string is its own only segment), eight bytes per load
     const bool rope = str_src(s) == S_ROPE;
     const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = rope ? (uint32_t)((s.p >> 24) & 0xFFu) : 1u;
@@ -424,12 +433,43 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
             uint64_t w = load8(p + i);
             const uint32_t take = sg.a - i < 8u ? sg.a - i : 8u;
             for (uint32_t j = 0; j < take; j++, w >>= 8) {
-                const uint32_t e = trans[st * nc + cm[(uint32_t)w & 0xFFu]];
+                const uint32_t b = (uint32_t)w & 0xFFu;
+                uint32_t cls = cm[b];
+                if (um != nullptr && (b >= 0x80u || pend != 0u)) {
+                    if (pend != 0u) {
+                        if ((b & 0xC0u) == 0x80u) {  // the open sequence goes on
+                            cp = (cp << 6) | (b & 0x3Fu);
+                            if (--pend != 0u) continue;
+                            const bool bad = (need == 2u && cp < 0x800u) || (need == 3u && (cp < 0x10000u || cp > 0x10FFFFu)) || (cp >= 0xD800u && cp <= 0xDFFFu);
+                            cls = bad ? d.ill_class : um[(0x110000u >> 7) * 2u + (uint32_t)reinterpret_cast<const uint16_t *>(um)[cp >> 7] * 128u + (cp & 127u)];
+                        } else {  // broken off: the lead byte was ill-formed; this byte is read on its own below
+                            pend = 0;
+                            const uint32_t e0 = trans[st * nc + d.ill_class];
+                            if (e0 & 0x8000u) return true;
+                            if (e0 & 0x4000u) return false;
+                            st = e0;
+                        }
+                    }
+                    if (pend == 0u && cls == cm[b] && b >= 0xC0u) {  // (cls still the byte's own: not the sequence that just closed) a lead byte
+                        if (b < 0xC2u || b > 0xF4u) cls = d.ill_class;
+                        else {
+                            need = pend = b >= 0xF0u ? 3u : b >= 0xE0u ? 2u : 1u;
+                            cp = b & (0x3Fu >> need);
+                            continue;
+                        }
+                    }
+                }
+                const uint32_t e = trans[st * nc + cls];
                 if (e & 0x8000u) return true;
                 if (e & 0x4000u) return false;
                 st = e;
             }
         }
+    }
+    if (pend != 0u) {  // the string ends inside a sequence: its lead byte was ill-formed
+        const uint32_t e0 = trans[st * nc + d.ill_class];
+        if (e0 & 0x8000u) return true;
+        st = e0 & 0x3FFFu;
     }
     return (fl[st] & 2u) != 0;
 }

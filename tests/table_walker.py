@@ -42,6 +42,22 @@ def parse_dump(blob: bytes):
     return sections
 
 
+def scalar_class(um: bytes, data: bytes, j: int) -> int:
+    """csrc/utf8.h restated: the class of the scalar value whose lead byte is data[j] (the ill-formed class when the bytes from j on
+    are not one well-formed sequence inside the field)."""
+    ill, img = um[0], um[8:]
+    b0 = data[j]
+    ln = 4 if b0 >= 0xF0 else 3 if b0 >= 0xE0 else 2
+    if b0 < 0xC2 or b0 > 0xF4 or len(data) - j < ln:
+        return ill
+    try:
+        cp = ord(bytes(data[j:j + ln]).decode("utf-8"))
+    except (UnicodeDecodeError, TypeError):
+        return ill
+    block = img[2 * (cp >> 7)] | (img[2 * (cp >> 7) + 1] << 8)
+    return img[2 * (0x110000 >> 7) + block * 128 + (cp & 127)]
+
+
 class Tables:
     def __init__(self, blob):
         """`blob`: a program dump, or the CompiledProgram itself (then the confirm tier of its filtered passes is evaluated too,
@@ -60,6 +76,10 @@ class Tables:
                 self.groups.append(cur)
             elif tag == "GCLS":
                 cur["classmap"] = np.frombuffer(pl, dtype=np.uint8)
+            elif tag == "GUMP":
+                cur["umap"] = pl  # byte 0: the class of an ill-formed byte; from byte 8: [stage1 u16 x 8704][stage2]
+            elif tag == "RUMP":
+                cur["rtier"]["umap"] = pl
             elif tag == "GTRN":
                 cur["trans"] = np.frombuffer(pl, dtype="<u2").reshape(cur["n_states"], cur["n_classes"])
             elif tag == "GEMO":
@@ -203,10 +223,15 @@ class Tables:
             for a in g["emit_list"][g["emit_off"][s]:g["emit_off"][s + 1]]:
                 cols.add(g["atom_base"] + int(a))
         emit(st)
-        cm, tr = g["classmap"], g["trans"]
+        cm, tr, um = g["classmap"], g["trans"], g.get("umap")
         for j in range(len(data)):
-            st = int(tr[st, cm[data[j]]])
-            emit(st)
+            c = int(cm[data[j]])
+            if um is not None and data[j] >= 0xC0:
+                c = scalar_class(um, data, j)  # scalar mode: the class of the scalar value that begins here (csrc/utf8.h)
+            nxt = int(tr[st, c])
+            if not (um is not None and 0x80 <= data[j] < 0xC0):  # (a continuation byte stays and emits nothing)
+                st = nxt
+                emit(st)
             self.n_steps += 1
         for a in g["end_list"][g["end_off"][st]:g["end_off"][st + 1]]:
             cols.add(g["atom_base"] + int(a))
