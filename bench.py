@@ -380,6 +380,27 @@ def main():
             phase("adversarial oracle check")
             traffic_modes["adversarial_tuned_on_benign"].update(oracle_check(wl, adv_host.slice(0, min(n, 60_000)), R.outs[0], os.cpu_count() or 1))
         del adv, adv_host
+        if args.config == 3 and rank == 0:
+            # SATURATED: url / path / User-Agent filled to their caps with tokens that complete a window of the pass's own
+            # (tuned) filter tables without being a rule literal — nearly every 16-byte chunk goes to the confirm tier: its worst case
+            phase("saturated run")
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pingoo_amd.engine import CompiledProgram
+            from saturated import saturated_batch
+
+            model = CompiledProgram(wl.rules, wl.lists, wl.geoip)
+            model.tune(wl.batch(total + rank * tune_n, tune_n, threads=threads))  # (the same sample the engine was tuned on: the same tables)
+            n_sat = min(n, 4_000_000)  # (a 500-byte url per request: the arena's 32-bit offsets hold 4M of them)
+            sat_host, sat_info = saturated_batch(wl, model, n_sat)
+            sat = DeviceBatch(sat_host, dev)
+            Rs = Runner(eng, sat_host.n, dev, world, 1)
+            ks = max(2, args.steps // 2)
+            el, kt, sat_counts = Rs.timed_run(sat, ks, 1)
+            traffic_modes["saturated"] = dict(Rs.mode_summary(el, kt, ks), requests=sat_host.n, bytes_per_request=round(sat_host.algorithmic_bytes() / sat_host.n, 1),
+                                              flagged_chunks_model=sat_info, action_counts_allow_block_captcha_bypass=sat_counts)
+            if not args.no_cpu_baseline:
+                traffic_modes["saturated"].update(oracle_check(wl, sat_host.slice(0, min(sat_host.n, 20_000)), Rs.outs[0], os.cpu_count() or 1))
+            del sat, sat_host, Rs, model
     traffic_modes["tuned_benign" if not args.adversarial else "adversarial_tuned_on_benign (headline)"] = head
 
     rules_desc = {3: "1k-rule WAF", 5: "4096-rule bot-protection set, 64 header fields (extension)"}.get(args.config, f"{len(wl.rules)}-rule set")

@@ -1268,12 +1268,6 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
     const uint64_t base64 = (uint64_t)slab * kStreamSlab;
     if (base64 >= a.total) return;
     const uint32_t total = a.total, base0 = (uint32_t)base64, slab_end = (uint32_t)min<uint64_t>(total, base64 + kStreamSlab);
-    // The batch's own bytes are [off[0], total): a slab view of a larger arena (a rank's share of a node batch, engine.cpp: col_begin) keeps
-    // absolute positions, and what lies before off[0] — another view's requests, stale staging bytes — must not flag a chunk: a chunk
-    // that no request owns has no pair (resolve_kernel), and its slot of the pair list would be read unwritten. The chunk that HOLDS
-    // off[0] counts (its later bytes are the first request's): chunks are flagged from (off[0] & ~15) on. One unsigned compare, as before.
-    const uint32_t lo16 = __builtin_amdgcn_readfirstlane(a.off[0]) & ~15u, span = total - lo16;
-    const uint32_t lane_at = 16u * lane - lo16;
     unsigned long long *my_bits = reinterpret_cast<unsigned long long *>(a.chunk_bits) + (size_t)rel * (kStreamSlab / 1024);  // one 64-bit word per row
     uint32_t n_hit = 0;  // wave-uniform: flagged chunks of the slab
     const uint32_t mul2 = a.mul | (a.mul << 16);
@@ -1475,7 +1469,7 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
                 for (int i = 0; i < 8; i++) { push(st, m[i]); seen &= st; }
             }
             carry = __builtin_amdgcn_readlane(tail, 63);
-            const bool hit = ((~seen) & 0xFF000000u) != 0 && b + kRow * q + lane_at < span;  // (inside [off[0] & ~15, total), wrapping below it)
+            const bool hit = ((~seen) & 0xFF000000u) != 0 && b + kRow * q + 16u * lane < total;
             hm[q] = __ballot(hit);  // bit l = the row's chunk l: the row's word of the pass's chunk bitmap as it is
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1840,6 +1834,24 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     // rank among the slab's flagged chunks (the prefix counts above): no second walk.
     const uint32_t pair_base = a.pairs != nullptr ? a.pair_base[rel] : 0u;
     const uint32_t begin = __builtin_amdgcn_readfirstlane(a.off[0]);  // != 0: a slab view of a larger arena
+    // A slab view keeps absolute arena positions and the filter streams whole slabs: what lies before off[0] in the view's first slab —
+    // another view's requests, stale staging bytes — may have flagged chunks that NO request of this batch owns. Their slots of the pair
+    // list are filled with "no pair" here (confirm_kernel skips those; left unwritten they would be read as stale {request, chunk}
+    // pairs: ADVICE r4). Only the chunks that end at or before off[0]: the chunk that holds off[0] belongs to the first request.
+    if (a.pairs != nullptr && (uint64_t)begin > b0) {
+        const uint32_t n_before = min((uint32_t)(((uint64_t)begin - b0) >> 4), kChunks);  // chunks [0, n_before) of this slab lie wholly before off[0]
+        for (uint32_t w = lane; w * 32u < n_before; w += 64) {
+            uint32_t bw = bits[w];
+            if (n_before - w * 32u < 32u) bw &= (1u << (n_before - w * 32u)) - 1u;
+            const uint32_t word = bits[w];
+            while (bw) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(bw);
+                bw &= bw - 1u;
+                const uint32_t at = pair_base + rank[w] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u));
+                if (at < a.pair_cap) a.pairs[at] = make_uint2(kNone, 0u);
+            }
+        }
+    }
     {
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
     uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;

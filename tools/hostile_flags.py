@@ -73,8 +73,9 @@ def main():
             tot[label][1] += chunks
             if cfg != 5:
                 print(f"{label:<8} pass {gi} {names[f] if f < 5 else 'hdr' + str(f - 5):<10} stride {g.get('f_stride')}: candidates {100 * (per > 0).mean():6.2f} % of requests, "
-                      f"{h.sum() / n:.3f} windows and {chunks / n:.3f} flagged chunks per request")
+                      f"{h.sum() / n:.3f} windows and {chunks / n:.3f} flagged chunks per request = {100.0 * chunks / max(1, (int(off[-1]) + 15) // 16):.1f} % of the arena's chunks")
         print(f"{label}: {tot[label][0] / n:.3f} (request, pass) candidates and {tot[label][1] / n:.3f} flagged chunks per request over all filtered passes")
 
 
-main()
+if __name__ == "__main__":
+    main()
