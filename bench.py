@@ -258,6 +258,7 @@ def main():
                     help="strong (default when --gpus > 1): BASELINE configs[3] as written — ONE batch of --requests requests, split over the GPUs by shard_bounds "
                          "(64-aligned contiguous slabs); weak (default at one GPU): --requests requests PER GPU")
     ap.add_argument("--lds-budget", type=int, default=0)
+    ap.add_argument("--engine-flags", type=lambda x: int(x, 0), default=0, help="extra pwaf_options.flags for A/B runs (e.g. 2048 = PWAF_OPT_DENSE_VERDICT: the round-4 column file); same verdicts")
     ap.add_argument("--adversarial", action="store_true", help="time the adversarial variant of the stream as the HEADLINE batch (the tuning sample stays benign)")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the untuned and adversarial side runs (traffic_modes)")
     ap.add_argument("--no-config5", action="store_true", help="skip the short BASELINE configs[4] leg of the default run")
@@ -324,6 +325,8 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     opts = {"lds_table_budget": args.lds_budget} if args.lds_budget else {}
+    if args.engine_flags:
+        opts["flags"] = args.engine_flags
     eng = RuleEngine(wl.rules, wl.lists, wl.geoip, **opts)
     t_compile = time.time() - t0
     stats = eng.stats()

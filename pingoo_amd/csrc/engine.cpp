@@ -157,6 +157,7 @@ struct Scratch {
     View res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, gate_lists, attr;
+    DevBuf verdict_spill;     // the sparse column file's per-wave spill arrays (kernels.h: VerdictArgs::spill)
     DevBuf res_words;  // specialized residual program: [words][n] match bits per (request, rule)
     // What a batch needs ZEROED lives in one block (one memset per batch instead of four): the control words ([0] pool allocator, [1]
     // status word, then one length per list slot and one pair count per filtered pass), the candidate bitmaps of the filtered passes,
@@ -208,7 +209,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &ipres, &rec, &res_words, &pool, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &ipres, &rec, &res_words, &pool, &verdict_spill, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (PinBuf &b : arg_slot) b.release();
@@ -867,6 +868,16 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.n = n;
     v.n_groups = n_groups;
     v.force_global_tables = (P.flags & PWAF_OPT_GLOBAL_VERDICT_TABLES) ? 1u : 0u;
+    v.sparse_mode = (P.flags & PWAF_OPT_DENSE_VERDICT) ? 0u : (P.flags & PWAF_OPT_TINY_VERDICT_SLOTS) ? 2u : 1u;
+    if (v.sparse_mode) {
+        // the sparse column file: value slots per wave, and the per-wave spill array for a group that dirties more columns than that
+        const VerdictShape vs = verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size(), v.force_global_tables != 0, (int)v.sparse_mode, n_passes);
+        v.v_cap = vs.v_cap;
+        if (vs.v_cap < P.n_cols) {
+            if ((rc = S.verdict_spill.reserve((size_t)verdict_blocks_sp(vs, e->n_cus) * vs.waves * (P.n_cols - vs.v_cap) * 8))) return rc;
+            v.spill = (unsigned long long *)S.verdict_spill.p;
+        }
+    }
 #ifdef PWAF_PROFILING
     {
         static const uint32_t skip = getenv("PWAF_DEBUG_SKIP") ? (uint32_t)strtoul(getenv("PWAF_DEBUG_SKIP"), nullptr, 0) : 0u;
@@ -1810,7 +1821,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         UP(trig_off, trig_off)
         UP(trig_rules, trig_rules)
         UP(always_rules, always)
-        if (verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size()).waves == 0) {
+        if (verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size(), (P.flags & PWAF_OPT_GLOBAL_VERDICT_TABLES) != 0,
+                          (P.flags & PWAF_OPT_DENSE_VERDICT) ? 0 : (P.flags & PWAF_OPT_TINY_VERDICT_SLOTS) ? 2 : 1).waves == 0 || P.n_cols >= 65536u) {
             fail(PWAF_E_UNSUPPORTED, "too many distinct predicates for one LDS column file (160 KiB)");
             return dev_fail(PWAF_E_UNSUPPORTED);
         }

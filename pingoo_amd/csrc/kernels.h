@@ -336,6 +336,9 @@ struct VerdictArgs {
     uint32_t n, n_groups;
     uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
     uint32_t force_global_tables;  // PWAF_OPT_GLOBAL_VERDICT_TABLES: the verdict kernel variant for programs whose tables do not fit LDS (same results)
+    uint32_t sparse_mode;          // verdict_shape's mode: 0 dense column file, 1 sparse, 2 sparse with 8 value slots
+    uint32_t v_cap;                // sparse: value slots per wave in LDS
+    unsigned long long *spill;     // sparse, v_cap < n_cols: [workgroups x waves][n_cols - v_cap] words for the dirty columns beyond v_cap
     const uint32_t *off[PWAF_N_FIELDS];
     const uint8_t *ip;
     const uint8_t *ip_is_v6;
@@ -441,8 +444,11 @@ int launch_dir24(const VerdictArgs &a, void *out /* 2^24 x u32, or null: count o
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;
+    uint32_t sparse, v_cap, per_cu;  // the sparse column file (kernels.hip: verdict_kernel<.., SP>): value slots per wave, workgroups per CU
 };
 // force_global (PWAF_OPT_GLOBAL_VERDICT_TABLES): take the variant whose program tables stay in global memory even when they would fit LDS
-VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false);
+// mode: 0 = the dense column file (PWAF_OPT_DENSE_VERDICT), 1 = sparse, 2 = sparse with 8 value slots (the spill path's test hook)
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false, int mode = 1, uint32_t n_passes = 0);
+uint32_t verdict_blocks_sp(const VerdictShape &sh, uint32_t n_cus);
 
 }  // namespace pwaf

@@ -1983,6 +1983,22 @@ __host__ __device__ static inline uint32_t verdict_wave_lds(uint32_t n_cols, uin
     return ((n_cols * 8 + colw * 4 + rulew * 4 + n_rules * 2) + 15) & ~15u;  // columns, bitmaps, candidates (also: the list of non-zero columns)
 }
 
+// SPARSE column file (verdict_kernel<.., SP = true>): of a rule set's ~1000 - 4500 columns a group of 64 requests dirties a hundred or two,
+// yet the dense file costs 8 bytes per COLUMN and wave — 9 KiB of the 1k-rule set's 11.5 KiB per wave, which is what held the kernel at
+// one workgroup of 11 waves per CU (under 3 waves per SIMD; 57 % of its wave cycles waiting: VERDICT r4). The sparse file keeps, per 32
+// columns, the dirty bits and the number of dirty columns before the word (8 bytes), and one 64-bit value per DIRTY column, at the
+// column's rank among the dirty ones: ~4 KiB per wave whatever the rule set, i.e. two workgroups of 12 waves per CU. A group is marked
+// twice — bits first (the ranks need all of them), values second — and a value read is two dependent LDS reads instead of one. A group
+// with more dirty columns than the value array holds (v_cap) keeps the rest in a per-wave spill array in global memory (same results).
+__host__ __device__ static inline uint32_t verdict_wave_lds_sp(uint32_t n_cols, uint32_t n_rules, uint32_t v_cap) {
+    const uint32_t colw = (n_cols + 31) / 32, rulew = (n_rules + 31) / 32;
+    return ((colw * 8 + v_cap * 8 + rulew * 4 + n_rules * 2) + 15) & ~15u;  // {dirty bits, rank} per 32 columns, values, rule bitmap, candidates
+}
+__host__ __device__ static inline uint32_t verdict_v_cap(uint32_t n_cols, bool tiny) {
+    const uint32_t v = tiny ? 8u : 256u + n_cols / 16u;
+    return v < n_cols ? v : n_cols;
+}
+
 // LDS-resident copies of the small read-mostly program tables (LT = true): trigger lists, rule headers and DNF literals are
 // gathered several times per 64-request group, and each gather from L2 is a ~1 us round trip that the few waves a CU can hold
 // (the column files fill LDS) cannot hide.
@@ -2002,8 +2018,8 @@ __host__ __device__ static inline VerdictTables verdict_tables(uint32_t n_cols, 
 }
 
 // BR = 64-pass bitmap registers (1: up to 64 passes, else kMaxPasses)
-template <bool LT, int BR>
-__global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
+template <bool LT, int BR, bool SP>
+__global__ __launch_bounds__(SP ? 768 : 1024, (SP && BR == 1) ? 6 : 1) void verdict_kernel(VerdictArgs a) {  // (sparse, up to 64 passes: 6 waves per SIMD = two 12-wave workgroups per CU)
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = wave_index(), lane = tid & 63, n_waves = blockDim.x >> 6;
 #ifdef PWAF_PROFILING
@@ -2012,11 +2028,16 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
     constexpr uint32_t dbg_skip = 0;
 #endif
     const uint32_t colw = (a.n_cols + 31) / 32, rulew = (a.n_rules + 31) / 32;
-    const uint32_t wave_bytes = verdict_wave_lds(a.n_cols, a.n_rules);
+    const uint32_t v_cap = a.v_cap;  // (SP) values held in LDS; dirty columns of higher rank: the wave's spill array
+    const uint32_t wave_bytes = SP ? verdict_wave_lds_sp(a.n_cols, a.n_rules, v_cap) : verdict_wave_lds(a.n_cols, a.n_rules);
     unsigned char *mine = lds + (size_t)wave * wave_bytes;
+    // dense: col[n_cols] | colnz[colw]; sparse: nz[colw] = {dirty bits, dirty columns before the word} | vals[v_cap]
     unsigned long long *col = reinterpret_cast<unsigned long long *>(mine);
     uint32_t *colnz = reinterpret_cast<uint32_t *>(col + a.n_cols);
-    uint32_t *rulebm = colnz + colw;
+    uint32_t *nz = reinterpret_cast<uint32_t *>(mine);
+    unsigned long long *vals = reinterpret_cast<unsigned long long *>(mine + (size_t)colw * 8);
+    unsigned long long *spill = (SP && a.spill != nullptr) ? a.spill + (size_t)(blockIdx.x * n_waves + wave) * (a.n_cols - v_cap) : nullptr;
+    uint32_t *rulebm = SP ? reinterpret_cast<uint32_t *>(vals + v_cap) : colnz + colw;
     uint16_t *cand = reinterpret_cast<uint16_t *>(rulebm + rulew);
     unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
     const VerdictTables vt = verdict_tables(a.n_cols, a.n_rules, a.n_trig, a.n_lits, LT);
@@ -2042,12 +2063,6 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
     // group-invariant, fetched once per wave: this lane's word of the always-candidate bitmap
     const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
-
-    // a lane marks "atom c holds for my request": its bit in the column word, and the column in the non-zero bitmap
-    auto set_col = [&](uint32_t c) {
-        atomicOr(&col[c], mybit);
-        atomicOr(&colnz[c >> 5], 1u << (c & 31));
-    };
 
     // A group's inputs — the hit records of up to kPre passes, the captcha flag, the attribute kernel's pair count and first 64
     // pairs — are requested ONE GROUP AHEAD: with ~9 waves per CU nothing else hides the ~2 us those first-touch loads take.
@@ -2127,8 +2142,10 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];  // (the buffer is padded: reading past the group's count is harmless)
         in.res0 = (a.res_words && valid) ? a.res_match[i] : 0u;
     };
-    for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;  // the column file starts clean; afterwards groups clean up after themselves
-    for (uint32_t k = lane; k < colw; k += 64) colnz[k] = 0;
+    if (!SP) {
+        for (uint32_t k = lane; k < a.n_cols; k += 64) col[k] = 0;  // the column file starts clean; afterwards groups clean up after themselves
+        for (uint32_t k = lane; k < colw; k += 64) colnz[k] = 0;
+    }
     const uint32_t g_stride = gridDim.x * n_waves;
     Inputs cur;
     Bits b_nxt;
@@ -2149,105 +2166,158 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
 
         // 1. clear the column file and the bitmaps; column 0 is the constant TRUE; rules that can match with every column
         //    zero (a term made of negations only) are always candidates
-        //    (only the columns the previous group dirtied are cleared: the non-zero bitmap names them)
-        for (uint32_t wv = lane; wv < colw; wv += 64) {
-            uint32_t nz = colnz[wv];
-            colnz[wv] = wv == 0 ? 1u : 0u;
-            while (nz) {
-                col[wv * 32 + (uint32_t)__builtin_ctz(nz)] = 0;
-                nz &= nz - 1;
+        //    (dense: only the columns the previous group dirtied are cleared — the non-zero bitmap names them; sparse: the dirty bits)
+        if (!SP) {
+            for (uint32_t wv = lane; wv < colw; wv += 64) {
+                uint32_t nzw = colnz[wv];
+                colnz[wv] = wv == 0 ? 1u : 0u;
+                while (nzw) {
+                    col[wv * 32 + (uint32_t)__builtin_ctz(nzw)] = 0;
+                    nzw &= nzw - 1;
+                }
             }
+        } else {
+            for (uint32_t wv = lane; wv < colw; wv += 64) nz[2 * wv] = wv == 0 ? 1u : 0u;
         }
         for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = k < 64 ? h_always : a.always_rules[k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) col[0] = ~0ull;
+        if (!SP && lane == 0) col[0] = ~0ull;
 
         const uint32_t flags = cur.flags;
         const uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
         const uint32_t n_pairs = cur.n_pairs;
         const uint4 pair0 = cur.pair0;
+        const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
 
-        // 2. scan results: each lane marks the columns its hit records name
-        auto mark_hits = [&](const uint32_t rv, const uint32_t base) {
-            if (__ballot(rv != 0) == 0) return;  // nobody in the group matched anything in this pass
-            if (rv & REC_OVERFLOW) {
-                for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
-                    const PoolEntry pe = a.pool[k];
-                    set_col(base + pe.atom);
-                    k = pe.next;
+        // Where column c's 64-request word lives. Dense: the column file. Sparse: at the column's rank among the group's dirty columns
+        // (in LDS below v_cap, in the wave's spill array beyond) — valid once the ranks are known (phase 1).
+        auto slot_of = [&](const uint32_t c) {
+            const uint32_t w = c >> 5, bits = nz[2 * w], before = nz[2 * w + 1];
+            return before + (uint32_t)__builtin_popcount(bits & ((1u << (c & 31u)) - 1u));
+        };
+        auto word_at = [&](const uint32_t slot) -> unsigned long long * { return slot < v_cap ? vals + slot : spill + (slot - v_cap); };
+        // PHASE 0 (sparse only): dirty bits. PHASE 1 (sparse): values. PHASE 2: the dense file, bits and values at once.
+        auto mark_all = [&](auto phase_tag) {
+            constexpr int PH = decltype(phase_tag)::value;
+            auto put = [&](const uint32_t c, const unsigned long long m) {  // (one lane speaks for column c)
+                if (PH == 0) atomicOr(&nz[2 * (c >> 5)], 1u << (c & 31u));
+                else if (PH == 1) atomicOr(word_at(slot_of(c)), m);
+                else {
+                    atomicOr(&col[c], m);
+                    atomicOr(&colnz[c >> 5], 1u << (c & 31));
+                }
+            };
+            // 2. scan results: each lane marks the columns its hit records name
+            auto mark_hits = [&](const uint32_t rv, const uint32_t base) {
+                if (__ballot(rv != 0) == 0) return;  // nobody in the group matched anything in this pass
+                if (rv & REC_OVERFLOW) {
+                    for (uint32_t k = rv & ~REC_OVERFLOW; k != kNone;) {
+                        const PoolEntry pe = a.pool[k];
+                        put(base + pe.atom, mybit);
+                        k = pe.next;
+                    }
+                }
+                // inline atoms: lanes that name the SAME atom (frequent atoms such as a browser User-Agent prefix are named by
+                // most of the 64 requests) are folded into one column update instead of 64 serialised LDS atomics
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const uint32_t x = (rv & REC_OVERFLOW) ? 0u : (half == 0 ? rv & 0x7FFFu : (rv >> 15) & 0x7FFFu);
+                    unsigned long long todo = __ballot(x != 0);
+                    while (todo) {
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                        const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)__builtin_amdgcn_readfirstlane(leader));
+                        const unsigned long long same = __ballot(x == xa);
+                        todo &= ~same;
+                        if (lane == leader) put(base + xa - 1, same);
+                    }
+                }
+            };
+            if (!(dbg_skip & 1u)) {
+#pragma unroll
+                for (int q = 0; q < kPre; q++) {
+                    if (cur.base[q] == kNone) break;
+                    mark_hits(cur.rv[q], cur.base[q]);
+                }
+                // more than kPre non-empty passes in this group (many dense passes, or a burst of candidates): fetched here
+#pragma unroll
+                for (int r = 0; r < kBitRegs; r++) {
+                    unsigned long long m = cur.rest[r];
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t ps = (uint32_t)r * 64 + (uint32_t)l;
+                        const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cur.bits.w[r] >> 32), l) << 32) |
+                                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.bits.w[r], l);
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
+                        mark_hits((valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u, base);
+                    }
                 }
             }
-            // inline atoms: lanes that name the SAME atom (frequent atoms such as a browser User-Agent prefix are named by
-            // most of the 64 requests) are folded into one column update instead of 64 serialised LDS atomics
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const uint32_t x = (rv & REC_OVERFLOW) ? 0u : (half == 0 ? rv & 0x7FFFu : (rv >> 15) & 0x7FFFu);
-                unsigned long long todo = __ballot(x != 0);
-                while (todo) {
-                    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-                    const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)__builtin_amdgcn_readfirstlane(leader));
-                    const unsigned long long same = __ballot(x == xa);
-                    todo &= ~same;
-                    if (lane == leader) {
-                        const uint32_t c = base + xa - 1;
-                        atomicOr(&col[c], same);
-                        atomicOr(&colnz[c >> 5], 1u << (c & 31));
+            // 2b. residual rules evaluated by their specialized program: one result word per request and 32 rules, transposed here into the
+            //     rules' column words (a ballot per rule that matched anybody in the group)
+            for (uint32_t w = 0; w < a.res_words; w++) {
+                const uint32_t mw = w == 0 ? cur.res0 : (valid ? a.res_match[(size_t)w * a.n + i] : 0u);
+                if (__ballot(mw != 0u) == 0ull) continue;
+                uint32_t any = mw;
+                for (uint32_t d = 1; d < 64u; d <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)d, 64);
+                any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+                for (; any; any &= any - 1u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(any);
+                    const unsigned long long who = __ballot(((mw >> k) & 1u) != 0u);
+                    if (lane == 0) put(a.res_base + 32u * w + k, who);
+                }
+            }
+            // 3. everything that is not a string scan (memberships, comparisons) arrives from the attribute kernel as ready-made
+            //    column words: one lane per pair (one pair per atom and group, and no scan pass owns these columns: a plain store)
+            if (!(dbg_skip & 2u)) {
+                for (uint32_t p = lane; p < n_pairs; p += 64) {
+                    const uint4 pr = p < 64 ? pair0 : pairs[p];
+                    const unsigned long long v = ((unsigned long long)pr.w << 32) | pr.z;
+                    if (PH == 0) atomicOr(&nz[2 * (pr.x >> 5)], 1u << (pr.x & 31u));
+                    else if (PH == 1) {
+                        const uint32_t sl = slot_of(pr.x);
+                        if (sl < v_cap) vals[sl] = v;
+                        else atomicOr(spill + (sl - v_cap), v);
+                    }
+                    else {
+                        col[pr.x] = v;
+                        atomicOr(&colnz[pr.x >> 5], 1u << (pr.x & 31));
                     }
                 }
             }
         };
-        if (!(dbg_skip & 1u)) {
-#pragma unroll
-            for (int q = 0; q < kPre; q++) {
-                if (cur.base[q] == kNone) break;
-                mark_hits(cur.rv[q], cur.base[q]);
+        uint32_t n_dirty = 0;  // (sparse) dirty columns of the group
+        if (SP) {
+            mark_all(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // the ranks: dirty columns before each word (the prefix sum also lists the dirty columns for step 4)
+            for (uint32_t wb = 0; wb < colw; wb += 64) {
+                const uint32_t bits = wb + lane < colw ? nz[2 * (wb + lane)] : 0u;
+                const uint32_t pc = (uint32_t)__builtin_popcount(bits), incl = wave_scan_add(pc);
+                if (wb + lane < colw) nz[2 * (wb + lane) + 1] = n_dirty + incl - pc;
+                n_dirty += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
-            // more than kPre non-empty passes in this group (many dense passes, or a burst of candidates): fetched here
-#pragma unroll
-            for (int r = 0; r < kBitRegs; r++) {
-                unsigned long long m = cur.rest[r];
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t ps = (uint32_t)r * 64 + (uint32_t)l;
-                    const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cur.bits.w[r] >> 32), l) << 32) |
-                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.bits.w[r], l);
-                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
-                    mark_hits((valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u, base);
-                }
+            // (column 0 = TRUE is dirty by construction and ranks first; a spilled word is reset with a read-modify-write, like everything
+            // that touches it afterwards: performed at L2 in order — a plain store could still be on its way when the first OR arrives)
+            for (uint32_t k = lane; k < n_dirty; k += 64) {
+                if (k < v_cap) vals[k] = k == 0 ? ~0ull : 0ull;
+                else atomicExch(spill + (k - v_cap), 0ull);
             }
-        }
-
-        // 2b. residual rules evaluated by their specialized program: one result word per request and 32 rules, transposed here into the
-        //     rules' column words (a ballot per rule that matched anybody in the group)
-        for (uint32_t w = 0; w < a.res_words; w++) {
-            const uint32_t mw = w == 0 ? cur.res0 : (valid ? a.res_match[(size_t)w * a.n + i] : 0u);
-            if (__ballot(mw != 0u) == 0ull) continue;
-            uint32_t any = mw;
-            for (uint32_t d = 1; d < 64u; d <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)d, 64);
-            any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
-            for (; any; any &= any - 1u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(any);
-                const unsigned long long who = __ballot(((mw >> k) & 1u) != 0u);
-                if (lane == 0) {
-                    const uint32_t c = a.res_base + 32u * w + k;
-                    atomicOr(&col[c], who);
-                    atomicOr(&colnz[c >> 5], 1u << (c & 31));
-                }
-            }
-        }
-
-        // 3. everything that is not a string scan (memberships, comparisons) arrives from the attribute kernel as ready-made
-        //    column words: one lane per pair, a plain LDS store each
-        const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
-        if (!(dbg_skip & 2u)) {
-            for (uint32_t p = lane; p < n_pairs; p += 64) {
-                const uint4 pr = p < 64 ? pair0 : pairs[p];
-                col[pr.x] = ((unsigned long long)pr.w << 32) | pr.z;  // (one pair per atom and group, and no scan pass owns these columns: a plain store)
-                atomicOr(&colnz[pr.x >> 5], 1u << (pr.x & 31));
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            mark_all(std::integral_constant<int, 1>{});
+        } else {
+            mark_all(std::integral_constant<int, 2>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the bitmap of non-zero columns (dense: colnz; sparse: the bit words of nz) and a column's word, for the steps below
+        auto nz_bits = [&](const uint32_t wv) { return SP ? nz[2 * wv] : colnz[wv]; };
+        auto col_word = [&](const uint32_t c) -> unsigned long long {
+            if (!SP) return col[c];
+            const uint32_t w = c >> 5, bits = nz[2 * w], before = nz[2 * w + 1];
+            if (!((bits >> (c & 31u)) & 1u)) return 0ull;
+            const uint32_t sl = before + (uint32_t)__builtin_popcount(bits & ((1u << (c & 31u)) - 1u));
+            return sl < v_cap ? vals[sl] : __hip_atomic_load(spill + (sl - v_cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a spilled word: from L2, where the ORs were performed)
+        };
 
         // 4. candidate rules: a rule can only match some request of this group if one of its terms has a non-zero positive
         //    column (trigger lists, one chosen literal per term) or consists of negations only (always_rules).
@@ -2258,13 +2328,13 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
         if (!(dbg_skip & 8u)) {
             uint32_t n_nz = 0;
             for (uint32_t wb = 0; wb < colw; wb += 64) {
-                uint32_t nz = wb + lane < colw ? colnz[wb + lane] : 0u;
-                const uint32_t pc = (uint32_t)__builtin_popcount(nz), incl = wave_scan_add(pc);
+                uint32_t nzv = wb + lane < colw ? nz_bits(wb + lane) : 0u;
+                const uint32_t pc = (uint32_t)__builtin_popcount(nzv), incl = wave_scan_add(pc);
                 uint32_t pos = n_nz + incl - pc;
-                while (nz) {
-                    if (pos < a.n_rules) cand[pos] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(nz));  // (a column file fits LDS: n_cols < 20480)
+                while (nzv) {
+                    if (pos < a.n_rules) cand[pos] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(nzv));  // (n_cols < 65536: launch_verdict)
                     pos++;
-                    nz &= nz - 1;
+                    nzv &= nzv - 1;
                 }
                 n_nz += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
@@ -2280,10 +2350,10 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                 }
             } else {  // (more non-zero columns than the list holds: word by word)
                 for (uint32_t wv = lane; wv < colw; wv += 64) {
-                    uint32_t nz = colnz[wv];
-                    while (nz) {
-                        const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nz);
-                        nz &= nz - 1;
+                    uint32_t nzv = nz_bits(wv);
+                    while (nzv) {
+                        const uint32_t c = wv * 32 + (uint32_t)__builtin_ctz(nzv);
+                        nzv &= nzv - 1;
                         const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
                         for (uint32_t k = kb; k < ke; k++) {
                             const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
@@ -2341,7 +2411,7 @@ __global__ __launch_bounds__(1024) void verdict_kernel(VerdictArgs a) {
                     for (int q = 0; q < 4; q++) lit[q] = k + q < lit_off + lit_cnt ? (LT ? l_lits[k + q] : a.lits[k + q]) : 0u;
                     unsigned long long cw[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) cw[q] = col[lit[q] & LIT_ATOM_MASK];
+                    for (int q = 0; q < 4; q++) cw[q] = col_word(lit[q] & LIT_ATOM_MASK);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         acc_and &= (lit[q] & LIT_NEG) ? ~cw[q] : cw[q];
@@ -2876,23 +2946,50 @@ int launch_attr(const VerdictArgs &a, void *stream) {
 // Workgroup shape of the verdict kernel: as many waves as LDS (160 KiB) holds column files for, next to one copy of the program
 // tables; if the tables do not leave room for at least 4 column files they stay in global memory (LT = false).
 static constexpr uint32_t kLdsPerGroup = 160u * 1024u;
-VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global) {
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global, int mode, uint32_t n_passes) {
     VerdictShape s{};
-    const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
     const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
+    if (mode != 0) {
+        // SPARSE column file (mode 1; 2 = the test hook with 8 value slots): as many workgroups of 12 waves per CU as LDS holds (two for
+        // the 1k-rule set: 6 waves per SIMD), program tables in LDS when one such workgroup still fits beside them
+        s.sparse = 1;
+        s.v_cap = verdict_v_cap(n_cols, mode == 2);
+        const uint32_t wave = verdict_wave_lds_sp(n_cols, n_rules, s.v_cap);
+        const bool fits = !force_global && n_trig < 65536 && t_lds + 8 * wave <= kLdsPerGroup;
+        s.lds_tables = fits ? 1 : 0;
+        const uint32_t tables = fits ? t_lds : t_glb;
+        // (registers: the variant for up to 64 passes is compiled for 6 waves per SIMD = 24 per CU, the general one takes 124 -> 16 per CU)
+        const uint32_t cu_waves = n_passes <= 64 ? 24u : 16u;
+        uint32_t best_w = 0, best_k = 1;
+        for (uint32_t k = 1; k <= 3; k++) {  // k workgroups per CU
+            const uint32_t share = kLdsPerGroup / k;
+            if (share <= tables + wave) continue;
+            const uint32_t w = std::min(std::min(12u, cu_waves / k), (share - tables) / wave);
+            if (w * k > best_w * best_k) { best_w = w; best_k = k; }
+        }
+        s.waves = best_w;
+        s.per_cu = best_k;
+        s.lds_bytes = tables + s.waves * wave;
+        return s;
+    }
+    const uint32_t wave = verdict_wave_lds(n_cols, n_rules);
     const bool fits = !force_global && n_trig < 65536 && t_lds + 4 * wave <= kLdsPerGroup;
     s.lds_tables = fits ? 1 : 0;
     const uint32_t tables = fits ? t_lds : t_glb;
     uint32_t w = tables + wave <= kLdsPerGroup ? (kLdsPerGroup - tables) / wave : 0;
     if (!fits) w = std::min(w, 4u);  // small workgroups: several share a CU
     s.waves = std::min(w, 16u);
+    s.per_cu = 1;
     s.lds_bytes = tables + s.waves * wave;
     return s;
 }
 
+uint32_t verdict_blocks_sp(const VerdictShape &sh, uint32_t n_cus) { return std::max(1u, n_cus) * sh.per_cu; }  // the sparse kernel's persistent grid (sizes the spill array)
+
 int launch_verdict(const VerdictArgs &a, void *stream) {
-    VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0);
-    if (sh.waves == 0) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
+    VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0, (int)a.sparse_mode, a.n_passes);
+    if (sh.waves == 0 || a.n_cols >= 65536u) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
+    if (sh.sparse && (a.v_cap != sh.v_cap || (sh.v_cap < a.n_cols && a.spill == nullptr))) return (int)hipErrorInvalidValue;
 #ifdef PWAF_PROFILING
     static const uint32_t cap_waves = getenv("PWAF_VERDICT_WAVES") ? (uint32_t)atoi(getenv("PWAF_VERDICT_WAVES")) : 0u;  // timing experiment: fewer waves per CU (same results)
     if (cap_waves && cap_waves < sh.waves) sh.waves = cap_waves;
@@ -2903,9 +3000,11 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
     static const int forced_variant = getenv("PWAF_VERDICT_VARIANT") ? atoi(getenv("PWAF_VERDICT_VARIANT")) : -1;  // a MORE general variant may be forced (same results)
     if (forced_variant >= 0 && forced_variant < variant) variant = forced_variant;
 #endif
-    const void *fns[2][2] = {{reinterpret_cast<const void *>(verdict_kernel<false, kBRmax>), reinterpret_cast<const void *>(verdict_kernel<false, 1>)},
-                             {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax>), reinterpret_cast<const void *>(verdict_kernel<true, 1>)}};
-    const void *fn = fns[sh.lds_tables ? 1 : 0][variant];
+    const void *fns[2][2][2] = {{{reinterpret_cast<const void *>(verdict_kernel<false, kBRmax, false>), reinterpret_cast<const void *>(verdict_kernel<false, 1, false>)},
+                                 {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax, false>), reinterpret_cast<const void *>(verdict_kernel<true, 1, false>)}},
+                                {{reinterpret_cast<const void *>(verdict_kernel<false, kBRmax, true>), reinterpret_cast<const void *>(verdict_kernel<false, 1, true>)},
+                                 {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax, true>), reinterpret_cast<const void *>(verdict_kernel<true, 1, true>)}}};
+    const void *fn = fns[sh.sparse ? 1 : 0][sh.lds_tables ? 1 : 0][variant];
     uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
 #ifdef PWAF_PROFILING
     static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;
@@ -2914,7 +3013,7 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
 #endif
     // with LDS tables a workgroup fills a CU: one persistent workgroup per CU (measured: 0.331 ms vs 0.346 at 4 per CU — every
     // workgroup stages 25 KiB of tables and clears its column files once); small workgroups: a few rounds per CU
-    const uint32_t cap = forced_cap ? forced_cap : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
+    const uint32_t cap = forced_cap ? forced_cap : sh.sparse ? verdict_blocks_sp(sh, a.attr_blocks) : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return 0;
     void *args[] = {const_cast<VerdictArgs *>(&a)};
@@ -2932,8 +3031,10 @@ int configure_kernels(int device) {
     const void *fns[] = {reinterpret_cast<const void *>(scan_kernel<1, false>), reinterpret_cast<const void *>(scan_kernel<2, false>),
                          reinterpret_cast<const void *>(scan_kernel<4, false>), reinterpret_cast<const void *>(scan_kernel<1, true>),
                          reinterpret_cast<const void *>(scan_kernel<2, true>), reinterpret_cast<const void *>(scan_kernel<4, true>),
-                         reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64>),
-                         reinterpret_cast<const void *>(verdict_kernel<true, 1>), reinterpret_cast<const void *>(verdict_kernel<false, 1>),
+                         reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64, false>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64, false>),
+                         reinterpret_cast<const void *>(verdict_kernel<true, 1, false>), reinterpret_cast<const void *>(verdict_kernel<false, 1, false>),
+                         reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64, true>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64, true>),
+                         reinterpret_cast<const void *>(verdict_kernel<true, 1, true>), reinterpret_cast<const void *>(verdict_kernel<false, 1, true>),
                          reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
                          lscan_fn(false), lscan_fn(true)};
     for (const void *fn : fns) {

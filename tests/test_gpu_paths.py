@@ -462,3 +462,38 @@ def test_host_batches_small_and_large_pageable_and_page_locked():
             batch.unpin()
             pv.free()
     eng.close()
+
+
+def test_verdict_sparse_column_file_dense_and_spill_agree():
+    """The verdict kernel's SPARSE column file (round 5: value slots per DIRTY column instead of 8 bytes per column and wave) against the
+    round-4 dense file (PWAF_OPT_DENSE_VERDICT) and with 8 value slots per wave (PWAF_OPT_TINY_VERDICT_SLOTS: every group spills its
+    dirty columns beyond the eighth into global memory) — the 1k-rule set on benign, hostile and UTF-8 traffic, a rule set where most
+    requests hit many atoms at once (overflowing hit records), and the oracle on a prefix."""
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    engines = {name: RuleEngine(w.rules, w.lists, w.geoip, flags=fl) for name, fl in (("sparse", 0), ("dense", _abi.OPT_DENSE_VERDICT), ("tiny", _abi.OPT_TINY_VERDICT_SLOTS))}
+    orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
+    for label, kw in (("benign", {}), ("hostile", {"adversarial": True}), ("utf8", {"utf8": True})):
+        batch = w.batch(300_000, 200_000, **kw)
+        got = {name: e.evaluate_batch(batch, with_counts=True) for name, e in engines.items()}
+        for name in ("dense", "tiny"):
+            H.assert_verdicts_equal(got[name][0], got["sparse"][0], batch, f"{label}: {name} vs sparse column file")
+            assert got[name][1].tolist() == got["sparse"][1].tolist()
+        pre = batch.slice(0, 6000)
+        H.assert_verdicts_equal(got["sparse"][0][:6000], orc.evaluate(pre, threads=16), pre, f"{label}: sparse vs oracle")
+    for e in engines.values():
+        e.close()
+    # many atoms per request, many distinct dirty columns per group
+    rng = random.Random(77)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(3)) for _ in range(300)]
+    rules = [(f"r{k}", f'http_request.url.contains("{wd}") && http_request.path.contains("{words[(k * 7) % 300]}")', [B if k % 3 else CAP]) for k, wd in enumerate(words)]
+    reqs = [Request(url="/" + "".join(rng.choice(words) for _ in range(rng.randint(0, 40))), path="/" + "".join(rng.choice(words) for _ in range(rng.randint(0, 12))), host="h",
+                    captcha_verified=rng.random() < 0.3) for _ in range(20_000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch, threads=16)
+    for fl in (0, _abi.OPT_DENSE_VERDICT, _abi.OPT_TINY_VERDICT_SLOTS):
+        e = RuleEngine(rules, flags=fl)
+        H.assert_verdicts_equal(e.evaluate_batch(batch), want, batch, f"many atoms per request, flags {fl}")
+        e.close()
+    assert len(set(want["action"].tolist())) >= 2

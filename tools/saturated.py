@@ -42,11 +42,11 @@ def _tokens(wl, tables, field):
     cands = set()
     for lit in lits:
         if len(lit) >= 5:
-            cands.update((lit[:-1], lit[1:], lit[1:-1]))
-    cands = sorted(c for c in cands if len(c) >= 4)
+            cands.update((lit[:-1], lit[1:-1]))  # (not lit[1:]: behind the separator it may spell the literal again)
+    cands = sorted(c for c in cands if len(c) >= 4 and not any(l in c for l in lits))
     passes = [g for g in tables.groups if g["field"] == field and "f_table" in g]
     if not cands or not passes:
-        return []
+        return [], sorted(lits)
     g = passes[0]
     sep = SEP[field]
     blob = sep.join(cands) + sep
@@ -56,7 +56,7 @@ def _tokens(wl, tables, field):
     csum = np.concatenate([[0], np.cumsum(h)])
     o = np.minimum(off, len(h))
     keep = (csum[o[1:]] - csum[o[:-1]]) > 0
-    return [c for c, k in zip(cands, keep) if k]
+    return [c for c, k in zip(cands, keep) if k], sorted(lits)
 
 
 def saturated_batch(wl, program, n, block=1 << 19, seed=0x5A7):
@@ -70,7 +70,7 @@ def saturated_batch(wl, program, n, block=1 << 19, seed=0x5A7):
     data, offs = list(base.data), list(base.offsets)
     info = {}
     for field in (1, 2, 4):
-        toks = _tokens(wl, tables, field)
+        toks, lits = _tokens(wl, tables, field) or ([], [])
         if not toks:
             continue
         sep, cap = SEP[field], CAPS[field]
@@ -80,6 +80,12 @@ def saturated_batch(wl, program, n, block=1 << 19, seed=0x5A7):
             while len(s) < cap:
                 s += toks[int(rng.integers(len(toks)))] + sep
             s = s[:cap].rstrip(b"/") if field == 2 else s[:cap]
+            for _ in range(8):  # near misses only: a value in which two tokens happen to spell a rule literal is redrawn piece by piece
+                bad = [l for l in lits if l in s]
+                if not bad:
+                    break
+                for l in bad:
+                    s = s.replace(l, l[:-1] + sep)[:cap]
             pool.append(s)
         pick = rng.integers(len(pool), size=block)
         lens = np.array([len(p) for p in pool], dtype=np.int64)[pick]
