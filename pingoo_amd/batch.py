@@ -151,6 +151,25 @@ class RequestBatch:
         return RequestBatch(datas, offs, self.ip[lo:hi], self.ip_is_v6[lo:hi], self.port[lo:hi], self.flags[lo:hi],
                             None if self.asn is None else self.asn[lo:hi], None if self.country is None else self.country[lo:hi], headers)
 
+    def take(self, idx) -> "RequestBatch":
+        """The requests at the (ascending or not) indices `idx` as an independent batch (test helper: a random sample of a large batch)."""
+        idx = np.asarray(idx, dtype=np.int64)
+
+        def gather(d, o):
+            o64 = o.astype(np.int64)
+            lens = o64[idx + 1] - o64[idx]
+            no = np.zeros(len(idx) + 1, dtype=np.uint32)
+            no[1:] = np.cumsum(lens).astype(np.uint32)
+            src = np.repeat(o64[idx] - no[:-1].astype(np.int64), lens) + np.arange(int(no[-1]), dtype=np.int64)
+            nd = np.zeros(int(no[-1]) + _abi.ARENA_PAD, dtype=np.uint8)
+            nd[: int(no[-1])] = d[src]
+            return nd, no
+
+        cols = [gather(d, o) for d, o in zip(self.data, self.offsets)]
+        headers = {name: gather(d, o) for name, (d, o) in self.headers.items()}
+        return RequestBatch([c[0] for c in cols], [c[1] for c in cols], self.ip[idx], self.ip_is_v6[idx], self.port[idx], self.flags[idx],
+                            None if self.asn is None else self.asn[idx], None if self.country is None else self.country[idx], headers)
+
     def tile(self, times: int) -> "RequestBatch":
         """The batch repeated `times` times (test / bench helper for very large uniform batches)."""
         datas, offs = [], []

@@ -404,7 +404,10 @@ PWAF_HD bool map_has(const Machine &m, const Val &mp, const Val &key, Val *out) 
     return false;
 }
 
-PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
+// (SCALAR is a template argument so that the walk of a table that reads BYTES keeps the loop — and the registers — it had: the
+// specialized program names the mode of each pattern at translation time, residual_jit.cpp)
+template <bool SCALAR>
+PWAF_HD_STR bool regex_match_t(const Machine &m, uint32_t id, const Val &s) {
     // Table entries (residual.cpp): next state | 0x8000 when entering it decides the match | 0x4000 when it is dead (nothing the rest
     // of the string holds can make the pattern match: an anchored pattern that has failed) — one table load per byte.
     // SCALAR MODE (a class beyond ASCII in the pattern: the regex crate matches scalar values, Cargo.lock:1694-1700): a byte below 0x80
@@ -415,7 +418,7 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
     const RegexDesc &d = section<RegexDesc>(m, m.h->regexes)[id];
     const uint16_t *trans = section<uint16_t>(m, d.trans);
     const uint8_t *cm = m.blob + d.classmap, *fl = m.blob + d.flags;
-    const uint8_t *um = d.umap ? m.blob + d.umap : nullptr;
+    const uint8_t *um = SCALAR ? m.blob + d.umap : nullptr;
     const uint32_t nc = d.n_classes;
     uint32_t st = 0;
     if (fl[0] & 1u) return true;
@@ -435,7 +438,7 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
             for (uint32_t j = 0; j < take; j++, w >>= 8) {
                 const uint32_t b = (uint32_t)w & 0xFFu;
                 uint32_t cls = cm[b];
-                if (um != nullptr && (b >= 0x80u || pend != 0u)) {
+                if (SCALAR && (b >= 0x80u || pend != 0u)) {
                     if (pend != 0u) {
                         if ((b & 0xC0u) == 0x80u) {  // the open sequence goes on
                             cp = (cp << 6) | (b & 0x3Fu);
@@ -466,12 +469,22 @@ PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
             }
         }
     }
-    if (pend != 0u) {  // the string ends inside a sequence: its lead byte was ill-formed
+    if (SCALAR && pend != 0u) {  // the string ends inside a sequence: its lead byte was ill-formed
         const uint32_t e0 = trans[st * nc + d.ill_class];
         if (e0 & 0x8000u) return true;
         st = e0 & 0x3FFFu;
     }
     return (fl[st] & 2u) != 0;
+}
+
+PWAF_HD_STR bool regex_match(const Machine &m, uint32_t id, const Val &s) {
+    return section<RegexDesc>(m, m.h->regexes)[id].umap ? regex_match_t<true>(m, id, s) : regex_match_t<false>(m, id, s);
+}
+// recv.matches(<literal pattern>) with the table's mode known (what op_call's FN_MATCHES case does, for the specialized program)
+template <bool SCALAR>
+PWAF_HD Val op_matches(const Machine &m, uint32_t aux, const Val &recv, const Val &arg) {
+    if (recv.t == T_ERR || arg.t == T_ERR || recv.t != T_STR || arg.t != T_STR || aux == 0xFFFu) return mk(T_ERR);  // (an invalid pattern is an execution error)
+    return mk_bool(regex_match_t<SCALAR>(m, aux, recv));
 }
 
 PWAF_HD Val arith(uint32_t op /* B_ADD.. */, const Val &l, const Val &r, Machine &m);

@@ -151,7 +151,13 @@ bool translate_rule(const Header &h, const uint8_t *blob, uint32_t rule, std::st
             case R_CALL: {
                 const uint32_t argc = in.b >> 12, aux = in.b & 0xFFFu;
                 const std::string recv = slot(d - 1 - (int)argc);
-                s += "    " + recv + " = op_call(m, " + u32(in.a) + ", " + u32(argc) + ", " + u32(aux) + ", " + recv + ", " + (argc ? slot(d - 1) : recv) + ");\n";
+                if (in.a == FN_MATCHES && argc == 1 && aux != 0xFFFu) {
+                    // the pattern's table reads bytes or scalar values (dfa.cpp): known now, so the walk is compiled for exactly that
+                    const RegexDesc &rd = reinterpret_cast<const RegexDesc *>(blob + h.regexes)[aux];
+                    s += "    " + recv + " = op_matches<" + (rd.umap ? "true" : "false") + ">(m, " + u32(aux) + ", " + recv + ", " + slot(d - 1) + ");\n";
+                } else {
+                    s += "    " + recv + " = op_call(m, " + u32(in.a) + ", " + u32(argc) + ", " + u32(aux) + ", " + recv + ", " + (argc ? slot(d - 1) : recv) + ");\n";
+                }
                 d -= (int)argc;
                 break;
             }

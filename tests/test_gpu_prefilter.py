@@ -1,5 +1,6 @@
 """The bigram prefilter on the device: filter_kernel + compact_kernel + list-driven DFA passes, through the C ABI, against the CPU
 oracle. The filter may only change WHICH requests a pass walks, never a verdict."""
+import os
 import random
 
 import numpy as np
@@ -329,14 +330,14 @@ def test_every_request_a_candidate_at_one_million():
 def test_config3_adversarial_stream_tuned_on_benign_vs_oracle():
     """BASELINE.json configs[2] rule set (1024 rules, 200 regex, CIDR lists, GeoIP) on its HOSTILE stream (near misses of the rule
     literals, maximum-length fields): the engine is tuned on benign traffic — the attacker picks the traffic, not the tuning sample —
-    and its verdicts on 24 000 hostile requests are the oracle's (mirror of the config-5 test above; VERDICT r3 weak #1b)."""
+    and its verdicts on 100 000 hostile requests are the oracle's (mirror of the config-5 test above; VERDICT r3 weak #1b, r4 weak #1b)."""
     from synth import pysynth
 
     w = pysynth.Workload(3)
     eng = RuleEngine(w.rules, w.lists, w.geoip)
     orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
-    hostile = w.batch(250_000, 24000, adversarial=True)
-    want = orc.evaluate(hostile, threads=16)
+    hostile = w.batch(250_000, 100_000, adversarial=True)
+    want = orc.evaluate(hostile, threads=os.cpu_count() or 16)
     got, counts = eng.evaluate_batch(hostile, with_counts=True)
     H.assert_verdicts_equal(got, want, hostile, "config 3 adversarial, untuned")
     eng.tune(w.batch(5_000_000, 32768))
@@ -344,6 +345,27 @@ def test_config3_adversarial_stream_tuned_on_benign_vs_oracle():
     H.assert_verdicts_equal(got, want, hostile, "config 3 adversarial, tuned on benign")
     assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
     assert np.count_nonzero(want["action"]) > 100
+    eng.close()
+
+
+def test_random_sample_of_the_10M_headline_batch_vs_oracle():
+    """VERDICT r4 weak #1b: the headline workload itself — BASELINE.json configs[2], the 10M-request benign batch bench.py times, tuned
+    as bench.py tunes — evaluated whole on the device, and 20 000 requests drawn at random from ALL of it (every arena position, every
+    slab, lists deep into the batch) compared with the oracle; the action counters against the verdict array."""
+    from synth import pysynth
+
+    n = 10_000_000
+    w = pysynth.Workload(3)
+    batch = w.batch(0, n, threads=os.cpu_count() or 16)
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    eng.tune(w.batch(n, 32768))
+    got, counts = eng.evaluate_batch(batch, with_counts=True)
+    assert counts.tolist() == np.bincount(got["action"], minlength=4).tolist() and counts.sum() == n
+    pick = np.sort(np.random.default_rng(2025).choice(n, 20_000, replace=False))
+    sample = batch.take(pick)
+    want = pyoracle.Oracle(w.rules, w.lists, w.geoip).evaluate(sample, threads=os.cpu_count() or 16)
+    H.assert_verdicts_equal(got[pick], want, sample, "random 20k sample of the 10M batch")
+    assert np.count_nonzero(want["action"]) > 200
     eng.close()
 
 
@@ -383,4 +405,52 @@ def test_slab_view_whose_first_bytes_complete_a_window():
     assert want["action"][64] == B
     H.assert_verdicts_equal(node.evaluate_batch(batch), want, batch, "node, second share off alignment")
     node.close()
+    eng.close()
+
+
+def test_saturated_stream_dense_confirm_path_vs_oracle():
+    """url / path / User-Agent filled to their caps with tokens that complete a window of the pass's own (tuned) filter
+    tables without being a rule literal (tools/saturated.py: chosen with the numpy model of filter_kernel over the engine's tables) —
+    nearly every 16-byte chunk is flagged, the passes are DENSE and take confirm_kernel<true> (work items' arena spans staged in LDS).
+    Engine vs oracle, vs the engine without a confirm tier, and a mixed batch (saturated and benign requests interleaved by slabs)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from pingoo_amd.engine import CompiledProgram
+    from saturated import saturated_batch
+    from synth import pysynth
+
+    w = pysynth.Workload(3)
+    sample = w.batch(5_000_000, 32768)
+    model = CompiledProgram(w.rules, w.lists, w.geoip)
+    model.tune(sample)
+    sat, info = saturated_batch(w, model, 40_000, block=40_000)
+    assert info["url"]["flagged_chunk_fraction_model"] > 0.9
+    eng = RuleEngine(w.rules, w.lists, w.geoip)
+    eng.tune(sample)
+    orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
+    want = orc.evaluate(sat, threads=os.cpu_count() or 16)
+    H.assert_verdicts_equal(eng.evaluate_batch(sat), want, sat, "saturated, tuned")
+    plain = RuleEngine(w.rules, w.lists, w.geoip, flags=_abi.OPT_NO_CONFIRM)
+    H.assert_verdicts_equal(plain.evaluate_batch(sat), want, sat, "saturated, no confirm tier")
+    plain.close()
+    # an untuned engine (other tables: the tokens flag less, some passes stay sparse) and a batch that is half benign
+    raw = RuleEngine(w.rules, w.lists, w.geoip)
+    H.assert_verdicts_equal(raw.evaluate_batch(sat), want, sat, "saturated, untuned engine")
+    raw.close()
+    benign = w.batch(100_000, 40_000)
+    mixed = RequestBatch.from_requests([])  # (built column by column below)
+    both = [sat.slice(0, 20_000), benign.slice(0, 20_000), sat.slice(20_000, 40_000), benign.slice(20_000, 40_000)]
+    data, offs = [], []
+    for f in range(5):
+        arena = np.concatenate([b.data[f][: int(b.offsets[f][-1])] for b in both] + [np.zeros(_abi.ARENA_PAD, np.uint8)])
+        o, base = [np.zeros(1, np.uint32)], 0
+        for b in both:
+            o.append((b.offsets[f][1:].astype(np.int64) + base).astype(np.uint32))
+            base += int(b.offsets[f][-1])
+        data.append(arena)
+        offs.append(np.concatenate(o))
+    mixed = RequestBatch(data, offs, np.concatenate([b.ip for b in both]), np.concatenate([b.ip_is_v6 for b in both]), np.concatenate([b.port for b in both]),
+                         np.concatenate([b.flags for b in both]))
+    H.assert_verdicts_equal(eng.evaluate_batch(mixed), orc.evaluate(mixed, threads=os.cpu_count() or 16), mixed, "saturated and benign slabs mixed")
     eng.close()
