@@ -80,25 +80,17 @@ PWAF_HD uint32_t confirm_table32(const uint8_t *p) {
 #endif
 }
 
-// Where the request TEXT of a comparison comes from. GlobalText: the arena (global memory; the host's form too). The device's dense
-// confirm kernel stages the arena span of a work item in LDS (kernels.hip: StagedText) and serves the comparisons from there.
-struct GlobalText {
-    const uint8_t *data;
-    PWAF_HD ConfirmText4 load128(const uint32_t at) const { return confirm_load128(data + at); }
-    PWAF_HD uint32_t load32(const uint32_t at) const { return confirm_load32(data + at); }
-};
-
 // One entry against the text: does the factor occur with its window's last bigram at arena position i, inside the field [fs, fe)?
 // 0 = no, 1 | atom << 8 = yes and it decides that literal atom, 2 = yes and it is a factor of a non-literal atom (walk).
 // The chain of dependent accesses is what a comparison costs, so it is kept short: the entry's three words together, then value, mask
 // and text of up to 16 bytes of the factor together.
-template <int SPACE, class Text>
+template <int SPACE>
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint32_t
-    confirm_entry_t(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const Text &text, const uint32_t fs, const uint32_t fe,
-                    const uint32_t i) {
+    confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
+                  const uint32_t i) {
     const uint8_t *ep = reinterpret_cast<const uint8_t *>(entries) + (size_t)index * sizeof(ConfirmEntry);
     const uint32_t e_off = confirm_table32<SPACE>(ep), e_ld = confirm_table32<SPACE>(ep + 4), e_af = confirm_table32<SPACE>(ep + 8);
     const uint32_t len = e_ld & 0xFFFFu, d = e_ld >> 16, atom = e_af & 0xFFFFu, flags = (e_af >> 16) & 0xFFu, n_cls = e_af >> 24;
@@ -114,7 +106,7 @@ inline uint32_t
     // factor: arenas carry PWAF_ARENA_PAD slack, the masks there are zero.)
     ConfirmText4 first{0u, 0u, 0u, 0u};  // the factor's first 16 bytes of text: class positions inside them need no load of their own
     for (uint32_t w = 0; w < l4; w += 16) {
-        const ConfirmText4 t4 = text.load128(q + w);  // (may read up to 15 bytes past the factor: PWAF_ARENA_PAD)
+        const ConfirmText4 t4 = confirm_load128(data + q + w);  // (may read up to 15 bytes past the factor: PWAF_ARENA_PAD)
         if (w == 0u) first = t4;
         const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
         uint32_t diff = 0;
@@ -130,7 +122,7 @@ inline uint32_t
             const uint32_t word = at < 4u ? first.x : at < 8u ? first.y : at < 12u ? first.z : first.w;
             return (word >> (8u * (at & 3u))) & 0xFFu;
         }
-        return text.load32(q + at) & 0xFFu;
+        return confirm_load32(data + q + at) & 0xFFu;
     };
     for (uint32_t k = 0; k < n_cls; k += 2) {
         const uint32_t pc = confirm_table32<SPACE>(cls + 2u * k);  // two {position, class id} pairs (the pool is padded to whole dwords)
@@ -142,15 +134,6 @@ inline uint32_t
         }
     }
     return atom == kConfirmWalk ? 2u : (1u | (atom << 8));
-}
-template <int SPACE>
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-inline uint32_t
-    confirm_entry(const ConfirmEntry *entries, const uint8_t *bytes, const uint32_t *classes, const uint32_t index, const uint8_t *data, const uint32_t fs, const uint32_t fe,
-                  const uint32_t i) {
-    return confirm_entry_t<SPACE>(entries, bytes, classes, index, GlobalText{data}, fs, fe, i);
 }
 
 // A flagged 16-byte arena chunk as the confirm tier sees it: the positions where a window of the pass's filter really COMPLETED inside
@@ -169,24 +152,22 @@ struct ConfirmChunk {
 struct ConfirmBytes {
     uint32_t w[7];
 };
-template <class Text>
-PWAF_HD ConfirmBytes confirm_chunk_bytes_t(const Text &text, const uint32_t c, const uint32_t readable /* arena bytes + PWAF_ARENA_PAD */) {
+PWAF_HD ConfirmBytes confirm_chunk_bytes(const uint8_t *data, const uint32_t c, const uint32_t readable /* arena bytes + PWAF_ARENA_PAD */) {
     const uint32_t base = c * 16u;
     ConfirmBytes t;
     if (base >= 8u && base + 24u <= readable) {  // (chunks are 16-aligned: every chunk but the arena's first has 8 bytes in front of it) two 16-byte loads: [base - 8, base + 24)
-        const ConfirmText4 lo = text.load128(base - 8u), hi = text.load128(base + 8u);
+        const ConfirmText4 lo = confirm_load128(data + base - 8u), hi = confirm_load128(data + base + 8u);
         t.w[0] = lo.x; t.w[1] = lo.y; t.w[2] = lo.z; t.w[3] = lo.w;
         t.w[4] = hi.x; t.w[5] = hi.y; t.w[6] = hi.z;
     } else {
-        const ConfirmText4 t4 = text.load128(base);
+        const ConfirmText4 t4 = confirm_load128(data + base);
         t.w[0] = t.w[1] = 0u;
-        if (base >= 8u) { t.w[0] = text.load32(base - 8u); t.w[1] = text.load32(base - 4u); }
+        if (base >= 8u) confirm_load64(data + base - 8u, t.w[0], t.w[1]);
         t.w[2] = t4.x; t.w[3] = t4.y; t.w[4] = t4.z; t.w[5] = t4.w;
-        t.w[6] = text.load32(base + 16u);
+        t.w[6] = confirm_load32(data + base + 16u);
     }
     return t;
 }
-PWAF_HD ConfirmBytes confirm_chunk_bytes(const uint8_t *data, const uint32_t c, const uint32_t readable) { return confirm_chunk_bytes_t(GlobalText{data}, c, readable); }
 template <class TabAt>
 PWAF_HD ConfirmChunk confirm_windows_of(const ConfirmView &cv, const ConfirmBytes &tb, const uint32_t fs, const uint32_t fe, const uint32_t c, TabAt &&tab_at) {
     const uint32_t base = c * 16u;

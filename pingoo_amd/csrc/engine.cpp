@@ -1333,8 +1333,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                      a_c = part((size_t)nc_conf * sizeof(ConfirmArgs)), a_l0 = part((la[0].size() + 1) * sizeof(ListScanArgs)), a_l1 = part((la[1].size() + 1) * sizeof(ListScanArgs)),
                      a_ptrs = part((size_t)ptrs.count * sizeof(void *));
         const size_t up_bytes = ab;
-        const size_t a_cplan = part((2 * (size_t)nc_conf + 4) * 4),  // (two plans: the sparse items and the dense ones)
-                      a_lplan = part((2 * (la[0].size() + la[1].size()) + 4) * 4);
+        const size_t a_cplan = part(((size_t)nc_conf + 2) * 4), a_lplan = part((2 * (la[0].size() + la[1].size()) + 4) * 4);
         if ((rc = S.args.reserve(ab))) return rc;
         char *const abase = (char *)S.args.p;
         d_all = (const FilterArgs *)(abase + a_all);

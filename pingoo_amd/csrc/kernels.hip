@@ -912,40 +912,24 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
 // ---------------------------------------------------------------------------------------------------------------------------------
 // confirm tier (confirm.h; program.h: ConfirmTable)
 // ---------------------------------------------------------------------------------------------------------------------------------
-// A pass is DENSE when more than a third of its arena's 16-byte chunks are flagged (an attacker's near misses back to back: DESIGN.md
-// 6.1 "saturated"): its work items then go to confirm_kernel<true>, which stages the arena span of an item in LDS — the pairs of an item
-// are 1024 CONSECUTIVE flagged chunks, a span of a few tens of KiB at that density — instead of fetching every comparison's text from
-// memory, one dependent round trip per entry and lane. Everything else (benign traffic: a flagged chunk every few KiB) stays with
-// confirm_kernel<false>. Two plans: [0, count] the sparse items, [count + 1, 2 count + 1] the dense ones.
-__global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, uint32_t *plan /* [2 (count + 1)] */) {
-    __shared__ uint32_t part[2][256];
+__global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, uint32_t *plan /* [count + 1] */) {
+    __shared__ uint32_t part[256];
     const uint32_t t = threadIdx.x;
-    uint32_t items[2] = {0, 0};
+    uint32_t items = 0;
     if (t < b.count) {
         const ConfirmArgs *pa = &b.c[t];
-        const uint32_t np = min(*pa->pair_count, pa->pair_cap);
-        const uint32_t n_items = (np + kConfirmThreads - 1) / kConfirmThreads;
-        const uint32_t chunks = (pa->total - pa->off[0] + 15u) / 16u;
-        items[(uint64_t)np * 3u > chunks ? 1 : 0] = n_items;
+        items = (min(*pa->pair_count, pa->pair_cap) + kConfirmThreads - 1) / kConfirmThreads;
     }
-    part[0][t] = items[0];
-    part[1][t] = items[1];
+    part[t] = items;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
-        const uint32_t v0 = t >= d ? part[0][t - d] : 0u, v1 = t >= d ? part[1][t - d] : 0u;
+        const uint32_t v = t >= d ? part[t - d] : 0u;
         __syncthreads();
-        part[0][t] += v0;
-        part[1][t] += v1;
+        part[t] += v;
         __syncthreads();
     }
-    if (t < b.count) {
-        plan[t] = part[0][t] - items[0];
-        plan[b.count + 1 + t] = part[1][t] - items[1];
-    }
-    if (t == 0) {
-        plan[b.count] = part[0][255];
-        plan[2 * b.count + 1] = part[1][255];
-    }
+    if (t < b.count) plan[t] = part[t] - items;
+    if (t == 0) plan[b.count] = part[255];
 }
 
 // A literal atom confirmed for request r, merged into its hit record. Several lanes — other flagged chunks of the same request, in other
@@ -1003,36 +987,9 @@ __device__ __noinline__ void merge_atom(PoolEntry *pool, uint32_t *pool_count, u
 // batch and 4 - 13 ms for the hostile stream's 11M (profiles/r4_confirm_v1_*). A pair is one chunk of text and the one or two
 // windows that completed in it: the same small amount of work in every lane, and nothing to do afterwards unless something was
 // confirmed.
-// The arena span of a dense work item, staged in LDS (confirm_kernel<true>): text of a comparison that lies inside it is read with
-// aligned LDS loads and byte-aligned in registers; anything else (a factor reaching beyond the span: never, the margins cover the
-// longest factor; a sparse item that ended up here) comes from the arena.
-static constexpr uint32_t kDenseTextBytes = 26 * 1024, kDenseMargin = 128;
-struct StagedText {
-    const uint8_t *data;
-    uint32_t lo, hi;  // arena bytes [lo, hi) are staged (hi == lo: nothing is)
-    PWAF_LDS const uint32_t *lds;
-    __device__ __forceinline__ ConfirmText4 load128(const uint32_t at) const {
-        if (at >= lo && at + 20u <= hi) {
-            const uint32_t o = at - lo, w = o >> 2, sh = o & 3u;
-            const uint32_t t0 = lds[w], t1 = lds[w + 1], t2 = lds[w + 2], t3 = lds[w + 3], t4 = lds[w + 4];
-            return ConfirmText4{__builtin_amdgcn_alignbyte(t1, t0, sh), __builtin_amdgcn_alignbyte(t2, t1, sh), __builtin_amdgcn_alignbyte(t3, t2, sh), __builtin_amdgcn_alignbyte(t4, t3, sh)};
-        }
-        return confirm_load128(data + at);
-    }
-    __device__ __forceinline__ uint32_t load32(const uint32_t at) const {
-        if (at >= lo && at + 8u <= hi) {
-            const uint32_t o = at - lo, w = o >> 2, sh = o & 3u;
-            return __builtin_amdgcn_alignbyte(lds[w + 1], lds[w], sh);
-        }
-        return confirm_load32(data + at);
-    }
-};
-
-template <bool DENSE>
-__global__ __launch_bounds__(kConfirmThreads, DENSE ? 4 : 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
+__global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTableDev b, const uint32_t *plan) {
     __shared__ uint32_t head[kFilterEntries], ftab[kFilterEntries];  // the confirm table's head words; the pass's filter table
     __shared__ uint32_t pool[kConfirmPoolBytes / 4];                 // entries | bytes | classes of the pass (when they fit)
-    __shared__ uint32_t text_lds[DENSE ? kDenseTextBytes / 4 : 1];    // (dense) the arena span of the current work item
     constexpr uint32_t kConfirmQueue = 1024;
     __shared__ uint32_t app_cnt, app_base, app_queue[kConfirmQueue];  // the workgroup's walk-list appends of the current pass
     __builtin_amdgcn_s_setprio(3);
@@ -1093,36 +1050,18 @@ __global__ __launch_bounds__(kConfirmThreads, DENSE ? 4 : 8) void confirm_kernel
         ConfirmBytes tb_next{};
         if (pr_next.x != kNone) {
             confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);  // (the request's two offsets: one scattered load)
-            if (!DENSE) tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
+            tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
         }
         for (; it < it_end; it++) {
-            // (dense) the arena span of this item's chunks, with a margin for the longest factor in front and the bytes a comparison
-            // may read behind, staged in LDS: one coalesced pass instead of a round trip per comparison and lane
-            StagedText stext{a.data, 0u, 0u, (PWAF_LDS const uint32_t *)text_lds};
-            if (DENSE) {
-                __syncthreads();  // (every lane is done with the previous item's text)
-                const uint32_t k0 = (it - first_item) * kConfirmThreads, k1 = min(n_p, k0 + kConfirmThreads) - 1u;
-                const uint32_t c_lo = __builtin_amdgcn_readfirstlane(a.pairs[k0].y), c_hi = __builtin_amdgcn_readfirstlane(a.pairs[k1].y);  // (the list ascends by chunk)
-                const uint32_t lo = c_lo * 16u > kDenseMargin ? c_lo * 16u - kDenseMargin : 0u;
-                const uint64_t hi64 = std::min<uint64_t>((uint64_t)c_hi * 16u + 16u + kDenseMargin, (uint64_t)a.total + PWAF_ARENA_PAD) & ~(uint64_t)15;
-                if (hi64 > lo && hi64 - lo <= kDenseTextBytes) {
-                    const uint32_t span = (uint32_t)hi64 - lo;
-                    for (uint32_t o = threadIdx.x * 16u; o < span; o += kConfirmThreads * 16u)
-                        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(text_lds) + o) = *reinterpret_cast<const uint4 *>(a.data + lo + o);  // (lo is a multiple of 16)
-                    stext.lo = lo;
-                    stext.hi = (uint32_t)hi64;
-                }
-                __syncthreads();
-            }
             const uint2 pr = pr_next;
             const bool live = pr.x != kNone;
             uint32_t r = live ? pr.x : 0u;  // the request that owns the chunk's first byte; a chunk that holds a field boundary also speaks for the next one(s)
             uint32_t fs = fs_next, fe = fe_next;
-            const ConfirmBytes tb = DENSE ? (live ? confirm_chunk_bytes_t(stext, pr.y, a.total + PWAF_ARENA_PAD) : ConfirmBytes{}) : tb_next;
+            const ConfirmBytes tb = tb_next;
             pr_next = pr_after;
             if (pr_next.x != kNone) {
                 confirm_load64(reinterpret_cast<const uint8_t *>(a.off + pr_next.x), fs_next, fe_next);
-                if (!DENSE) tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
+                tb_next = confirm_chunk_bytes(a.data, pr_next.y, a.total + PWAF_ARENA_PAD);
             }
             pr_after = pair_of(it + 2u);
             ConfirmChunk ch{0u, 0ull};
@@ -1170,9 +1109,8 @@ __global__ __launch_bounds__(kConfirmThreads, DENSE ? 4 : 8) void confirm_kernel
                     j = 0;
                 }
                 if (j < cnt) {
-                    uint32_t res;
-                    if (DENSE) res = in_lds ? confirm_entry_t<3>(t_entries, t_bytes, t_classes, e0 + j, stext, fs, fe, pos) : confirm_entry_t<1>(t_entries, t_bytes, t_classes, e0 + j, stext, fs, fe, pos);
-                    else res = in_lds ? confirm_entry<3>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos) : confirm_entry<1>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
+                    const uint32_t res = in_lds ? confirm_entry<3>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos)
+                                                : confirm_entry<1>(t_entries, t_bytes, t_classes, e0 + j, a.data, fs, fe, pos);
                     j++;
                     if (res == 2u) {
                         walk = true;
@@ -1251,18 +1189,12 @@ int launch_confirm(const ConfirmArgs *host, uint32_t count, const ConfirmArgs *d
     hipLaunchKernelGGL(confirm_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, plan);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // persistent grids, never more workgroups than the items a full batch could produce. Sparse passes: 2 workgroups of 1024 per CU (76
-    // KiB of LDS each: 32 waves per CU). Dense passes (the plan kernel decides, on the device): 1 per CU (+ 26 KiB for the staged text);
-    // a batch without dense passes finds that launch's plan empty and leaves at once.
+    // persistent grid: 2 workgroups of 1024 per CU (76 KiB of LDS each: 32 waves per CU), never more than the items a full batch could produce
     uint64_t max_items = 0;
     for (uint32_t k = 0; k < count; k++) max_items += ((uint64_t)host[k].pair_cap + kConfirmThreads - 1) / kConfirmThreads;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)std::max(1u, n_cus) * 2u);
     const uint32_t *cplan = plan;
-    hipLaunchKernelGGL(confirm_kernel<false>, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    const uint32_t *dplan = plan + count + 1;
-    hipLaunchKernelGGL(confirm_kernel<true>, dim3(std::min<uint32_t>(blocks, std::max(1u, n_cus))), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, dplan);
+    hipLaunchKernelGGL(confirm_kernel, dim3(blocks), dim3(kConfirmThreads), 0, (hipStream_t)stream, b, cplan);
     return (int)hipGetLastError();
 }
 
@@ -1916,7 +1848,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
                 const uint32_t bit = (uint32_t)__builtin_ctz(bw);
                 bw &= bw - 1u;
                 const uint32_t at = pair_base + rank[w] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u));
-                if (at < a.pair_cap) a.pairs[at] = make_uint2(kNone, c_first + w * 32u + bit);  // (the chunk stays: the pair list ascends by chunk)
+                if (at < a.pair_cap) a.pairs[at] = make_uint2(kNone, 0u);
             }
         }
     }
