@@ -1394,7 +1394,7 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
     if (!(P.flags & PWAF_OPT_NO_PREFILTER))
         for (auto &g : P.groups) {
             if (P.flags & PWAF_OPT_FILTER_STRIDE2) {
-                build_group_filter(P.atoms, g, nullptr, g.filter, 2);
+                build_group_filter(P.atoms, g, nullptr, g.filter, 2, true);  // (with extended windows: Model::best_window)
                 if (g.filter.enabled) continue;
             }
             build_group_filter(P.atoms, g, nullptr, g.filter, 1);

@@ -188,7 +188,7 @@ PWAF_HD ConfirmChunk confirm_windows_of(const ConfirmView &cv, const ConfirmByte
         }
         st = (st << 8) | tab_at(bin);
         const uint32_t i = base + t - 8u;
-        if (((~st) & 0xFF000000u) != 0u && i >= fs && i + 1u < fe) {  // a window completed here, both bytes inside the field
+        if (((~st) & 0xFF000000u) != 0u && i >= fs && i < fe) {  // a window completed here, its last bigram starting inside the field (its second byte may be the byte behind the field: the window of a short factor that ends with the field — filter.cpp, Model::best_window)
             mask |= 1u << (t - 8u);
             if (found < 4u) bins |= (uint64_t)bin << (16u * found);
             found++;

@@ -2410,7 +2410,7 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
         // (the device samples the bigrams of a stride-2 pass at the even bytes of the ARENA: a field's phase is its offset's parity)
         auto flagged = [&](const GroupFilter &f, const pwaf_strcol *sc, uint32_t i) {
             const uint32_t *off = sc->offsets;
-            return filter_candidate_host(f, sc->data + off[i], off[i + 1] - off[i], f.stride == 2 ? (off[i] & 1u) : 0u);
+            return filter_candidate_arena(f, sc->data, off[i], off[i + 1], off[n]);  // (the sample's arena carries no slack)
         };
         auto sample_rate = [&](const GroupFilter &f, const pwaf_strcol *sc) {
             uint64_t c = 0;
@@ -2438,20 +2438,46 @@ int tune_host(const Program &P, const pwaf_batch *sample, TuneOut &T) {
             gf.est_candidate_rate = sample_rate(gf, sc);
             GroupFilter &g2 = alt[k];
             build_group_filter(P.atoms, g, &h, g2, 2);
+            const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
 #ifdef PWAF_PROFILING
             static const long s2_mask = getenv("PWAF_STRIDE2_FIELDS") ? strtol(getenv("PWAF_STRIDE2_FIELDS"), nullptr, 0) : -1;  // timing experiments: fields that may take stride 2
-            if (!((s2_mask >> g.field) & 1)) g2.enabled = false;
+            const bool s2_allowed = ((s2_mask >> g.field) & 1) != 0;
+#else
+            const bool s2_allowed = true;
 #endif
+            // The pass takes stride 2 when that flags at most two points more of the sample than stride 1 (never above 25 %).
+            if (g2.enabled) {
+                g2.est_candidate_rate = sample_rate(g2, sc);
+                g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);
+            }
+            const double plain_rate = g2.est_candidate_rate;
+            const bool plain_ok = g2.enabled;
+            // The same pass with EXTENDED windows (filter.cpp, Model::best_window: a window with fewer than four sampled bigrams reaches
+            // one bigram beyond its factor on either side, and short windows get buckets of their own). What surrounds a factor in
+            // THIS traffic decides whether that pays, so it is measured: a pass that takes stride 2 anyway takes whichever form flags
+            // less of the sample; a pass that qualifies ONLY with extended windows (the URL pass of the 1k-rule set: "../" made 34 % of
+            // the sample a candidate at stride 2, 2.8 % extended, 1.75 % at stride 1) takes stride 2 only when that costs next to no
+            // candidates — measured on MI355X: with the other three arenas at stride 2 the launch is bound by HBM either
+            // way (0.607 ms all stride 2, 0.599 ms mixed), while the extra candidates cost the confirm tier 0.09 ms on benign traffic and
+            // 2.2 ms on the hostile stream (near misses survive half the bigrams far more often).
+            {
+                GroupFilter g2x;
+                build_group_filter(P.atoms, g, &h, g2x, 2, true);
+                if (g2x.enabled) {
+                    g2x.est_candidate_rate = sample_rate(g2x, sc);
+                    const bool take = forced ? (g2x.est_candidate_rate <= 0.4 && (!plain_ok || g2x.est_candidate_rate < plain_rate))
+                                      : plain_ok ? g2x.est_candidate_rate < plain_rate
+                                                 : (g2x.est_candidate_rate <= gf.est_candidate_rate * 1.2 + 0.001 && g2x.est_candidate_rate <= 0.25);
 #ifdef PWAF_PROFILING
-            if (getenv("PWAF_TUNE_DEBUG") && !g2.enabled) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample, %zu heads; stride 2 not built: %s\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.note.c_str());
+                    if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample, stride 2 %.4f (%s), with extended windows %.4f (%s)\n", k, g.field, gf.est_candidate_rate, plain_rate, plain_ok ? "ok" : "no", g2x.est_candidate_rate, take ? "taken" : "not taken");
 #endif
-            if (!g2.enabled) continue;
-            g2.est_candidate_rate = sample_rate(g2, sc);
+                    if (take) g2 = std::move(g2x);
+                }
+            }
+            if (!s2_allowed) g2.enabled = false;
 #ifdef PWAF_PROFILING
-            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads), stride 2 %.4f (%zu heads), mean field length %.1f\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.est_candidate_rate, g2.heads.size(), mean_len[g.field]);
+            if (getenv("PWAF_TUNE_DEBUG")) fprintf(stderr, "[tune] pass %zu field %d: stride 1 flags %.4f of the sample (%zu heads), stride 2 %s %.4f, mean field length %.1f%s%s\n", k, g.field, gf.est_candidate_rate, gf.heads.size(), g2.enabled ? "taken:" : "not taken:", g2.est_candidate_rate, mean_len[g.field], g2.note.empty() ? "" : " — ", g2.note.c_str());
 #endif
-            const bool forced = (P.flags & PWAF_OPT_FILTER_STRIDE2) != 0;
-            g2.enabled = forced ? g2.est_candidate_rate <= 0.4 : (g2.est_candidate_rate <= gf.est_candidate_rate + 0.02 && g2.est_candidate_rate <= 0.25);
         }
         for (size_t k = 0; k < P.groups.size(); k++) {
             const DfaGroup &g = P.groups[k];

@@ -54,6 +54,7 @@ static inline uint32_t fold_pair(uint8_t a, uint8_t b) { return filter_fold(a) |
 struct Model {
     const double *pairw;  // 65536 probabilities of the case-folded bigrams
     size_t stride;        // sampling stride of the filter being built
+    bool extend;          // short windows may reach one bigram beyond their factor (best_window)
     // the distinct folded pairs of two byte sets
     static void pairs_of(const ByteSet &a, const ByteSet &b, std::vector<uint16_t> &out) {
         std::set<uint32_t> ps;
@@ -75,14 +76,30 @@ struct Model {
     // Cheapest window of <= 4 sampled bigrams for a factor whose first byte sits `o` bytes past a sampling point (o < stride):
     // sampled bigrams start at o' = (stride - o) % stride ... i.e. at internal offsets a, a + stride, ...; returns its cost, the
     // internal offset of its first bigram and the bigram count (0 = the factor is too short for this alignment).
-    double best_window(const CStr &s, size_t a, size_t &start, size_t &k) {
-        std::vector<size_t> pos;
-        for (size_t j = a; j + 1 < s.size(); j += stride) pos.push_back(j);
+    // A factor with fewer than FOUR sampled bigrams of its own ("../" at stride 2: ".." or "./", whichever the alignment samples) is
+    // EXTENDED by the sampled bigram that straddles its start — (any byte, s[0]): internal offset -1 — and / or its end —
+    // (s[len - 1], any byte): offset len - 1 — when the alignment samples those: the text around an occurrence is part of the same
+    // byte stream, so the straddling bigrams are always there (fields lie back to back in the arena, PWAF_ARENA_PAD behind the last;
+    // in front only at stride 2, where offset -1 is sampled for factors at ODD arena positions: there is a byte before those). A window of
+    // one bigram made every other request a candidate (the URL pass of the 1k-rule set: 33 % of the sample at stride 2 — which is what
+    // kept a third of the streamed bytes on the LDS-bound stride-1 path); two positions, one of them a class of 256 pairs, flag a few
+    // requests in a thousand. The window's LAST bigram always starts inside the factor (the confirm tier finds the factor from there).
+    double best_window(const CStr &s, size_t a, long &start, size_t &k) {
+        std::vector<long> pos;
+        for (size_t j = a; j + 1 < s.size(); j += stride) pos.push_back((long)j);
+        if (extend && stride > 1 && pos.size() < 4 && !s.empty()) {  // (stride 1: neighbouring bigrams overlap — the bigram behind a factor's last one is implied by it, an extension there filters nothing)
+            const long last = (long)s.size() - 1;
+            if (a + 1 == stride) pos.insert(pos.begin(), -1L);
+            if (last >= (long)a && ((size_t)last - a) % stride == 0) pos.push_back(last);
+            if (pos.size() == 1 && pos[0] < 0) pos.clear();  // (only the bigram in front: no position inside the factor to find it from)
+        }
         k = std::min<size_t>(4, pos.size());
         start = 0;
         if (k == 0) return INFINITY;
+        ByteSet any;
+        any.set();
         std::vector<double> w(pos.size());
-        for (size_t q = 0; q < pos.size(); q++) w[q] = pair_weight(s[pos[q]], s[pos[q] + 1]);
+        for (size_t q = 0; q < pos.size(); q++) w[q] = pair_weight(pos[q] < 0 ? any : s[(size_t)pos[q]], (size_t)(pos[q] + 1) < s.size() ? s[(size_t)pos[q] + 1] : any);
         double best = 2;
         for (size_t st = 0; st + k <= pos.size(); st++) {
             double c = 1;
@@ -98,7 +115,8 @@ struct Model {
         for (auto &s : c.s) {
             if (s.size() < 1 + stride) return INFINITY;
             for (size_t a = 0; a < stride; a++) {
-                size_t st, k;
+                long st;
+                size_t k;
                 t += best_window(s, a, st, k);
             }
         }
@@ -339,7 +357,7 @@ bool build_confirm_table(std::vector<ConfirmSeed> &seeds, uint32_t mul, ConfirmT
     std::vector<Placed> placed;
     for (const ConfirmSeed &sd : seeds) {
         const size_t len = sd.s.size();
-        if (len < 2 || len > kMaxLen || (size_t)sd.d + 2 > len) return false;  // (the window's last bigram lies inside the factor)
+        if (len < 2 || len > kMaxLen || (size_t)sd.d + 1 > len) return false;  // (the window's last bigram starts inside the factor; d = len - 1: its second byte is the byte behind the factor)
         const size_t l4 = (len + 3) & ~(size_t)3;
         ConfirmEntry e{};
         e.bytes_off = (uint32_t)out.bytes.size();
@@ -384,7 +402,9 @@ bool build_confirm_table(std::vector<ConfirmSeed> &seeds, uint32_t mul, ConfirmT
         while (out.bytes.size() & 3) out.bytes.push_back(0);
         // the bins the window's LAST bigram can fall into: the entry is listed under each
         std::vector<uint16_t> pairs;
-        Model::pairs_of(sd.s[sd.d], sd.s[sd.d + 1], pairs);
+        ByteSet any;
+        any.set();
+        Model::pairs_of(sd.s[sd.d], (size_t)sd.d + 1 < len ? sd.s[sd.d + 1] : any, pairs);
         std::set<uint32_t> bins;
         for (uint16_t pr : pairs) bins.insert(filter_bin((uint8_t)pr, (uint8_t)(pr >> 8), mul));
         for (uint32_t bn : bins) placed.push_back({bn, e});
@@ -409,7 +429,7 @@ bool build_confirm_table(std::vector<ConfirmSeed> &seeds, uint32_t mul, ConfirmT
 }
 }  // namespace
 
-void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride) {
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride, bool extend) {
     out = GroupFilter();
     out.stride = stride;
     std::vector<double> prior;
@@ -422,7 +442,7 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     // smoothed: a bigram the sample never showed is still possible
     std::vector<double> pw(65536);
     for (uint32_t x = 0; x < 65536; x++) pw[x] = pairw0[x] * 0.98 + 0.02 / 65536;
-    Model m{pw.data(), stride};
+    Model m{pw.data(), stride, extend && stride > 1};
 
     if (g.field == PWAF_FIELD_METHOD) { out.note = "method: a handful of bytes per request, the DFA pass is already cheaper than a filter + confirmation"; return; }
     if (hints && hints->mean_len > 0 && hints->mean_len < 8) { out.note = "mean field length below 8 bytes"; return; }
@@ -505,26 +525,29 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         }
         for (auto &s : f.s)
             for (size_t al = 0; al < stride; al++) {
-                size_t st, k;
+                long st;
+                size_t k;
                 Window wd;
                 wd.cost = m.best_window(s, al, st, k);
                 wd.k = k;
                 std::string key = std::to_string(k) + ":";
+                ByteSet any;
+                any.set();
                 for (size_t j = 0; j < k; j++) {
-                    const size_t at = st + j * stride;
-                    Model::pairs_of(s[at], s[at + 1], wd.pairs[j]);
+                    const long at = st + (long)(j * stride);  // (-1 / len - 1: the bigram that straddles the factor's start / end)
+                    Model::pairs_of(at < 0 ? any : s[(size_t)at], (size_t)(at + 1) < s.size() ? s[(size_t)at + 1] : any, wd.pairs[j]);
                     for (uint16_t pr : wd.pairs[j]) key += std::to_string(pr) + ",";
                     key += ";";
                 }
 #ifdef PWAF_PROFILING
-                if (getenv("PWAF_FILTER_DEBUG") && wd.cost > 1e-5) {
+                if (getenv("PWAF_FILTER_DEBUG") && (wd.cost > 1e-5 || (k <= 2 && stride > 1))) {
                     std::string txt;
                     for (auto &bs : s) { int c = -1, cnt = 0; for (int b = 0; b < 256; b++) if (bs[(size_t)b]) { c = b; cnt++; } txt += cnt == 1 ? (char)c : '#'; }
                     fprintf(stderr, "filter field %d: factor '%s' align %zu window at %zu x%zu cost %.2e (atom %s)\n", g.field, txt.c_str(), al, st, k, wd.cost, at.key.substr(0, 60).c_str());
                 }
 #endif
                 if (index.emplace(key, wins.size()).second) wins.push_back(std::move(wd));
-                seeds.push_back(ConfirmSeed{s, (uint32_t)(st + (k - 1) * stride), is_lit ? (uint16_t)l : kConfirmWalk,
+                seeds.push_back(ConfirmSeed{s, (uint32_t)(st + (long)((k - 1) * stride)), is_lit ? (uint16_t)l : kConfirmWalk,
                                             (uint8_t)(is_lit ? ((c_start ? kConfirmAtStart : 0) | (c_end ? kConfirmAtEnd : 0)) : 0)});
             }
     }
@@ -547,6 +570,8 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
     std::vector<size_t> order(wins.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].k != wins[b].k ? wins[a].k > wins[b].k : wins[a].cost > wins[b].cost; });
+    std::vector<size_t> order_short_first = order;
+    std::stable_sort(order_short_first.begin(), order_short_first.end(), [&](size_t a, size_t b) { return wins[a].k != wins[b].k ? wins[a].k < wins[b].k : wins[a].cost > wins[b].cost; });
     static const uint32_t kMuls[] = {kFilterMul, 0x85EBu, 0xC2B3u, 0x27D5u, 0x165Bu, 0xB5A7u, 0x6F4Fu, 0x93D7u, 0xE995u, 0x4F1Du, 0xA3C1u, 0x7A6Bu,
                                      0x3C6Fu, 0xD1B5u, 0x5BD1u, 0xE6A9u, 0x2F8Du, 0x9A4Bu, 0x7F4Bu, 0xC34Fu};
     // Two things depend on the multiplier: how far the factor windows stay from the traffic's frequent bigrams (false positives ->
@@ -586,19 +611,35 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
                 }
             }
         };
-        for (size_t wi : order) {
-            int best_b = 0;
-            double best_d = INFINITY;
-            for (int b = 0; b < 8; b++) {
-                Bucket t = bk[b];
-                add(t, wins[wi]);
-                const double d = t.fp() - bk[b].fp();
-                if (d < best_d) { best_d = d; best_b = b; }
+        auto assign = [&](const std::vector<size_t> &ord, Bucket (&out_bk)[8]) {
+            for (size_t wi : ord) {
+                int best_b = 0;
+                double best_d = INFINITY;
+                for (int b = 0; b < 8; b++) {
+                    Bucket t = out_bk[b];
+                    add(t, wins[wi]);
+                    const double d = t.fp() - out_bk[b].fp();
+                    if (d < best_d) { best_d = d; best_b = b; }
+                }
+                add(out_bk[best_b], wins[wi]);
             }
-            add(bk[best_b], wins[wi]);
+            double fp = 0;
+            for (int b = 0; b < 8; b++) fp += out_bk[b].fp();
+            return fp;
+        };
+        double fp_pos = assign(order, bk);
+        if (extend && stride > 1) {
+            // Short windows FIRST: a bucket tests only its last kmin positions, so a two-bigram window that arrives when all eight
+            // buckets are taken cuts some bucket's members down to their last two bigrams (the URL pass: "../" joined a bucket of
+            // three- and four-bigram windows, whose cross products with its 256-pair class then flagged 14 % of the sample). Placed
+            // first, the short windows keep buckets of their own and the long ones share the rest. Whichever order estimates lower.
+            Bucket alt[8];
+            const double fp_alt = assign(order_short_first, alt);
+            if (fp_alt < fp_pos) {
+                fp_pos = fp_alt;
+                for (int b = 0; b < 8; b++) bk[b] = alt[b];
+            }
         }
-        double fp_pos = 0;
-        for (int b = 0; b < 8; b++) fp_pos += bk[b].fp();
         if (pass == 0) {
             mul_fp.push_back(fp_pos);
             mul_bank.push_back(bank_collision(w));
@@ -607,6 +648,13 @@ void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const
         }
         best_bank = mul_bank[mi];
         best_fp = fp_pos;
+#ifdef PWAF_PROFILING
+        if (getenv("PWAF_FILTER_DEBUG")) {
+            fprintf(stderr, "filter field %d stride %u mul %#x: fp per position %.3e;", g.field, stride, mul, fp_pos);
+            for (int b = 0; b < 8; b++) fprintf(stderr, " bucket %d kmin %zu fp %.2e (w %.3f %.3f %.3f %.3f)", b, bk[b].kmin, bk[b].fp(), bk[b].wsum[0], bk[b].wsum[1], bk[b].wsum[2], bk[b].wsum[3]);
+            fprintf(stderr, "\n");
+        }
+#endif
         out.mul = mul;
         out.table.assign(kFilterEntries, 0xFFFFFFFFu);
         out.init = 0xFFFFFFFFu;
@@ -647,6 +695,29 @@ bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n,
     return false;
 }
 
+// The filter over the field [fs, fe) of an arena as the device's flat stream sees it: the state at the field's first sampled position
+// is what the (up to four) sampled bigrams in front of it left behind — the previous fields' bytes, or the init state at the arena's
+// start — and the field's last position pairs its last byte with the byte behind the field (the windows of short factors reach one
+// bigram beyond the factor on either side: Model::best_window). flag(i) for every position of the field that completes a window;
+// bytes at or beyond `readable` read as zero.
+template <class Flag>
+static void filter_field_positions(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, uint64_t readable, Flag &&flag) {
+    const uint32_t s = f.stride ? f.stride : 1u;
+    const uint32_t i0 = s == 2 ? (fs + 1u) & ~1u : fs;  // (bigrams are sampled at the even bytes of the ARENA)
+    uint32_t st = f.init;
+    auto at = [&](uint64_t i) -> uint8_t { return i < readable ? arena[i] : (uint8_t)0; };
+    for (uint32_t i = i0 >= 4u * s ? i0 - 4u * s : i0 % s; i < fe; i += s) {
+        st = (st << 8) | f.table[filter_bin(at(i), at((uint64_t)i + 1), f.mul)];
+        if (i >= i0 && ((~st) & 0xFF000000u)) flag(i);
+    }
+}
+
+bool filter_candidate_arena(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, uint64_t readable) {
+    bool any = false;
+    filter_field_positions(f, arena, fs, fe, readable, [&](uint32_t) { any = true; });
+    return any;
+}
+
 uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n) {
     uint32_t r = 0;
     for (size_t k = 0; k < f.heads.size(); k++) {
@@ -662,17 +733,15 @@ uint32_t filter_heads_host(const GroupFilter &f, const uint8_t *bytes, size_t n)
 namespace pwaf {
 
 // Host model of filter + confirm tier over the field [fs, fe) of an arena with PWAF_ARENA_PAD readable bytes behind it: the chunks
-// the filter flags for the field's own bytes (the device may flag more — it also sees the neighbours' bytes — which the exact
-// comparison makes irrelevant), then confirm.h over each of them. Appends the confirmed literal atoms (local ids, possibly
+// the filter flags at the field's positions (filter_field_positions: as the device's stream sees them, neighbours included), then
+// confirm.h over each of them. Appends the confirmed literal atoms (local ids, possibly
 // repeated) to `lits`; returns true when the request must be walked through the DFA (always, for a flagged field of a pass without
 // a confirm table). `flagged` (optional): the filter flagged the field at all.
 bool confirm_field_host(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, std::vector<uint16_t> &lits, bool *flagged) {
     std::vector<uint32_t> chunks;
-    uint32_t st = f.init;
-    for (uint32_t i = f.stride == 2 ? (fs + 1u) & ~1u : fs; i + 1 < fe; i += f.stride) {
-        st = (st << 8) | f.table[filter_bin(arena[i], arena[i + 1], f.mul)];
-        if (((~st) & 0xFF000000u) && (chunks.empty() || chunks.back() != (i >> 4))) chunks.push_back(i >> 4);
-    }
+    filter_field_positions(f, arena, fs, fe, (uint64_t)fe + PWAF_ARENA_PAD, [&](uint32_t i) {
+        if (chunks.empty() || chunks.back() != (i >> 4)) chunks.push_back(i >> 4);
+    });
     if (flagged) *flagged = !chunks.empty();
     if (chunks.empty()) return false;
     if (!f.confirm.enabled) return true;

@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(kConfirmThreads, 8) void confirm_kernel(ConfirmTabl
                         fs = fe;
                         fe = a.off[r + 1];
                     }
-                    if (pos + 1u >= fe) continue;  // the bigram crosses the field's end (or lies in the arena's slack)
+                    if (pos >= fe) continue;  // the bigram starts in the arena's slack (one that starts on the field's last byte may be the window of a short factor: confirm.h)
                     const uint32_t hd = head[bin];
                     e0 = hd & 0xFFFFFu;
                     cnt = hd >> 20;

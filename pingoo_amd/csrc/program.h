@@ -108,10 +108,12 @@ static constexpr uint32_t kFilterBits = 12, kFilterEntries = 1u << kFilterBits;
 // Bigrams are sampled at every stride-th byte of the arena stream; a factor is entered once per alignment it can have relative to
 // the sampling grid. Stride 2 halves the lookups per input byte (the filter kernel is bound by LDS gathers: ~8 LDS cycles per wave
 // lookup, three quarters of them bank conflicts) at the price of windows that span up to 8 bytes: factors shorter than 3 bytes
-// cannot be filtered and 3-4 byte factors contribute a single position.
-// GroupFilter::stride: 1, or 2 for a pass whose factors are long enough (host names, paths, User-Agent tokens) that two to four
-// sampled bigrams per alignment stay selective — half the table lookups per byte. (Stride 2 for EVERY pass was tried first: a 3-byte
-// factor such as "../" then owns a single sampled position and floods the candidates. pwaf_engine_tune decides per pass from the sample.)
+// cannot be filtered, and a 3-4 byte factor has a single sampled bigram of its own per alignment.
+// GroupFilter::stride: 1, or 2 for a pass whose factors stay selective with half the bigrams sampled — half the table lookups per
+// byte. (Stride 2 for EVERY pass was tried first: a 3-byte factor such as "../" then owns a single sampled position and floods the
+// candidates — 34 % of the URL sample. Round 5: such a window is EXTENDED by the sampled bigrams that straddle the factor's start and
+// end — (any byte, first byte), (last byte, any byte) — and short windows get buckets of their own: 2.8 %, filter.cpp
+// Model::best_window.) pwaf_engine_tune decides per pass from the sample, with and without extended windows.
 static constexpr uint32_t kFilterMul = 0x9E37u;  // default 16-bit multiplier of the bigram hash (v_pk_mul_lo_u16 on the device); a pass picks its own from a
                                                  // few candidates so that its factor windows avoid the bins frequent bigrams fall into (GroupFilter::mul)
 #if defined(__HIPCC__)
@@ -356,7 +358,10 @@ void dfa_run_host(const DfaGroup &g, const uint8_t *bytes, size_t n, std::vector
 
 // Builds the bigram prefilter of pass `g` (filter.cpp). `atoms` = Program::atoms. Leaves filter.enabled false (with a note)
 // when some pattern has no usable literal factor.
-void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride = 1);
+// extend (stride 2 only): windows with fewer than four sampled bigrams may reach one bigram beyond their factor on either side
+// (filter.cpp: Model::best_window). Their selectivity depends on the text AROUND factors, which only a traffic sample can tell:
+// creation decides without them, pwaf_engine_tune builds both forms and keeps the one that flags less of the sample.
+void build_group_filter(const std::vector<Atom> &atoms, const DfaGroup &g, const FilterHints *hints, GroupFilter &out, uint32_t stride = 1, bool extend = false);
 // An atom the confirm tier decides by itself: (\A)? literal (\z)? with a literal of 2 .. 64 single bytes.
 bool confirm_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_end);
 // Host model of the filter kernel over one field value: true = candidate. (Used by tune to measure the candidate rate on the
@@ -364,6 +369,7 @@ bool confirm_literal(const RNode &n, std::string &lit, bool &at_start, bool &at_
 // `\A literal` / `\A literal \z` with a literal of at most 8 single bytes (kernels.h: ShortAtom)
 bool short_literal_atom(const RNode &n, std::string &lit, bool &exact);
 bool filter_candidate_host(const GroupFilter &f, const uint8_t *bytes, size_t n, size_t phase = 0);  // phase: offset of the first sampled byte (< stride)
+bool filter_candidate_arena(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, uint64_t readable);  // the same question for the field [fs, fe) of an arena, its neighbours' bytes included (what the device's flat stream sees); bytes at or beyond `readable` read as zero
 // Host model of filter + confirm tier over one field [fs, fe) of an arena with PWAF_ARENA_PAD readable bytes behind its end: the literal
 // atoms confirmed (appended to lits), returns "walk the request through the DFA" (filter.cpp; tune and the CPU test hook use it).
 bool confirm_field_host(const GroupFilter &f, const uint8_t *arena, uint32_t fs, uint32_t fe, std::vector<uint16_t> &lits, bool *flagged = nullptr);

@@ -147,16 +147,22 @@ class Tables:
         return (((f0 | (f1 << 8)) * mul) & 0xFFFF) >> 4
 
     def filter_flags(self, g: dict, data: bytes):
-        """The bigram prefilter of a pass exactly as filter_kernel applies it to the bytes of ONE field value that starts
-        `arena_offset` bytes into the arena: the 16-byte arena chunks holding a position that completed a window. (The device also
-        sees the neighbouring fields' bytes, which can only flag more chunks: the walk this model derives is the SHORTEST one the
-        device may take.)"""
-        st, tab, flags = g["f_init"], g["f_table"], set()
-        o = self.arena_offset
-        for i in range((o + self.filter_phase) % g["f_stride"], len(data) - 1, g["f_stride"]):
-            st = ((st << 8) | int(tab[self.filter_bin(data[i], data[i + 1], g["f_mul"])])) & 0xFFFFFFFF
-            if (~st) & 0xFF000000:
-                flags.add((o + i) // 16)
+        """The bigram prefilter of a pass exactly as filter_kernel applies it to ONE field value inside an arena (csrc/filter.cpp:
+        filter_field_positions): the field starts A = arena_offset + filter_phase + 16 arena_chunks bytes into an arena whose other
+        bytes are '~' (what the test hook pwaf_program_confirm_field builds around it). The state at the field's first sampled
+        position is what the (up to four) sampled bigrams in front of it left — the init state at the arena's start — and the last
+        position pairs the field's last byte with the byte behind it: windows of short factors reach one bigram beyond the factor.
+        Returns the 16-byte arena chunks holding a position of the field that completed a window."""
+        tab, flags, s = g["f_table"], set(), g["f_stride"]
+        A = self.arena_offset + self.filter_phase + 16 * self.arena_chunks
+        arena = b"~" * A + bytes(data) + b"~" * 32
+        fs, fe = A, A + len(data)
+        i0 = (fs + 1) & ~1 if s == 2 else fs
+        st = g["f_init"]
+        for i in range(i0 - 4 * s if i0 >= 4 * s else i0 % s, fe, s):
+            st = ((st << 8) | int(tab[self.filter_bin(arena[i], arena[i + 1], g["f_mul"])])) & 0xFFFFFFFF
+            if i >= i0 and (~st) & 0xFF000000:
+                flags.add(i // 16)
         return flags
 
     def filter_candidate(self, g: dict, data: bytes) -> bool:

@@ -454,3 +454,36 @@ def test_saturated_stream_vs_oracle():
                          np.concatenate([b.flags for b in both]))
     H.assert_verdicts_equal(eng.evaluate_batch(mixed), orc.evaluate(mixed, threads=os.cpu_count() or 16), mixed, "saturated and benign slabs mixed")
     eng.close()
+
+
+def test_short_factors_at_stride_two_on_the_device():
+    """Round 5: stride-2 windows of factors with fewer than four sampled bigrams reach one bigram beyond the factor on either side
+    (csrc/filter.cpp, Model::best_window): the bigram behind a factor that ENDS its field pairs the field's last byte with the next
+    request's first byte (or the arena's slack), the one in front of a factor that STARTS its field with the previous request's last
+    byte. Literals of 3 to 7 bytes as contains / starts_with / ends_with / ==, fields that ARE the literal or hold it at their start /
+    middle / end, packed back to back at every arena alignment (filler requests of 0..17 bytes in between), the first and the last
+    request of the batch included — against the oracle, and against the engine without the confirm tier."""
+    rng = random.Random(55)
+    lits = ["../", "%00x", "/.env", "passwd", "<script"]
+    rules = []
+    for k, lit in enumerate(lits):
+        rules += [(f"c{k}", f"http_request.path.contains({H.q(lit)})", [B]), (f"s{k}", f"http_request.url.starts_with({H.q(lit)})", [CAP]),
+                  (f"e{k}", f"http_request.user_agent.ends_with({H.q(lit)})", [B]), (f"q{k}", f"http_request.host == {H.q(lit)}", [CAP])]
+    reqs = []
+    for lit in lits:
+        for v in [lit, lit + "a", "a" + lit, "ab" + lit, lit + "ab", "a" + lit + "b", "abcdefghijklmnop" + lit, lit + "abcdefghijklmnopq", "xyz" + lit[:-1], lit[1:] + "xyz",
+                  "abcdefghijklm" + lit + "nopqrstuvwxyz", lit[:-1] + "~", "~" + lit[1:]]:
+            for pad in range(18):
+                reqs.append(Request(host=v, url=v, path=v, method="GET", user_agent=v))
+                if pad:
+                    f = H.rstr(rng, pad, pad, "abcxyz0189")
+                    reqs.append(Request(host=f, url=f, path=f, method="GET", user_agent=f))
+    reqs = [Request(host=lits[0], url=lits[0], path=lits[0], method="GET", user_agent=lits[0])] + reqs + [Request(host=lits[1], url=lits[1], path=lits[1], method="GET", user_agent=lits[1])]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, {}, flags=_abi.OPT_NO_UA_GATE).evaluate(batch)
+    assert np.count_nonzero(want["action"]) > 500
+    for extra in (0, _abi.OPT_NO_CONFIRM):
+        eng = RuleEngine(rules, {}, flags=_abi.OPT_FILTER_STRIDE2 | _abi.OPT_NO_UA_GATE | extra)
+        assert eng.stats()["n_filtered_groups"] == 4
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"stride 2, flags {extra}")
+        eng.close()

@@ -310,6 +310,37 @@ def test_confirm_tier_decides_literals_and_walks_only_confirmed_regex_factors(se
     assert plain.n_confirm_hits == 0 and all(not g.get("confirm") for g in plain.groups)
 
 
+@pytest.mark.parametrize("length", [3, 4, 5, 6, 7])
+def test_short_factors_at_stride_two_reach_into_their_neighbours(length):
+    """Round 5: at stride 2 a factor with fewer than four sampled bigrams of its own takes the sampled bigram that STRADDLES its start
+    (any byte, first byte) and / or its end (last byte, any byte) into its window (csrc/filter.cpp, Model::best_window) — "../" owns
+    one sampled bigram per alignment, which alone flagged a third of the benign URLs. The straddling bytes belong to whatever precedes /
+    follows the occurrence: the neighbouring fields of the arena, its very start, the slack behind it. Literals of 3 to 7 bytes as
+    contains / starts_with / ends_with / ==, the field BEING the literal or holding it at its start, middle and end, at every arena
+    offset 0..17 (offset 0 = nothing in front of the field), against the expected truth; and no literal atom is lost."""
+    lit = ("../", "%00x", "/.env", "passwd", "<script")[length - 3]
+    assert len(lit) == length
+    rules = [("c", f"http_request.path.contains({H.q(lit)})", [H.B]), ("s", f"http_request.url.starts_with({H.q(lit)})", [H.B]),
+             ("e", f"http_request.user_agent.ends_with({H.q(lit)})", [H.B]), ("q", f"http_request.host == {H.q(lit)}", [H.B])]
+    prog = CompiledProgram(rules, {}, flags=_abi.OPT_FILTER_STRIDE2 | _abi.OPT_NO_UA_GATE)
+    t = table_walker.Tables(prog)
+    assert {g["f_stride"] for g in t.groups if "f_table" in g} == {2}
+    from pingoo_amd import Request
+    values = [lit, lit + "a", "a" + lit, "ab" + lit, lit + "ab", "a" + lit + "b", "ab" + lit + "cd", "abcdefghijklmnop" + lit, lit + "abcdefghijklmnopq", "xyz" + lit[:-1], lit[1:] + "xyz",
+              "abcdefghijklm" + lit + "nopqrstuvwxyz", lit[:-1] + "~", "~" + lit[1:], ""]
+    checked = 0
+    for v in values:
+        req = Request(host=v or "h", url=v, path=v, method="GET", user_agent=v or "u")
+        batch = RequestBatch.from_requests([req])
+        expect = pyoracle.Oracle(rules, {}, flags=_abi.OPT_NO_UA_GATE).evaluate(batch)[0]
+        for off in range(18):
+            t.arena_offset, t.filter_phase, t.arena_chunks = off % 16, 0, off // 16
+            got = t.evaluate(batch, 0)
+            assert got == (int(expect["action"]), int(expect["rule_idx"])), (lit, v, off)
+            checked += 1
+    assert checked == 18 * len(values)
+
+
 def test_confirm_tier_on_the_synthetic_hostile_stream():
     """The 1k-rule set (BASELINE.json configs[2]) on its hostile stream: most candidates of the literal-heavy passes are near misses,
     which the confirm tier settles without a walk; verdicts are the oracle's."""

@@ -35,6 +35,7 @@ for seed in range(lo, hi):
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
     t = Tables(prog)
     t.filter_phase = seed & 1
+    t.arena_offset, t.arena_chunks = (seed >> 1) % 16, (seed >> 5) % 3  # (where the field lies in its arena: the windows of short factors reach into the neighbouring bytes)
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     try:
         H.assert_verdicts_equal(got, want, batch, f"seed {seed}")
