@@ -1723,6 +1723,20 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// A wave-uniform 64-bit mask into ONE lane of a register pair (v_writelane_b32): `x = lane == l ? m : x` without the compare of the
+// lane id, the two selects and the moves of the scalar pair into vector registers — two vector instructions instead of seven where a
+// kernel is bound by vector-ALU issue (attr_kernel: one such parking per present membership bit and per comparison atom). gfx9 lets
+// a VALU instruction read ONE scalar register, M0 not counted: the lane select travels in M0. (No compiler builtin for v_writelane.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // (M0 is a reserved register: naming it as clobbered is what is meant)
+__device__ __forceinline__ void park64(uint32_t &lo, uint32_t &hi, const unsigned long long m, const uint32_t l) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                 : "+v"(lo), "+v"(hi)
+                 : "s"((uint32_t)m), "s"(l), "s"((uint32_t)(m >> 32))
+                 : "m0");
+}
+#pragma clang diagnostic pop
+
 // Inclusive prefix sum over the 64 lanes, same DPP network (no LDS round trips, unlike __shfl_up).
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
 #define PWAF_DPP_ADD(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (ctrl), (rows), 0xF, true)
@@ -2789,15 +2803,17 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         auto transpose = [&](const uint32_t w, const uint32_t src_word) {
             const uint32_t orw0 = wave_or(w);
             if (orw0 == 0) return;
-            unsigned long long mine_m = 0;
+            // (the mask is PARKED in lane b with v_writelane: two vector instructions per bit — a compare of the lane id and two
+            // selects, with the mask moved into vector registers first, were seven; the kernel is bound by vector-ALU issue)
+            uint32_t mine_lo = 0, mine_hi = 0;
             for (uint32_t orw = orw0; orw; orw &= orw - 1) {
                 const uint32_t b = (uint32_t)__builtin_ctz(orw);
-                const unsigned long long m = __ballot((w >> b) & 1u);
-                if (lane == b) mine_m = m;
+                const unsigned long long m = __ballot((w & (1u << b)) != 0u);
+                park64(mine_lo, mine_hi, m, b);
             }
             const bool owner = lane < 32 && ((orw0 >> lane) & 1u);
             const uint32_t c = owner ? a.bit_col[src_word * 32 + lane] : 0u;  // (source word, bit) -> column, 0 = no such atom
-            emit_pairs(c != 0, c, (uint32_t)mine_m, (uint32_t)(mine_m >> 32));
+            emit_pairs(c != 0, c, mine_lo, mine_hi);
         };
         if (!skip_transpose) {
 #pragma unroll
@@ -2835,8 +2851,7 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                         todo &= todo - 1;
                         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m_c, (int)j);
                         const unsigned long long m = __ballot(op == 0 ? v == c : v <= c) & valid_mask;
-                        acc_lo = lane == j ? (uint32_t)m : acc_lo;
-                        acc_hi = lane == j ? (uint32_t)(m >> 32) : acc_hi;
+                        park64(acc_lo, acc_hi, m, j);
                     }
                 }
             };
@@ -2867,10 +2882,11 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                 const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)m.len_exact, (int)j), len = le & 0xFFu;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m.lit_lo, (int)j), hi = (uint32_t)__builtin_amdgcn_readlane((int)m.lit_hi, (int)j);
                 const uint32_t mlo = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u, mhi = len >= 8 ? 0xFFFFFFFFu : len > 4 ? (1u << (8 * (len - 4))) - 1u : 0u;
-                const bool len_ok = (le >> 8) ? cur.slen == len : cur.slen >= len;
-                const unsigned long long hit = __ballot(len_ok && ((c_slo ^ lo) & mlo) == 0 && ((c_shi ^ hi) & mhi) == 0) & valid_mask;
-                acc_lo = lane == j ? (uint32_t)hit : acc_lo;
-                acc_hi = lane == j ? (uint32_t)(hit >> 32) : acc_hi;
+                // (the length test is chosen by a SCALAR branch — `exact` is the atom's, not the request's — and the two masked compares
+                // are one: xor, xor-and, and-or, compare)
+                const unsigned long long len_ok = (le >> 8) ? __ballot(cur.slen == len) : __ballot(cur.slen >= len);
+                const unsigned long long hit = __ballot((((c_slo ^ lo) & mlo) | ((c_shi ^ hi) & mhi)) == 0u) & len_ok & valid_mask;
+                park64(acc_lo, acc_hi, hit, j);
             }
             emit_pairs((acc_lo | acc_hi) != 0, m.col, acc_lo, acc_hi);
         }
