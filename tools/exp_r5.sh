@@ -10,6 +10,7 @@ for what in "$@"; do
     skip=*) v=${what#skip=}; PWAF_LIB_VARIANT=prof PWAF_DEBUG_SKIP=$v $B > $O/skip_$v.json 2> $O/skip_$v.err; PWAF_LIB_VARIANT=prof PWAF_PLACEMENT=1 PWAF_DEBUG_SKIP=$v $B > $O/alone_skip_$v.json 2> $O/alone_skip_$v.err ;;
     bench) python $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json ;;
     flags=*) v=${what#flags=}; python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-config5 --residual 0 --engine-flags $v > $O/flags_$v.json 2> $O/flags_$v.err ;;
+    place=*) v=${what#place=}; PWAF_LIB_VARIANT=prof PWAF_PLACEMENT=$v $B > $O/place_$v.json 2> $O/place_$v.err ;;
     quick) $B > $O/quick.json 2> $O/quick.err ;;
     profile=*) bash $R/tools/profile_round.sh $TAG/${what#profile=} ;;
   esac

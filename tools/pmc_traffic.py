@@ -31,4 +31,13 @@ for k, d in per.items():
     f, w = f[-n:], w[-n:]
     factor = 2
     out["kernels"][k] = {"launches": len(f), "fetch_factor": factor, "fetch_bytes": [int(x * 1024 * factor) for x in f], "write_bytes": [int(x * 1024) for x in w]}
+# ipres_kernel: what it fetches against the address bytes it needs (16-byte address + 1-byte family per request; VERDICT r4 asked for the
+# ratio). Its table gathers are L2 misses served by the Infinity Cache (the 8 MiB table is resident in its 256 MiB; the counter sits
+# on the L2's fabric side and counts those hits too), in requests whose size the x2 calibration does not cover: see rdreq.txt.
+for k, v in out["kernels"].items():
+    if "ipres_kernel" in k and v["write_bytes"]:
+        n_req = v["write_bytes"][-1] // 4  # (packed results: 4 bytes per request)
+        v["requests"] = n_req
+        v["address_bytes"] = 17 * n_req
+        v["fetch_over_address_bytes"] = round(v["fetch_bytes"][-1] / max(1, 17 * n_req), 2)
 print(json.dumps(out, indent=1))
