@@ -247,6 +247,18 @@ def config5_leg(dev, threads, steps, verbose, check_adversarial=True):
     return out
 
 
+def slab_of(scaling, n_arg, rank, world):
+    """(requests of this rank, requests of the whole job, index of this rank's first request in the global seeded stream).
+    strong: BASELINE configs[3] as written — ONE batch of n_arg requests, rank r takes its 64-aligned slab (pingoo_amd/shard.py =
+    pwaf_node_shard_bounds); weak: n_arg requests per GPU."""
+    if scaling == "strong":
+        from pingoo_amd import shard
+
+        first, last = shard.shard_bounds(n_arg, rank, world)
+        return last - first, n_arg, first
+    return n_arg, n_arg * world, rank * n_arg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,12 +316,7 @@ def main():
 
     scaling = args.scaling or ("strong" if world > 1 else "weak")
     n_arg = args.requests or DEFAULT_N.get(args.config, 100_000)
-    if scaling == "strong":  # one batch, split: rank r takes its 64-aligned slab of it (pingoo_amd/shard.py = pwaf_node_shard_bounds)
-        total = n_arg
-        first, last = shard.shard_bounds(total, rank, world)
-        n = last - first
-    else:
-        n, total, first = n_arg, n_arg * world, rank * n_arg
+    n, total, first = slab_of(scaling, n_arg, rank, world)
     if n == 0:
         raise SystemExit(f"rank {rank}: an empty slab ({total} requests over {world} GPUs)")
     threads = max(1, (os.cpu_count() or 1) // world)

@@ -131,3 +131,21 @@ def test_world_size_one_under_a_launcher_still_runs_the_collective():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert before == 0 and world == 1 and inited and vals == [5, 6, 7, 8]
+
+
+def test_bench_slabs_weak_and_strong():
+    """bench.py --scaling strong (the default when --gpus > 1) splits ONE batch (BASELINE configs[3]: "10M-request batch ... sharded
+    2/4/8 GPUs") into the same 64-aligned slabs the node API uses; weak gives every rank its own batch of the global seeded stream."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for world in (1, 2, 4, 8):
+        for n_arg in (10_000_000, 1_000_003, 65, 64):
+            slabs = [bench.slab_of("strong", n_arg, r, world) for r in range(world)]
+            assert all(t == n_arg for _, t, _ in slabs)
+            assert slabs[0][2] == 0 and sum(n for n, _, _ in slabs) == n_arg
+            for (n0, _, f0), (_, _, f1) in zip(slabs, slabs[1:]):
+                assert f0 + n0 == f1 and f1 % 64 == 0  # contiguous, whole 64-request groups
+            assert [(n, f) for n, _, f in slabs] == [(hi - lo, lo) for lo, hi in (shard.shard_bounds(n_arg, r, world) for r in range(world))]
+            weak = [bench.slab_of("weak", n_arg, r, world) for r in range(world)]
+            assert weak == [(n_arg, n_arg * world, r * n_arg) for r in range(world)]
