@@ -1101,10 +1101,27 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         rlists.push_back(std::move(rl));
     }
     std::vector<Syntax> syntaxes(in.n_rules);
+    // EXTENSION: the headers map holds the names the WHOLE rule set mentions with a literal key. They are collected
+    // before any rule is compiled — the oracle's rule and order (collect_header_names) — so that the set is CLOSED when a rule needs the
+    // map as a value (a computed key into http_request / http_request.headers, length() of the headers map: residual.cpp). A syntax
+    // error ends the collection: the loop below reports it (or an earlier rule's error) and creation fails.
+    bool headers_closed = true;
+    {
+        std::vector<std::string> names;
+        for (size_t k = 0; k < in.n_rules; k++) {
+            if (!in.rules[k].expression) continue;
+            Syntax syn;
+            std::string perr;
+            if (!parse_expression(in.rules[k].expression, syn, perr)) { headers_closed = false; break; }
+            collect_header_names(syn, names);
+        }
+        if (names.size() > kMaxHeaders) headers_closed = false;  // (the rule that mentions one name too many is refused below, as before)
+        else for (const std::string &nm : names) rc.header_field(nm);
+    }
     auto try_residual = [&](size_t k, const std::string &col_why, std::string &why) -> int {
         if (P.flags & PWAF_OPT_NO_RESIDUAL) { why = col_why; return -1; }
         std::string rwhy;
-        const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_field(name); }, rwhy);
+        const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_field(name); }, rwhy, headers_closed ? &P.header_names : nullptr);
         if (idx < 0) { why = col_why + "; and the residual interpreter cannot take it either: " + rwhy; return -1; }
         if (P.residual_rule.size() <= (size_t)idx) P.residual_rule.resize((size_t)idx + 1, 0xFFFFFFFFu);
         P.residual_rule[(size_t)idx] = (uint32_t)k;

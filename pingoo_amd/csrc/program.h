@@ -400,6 +400,11 @@ struct ResidualList {  // a configured list as the residual compiler sees it (pa
     std::vector<PrefixEntry> nets;
     size_t size() const { return type == PWAF_LIST_STRING ? strs.size() : type == PWAF_LIST_INT ? ints.size() : nets.size(); }
 };
+// EXTENSION: the names of the headers map = what the rule set asks of it with a LITERAL key — http_request.headers["x"],
+// http_request.headers.x, "x" in http_request.headers, http_request.headers.contains("x") (and the same behind http_request["headers"]) —
+// appended to `names` in order of first use, pre-order, left to right (the oracle's rule: oracle/oracle_engine.cpp, pwaf_oracle_create).
+void collect_header_names(const Syntax &syn, std::vector<std::string> &names);
+
 class ResidualBuilder {
 public:
     ResidualBuilder();
@@ -408,7 +413,11 @@ public:
     ResidualBuilder &operator=(const ResidualBuilder &) = delete;
     // Lowers one rule; returns its index among the residual rules, or -1 with the reason (nothing of the rule is kept then).
     // header_field(name) = string column of a header name (registers the name with the program on first use).
-    int compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why);
+    // closed_headers (may be null): EVERY header name the whole rule set mentions with a literal key, in the order their columns have
+    // (collect_header_names over all rules, before any is compiled) — what the headers map IS as a value: needed by a computed key into
+    // http_request / http_request.headers and by length() of the headers map; without it such a rule is refused.
+    int compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why,
+                     const std::vector<std::string> *closed_headers = nullptr);
     size_t n_rules() const;
     bool needs_geo() const;  // some rule reads client.asn / client.country
     std::vector<uint8_t> blob() const;  // the device image (rvm::Header + sections)

@@ -54,6 +54,7 @@ struct ResidualBuilder::Impl {
     const Syntax *syn = nullptr;
     const std::vector<ResidualList> *host_lists = nullptr;
     std::function<int(const std::string &)> header_field;
+    const std::vector<std::string> *closed_headers = nullptr;  // every header name of the rule set, in column order (null: not known)
     uint32_t depth = 0, max_depth = 0, heap = 0;
     uint32_t heap_items = 0;  // the largest heap bound over the accepted rules (Header::heap_items)
 
@@ -234,19 +235,26 @@ struct ResidualBuilder::Impl {
     }
 
     // A context map as a real Map VALUE, built per request: what a COMPUTED key needs (`client[http_request.method]`,
-    // `http_request.host in lists`): the key sets of http_request / client / lists are closed, so the map is a literal of this compiler's
-    // own making and the generic Map operations answer — a key that is not a String is an execution error, an absent one an error
-    // for [] and false for `in` / contains, exactly as for any map. keys_only: the values are never read (membership tests).
-    // Not offered: the headers map (it holds the names the WHOLE rule set mentions — later rules add to it), and http_request[computed]
-    // (its "headers" entry is that map).
+    // `http_request.host in lists`, `http_request[k]`, `http_request.headers[k]`): the key sets of http_request / client / lists are
+    // closed, and so is the headers map's once every rule has been read (closed_headers: the names the WHOLE rule set mentions with a
+    // literal key) — the map is a literal of this compiler's own making and the generic Map operations answer: a key that is not a
+    // String is an execution error, an absent one an error for [] and false for `in` / contains, exactly as for any map. keys_only: the
+    // values are never read (membership tests). A map's entries sit on the stack until R_MKMAP: a rule set that mentions more header
+    // names than the stack holds is refused here (stack slots), as is one whose names are not known yet (closed_headers == null).
     void gen_ctx_map(int ctx, bool keys_only, Info &r) {
         static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
         uint32_t n = 0;
         auto key = [&](const std::string &k) { push_str(k); n++; };
+        Info inner;  // (a value that is itself a map: http_request's "headers" entry)
         if (ctx == 1) {
-            if (!keys_only) throw Reject{"http_request indexed with a computed key (its headers entry is a map of the rule set's header names)"};
-            for (auto f : kFields) { key(f); push_bool(true); }
-            key("headers"); push_bool(true);
+            for (int f = 0; f < 5; f++) {
+                key(kFields[f]);
+                if (keys_only) push_bool(true);
+                else { emit(R_FIELD, 0, (uint32_t)f); push(); }
+            }
+            key("headers");
+            if (keys_only) push_bool(true);
+            else gen_ctx_map(4, false, inner);
         } else if (ctx == 2) {
             key("ip"); if (keys_only) push_bool(true); else { emit(R_IP); push(); }
             key("remote_port"); if (keys_only) push_bool(true); else { emit(R_PORT); push(); }
@@ -262,8 +270,17 @@ struct ResidualBuilder::Impl {
                 else { emit(R_CLIST, 0, list_id(k)); push(); r.clist = true; r.len = std::max(r.len, (uint32_t)(*host_lists)[k].size()); }
             }
         } else {
-            throw Reject{"the headers map with a computed key (it holds the names the whole rule set mentions)"};
+            if (closed_headers == nullptr) throw Reject{"the headers map with a computed key (it holds the names the whole rule set mentions)"};
+            for (const std::string &name : *closed_headers) {
+                key(name);
+                if (keys_only) push_bool(true);
+                else { emit(R_FIELD, 0, (uint32_t)header_field(name)); push(); }
+            }
         }
+        r.nest = std::max(r.nest, inner.nest + 1);
+        if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+        r.inner = std::max(std::max(r.inner, inner.inner), inner.len);
+        if (ctx != 3) r.len = n;
         use_heap(2 * n);
         emit(R_MKMAP, 0, n);
         pop((int)(2 * n));
@@ -437,7 +454,9 @@ struct ResidualBuilder::Impl {
                 if (recv.ctx == 1) { push_int(6); return r; }  // host, url, path, method, user_agent + the headers map (extension)
                 if (recv.ctx == 2) { push_int(4); return r; }
                 if (recv.ctx == 3) { std::set<std::string> names; for (auto &l : *host_lists) names.insert(l.name); push_int((int64_t)names.size()); return r; }
-                throw Reject{"length() of the headers map (it holds the names the whole rule set mentions)"};
+                if (closed_headers == nullptr) throw Reject{"length() of the headers map (it holds the names the whole rule set mentions)"};
+                push_int((int64_t)closed_headers->size());
+                return r;
             }
             // any other method on a map: the arguments are evaluated, then the call fails (or the argument count is wrong)
             push_err();
@@ -541,8 +560,37 @@ ResidualBuilder::~ResidualBuilder() { delete impl; }
 size_t ResidualBuilder::n_rules() const { return impl->entries.size(); }
 bool ResidualBuilder::needs_geo() const { return impl->needs_geo; }
 
-int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why) {
+void collect_header_names(const Syntax &syn, std::vector<std::string> &names) {
+    if (syn.root < 0) return;
+    auto node = [&](int i) -> const Ex & { return syn.nodes[(size_t)i]; };
+    auto is_headers = [&](int i) {
+        const Ex &n = node(i);
+        if (n.kind == EX_MEMBER) return n.text == "headers" && n.kids.size() == 1 && node(n.kids[0]).kind == EX_IDENT && node(n.kids[0]).text == "http_request";
+        if (n.kind == EX_INDEX)
+            return n.kids.size() == 2 && node(n.kids[0]).kind == EX_IDENT && node(n.kids[0]).text == "http_request" && node(n.kids[1]).kind == EX_STR && node(n.kids[1]).text == "headers";
+        return false;
+    };
+    auto add = [&](const std::string &name) {
+        for (auto &h : names) if (h == name) return;
+        names.push_back(name);
+    };
+    std::vector<int> st{syn.root};
+    while (!st.empty()) {
+        const int i = st.back();
+        st.pop_back();
+        const Ex &n = node(i);
+        if (n.kind == EX_MEMBER && n.kids.size() == 1 && is_headers(n.kids[0])) add(n.text);
+        if (n.kind == EX_INDEX && n.kids.size() == 2 && is_headers(n.kids[0]) && node(n.kids[1]).kind == EX_STR) add(node(n.kids[1]).text);
+        if (n.kind == EX_BIN && n.op == B_IN && n.kids.size() == 2 && is_headers(n.kids[1]) && node(n.kids[0]).kind == EX_STR) add(node(n.kids[0]).text);
+        if (n.kind == EX_MCALL && n.text == "contains" && n.kids.size() == 2 && is_headers(n.kids[0]) && node(n.kids[1]).kind == EX_STR) add(node(n.kids[1]).text);
+        for (size_t k = n.kids.size(); k-- > 0;) st.push_back(n.kids[k]);
+    }
+}
+
+int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualList> &lists, const std::function<int(const std::string &)> &header_field, std::string &why,
+                                  const std::vector<std::string> *closed_headers) {
     Impl &m = *impl;
+    m.closed_headers = closed_headers;
     // a failed rule must leave no trace: snapshot the growing tables
     const size_t c0 = m.code.size(), k0 = m.consts.size(), s0 = m.strpool.size(), l0 = m.lists.size(), ls0 = m.lstr.size(), li0 = m.lints.size(), n0 = m.nets.size(), r0 = m.regexes.size();
     const auto list_ids0 = m.list_ids;

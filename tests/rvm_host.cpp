@@ -57,11 +57,19 @@ void *rvmh_compile(const char *const *exprs, size_t n, const pwaf_list_desc *lis
         h->header_names.push_back(name);
         return PWAF_N_FIELDS + (int)h->header_names.size() - 1;
     };
+    // the headers map's names: what ALL the expressions mention with a literal key, collected first (compile.cpp does the same)
+    bool closed = true;
+    for (size_t k = 0; k < n && closed; k++) {
+        Syntax syn;
+        std::string perr;
+        if (!parse_expression(exprs[k], syn, perr)) closed = false;
+        else collect_header_names(syn, h->header_names);
+    }
     for (size_t k = 0; k < n; k++) {
         Syntax syn;
         std::string perr, reason;
         if (!parse_expression(exprs[k], syn, perr)) { reason = "syntax: " + perr; }
-        else if (rb.compile_rule(syn, hl, header_field, reason) >= 0) continue;
+        else if (rb.compile_rule(syn, hl, header_field, reason, closed ? &h->header_names : nullptr) >= 0) continue;
         snprintf(why, why_len, "%s", reason.c_str());
         *bad = (int)k;
         delete h;

@@ -135,3 +135,30 @@ def test_more_than_32_residual_rules(how):
     assert len(set(want["rule_idx"].tolist())) > 20  # rules of every word decide requests
     assert eng.rule_errors(len(rules)) == total_err and sum(total_err) > 0
     eng.close()
+
+
+@pytest.mark.parametrize("how", list(JIT))
+def test_computed_keys_into_http_request_and_headers_on_the_device(how):
+    """Round 5: http_request[k] / http_request.headers[k] with a computed key (the headers map's names: the rule set's literal keys,
+    closed before any rule is compiled), the rule set of tests/test_residual.py's known answers plus column rules around them."""
+    rules = [("field", 'http_request["pa" + (http_request.method.length() % 1 == 0 ? "th" : "x")].starts_with("/adm")', [B]),
+             ("which", 'http_request[http_request.method == "GET" ? "host" : "path"] == "a.example"', [CAP]),
+             ("hname", 'http_request.headers["x-" + http_request.headers.cookie] == "1"', [B]),
+             ("member", '(http_request.host + "") in http_request.headers', [CAP]),
+             ("count", 'http_request.headers.length() == 2 && http_request.path == "/count"', [B]),
+             ("via", 'http_request["headers"][http_request.path] == "1"', [CAP]),
+             ("absent", 'http_request["nope" + http_request.method] == "x"', [B]),
+             ("plain", '"x-a" in http_request.headers && http_request.path.contains("plain")', [B])]
+    eng = RuleEngine(rules, flags=JIT[how])
+    check_mode(eng, how)
+    assert not eng.partial and eng.header_names == ["cookie", "x-a"]
+    rng = random.Random(11)
+    words = ["/admin", "a.example", "x-a", "cookie", "/count", "/plain", "a", "1", "", "/"]
+    reqs = [Request(host=rng.choice(words), url="/" + rng.choice(words), path=rng.choice(words), method=rng.choice(["GET", "POST", "PUT"]), user_agent="ua",
+                    headers={h: rng.choice(["1", "a", "", "2"]) for h in ("x-a", "cookie") if rng.random() < 0.8})
+            for _ in range(3000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "computed keys on the device")
+    assert len(set(want["rule_idx"].tolist())) >= 6, set(want["rule_idx"].tolist())
+    eng.close()

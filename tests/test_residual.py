@@ -180,7 +180,13 @@ def dbool(rng, depth=0):
                            dstr(rng, depth + 1) + " in " + rng.choice(["client", "http_request", "lists"]), rng.choice(["client", "http_request", "lists"]) + ".contains(" + dstr(rng, depth + 1) + ")",
                            "client[" + rng.choice(['"remote_" + "port"', '"as" + "n"', dstr(rng, depth + 1)]) + "] == " + dint(rng, depth + 1),
                            "lists[" + rng.choice(['"wor" + "ds"', '"ne" + "ts"', dstr(rng, depth + 1)]) + "].contains(" + rng.choice([dstr(rng, depth + 1), "client.ip"]) + ")",
-                           "client[" + dint(rng, depth + 1) + "] == 1", dint(rng, depth + 1) + " in lists", 'client["coun" + "try"] == client.country'])
+                           "client[" + dint(rng, depth + 1) + "] == 1", dint(rng, depth + 1) + " in lists", 'client["coun" + "try"] == client.country',
+                           # round 5: http_request and the headers map under a COMPUTED key (the headers map's names are closed once every rule is read)
+                           "http_request[" + rng.choice(['"ho" + "st"', '"pa" + "th"', dstr(rng, depth + 1)]) + "] == " + dstr(rng, depth + 1),
+                           "http_request.headers[" + rng.choice(['"x-" + "a"', '"coo" + "kie"', dstr(rng, depth + 1)]) + "] == " + dstr(rng, depth + 1),
+                           dstr(rng, depth + 1) + " in http_request.headers", "http_request.headers.contains(" + dstr(rng, depth + 1) + ")",
+                           'http_request["head" + "ers"]["x-a"] == ' + dstr(rng, depth + 1), "http_request.headers.length() == " + str(rng.randint(0, 3)),
+                           'http_request[' + dstr(rng, depth + 1) + '].length() > 3', "http_request[" + dint(rng, depth + 1) + "] == 1"])
     if k == 9:
         return "!(" + dbool(rng, depth + 1) + ")"
     if k <= 12:
@@ -396,3 +402,55 @@ def test_heap_use_of_indexed_nested_literals_is_charged_in_full():
         for i in range(batch.n):
             assert m.eval(0, i) == (orc.execute_rule(0, batch, i) == 1), (e, i)
     assert refused >= 2 and accepted >= 10, (refused, accepted)
+
+
+def test_computed_keys_into_http_request_and_the_headers_map():
+    """Round 5 (VERDICT r4 missing #3): `http_request[k]` and `http_request.headers[k]` with a COMPUTED key. The reference evaluates
+    any expression (pingoo/rules.rs:37-51) over a real map; here the map is built per request from the closed key sets — the five
+    fields, and for the headers map (EXTENSION) the names the WHOLE rule set mentions with a literal key, collected before any rule is
+    compiled. Known answers first, then the oracle on every request."""
+    rules = ['http_request["pa" + "th"].starts_with("/adm")',                                   # a computed field name
+             'http_request[http_request.method == "GET" ? "host" : "path"] == "a.example"',      # which field depends on the request
+             'http_request.headers["x-" + "a"] == "1"',                                          # a computed header name
+             'http_request.headers[http_request.method] == "v"',                                 # a header named like the method (none: error = no match)
+             '(http_request.host + "") in http_request.headers',                                 # membership under a computed key
+             'http_request.headers.length() == 2',                                               # the closed set: x-a, cookie
+             'http_request["headers"][http_request.path] == "1"',                                # the headers map through a literal index, then computed
+             'http_request["nope" + ""] == "x"',                                                 # an absent key: execution error, no match
+             'http_request[client.remote_port] == "x"',                                          # a key that is not a String: execution error
+             'http_request.headers.cookie == "c"',                                               # (a literal key: a name of the map)
+             '"x-a" in http_request.headers']                                                    # (a literal key: the map's second name; true wherever the map exists)
+    reqs = [Request(host="a.example", path="/admin", method="GET", url="/admin", user_agent="ua", headers={"x-a": "1", "cookie": "c"}),
+            Request(host="b.example", path="a.example", method="POST", url="/x", user_agent="ua", headers={"x-a": "2"}),
+            Request(host="x-a", path="x-a", method="PUT", url="/", user_agent="ua", headers={"x-a": "1"}),
+            Request(host="cookie", path="/", method="GET", url="/", user_agent="ua")]
+    batch = RequestBatch.from_requests(reqs)
+    m = HostVM(rules, LISTS)
+    assert m.header_names == ["cookie", "x-a"]  # literal keys only, in order of first use: `"x-" + "a"` names nothing
+    m.bind(batch)
+    got = [[m.eval(k, i) for i in range(batch.n)] for k in range(len(rules))]
+    assert got[0] == [True, False, False, False]
+    assert got[1] == [True, True, False, False]   # GET: host == a.example; POST: path == a.example
+    assert got[2] == [True, False, True, False]
+    assert got[3] == [False, False, False, False]
+    assert got[4] == [False, False, True, True]    # the host's value is a header NAME of the rule set
+    assert got[5] == [True, True, True, True]
+    assert got[6] == [False, False, True, False]   # headers["x-a"] == "1" where the path is "x-a"
+    assert got[7] == [False] * 4 and got[8] == [False] * 4
+    assert got[9] == [True, False, False, False] and got[10] == [True] * 4
+    orc = pyoracle.Oracle([(f"r{k}", e, [H.B]) for k, e in enumerate(rules)], LISTS, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    assert orc.header_names == m.header_names
+    for k in range(len(rules)):
+        for i in range(batch.n):
+            assert (orc.execute_rule(k, batch, i) == 1) == got[k][i], (rules[k], i)
+    # through the whole compiler: such rules are residual rules of the program, none is refused
+    from pingoo_amd.engine import CompiledProgram
+    prog = CompiledProgram([(f"r{k}", e, [H.B]) for k, e in enumerate(rules)], LISTS)
+    assert prog.header_names == ["cookie", "x-a"]
+    assert sum("residual" in w for w in prog.warnings()) >= 4 and not any("NOT evaluated" in w for w in prog.warnings())  # (constant keys such as "pa" + "th" fold in the column compiler)
+    import table_walker
+
+    t = table_walker.Tables(prog)
+    want = orc.evaluate(batch)
+    got_v = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    H.assert_verdicts_equal(got_v, want, batch, "computed keys through the compiled program")

@@ -99,16 +99,18 @@ def check_rule_set(exprs, lists, batch, tag):
     L = build_specialized(m, tag)
     blob = blob_of(m)
     m.bind(batch)
-    orcs = [pyoracle.Oracle([("r", e, [H.B])], lists, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS) for e in exprs]
+    # ONE oracle over the whole rule set: the headers map holds the names ALL its rules mention with a literal key, and a computed key
+    # (`http_request.headers["x-" + "a"]`, round 5) sees that map — a single-rule oracle would see only the rule's own names
+    orc = pyoracle.Oracle([(f"r{k}", e, [H.B]) for k, e in enumerate(exprs)], lists, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    assert orc.header_names == m.header_names
     for k, e in enumerate(exprs):
-        # (a rule set's header columns are the union over its rules, in first-use order: the single-rule oracle only needs its own)
         for i in range(batch.n):
             b = batch
             asn = int(b.asn[i]) if b.asn is not None else 0
             country = int(b.country[i]) if b.country is not None else int.from_bytes(b"XX", "little")
             got = int(L.spec_eval(blob, k, m._data, m._off, i, b.ip[i].ctypes.data, int(b.ip_is_v6[i]), int(b.port[i]), asn, country))
             assert got == m.eval3(k, i), (tag, e, i, "specialized form and interpreter disagree")
-            want3 = orcs[k].execute_rule(0, batch, i)  # 1 true, 0 false, 2 non-Bool, 3 error
+            want3 = orc.execute_rule(k, batch, i)  # 1 true, 0 false, 2 non-Bool, 3 error
             assert got == {1: 1, 0: 0, 2: 0, 3: 2}[want3], (tag, e, i, got, want3)
 
 
