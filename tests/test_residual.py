@@ -339,11 +339,28 @@ def test_rule_sets_mixing_column_and_residual_rules_through_the_compiler(seed):
     t = table_walker.Tables(prog)
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, f"seed {seed}: {[r[1] for r in rules]}")
-    test_rule_sets_mixing_column_and_residual_rules_through_the_compiler.n_residual = getattr(test_rule_sets_mixing_column_and_residual_rules_through_the_compiler, "n_residual", 0) + getattr(t, "n_residual", 0)
 
 
 def test_the_mixed_rule_sets_did_exercise_residual_rules():
-    assert getattr(test_rule_sets_mixing_column_and_residual_rules_through_the_compiler, "n_residual", 0) >= 20
+    """(Counts by compiling the first seeds' rule sets again: an accumulator filled by the test above is empty when pytest-xdist ran
+    that test in other worker processes.)"""
+    from pingoo_amd.engine import CompiledProgram
+
+    n_residual = 0
+    for seed in range(30):
+        rng = random.Random(616100 + seed)
+        rules = []
+        for k in range(rng.randint(2, 10)):
+            e = dbool(rng) if rng.random() < 0.5 else H.rexpr(rng, LISTS)
+            try:
+                pyoracle.compile_expression(e)
+            except pyoracle.OracleError:
+                e = "true"
+            rules.append((f"r{k}", e, H.fuzz_actions(rng)))
+        flags = rng.choice([0, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
+        prog = CompiledProgram(rules, LISTS, flags=flags | _abi.OPT_LENIENT)
+        n_residual += sum("residual program" in w for w in prog.warnings())
+    assert n_residual >= 20, n_residual
 
 
 def test_dnf_explosion_falls_to_the_interpreter():
