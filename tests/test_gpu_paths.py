@@ -423,7 +423,7 @@ def test_lenient_node_keeps_its_engines_when_a_rule_is_refused():
     that as a failure (and leak the engine). The node now exists, says `partial`, and the refused rule alone never matches."""
     from pingoo_amd.engine import NodeEngine, PwafError
 
-    rules = [("dyn", 'http_request[client.country] == "x"', [B]), ("ok", 'http_request.path == "/a"', [B])]
+    rules = [("dyn", 'http_request.path.matches(http_request.host)', [B]), ("ok", 'http_request.path == "/a"', [B])]  # (a regex compiled per request: refused)
     with pytest.raises(PwafError):
         NodeEngine(rules, devices=[0, 0])
     node = NodeEngine(rules, devices=[0, 0], flags=_abi.OPT_LENIENT)
