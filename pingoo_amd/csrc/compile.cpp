@@ -147,6 +147,17 @@ public:
     uint32_t max_dfa_states = 0, max_table_bytes = 0;
 
     // ---- atoms ----
+    // Once the rule set's header names are CLOSED (compile_program collected them from every rule's literal keys before compiling any),
+    // a name that is not among them is an ABSENT key of the headers map — reachable through a key that only constant folding makes a
+    // literal (`http_request["head" + "ers"]["x"]`, `http_request.headers["x-" + "a"]`): the oracle's headers map does not hold it
+    // (oracle_engine.cpp: the names come from literal keys in the SYNTAX), so neither does this one. -1 = absent.
+    bool headers_closed = false;
+    int header_lookup(const std::string &name) {
+        if (!headers_closed) return header_field(name);
+        for (size_t k = 0; k < prog.header_names.size(); k++)
+            if (prog.header_names[k] == name) return PWAF_N_FIELDS + (int)k;
+        return -1;
+    }
     int header_field(const std::string &name) {
         for (size_t k = 0; k < prog.header_names.size(); k++)
             if (prog.header_names[k] == name) return PWAF_N_FIELDS + (int)k;
@@ -496,7 +507,7 @@ public:
             }
             if (coll.k == SVal::MAP_HTTP) { for (auto f : kFieldNames) if (x.c.s == f) return sv_bool(true); return sv_bool(x.c.s == "headers"); }
             // (the headers map holds exactly the names the rule set mentions: asking for one makes it one of them)
-            if (coll.k == SVal::MAP_HEADERS) { header_field(x.c.s); return sv_bool(true); }
+            if (coll.k == SVal::MAP_HEADERS) return sv_bool(header_lookup(x.c.s) >= 0);
             if (coll.k == SVal::MAP_CLIENT) return sv_bool(x.c.s == "ip" || x.c.s == "remote_port" || x.c.s == "asn" || x.c.s == "country");
             if (coll.k == SVal::MAP_LISTS) { for (auto &l : lists) if (l.name == x.c.s) return sv_bool(true); return sv_bool(false); }
             for (auto &p : coll.c.pairs) if (p.first == x.c.s) return sv_bool(true);
@@ -703,7 +714,8 @@ public:
         if (o.k == SVal::MAP_HEADERS) {
             // EXTENSION (no reference counterpart, pingoo/rules.rs:16-25): one more String field per header name
             v.k = SVal::FIELD;
-            v.field = header_field(key);
+            v.field = header_lookup(key);
+            if (v.field < 0) return sv_err("no such key: " + key);
             return v;
         }
         if (o.k == SVal::MAP_CLIENT) {
@@ -1117,11 +1129,12 @@ int compile_program(const CompileInput &in, std::unique_ptr<Program> &out, pwaf_
         }
         if (names.size() > kMaxHeaders) headers_closed = false;  // (the rule that mentions one name too many is refused below, as before)
         else for (const std::string &nm : names) rc.header_field(nm);
+        rc.headers_closed = headers_closed;
     }
     auto try_residual = [&](size_t k, const std::string &col_why, std::string &why) -> int {
         if (P.flags & PWAF_OPT_NO_RESIDUAL) { why = col_why; return -1; }
         std::string rwhy;
-        const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_field(name); }, rwhy, headers_closed ? &P.header_names : nullptr);
+        const int idx = residual.compile_rule(syntaxes[k], rlists, [&](const std::string &name) { return rc.header_lookup(name); }, rwhy, headers_closed ? &P.header_names : nullptr);
         if (idx < 0) { why = col_why + "; and the residual interpreter cannot take it either: " + rwhy; return -1; }
         if (P.residual_rule.size() <= (size_t)idx) P.residual_rule.resize((size_t)idx + 1, 0xFFFFFFFFu);
         P.residual_rule[(size_t)idx] = (uint32_t)k;

@@ -207,7 +207,9 @@ struct ResidualBuilder::Impl {
             return r;
         }
         if (ctx == 4) {  // EXTENSION: one String column per header name the rule set mentions
-            emit(R_FIELD, 0, (uint32_t)header_field(key));
+            const int f = header_field(key);
+            if (f < 0) { push_err(); return r; }  // (the names are closed and this is none of them: an absent key)
+            emit(R_FIELD, 0, (uint32_t)f);
             push();
             return r;
         }
@@ -228,7 +230,7 @@ struct ResidualBuilder::Impl {
     bool ctx_has(int ctx, const std::string &key) {
         static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
         if (ctx == 1) { for (auto f : kFields) if (key == f) return true; return key == "headers"; }
-        if (ctx == 4) { header_field(key); return true; }  // (the headers map holds exactly the names the rule set mentions: asking for one makes it one of them)
+        if (ctx == 4) return header_field(key) >= 0;  // (the headers map holds exactly the names the rule set mentions with a literal key: open set — asking makes it one; closed — it is one or not)
         if (ctx == 2) return key == "ip" || key == "remote_port" || key == "asn" || key == "country";
         for (auto &l : *host_lists) if (l.name == key) return true;
         return false;

@@ -52,13 +52,15 @@ void *rvmh_compile(const char *const *exprs, size_t n, const pwaf_list_desc *lis
     }
     auto *h = new Handle;
     ResidualBuilder rb;
+    // the headers map's names: what ALL the expressions mention with a literal key, collected first (compile.cpp does the same); once
+    // closed, any other name is an absent key (-1)
+    bool closed = true;
     auto header_field = [&](const std::string &name) -> int {
         for (size_t k = 0; k < h->header_names.size(); k++) if (h->header_names[k] == name) return PWAF_N_FIELDS + (int)k;
+        if (closed) return -1;
         h->header_names.push_back(name);
         return PWAF_N_FIELDS + (int)h->header_names.size() - 1;
     };
-    // the headers map's names: what ALL the expressions mention with a literal key, collected first (compile.cpp does the same)
-    bool closed = true;
     for (size_t k = 0; k < n && closed; k++) {
         Syntax syn;
         std::string perr;

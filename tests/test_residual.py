@@ -471,3 +471,30 @@ def test_computed_keys_into_http_request_and_the_headers_map():
     want = orc.evaluate(batch)
     got_v = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got_v, want, batch, "computed keys through the compiled program")
+
+
+def test_header_keys_that_only_constant_folding_makes_literal():
+    """Found by tools/gpufuzz.py (round 5): the column compiler folds `"head" + "ers"` and `"x-" + "a"` to constants and used to treat the
+    result like a LITERAL key — registering a header name the oracle's headers map does not hold (its names come from literal keys in the
+    syntax: oracle_engine.cpp). With the names closed before compilation such a key is an absent key: an error under [], false under `in`."""
+    import table_walker
+    from pingoo_amd.engine import CompiledProgram
+
+    reqs = [Request(host="h", path="/", url="/1", user_agent="ua", headers={"x-a": "1", "cookie": "c"}), Request(host="h", path="/", url="/", user_agent="ua", headers={"x-a": "2"}),
+            Request(host="h", path="/", url="/", user_agent="ua")]
+    for rules, names in (([("fold", 'http_request["head" + "ers"]["x-a"] == "1"', [H.B]), ("foldin", '("x-" + "a") in http_request.headers', [H.CAP]),
+                           ("foldidx", 'http_request.headers["x-" + "a"] != "zz"', [H.B]), ("last", 'http_request.path == "/"', [H.CAP])], []),
+                         ([("fold", 'http_request["head" + "ers"]["x-a"] == "1"', [H.B]), ("lit", 'http_request.headers["x-a"] == "2"', [H.CAP]),
+                           ("foldin", '("coo" + "kie") in http_request.headers', [H.B]), ("last", 'http_request.path == "/"', [H.CAP])], ["x-a"])):
+        prog = CompiledProgram(rules, LISTS)
+        orc = pyoracle.Oracle(rules, LISTS)
+        assert prog.header_names == names == orc.header_names
+        batch = RequestBatch.from_requests(reqs)
+        want = orc.evaluate(batch)
+        t = table_walker.Tables(prog)
+        got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+        H.assert_verdicts_equal(got, want, batch, str(names))
+        if names:
+            assert want["rule_idx"].tolist() == [0, 1, 3]  # the folded key reads the column a literal mention made; "cookie" is no name of this set
+        else:
+            assert want["rule_idx"].tolist() == [3, 3, 3]  # no name at all: every folded key is absent
