@@ -21,7 +21,7 @@ from pingoo_amd import RequestBatch, _abi  # noqa: E402
 from pingoo_amd.engine import CompiledProgram  # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-t0, bad, n_rules = time.time(), [], 0
+t0, bad, n_rules, n_refused = time.time(), [], 0, 0
 for seed in range(lo, hi):
     rng = random.Random(8_000_000 + seed)
     rules = []
@@ -35,7 +35,11 @@ for seed in range(lo, hi):
     geo = H.fuzz_geoip(rng) if seed % 2 else None
     flags = rng.choice([0, _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS])
     prog = CompiledProgram(rules, TR.LISTS, geo, flags=flags | _abi.OPT_LENIENT)
-    seen, _ = H.as_the_engine_sees(rules, prog)
+    try:
+        seen, _ = H.as_the_engine_sees(rules, prog)
+    except AssertionError:  # a rule beyond the interpreter's documented limits (64 heap items, 24 stack slots, 4 levels): refused, by index —
+        n_refused += 1      # the set is skipped (the oracle would have to forget the refused rule's header names as well)
+        continue
     reqs = TR.requests(rng, min(rng.choice([1, 64, 65, 300, 1000]), 65))  # (the walker is Python: bounded batches)
     if geo is not None:
         for r in reqs:
@@ -49,4 +53,4 @@ for seed in range(lo, hi):
     if prog.header_names != orc.header_names or ((got["action"] != want["action"]) | (got["rule_idx"] != want["rule_idx"])).any():
         bad.append(seed)
         print("MISMATCH seed", seed, prog.header_names, orc.header_names, [r[1] for r in rules], flush=True)
-print("done", lo, hi, "rules", n_rules, "mismatching seeds", len(bad), bad[:10], "time", round(time.time() - t0, 1))
+print("done", lo, hi, "rules", n_rules, "rule sets with a refused rule", n_refused, "mismatching seeds", len(bad), bad[:10], "time", round(time.time() - t0, 1))
