@@ -1,5 +1,5 @@
 """Extended CPU fuzz: compiled tables (interpreted by tests/table_walker.py) against the oracle on random rule sets.
-usage: [PWAF_FUZZ_STRIDE2=1] python tools/bigfuzz.py <first seed> <last seed>   (about 70 seeds per second and core; no GPU involved)"""
+usage: [PWAF_FUZZ_STRIDE2=1] [PWAF_FUZZ_TUNE=1] python tools/bigfuzz.py <first seed> <last seed>   (about 70 seeds per second and core; no GPU involved)"""
 import sys, random, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +30,10 @@ for seed in range(lo, hi):
         prog = CompiledProgram(rules, lists, geo, flags=flags | _abi.OPT_LENIENT, max_table_bytes=rng.choice([0, 0, 2048, 4096]), max_dfa_states=rng.choice([0, 0, 40]))
     except UnsupportedExpression:
         continue
+    if os.environ.get("PWAF_FUZZ_TUNE"):
+        # profile-guided tables (pwaf_program_tune: prefilter bigram statistics and heads, stride choice, LDS-resident rows) from a traffic
+        # sample of random size: tuning may change speed, never a verdict
+        prog.tune(RequestBatch.from_requests(H.fuzz_requests(rng, rng.choice([1, 5, 48, 200]), with_geo)))
     batch = RequestBatch.from_requests(H.fuzz_requests(rng, 48, with_geo))
     rules, _ = H.as_the_engine_sees(rules, prog)
     want = pyoracle.Oracle(rules, lists, geo, flags=flags).evaluate(batch)
