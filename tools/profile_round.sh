@@ -5,7 +5,7 @@
 # the issue / LDS counters per product kernel (counters.txt). The bench line itself comes from a plain `python bench.py` run.
 TAG=${1:-r5}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-modes --no-pcie --no-config5 $@"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-extra-modes --no-pcie --no-config5 $@"   # (the driver's step counts: a 4-launch trace caught one box before its clocks settled — 0.624 ms for a kernel the 25-launch trace and the bench's own events put at 0.572 / 0.577)
 export PWAF_COMMIT=$(cat $R/.commit_id 2>/dev/null || echo "?")
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
