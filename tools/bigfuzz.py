@@ -1,5 +1,5 @@
 """Extended CPU fuzz: compiled tables (interpreted by tests/table_walker.py) against the oracle on random rule sets.
-usage: [PWAF_FUZZ_STRIDE2=1] [PWAF_FUZZ_TUNE=1] python tools/bigfuzz.py <first seed> <last seed>   (about 70 seeds per second and core; no GPU involved)"""
+usage: [PWAF_FUZZ_STRIDE2=1] [PWAF_FUZZ_TUNE=1] [PWAF_FUZZ_MANY=1] python tools/bigfuzz.py <first seed> <last seed>   (about 70 seeds per second and core; no GPU involved)"""
 import sys, random, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,8 @@ for seed in range(lo, hi):
     geo = H.fuzz_geoip(rng) if rng.random() < 0.7 else None
     with_geo = rng.random() < 0.3
     rules = []
-    for k in range(rng.randint(1, 12)):
+    many = bool(os.environ.get("PWAF_FUZZ_MANY"))  # rule sets of 40 - 300 rules: pass splitting, atom de-duplication, rule bitmaps beyond one word
+    for k in range(rng.choice([40, 80, 150, 300]) if many else rng.randint(1, 12)):
         e = H.rexpr(rng, lists) if rng.random() < 0.95 else None
         acts = H.fuzz_actions(rng)
         rules.append((f"r{k}", e, acts))
