@@ -225,6 +225,12 @@ public:
 
     // one request string field against another (pingoo/rules.rs:37-51 evaluates any expression: `url.contains(host)`,
     // `host == headers["x-forwarded-host"]`, `path.length() < url.length()` are all legal): a device atom of its own kind
+    // The device evaluates them in one pseudo pass that holds kMaxFcmpAtoms predicates over kMaxFcmpFields distinct fields (fcmp_kernel:
+    // the field pointers travel as kernel arguments). A rule that would need one more is lowered to a residual program instead (the caller
+    // catches Unsupported) — it used to fail the WHOLE creation, lenient or not, without naming a rule. (Counted over every atom made, used
+    // or not: conservative.)
+    std::set<std::string> fcmp_keys;
+    std::vector<int> fcmp_fields;
     TF fcmp_atom(int a, int b, FcmpOp op) {
         Atom at;
         at.kind = ATOM_FCMP;
@@ -232,6 +238,16 @@ public:
         at.ref = (uint32_t)b;
         at.c = (int64_t)op;
         at.key = "F" + std::to_string(a) + ":" + std::to_string((int)op) + ":" + std::to_string(b);
+        if (!fcmp_keys.count(at.key)) {
+            auto known = [&](int f) { return std::find(fcmp_fields.begin(), fcmp_fields.end(), f) != fcmp_fields.end(); };
+            const size_t nf = fcmp_fields.size() + (known(a) ? 0 : 1) + ((b != a && !known(b)) ? 1 : 0);
+            if (fcmp_keys.size() >= kMaxFcmpAtoms || nf > kMaxFcmpFields)
+                throw Unsupported{"more field-against-field predicates than the device's table holds (" + std::to_string(kMaxFcmpAtoms) + " predicates over " +
+                                  std::to_string(kMaxFcmpFields) + " distinct fields)"};
+            fcmp_keys.insert(at.key);
+            for (int f : {a, b})
+                if (std::find(fcmp_fields.begin(), fcmp_fields.end(), f) == fcmp_fields.end()) fcmp_fields.push_back(f);
+        }
         return atom_tf(intern_atom(std::move(at)));
     }
 

@@ -341,3 +341,31 @@ def test_utf8_stream_of_the_1k_rule_set():
         non_ascii += not b.field_bytes(1, i).isascii()
         assert t.evaluate(b, i) == (int(wb[i]["action"]), int(wb[i]["rule_idx"])), (i, b.field_bytes(1, i))
     assert non_ascii > 150 and np.count_nonzero(wb["action"]) > np.count_nonzero(wa["action"]) + 10
+
+
+def test_field_against_field_predicates_beyond_the_device_table_become_residual_rules():
+    """The device evaluates field-against-field atoms in one pseudo pass of 32 predicates over 8 distinct fields. A rule set that needs more
+    used to fail creation as a whole (PWAF_E_UNSUPPORTED without a rule index, lenient or not: found by tools/headerfuzz.py, round 5); the
+    rules beyond the table are now lowered to residual programs — same verdicts, by the reference's rule: every valid expression is
+    evaluated (pingoo/rules.rs:37-51)."""
+    import numpy as np
+    import table_walker
+    from pingoo_amd import Request, RequestBatch
+    from pingoo_amd.engine import CompiledProgram
+
+    names = [f"x-h{k}" for k in range(12)]
+    rules = [(f"r{k}", f'http_request.headers["{names[k % 12]}"] {["==", "!="][k % 2]} http_request.{["host", "path", "method", "url"][k % 4]}' +
+              (f' && http_request.headers["{names[(k + 5) % 12]}"].contains(http_request.host)' if k % 3 == 0 else ""), [H.B if k % 2 else H.CAP]) for k in range(48)]
+    prog = CompiledProgram(rules)  # strict: must not raise
+    assert sorted(prog.header_names) == sorted(names) and prog.header_names == pyoracle.Oracle(rules).header_names  # (order of first use)
+    n_res = sum("residual" in w for w in prog.warnings())
+    assert 8 <= n_res < 48, n_res  # the table's share stays on the column path, the rest is residual
+    rng = random.Random(3)
+    reqs = [Request(host=rng.choice(["a", "b", ""]), path="/" + rng.choice(["a", "b"]), url="/" + rng.choice(["a", "b"]), method=rng.choice(["a", "GET"]), user_agent="ua",
+                    headers={nm: rng.choice(["a", "b", "/a", "/b", "GET", ""]) for nm in names if rng.random() < 0.7}) for _ in range(200)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    t = table_walker.Tables(prog)
+    got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    H.assert_verdicts_equal(got, want, batch, "field-against-field overflow")
+    assert len(set(want["rule_idx"].tolist())) >= 4

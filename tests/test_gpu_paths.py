@@ -497,3 +497,21 @@ def test_verdict_sparse_column_file_dense_and_spill_agree():
         H.assert_verdicts_equal(e.evaluate_batch(batch), want, batch, f"many atoms per request, flags {fl}")
         e.close()
     assert len(set(want["action"].tolist())) >= 2
+
+
+def test_field_against_field_overflow_runs_as_residual_rules_on_the_device():
+    """48 rules of field-against-field predicates over 12 header columns: the device's table holds 32 predicates over 8 fields; the rest
+    is lowered to residual programs (round 5; creation used to fail). Same verdicts as the oracle, nothing refused."""
+    names = [f"x-h{k}" for k in range(12)]
+    rules = [(f"r{k}", f'http_request.headers["{names[k % 12]}"] {["==", "!="][k % 2]} http_request.{["host", "path", "method", "url"][k % 4]}' +
+              (f' && http_request.headers["{names[(k + 5) % 12]}"].contains(http_request.host)' if k % 3 == 0 else ""), [B if k % 2 else CAP]) for k in range(48)]
+    eng = RuleEngine(rules)
+    assert not eng.partial and 8 <= sum("residual" in w for w in eng.program.warnings()) < 48
+    rng = random.Random(3)
+    reqs = [Request(host=rng.choice(["a", "b", ""]), path="/" + rng.choice(["a", "b"]), url="/" + rng.choice(["a", "b"]), method=rng.choice(["a", "GET"]), user_agent="ua",
+                    headers={nm: rng.choice(["a", "b", "/a", "/b", "GET", ""]) for nm in names if rng.random() < 0.7}) for _ in range(3000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "field-against-field overflow on the device")
+    assert len(set(want["rule_idx"].tolist())) >= 4
+    eng.close()
