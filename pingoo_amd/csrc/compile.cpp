@@ -212,6 +212,7 @@ public:
         auto it = lut_index.find(k);
         uint32_t idx;
         if (it == lut_index.end()) {
+            if (prog.country_luts.size() >= kDevMaxCountryLuts) throw Unsupported{"more than " + std::to_string(kDevMaxCountryLuts) + " distinct client.country predicates"};
             idx = (uint32_t)prog.country_luts.size();
             prog.country_luts.push_back(lut);
             lut_index.emplace(k, idx);
@@ -231,6 +232,11 @@ public:
     // or not: conservative.)
     std::set<std::string> fcmp_keys;
     std::vector<int> fcmp_fields;
+    // (mirrors of the device tables' widths: kernels.h kMaxHeaderLens, engine.cpp's 128 asn comparisons / 256 country tables / 128 integer
+    // sets per client variable — the class-row and membership-row words of attr_kernel)
+    static constexpr uint32_t kDevMaxHeaderLens = 8, kDevMaxAsnCmp = 128, kDevMaxCountryLuts = 256, kDevMaxIntSets = 128;
+    std::vector<int> hlen_fields_seen;
+    uint32_t n_asn_cmp = 0, n_int_sets[2] = {0, 0};
     TF fcmp_atom(int a, int b, FcmpOp op) {
         Atom at;
         at.kind = ATOM_FCMP;
@@ -285,6 +291,20 @@ public:
             a.op = op;
             a.c = c;
             a.key = std::string(v.k == SVal::LEN ? "L" : "I") + std::to_string(v.field) + "o" + std::to_string((int)op) + ":" + std::to_string(c);
+            if (!atom_index.count(a.key)) {
+                // Device-table limits that used to fail engine creation AS A WHOLE (engine.cpp checks them again): a rule that would
+                // exceed one is lowered to a residual program instead — the caller catches Unsupported. Counted over every atom made.
+                if (v.k == SVal::LEN && v.field >= PWAF_N_FIELDS) {
+                    if (std::find(hlen_fields_seen.begin(), hlen_fields_seen.end(), v.field) == hlen_fields_seen.end()) {
+                        if (hlen_fields_seen.size() >= kDevMaxHeaderLens) throw Unsupported{"length() of more than " + std::to_string(kDevMaxHeaderLens) + " distinct headers is compared"};
+                        hlen_fields_seen.push_back(v.field);
+                    }
+                }
+                if (v.k != SVal::LEN && v.field == VAR_ASN) {
+                    if (n_asn_cmp >= kDevMaxAsnCmp) throw Unsupported{"more than " + std::to_string(kDevMaxAsnCmp) + " distinct client.asn comparisons"};
+                    n_asn_cmp++;
+                }
+            }
             r = atom_tf(intern_atom(std::move(a)));
         }
         return neg ? tf_not(r) : r;
@@ -339,6 +359,11 @@ public:
         a.field = (uint8_t)v.field;
         a.ref = idx;
         a.key = "J" + std::to_string(v.field) + ":" + std::to_string(idx);
+        if (!atom_index.count(a.key)) {
+            uint32_t &cnt = n_int_sets[v.field == VAR_ASN ? 1 : 0];
+            if (cnt >= kDevMaxIntSets) throw Unsupported{"more than " + std::to_string(kDevMaxIntSets) + " integer-set predicates on one client variable"};
+            cnt++;
+        }
         return atom_tf(intern_atom(std::move(a)));
     }
 

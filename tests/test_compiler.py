@@ -369,3 +369,37 @@ def test_field_against_field_predicates_beyond_the_device_table_become_residual_
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, "field-against-field overflow")
     assert len(set(want["rule_idx"].tolist())) >= 4
+
+
+@pytest.mark.parametrize("what", ["asn_comparisons", "header_lengths", "country_tables", "port_sets"])
+def test_rule_sets_beyond_a_device_table_width_fall_to_residual_programs(what):
+    """Widths of the attribute kernel's rows (128 asn comparisons, 8 header-length variables, 256 country tables, 128 integer sets per
+    client variable) used to fail ENGINE creation as a whole once a rule set crossed one — 200 rules `client.asn == N` are a plausible rule
+    set. The rule that would cross a width is now lowered to a residual program (round 5): nothing refused, same verdicts."""
+    import table_walker
+
+    rng = random.Random(17)
+    if what == "asn_comparisons":
+        rules = [(f"r{k}", f"client.asn == {1000 + k}", [H.B]) for k in range(200)]
+        n_over = 200 - 128
+    elif what == "header_lengths":
+        rules = [(f"r{k}", f'http_request.headers["x-h{k}"].length() > {k % 4}', [H.B]) for k in range(12)]
+        n_over = 12 - 8
+    elif what == "country_tables":
+        cc = [chr(65 + a) + chr(65 + b) for a in range(26) for b in range(26)]
+        rules = [(f"r{k}", f'["{cc[k]}", "{cc[(7 * k + 3) % 676]}"].contains(client.country) && client.remote_port > 5', [H.B]) for k in range(300)]
+        n_over = 300 - 256
+    else:
+        rules = [(f"r{k}", f"[{k + 2}, {k + 70000 % 60000}, 9].contains(client.remote_port)", [H.B]) for k in range(150)]
+        n_over = 150 - 128
+    prog = CompiledProgram(rules)  # strict: nothing may be refused
+    n_res = sum("residual" in w for w in prog.warnings())
+    assert n_over <= n_res < len(rules), (n_res, n_over)
+    reqs = [Request(host="h", path="/", url="/", user_agent="ua", remote_port=rng.choice([2, 3, 9, 50, 150, 10000]), asn=rng.choice([1000, 1100, 1150, 1199, 5]),
+                    country=rng.choice(["AA", "AD", "KX", "ZZ", "FR"]), headers={f"x-h{k}": "a" * rng.randint(0, 5) for k in range(12) if rng.random() < 0.6}) for _ in range(150)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    t = table_walker.Tables(prog)
+    got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    H.assert_verdicts_equal(got, want, batch, what)
+    assert len(set(want["rule_idx"].tolist())) >= 3, set(want["rule_idx"].tolist())
