@@ -515,3 +515,29 @@ def test_field_against_field_overflow_runs_as_residual_rules_on_the_device():
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "field-against-field overflow on the device")
     assert len(set(want["rule_idx"].tolist())) >= 4
     eng.close()
+
+
+@pytest.mark.parametrize("what", ["asn_comparisons", "header_lengths", "country_tables", "port_sets"])
+def test_rule_sets_beyond_a_device_row_width_create_and_match_on_the_device(what):
+    """tests/test_compiler.py: test_rule_sets_beyond_a_device_table_width_fall_to_residual_programs, on the device: the engine is CREATED
+    (it used to refuse such a rule set as a whole) and gives the oracle's verdicts; the residual rules run in the interpreter kernel here
+    (no hiprtc compile: the specialized form of the same programs is covered by tests/test_gpu_residual.py)."""
+    rng = random.Random(17)
+    if what == "asn_comparisons":
+        rules = [(f"r{k}", f"client.asn == {1000 + k}", [B]) for k in range(200)]
+    elif what == "header_lengths":
+        rules = [(f"r{k}", f'http_request.headers["x-h{k}"].length() > {k % 4}', [B]) for k in range(12)]
+    elif what == "country_tables":
+        cc = [chr(65 + a) + chr(65 + b) for a in range(26) for b in range(26)]
+        rules = [(f"r{k}", f'["{cc[k]}", "{cc[(7 * k + 3) % 676]}"].contains(client.country) && client.remote_port > 5', [B]) for k in range(300)]
+    else:
+        rules = [(f"r{k}", f"[{k + 2}, {k + 70000 % 60000}, 9].contains(client.remote_port)", [B]) for k in range(150)]
+    eng = RuleEngine(rules, flags=_abi.OPT_NO_RESIDUAL_JIT)
+    assert not eng.partial and eng.residual_mode == 1
+    reqs = [Request(host="h", path="/", url="/", user_agent="ua", remote_port=rng.choice([2, 3, 9, 50, 150, 10000]), asn=rng.choice([1000, 1100, 1150, 1199, 5]),
+                    country=rng.choice(["AA", "AD", "KX", "ZZ", "FR"]), headers={f"x-h{k}": "a" * rng.randint(0, 5) for k in range(12) if rng.random() < 0.6}) for _ in range(2000)]
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, what)
+    assert len(set(want["rule_idx"].tolist())) >= 3
+    eng.close()
