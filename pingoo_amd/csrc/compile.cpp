@@ -547,7 +547,8 @@ public:
                 return sv_err("map keys are Strings");
             }
             if (coll.k == SVal::MAP_HTTP) { for (auto f : kFieldNames) if (x.c.s == f) return sv_bool(true); return sv_bool(x.c.s == "headers"); }
-            // (the headers map holds exactly the names the rule set mentions: asking for one makes it one of them)
+            // (the headers map holds exactly the names the rule set mentions with a literal key: a literal `"x" in ..` names x — the
+            // pre-scan has seen it —, a key that only folding made constant is one of them or absent)
             if (coll.k == SVal::MAP_HEADERS) return sv_bool(header_lookup(x.c.s) >= 0);
             if (coll.k == SVal::MAP_CLIENT) return sv_bool(x.c.s == "ip" || x.c.s == "remote_port" || x.c.s == "asn" || x.c.s == "country");
             if (coll.k == SVal::MAP_LISTS) { for (auto &l : lists) if (l.name == x.c.s) return sv_bool(true); return sv_bool(false); }
