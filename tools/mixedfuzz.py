@@ -2,7 +2,7 @@
 """CPU fuzz of rule sets MIXING column rules and residual rules (the generator of tools/gpufuzz.py's mixed legs and of
 tests/test_gpu_residual.py: test_mixed_rule_sets_on_the_device) through the compiled program — tables interpreted by
 tests/table_walker.py, residual programs by the host build of residual.h — against the oracle.
-usage: python tools/mixedfuzz.py <first seed> <last seed>   (0 mismatches expected; found round 5's constant-folded header keys)"""
+usage: [PWAF_FUZZ_TUNE=1] python tools/mixedfuzz.py <first seed> <last seed>   (0 mismatches expected; found round 5's constant-folded header keys)"""
 import os
 import random
 import sys
@@ -45,6 +45,8 @@ for seed in range(lo, hi):
         for r in reqs:
             r.asn = r.country = None
     batch = RequestBatch.from_requests(reqs)
+    if os.environ.get("PWAF_FUZZ_TUNE"):  # profile-guided tables first (speed only, never a verdict)
+        prog.tune(RequestBatch.from_requests(TR.requests(rng, rng.choice([1, 8, 64]))))
     orc = pyoracle.Oracle(seen, TR.LISTS, geo, flags=flags)
     want = orc.evaluate(batch)
     t = table_walker.Tables(prog)
