@@ -47,7 +47,10 @@ def is_stale(lib: str = LIB) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
-    """variant "prof": libpwaf_prof.so, the -DPWAF_PROFILING build (timing-experiment switches for tools/*.sh; never the product)."""
+    """variant "prof": libpwaf_prof.so, the -DPWAF_PROFILING build (timing-experiment switches for tools/*.sh; never the product).
+    variant "asan": libpwaf_asan.so — the HOST translation units (rule compiler, loaders, batcher, node) under AddressSanitizer + UBSan, the
+    HIP ones as usual: for the CPU fuzz tools and the CPU suite (PWAF_LIB_VARIANT=asan, LD_PRELOAD = the toolchain's
+    libclang_rt.asan-x86_64.so, ASAN_OPTIONS=detect_leaks=0; tests/test_batcher_cpu.py's ThreadSanitizer leg cannot share a process with it)."""
     lib = LIB if not variant else os.path.join(HERE, f"libpwaf_{variant}.so")
     if not force and not is_stale(lib):
         return lib
@@ -73,7 +76,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
             cmd[1:1] = ["-x", "hip", "--offload-arch=gfx950"]
         else:
             # host-only translation units (no HIP headers): plain C++
-            cmd[1:1] = ["-x", "c++"]
+            cmd[1:1] = ["-x", "c++"] + (["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"] if variant == "asan" else [])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -83,7 +86,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *(["-fsanitize=address,undefined", "-shared-libsan"] if variant == "asan" else []), "-o", lib, *objs]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
@@ -91,4 +94,4 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, variant="prof" if "--prof" in sys.argv else ""))
+    print(build(force="--force" in sys.argv, verbose=True, variant="prof" if "--prof" in sys.argv else "asan" if "--asan" in sys.argv else ""))
