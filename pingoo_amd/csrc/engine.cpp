@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "frontend.h"
@@ -252,7 +253,8 @@ struct pwaf_engine {
     std::string residual_note;  // why the residual rules are interpreted although specialization was asked for (pwaf_engine_residual_fallback)
     JitKernel residual_jit;  // the specialized residual program (residual_jit.cpp + rtc.cpp); function == nullptr: the rules are interpreted
     DevBuf residual_blob, geo_rec_root4, geo_rec_root6, geo_rec_nodes;  // residual rules: the program image; the GeoIP trie with RECORD leaves (client.asn / country values)
-    DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals;
+    DevBuf pass_base, colmask, dir24 /* build-time only: released once compressed */, dir_chunks, dir_vals, dir_summary;
+    uint32_t dir_sum_shift = 0, dir_common = 0;  // (VerdictArgs::dir_summary)
     uint32_t n_need = 0;   // sharing owners (need-mask arrays per batch)
     uint32_t n_visit = 0;  // gap passes (visited bitmaps per batch)
     std::vector<double> mean_len;  // per field, from the tuning sample (0 = unknown)
@@ -281,6 +283,14 @@ int check_opts(const pwaf_options *o, pwaf_options &out) {
     if (o->struct_size != sizeof(pwaf_options)) return fail(PWAF_E_INVALID_ARG, "pwaf_options.struct_size mismatch");
     out = *o;
     return PWAF_OK;
+}
+
+// which verdict kernel (kernels.h: verdict_shape's mode): the entry list unless an A/B flag asks for an earlier column file
+uint32_t verdict_mode(uint32_t flags) {
+    const bool tiny = (flags & PWAF_OPT_TINY_VERDICT_SLOTS) != 0;
+    if (flags & PWAF_OPT_DENSE_VERDICT) return 0u;
+    if (flags & PWAF_OPT_SPARSE_VERDICT) return tiny ? 2u : 1u;
+    return tiny ? 4u : 3u;
 }
 
 void put_err(pwaf_compile_error *dst, const pwaf_compile_error &src) {
@@ -570,6 +580,9 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.dir_chunks = (const uint32_t *)e->dir_chunks.p;
     v.dir_vals = (const uint32_t *)e->dir_vals.p;
     v.dir_esc = (const uint2 *)e->dir_esc.p;
+    v.dir_summary = (const uint32_t *)e->dir_summary.p;
+    v.dir_sum_shift = e->dir_sum_shift;
+    v.dir_common = e->dir_common;
     v.class_rows = (const uint32_t *)e->class_rows.p;
     v.class_words = e->class_words;
     v.acmp_words = e->acmp_words;
@@ -868,8 +881,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.n = n;
     v.n_groups = n_groups;
     v.force_global_tables = (P.flags & PWAF_OPT_GLOBAL_VERDICT_TABLES) ? 1u : 0u;
-    v.sparse_mode = (P.flags & PWAF_OPT_DENSE_VERDICT) ? 0u : (P.flags & PWAF_OPT_TINY_VERDICT_SLOTS) ? 2u : 1u;
-    if (v.sparse_mode) {
+    v.sparse_mode = verdict_mode(P.flags);
+    if (v.sparse_mode >= 3) {
+        // the entry list: entries per wave in LDS, and the per-wave spill array (by column) for a group that appends more
+        const VerdictShape vs = verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size(), v.force_global_tables != 0, (int)v.sparse_mode, n_passes);
+        v.v_cap = vs.v_cap;
+        if ((rc = S.verdict_spill.reserve((size_t)verdict_blocks_sp(vs, e->n_cus) * vs.waves * P.n_cols * 8))) return rc;
+        v.spill = (unsigned long long *)S.verdict_spill.p;
+    } else if (v.sparse_mode) {
         // the sparse column file: value slots per wave, and the per-wave spill array for a group that dirties more columns than that
         const VerdictShape vs = verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size(), v.force_global_tables != 0, (int)v.sparse_mode, n_passes);
         v.v_cap = vs.v_cap;
@@ -1822,7 +1841,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         UP(trig_rules, trig_rules)
         UP(always_rules, always)
         if (verdict_shape(P.n_cols, (uint32_t)P.rules.size(), e->n_trig, (uint32_t)P.lits.size(), (P.flags & PWAF_OPT_GLOBAL_VERDICT_TABLES) != 0,
-                          (P.flags & PWAF_OPT_DENSE_VERDICT) ? 0 : (P.flags & PWAF_OPT_TINY_VERDICT_SLOTS) ? 2 : 1).waves == 0 || P.n_cols >= 65536u) {
+                          (int)verdict_mode(P.flags), (uint32_t)P.groups.size() + 2u).waves == 0 || P.n_cols >= 65536u) {
             fail(PWAF_E_UNSUPPORTED, "too many distinct predicates for one LDS column file (160 KiB)");
             return dev_fail(PWAF_E_UNSUPPORTED);
         }
@@ -1947,6 +1966,44 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             }
             if (vals.empty()) vals.push_back(0);
             if ((rc = upload(e->dir_chunks, chunks)) || (rc = upload(e->dir_vals, vals))) return dev_fail(rc);
+            // The summary bitmap (round 6; kernels.h: VerdictArgs::dir_summary). Most of the address space holds ONE entry — for a WAF
+            // rule set the one that says "no list holds this address and no rule asks about its GeoIP record" — so one bit per block
+            // of /24s answers most lookups from a bitmap small enough to stay in every XCD's L2. Granularity: /20 ... /24 blocks,
+            // whichever minimises (fraction of the space that still needs the table) + (bitmap bytes / 8 MiB); no summary when more
+            // than half of the blocks need the table anyway. Skipped with PWAF_OPT_NO_DIR_SUMMARY (A/B runs and tests: same results).
+            if (!(P.flags & PWAF_OPT_NO_DIR_SUMMARY)) {
+                std::unordered_map<uint32_t, uint64_t> run_len;
+                for (size_t x = 0; x < d24.size();) {
+                    size_t y = x + 1;
+                    while (y < d24.size() && d24[y] == d24[x]) y++;
+                    run_len[d24[x]] += y - x;
+                    x = y;
+                }
+                uint32_t common = 0;
+                uint64_t best_len = 0;
+                for (const auto &kv : run_len)
+                    if (kv.second > best_len || (kv.second == best_len && kv.first < common)) { common = kv.first; best_len = kv.second; }
+                double best_cost = 1e9;
+                uint32_t best_shift = 0;
+                std::vector<uint32_t> best_bits;
+                for (uint32_t shift = 0; shift <= 4; shift++) {
+                    const size_t n_blk = d24.size() >> shift;
+                    std::vector<uint32_t> bits(n_blk / 32, 0);
+                    uint64_t set = 0;
+                    for (size_t b = 0; b < n_blk; b++) {
+                        bool other = false;
+                        for (size_t j = b << shift; j < ((b + 1) << shift) && !other; j++) other = d24[j] != common;
+                        if (other) { bits[b >> 5] |= 1u << (b & 31); set++; }
+                    }
+                    const double cost = (double)set / (double)n_blk + (double)(n_blk / 8) / (8.0 * 1024 * 1024);
+                    if (cost < best_cost && set * 2 <= n_blk) { best_cost = cost; best_shift = shift; best_bits.swap(bits); }
+                }
+                if (!best_bits.empty()) {
+                    if ((rc = upload(e->dir_summary, best_bits))) return dev_fail(rc);
+                    e->dir_sum_shift = best_shift;
+                    e->dir_common = common;
+                }
+            }
             e->dir24.release();
         }
     }
@@ -1959,7 +2016,7 @@ void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.c_head, &g.c_entries, &g.c_bytes, &g.c_classes}) b->release(); g.fl.release(); g.rt.release(); }
     for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
-                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->class_rows,
+                      &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->dir_summary, &e->class_rows,
                       &e->dir_esc, &e->leaf_root, &e->pass_table})
         b->release();
     if (e->residual_jit.module) {  // (a module belongs to the device it was loaded on)

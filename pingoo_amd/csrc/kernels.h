@@ -336,9 +336,9 @@ struct VerdictArgs {
     uint32_t n, n_groups;
     uint32_t debug_skip;  // profiling aid (PWAF_DEBUG_SKIP env): bit k disables section k of the kernel; 0 in production
     uint32_t force_global_tables;  // PWAF_OPT_GLOBAL_VERDICT_TABLES: the verdict kernel variant for programs whose tables do not fit LDS (same results)
-    uint32_t sparse_mode;          // verdict_shape's mode: 0 dense column file, 1 sparse, 2 sparse with 8 value slots
-    uint32_t v_cap;                // sparse: value slots per wave in LDS
-    unsigned long long *spill;     // sparse, v_cap < n_cols: [workgroups x waves][n_cols - v_cap] words for the dirty columns beyond v_cap
+    uint32_t sparse_mode;          // verdict_shape's mode: 3 entry list (default), 4 entry list with 8 slots; 0 dense column file, 1 sparse, 2 sparse with 8 value slots
+    uint32_t v_cap;                // sparse: value slots per wave in LDS; entry list: entries per wave in LDS
+    unsigned long long *spill;     // sparse, v_cap < n_cols: [workgroups x waves][n_cols - v_cap] words for the dirty columns beyond v_cap; entry list: [workgroups x waves][n_cols], by column
     const uint32_t *off[PWAF_N_FIELDS];
     const uint8_t *ip;
     const uint8_t *ip_is_v6;
@@ -400,6 +400,12 @@ struct VerdictArgs {
     // entry of the first run starting inside the group, index in dir_vals of the entries of the group's further runs}.
     // dir_chunks null = walk from the roots.
     const uint32_t *dir_chunks, *dir_vals;
+    // SUMMARY in front of the table (round 6): one bit per block of 2^dir_sum_shift /24s — 0 = every /24 of the block holds the table's
+    // most common entry `dir_common` (for a WAF rule set: "no predicate cares about this address") and the lookup ends there. The bitmap
+    // is a few hundred KiB (L2-resident), the table 8 MiB (94 % of 10M uniform lookups missed the XCD's 4 MiB L2: 1.2 GB of 128-byte
+    // lines over the fabric per batch). Null: no summary (most blocks differ: the bit would cost a load and save nothing).
+    const uint32_t *dir_summary;
+    uint32_t dir_sum_shift, dir_common;
     const uint2 *dir_esc;         // {geo trie entry, ip-list trie entry} of the escaped /24s
     const uint32_t *class_rows;   // per GeoIP class: country-table words, asn-set words, asn-comparison words (class 0 = all zero)
     uint32_t class_words;
@@ -444,11 +450,12 @@ int launch_dir24(const VerdictArgs &a, void *out /* 2^24 x u32, or null: count o
 uint32_t scan_lds_bytes(uint32_t n_hot, uint32_t stride, uint32_t n_gate_atoms);
 struct VerdictShape {
     uint32_t waves, lds_bytes, lds_tables;
-    uint32_t sparse, v_cap, per_cu;  // the sparse column file (kernels.hip: verdict_kernel<.., SP>): value slots per wave, workgroups per CU
+    uint32_t sparse, v_cap, per_cu;  // sparse: 1 = the sparse column file, 2 = the entry list (verdict2_kernel); (kernels.hip: verdict_kernel<.., SP>): value slots per wave, workgroups per CU
 };
 // force_global (PWAF_OPT_GLOBAL_VERDICT_TABLES): take the variant whose program tables stay in global memory even when they would fit LDS
-// mode: 0 = the dense column file (PWAF_OPT_DENSE_VERDICT), 1 = sparse, 2 = sparse with 8 value slots (the spill path's test hook)
-VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false, int mode = 1, uint32_t n_passes = 0);
+// mode: 3 = entry list (default), 4 = entry list with 8 entry slots (PWAF_OPT_TINY_VERDICT_SLOTS: the spill path's test hook); 0 = the dense column file
+// (PWAF_OPT_DENSE_VERDICT), 1 = the sparse column file of round 5 (PWAF_OPT_SPARSE_VERDICT), 2 = that with 8 value slots (both flags)
+VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global = false, int mode = 3, uint32_t n_passes = 0);
 uint32_t verdict_blocks_sp(const VerdictShape &sh, uint32_t n_cus);
 
 }  // namespace pwaf

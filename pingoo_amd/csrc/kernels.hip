@@ -2519,6 +2519,472 @@ __global__ __launch_bounds__(SP ? 768 : 1024, (SP && BR == 1) ? 6 : 1) void verd
 }
 
 // -------------------------------------------------------------------------------------------------
+// verdict, ENTRY-LIST form (round 6; the default: VerdictArgs::sparse_mode 3, 4 = its test hook with 8 entry slots)
+// -------------------------------------------------------------------------------------------------
+// What a group of 64 requests knows about its columns arrives as a LIST already: the attribute kernel's (column, mask) pairs, one per
+// atom that holds for somebody, and per scan pass a handful of distinct atoms named by the hit records. The sparse column file above
+// turns that list into {dirty bits, rank, value} in two marking passes with a prefix sum between them and a third walk over the bitmap
+// to list the dirty columns again for the trigger step — 0.14 ms of marking and 0.08 ms of listing / triggers in a 0.31 ms kernel
+// (profiles/r6_verdict_sections.txt). Here an entry keeps the place it is appended at:
+//     slot[column]  one BYTE per column: 0 = clean, 1 + entry index, 255 = the entry lies beyond e_cap: its word is spill[column]
+//     vals[e], ecol[e]  the entry's 64-request word and its column (to clean slot[] after the group: only the entries are touched)
+// One pass over the inputs, a whole batch of up to 64 entries per instruction: lane k of the batch registers writes slot, value and column
+// of entry n + k and walks the column's trigger list. The hit records' atoms are first gathered into the batch registers with
+// v_writelane (one entry per DISTINCT atom of a pass: lanes naming the same atom are folded by a ballot). Column 0 = TRUE is entry 0
+// for the life of the wave. A column's word for the DNF step is two dependent LDS reads (slot, value), like the sparse file's.
+// Duplicates: a column belongs to one pass; inside a pass only an overflow chain (a request with more than two atoms) can name a column that
+// another lane's record already named — a pass with such a record appends one column at a time through a lookup of slot[] (rare).
+__host__ __device__ static inline uint32_t verdict_wave_lds_el(uint32_t n_cols, uint32_t n_rules, uint32_t e_cap) {
+    const uint32_t rulew = (n_rules + 31) / 32;
+    // vals | rule bitmap | entry columns (u16) | candidates (u16) | slot bytes
+    return (e_cap * 8 + rulew * 4 + ((e_cap * 2 + 3) & ~3u) + ((n_rules * 2 + 3) & ~3u) + ((n_cols + 7) & ~7u) + 15) & ~15u;
+}
+
+// one wave-uniform (column, mask) into lane l of three registers (see park64)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void park96(uint32_t &c, uint32_t &lo, uint32_t &hi, const uint32_t col, const unsigned long long m, const uint32_t l) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
+                 : "+v"(c), "+v"(lo), "+v"(hi)
+                 : "s"(col), "s"(l), "s"((uint32_t)m), "s"((uint32_t)(m >> 32))
+                 : "m0");
+}
+#pragma clang diagnostic pop
+
+template <bool LT, int BR>
+__global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, wave = wave_index(), lane = tid & 63, n_waves = blockDim.x >> 6;
+#ifdef PWAF_PROFILING
+    const uint32_t dbg_skip = a.debug_skip;
+#else
+    constexpr uint32_t dbg_skip = 0;
+#endif
+    const uint32_t rulew = (a.n_rules + 31) / 32;
+    const uint32_t e_cap = a.v_cap;  // entries held in LDS (entry 0 = TRUE included); later entries: the wave's spill array, by column
+    const uint32_t wave_bytes = verdict_wave_lds_el(a.n_cols, a.n_rules, e_cap);
+    unsigned char *mine = lds + (size_t)wave * wave_bytes;
+    unsigned long long *vals = reinterpret_cast<unsigned long long *>(mine);
+    uint32_t *rulebm = reinterpret_cast<uint32_t *>(vals + e_cap);
+    uint16_t *ecol = reinterpret_cast<uint16_t *>(rulebm + rulew);
+    uint16_t *cand = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(ecol) + ((e_cap * 2 + 3) & ~3u));
+    uint8_t *slot = reinterpret_cast<unsigned char *>(cand) + ((a.n_rules * 2 + 3) & ~3u);
+    const uint32_t slot_words = ((a.n_cols + 7) & ~7u) / 4;
+    unsigned long long *spill = a.spill + (size_t)(blockIdx.x * n_waves + wave) * a.n_cols;
+    unsigned char *tables = lds + (size_t)n_waves * wave_bytes;
+    const VerdictTables vt = verdict_tables(a.n_cols, a.n_rules, a.n_trig, a.n_lits, LT);
+    uint16_t *l_trig_off = reinterpret_cast<uint16_t *>(tables + vt.trig_off);
+    uint16_t *l_trig_rules = reinterpret_cast<uint16_t *>(tables + vt.trig_rules);
+    uint2 *l_rules = reinterpret_cast<uint2 *>(tables + vt.rules);
+    uint32_t *l_lits = reinterpret_cast<uint32_t *>(tables + vt.lits);
+    uint16_t *l_pub = reinterpret_cast<uint16_t *>(tables + vt.pub);
+    if (LT) {
+        for (uint32_t k = tid; k <= a.n_cols; k += blockDim.x) l_trig_off[k] = (uint16_t)a.trig_off[k];
+        for (uint32_t k = tid; k < a.n_trig; k += blockDim.x) l_trig_rules[k] = a.trig_rules[k];
+        for (uint32_t k = tid; k < a.n_rules; k += blockDim.x) {
+            const DevRule dr = a.rules[k];
+            l_rules[k] = make_uint2(dr.lit_off, dr.lit_cnt | ((uint32_t)dr.eff_unverified << 16) | ((uint32_t)dr.eff_verified << 24));
+            l_pub[k] = (uint16_t)dr.public_idx;
+        }
+        for (uint32_t k = tid; k < a.n_lits; k += blockDim.x) l_lits[k] = a.lits[k];
+    }
+    // the wave's slot bytes start clean; entry 0 is column 0 = TRUE
+    for (uint32_t k = lane; k < slot_words; k += 64) reinterpret_cast<uint32_t *>(slot)[k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+        slot[0] = 1;
+        vals[0] = ~0ull;
+        ecol[0] = 0;
+    }
+    __syncthreads();
+    const unsigned long long mybit = 1ull << lane;
+    const unsigned long long lt_mask = mybit - 1;
+    unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;
+    const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
+
+    // inputs one group ahead, visited bits two groups ahead: see verdict_kernel
+    constexpr int kPre = kVerdictPre;
+    constexpr int kBitRegs = BR;
+    struct Bits {
+        unsigned long long w[kBitRegs];
+    };
+    struct Inputs {
+        uint32_t rv[kPre];
+        uint32_t base[kPre];
+        Bits bits;
+        unsigned long long rest[kBitRegs];
+        uint32_t flags, n_pairs;
+        uint4 pair0;
+        uint32_t res0;
+    };
+    const uint32_t *my_bits[kBitRegs];
+    uint32_t my_base[kBitRegs];
+    bool my_live[kBitRegs];
+#pragma unroll
+    for (int r = 0; r < kBitRegs; r++) {
+        const uint32_t ps = (uint32_t)r * 64 + lane;
+        my_live[r] = ps < a.n_passes;
+        my_bits[r] = nullptr;
+        my_base[r] = 0;
+        if (my_live[r]) {
+            const PassInfo pi = a.passes[ps];
+            const uint32_t kind = pi.kind_slot >> 24, sl = pi.kind_slot & 0xFFFFFFu;
+            if (kind == 3) my_live[r] = false;
+            my_bits[r] = kind == 1 ? a.cand_bits + (size_t)sl * a.bit_words : kind == 2 ? a.visit_bits + (size_t)sl * a.bit_words : nullptr;
+            my_base[r] = pi.base;
+        }
+    }
+    auto request_bits = [&](const uint32_t g, Bits &bt) {
+        const uint32_t gg = min(g, a.n_groups - 1);
+#pragma unroll
+        for (int r = 0; r < kBitRegs; r++)
+            bt.w[r] = !my_live[r] ? 0ull : my_bits[r] != nullptr ? *reinterpret_cast<const unsigned long long *>(my_bits[r] + 2 * (size_t)gg) : ~0ull;
+    };
+    auto request_inputs = [&](const uint32_t g, const Bits &bt, Inputs &in) {
+        const uint32_t i = g * 64 + lane;
+        const bool valid = g < a.n_groups && i < a.n;
+        unsigned long long nzp[kBitRegs];
+#pragma unroll
+        for (int r = 0; r < kBitRegs; r++) nzp[r] = (uint32_t)r * 64 < a.n_passes ? __ballot(bt.w[r] != 0) : 0ull;
+#pragma unroll
+        for (int q = 0; q < kPre; q++) {
+            uint32_t ps = kNone, base = kNone;
+            unsigned long long word = 0;
+#pragma unroll
+            for (int r = 0; r < kBitRegs; r++) {
+                if (ps == kNone && nzp[r] != 0) {
+                    const int l = __builtin_ctzll(nzp[r]);
+                    nzp[r] &= nzp[r] - 1;
+                    ps = (uint32_t)r * 64 + (uint32_t)l;
+                    word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(bt.w[r] >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bt.w[r], l);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
+                }
+            }
+            in.base[q] = base;
+            in.rv[q] = (ps != kNone && valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kBitRegs; r++) in.rest[r] = nzp[r];
+        in.bits = bt;
+        in.flags = valid ? (uint32_t)a.flags[i] : 0u;
+        const uint32_t gg = min(g, a.n_groups - 1);
+        in.n_pairs = a.ghdr[gg];
+        in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];
+        in.res0 = (a.res_words && valid) ? a.res_match[i] : 0u;
+    };
+    const uint32_t g_stride = gridDim.x * n_waves;
+    Inputs cur;
+    Bits b_nxt;
+    {
+        Bits b_cur;
+        request_bits(blockIdx.x * n_waves + wave, b_cur);
+        request_inputs(blockIdx.x * n_waves + wave, b_cur, cur);
+        request_bits(blockIdx.x * n_waves + wave + g_stride, b_nxt);
+    }
+
+    for (uint32_t g = blockIdx.x * n_waves + wave; g < a.n_groups; g += g_stride) {
+        const uint32_t i = g * 64 + lane;
+        const bool valid = i < a.n;
+        const unsigned long long valid_mask = __ballot(valid);
+        Inputs nxt;
+        request_inputs(g + g_stride, b_nxt, nxt);
+        request_bits(g + 2 * g_stride, b_nxt);
+
+        // 1. the rule bitmap starts from the rules that need no positive column (a term made of negations only)
+        for (uint32_t k = lane; k < rulew; k += 64) rulebm[k] = k < 64 ? h_always : a.always_rules[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const uint32_t flags = cur.flags;
+        const uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
+        const uint32_t n_pairs = cur.n_pairs;
+        const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
+
+        uint32_t n_entries = 1;  // (entry 0 = TRUE)
+        // a column's rules: the rule bitmap gets the trigger list of every appended column
+        auto triggers = [&](const uint32_t c) {
+            if (dbg_skip & 8u) return;
+            const uint32_t kb = LT ? (uint32_t)l_trig_off[c] : a.trig_off[c], ke = LT ? (uint32_t)l_trig_off[c + 1] : a.trig_off[c + 1];
+            for (uint32_t k = kb; k < ke; k++) {
+                const uint32_t r = LT ? (uint32_t)l_trig_rules[k] : (uint32_t)a.trig_rules[k];
+                atomicOr(&rulebm[r >> 5], 1u << (r & 31));
+            }
+        };
+        // `cnt` entries, lane k < cnt holding entry n_entries + k (distinct columns, none of them appended before)
+        auto append_batch = [&](const uint32_t c, const uint32_t lo, const uint32_t hi, const uint32_t cnt) {
+            if (lane < cnt) {
+                const uint32_t e = n_entries + lane;
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                if (e < e_cap) {
+                    slot[c] = (uint8_t)(e + 1u);
+                    vals[e] = m;
+                    ecol[e] = (uint16_t)c;
+                } else {
+                    slot[c] = 255;
+                    atomicExch(spill + c, m);  // (a read-modify-write, like everything that touches a spilled word: performed at L2 in order)
+                }
+                triggers(c);
+            }
+            n_entries += cnt;
+        };
+        // the batch registers: entries gathered one (wave-uniform) column at a time
+        uint32_t b_col = 0, b_lo = 0, b_hi = 0, bn = 0;
+        auto flush = [&]() {
+            if (bn == 0) return;
+            append_batch(b_col, b_lo, b_hi, bn);
+            bn = 0;
+        };
+        auto append = [&](const uint32_t c, const unsigned long long m) {
+            park96(b_col, b_lo, b_hi, c, m, bn);
+            if (++bn == 64) flush();
+        };
+        // one wave-uniform column that MAY have an entry already (passes with overflow chains): through slot[]
+        auto merge_or_append = [&](const uint32_t c, const unsigned long long m) {
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot[c]);
+            if (s == 0) {
+                const uint32_t e = n_entries++;
+                if (lane == 0) {
+                    if (e < e_cap) {
+                        slot[c] = (uint8_t)(e + 1u);
+                        vals[e] = m;
+                        ecol[e] = (uint16_t)c;
+                    } else {
+                        slot[c] = 255;
+                        atomicExch(spill + c, m);
+                    }
+                    triggers(c);
+                }
+            } else if (lane == 0) {
+                if (s < 255u) vals[s - 1u] |= m;
+                else atomicOr(spill + c, m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
+        // 2. scan results: per pass one entry per DISTINCT atom its records name (lanes naming the same atom are one ballot)
+        auto mark_hits = [&](const uint32_t rv, const uint32_t base) {
+            if (__ballot(rv != 0) == 0) return;
+            const bool chained = (rv & REC_OVERFLOW) != 0;
+            const bool any_chain = __ballot(chained) != 0;
+            if (any_chain) {
+                flush();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            const uint32_t x0 = chained ? 0u : rv & 0x7FFFu, x1 = chained ? 0u : (rv >> 15) & 0x7FFFu;
+            unsigned long long t0 = __ballot(x0 != 0), t1 = __ballot(x1 != 0);
+            while ((t0 | t1) != 0) {
+                uint32_t xa;
+                if (t0 != 0) xa = (uint32_t)__builtin_amdgcn_readlane((int)x0, __builtin_ctzll(t0));
+                else xa = (uint32_t)__builtin_amdgcn_readlane((int)x1, __builtin_ctzll(t1));
+                const unsigned long long s0 = __ballot(x0 == xa), s1 = __ballot(x1 == xa);
+                t0 &= ~s0;
+                t1 &= ~s1;
+                if (any_chain) merge_or_append(base + xa - 1u, s0 | s1);
+                else append(base + xa - 1u, s0 | s1);
+            }
+            if (any_chain) {
+                // the chains, all lanes advancing together: per step the distinct atoms of the lanes that still have one
+                uint32_t k = chained ? rv & ~REC_OVERFLOW : kNone;
+                while (__ballot(k != kNone) != 0) {
+                    uint32_t x = 0;
+                    if (k != kNone) {
+                        const PoolEntry pe = a.pool[k];
+                        x = pe.atom + 1u;
+                        k = pe.next;
+                    }
+                    unsigned long long todo = __ballot(x != 0);
+                    while (todo != 0) {
+                        const uint32_t xa = (uint32_t)__builtin_amdgcn_readlane((int)x, __builtin_ctzll(todo));
+                        const unsigned long long same = __ballot(x == xa);
+                        todo &= ~same;
+                        merge_or_append(base + xa - 1u, same);
+                    }
+                }
+            }
+        };
+        if (!(dbg_skip & 1u)) {
+#pragma unroll
+            for (int q = 0; q < kPre; q++) {
+                if (cur.base[q] == kNone) break;
+                mark_hits(cur.rv[q], cur.base[q]);
+            }
+#pragma unroll
+            for (int r = 0; r < kBitRegs; r++) {
+                unsigned long long m = cur.rest[r];
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t ps = (uint32_t)r * 64 + (uint32_t)l;
+                    const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cur.bits.w[r] >> 32), l) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.bits.w[r], l);
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base[r], l);
+                    mark_hits((valid && ((word >> lane) & 1ull)) ? a.rec[(size_t)ps * a.n + i] : 0u, base);
+                }
+            }
+        }
+        // 2b. the specialized residual program's result words: one entry per rule that matched anybody in the group
+        for (uint32_t w = 0; w < a.res_words; w++) {
+            const uint32_t mw = w == 0 ? cur.res0 : (valid ? a.res_match[(size_t)w * a.n + i] : 0u);
+            if (__ballot(mw != 0u) == 0ull) continue;
+            for (uint32_t any = wave_or(mw); any; any &= any - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(any);
+                append(a.res_base + 32u * w + k, __ballot(((mw >> k) & 1u) != 0u));
+            }
+        }
+        flush();
+        // 3. the attribute kernel's pairs are entries as they come: 64 per step
+        if (!(dbg_skip & 2u)) {
+            for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64) {
+                const uint32_t cnt = min(64u, n_pairs - p0);
+                uint4 pr = cur.pair0;
+                if (p0 != 0 && lane < cnt) pr = pairs[p0 + lane];
+                append_batch(pr.x, pr.z, pr.w, cnt);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        auto col_word = [&](const uint32_t c) -> unsigned long long {
+            const uint32_t s = slot[c];
+            if (s == 0) return 0ull;
+            return s < 255u ? vals[s - 1u] : __hip_atomic_load(spill + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        // 4. ordered compaction of the rule bitmap into the candidate list (ascending rule index = evaluation order)
+        uint32_t n_cand = 0;
+        for (uint32_t wb = 0; wb < rulew && !(dbg_skip & 16u); wb += 64) {
+            const uint32_t word = wb + lane < rulew ? rulebm[wb + lane] : 0u;
+            const uint32_t pc = (uint32_t)__builtin_popcount(word), incl = wave_scan_add(pc);
+            uint32_t pos = n_cand + incl - pc, wrd = word;
+            while (wrd) {
+                cand[pos++] = (uint16_t)((wb + lane) * 32 + (uint32_t)__builtin_ctz(wrd));
+                wrd &= wrd - 1;
+            }
+            n_cand += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        // 5. evaluate candidates: one lane per rule, 64 requests per ALU op; first match wins (see verdict_kernel)
+        unsigned long long pending = valid_mask;
+        bool undecided = valid;
+        uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
+        for (uint32_t base = 0; base < n_cand && pending != 0 && !(dbg_skip & 32u); base += 64) {
+            unsigned long long fire = 0;
+            if (base + lane < n_cand) {
+                const uint32_t my_cand = cand[base + lane];
+                uint32_t lit_off, lit_cnt, eff_u, eff_v;
+                if (LT) {
+                    const uint2 hdr = l_rules[my_cand];
+                    lit_off = hdr.x;
+                    lit_cnt = hdr.y & 0xFFFFu;
+                    eff_u = (hdr.y >> 16) & 0xFFu;
+                    eff_v = hdr.y >> 24;
+                } else {
+                    const DevRule dr = a.rules[my_cand];
+                    lit_off = dr.lit_off;
+                    lit_cnt = dr.lit_cnt;
+                    eff_u = dr.eff_unverified;
+                    eff_v = dr.eff_verified;
+                }
+                unsigned long long acc_or = 0, acc_and = ~0ull;
+                for (uint32_t k = lit_off; k < lit_off + lit_cnt; k += 4) {
+                    uint32_t lit[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) lit[q] = k + q < lit_off + lit_cnt ? (LT ? l_lits[k + q] : a.lits[k + q]) : 0u;
+                    unsigned long long cw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cw[q] = col_word(lit[q] & LIT_ATOM_MASK);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc_and &= (lit[q] & LIT_NEG) ? ~cw[q] : cw[q];
+                        if (lit[q] & LIT_TERM_END) {
+                            acc_or |= acc_and;
+                            acc_and = ~0ull;
+                        }
+                    }
+                }
+                fire = acc_or & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
+            }
+            unsigned long long firing = __ballot(fire != 0);
+            uint32_t first = kNone;
+            while (firing != 0 && pending != 0) {
+                const int j = __builtin_ctzll(firing);
+                firing &= firing - 1;
+                const unsigned long long fj = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fire >> 32), j) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fire, j)) & pending;
+                if (fj & mybit) first = (uint32_t)j;
+                pending &= ~fj;
+            }
+            if (undecided && first != kNone) {
+                undecided = false;
+                const uint32_t jc = cand[base + first];
+                uint32_t eff_u, eff_v;
+                if (LT) {
+                    const uint32_t y = l_rules[jc].y;
+                    eff_u = (y >> 16) & 0xFFu;
+                    eff_v = y >> 24;
+                    const uint32_t pi = l_pub[jc];
+                    my_rule = pi >= 0xFFF0u ? 0xFFFF0000u | pi : pi;
+                } else {
+                    const DevRule dr = a.rules[jc];
+                    eff_u = dr.eff_unverified;
+                    eff_v = dr.eff_verified;
+                    my_rule = dr.public_idx;
+                }
+                my_action = (verified_mask & mybit) ? eff_v : eff_u;
+            }
+        }
+        if (dbg_skip & 64u) my_rule = n_cand | (n_entries << 16);  // profiling aid: candidates and entries of the group instead of the deciding rule
+
+        // 6. outputs
+        if (valid) {
+            uint2 v;
+            v.x = my_action;
+            v.y = my_rule;
+            *reinterpret_cast<uint2 *>(&a.out[i]) = v;
+        }
+        const unsigned long long m_block = __ballot(valid && my_action == PWAF_ACTION_BLOCK);
+        const unsigned long long m_captcha = __ballot(valid && my_action == PWAF_ACTION_CAPTCHA);
+        const unsigned long long m_bypass = __ballot(valid && my_action == PWAF_ACTION_BYPASS);
+        cnt_block += (unsigned)__builtin_popcountll(m_block);
+        cnt_captcha += (unsigned)__builtin_popcountll(m_captcha);
+        cnt_bypass += (unsigned)__builtin_popcountll(m_bypass);
+        cnt_allow += (unsigned)__builtin_popcountll(valid_mask & ~(m_block | m_captcha | m_bypass));
+        if (a.match_idx != nullptr) {
+            const unsigned long long hit = m_block | m_captcha | m_bypass;
+            if (hit) {
+                uint32_t basei = 0;
+                if (lane == 0) basei = atomicAdd(a.n_matches, (uint32_t)__builtin_popcountll(hit));
+                basei = __builtin_amdgcn_readfirstlane(basei);
+                if (hit & mybit) a.match_idx[basei + (uint32_t)__builtin_popcountll(hit & lt_mask)] = i;
+            }
+        }
+        // 7. the group cleans up after itself: the slot bytes of its entries (all of slot[] when entries went beyond e_cap: their columns
+        //    are not listed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (n_entries <= e_cap) {
+            for (uint32_t e = 1u + lane; e < n_entries; e += 64) slot[ecol[e]] = 0;
+        } else {
+            for (uint32_t k = lane; k < slot_words; k += 64) reinterpret_cast<uint32_t *>(slot)[k] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane == 0) slot[0] = 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cur = nxt;
+    }
+    __syncthreads();
+    unsigned long long *tally = reinterpret_cast<unsigned long long *>(lds);
+    if (lane == 0) {
+        tally[wave * 4 + PWAF_ACTION_ALLOW] = cnt_allow;
+        tally[wave * 4 + PWAF_ACTION_BLOCK] = cnt_block;
+        tally[wave * 4 + PWAF_ACTION_CAPTCHA] = cnt_captcha;
+        tally[wave * 4 + PWAF_ACTION_BYPASS] = cnt_bypass;
+    }
+    __syncthreads();
+    if (a.counts != nullptr && tid < 4) {
+        unsigned long long sum = 0;
+        for (uint32_t wv = 0; wv < n_waves; wv++) sum += tally[wv * 4 + tid];
+        if (sum) atomicAdd(&a.counts[tid], sum);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // attributes: everything about a request that is NOT a string scan — GeoIP record, ip-list membership, country / integer-set
 // membership, length / port / asn comparisons — reduced per 64-request group to a list of (column, 64-request mask) pairs
 // -------------------------------------------------------------------------------------------------
@@ -2600,19 +3066,29 @@ __global__ __launch_bounds__(256) void ipres_kernel(VerdictArgs a) {
                 if (a.n_ip_lists) ei[u] = (v6[u] ? a.ip_root6 : a.ip_root4)[top16[u]];
             }
         }
+        // phase 1b: the summary bit of the address's block of /24s (L2-resident bitmap): 0 = the table's most common entry, no gather
+        uint32_t look[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            look[u] = chunked[u] ? 1u : 0u;
+            if (chunked[u] && a.dir_summary != nullptr) {
+                const uint32_t blk = ((top16[u] << 8) | ip_byte(ipw[u], 2)) >> a.dir_sum_shift;
+                look[u] = (a.dir_summary[blk >> 5] >> (blk & 31u)) & 1u;
+            }
+        }
         uint4 rec4[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             rec4[u] = make_uint4(0u, 0u, 0u, 0u);
             // ONE 16-byte gather: the record of the address's group of 32 /24s
-            if (chunked[u]) rec4[u] = *reinterpret_cast<const uint4 *>(a.dir_chunks + (size_t)top16[u] * kDirChunkWords + 4u * (ip_byte(ipw[u], 2) >> 5));
+            if (look[u]) rec4[u] = *reinterpret_cast<const uint4 *>(a.dir_chunks + (size_t)top16[u] * kDirChunkWords + 4u * (ip_byte(ipw[u], 2) >> 5));
         }
         // phase 2: the run's entry — carried into the group, the first run inside it, or (rarely) a further run from dir_vals
         uint32_t e24[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            e24[u] = 0;
-            if (chunked[u]) {
+            e24[u] = a.dir_common;
+            if (look[u]) {
                 const uint32_t rank = (uint32_t)__builtin_popcount(rec4[u].x & (0xFFFFFFFFu >> (31u - (ip_byte(ipw[u], 2) & 31u))));  // run starts at or before the /24, inside its group
                 e24[u] = rank == 0 ? rec4[u].y : rank == 1 ? rec4[u].z : a.dir_vals[rec4[u].w + rank - 2u];
             }
@@ -2965,6 +3441,41 @@ static constexpr uint32_t kLdsPerGroup = 160u * 1024u;
 VerdictShape verdict_shape(uint32_t n_cols, uint32_t n_rules, uint32_t n_trig, uint32_t n_lits, bool force_global, int mode, uint32_t n_passes) {
     VerdictShape s{};
     const uint32_t t_lds = verdict_tables(n_cols, n_rules, n_trig, n_lits, true).end, t_glb = verdict_tables(n_cols, n_rules, n_trig, n_lits, false).end;
+    if (mode >= 3) {
+        // ENTRY LIST (mode 3; 4 = the test hook with 8 entry slots: every group takes the spill path): as many 12-wave workgroups per CU as
+        // LDS holds, and the largest entry capacity that does not cost a wave (a group of the 1k-rule set appends 50-100 entries)
+        s.sparse = 2;
+        const uint32_t cu_waves = n_passes <= 64 ? 24u : 16u;
+        auto fit = [&](uint32_t cap, uint32_t &bw, uint32_t &bk, uint32_t &lt) {
+            const uint32_t wave = verdict_wave_lds_el(n_cols, n_rules, cap);
+            const bool fits = !force_global && n_trig < 65536 && t_lds + 8 * wave <= kLdsPerGroup;
+            const uint32_t tables = fits ? t_lds : t_glb;
+            bw = 0; bk = 1; lt = fits ? 1u : 0u;
+            for (uint32_t k = 1; k <= 3; k++) {
+                const uint32_t share = kLdsPerGroup / k;
+                if (share <= tables + wave) continue;
+                const uint32_t w = std::min(std::min(12u, cu_waves / k), (share - tables) / wave);
+                if (w * k > bw * bk) { bw = w; bk = k; }
+            }
+        };
+        uint32_t cap = 8, bw = 0, bk = 1, lt = 0;
+        if (mode == 4) fit(cap, bw, bk, lt);
+        else {
+            uint32_t w0, k0, l0;
+            fit(64, w0, k0, l0);  // the occupancy the smallest capacity reaches ...
+            for (uint32_t c : {254u, 224u, 192u, 160u, 128u, 96u, 64u}) {  // ... kept by the largest capacity that still reaches it
+                fit(c, bw, bk, lt);
+                cap = c;
+                if (bw * bk >= w0 * k0) break;
+            }
+        }
+        s.v_cap = cap;
+        s.waves = bw;
+        s.per_cu = bk;
+        s.lds_tables = lt;
+        s.lds_bytes = (lt ? t_lds : t_glb) + bw * verdict_wave_lds_el(n_cols, n_rules, cap);
+        return s;
+    }
     if (mode != 0) {
         // SPARSE column file (mode 1; 2 = the test hook with 8 value slots): as many workgroups of 12 waves per CU as LDS holds (two for
         // the 1k-rule set: 6 waves per SIMD), program tables in LDS when one such workgroup still fits beside them
@@ -3005,7 +3516,8 @@ uint32_t verdict_blocks_sp(const VerdictShape &sh, uint32_t n_cus) { return std:
 int launch_verdict(const VerdictArgs &a, void *stream) {
     VerdictShape sh = verdict_shape(a.n_cols, a.n_rules, a.n_trig, a.n_lits, a.force_global_tables != 0, (int)a.sparse_mode, a.n_passes);
     if (sh.waves == 0 || a.n_cols >= 65536u) return (int)hipErrorInvalidValue;  // (engine_create refuses such programs)
-    if (sh.sparse && (a.v_cap != sh.v_cap || (sh.v_cap < a.n_cols && a.spill == nullptr))) return (int)hipErrorInvalidValue;
+    if (sh.sparse == 1 && (a.v_cap != sh.v_cap || (sh.v_cap < a.n_cols && a.spill == nullptr))) return (int)hipErrorInvalidValue;
+    if (sh.sparse == 2 && (a.v_cap != sh.v_cap || a.spill == nullptr)) return (int)hipErrorInvalidValue;
 #ifdef PWAF_PROFILING
     static const uint32_t cap_waves = getenv("PWAF_VERDICT_WAVES") ? (uint32_t)atoi(getenv("PWAF_VERDICT_WAVES")) : 0u;  // timing experiment: fewer waves per CU (same results)
     if (cap_waves && cap_waves < sh.waves) sh.waves = cap_waves;
@@ -3020,7 +3532,9 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
                                  {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax, false>), reinterpret_cast<const void *>(verdict_kernel<true, 1, false>)}},
                                 {{reinterpret_cast<const void *>(verdict_kernel<false, kBRmax, true>), reinterpret_cast<const void *>(verdict_kernel<false, 1, true>)},
                                  {reinterpret_cast<const void *>(verdict_kernel<true, kBRmax, true>), reinterpret_cast<const void *>(verdict_kernel<true, 1, true>)}}};
-    const void *fn = fns[sh.sparse ? 1 : 0][sh.lds_tables ? 1 : 0][variant];
+    const void *fns2[2][2] = {{reinterpret_cast<const void *>(verdict2_kernel<false, kBRmax>), reinterpret_cast<const void *>(verdict2_kernel<false, 1>)},
+                              {reinterpret_cast<const void *>(verdict2_kernel<true, kBRmax>), reinterpret_cast<const void *>(verdict2_kernel<true, 1>)}};
+    const void *fn = sh.sparse == 2 ? fns2[sh.lds_tables ? 1 : 0][variant] : fns[sh.sparse ? 1 : 0][sh.lds_tables ? 1 : 0][variant];
     uint32_t blocks = (a.n_groups + sh.waves - 1) / sh.waves;
 #ifdef PWAF_PROFILING
     static const uint32_t forced_cap = getenv("PWAF_VERDICT_BLOCKS") ? (uint32_t)atoi(getenv("PWAF_VERDICT_BLOCKS")) : 0u;
@@ -3029,7 +3543,7 @@ int launch_verdict(const VerdictArgs &a, void *stream) {
 #endif
     // with LDS tables a workgroup fills a CU: one persistent workgroup per CU (measured: 0.331 ms vs 0.346 at 4 per CU — every
     // workgroup stages 25 KiB of tables and clears its column files once); small workgroups: a few rounds per CU
-    const uint32_t cap = forced_cap ? forced_cap : sh.sparse ? verdict_blocks_sp(sh, a.attr_blocks) : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
+    const uint32_t cap = (forced_cap && !sh.sparse) ? forced_cap : sh.sparse ? verdict_blocks_sp(sh, a.attr_blocks) : sh.lds_tables ? std::max(1u, a.attr_blocks) : 2048u;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return 0;
     void *args[] = {const_cast<VerdictArgs *>(&a)};
@@ -3051,6 +3565,8 @@ int configure_kernels(int device) {
                          reinterpret_cast<const void *>(verdict_kernel<true, 1, false>), reinterpret_cast<const void *>(verdict_kernel<false, 1, false>),
                          reinterpret_cast<const void *>(verdict_kernel<true, (kMaxPasses + 1 + 63) / 64, true>), reinterpret_cast<const void *>(verdict_kernel<false, (kMaxPasses + 1 + 63) / 64, true>),
                          reinterpret_cast<const void *>(verdict_kernel<true, 1, true>), reinterpret_cast<const void *>(verdict_kernel<false, 1, true>),
+                         reinterpret_cast<const void *>(verdict2_kernel<true, (kMaxPasses + 1 + 63) / 64>), reinterpret_cast<const void *>(verdict2_kernel<false, (kMaxPasses + 1 + 63) / 64>),
+                         reinterpret_cast<const void *>(verdict2_kernel<true, 1>), reinterpret_cast<const void *>(verdict2_kernel<false, 1>),
                          reinterpret_cast<const void *>(filter_kernel<true>), reinterpret_cast<const void *>(filter_kernel<false>),
                          lscan_fn(false), lscan_fn(true)};
     for (const void *fn : fns) {

@@ -187,24 +187,24 @@ PWAF_HD const T *in_global(const T *p) { return p; }
 #endif
 // Eight bytes at any address (strings are read a word at a time: a lane's string lives in its own cache lines, so every load
 // instruction of a wave touches up to 64 of them — the cost is per instruction, not per byte). Reads up to 7 bytes past the string:
-// field arenas carry PWAF_ARENA_PAD, the program image ends in padding, the inline buffer has 8 bytes.
+// field arenas carry PWAF_ARENA_PAD, the program image ends in padding, the inline buffer (≤ 6 value bytes) has 16.
 typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
 PWAF_HD uint64_t load8(const uint8_t *p) { return *reinterpret_cast<const u64_unaligned *>(p); }
 // Bytes of a non-rope string (nullptr for a rope).
-PWAF_HD const uint8_t *flat_ptr(const Machine &m, const Val &s, uint8_t (&inl)[8]) {
+PWAF_HD const uint8_t *flat_ptr(const Machine &m, const Val &s, uint8_t (&inl)[16]) {
     const uint32_t src = str_src(s);
     const uint32_t off = (uint32_t)(s.p & 0xFFFFFFFFu);
     if (src < S_CONST) return in_global(m.q.data[src]) + in_global(m.q.off[src])[m.q.r] + off;
     if (src == S_CONST) return m.blob + m.h->strpool + off;
     if (src == S_INLINE) {
-        for (int k = 0; k < 8; k++) inl[k] = k < 6 ? (uint8_t)(s.p >> (8 * k)) : (uint8_t)0;
+        for (int k = 0; k < 16; k++) inl[k] = k < 6 ? (uint8_t)(s.p >> (8 * k)) : (uint8_t)0;  // (16: load8 at any offset of the ≤ 6 value bytes stays inside)
         return inl;
     }
     return nullptr;
 }
 // Byte i of any string (ropes: a walk over the segments — residual rules are rare, clarity over speed).
 PWAF_HD_STR uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
-    uint8_t inl[8];
+    uint8_t inl[16];
     if (str_src(s) != S_ROPE) return flat_ptr(m, s, inl)[i];
     const uint32_t first = (uint32_t)(s.p & 0xFFFFFFu), nseg = (uint32_t)((s.p >> 24) & 0xFFu);
     PWAF_UNROLL
@@ -217,7 +217,7 @@ PWAF_HD_STR uint8_t str_byte(const Machine &m, const Val &s, uint32_t i) {
 }
 PWAF_HD_STR bool str_eq_at(const Machine &m, const Val &h, uint32_t at, const Val &n) {  // h[at, at + n.a) == n (caller checks the bounds)
     if (str_src(h) != S_ROPE && str_src(n) != S_ROPE) {  // (decided by the KIND of the sources, which the specialized form usually knows at compile time)
-        uint8_t i1[8], i2[8];
+        uint8_t i1[16], i2[16];
         const uint8_t *ph = flat_ptr(m, h, i1), *pn = flat_ptr(m, n, i2);
         for (uint32_t k = 0; k < n.a; k += 8) {
             uint64_t x = load8(ph + at + k) ^ load8(pn + k);
@@ -234,7 +234,7 @@ PWAF_HD_STR bool str_eq_at(const Machine &m, const Val &h, uint32_t at, const Va
 PWAF_HD int str_cmp(const Machine &m, const Val &a, const Val &b) {  // bytewise, like std::string_view::compare
     const uint32_t n = a.a < b.a ? a.a : b.a;
     if (str_src(a) != S_ROPE && str_src(b) != S_ROPE) {
-        uint8_t i1[8], i2[8];
+        uint8_t i1[16], i2[16];
         const uint8_t *pa = flat_ptr(m, a, i1), *pb = flat_ptr(m, b, i2);
         for (uint32_t k = 0; k < n; k += 8) {
             const uint64_t wa = load8(pa + k), wb = load8(pb + k);
@@ -430,7 +430,7 @@ PWAF_HD_STR bool regex_match_t(const Machine &m, uint32_t id, const Val &s) {
     PWAF_UNROLL
     for (uint32_t k = 0; k < nseg; k++) {
         const Val sg = rope ? m.heap[first + k] : s;
-        uint8_t inl[8];
+        uint8_t inl[16];
         const uint8_t *p = flat_ptr(m, sg, inl);
         for (uint32_t i = 0; i < sg.a; i += 8) {
             uint64_t w = load8(p + i);
