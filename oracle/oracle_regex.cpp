@@ -307,6 +307,7 @@ struct Parser {
             case 'x': case 'u': case 'U': {
                 if (eof()) { fail("incomplete hexadecimal escape"); return -1; }
                 unsigned long v = 0;
+                bool byte_form = false;  // regex-syntax: only the fixed two-digit \xHH is a byte literal when the u flag is off
                 if (peek() == '{') {
                     pos++;
                     int n = 0;
@@ -321,6 +322,7 @@ struct Parser {
                     pos++;
                 } else {
                     const int digits = c == 'x' ? 2 : c == 'u' ? 4 : 8;
+                    byte_form = c == 'x';
                     for (int k = 0; k < digits; k++) {
                         if (eof()) { fail("incomplete hexadecimal escape"); return -1; }
                         int h = hexv(peek());
@@ -330,7 +332,7 @@ struct Parser {
                     }
                 }
                 if (v > kMaxCp || (v >= 0xD800 && v <= 0xDFFF)) { fail("hex escape is not a scalar value"); return -1; }
-                if (!f.u && v > 0x7F) { fail("pattern can match invalid UTF-8 (byte escape without the u flag)"); return -1; }
+                if (!f.u && v > 0x7F && byte_form) { fail("pattern can match invalid UTF-8 (byte escape without the u flag)"); return -1; }
                 return (long)v;
             }
             default:

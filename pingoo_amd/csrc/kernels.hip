@@ -2601,6 +2601,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
     const unsigned long long lt_mask = mybit - 1;
     unsigned long long cnt_block = 0, cnt_captcha = 0, cnt_bypass = 0, cnt_allow = 0;
     const uint32_t h_always = lane < rulew ? a.always_rules[lane] : 0u;
+    const bool true_triggers = a.trig_off[1] != a.trig_off[0];  // rules whose chosen positive literal is the constant TRUE (`expression: None`)
 
     // inputs one group ahead, visited bits two groups ahead: see verdict_kernel
     constexpr int kPre = kVerdictPre;
@@ -2710,6 +2711,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
             }
         };
         // `cnt` entries, lane k < cnt holding entry n_entries + k (distinct columns, none of them appended before)
+        if (true_triggers && lane == 0) triggers(0);  // (entry 0 = TRUE is never appended: a match-all rule is filed under column 0)
         auto append_batch = [&](const uint32_t c, const uint32_t lo, const uint32_t hi, const uint32_t cnt) {
             if (lane < cnt) {
                 const uint32_t e = n_entries + lane;

@@ -370,6 +370,7 @@ struct RxParser {
             case 'v': return 11;
             case 'x': case 'u': case 'U': {
                 unsigned long v = 0;
+                bool byte_form = false;  // only the fixed two-digit \xHH denotes a BYTE without the u flag (regex-syntax: Literal::byte() is Some for HexFixed(X) alone)
                 if (i < p.size() && p[i] == '{') {
                     size_t j = i + 1;
                     int nd = 0;
@@ -383,6 +384,7 @@ struct RxParser {
                     i = j + 1;
                 } else {
                     const size_t digits = c == 'x' ? 2 : c == 'u' ? 4 : 8;
+                    byte_form = c == 'x';
                     if (i + digits > p.size()) { invalid("invalid hexadecimal escape"); return -1; }
                     for (size_t k = 0; k < digits; k++) {
                         if (hex(p[i + k]) < 0) { invalid("invalid hexadecimal escape"); return -1; }
@@ -391,7 +393,8 @@ struct RxParser {
                     i += digits;
                 }
                 if (v > kLastScalar || (v >= 0xD800 && v <= 0xDFFF)) { invalid("hexadecimal escape is not a scalar value"); return -1; }
-                if (!fl.unicode && v > 0x7F) { invalid("pattern can match invalid UTF-8: byte escape without the u flag"); return -1; }
+                // (\x{..}, \uHHHH and \UHHHHHHHH denote the scalar value with or without the u flag: its UTF-8 encoding, like a raw non-ASCII character)
+                if (!fl.unicode && v > 0x7F && byte_form) { invalid("pattern can match invalid UTF-8: byte escape without the u flag"); return -1; }
                 return (long)v;
             }
             default: break;

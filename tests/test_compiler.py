@@ -268,7 +268,10 @@ def test_unicode_classes_follow_the_regex_crate():
              (r"^\x{e9}\u00e9\u{e9}\U000000e9\xe9$", [E * 5, E * 4]), (r"^\p{Greek}+$", ["\u03b1\u03b2", "\u03b1a"]), (r"^\p{sc=Cyrillic}\p{Script=Latin}$", ["\u0436z", "z\u0436"]),
              (r"^\p{gc=Nd}\p{Alphabetic}\p{White_Space}$", ["\u0663" + E + "\u3000", "1a "]), (r"(?x) union \s+ select  # comment", ["union select", "unionselect"]),
              (r"(?x)a\ b [ c d ]{ 1, 2 }$", ["a bdc", "a b d"]), (r"(?s)^.$", ["\n", E]), (r"^[^\n" + E + "]+$", ["a" + EU, "a" + E]), (r"(?i)\u017f\u212a", ["sk", "SK", "\u017fK"]),
-             (r"<script[^>]*>", ["<script " + E + EM + ">", "<script " + E], )]
+             (r"<script[^>]*>", ["<script " + E + EM + ">", "<script " + E], ),
+             # without the u flag only the fixed two-digit \xHH is a BYTE (regex-syntax: Literal::byte() is Some for HexFixed(X) alone); the brace, \u and \U
+             # forms denote the scalar value = its UTF-8 encoding, like a raw non-ASCII character
+             (r"(?-u)caf\x{e9}$", ["caf" + E, "cafe"]), (r"(?-u:\u00e9\U000000e9)" + E, [E * 3, E * 2]), (r"(?i-u)\x{e9}x", [E + "X", "\u00c9x"])]
     rules = [(f"r{k}", f"http_request.path.matches({H.q(pat)})", [H.B]) for k, (pat, _) in enumerate(cases)]
     prog = CompiledProgram(rules, {}, flags=_abi.OPT_NO_UA_GATE)
     assert prog.unsupported_rules(len(rules)) == []

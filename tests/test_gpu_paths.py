@@ -465,20 +465,22 @@ def test_host_batches_small_and_large_pageable_and_page_locked():
 
 
 def test_verdict_sparse_column_file_dense_and_spill_agree():
-    """The verdict kernel's SPARSE column file (round 5: value slots per DIRTY column instead of 8 bytes per column and wave) against the
-    round-4 dense file (PWAF_OPT_DENSE_VERDICT) and with 8 value slots per wave (PWAF_OPT_TINY_VERDICT_SLOTS: every group spills its
-    dirty columns beyond the eighth into global memory) — the 1k-rule set on benign, hostile and UTF-8 traffic, a rule set where most
-    requests hit many atoms at once (overflowing hit records), and the oracle on a prefix."""
+    """The verdict kernel's ENTRY LIST (round 6: verdict2_kernel, the default) against the round-5 sparse column file
+    (PWAF_OPT_SPARSE_VERDICT), the round-4 dense file (PWAF_OPT_DENSE_VERDICT) and both with 8 slots per wave
+    (PWAF_OPT_TINY_VERDICT_SLOTS: every group spills what lies beyond the eighth entry / dirty column into global memory) — the 1k-rule
+    set on benign, hostile and UTF-8 traffic, a rule set where most requests hit many atoms at once (overflowing hit records: the
+    entry list's merge path), and the oracle on a prefix."""
     from synth import pysynth
 
     w = pysynth.Workload(3)
-    engines = {name: RuleEngine(w.rules, w.lists, w.geoip, flags=fl) for name, fl in (("sparse", 0), ("dense", _abi.OPT_DENSE_VERDICT), ("tiny", _abi.OPT_TINY_VERDICT_SLOTS))}
+    engines = {name: RuleEngine(w.rules, w.lists, w.geoip, flags=fl) for name, fl in (("sparse", 0), ("dense", _abi.OPT_DENSE_VERDICT), ("tiny", _abi.OPT_TINY_VERDICT_SLOTS), ("file", _abi.OPT_SPARSE_VERDICT),
+                                                                                    ("file_tiny", _abi.OPT_SPARSE_VERDICT | _abi.OPT_TINY_VERDICT_SLOTS))}
     orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
     for label, kw in (("benign", {}), ("hostile", {"adversarial": True}), ("utf8", {"utf8": True})):
         batch = w.batch(300_000, 200_000, **kw)
         got = {name: e.evaluate_batch(batch, with_counts=True) for name, e in engines.items()}
-        for name in ("dense", "tiny"):
-            H.assert_verdicts_equal(got[name][0], got["sparse"][0], batch, f"{label}: {name} vs sparse column file")
+        for name in ("dense", "tiny", "file", "file_tiny"):
+            H.assert_verdicts_equal(got[name][0], got["sparse"][0], batch, f"{label}: {name} vs the entry list")
             assert got[name][1].tolist() == got["sparse"][1].tolist()
         pre = batch.slice(0, 6000)
         H.assert_verdicts_equal(got["sparse"][0][:6000], orc.evaluate(pre, threads=16), pre, f"{label}: sparse vs oracle")
@@ -492,7 +494,7 @@ def test_verdict_sparse_column_file_dense_and_spill_agree():
                     captcha_verified=rng.random() < 0.3) for _ in range(20_000)]
     batch = RequestBatch.from_requests(reqs)
     want = pyoracle.Oracle(rules).evaluate(batch, threads=16)
-    for fl in (0, _abi.OPT_DENSE_VERDICT, _abi.OPT_TINY_VERDICT_SLOTS):
+    for fl in (0, _abi.OPT_DENSE_VERDICT, _abi.OPT_TINY_VERDICT_SLOTS, _abi.OPT_SPARSE_VERDICT, _abi.OPT_SPARSE_VERDICT | _abi.OPT_TINY_VERDICT_SLOTS):
         e = RuleEngine(rules, flags=fl)
         H.assert_verdicts_equal(e.evaluate_batch(batch), want, batch, f"many atoms per request, flags {fl}")
         e.close()

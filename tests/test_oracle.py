@@ -241,6 +241,11 @@ def test_regex_syntax_errors_and_unsupported():
                 "\\x{110000}", "\\x{D800}", "(?R)a", "(?-u:.)", "(?-u:\\W)", "(?-u:[^a])", "(?-u:\\xFF)", "(?-u:\\pL)", "\\b{start}a", "\\<a"]:
         with pytest.raises(pyoracle.OracleError):
             pyoracle.regex_is_match(pat, b"a")
+    # (?-u): only the two-digit \xHH is a byte; \x{..} \uHHHH \UHHHHHHHH stay scalar values (regex-syntax Literal::byte(): ADVICE r5)
+    assert pyoracle.regex_is_match("(?-u:\\x{e9}\\u00e9\\U000000e9)$", "\u00e9\u00e9\u00e9".encode()) and not pyoracle.regex_is_match("(?-u:\\x{e9})", b"\xe9")
+    for pat in ["(?-u:[\\x{e9}])", "(?-u:\\xe9)"]:
+        with pytest.raises(pyoracle.OracleError):
+            pyoracle.regex_is_match(pat, b"a")
     assert pyoracle.regex_is_match("[[:alpha:]]+[[:digit:]]", b"..ab1")
     assert pyoracle.regex_is_match("^\\p{L}+\\p{N}$", b"ab1") and not pyoracle.regex_is_match("^\\P{L}$", b"a")  # general categories, over ASCII
     assert pyoracle.regex_is_match("(?i)union\\s+select", b"x UnIoN \t SELECT y")
