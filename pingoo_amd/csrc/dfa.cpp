@@ -758,7 +758,15 @@ std::vector<uint8_t> scalar_map_image(const ScalarMap &m) {
 }
 uint32_t dfa_class_at(const DfaGroup &g, const uint8_t *bytes, size_t i, size_t n) {
     const uint32_t b = bytes[i];
-    if (b < 0xC0u || !g.umap.on()) return g.classmap[b];
+    if (b < 0x80u || !g.umap.on()) return g.classmap[b];
+    if (b < 0xC0u) {
+        // a continuation byte: the table's own class (stays) when a well-formed sequence holds it, else ill-formed (utf8.h: utf8_cont_covered)
+        const uint32_t back = (uint32_t)std::min<size_t>(3, i);
+        uint32_t prev = 0, self_next = 0;
+        for (uint32_t d = 1; d <= back; d++) prev |= (uint32_t)bytes[i - d] << (8 * (d - 1));
+        for (size_t k = 0; k < 4 && i + k < n; k++) self_next |= (uint32_t)bytes[i + k] << (8 * k);
+        return utf8_cont_covered(prev, self_next, back, (uint32_t)std::min<size_t>(n - i, 0xFFFFu)) ? g.classmap[b] : g.umap.ill_class;
+    }
     uint32_t next = 0;
     for (size_t k = 1; k < 4 && i + k < n; k++) next |= (uint32_t)bytes[i + k] << (8 * (k - 1));
     // (a walk that looks classes up often builds the image once; this is the simple form for the test hooks)

@@ -229,6 +229,18 @@ __device__ __noinline__ uint32_t lead_class(const uint8_t *umap, const uint32_t 
     return utf8_class(umap, ill_class, b0, next, end - at);
 }
 
+// scalar mode: a window with any byte beyond ASCII takes the class fix-up (lead bytes AND continuation bytes are looked at)
+__device__ __forceinline__ bool window_has_high(const u32x4 w) { return ((w.x | w.y | w.z | w.w) & 0x80808080u) != 0u; }
+// The class of a CONTINUATION byte at arena position `at` of the field [start, end): the table's own (every transition stays: the
+// sequence's symbol was read at its lead byte) when a well-formed sequence holds it, else the ill-formed class (utf8.h: utf8_cont_covered).
+__device__ __noinline__ uint32_t cont_class(const uint32_t own_class, const uint32_t ill_class, const PWAF_GLOBAL unsigned char *gdata, const uint32_t at, const uint32_t start, const uint32_t end) {
+    const uint32_t back = min(3u, at - start);
+    uint32_t prev = 0;
+    for (uint32_t d = 1; d <= back; d++) prev |= (uint32_t)gdata[at - d] << (8u * (d - 1u));
+    const uint32_t self_next = *reinterpret_cast<const PWAF_GLOBAL uint32_t __attribute__((aligned(1))) *>(gdata + at);  // (PWAF_ARENA_PAD covers the read behind the arena's end)
+    return utf8_cont_covered(prev, self_next, back, end - at) ? own_class : ill_class;
+}
+
 template <class T>
 __device__ __forceinline__ T load_descriptor(const T *p) {
     static_assert(sizeof(T) % 4 == 0, "descriptor size");
@@ -393,11 +405,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a) {
             const uint32_t c = WIDE ? *reinterpret_cast<lds_u32_ptr>((uintptr_t)(byte << 2)) : (uint32_t)*reinterpret_cast<lds_u8_ptr>((uintptr_t)byte);
             c2[k] = (uint32_t)k < cnt ? c : stay2;  // past the end: the STAY cell
         }
-        if (a.umap != nullptr && __ballot(cnt != 0u && window_has_lead(w[q])) != 0ull) {  // scalar mode, a lead byte in somebody's chunk (rare)
+        if (a.umap != nullptr && __ballot(cnt != 0u && window_has_high(w[q])) != 0ull) {  // scalar mode, a byte beyond ASCII in somebody's chunk (rare)
+            const uint32_t f_start = r != kNone ? a.off[r] : 0u;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t byte = (wd[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
                 if (byte >= 0xC0u && (uint32_t)k < cnt) c2[k] = 2u * lead_class(a.umap, a.ill_class, gdata, byte, p + 16u * (uint32_t)q + (uint32_t)k, end);
+                else if (byte >= 0x80u && (uint32_t)k < cnt) c2[k] = cont_class(c2[k], 2u * a.ill_class, gdata, p + 16u * (uint32_t)q + (uint32_t)k, f_start, end);
             }
         }
         // The 16 steps run in groups of 4 with ONE check per group: inside a group every lane chains lookup to lookup
@@ -630,11 +644,13 @@ __device__ __forceinline__ void lscan_async(const ListScanArgs &a, const uint16_
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) c[k] = cls[(wd >> (k * 8)) & 0xFFu];
             asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));  // (the four class lookups stay unconditional: left alone the compiler sinks each under its "k < cnt" — sixteen exec-mask branches per window, which doubled the walk's time)
-            if (a.umap != nullptr && __ballot(active && ((wd & (wd << 1)) & 0x80808080u) != 0u) != 0ull) {  // scalar mode, a lead byte somewhere (rare): the scalar's class
+            if (a.umap != nullptr && __ballot(active && (wd & 0x80808080u) != 0u) != 0ull) {  // scalar mode, a byte beyond ASCII somewhere (rare): the scalar's class at a lead byte, a stray continuation byte is ill-formed
+                const uint32_t f_start = active ? a.off[r] : 0u;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t byte = (wd >> (k * 8)) & 0xFFu;
                     if (byte >= 0xC0u && k < cnt) c[k] = lead_class(a.umap, a.ill_class, gdata, byte, p + k, end);
+                    else if (byte >= 0x80u && k < cnt) c[k] = cont_class(c[k], a.ill_class, gdata, p + k, f_start, end);
                 }
             }
 #pragma unroll
@@ -817,13 +833,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                 if (!more) break;
                 u32x4 wn[kListWalks];
                 uint32_t cnt[kListWalks];
-                bool lead_here = false;  // scalar mode: some walk's window holds a lead byte (wave-uniform after the ballot)
+                bool lead_here = false;  // scalar mode: some walk's window holds a byte beyond ASCII (wave-uniform after the ballot)
 #pragma unroll
                 for (uint32_t u = 0; u < kListWalks; u++) {
                     const uint32_t pn = p[u] + 16u;
                     wn[u] = *reinterpret_cast<const PWAF_GLOBAL u32x4_u *>(gdata + (pn < end[u] ? pn : 0u));
                     cnt[u] = p[u] < end[u] ? min(16u, end[u] - p[u]) : 0u;
-                    if (a.umap != nullptr) lead_here = lead_here || (cnt[u] != 0u && window_has_lead(w[u]));
+                    if (a.umap != nullptr) lead_here = lead_here || (cnt[u] != 0u && window_has_high(w[u]));
                 }
                 const bool fix_classes = a.umap != nullptr && __ballot(lead_here) != 0ull;
 #pragma unroll
@@ -837,11 +853,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
                             const uint32_t cl = cls[(wd >> (k * 8)) & 0xFFu];
                             c[u][k] = k0 + k < cnt[u] ? cl : ncls + 1u;
                         }
-                        if (fix_classes) {  // (uniform, rare) a lead byte reads as the class of the scalar value it begins; its continuation bytes stay
+                        if (fix_classes) {  // (uniform, rare) a lead byte reads as the class of the scalar value it begins; its continuation bytes stay, a stray one is ill-formed
 #pragma unroll
                             for (uint32_t k = 0; k < 4; k++) {
                                 const uint32_t byte = (wd >> (k * 8)) & 0xFFu;
                                 if (byte >= 0xC0u && k0 + k < cnt[u]) c[u][k] = lead_class(a.umap, a.ill_class, gdata, byte, p[u] + k0 + k, end[u]);
+                                else if (byte >= 0x80u && k0 + k < cnt[u]) c[u][k] = cont_class(c[u][k], a.ill_class, gdata, p[u] + k0 + k, live[u] ? a.off[r[u]] : 0u, end[u]);
                             }
                         }
                     }

@@ -413,8 +413,8 @@ PWAF_HD_STR bool regex_match_t(const Machine &m, uint32_t id, const Val &s) {
     // SCALAR MODE (a class beyond ASCII in the pattern: the regex crate matches scalar values, Cargo.lock:1694-1700): a byte below 0x80
     // is its own symbol, a well-formed sequence is ONE symbol — its scalar's class from the two-stage map — taken when its last byte
     // arrives (the string may be a rope: the sequence may straddle two segments), a lead byte that the next byte does not continue is
-    // the ill-formed class and that byte is then read on its own; a continuation byte that continues nothing is skipped, as the table
-    // walkers of kernels.hip do (utf8.h decodes at the lead byte there: the same symbols in the same order).
+    // the ill-formed class and that byte is then read on its own; a continuation byte that continues nothing is the ill-formed class too, as for the
+    // table walkers of kernels.hip (utf8.h decodes at the lead byte there and asks of a continuation byte whether a sequence holds it).
     const RegexDesc &d = section<RegexDesc>(m, m.h->regexes)[id];
     const uint16_t *trans = section<uint16_t>(m, d.trans);
     const uint8_t *cm = m.blob + d.classmap, *fl = m.blob + d.flags;
@@ -439,12 +439,14 @@ PWAF_HD_STR bool regex_match_t(const Machine &m, uint32_t id, const Val &s) {
                 const uint32_t b = (uint32_t)w & 0xFFu;
                 uint32_t cls = cm[b];
                 if (SCALAR && (b >= 0x80u || pend != 0u)) {
+                    bool closed = false;  // this byte ended an open sequence: cls is that sequence's symbol
                     if (pend != 0u) {
                         if ((b & 0xC0u) == 0x80u) {  // the open sequence goes on
                             cp = (cp << 6) | (b & 0x3Fu);
                             if (--pend != 0u) continue;
                             const bool bad = (need == 2u && cp < 0x800u) || (need == 3u && (cp < 0x10000u || cp > 0x10FFFFu)) || (cp >= 0xD800u && cp <= 0xDFFFu);
                             cls = bad ? d.ill_class : um[(0x110000u >> 7) * 2u + (uint32_t)reinterpret_cast<const uint16_t *>(um)[cp >> 7] * 128u + (cp & 127u)];
+                            closed = true;
                         } else {  // broken off: the lead byte was ill-formed; this byte is read on its own below
                             pend = 0;
                             const uint32_t e0 = trans[st * nc + d.ill_class];
@@ -453,13 +455,15 @@ PWAF_HD_STR bool regex_match_t(const Machine &m, uint32_t id, const Val &s) {
                             st = e0;
                         }
                     }
-                    if (pend == 0u && cls == cm[b] && b >= 0xC0u) {  // (cls still the byte's own: not the sequence that just closed) a lead byte
+                    if (!closed && pend == 0u && b >= 0xC0u) {  // a lead byte
                         if (b < 0xC2u || b > 0xF4u) cls = d.ill_class;
                         else {
                             need = pend = b >= 0xF0u ? 3u : b >= 0xE0u ? 2u : 1u;
                             cp = b & (0x3Fu >> need);
                             continue;
                         }
+                    } else if (!closed && pend == 0u && b >= 0x80u) {
+                        cls = d.ill_class;  // a continuation byte that continues nothing: an ill-formed unit (round 6: it used to be skipped)
                     }
                 }
                 const uint32_t e = trans[st * nc + cls];

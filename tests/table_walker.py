@@ -58,6 +58,28 @@ def scalar_class(um: bytes, data: bytes, j: int) -> int:
     return img[2 * (0x110000 >> 7) + block * 128 + (cp & 127)]
 
 
+def cont_covered(data: bytes, j: int) -> bool:
+    """csrc/utf8.h utf8_cont_covered restated: the continuation byte data[j] belongs to a well-formed sequence of the field (then the walker
+    stays: the sequence was read at its lead byte); otherwise it is an ill-formed unit like any other (round 6)."""
+    for d in (1, 2, 3):
+        if d > j:
+            return False
+        lead = data[j - d]
+        if lead < 0x80:
+            return False
+        if lead < 0xC0:
+            continue
+        ln = 4 if lead >= 0xF0 else 3 if lead >= 0xE0 else 2
+        if ln <= d or lead < 0xC2 or lead > 0xF4 or j - d + ln > len(data):
+            return False
+        try:
+            bytes(data[j - d:j - d + ln]).decode("utf-8")
+            return True
+        except UnicodeDecodeError:
+            return False
+    return False
+
+
 class Tables:
     def __init__(self, blob):
         """`blob`: a program dump, or the CompiledProgram itself (then the confirm tier of its filtered passes is evaluated too,
@@ -234,8 +256,11 @@ class Tables:
             c = int(cm[data[j]])
             if um is not None and data[j] >= 0xC0:
                 c = scalar_class(um, data, j)  # scalar mode: the class of the scalar value that begins here (csrc/utf8.h)
+            stays = um is not None and 0x80 <= data[j] < 0xC0 and cont_covered(data, j)  # (a continuation byte of a well-formed sequence stays and emits nothing)
+            if um is not None and 0x80 <= data[j] < 0xC0 and not stays:
+                c = um[0]  # a stray continuation byte: the ill-formed class
             nxt = int(tr[st, c])
-            if not (um is not None and 0x80 <= data[j] < 0xC0):  # (a continuation byte stays and emits nothing)
+            if not stays:
                 st = nxt
                 emit(st)
             self.n_steps += 1

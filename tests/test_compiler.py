@@ -406,3 +406,38 @@ def test_rule_sets_beyond_a_device_table_width_fall_to_residual_programs(what):
     got = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got, want, batch, what)
     assert len(set(want["rule_idx"].tolist())) >= 3, set(want["rule_idx"].tolist())
+
+
+ILL_PATTERNS = [r"^a.b$", r"^a.{2}b$", r"(é|x)?ab", r"\bselect", r"select\b", r"^\w+$", r"a[^x]b", r"^(é)+$", r"q=\w+&", r"(?i)café"]
+ILL_HAYS = [b"a\x80b", b"ab", b"a\xc3\xa9b", b"a\xc3\xa9\x80b", b"a\xe2\x82b", b"a\xe2\x82\xacb", b"a\xed\xa0\x80b", b"a\xc0\x80b", b"a\xf4\x90\x80\x80b", b"a\xf0\x9f\x98\x80b", b"\x80ab", b"ab\x80",
+            b"a\xc3b", b"a\xc3\xa9\xa9b", b"\x80select", b"select\x80", b"\xc3\xa9select", b"select\xbf x", b"\xc3\xa9\xc3\xa9", b"\xc3\xa9\x80\xc3\xa9", b"\xc3\xa9\xc3", b"q=\xc3\xa9\x80&", b"q=\xc3\xa9x&",
+            b"caf\xc3\x89", b"caf\xc3\x80\x89", b"a\xbf\xbf\xbfb", b"a\xe2\x82\xac\x80b", b"a\xf0\x9f\x98b", b"\xf0\x9f\x98\x80", b"a\xc3\xa9", b"\xa9b"]
+
+
+def test_ill_formed_utf8_is_a_unit_no_class_matches_for_every_table_walker():
+    """D17 closed: the C ABI takes arbitrary bytes where the reference has Rust str. A byte that belongs to no
+    well-formed sequence — a stray continuation byte, a truncated sequence, a surrogate, an overlong form, > U+10FFFF — is a unit that no regex
+    class matches, for the oracle's decoder AND for the walkers of a scalar-mode table (they used to SKIP a stray continuation byte:
+    `a\\x80b` held "ab"). The compiled tables (CPU walk = csrc/utf8.h restated) against the oracle, pattern by pattern, all patterns in one
+    table, and beside byte-substring predicates that share the table."""
+    rules = [(f"r{k}", f"http_request.path.matches({H.q(pat)})", [H.B]) for k, pat in enumerate(ILL_PATTERNS)]
+    rules += [("lit_ab", 'http_request.path.contains("ab")', [H.B]), ("lit_e", 'http_request.path.ends_with("é")', [H.B]), ("lit_sel", 'http_request.path.starts_with("select")', [H.B])]
+    batch = RequestBatch.from_requests([Request(path=h, url=b"/", host="h") for h in ILL_HAYS])
+    n_match = 0
+    for k, rule in enumerate(rules):
+        want = pyoracle.Oracle([rule], {}, flags=_abi.OPT_NO_UA_GATE).evaluate(batch)
+        one = Tables(CompiledProgram([rule], {}, flags=_abi.OPT_NO_UA_GATE))
+        for i in range(batch.n):
+            assert one.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), (rule[1], ILL_HAYS[i])
+        n_match += int(np.count_nonzero(want["action"]))
+    assert n_match >= 25
+    # known answers (hand-derived from decode_units' definition): a stray byte separates, a well-formed sequence is one unit
+    orc = pyoracle.Oracle(rules, {}, flags=_abi.OPT_NO_UA_GATE)
+    M = lambda pat, h: pyoracle.regex_is_match(pat, h)
+    assert not M(r"(é|x)?ab", b"a\x80b") and M(r"^a.b$", b"a\xc3\xa9b") and not M(r"^a.b$", b"a\x80b") and not M(r"^a.{2}b$", b"a\xc3\xa9\x80b") and not M(r"^a.b$", b"a\xe2\x82b")
+    assert not M(r"\bselect", b"\x80select") and M(r"\bselect", b" select") and not M(r"^\w+$", b"\xc3\xa9\x80\xc3\xa9") and M(r"^\w+$", b"\xc3\xa9\xc3\xa9")
+    # every pattern in ONE table (the literals share it: scalar mode)
+    t = Tables(CompiledProgram(rules, {}, flags=_abi.OPT_NO_UA_GATE))
+    want = orc.evaluate(batch)
+    for i in range(batch.n):
+        assert t.evaluate(batch, i) == (int(want[i]["action"]), int(want[i]["rule_idx"])), ILL_HAYS[i]

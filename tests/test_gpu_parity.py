@@ -299,3 +299,35 @@ def test_utf8_stream_unicode_regex_semantics_on_the_device():
         got = e2.evaluate_batch(kb)
         assert [(int(a), int(r)) for a, r in zip(got["action"], got["rule_idx"])] == [(int(a), int(r)) for a, r in expect], c["name"]
         e2.close()
+
+
+@pytest.mark.gpu
+def test_ill_formed_utf8_on_the_device_every_walker():
+    """D17 closed: pwaf_batch takes arbitrary bytes where the reference has Rust str. Stray continuation bytes, truncated
+    sequences, surrogates, overlong forms and > U+10FFFF in url and path — scan_kernel (unfiltered passes, PWAF_OPT_NO_PREFILTER), the
+    confirm tier + R-tier walks, whole-pass list walks (PWAF_OPT_NO_CONFIRM), the residual programs' regex walker (interpreted and
+    specialized) — all against the oracle's decode_units: such a byte is a unit no class matches (the walkers used to skip a stray
+    continuation byte, so that `a\\x80b` held "ab")."""
+    from test_compiler import ILL_HAYS, ILL_PATTERNS
+
+    rules = [(f"p{k}", f"http_request.path.matches({H.q(pat)})", [B]) for k, pat in enumerate(ILL_PATTERNS)]
+    rules += [(f"u{k}", f"http_request.url.matches({H.q(pat)})", [CAP]) for k, pat in enumerate(ILL_PATTERNS)]
+    rules += [("lit_ab", 'http_request.path.contains("ab")', [B]), ("lit_e", 'http_request.url.ends_with("é")', [B]), ("lit_sel", 'http_request.url.starts_with("select")', [CAP])]
+    rules += [(f"res{k}", f"(http_request.host + http_request.path).matches({H.q(pat)}) && client.remote_port % 2 == 1", [B]) for k, pat in enumerate(ILL_PATTERNS[:6])]
+    rng = random.Random(11)
+    filler = [b"/index.html", b"/a/b/c", b"/x?q=1", b"/caf\xc3\xa9", b"/\xe2\x82\xac", b"/select", b"/ab"]
+    reqs = []
+    for rep in range(40):
+        for h in ILL_HAYS:
+            pad = rng.choice(filler) if rep else b""
+            reqs.append(Request(path=h + (pad if rep % 2 else b""), url=(pad if rep % 3 == 0 else b"") + h, host=rng.choice([b"", b"a", b"\xc3"]), remote_port=rng.randint(1, 65535),
+                                captcha_verified=rng.random() < 0.3))
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules).evaluate(batch, threads=8)
+    assert len(set(want["rule_idx"].tolist())) > 12
+    for fl in (0, _abi.OPT_NO_PREFILTER, _abi.OPT_NO_CONFIRM, _abi.OPT_NO_RESIDUAL_JIT, _abi.OPT_FILTER_STRIDE2):
+        eng = RuleEngine(rules, flags=fl)
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"ill-formed UTF-8, flags {fl}")
+        eng.tune(batch.slice(0, 500))
+        H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"ill-formed UTF-8, tuned, flags {fl}")
+        eng.close()

@@ -23,7 +23,7 @@ CSRC = os.path.join(HERE, "..", "pingoo_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "librvm_host.so")
 SRCS = [os.path.join(HERE, "rvm_host.cpp")] + [os.path.join(CSRC, f) for f in ("residual.cpp", "residual_jit.cpp", "frontend.cpp", "pattern.cpp", "dfa.cpp", "iptrie.cpp")]
-DEPS = SRCS + [os.path.join(CSRC, f) for f in ("residual.h", "program.h", "frontend.h")]
+DEPS = SRCS + [os.path.join(CSRC, f) for f in ("residual.h", "program.h", "frontend.h", "utf8.h")]
 
 
 def build_host_vm() -> str:
@@ -498,3 +498,23 @@ def test_header_keys_that_only_constant_folding_makes_literal():
             assert want["rule_idx"].tolist() == [0, 1, 3]  # the folded key reads the column a literal mention made; "cookie" is no name of this set
         else:
             assert want["rule_idx"].tolist() == [3, 3, 3]  # no name at all: every folded key is absent
+
+
+def test_residual_regex_walker_reads_a_stray_continuation_byte_as_an_ill_formed_unit():
+    """D17 closed: the residual programs' own regex walker (residual.h: regex_match_t, one table per pattern) on ill-formed UTF-8 — through the
+    host VM and the oracle; ropes too (a sequence that straddles two segments)."""
+    from test_compiler import ILL_HAYS, ILL_PATTERNS
+
+    reqs = [Request(path=h, url=b"/", host=b"", user_agent="ua") for h in ILL_HAYS] + [Request(path=h[1:], host=h[:1], url=b"/", user_agent="ua") for h in ILL_HAYS if len(h) > 1]
+    batch = RequestBatch.from_requests(reqs)
+    n_true = 0
+    for pat in ILL_PATTERNS:
+        e = f"(http_request.host + http_request.path).matches({H.q(pat)})"
+        m = HostVM([e], LISTS)
+        m.bind(batch)
+        orc = pyoracle.Oracle([("r", e, [H.B])], LISTS, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+        for i in range(batch.n):
+            want = orc.execute_rule(0, batch, i) == 1
+            assert m.eval(0, i) == want, (pat, reqs[i].host, reqs[i].path)
+            n_true += want
+    assert n_true > 40
