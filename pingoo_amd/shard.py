@@ -50,8 +50,15 @@ def init_process_group(backend: str | None = None, always: bool = False):
                 s.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         else:
-            # ranks started by hand (RANK / WORLD_SIZE set, no launcher) must agree on ONE port: a random one per rank never meets
-            os.environ["MASTER_PORT"] = "29517"  # 
+            # ranks started by hand (RANK / WORLD_SIZE set, no launcher) must agree on ONE port — a random one per rank never meets, a fixed
+            # default lets two jobs on one host collide or cross-join: derived from a job id every rank shares, else refused
+            job = os.environ.get("PWAF_JOB_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID")
+            if not job:
+                raise RuntimeError(f"rank {rank} of {world} was started without a launcher and without MASTER_PORT: set MASTER_PORT (the same on every rank), "
+                                   "or PWAF_JOB_ID to derive one, or start the ranks with `python -m torch.distributed.run --master-port P`")
+            import zlib
+
+            os.environ["MASTER_PORT"] = str(20000 + zlib.crc32(job.encode()) % 20000)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":

@@ -36,7 +36,8 @@ def test_every_caller_gets_its_own_verdict_and_latency_of_the_model():
     assert out["batches"] < out["requests"] / 4, out  # 64 native callers really are batched
     print("micro-batcher over the stub engine (150 us per batch):", out)
     # not a timing assertion a loaded CI host could fail on, only a sanity bound: a request is answered within a few batch times
-    assert out["p50_us"] < 50000, out  # (a host running a dozen other processes measured 8 ms)
+    # (a host running a dozen other processes measured 8 ms: the default bound only catches a hang; PWAF_TEST_QUIET_HOST=1 keeps the tight one)
+    assert out["p50_us"] < (5000 if os.environ.get("PWAF_TEST_QUIET_HOST") else 50000), out
 
 
 @pytest.mark.parametrize("threads,per,deadline,max_batch", [(16, 100, 200, 4), (8, 50, 50, 1), (3, 200, 1000, 4096), (1, 50, 200, 4096)])
