@@ -2621,7 +2621,9 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
     const bool true_triggers = a.trig_off[1] != a.trig_off[0];  // rules whose chosen positive literal is the constant TRUE (`expression: None`)
 
     // inputs one group ahead, visited bits two groups ahead: see verdict_kernel
-    constexpr int kPre = kVerdictPre;
+    // (<= 64 passes: a group of the 1k-rule set has one dense pass and two or three non-empty sparse ones; every slot costs a dozen instructions per group
+    // whether it is used or not — the rest are fetched inside the group)
+    constexpr int kPre = BR == 1 ? 4 : kVerdictPre;
     constexpr int kBitRegs = BR;
     struct Bits {
         unsigned long long w[kBitRegs];
@@ -2745,8 +2747,14 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
             }
             n_entries += cnt;
         };
-        // the batch registers: entries gathered one (wave-uniform) column at a time
-        uint32_t b_col = 0, b_lo = 0, b_hi = 0, bn = 0;
+        // the batch registers: the attribute kernel's first pairs are entries as they come (lane k = pair k); the scans' entries are gathered
+        // behind them one (wave-uniform) column at a time — one batch, one append, in the common case
+        const uint32_t n_first = (dbg_skip & 2u) ? 0u : min(n_pairs, 64u);
+        uint32_t b_col = cur.pair0.x, b_lo = cur.pair0.z, b_hi = cur.pair0.w, bn = n_first;
+        if (bn == 64) {
+            append_batch(b_col, b_lo, b_hi, 64);
+            bn = 0;
+        }
         auto flush = [&]() {
             if (bn == 0) return;
             append_batch(b_col, b_lo, b_hi, bn);
@@ -2849,18 +2857,25 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
             }
         }
         flush();
-        // 3. the attribute kernel's pairs are entries as they come: 64 per step
+        // 3. the attribute kernel's pairs beyond the first 64 (rare)
         if (!(dbg_skip & 2u)) {
-            for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64) {
+            for (uint32_t p0 = 64; p0 < n_pairs; p0 += 64) {
                 const uint32_t cnt = min(64u, n_pairs - p0);
-                uint4 pr = cur.pair0;
-                if (p0 != 0 && lane < cnt) pr = pairs[p0 + lane];
+                uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < cnt) pr = pairs[p0 + lane];
                 append_batch(pr.x, pr.z, pr.w, cnt);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // a column's word: two dependent LDS reads, no branch (entry 0 = TRUE stands in for a clean column's index) — unless the group
+        // appended more entries than LDS holds (wave-uniform, rare): then a spilled word comes from L2, where the ORs were performed
+        const bool spilled = n_entries > e_cap;
         auto col_word = [&](const uint32_t c) -> unsigned long long {
             const uint32_t s = slot[c];
+            if (!spilled) {
+                const unsigned long long v = vals[s ? s - 1u : 0u];
+                return s ? v : 0ull;
+            }
             if (s == 0) return 0ull;
             return s < 255u ? vals[s - 1u] : __hip_atomic_load(spill + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
