@@ -235,12 +235,14 @@ struct pwaf_engine {
     size_t next_ctx = 0;
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
-    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0;
+    uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0, n_lazy = 0;
+    DevBuf lazy_atoms;  // (VerdictArgs::lazy)
+    std::vector<uint32_t> lazy_vars;  // (VerdictArgs::lazy_var)
     uint32_t n_short = 0;  // short-literal atoms (kernels.h: ShortAtom) of the one field handled that way
     int short_field = -1;
     DevBuf short_atoms;
     uint32_t class_words = 1, acmp_words = 0, geo_default = 0, n_classes = 1;
-    DevBuf class_rows, dir_esc, leaf_root;
+    DevBuf class_rows, dir_esc, leaf_root, geo_leaf_root;
     std::vector<uint32_t> host_cc_masks, host_iu_masks1;  // kept for building the per-record rows
     std::vector<std::pair<uint32_t, uint32_t>> host_acmp;  // (operator 0: ==, 1: <=; constant) of the client.asn comparisons
     std::vector<int64_t> host_iu_vals1;
@@ -572,8 +574,9 @@ void set_trie_args(const pwaf_engine *e, VerdictArgs &v) {
     v.set_masks = (const uint32_t *)e->set_masks.p;
     v.set_words = P.set_words;
     v.n_ip_lists = P.n_ip_lists;
-    v.geo_root4 = P.geo_trie.root4.empty() ? leaf : (const uint32_t *)e->geo_root4.p;
-    v.geo_root6 = P.geo_trie.root6.empty() ? leaf : (const uint32_t *)e->geo_root6.p;
+    const uint32_t *geo_leaf = (const uint32_t *)e->geo_leaf_root.p;
+    v.geo_root4 = P.geo_trie.root4.empty() ? geo_leaf : (const uint32_t *)e->geo_root4.p;
+    v.geo_root6 = P.geo_trie.root6.empty() ? geo_leaf : (const uint32_t *)e->geo_root6.p;
     v.geo_nodes = (const uint32_t *)e->geo_nodes.p;
     v.has_geo = P.has_geo ? 1u : 0u;
     v.dir24 = (const uint32_t *)e->dir24.p;
@@ -945,6 +948,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.pool = (const PoolEntry *)S.pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
+    v.lazy = (const CmpAtomDev *)e->lazy_atoms.p;
+    v.n_lazy = e->n_lazy;
+    v.n_lazy_var = (uint32_t)e->lazy_vars.size();
+    for (size_t k = 0; k < e->lazy_vars.size(); k++) v.lazy_var[k] = e->lazy_vars[k];
     v.n_short = e->n_short;
     v.short_atoms = (const ShortAtom *)e->short_atoms.p;
     if (e->n_short) {
@@ -1794,8 +1801,6 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             }
         }
         e->acmp_words = ((uint32_t)e->host_acmp.size() + 31) / 32;
-        e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
-        UP(num_atoms, cmp_atoms)
         UP(bit_atoms, bit_col)
         // Trigger lists: a rule can match only if one of its DNF terms is true; a term with a positive literal needs that
         // column to be non-zero. Per term pick the positive literal least likely to be set (scan < membership < comparison <
@@ -1812,20 +1817,24 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         for (uint32_t d : bit_atoms) rank[d & 0xFFFFFu] = 60;
         std::vector<std::vector<uint16_t>> by_col(P.n_cols);
         std::vector<uint32_t> always((P.rules.size() + 31) / 32 + 1, 0);
+        std::vector<uint8_t> in_untriggered_term(P.n_cols, 0);  // the column stands in a term made of negations only: its rule is a candidate in EVERY group
         for (size_t r = 0; r < P.rules.size(); r++) {
             const DevRule &dr = P.rules[r];
             int best = -1;
             bool term_open = false;
+            uint32_t term_first = dr.lit_off;
             for (uint32_t k = dr.lit_off; k < dr.lit_off + dr.lit_cnt; k++) {
                 const uint32_t lit = P.lits[k];
-                if (!term_open) { best = -1; term_open = true; }
+                if (!term_open) { best = -1; term_open = true; term_first = k; }
                 if (!(lit & LIT_NEG)) {
                     const int c = (int)(lit & LIT_ATOM_MASK);
                     if (best < 0 || rank[c] < rank[best]) best = c;
                 }
                 if (lit & LIT_TERM_END) {
-                    if (best < 0) always[r >> 5] |= 1u << (r & 31);
-                    else if (by_col[best].empty() || by_col[best].back() != (uint16_t)r) by_col[best].push_back((uint16_t)r);
+                    if (best < 0) {
+                        always[r >> 5] |= 1u << (r & 31);
+                        for (uint32_t q = term_first; q <= k; q++) in_untriggered_term[P.lits[q] & LIT_ATOM_MASK] = 1;
+                    } else if (by_col[best].empty() || by_col[best].back() != (uint16_t)r) by_col[best].push_back((uint16_t)r);
                     term_open = false;
                 }
             }
@@ -1837,6 +1846,51 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             trig_off.push_back((uint32_t)trig_rules.size());
         }
         e->n_trig = (uint32_t)trig_rules.size();
+        // LAZY comparison atoms (round 6; program.h: LIT_LAZY). `path.length() > 20`, `remote_port >= 1024` hold for somebody in nearly every
+        // group of 64 requests, yet almost all of them only ever stand beside a rarer literal (`lit && path.length() > K`): the attribute kernel
+        // spent a third of its time evaluating them for every group, and the verdict kernel filed a pair for each. An atom that is NO rule's
+        // trigger (and stands in no term of negations only) is only needed once such a rule is a candidate whose other literals hold for somebody: the verdict kernel then compares the
+        // 64 requests' values itself. (client.asn comparisons stay eager: engine-resolved records answer them through class-row bits.)
+        std::vector<CmpAtomDev> lazy_atoms;
+        std::vector<uint32_t> lazy_of(P.n_cols, 0xFFFFFFFFu);
+        if (verdict_mode(P.flags) >= 3u && !(P.flags & PWAF_OPT_EAGER_CMP)) {
+            // (up to four variables, constants that a value clipped to 16 bits still compares exactly against: the verdict kernel keeps a
+            // group's values of the lazy variables in two registers)
+            std::vector<CmpAtomDev> eager;
+            for (const CmpAtomDev &ca : cmp_atoms) {
+                const uint32_t col = ca.col & 0xFFFFFFu, code = ca.col >> 24, vi = code / 2u;
+                // (an atom of a term without a trigger — `user_agent.length() >= 256` is NOT(length <= 255): gate A — would be evaluated lazily in every group)
+                bool lazy = vi != 6u && by_col[col].empty() && !in_untriggered_term[col] && ca.c <= 65534u;
+                uint32_t slot = 0;
+                if (lazy) {
+                    slot = (uint32_t)(std::find(e->lazy_vars.begin(), e->lazy_vars.end(), vi) - e->lazy_vars.begin());
+                    if (slot == e->lazy_vars.size()) {
+                        if (slot < 4) e->lazy_vars.push_back(vi);
+                        else lazy = false;
+                    }
+                }
+                if (lazy) {
+                    lazy_of[col] = (uint32_t)lazy_atoms.size();
+                    lazy_atoms.push_back({(2u * slot + (code & 1u)) << 24, ca.c});
+                } else {
+                    eager.push_back(ca);
+                }
+            }
+            cmp_atoms.swap(eager);
+        }
+        e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
+        e->n_lazy = (uint32_t)lazy_atoms.size();
+        if (lazy_atoms.empty()) lazy_atoms.push_back({0, 0});
+        UP(num_atoms, cmp_atoms)
+        UP(lazy_atoms, lazy_atoms)
+        {
+            std::vector<uint32_t> dev_lits = P.lits;
+            for (uint32_t &lit : dev_lits) {
+                const uint32_t j = lazy_of[lit & LIT_ATOM_MASK];
+                if (j != 0xFFFFFFFFu) lit = (lit & (LIT_NEG | LIT_TERM_END)) | LIT_LAZY | j;
+            }
+            UP(lits, dev_lits)
+        }
         UP(trig_off, trig_off)
         UP(trig_rules, trig_rules)
         UP(always_rules, always)
@@ -1858,7 +1912,6 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         UP(country_luts, masks)
     }
     UP(rules, P.rules)
-    UP(lits, P.lits)
     UP(set_masks, P.set_masks)
     UP(ip_root4, P.ipset_trie.root4)
     UP(ip_root6, P.ipset_trie.root6)
@@ -1903,6 +1956,11 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         UP(geo_nodes, nd)
         const std::vector<uint32_t> leaf(65536, TRIE_LEAF);
         UP(leaf_root, leaf)
+        // (a GeoIP family without prefixes: every address reads the DEFAULT record's class — not class 0: `["XX"].contains(client.country)` or
+        // `client.asn < N` hold for the default record. Round 6: an IPv6 client against a table of IPv4 prefixes read class 0 and such a rule
+        // failed open; found by tests/test_gpu_paths.py: test_lazy_comparison_atoms_agree_with_eager_ones_and_the_oracle)
+        const std::vector<uint32_t> geo_leaf(65536, TRIE_LEAF | e->geo_default);
+        UP(geo_leaf_root, geo_leaf)
     }
     if (P.n_residual) {
         UP(residual_blob, P.residual_blob)
@@ -2015,9 +2073,9 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
 void pwaf_engine_destroy(pwaf_engine *e) {
     if (!e) return;
     for (auto &g : e->groups) { for (DevBuf *b : {&g.tab, &g.classmap, &g.special, &g.list_off, &g.list, &g.ftable, &g.c_head, &g.c_entries, &g.c_bytes, &g.c_classes}) b->release(); g.fl.release(); g.rt.release(); }
-    for (DevBuf *b : {&e->num_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
+    for (DevBuf *b : {&e->num_atoms, &e->lazy_atoms, &e->bit_atoms, &e->trig_off, &e->trig_rules, &e->always_rules, &e->iu_vals[0], &e->iu_vals[1], &e->iu_masks[0], &e->iu_masks[1], &e->country_luts, &e->rules, &e->lits,
                       &e->set_masks, &e->ip_root4, &e->ip_root6, &e->ip_nodes, &e->geo_root4, &e->geo_root6, &e->geo_nodes, &e->geo_recs, &e->residual_blob, &e->residual_errors, &e->geo_rec_root4, &e->geo_rec_root6, &e->geo_rec_nodes, &e->pass_base, &e->colmask, &e->dir24, &e->dir_chunks, &e->dir_vals, &e->dir_summary, &e->class_rows,
-                      &e->dir_esc, &e->leaf_root, &e->pass_table})
+                      &e->dir_esc, &e->leaf_root, &e->geo_leaf_root, &e->pass_table})
         b->release();
     if (e->residual_jit.module) {  // (a module belongs to the device it was loaded on)
         int cur = -1;

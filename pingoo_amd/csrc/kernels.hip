@@ -2636,6 +2636,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
         uint32_t flags, n_pairs;
         uint4 pair0;
         uint32_t res0;
+        uint32_t lv[2];  // the requests' values of the lazy comparison variables (VerdictArgs::lazy_var), 16 bits each
     };
     const uint32_t *my_bits[kBitRegs];
     uint32_t my_base[kBitRegs];
@@ -2691,6 +2692,18 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
         in.n_pairs = a.ghdr[gg];
         in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];
         in.res0 = (a.res_words && valid) ? a.res_match[i] : 0u;
+        in.lv[0] = in.lv[1] = 0u;
+        const uint32_t ii = valid ? i : 0u;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 4; sl++) {
+            if (sl >= a.n_lazy_var) break;  // (wave-uniform)
+            const uint32_t vi = a.lazy_var[sl];
+            uint32_t v;
+            if (vi < 5u) v = a.off[vi][ii + 1] - a.off[vi][ii];
+            else if (vi == 5u) v = a.port[ii];
+            else v = a.hoff[vi - 7u][ii + 1] - a.hoff[vi - 7u][ii];
+            in.lv[sl >> 1] |= min(v, 65535u) << (16u * (sl & 1u));
+        }
     };
     const uint32_t g_stride = gridDim.x * n_waves;
     Inputs cur;
@@ -2899,10 +2912,12 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
         bool undecided = valid;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
         for (uint32_t base = 0; base < n_cand && pending != 0 && !(dbg_skip & 32u); base += 64) {
-            unsigned long long fire = 0;
+            unsigned long long fire = 0, eff_mask = 0;
+            uint32_t lit_off = 0, lit_cnt = 0;
+            bool lazy_seen = false;
             if (base + lane < n_cand) {
                 const uint32_t my_cand = cand[base + lane];
-                uint32_t lit_off, lit_cnt, eff_u, eff_v;
+                uint32_t eff_u, eff_v;
                 if (LT) {
                     const uint2 hdr = l_rules[my_cand];
                     lit_off = hdr.x;
@@ -2923,17 +2938,52 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
                     for (int q = 0; q < 4; q++) lit[q] = k + q < lit_off + lit_cnt ? (LT ? l_lits[k + q] : a.lits[k + q]) : 0u;
                     unsigned long long cw[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) cw[q] = col_word(lit[q] & LIT_ATOM_MASK);
+                    for (int q = 0; q < 4; q++) cw[q] = col_word(lit[q] & LIT_ATOM_MASK);  // (a lazy literal's index is below n_cols too: the read is harmless)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        acc_and &= (lit[q] & LIT_NEG) ? ~cw[q] : cw[q];
+                        // a LAZY comparison atom reads as TRUE here, negated or not: what comes out is a superset of the rule's matches
+                        const unsigned long long t = (lit[q] & LIT_NEG) ? ~cw[q] : cw[q];
+                        acc_and &= (lit[q] & LIT_LAZY) ? ~0ull : t;
+                        lazy_seen = lazy_seen || (lit[q] & LIT_LAZY) != 0u;
                         if (lit[q] & LIT_TERM_END) {
                             acc_or |= acc_and;
                             acc_and = ~0ull;
                         }
                     }
                 }
-                fire = acc_or & ((eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull));
+                eff_mask = (eff_u ? ~verified_mask : 0ull) | (eff_v ? verified_mask : 0ull);
+                fire = acc_or & eff_mask;
+            }
+            // Rules with lazy comparison atoms whose OTHER literals hold for somebody (rare): the rule again, exactly, one request per lane —
+            // an eager literal's bit from its column word, a lazy one from the request's own value (fetched with the group's inputs)
+            for (unsigned long long need = __ballot(lazy_seen && fire != 0); need != 0; need &= need - 1) {
+                const int j = __builtin_ctzll(need);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lit_off, j), cn = (uint32_t)__builtin_amdgcn_readlane((int)lit_cnt, j);
+                const unsigned long long em = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(eff_mask >> 32), j) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eff_mask, j);
+                bool r_or = false, r_and = true;
+                for (uint32_t k = lo; k < lo + cn; k++) {
+                    const uint32_t lit = (uint32_t)__builtin_amdgcn_readfirstlane((int)(LT ? l_lits[k] : a.lits[k]));
+                    bool bit;
+                    if (lit & LIT_LAZY) {
+                        const CmpAtomDev la = a.lazy[lit & LIT_ATOM_MASK];
+                        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)(la.col >> 24)), cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)la.c), sl = code >> 1;
+                        const uint32_t v = (((sl & 2u) ? cur.lv[1] : cur.lv[0]) >> (16u * (sl & 1u))) & 0xFFFFu;  // (no dynamic index: the inputs stay in registers)
+                        bit = (code & 1u) ? v <= cc : v == cc;
+                    } else {
+                        bit = ((col_word(lit & LIT_ATOM_MASK) >> lane) & 1ull) != 0ull;
+                    }
+                    if (lit & LIT_NEG) bit = !bit;
+                    r_and = r_and && bit;
+                    if (lit & LIT_TERM_END) {
+                        r_or = r_or || r_and;
+                        r_and = true;
+                    }
+                }
+                const unsigned long long exact = __ballot(r_or && valid) & em;
+                uint32_t f_lo = (uint32_t)fire, f_hi = (uint32_t)(fire >> 32);
+                park64(f_lo, f_hi, exact, (uint32_t)j);
+                fire = ((unsigned long long)f_hi << 32) | f_lo;
             }
             unsigned long long firing = __ballot(fire != 0);
             uint32_t first = kNone;

@@ -263,6 +263,10 @@ struct DevRule {
 static constexpr uint32_t LIT_NEG = 1u << 30;       // negated atom
 static constexpr uint32_t LIT_TERM_END = 1u << 31;  // last literal of its conjunction
 static constexpr uint32_t LIT_ATOM_MASK = (1u << 24) - 1;
+// DEVICE copy of the literals only (engine.cpp; never in Program::lits): a LAZY comparison atom — `length / port op constant` that is no rule's
+// trigger — is not evaluated per group by the attribute kernel; its literal carries an index into VerdictArgs::lazy instead of a column and the
+// verdict kernel evaluates it for the few rules whose other literals already hold for somebody (kernels.hip: verdict2_kernel)
+static constexpr uint32_t LIT_LAZY = 1u << 29;
 
 struct NumAtomDev {  // numeric atom descriptor consumed by the verdict kernel
     uint32_t col;    // device column

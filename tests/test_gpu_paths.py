@@ -543,3 +543,68 @@ def test_rule_sets_beyond_a_device_row_width_create_and_match_on_the_device(what
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, what)
     assert len(set(want["rule_idx"].tolist())) >= 3
     eng.close()
+
+
+def test_lazy_comparison_atoms_agree_with_eager_ones_and_the_oracle():
+    """Round 6: a length / port comparison that is no rule's trigger is not evaluated per group by the attribute kernel any more — the verdict
+    kernel evaluates it for the rules whose other literals already hold for somebody (program.h: LIT_LAZY). Rule sets that mix such atoms
+    every way the DNF allows — beside a literal, negated, in several terms, under a conditional, beside a membership atom, alone (then the
+    atom IS the trigger and stays eager), over header lengths — against the oracle and against PWAF_OPT_EAGER_CMP (round 5's evaluation)."""
+    rng = random.Random(23)
+    words = ["admin", "login", "wp-", ".php", "select", "etc/passwd", "api/v", "..%2f"] + ["".join(rng.choice("bcdfgklmnprstvz") for _ in range(5)) for _ in range(40)]
+    neutral = ["".join(rng.choice("aeiouy") for _ in range(rng.randrange(1, 9))) for _ in range(300)] + ["index.html", "x" * 25]
+    F = ["http_request.path", "http_request.url", "http_request.host", "http_request.user_agent", 'http_request.headers["x-tok"]']
+
+    def cmp_atom():
+        k = rng.randrange(6)
+        if k == 0:
+            return f"{rng.choice(F)}.length() {rng.choice(['>', '>=', '<', '<=', '==', '!='])} {rng.choice([0, 1, 5, 12, 20, 40, 64, 255, 256])}"
+        if k == 1:
+            return f"client.remote_port {rng.choice(['>', '>=', '<', '<=', '==', '!='])} {rng.choice([0, 80, 1024, 30000, 65535, 70000])}"
+        if k == 2:
+            return f"!({rng.choice(F)}.length() > {rng.choice([3, 10, 30])})"
+        if k == 3:
+            return f"client.asn {rng.choice(['==', '<', '>='])} {rng.choice([0, 64512, 15169])}"
+        if k == 4:
+            return f"({rng.choice(F)}.length() < 8 || client.remote_port % 2 == 0)"  # (a residual atom beside a lazy one)
+        return f"{rng.choice(F)}.length() + 0 == {rng.choice([5, 12])}"
+
+    def lit():
+        return f'{rng.choice(F[:2])}.contains("{rng.choice(words)}")'
+
+    rules = []
+    for k in range(120):
+        shape = rng.randrange(8)
+        if shape == 0: e = f"{lit()} && {cmp_atom()}"
+        elif shape == 1: e = f"({lit()} || {lit()}) && {cmp_atom()} && !({cmp_atom()})"
+        elif shape == 2: e = f"{cmp_atom()} ? {lit()} : ({lit()} && {cmp_atom()})"
+        elif shape == 3: e = f"{cmp_atom()} && {cmp_atom()} && {rng.choice(F[:2])}.length() == {rng.randrange(3, 60)}"  # no other literal: one of the atoms is the trigger
+        elif shape == 4: e = f'lists["nets"].contains(client.ip) && {cmp_atom()}'
+        elif shape == 5: e = f"({lit()} && {cmp_atom()}) || ({lit()} && {cmp_atom()}) || ({cmp_atom()} && {lit()} && {lit()})"
+        elif shape == 6: e = f"!({lit()}) ? false : {cmp_atom()}"
+        else: e = f'http_request.method == "POST" && {cmp_atom()} && {lit()}'
+        rules.append((f"r{k}", e, [B if k % 3 else CAP]))
+    lists = {"nets": (_abi.LIST_IP, ["10.0.0.0/8", "1.2.3.0/24", "2001:db8::/32"])}
+    geo = geoip_entries([("8.8.8.0/24", 15169, "US"), ("5.5.0.0/16", 64512, "KP")])
+    reqs = []
+    for _ in range(30_000):
+        segs = "/".join(rng.choice(words) if rng.random() < 0.12 else rng.choice(neutral) for _ in range(rng.randrange(1, 5)))
+        reqs.append(Request(path="/" + segs, url="/" + segs + rng.choice(["", "?q=1", "?id=" + "9" * rng.randrange(0, 40)]), host=rng.choice(["a.b", "example.com", "h" * 20]),
+                            method=rng.choice(["GET", "POST"]), user_agent=rng.choice(["Mozilla/5.0 (X11)", "curl/8", "x" * 64]), ip=rng.choice(["8.8.8.8", "10.1.2.3", "5.5.1.1", "9.9.9.9", "2001:db8::1"] + ["9.9.9.9"] * 20),
+                            remote_port=rng.choice([80, 1023, 1024, 30000, 65535]), captcha_verified=rng.random() < 0.3, headers={"x-tok": "t" * rng.randrange(0, 16)} if rng.random() < 0.5 else None))
+    batch = RequestBatch.from_requests(reqs)
+    want = pyoracle.Oracle(rules, lists, geo).evaluate(batch, threads=8)
+    assert len(set(want["rule_idx"].tolist())) > 20
+    for fl in (0, _abi.OPT_EAGER_CMP, _abi.OPT_TINY_VERDICT_SLOTS, _abi.OPT_SPARSE_VERDICT):
+        eng = RuleEngine(rules, lists, geo, flags=fl)
+        got, counts = eng.evaluate_batch(batch, with_counts=True)
+        H.assert_verdicts_equal(got, want, batch, f"lazy comparison atoms, flags {fl}")
+        assert counts.tolist() == np.bincount(want["action"], minlength=4).tolist()
+        eng.close()
+    # the batch supplies asn / country itself: client.asn comparisons are comparison atoms then (never lazy)
+    for r in reqs[:5000]:
+        r.asn, r.country = rng.choice([0, 64512, 15169, 7]), "US"
+    b2 = RequestBatch.from_requests(reqs[:5000])
+    eng = RuleEngine(rules, lists, geo)
+    H.assert_verdicts_equal(eng.evaluate_batch(b2), pyoracle.Oracle(rules, lists, geo).evaluate(b2, threads=8), b2, "lazy comparison atoms, asn in the batch")
+    eng.close()
