@@ -1,6 +1,7 @@
 """Pins the CPU oracle: golden vectors derived from the reference's docs/call sites, and independent
 third-party implementations (CPython `re`, `ipaddress`) for the parts whose algorithm lives in
 un-vendored dependencies of the reference (regex 1.12.2, ipnetwork 0.21.1, maxminddb 0.24.0)."""
+import os
 import ipaddress
 import random
 import re
@@ -216,24 +217,70 @@ def test_regex_unicode_matches_cpython_re_in_str_mode():
 
 
 def test_unicode_tables_agree_with_cpython_unicodedata():
-    """unicode_data.inc comes from perl's UCD; CPython carries its own copy of the same Unicode version: every general category, code
-    point by code point, through the oracle's \\p{..}; \\d against str.isdecimal."""
+    """CPython carries its own copy of the Unicode Character Database (13.0.0): every general category, code point by code point, through
+    the oracle's \\p{..}; \\d against str.isdecimal. The oracle's tables describe 14.0 since round 6 (perl's 13.0 + node's answer on what 14.0
+    added, tools/merge_unicode_delta.py): compared on the code points 13.0 assigns, minus U+1734 whose category 14.0 changed (Mn -> Mc)."""
     import unicodedata
 
     assert unicodedata.unidata_version == "13.0.0"
-    cats = sorted({unicodedata.category(chr(c)) for c in range(0x110000)} - {"Cs"})
-    text = "".join(chr(c) for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF)
+    pts = [c for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF and unicodedata.category(chr(c)) != "Cn" and c != 0x1734]
+    text = "".join(chr(c) for c in pts)
     by_cat = {}
     for ch in text:
         by_cat.setdefault(unicodedata.category(ch), []).append(ch)
-    for cat in cats:
+    for cat in sorted(by_cat):
         inside = "".join(by_cat[cat])
         assert pyoracle.regex_is_match("^\\p{%s}+$" % cat, inside.encode()), cat
         assert not pyoracle.regex_is_match("\\P{%s}" % cat, inside.encode()), cat
         outside = "".join("".join(v) for k, v in by_cat.items() if k != cat)
         assert not pyoracle.regex_is_match("\\p{%s}" % cat, outside.encode()), cat
+    assert not pyoracle.regex_is_match("\\p{Cn}", text.encode())  # nothing 13.0 assigns is unassigned in 14.0
+    assert pyoracle.regex_is_match("^\\p{Mc}$", "\u1734".encode()) and pyoracle.regex_is_match("^\\p{Vithkuqi}\\p{Lu}$", "\U00010570\U00010570".encode())  # 14.0
     digits = "".join(ch for ch in text if ch.isdecimal())
     assert pyoracle.regex_is_match("^\\d+$", digits.encode()) and not pyoracle.regex_is_match("\\d", "".join(ch for ch in text if not ch.isdecimal()).encode())
+
+
+def test_unicode_tables_come_from_two_independent_sources(tmp_path):
+    """oracle/unicode_data.inc and pingoo_amd/csrc/unicode_data.inc used to be the SAME file (one generator, perl's
+    Unicode::UCD): a wrong script range, White_Space member or case-folding orbit was invisible to every product-vs-oracle test. Now the device
+    compiler reads what node's ICU says (tools/gen_unicode_tables_node.js, Unicode 14.0: /\\p{..}/u and /c/iu over every scalar value) and the
+    oracle what perl says on everything 13.0 assigns (+ node on the code points 14.0 added: tools/merge_unicode_delta.py). The generators
+    are re-run here and compared: outside 13.0's unassigned space they may differ ONLY where the standard itself changed between the versions —
+    U+1734 Mn -> Mc, U+16FE2/3 Common -> Han — and on the three case-folding orbits CaseFolding.txt gained in 15.1 (V8 folds them already)."""
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import merge_unicode_delta as M
+
+    committed_oracle, committed_product = os.path.join(root, "oracle", "unicode_data.inc"), os.path.join(root, "pingoo_amd", "csrc", "unicode_data.inc")
+    assert open(committed_product).readline().startswith("// GENERATED by tools/gen_unicode_tables_node.js") and "merge_unicode_delta.py" in open(committed_oracle).readline()
+    ot, of = M.parse(committed_oracle)
+    pt, pf = M.parse(committed_product)
+    do, dp = {M.key(t): M.to_set(t[2]) for t in ot}, {M.key(t): M.to_set(t[2]) for t in pt}
+    assert set(do) == set(dp) and len(do) > 200
+    assert all(do[k] == dp[k] for k in do) and set(of) == set(pf)  # the two committed files describe the same sets (from different sources)
+    if not (shutil.which("perl") and shutil.which("node")) or subprocess.run(["perl", "-MUnicode::UCD", "-e", "1"]).returncode != 0:
+        pytest.skip("perl (Unicode::UCD) and node are needed to re-run the two generators")
+    perl_out, node_out = tmp_path / "perl.inc", tmp_path / "node.inc"
+    perl_out.write_bytes(subprocess.run(["perl", os.path.join(root, "tools", "gen_unicode_tables.pl")], check=True, stdout=subprocess.PIPE).stdout)
+    node_out.write_bytes(subprocess.run(["node", "--max-old-space-size=4096", os.path.join(root, "tools", "gen_unicode_tables_node.js")], check=True, stdout=subprocess.PIPE).stdout)
+    assert node_out.read_bytes() == open(committed_product, "rb").read()  # the product's file IS node's output
+    a, fa = M.parse(str(perl_out))
+    b, fb = M.parse(str(node_out))
+    cn13 = M.unassigned(a)
+    assert 830 <= len(cn13 - M.unassigned(b)) <= 850  # 14.0 added 838 characters
+    da, db = {M.key(t): M.to_set(t[2]) for t in a}, {M.key(t): M.to_set(t[2]) for t in b}
+    diff = set()
+    for k in set(da) | set(db):
+        diff |= (da.get(k, set()) ^ db.get(k, set())) - cn13
+    assert diff == M.CHANGED_IN_14, sorted(hex(x) for x in diff)
+    assert {p for p in set(fa) ^ set(fb) if p[0] not in cn13 and p[1] not in cn13} == M.FOLDS_SINCE_15_1
+    # ... and the oracle's committed file is the merge of the two
+    merged = subprocess.run([sys.executable, os.path.join(root, "tools", "merge_unicode_delta.py"), str(perl_out), str(node_out)], check=True, stdout=subprocess.PIPE).stdout
+    assert merged == open(committed_oracle, "rb").read()
 
 
 def test_regex_syntax_errors_and_unsupported():
