@@ -1854,24 +1854,23 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         std::vector<CmpAtomDev> lazy_atoms;
         std::vector<uint32_t> lazy_of(P.n_cols, 0xFFFFFFFFu);
         if (verdict_mode(P.flags) >= 3u && !(P.flags & PWAF_OPT_EAGER_CMP)) {
-            // (up to four variables, constants that a value clipped to 16 bits still compares exactly against: the verdict kernel keeps a
-            // group's values of the lazy variables in two registers)
+            // (up to two variables: the verdict kernel keeps a group's raw values of the lazy variables in two registers)
             std::vector<CmpAtomDev> eager;
             for (const CmpAtomDev &ca : cmp_atoms) {
                 const uint32_t col = ca.col & 0xFFFFFFu, code = ca.col >> 24, vi = code / 2u;
                 // (an atom of a term without a trigger — `user_agent.length() >= 256` is NOT(length <= 255): gate A — would be evaluated lazily in every group)
-                bool lazy = vi != 6u && by_col[col].empty() && !in_untriggered_term[col] && ca.c <= 65534u;
+                bool lazy = vi != 6u && by_col[col].empty() && !in_untriggered_term[col] && ca.c <= 0xFFFFu;  // (the constant travels inside the literal word)
                 uint32_t slot = 0;
                 if (lazy) {
                     slot = (uint32_t)(std::find(e->lazy_vars.begin(), e->lazy_vars.end(), vi) - e->lazy_vars.begin());
                     if (slot == e->lazy_vars.size()) {
-                        if (slot < 4) e->lazy_vars.push_back(vi);
+                        if (slot < 2) e->lazy_vars.push_back(vi);
                         else lazy = false;
                     }
                 }
                 if (lazy) {
-                    lazy_of[col] = (uint32_t)lazy_atoms.size();
-                    lazy_atoms.push_back({(2u * slot + (code & 1u)) << 24, ca.c});
+                    lazy_of[col] = ca.c | ((code & 1u) << 16) | (slot << 17);
+                    lazy_atoms.push_back({(2u * slot + (code & 1u)) << 24, ca.c});  // (kept for pwaf_engine_stats-style introspection: the kernel reads the literal word)
                 } else {
                     eager.push_back(ca);
                 }

@@ -374,8 +374,8 @@ struct VerdictArgs {
                                   // code = 2 * variable (0-4 field lengths, 5 port, 6 asn) + operator (0: ==, 1: <=)
     uint32_t n_cmp;
     // LAZY comparison atoms (program.h: LIT_LAZY), evaluated by the verdict kernel on demand: col = (2 * slot + operator) << 24, c = the
-    // constant (<= 65534); slot s = comparison variable lazy_var[s] (as above: 0-4 field lengths, 5 port, 7 + k header lengths), whose values
-    // the verdict kernel fetches with a group's other inputs, clipped to 16 bits (exact for every constant a lazy atom may have)
+    // constant; slot s = comparison variable lazy_var[s] (as above: 0-4 field lengths, 5 port, 7 + k header lengths; at most two), whose raw
+    // values the verdict kernel fetches with a group's other inputs
     const CmpAtomDev *lazy;
     uint32_t n_lazy;
     uint32_t lazy_var[4], n_lazy_var;

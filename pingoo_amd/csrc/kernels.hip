@@ -2636,7 +2636,9 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
         uint32_t flags, n_pairs;
         uint4 pair0;
         uint32_t res0;
-        uint32_t lv[2];  // the requests' values of the lazy comparison variables (VerdictArgs::lazy_var), 16 bits each
+        // the lazy comparison variables (VerdictArgs::lazy_var, at most two), RAW — nothing here may wait for a load: a length as the request's END
+        // offset (its start is the neighbour lane's end; lane 0's is fetched when an atom is evaluated: rare), the port as it is
+        uint32_t lraw[2];
     };
     const uint32_t *my_bits[kBitRegs];
     uint32_t my_base[kBitRegs];
@@ -2689,20 +2691,32 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
         in.bits = bt;
         in.flags = valid ? (uint32_t)a.flags[i] : 0u;
         const uint32_t gg = min(g, a.n_groups - 1);
-        in.n_pairs = a.ghdr[gg];
+        {
+            // one register, three group-wide words: lane 0 = the attribute kernel's pair count, lane 1 + s = the group's FIRST offset of lazy length
+            // variable s (lane 0's start: every other lane's start is its neighbour's end)
+            const uint32_t *src = a.ghdr + gg;
+#pragma unroll
+            for (uint32_t sl = 0; sl < 2; sl++) {
+                if (sl >= a.n_lazy_var) break;
+                const uint32_t vi = a.lazy_var[sl];
+                if (vi != 5u && lane == 1u + sl) src = (vi < 5u ? a.off[vi] : a.hoff[vi - 7u]) + gg * 64u;
+            }
+            in.n_pairs = *src;
+        }
         in.pair0 = a.gpairs[(size_t)gg * a.pair_stride + lane];
         in.res0 = (a.res_words && valid) ? a.res_match[i] : 0u;
-        in.lv[0] = in.lv[1] = 0u;
+        in.lraw[0] = in.lraw[1] = 0u;
         const uint32_t ii = valid ? i : 0u;
 #pragma unroll
-        for (uint32_t sl = 0; sl < 4; sl++) {
-            if (sl >= a.n_lazy_var) break;  // (wave-uniform)
+        for (uint32_t sl = 0; sl < 2; sl++) {
+            if (sl >= a.n_lazy_var || (dbg_skip & 2048u)) break;  // (wave-uniform)
             const uint32_t vi = a.lazy_var[sl];
-            uint32_t v;
-            if (vi < 5u) v = a.off[vi][ii + 1] - a.off[vi][ii];
-            else if (vi == 5u) v = a.port[ii];
-            else v = a.hoff[vi - 7u][ii + 1] - a.hoff[vi - 7u][ii];
-            in.lv[sl >> 1] |= min(v, 65535u) << (16u * (sl & 1u));
+            if (vi == 5u) {
+                in.lraw[sl] = a.port[ii];
+            } else {
+                const uint32_t *o = vi < 5u ? a.off[vi] : a.hoff[vi - 7u];
+                in.lraw[sl] = o[ii + 1];
+            }
         }
     };
     const uint32_t g_stride = gridDim.x * n_waves;
@@ -2729,7 +2743,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
 
         const uint32_t flags = cur.flags;
         const uint4 *pairs = a.gpairs + (size_t)g * a.pair_stride;
-        const uint32_t n_pairs = cur.n_pairs;
+        const uint32_t n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)cur.n_pairs, 0);
         const unsigned long long verified_mask = __ballot(valid && (flags & PWAF_FLAG_CAPTCHA_VERIFIED));
 
         uint32_t n_entries = 1;  // (entry 0 = TRUE)
@@ -2909,6 +2923,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
 
         // 5. evaluate candidates: one lane per rule, 64 requests per ALU op; first match wins (see verdict_kernel)
         unsigned long long pending = valid_mask;
+        uint32_t n_exact = 0;
         bool undecided = valid;
         uint32_t my_action = PWAF_ACTION_ALLOW, my_rule = PWAF_RULE_NONE;
         for (uint32_t base = 0; base < n_cand && pending != 0 && !(dbg_skip & 32u); base += 64) {
@@ -2956,7 +2971,8 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
             }
             // Rules with lazy comparison atoms whose OTHER literals hold for somebody (rare): the rule again, exactly, one request per lane —
             // an eager literal's bit from its column word, a lazy one from the request's own value (fetched with the group's inputs)
-            for (unsigned long long need = __ballot(lazy_seen && fire != 0); need != 0; need &= need - 1) {
+            if (dbg_skip & 512u) n_exact += (uint32_t)__builtin_popcountll(__ballot(lazy_seen && fire != 0));
+            for (unsigned long long need = (dbg_skip & 1024u) ? 0ull : __ballot(lazy_seen && fire != 0); need != 0; need &= need - 1) {
                 const int j = __builtin_ctzll(need);
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lit_off, j), cn = (uint32_t)__builtin_amdgcn_readlane((int)lit_cnt, j);
                 const unsigned long long em = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(eff_mask >> 32), j) << 32) |
@@ -2966,10 +2982,14 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
                     const uint32_t lit = (uint32_t)__builtin_amdgcn_readfirstlane((int)(LT ? l_lits[k] : a.lits[k]));
                     bool bit;
                     if (lit & LIT_LAZY) {
-                        const CmpAtomDev la = a.lazy[lit & LIT_ATOM_MASK];
-                        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)(la.col >> 24)), cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)la.c), sl = code >> 1;
-                        const uint32_t v = (((sl & 2u) ? cur.lv[1] : cur.lv[0]) >> (16u * (sl & 1u))) & 0xFFFFu;  // (no dynamic index: the inputs stay in registers)
-                        bit = (code & 1u) ? v <= cc : v == cc;
+                        const uint32_t cc = lit & 0xFFFFu, sl = (lit >> 17) & 1u;
+                        const uint32_t raw = sl ? cur.lraw[1] : cur.lraw[0];  // (no dynamic index: the inputs stay in registers)
+                        uint32_t v = raw;
+                        if (a.lazy_var[sl] != 5u) {  // length = end - the neighbour's end (lane 0: the group's first offset)
+                            const uint32_t st0 = sl ? (uint32_t)__builtin_amdgcn_readlane((int)cur.n_pairs, 2) : (uint32_t)__builtin_amdgcn_readlane((int)cur.n_pairs, 1);
+                            v = raw - (uint32_t)__builtin_amdgcn_update_dpp((int)st0, (int)raw, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                        }
+                        bit = (lit & 0x10000u) ? v <= cc : v == cc;
                     } else {
                         bit = ((col_word(lit & LIT_ATOM_MASK) >> lane) & 1ull) != 0ull;
                     }
@@ -3014,6 +3034,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
                 my_action = (verified_mask & mybit) ? eff_v : eff_u;
             }
         }
+        if (dbg_skip & 512u) my_rule = n_exact;  // profiling aid: rules evaluated exactly for their lazy comparison atoms
         if (dbg_skip & 64u) my_rule = n_cand | (n_entries << 16);  // profiling aid: candidates and entries of the group instead of the deciding rule
 
         // 6. outputs
