@@ -235,6 +235,7 @@ struct pwaf_engine {
     size_t next_ctx = 0;
     std::vector<DevGroup> groups;
     DevBuf num_atoms, bit_atoms /* (source word, bit) -> column */, trig_off, trig_rules, always_rules, country_luts /* transposed: [676][cc_words] */, rules, lits, set_masks;
+    uint32_t cmp_vars = 0;  // (VerdictArgs::cmp_vars)
     uint32_t cc_words = 1, n_cmp_atoms = 0, n_bit_atoms = 0, n_trig = 0, n_lazy = 0;
     DevBuf lazy_atoms;  // (VerdictArgs::lazy)
     std::vector<uint32_t> lazy_vars;  // (VerdictArgs::lazy_var)
@@ -948,6 +949,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     v.pool = (const PoolEntry *)S.pool.p;
     v.cmp = (const CmpAtomDev *)e->num_atoms.p;
     v.n_cmp = e->n_cmp_atoms;
+    v.cmp_vars = e->cmp_vars;
     v.lazy = (const CmpAtomDev *)e->lazy_atoms.p;
     v.n_lazy = e->n_lazy;
     v.n_lazy_var = (uint32_t)e->lazy_vars.size();
@@ -1788,9 +1790,25 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
         }
         std::stable_sort(canon.begin(), canon.end(), [](const Canon &x, const Canon &y) { return x.vi != y.vi ? x.vi < y.vi : x.op < y.op; });
         if (canon.size() > 65535) { fail(PWAF_E_UNSUPPORTED, "more than 65535 comparison predicates"); return dev_fail(PWAF_E_UNSUPPORTED); }
+        // POLARITY (round 6). `user_agent.length() >= 256` reaches here as NOT(length <= 255), `path.length() > 20` as NOT(length <= 20): atoms that
+        // hold for nearly every request and only ever appear negated — a (column, mask) pair per group for nothing, and gate A's term
+        // [NOT(length <= 255)] has no positive literal at all: the gate was a candidate rule in EVERY group. An atom whose literals are mostly
+        // negations is evaluated COMPLEMENTED on the device (flag 0x80 of its code: `v > c`, `v != c`) and every literal of it toggles its
+        // negation in the device copy of the literals: same truth table, rare columns, and gate A becomes a triggered rule. (client.asn
+        // comparisons keep their polarity: an engine-resolved record answers them through class-row bits computed below.)
+        std::vector<uint8_t> flipped(P.n_cols, 0);
+        if (verdict_mode(P.flags) >= 3u && !(P.flags & PWAF_OPT_EAGER_CMP)) {
+            std::vector<uint32_t> n_pos(P.n_cols, 0), n_neg(P.n_cols, 0);
+            for (const uint32_t lit : P.lits) ((lit & LIT_NEG) ? n_neg : n_pos)[lit & LIT_ATOM_MASK]++;
+            for (const Canon &cn : canon)
+                if (cn.vi != 6u && n_neg[cn.col] > n_pos[cn.col]) flipped[cn.col] = 1;
+        }
+        std::vector<uint32_t> L = P.lits;  // the literals as the device evaluates them
+        for (uint32_t &lit : L)
+            if (flipped[lit & LIT_ATOM_MASK]) lit ^= LIT_NEG;
         std::vector<CmpAtomDev> cmp_atoms;
         for (const Canon &cn : canon) {
-            cmp_atoms.push_back({cn.col | ((2 * cn.vi + cn.op) << 24), cn.c});
+            cmp_atoms.push_back({cn.col | (((2 * cn.vi + cn.op) | (flipped[cn.col] ? 0x80u : 0u)) << 24), cn.c});
             if (cn.vi == 6) {
                 // client.asn against a constant is a function of the GeoIP record: bit j of the class row's comparison words
                 // (source words 24..27) when the engine resolves the record itself
@@ -1824,7 +1842,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             bool term_open = false;
             uint32_t term_first = dr.lit_off;
             for (uint32_t k = dr.lit_off; k < dr.lit_off + dr.lit_cnt; k++) {
-                const uint32_t lit = P.lits[k];
+                const uint32_t lit = L[k];
                 if (!term_open) { best = -1; term_open = true; term_first = k; }
                 if (!(lit & LIT_NEG)) {
                     const int c = (int)(lit & LIT_ATOM_MASK);
@@ -1833,7 +1851,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                 if (lit & LIT_TERM_END) {
                     if (best < 0) {
                         always[r >> 5] |= 1u << (r & 31);
-                        for (uint32_t q = term_first; q <= k; q++) in_untriggered_term[P.lits[q] & LIT_ATOM_MASK] = 1;
+                        for (uint32_t q = term_first; q <= k; q++) in_untriggered_term[L[q] & LIT_ATOM_MASK] = 1;
                     } else if (by_col[best].empty() || by_col[best].back() != (uint16_t)r) by_col[best].push_back((uint16_t)r);
                     term_open = false;
                 }
@@ -1857,7 +1875,7 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             // (up to two variables: the verdict kernel keeps a group's raw values of the lazy variables in two registers)
             std::vector<CmpAtomDev> eager;
             for (const CmpAtomDev &ca : cmp_atoms) {
-                const uint32_t col = ca.col & 0xFFFFFFu, code = ca.col >> 24, vi = code / 2u;
+                const uint32_t col = ca.col & 0xFFFFFFu, code = ca.col >> 24, vi = (code & 0x7Fu) / 2u;
                 // (an atom of a term without a trigger — `user_agent.length() >= 256` is NOT(length <= 255): gate A — would be evaluated lazily in every group)
                 bool lazy = vi != 6u && by_col[col].empty() && !in_untriggered_term[col] && ca.c <= 0xFFFFu;  // (the constant travels inside the literal word)
                 uint32_t slot = 0;
@@ -1869,8 +1887,8 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
                     }
                 }
                 if (lazy) {
-                    lazy_of[col] = ca.c | ((code & 1u) << 16) | (slot << 17);
-                    lazy_atoms.push_back({(2u * slot + (code & 1u)) << 24, ca.c});  // (kept for pwaf_engine_stats-style introspection: the kernel reads the literal word)
+                    lazy_of[col] = ca.c | ((code & 1u) << 16) | (slot << 17) | ((code & 0x80u) ? 1u << 18 : 0u);
+                    lazy_atoms.push_back({((2u * slot + (code & 1u)) | (code & 0x80u)) << 24, ca.c});  // (kept for pwaf_engine_stats-style introspection: the kernel reads the literal word)
                 } else {
                     eager.push_back(ca);
                 }
@@ -1878,12 +1896,14 @@ int pwaf_engine_create(const pwaf_rule_desc *rules, size_t n_rules, const pwaf_l
             cmp_atoms.swap(eager);
         }
         e->n_cmp_atoms = (uint32_t)cmp_atoms.size();
+        e->cmp_vars = 0;
+        for (const CmpAtomDev &ca : cmp_atoms) e->cmp_vars |= 1u << std::min(31u, ((ca.col >> 24) & 0x7Fu) / 2u);
         e->n_lazy = (uint32_t)lazy_atoms.size();
         if (lazy_atoms.empty()) lazy_atoms.push_back({0, 0});
         UP(num_atoms, cmp_atoms)
         UP(lazy_atoms, lazy_atoms)
         {
-            std::vector<uint32_t> dev_lits = P.lits;
+            std::vector<uint32_t> dev_lits = L;
             for (uint32_t &lit : dev_lits) {
                 const uint32_t j = lazy_of[lit & LIT_ATOM_MASK];
                 if (j != 0xFFFFFFFFu) lit = (lit & (LIT_NEG | LIT_TERM_END)) | LIT_LAZY | j;

@@ -373,6 +373,7 @@ struct VerdictArgs {
     const CmpAtomDev *cmp;        // comparison atoms (LEN / INT against a constant): col = column | code << 24 with
                                   // code = 2 * variable (0-4 field lengths, 5 port, 6 asn) + operator (0: ==, 1: <=)
     uint32_t n_cmp;
+    uint32_t cmp_vars;            // bit v: some (eager) comparison atom reads variable v — the attribute kernel fetches no other length
     // LAZY comparison atoms (program.h: LIT_LAZY), evaluated by the verdict kernel on demand: col = (2 * slot + operator) << 24, c = the
     // constant; slot s = comparison variable lazy_var[s] (as above: 0-4 field lengths, 5 port, 7 + k header lengths; at most two), whose raw
     // values the verdict kernel fetches with a group's other inputs

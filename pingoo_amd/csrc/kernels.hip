@@ -2561,9 +2561,13 @@ __host__ __device__ static inline uint32_t verdict_wave_lds_el(uint32_t n_cols, 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void park96(uint32_t &c, uint32_t &lo, uint32_t &hi, const uint32_t col, const unsigned long long m, const uint32_t l) {
+    // (scalar registers whatever the register allocator did with the wave-uniform values: under scalar-register pressure it keeps some in
+    // vector registers and hands THOSE to an "s" operand)
+    const uint32_t s_col = (uint32_t)__builtin_amdgcn_readfirstlane((int)col), s_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+    const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m), s_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
                  : "+v"(c), "+v"(lo), "+v"(hi)
-                 : "s"(col), "s"(l), "s"((uint32_t)m), "s"((uint32_t)(m >> 32))
+                 : "s"(s_col), "s"(s_l), "s"(s_lo), "s"(s_hi)
                  : "m0");
 }
 #pragma clang diagnostic pop
@@ -2990,6 +2994,7 @@ __global__ __launch_bounds__(768, BR == 1 ? 6 : 1) void verdict2_kernel(VerdictA
                             v = raw - (uint32_t)__builtin_amdgcn_update_dpp((int)st0, (int)raw, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
                         }
                         bit = (lit & 0x10000u) ? v <= cc : v == cc;
+                        if (lit & 0x40000u) bit = !bit;  // (the atom's polarity on the device: engine.cpp, POLARITY)
                     } else {
                         bit = ((col_word(lit & LIT_ATOM_MASK) >> lane) & 1ull) != 0ull;
                     }
@@ -3293,7 +3298,7 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
         }
         in.port = a.port[i];
 #pragma unroll
-        for (int f = 0; f < 5; f++) in.len[f] = a.off[f][i + 1] - a.off[f][i];
+        for (int f = 0; f < 5; f++) in.len[f] = ((a.cmp_vars >> f) & 1u) ? a.off[f][i + 1] - a.off[f][i] : 0u;  // (wave-uniform: only the lengths some comparison atom reads)
         in.asn = from_row ? 0u : a.asn[i];
         in.country = from_row ? 0u : (uint32_t)a.country[i];
         in.sstart = a.n_short ? a.short_off[i] : 0u;
@@ -3421,7 +3426,8 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                     m_c = a.cmp[base + lane].c;
                 }
             }
-            const uint32_t my_code = base + lane < a.n_cmp ? m_col >> 24 : 0xFFu;
+            const uint32_t my_code = base + lane < a.n_cmp ? (m_col >> 24) & 0x7Fu : 0xFFu;
+            const unsigned long long flip_atoms = __ballot(base + lane < a.n_cmp && ((m_col >> 31) & 1u) != 0u);  // atoms evaluated complemented (engine.cpp, POLARITY)
             uint32_t acc_lo = 0, acc_hi = 0;
             auto cmp_var = [&](const uint32_t v, const int vi) {
 #pragma unroll
@@ -3431,18 +3437,17 @@ __global__ __launch_bounds__(256) void attr_kernel(VerdictArgs a) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1;
                         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m_c, (int)j);
-                        const unsigned long long m = __ballot(op == 0 ? v == c : v <= c) & valid_mask;
-                        park64(acc_lo, acc_hi, m, j);
+                        unsigned long long m = __ballot(op == 0 ? v == c : v <= c);
+                        if ((flip_atoms >> j) & 1ull) m = ~m;
+                        park64(acc_lo, acc_hi, m & valid_mask, j);
                     }
                 }
             };
-            cmp_var(cur.len[0], 0);
-            cmp_var(cur.len[1], 1);
-            cmp_var(cur.len[2], 2);
-            cmp_var(cur.len[3], 3);
-            cmp_var(cur.len[4], 4);
-            cmp_var(port, 5);
-            if (!from_row) cmp_var(asn, 6);
+#pragma unroll
+            for (int f = 0; f < 5; f++)
+                if ((a.cmp_vars >> f) & 1u) cmp_var(cur.len[f], f);
+            if ((a.cmp_vars >> 5) & 1u) cmp_var(port, 5);
+            if (!from_row && ((a.cmp_vars >> 6) & 1u)) cmp_var(asn, 6);
             for (uint32_t f = 0; f < a.n_hlen; f++) {  // EXTENSION: lengths of header columns (rare: fetched here, not prefetched)
                 const uint32_t ii = valid ? i : 0u;
                 cmp_var(a.hoff[f][ii + 1] - a.hoff[f][ii], 7 + (int)f);

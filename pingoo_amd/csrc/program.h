@@ -266,7 +266,7 @@ static constexpr uint32_t LIT_ATOM_MASK = (1u << 24) - 1;
 // DEVICE copy of the literals only (engine.cpp; never in Program::lits): a LAZY comparison atom — `length / port op constant` that is no rule's
 // trigger — is not evaluated per group by the attribute kernel; its literal carries an index into VerdictArgs::lazy instead of a column and the
 // verdict kernel evaluates it for the few rules whose other literals already hold for somebody (kernels.hip: verdict2_kernel)
-static constexpr uint32_t LIT_LAZY = 1u << 29;  // then bits [15:0] = the constant (<= 65534... any 16-bit value), bit 16 = operator (0: ==, 1: <=), bit 17 = slot of the variable (VerdictArgs::lazy_var)
+static constexpr uint32_t LIT_LAZY = 1u << 29;  // then bits [15:0] = the constant (<= 65534... any 16-bit value), bit 16 = operator (0: ==, 1: <=), bit 17 = slot of the variable (VerdictArgs::lazy_var), bit 18 = the atom is evaluated complemented (!=, >)
 
 struct NumAtomDev {  // numeric atom descriptor consumed by the verdict kernel
     uint32_t col;    // device column
