@@ -130,6 +130,7 @@ void pwaf_list_free(char **items, size_t n);
 #define PWAF_OPT_SPARSE_VERDICT 16384u /* A-B / testing: the verdict kernel with the round-5 SPARSE column file (dirty bits + rank per 32 columns) instead of the entry list (same verdicts) */
 #define PWAF_OPT_DENSE_VERDICT 2048u  /* A-B / testing: the verdict kernel with the round-4 DENSE column file (8 bytes per column and wave) instead of the sparse one (same verdicts) */
 #define PWAF_OPT_TINY_VERDICT_SLOTS 4096u /* testing: 8 entry slots per wave (with PWAF_OPT_SPARSE_VERDICT: 8 value slots of the sparse column file), so that every group takes the spill path (same verdicts) */
+#define PWAF_OPT_NO_DENSE_SWITCH 65536u /* A-B / testing: a pass whose prefilter flags most of the arena is still confirmed chunk by chunk (round 5), never walked whole (same verdicts) */
 #define PWAF_OPT_EAGER_CMP 32768u      /* A-B / testing: every length / port comparison is evaluated per group by the attribute kernel (round 5), none lazily by the verdict kernel (same verdicts) */
 #define PWAF_OPT_NO_DIR_SUMMARY 8192u  /* A-B / testing: IPv4 lookups always gather from the compressed DIR-24 table, without the summary bitmap in front of it (same verdicts) */
 #define PWAF_OPT_NO_RESIDUAL 64u      /* do not use the per-request residual interpreter (testing / benchmarking the column path alone) */

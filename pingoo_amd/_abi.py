@@ -24,7 +24,7 @@ RULE_ACTION_BLOCK, RULE_ACTION_CAPTCHA = 1, 2
 
 LIST_STRING, LIST_INT, LIST_IP = 0, 1, 2
 OPT_NO_UA_GATE, OPT_NO_CAPTCHA_BYPASS, OPT_NO_PREFILTER, OPT_STRICT, OPT_FILTER_STRIDE2, OPT_LENIENT, OPT_NO_RESIDUAL, OPT_GLOBAL_VERDICT_TABLES, OPT_NO_CONFIRM, OPT_NO_RESIDUAL_JIT = 1, 2, 4, 8, 16, 32, 64, 128, 512, 1024
-OPT_DENSE_VERDICT, OPT_TINY_VERDICT_SLOTS, OPT_NO_DIR_SUMMARY, OPT_SPARSE_VERDICT, OPT_EAGER_CMP = 2048, 4096, 8192, 16384, 32768
+OPT_DENSE_VERDICT, OPT_TINY_VERDICT_SLOTS, OPT_NO_DIR_SUMMARY, OPT_SPARSE_VERDICT, OPT_EAGER_CMP, OPT_NO_DENSE_SWITCH = 2048, 4096, 8192, 16384, 32768, 65536
 W_PARTIAL = 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CAPTCHA_VERIFIED = 1

@@ -781,7 +781,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     if ((rc = S.attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     const size_t n_slots = (size_t)std::max(kGapLists, e->n_gated);
-    const size_t ctrl_words = 2 + n_slots + e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count per filtered pass
+    const size_t ctrl_words = 2 + n_slots + 2 * (size_t)e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count and one dense-walk flag per filtered pass
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
     // zeroing the hit records themselves would write. They share ONE zeroed block with the control words and the confirm tier's walk bitmaps.
     const uint32_t bit_words = 2 * n_groups;
@@ -1108,7 +1108,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         if (all_confirm) list_variant[0] = 0;
     }
     const ListShape lshapes[2] = {list_shape(list_variant[0]), list_shape(list_variant[1])};
-    auto list_args = [&](size_t gi, const ListShape &lshape) -> ListScanArgs {
+    auto list_args = [&](size_t gi, const ListShape &lshape, bool full_table = false) -> ListScanArgs {
         const DevGroup &d = e->groups[gi];
         ListScanArgs a{};
         const DevGroup &src = d.share_owner >= 0 ? e->groups[(size_t)d.share_owner] : d;  // whose list this pass walks
@@ -1138,7 +1138,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         a.data = cols[d.field].data;
         a.off = cols[d.field].offsets;
         a.n = n;
-        const FlatDev &F = (d.confirm && d.rt.n_states) ? d.rt : d.fl;  // (a confirmed candidate walks the DFA of the pass's non-literal atoms)
+        const FlatDev &F = (d.confirm && d.rt.n_states && !full_table) ? d.rt : d.fl;  // (a confirmed candidate walks the DFA of the pass's non-literal atoms)
         a.flat = (const uint16_t *)F.flat.p;
         a.classmap = (const uint8_t *)F.flat_classmap.p;
         a.umap = F.scalar_mode ? (const uint8_t *)F.flat_classmap.p + kUmapAt : nullptr;
@@ -1183,6 +1183,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     // ---- 2. the descriptors of every launch of the batch (prefilter, resolve, confirm tier, list scans, residual kernel): built here,
     //         uploaded ONCE ----
     std::vector<uint32_t> &totals = col_bytes;
+    // the flag-density switch (kernels.h: ListScanArgs::dense_flag): per pass with a confirm tier, the device word that says "walked whole this batch"
+    std::vector<const uint32_t *> dense_flag_of(e->groups.size(), nullptr);
+    std::vector<uint32_t> filter_index(e->groups.size(), 0);  // a filtered pass's index among the filtered passes (its candidate / valid bitmap)
+    const bool dense_switch = !(P.flags & PWAF_OPT_NO_DENSE_SWITCH);
     std::vector<FilterArgs> fall;        // every filtered pass, in pass order
     std::vector<FilterArgs> by_stride[2];
     std::vector<ConfirmArgs> call;
@@ -1256,6 +1260,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             f.pair_base = f.sub_count + slabs;
             f.block_count = f.pair_base + slabs;
             f.bitmap = (uint32_t *)S.cand_bits.p + (size_t)fi * bit_words;
+            filter_index[gi] = fi;
             f.list = (uint32_t *)S.gate_lists.p + (size_t)d.gate * n;
             f.list_count = (uint32_t *)S.ctrl.p + 2 + d.gate;
             if (d.confirm) {
@@ -1264,6 +1269,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 f.pairs = (uint2 *)((char *)S.pairs.p + pair_at);
                 f.pair_count = (uint32_t *)S.ctrl.p + 2 + n_slots + fi;
                 pair_at += (uint64_t)f.pair_cap * sizeof(uint2);
+                if (dense_switch) {
+                    // more than half of the arena's 16-byte chunks flagged: confirming them one by one costs more than walking every request
+                    // (measured, round 5: the saturated stream took 22 ms in the confirm tier against 9 ms for the plain DFA over the same bytes;
+                    // the hostile stream of the 1k-rule set flags a quarter of its chunks and stays on the confirm tier: 1.3 ms against 3.9)
+                    f.dense_flag = (uint32_t *)S.ctrl.p + 2 + n_slots + e->n_filtered + fi;
+                    f.dense_thresh = (uint32_t)std::min<uint64_t>(0xFFFFFFFEu, (uint64_t)slabs * (kStreamSlab / 16) / 2);
+                    dense_flag_of[gi] = f.dense_flag;
+                }
             }
             f.first_block = 0;
             sub_at += (uint64_t)slabs * (kStreamSlab / 512);
@@ -1307,6 +1320,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.n_class_words = (uint32_t)d.filter.confirm.classes.size();
             c.rec = f.rec;
             c.valid_bits = f.bitmap;
+            c.dense_flag = f.dense_flag;
             c.walk_bits = (uint32_t *)S.walk_bits.p + (size_t)wi++ * bit_words;
             if (d.confirm_walk) {
                 c.walk_list = f.list;
@@ -1333,12 +1347,32 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         for (size_t gi = 0; gi < e->groups.size(); gi++) {
             const DevGroup &d = e->groups[gi];
             if (d.identity ? phase != 0 : (d.gate < 0 || d.filtered != (phase == 0))) continue;
+            if (phase == 0 && d.confirm && dense_flag_of[gi] != nullptr) {
+                // the pass's dense alternative: EVERY request through the full table (the whole-pass walk of PWAF_OPT_NO_CONFIRM, over the
+                // identity list), records and valid bits written for all; gets work only when the device set the pass's flag
+                ListScanArgs a = list_args(gi, lshapes[phase], /*full_table=*/true);
+                a.req_list = nullptr;
+                a.n_list = nullptr;
+                a.merge_rec = 0;
+                a.visited = (uint32_t *)S.cand_bits.p + (size_t)filter_index[gi] * bit_words;
+                a.dense_flag = dense_flag_of[gi];
+                a.dense_mode = 1;
+                la[phase].push_back(a);
+            }
             if (d.confirm && !d.confirm_walk) continue;  // every atom of the pass is a literal the confirm tier decided: nothing to walk
 #ifdef PWAF_PROFILING
             static const bool skip_identity = getenv("PWAF_SKIP_IDENTITY") != nullptr;  // timing experiment (wrong results)
             if (skip_identity && d.identity) continue;
 #endif
-            la[phase].push_back(list_args(gi, lshapes[phase]));
+            ListScanArgs a = list_args(gi, lshapes[phase]);
+            if (phase == 0 && d.confirm && dense_flag_of[gi] != nullptr) {  // the R-tier walk over the confirm tier's walk list: idle when the pass is walked whole
+                a.dense_flag = dense_flag_of[gi];
+                a.dense_mode = 2;
+            } else if (d.share_owner >= 0 && dense_flag_of[(size_t)d.share_owner] != nullptr) {  // a gap pass riding the owner's list through need masks
+                a.dense_flag = dense_flag_of[(size_t)d.share_owner];
+                a.dense_mode = 3;
+            }
+            la[phase].push_back(a);
         }
     ColPtrChunk ptrs{};  // residual kernel: the batch's string columns as arrays of pointers
     if (P.n_residual) {

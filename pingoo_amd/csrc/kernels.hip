@@ -541,13 +541,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 // spread one or a few walks per wave over the waves the launch has: the 64 walks of a wave advance in lockstep and every emit or cold
 // cell of one lane sends the whole wave through the slow path of its group of steps, so a wave of 64 true hits (what a dense walk list
 // is made of) crawls while the rest of the chip idles (measured: 0.07 -> 0.5 ms for ~10k walks when the lists became dense).
+// the list a pass walks in this batch (kernels.h: ListScanArgs::dense_flag)
+__device__ __forceinline__ ListOf list_of(const ListScanArgs &a) {
+    ListOf l{a.req_list, a.req_list != nullptr ? min(*a.n_list, a.n) : a.n};
+    if (a.dense_mode != 0u) {
+        const bool dense = *a.dense_flag != 0u;
+        if (a.dense_mode == 1u && !dense) l.n_l = 0u;
+        if (a.dense_mode == 2u && dense) l.n_l = 0u;
+        if (a.dense_mode == 3u && dense) l = ListOf{nullptr, a.n};
+    }
+    return l;
+}
+
 __global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t *plan /* [2 count + 1] */, uint32_t n_waves) {
     __shared__ uint32_t part[256];
     const uint32_t t = threadIdx.x;
     uint32_t items = 0;
     if (t < b.count) {
-        const ListScanArgs *pa = &b.g[t];
-        const uint32_t n_l = pa->req_list != nullptr ? min(*pa->n_list, pa->n) : pa->n;
+        const uint32_t n_l = list_of(b.g[t]).n_l;
         uint32_t epi = 1;
         while (epi < 64u * kListWalks && (n_l + epi - 1) / epi > n_waves) epi <<= 1;
         items = (n_l + epi - 1) / epi;
@@ -723,7 +734,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
             ps = lo;
         }
         const uint32_t first = plan[ps], it_end = min(it1, plan[ps + 1]), epi = plan[b.count + 1 + ps];
-        const ListScanArgs a = load_descriptor(&b.g[ps]);
+        ListScanArgs a = load_descriptor(&b.g[ps]);
+        const ListOf lst = list_of(a);
+        a.req_list = lst.req_list;  // (the flag-density switch may have turned a shared list into "every request")
         const uint32_t ncls = a.n_classes, stride = ncls + 3u;  // row: ncls transitions, the EMIT cell, the STAY cell, the END cell
         const uint32_t hot_elems = a.n_hot * stride;
         uint64_t *delta_lds = reinterpret_cast<uint64_t *>(lscan_lds) + (hot_elems * 2u + 2u + 15u) / 16u * 2u;  // (16-byte aligned, behind the sentinel cell)
@@ -751,7 +764,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void lscan_kernel(
         // index beyond the hot rows is clamped onto it and reads 0xFFFF = "this cell is cold" (no state has id 0x7FFF)
         if (threadIdx.x == 0) reinterpret_cast<uint16_t *>(lscan_lds)[hot_elems] = 0xFFFFu;
         __syncthreads();
-        const uint32_t n_l = a.req_list != nullptr ? min(*a.n_list, a.n) : a.n;
+        const uint32_t n_l = lst.n_l;
         // (the gap passes' lists stay with the lockstep loop: measured 0.25 -> 0.40 ms with this one on the hostile stream — their walks
         // are short and mostly LDS-resident, and the asynchronous iteration costs more per group)
 #ifdef PWAF_PROFILING
@@ -935,7 +948,8 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
     uint32_t items = 0;
     if (t < b.count) {
         const ConfirmArgs *pa = &b.c[t];
-        items = (min(*pa->pair_count, pa->pair_cap) + kConfirmThreads - 1) / kConfirmThreads;
+        const bool dense = pa->dense_flag != nullptr && *pa->dense_flag != 0u;  // (walked whole this batch: nothing to confirm)
+        items = dense ? 0u : (min(*pa->pair_count, pa->pair_cap) + kConfirmThreads - 1) / kConfirmThreads;
     }
     part[t] = items;
     __syncthreads();
@@ -1790,7 +1804,10 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(FilterTable B) {
         a.pair_base[k] = at;
         at += a.sub_count[k];
     }
-    if (t == 1023) *a.pair_count = part[1023];
+    if (t == 1023) {
+        *a.pair_count = part[1023];
+        if (a.dense_flag != nullptr) *a.dense_flag = part[1023] > a.dense_thresh ? 1u : 0u;  // the flag-density switch (kernels.h: ListScanArgs::dense_flag)
+    }
 }
 
 // resolve_kernel: one wave per slab turns the slab's flagged chunks into candidate REQUESTS. Request-driven: the flagged 16-byte
@@ -1806,6 +1823,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     const FilterArgs *pa = &B.f[blockIdx.y];
     if ((uint64_t)(pa->slab0 + blockIdx.x * 4) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
     const FilterArgs a = load_descriptor(pa);
+    if (a.dense_flag != nullptr && *a.dense_flag != 0u) return;  // (the pass is walked whole this batch: no pairs, no records to reset)
     const uint32_t wave = wave_index(), rel = blockIdx.x * 4 + wave, slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];

@@ -430,7 +430,11 @@ def test_saturated_stream_vs_oracle():
     eng.tune(sample)
     orc = pyoracle.Oracle(w.rules, w.lists, w.geoip)
     want = orc.evaluate(sat, threads=os.cpu_count() or 16)
-    H.assert_verdicts_equal(eng.evaluate_batch(sat), want, sat, "saturated, tuned")
+    H.assert_verdicts_equal(eng.evaluate_batch(sat), want, sat, "saturated, tuned")  # (round 6: the flagged passes are walked WHOLE — the flag-density switch)
+    chunkwise = RuleEngine(w.rules, w.lists, w.geoip, flags=_abi.OPT_NO_DENSE_SWITCH)  # ... and confirmed chunk by chunk, as in round 5
+    chunkwise.tune(sample)
+    H.assert_verdicts_equal(chunkwise.evaluate_batch(sat), want, sat, "saturated, tuned, no dense switch")
+    chunkwise.close()
     plain = RuleEngine(w.rules, w.lists, w.geoip, flags=_abi.OPT_NO_CONFIRM)
     H.assert_verdicts_equal(plain.evaluate_batch(sat), want, sat, "saturated, no confirm tier")
     plain.close()
@@ -452,7 +456,15 @@ def test_saturated_stream_vs_oracle():
         offs.append(np.concatenate(o))
     mixed = RequestBatch(data, offs, np.concatenate([b.ip for b in both]), np.concatenate([b.ip_is_v6 for b in both]), np.concatenate([b.port for b in both]),
                          np.concatenate([b.flags for b in both]))
-    H.assert_verdicts_equal(eng.evaluate_batch(mixed), orc.evaluate(mixed, threads=os.cpu_count() or 16), mixed, "saturated and benign slabs mixed")
+    want_mixed = orc.evaluate(mixed, threads=os.cpu_count() or 16)
+    H.assert_verdicts_equal(eng.evaluate_batch(mixed), want_mixed, mixed, "saturated and benign slabs mixed")
+    # the switch is per pass and per batch: benign batches before and after a saturated one take the confirm tier again (same engine, same scratch)
+    H.assert_verdicts_equal(eng.evaluate_batch(benign), orc.evaluate(benign, threads=os.cpu_count() or 16), benign, "benign after saturated")
+    H.assert_verdicts_equal(eng.evaluate_batch(sat), want, sat, "saturated after benign")
+    # a batch in which only ONE field is saturated (the other passes keep their confirm tier in the same launch)
+    half = RequestBatch([sat.data[0], sat.data[1], benign.data[2], sat.data[3], benign.data[4]], [sat.offsets[0], sat.offsets[1], benign.offsets[2], sat.offsets[3], benign.offsets[4]],
+                        sat.ip, sat.ip_is_v6, sat.port, sat.flags)
+    H.assert_verdicts_equal(eng.evaluate_batch(half), orc.evaluate(half, threads=os.cpu_count() or 16), half, "url saturated, path and user-agent benign")
     eng.close()
 
 

@@ -413,3 +413,61 @@ def test_regex_rule_sets_of_the_synthetic_configs_match_cpython_re():
     spec.loader.exec_module(mod)
     n_pats, checked, bad = mod.crosscheck(3, 150, verbose=False)
     assert n_pats >= 150 and checked > 50_000 and bad == 0
+
+
+def test_regex_unicode_matches_node_u_mode():
+    """VERDICT r5 #5c: ECMAScript RegExp in `u` mode (node: V8 + ICU) as a THIRD implementation of the scalar-value regex semantics, on the
+    constructs whose meaning coincides with the regex crate's: `.` (s flag) and negated classes take one scalar value, \\p{..} general
+    categories and scripts, explicit ranges beyond ASCII, quantifiers over multi-byte scalars, and (?i) = simple case folding on literals and
+    positive ranges (U+017F ~ s, U+212A ~ k). 6 000 generated (pattern, haystack) pairs; tools/regex_node_crosscheck.js evaluates them."""
+    import json
+    import shutil
+    import subprocess
+
+    if not shutil.which("node"):
+        pytest.skip("node is not installed")
+    rng = random.Random(20260930)
+    alpha = ["a", "b", "k", "s", "S", "K", "z", "0", "7", "_", "-", " ", "/", "é", "É", "ſ", "K", "€", "\U0001F600", "α", "Ω", "ж", "Ж", "٣",
+             " ", "你", "́", "᜴", "\U00010570"]
+    classes_plain = ["[a-k]", "[α-ω]", "[а-я]", "[aé€]", "[0-9٠-٩]"]
+    classes_unicode = ["\\p{L}", "\\p{Lu}", "\\p{Ll}", "\\P{L}", "\\p{Nd}", "\\p{Greek}", "\\p{Cyrillic}", "\\p{Mn}", "\\p{Mc}", "\\p{Vithkuqi}", "[^a-c]", "[^\\p{L}]", "[\\p{L}\\p{Nd}_]", "[^é]", "."]
+
+    def atom(ci):
+        r = rng.random()
+        if r < 0.5:
+            ch = rng.choice(alpha)
+            return "\\" + ch if ch in "-/ " and rng.random() < 0.2 and ch != " " else ch
+        if r < 0.7 or ci:
+            return rng.choice(classes_plain)
+        return rng.choice(classes_unicode)
+
+    def piece(ci, depth=0):
+        a = atom(ci) if depth > 1 or rng.random() < 0.8 else "(?:" + expr(ci, depth + 1) + ")"
+        return a + rng.choice(["", "", "", "*", "+", "?", "{2}", "{1,3}"])
+
+    def expr(ci, depth=0):
+        alts = ["".join(piece(ci, depth) for _ in range(rng.randint(1, 4))) for _ in range(rng.choice([1, 1, 1, 2]))]
+        return "|".join(alts)
+
+    cases = []
+    for _ in range(6000):
+        ci = rng.random() < 0.3
+        pat = expr(ci)
+        if rng.random() < 0.3:
+            pat = "^" + pat
+        if rng.random() < 0.3:
+            pat = pat + "$"
+        hay = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 8)))
+        cases.append((pat, ci, hay))
+    js_in = [[p.replace("\\p{Greek}", "\\p{Script=Greek}").replace("\\p{Cyrillic}", "\\p{Script=Cyrillic}").replace("\\p{Vithkuqi}", "\\p{Script=Vithkuqi}").replace("\\-", "-").replace("\\/", "/"),
+              "su" + ("i" if ci else ""), h] for p, ci, h in cases]
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "regex_node_crosscheck.js")
+    res = json.loads(subprocess.run(["node", tool], input=json.dumps(js_in).encode(), stdout=subprocess.PIPE, check=True).stdout)
+    n_true = n_multi = 0
+    for (pat, ci, hay), js in zip(cases, res):
+        assert not isinstance(js, str), (pat, js)
+        got = pyoracle.regex_is_match("(?s" + ("i" if ci else "") + ")" + pat, hay.encode())
+        assert got == js, (pat, ci, hay, got, js)
+        n_true += js
+        n_multi += js and not hay.isascii()
+    assert n_true > 900 and n_multi > 500, (n_true, n_multi)
