@@ -781,7 +781,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     if ((rc = S.attr.reserve(((size_t)n_groups * pair_stride + 64) * 16 + (size_t)n_groups * 4))) return rc;
     if ((rc = S.pool.reserve((size_t)pool_cap * sizeof(PoolEntry)))) return rc;
     const size_t n_slots = (size_t)std::max(kGapLists, e->n_gated);
-    const size_t ctrl_words = 2 + n_slots + 2 * (size_t)e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count and one dense-walk flag per filtered pass
+    const size_t ctrl_words = 2 + n_slots + e->n_filtered;  // [0] pool allocator, [1] status word, one length per list slot, one pair count per filtered pass
     // visited bitmaps of the list-driven passes (one bit per request, whole 64-request groups): zeroed per batch — 1/32 of what
     // zeroing the hit records themselves would write. They share ONE zeroed block with the control words and the confirm tier's walk bitmaps.
     const uint32_t bit_words = 2 * n_groups;
@@ -1185,6 +1185,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     std::vector<uint32_t> &totals = col_bytes;
     // the flag-density switch (kernels.h: ListScanArgs::dense_flag): per pass with a confirm tier, the device word that says "walked whole this batch"
     std::vector<const uint32_t *> dense_flag_of(e->groups.size(), nullptr);
+    std::vector<uint32_t> dense_thresh_of(e->groups.size(), 0);
     std::vector<uint32_t> filter_index(e->groups.size(), 0);  // a filtered pass's index among the filtered passes (its candidate / valid bitmap)
     const bool dense_switch = !(P.flags & PWAF_OPT_NO_DENSE_SWITCH);
     std::vector<FilterArgs> fall;        // every filtered pass, in pass order
@@ -1273,9 +1274,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                     // more than half of the arena's 16-byte chunks flagged: confirming them one by one costs more than walking every request
                     // (measured, round 5: the saturated stream took 22 ms in the confirm tier against 9 ms for the plain DFA over the same bytes;
                     // the hostile stream of the 1k-rule set flags a quarter of its chunks and stays on the confirm tier: 1.3 ms against 3.9)
-                    f.dense_flag = (uint32_t *)S.ctrl.p + 2 + n_slots + e->n_filtered + fi;
+                    f.dense_flag = f.pair_count;  // (the count filter_kernel leaves there, against dense_thresh)
                     f.dense_thresh = (uint32_t)std::min<uint64_t>(0xFFFFFFFEu, (uint64_t)slabs * (kStreamSlab / 16) / 2);
                     dense_flag_of[gi] = f.dense_flag;
+                    dense_thresh_of[gi] = f.dense_thresh;
                 }
             }
             f.first_block = 0;
@@ -1321,6 +1323,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             c.rec = f.rec;
             c.valid_bits = f.bitmap;
             c.dense_flag = f.dense_flag;
+            c.dense_thresh = f.dense_thresh;
             c.walk_bits = (uint32_t *)S.walk_bits.p + (size_t)wi++ * bit_words;
             if (d.confirm_walk) {
                 c.walk_list = f.list;
@@ -1356,6 +1359,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
                 a.merge_rec = 0;
                 a.visited = (uint32_t *)S.cand_bits.p + (size_t)filter_index[gi] * bit_words;
                 a.dense_flag = dense_flag_of[gi];
+                a.dense_thresh = dense_thresh_of[gi];
                 a.dense_mode = 1;
                 la[phase].push_back(a);
             }
@@ -1367,9 +1371,11 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             ListScanArgs a = list_args(gi, lshapes[phase]);
             if (phase == 0 && d.confirm && dense_flag_of[gi] != nullptr) {  // the R-tier walk over the confirm tier's walk list: idle when the pass is walked whole
                 a.dense_flag = dense_flag_of[gi];
+                a.dense_thresh = dense_thresh_of[gi];
                 a.dense_mode = 2;
             } else if (d.share_owner >= 0 && dense_flag_of[(size_t)d.share_owner] != nullptr) {  // a gap pass riding the owner's list through need masks
                 a.dense_flag = dense_flag_of[(size_t)d.share_owner];
+                a.dense_thresh = dense_thresh_of[(size_t)d.share_owner];
                 a.dense_mode = 3;
             }
             la[phase].push_back(a);

@@ -125,12 +125,13 @@ struct ListScanArgs {
     uint32_t n_cus;
     // The flag-density switch (round 6; FilterArgs::dense_flag): a filtered pass whose prefilter flagged more than half of the arena's chunks —
     // an attacker can make it flag all of them — is not confirmed chunk by chunk (5.6 x slower than no filter at all, measured) but walked
-    // whole, every request through the pass's FULL DFA. The decision is per pass and per batch, on the device (pair_scan_kernel), so both
+    // whole, every request through the pass's FULL DFA. The decision is per pass and per batch, on the device (the flagged-chunk count filter_kernel leaves), so both
     // forms are in the launch and the plan kernel gives the untaken one no work:
-    //   dense_mode 1  the dense alternative itself: every request (req_list null), the full table — runs only when *dense_flag != 0
-    //   dense_mode 2  the pass's R-tier walk over the confirm tier's walk list — nothing to do when *dense_flag != 0
-    //   dense_mode 3  a gap pass that shares the pass's list through need masks: every request when *dense_flag != 0 (the dense walk writes the masks by request)
-    const uint32_t *dense_flag;
+    //   dense_mode 1  the dense alternative itself: every request (req_list null), the full table — runs only when *dense_flag > dense_thresh
+    //   dense_mode 2  the pass's R-tier walk over the confirm tier's walk list — nothing to do when it does
+    //   dense_mode 3  a gap pass that shares the pass's list through need masks: every request when it does (the dense walk writes the masks by request)
+    const uint32_t *dense_flag;  // the pass's flagged-chunk count on the device (filter_kernel adds each slab's); the pass is dense when it exceeds dense_thresh
+    uint32_t dense_thresh;
     uint32_t dense_mode;
 };
 // the list a pass walks in this batch: (req_list, entries) after the flag-density switch
@@ -176,7 +177,8 @@ struct ConfirmArgs {
     uint32_t *enq_bits;
     uint32_t enq_words;
     uint32_t shared_bits;       // gap passes that share this pass's walk list (ListScanArgs::need_out): a literal hit that calls for one sends the request through the walk
-    const uint32_t *dense_flag; // != 0 on the device: the pass is walked whole this batch (ListScanArgs::dense_flag): no pair of it is confirmed
+    const uint32_t *dense_flag; // the pass's flagged-chunk count; above dense_thresh the pass is walked whole this batch (ListScanArgs::dense_flag): no pair of it is confirmed
+    uint32_t dense_thresh;
 };
 static constexpr uint32_t kConfirmThreads = 1024;
 static constexpr uint32_t kConfirmPoolBytes = 40 * 1024;  // LDS for a pass's entries + bytes + classes, next to the two 16 KiB tables: two 1024-thread workgroups per CU
@@ -230,10 +232,10 @@ struct FilterArgs {
     uint2 *pairs;
     uint32_t *pair_count;
     uint32_t pair_cap;
-    uint32_t *pair_base;      // [slabs]: where each slab's pairs begin in the list (pair_scan_kernel: exclusive prefix sums of sub_count)
-    // the flag-density switch (ListScanArgs::dense_flag): pair_scan_kernel sets *dense_flag when the pass's flagged chunks exceed dense_thresh;
-    // resolve_kernel then leaves the pass alone (null: the pass has no dense alternative)
-    uint32_t *dense_flag;
+    uint32_t *pair_base;      // [slabs]: where each slab's pairs begin in the list (filter_kernel: one atomic on pair_count per slab)
+    // the flag-density switch (ListScanArgs::dense_flag): when the pass's flagged chunks (*dense_flag = its pair count) exceed dense_thresh,
+    // resolve_kernel leaves the pass alone (null: the pass has no dense alternative)
+    const uint32_t *dense_flag;
     uint32_t dense_thresh;
     uint32_t first_block;     // first workgroup of this pass in the fused filter launch
     uint32_t debug;           // -DPWAF_PROFILING timing experiments only (wrong results): 1 = no table lookups, 2 = no loads after a slab's first iteration

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a) { scan_b
 __device__ __forceinline__ ListOf list_of(const ListScanArgs &a) {
     ListOf l{a.req_list, a.req_list != nullptr ? min(*a.n_list, a.n) : a.n};
     if (a.dense_mode != 0u) {
-        const bool dense = *a.dense_flag != 0u;
+        const bool dense = *a.dense_flag > a.dense_thresh;
         if (a.dense_mode == 1u && !dense) l.n_l = 0u;
         if (a.dense_mode == 2u && dense) l.n_l = 0u;
         if (a.dense_mode == 3u && dense) l = ListOf{nullptr, a.n};
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void confirm_plan_kernel(ConfirmTableDev b, ui
     uint32_t items = 0;
     if (t < b.count) {
         const ConfirmArgs *pa = &b.c[t];
-        const bool dense = pa->dense_flag != nullptr && *pa->dense_flag != 0u;  // (walked whole this batch: nothing to confirm)
+        const bool dense = pa->dense_flag != nullptr && *pa->dense_flag > pa->dense_thresh;  // (walked whole this batch: nothing to confirm)
         items = dense ? 0u : (min(*pa->pair_count, pa->pair_cap) + kConfirmThreads - 1) / kConfirmThreads;
     }
     part[t] = items;
@@ -1520,7 +1520,14 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
     }
     // (the arena's last slab: the words of the iterations it does not have read as "no chunk flagged")
     for (uint32_t wd = (slab_end - base0 + kStreamIter - 1) / kStreamIter * 4 + lane; wd < kStreamSlab / kRow; wd += 64) my_bits[wd] = 0;
-    if (lane == 0) a.sub_count[rel] = n_hit;
+    if (lane == 0) {
+        a.sub_count[rel] = n_hit;
+        // where the slab's pairs begin in the pass's pair list: one returned atomic per slab, here at the slab's end (round 6; until then a scan
+        // kernel of its own between this launch and resolve_kernel: 7 us + a launch gap on the critical path. The same atomic taken by
+        // resolve_kernel's waves as they START held every one of them up for its turn — here the slabs end spread over the launch). The order
+        // of a pass's pairs no longer follows the arena; nothing reads it as ordered.
+        if (a.pairs != nullptr) a.pair_base[rel] = n_hit ? atomicAdd(a.pair_count, n_hit) : 0u;
+    }
 }
 
 // ONE launch for every filtered pass, both strides: stride-1 passes are bound by the LDS lookups, stride-2 passes by HBM, so their
@@ -1562,7 +1569,6 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterMix M) 
 }
 
 __global__ void resolve_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
-__global__ void pair_scan_kernel(FilterTable B);
 
 // bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
 // (kCompactWords bitmap words each), then every workgroup sums the counts before it (a few hundred values) and writes its part.
@@ -1612,12 +1618,6 @@ int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev
     if (count == 0 || max_slabs == 0) return 0;
     FilterTable t{dev, count};
     void *args[] = {&t};
-    bool any_pairs = false;
-    for (uint32_t k = 0; k < count; k++) any_pairs = any_pairs || host[k].pairs != nullptr;
-    if (any_pairs) {
-        hipError_t e0 = hipLaunchKernel(reinterpret_cast<const void *>(pair_scan_kernel), dim3(count), dim3(1024), args, 0, (hipStream_t)stream);
-        if (e0 != hipSuccess) return (int)e0;
-    }
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
@@ -1781,35 +1781,6 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
     return x;
 }
 
-// pair_scan_kernel: one workgroup per pass with a confirm tier — exclusive prefix sums of the slabs' flag counts = where each slab's
-// pairs begin in the pass's pair list, and the list's length.
-__global__ __launch_bounds__(1024) void pair_scan_kernel(FilterTable B) {
-    __shared__ uint32_t part[1024];
-    const FilterArgs a = load_descriptor(&B.f[blockIdx.x]);
-    if (a.pairs == nullptr) return;
-    const uint32_t slabs = (uint32_t)(((uint64_t)a.total + kStreamSlab - 1) / kStreamSlab) - a.slab0, t = threadIdx.x;
-    const uint32_t per = (slabs + 1023u) / 1024u, k0 = t * per, k1 = min(slabs, k0 + per);
-    uint32_t sum = 0;
-    for (uint32_t k = k0; k < k1; k++) sum += a.sub_count[k];
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t at = part[t] - sum;
-    for (uint32_t k = k0; k < k1; k++) {
-        a.pair_base[k] = at;
-        at += a.sub_count[k];
-    }
-    if (t == 1023) {
-        *a.pair_count = part[1023];
-        if (a.dense_flag != nullptr) *a.dense_flag = part[1023] > a.dense_thresh ? 1u : 0u;  // the flag-density switch (kernels.h: ListScanArgs::dense_flag)
-    }
-}
-
 // resolve_kernel: one wave per slab turns the slab's flagged chunks into candidate REQUESTS. Request-driven: the flagged 16-byte
 // chunks of the slab become a bitmap in LDS (8192 bits) with per-word prefix counts, then the wave walks the requests that overlap
 // the slab — 64 per step, offsets read coalesced — and a request is a candidate when a flagged chunk lies within its bytes extended
@@ -1823,7 +1794,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     const FilterArgs *pa = &B.f[blockIdx.y];
     if ((uint64_t)(pa->slab0 + blockIdx.x * 4) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
     const FilterArgs a = load_descriptor(pa);
-    if (a.dense_flag != nullptr && *a.dense_flag != 0u) return;  // (the pass is walked whole this batch: no pairs, no records to reset)
+    if (a.dense_flag != nullptr && *a.dense_flag > a.dense_thresh) return;  // (the pass is walked whole this batch: no pairs, no records to reset)
     const uint32_t wave = wave_index(), rel = blockIdx.x * 4 + wave, slab = a.slab0 + rel, lane = threadIdx.x & 63;
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];
@@ -1878,9 +1849,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
     // A pass with a confirm tier lists its flagged chunks instead of marking candidates: every flagged chunk of the slab becomes ONE pair
     // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — it begins
-    // at the sum of the earlier slabs' flag counts, which filter_kernel left in sub_count (pair_scan_kernel: an atomic per slab on the
-    // list's length, ~20k returned same-address atomics per batch, held every wave up for its turn) — and a chunk's place in it is its
-    // rank among the slab's flagged chunks (the prefix counts above): no second walk.
+    // where filter_kernel's atomic on the list's length put it as the slab ended (pair_base; the same atomic taken HERE, ~20k returned
+    // same-address atomics as these waves start, held every wave up for its turn) — and a chunk's place in it is its rank among the
+    // slab's flagged chunks (the prefix counts above): no second walk.
     const uint32_t pair_base = a.pairs != nullptr ? a.pair_base[rel] : 0u;
     const uint32_t begin = __builtin_amdgcn_readfirstlane(a.off[0]);  // != 0: a slab view of a larger arena
     // A slab view keeps absolute arena positions and the filter streams whole slabs: what lies before off[0] in the view's first slab —
