@@ -141,10 +141,17 @@ class Runner:
                 self.eng.evaluate_device(db, out=self.outs[k], counts=self.cnts[k], stream=streams[k].cuda_stream)
                 shard.allreduce_counts(self.cnts[k])  # the path's only exchange: 4 counters over RCCL/xGMI
 
+        # The WARMUP steps carry HIP events around EVERY kernel (the per-kernel table, `kernels_ms_per_step`); the TIMED steps only around the launch
+        # that streams the request bytes — the dominant kernel the roofline is quoted on, measured live in the timed region as the contract asks.
+        # (An event between two kernels keeps the second from starting while the first drains: ~20 us per step with a dozen launches, which
+        # rounds 1-5 charged to the headline.) PWAF_BENCH_ALL_EVENTS=1 restores events around every kernel in the timed steps.
+        want_events = events and not os.environ.get("PWAF_BENCH_NO_EVENTS")
+        self.eng.set_profiling(1 if want_events else 0)
         for i in range(warmup):
             step(i)
         self.barrier()
-        self.eng.set_profiling(events and not os.environ.get("PWAF_BENCH_NO_EVENTS"))  # HIP events around every kernel launch, on the launch stream
+        self.warm_kt, self.warm_steps = (self.eng.kernel_times(), warmup) if want_events and warmup else ([], 0)
+        self.eng.set_profiling((1 if os.environ.get("PWAF_BENCH_ALL_EVENTS") else 2) if want_events else 0)
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -184,11 +191,18 @@ class Runner:
         dom = max(kinds, key=lambda kk: kinds[kk][0])
         ms, _, nbytes = kinds[dom]
         ach = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+        # per-kernel durations: from the warmup steps of the same run (events around every kernel there), the streaming launch from the timed steps
         per = {}
+        if getattr(self, "warm_kt", None) and len(kt) < len(self.warm_kt) * steps // max(1, self.warm_steps):
+            for name, kms, _ in self.warm_kt:
+                per[name] = per.get(name, 0.0) + kms / self.warm_steps
+            for name in {n for n, _, _ in kt}:
+                per[name] = 0.0
         for name, kms, _ in kt:
             per[name] = per.get(name, 0.0) + kms / steps
         return {"requests_per_s": self.n * self.world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel": dom, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
-                "kernels_ms_per_step": {k: round(v, 4) for k, v in per.items()}}
+                "kernels_ms_per_step": {k: round(v, 4) for k, v in per.items()},
+                "kernels_ms_source": "streaming launch: HIP events in the timed steps; the other kernels: HIP events in the warmup steps of the same run"}
 
     def batch_latency(self, db, calls=40):
         """Per-batch latency: one synchronised device-resident call per batch."""
@@ -475,7 +489,14 @@ def main():
     }
 
     if rank == 0:
-        kinds, other_ms = R.stream_kernels(ktimes)
+        kinds, _ = R.stream_kernels(ktimes)
+        # the kernels that do not stream request bytes: per-step durations from the warmup steps' events (mode_summary), here as totals over the timed steps
+        streaming_names = {name for name, _, _ in ktimes}
+        other_ms = {}
+        for name, ms_step in head["kernels_ms_per_step"].items():
+            if name not in streaming_names and not name.startswith(("filter_", "scan_")):
+                k2 = name.split("_x")[0]
+                other_ms[k2] = other_ms.get(k2, 0.0) + ms_step * args.steps
         verdict_ms = other_ms.pop("verdict", 0.0)
         attr_ms = other_ms.pop("attr", 0.0) + other_ms.pop("ipres", 0.0)  # side stream: address lookups, then rows / transposes / comparisons
         dom = head["kernel"]

@@ -376,8 +376,9 @@ typedef struct pwaf_kernel_time {
     float ms;            /* HIP-event duration of the last profiled evaluate call */
     uint64_t alg_bytes;  /* algorithmic bytes this launch is credited with */
 } pwaf_kernel_time;
-/* When on, every evaluate call brackets each kernel with hipEvents on the launch stream. Calling it (on or off)
- * starts a new measurement window. */
+/* on = 1: every evaluate call brackets each kernel with hipEvents on the launch stream; on = 2: only the launches that STREAM the request
+ * bytes (filter_kernel, scan_kernel: what the HBM roofline is quoted on) — an event between two kernels keeps the second from starting
+ * while the first drains, ~20 us per batch of a dozen launches. Calling it (any value) starts a new measurement window. */
 int pwaf_engine_set_profiling(pwaf_engine *, int on);
 /* Blocks until the last profiled launch finished; fills up to cap entries, one per kernel launch since the window
  * started (in launch order); returns the count. */

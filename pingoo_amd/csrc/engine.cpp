@@ -268,7 +268,7 @@ struct pwaf_engine {
     std::vector<uint32_t> hlen_fields;  // header columns whose length some rule compares (comparison variable 7 + k)
     uint32_t n_fields = PWAF_N_FIELDS;  // 5 + header columns
     // profiling
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every kernel, 2 only the launches that stream request bytes (pwaf_engine_set_profiling)
     std::vector<hipEvent_t> ev;
     std::vector<pwaf_kernel_time> times;
     std::vector<std::pair<size_t, size_t>> time_ev;  // (begin, end) event index of each entry of `times`
@@ -854,6 +854,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         return PWAF_OK;
     };
     long open_begin = -1;
+    bool stream_mark = false;  // the marks of a launch that streams request bytes (level 2 records no others)
     auto mark = [&](const char *name, uint64_t alg_bytes, hipStream_t on = nullptr) -> int {
 #ifdef PWAF_PROFILING
         static const bool sync_each = getenv("PWAF_SYNC_EACH") != nullptr;  // debugging aid: which launch faults
@@ -862,7 +863,7 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             fprintf(stderr, "[pwaf] %s done: %s\n", name, hipGetErrorString(se));
         }
 #endif
-        if (!e->profiling) return PWAF_OK;
+        if (!e->profiling || (e->profiling == 2 && !stream_mark)) return PWAF_OK;
         int rc2;
         if (!name) {  // begin
             if (!on && last_main >= 0) { open_begin = last_main; return PWAF_OK; }
@@ -1175,10 +1176,12 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         char nm[48];
         if (d.field < PWAF_N_FIELDS) snprintf(nm, sizeof nm, "scan_%s_g%zu", fn[d.field], gi);
         else snprintf(nm, sizeof nm, "scan_hdr%u_g%zu", d.field - PWAF_N_FIELDS, gi);
+        stream_mark = true;
         if ((rc = mark(nullptr, 0))) return rc;
         int he = launch_scan(a, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("scan kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         if ((rc = mark(nm, (uint64_t)col_bytes[d.field] + 4ull * (n + 1)))) return rc;  // algorithmic bytes: the field's bytes + its offsets (0 bytes when the arena size is unknown)
+        stream_mark = false;
     }
     // ---- 2. the descriptors of every launch of the batch (prefilter, resolve, confirm tier, list scans, residual kernel): built here,
     //         uploaded ONCE ----
@@ -1436,11 +1439,13 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     //          bitmaps / pair lists ----
     if (e->n_filtered) {
         int he;
+        stream_mark = true;
         if ((rc = mark(nullptr, 0))) return rc;
         he = launch_filter(by_stride[0].data(), (uint32_t)by_stride[0].size(), d_s1, by_stride[1].data(), (uint32_t)by_stride[1].size(), d_s2, stream);
         if (he) return fail(PWAF_E_DEVICE, std::string("filter kernel launch failed: ") + hipGetErrorString((hipError_t)he));
         // algorithmic bytes: every streamed arena once + its offsets. The mark's name tells the bench which strides the launch mixed.
         if ((rc = mark(by_stride[1].empty() ? "filter_s1" : by_stride[0].empty() ? "filter_s2" : "filter_mix", alg_bytes[1] + alg_bytes[2]))) return rc;
+        stream_mark = false;
 #ifdef PWAF_PROFILING
         static const bool attr_after_compact = getenv("PWAF_ATTR_AFTER_COMPACT") != nullptr;  // timing experiment
         if (!attr_after_compact)
@@ -2846,7 +2851,7 @@ int pwaf_engine_set_profiling(pwaf_engine *e, int on) {
     if (!e) return fail(PWAF_E_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(e->mu);
     std::lock_guard<std::mutex> plk(e->prof_mu);
-    e->profiling = on != 0;
+    e->profiling = on < 0 ? 0 : on > 2 ? 1 : on;
     e->times.clear();  // (re)starting a measurement window: kernel_times() reports every launch since this call
     e->time_ev.clear();
     e->n_timed = 0;

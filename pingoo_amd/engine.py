@@ -465,7 +465,8 @@ class RuleEngine:
         if rc != 0:
             _raise(rc, lib().pwaf_last_error().decode(errors="replace"))
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """False / 0: off; True / 1: HIP events around every kernel; 2: only around the launches that stream the request bytes."""
         lib().pwaf_engine_set_profiling(self._h, int(on))
 
     def kernel_times(self) -> List[Tuple[str, float, int]]:
