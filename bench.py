@@ -134,12 +134,16 @@ class Runner:
         inflight = inflight or self.inflight
         streams = [torch.cuda.current_stream(self.dev)] if inflight == 1 else self.own_streams
 
-        def step(i):
+        # every step accumulates into a counter row of its own, zeroed before the run (a caller that hands each batch fresh counters): a
+        # `zero_()` per step was one more 6 us launch in front of every batch of the timed region
+        ring = torch.zeros((warmup + steps, 4), dtype=torch.int64, device=self.dev)
+        self.barrier()
+
+        def step(i, row):
             k = i % inflight
             with torch.cuda.stream(streams[k]):
-                self.cnts[k].zero_()
-                self.eng.evaluate_device(db, out=self.outs[k], counts=self.cnts[k], stream=streams[k].cuda_stream)
-                shard.allreduce_counts(self.cnts[k])  # the path's only exchange: 4 counters over RCCL/xGMI
+                self.eng.evaluate_device(db, out=self.outs[k], counts=ring[row], stream=streams[k].cuda_stream)
+                shard.allreduce_counts(ring[row])  # the path's only exchange: 4 counters over RCCL/xGMI
 
         # The WARMUP steps carry HIP events around EVERY kernel (the per-kernel table, `kernels_ms_per_step`); the TIMED steps only around the launch
         # that streams the request bytes — the dominant kernel the roofline is quoted on, measured live in the timed region as the contract asks.
@@ -148,14 +152,14 @@ class Runner:
         want_events = events and not os.environ.get("PWAF_BENCH_NO_EVENTS")
         self.eng.set_profiling(1 if want_events else 0)
         for i in range(warmup):
-            step(i)
+            step(i, i)
         self.barrier()
         self.warm_kt, self.warm_steps = (self.eng.kernel_times(), warmup) if want_events and warmup else ([], 0)
         self.eng.set_profiling((1 if os.environ.get("PWAF_BENCH_ALL_EVENTS") else 2) if want_events else 0)
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i)
+            step(i, warmup + i)
         self.issue_ms = 1e3 * (time.perf_counter() - t0) / steps  # host time to enqueue one step (the device runs behind it)
         self.barrier()
         elapsed = time.perf_counter() - t0
@@ -165,7 +169,7 @@ class Runner:
             elapsed = float(t.item())
         kt = self.eng.kernel_times()
         self.eng.set_profiling(False)
-        return elapsed, kt, self.cnts[0].cpu().tolist()
+        return elapsed, kt, ring[warmup + steps - 1].cpu().tolist()
 
     @staticmethod
     def stream_kernels(kt):

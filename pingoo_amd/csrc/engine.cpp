@@ -787,13 +787,21 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
     const uint32_t bit_words = 2 * n_groups;
     uint32_t n_conf = 0;
     for (const DevGroup &d : e->groups) n_conf += (d.filtered && d.confirm) ? 1u : 0u;
+    bool zero_deferred = false;
+    size_t zero_bytes = 0;
+    int arg_slot_used = -1;
     {
         size_t zb = 0;
         auto part = [&](size_t bytes) { const size_t at = zb; zb = (zb + bytes + 255) & ~(size_t)255; return at; };
         const size_t z_ctrl = part(4 * ctrl_words), z_cand = part((size_t)e->n_filtered * bit_words * 4), z_visit = part((size_t)e->n_visit * bit_words * 4),
                      z_walk = part((size_t)n_conf * bit_words * 4);
         if ((rc = S.zero_block.reserve(zb))) return rc;
-        HIP_TRY(hipMemsetAsync(S.zero_block.p, 0, zb, stream));
+        // (cleared by the descriptor upload's launch when nothing needs it before that: no pass that streams every request — those run first and
+        // count into the control words)
+        zero_deferred = e->n_filtered != 0;
+        for (const DevGroup &d : e->groups) zero_deferred = zero_deferred && (d.gate >= 0 || d.identity || d.short_lit);
+        zero_bytes = zb;
+        if (!zero_deferred) HIP_TRY(hipMemsetAsync(S.zero_block.p, 0, zb, stream));
         char *const zbase = (char *)S.zero_block.p;
         S.ctrl.p = zbase + z_ctrl;
         S.cand_bits.p = zbase + z_cand;
@@ -1429,10 +1437,14 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
             put(a_l0, la[0].data(), la[0].size() * sizeof(ListScanArgs));
             put(a_l1, la[1].data(), la[1].size() * sizeof(ListScanArgs));
             put(a_ptrs, ptrs.p, (size_t)ptrs.count * sizeof(void *));
-            int he = upload_args_block(hb, S.args.p, up_bytes, stream);
+            int he = upload_args_block(hb, S.args.p, up_bytes, zero_deferred ? S.zero_block.p : nullptr, zero_deferred ? zero_bytes : 0, stream);
             if (he) return fail(PWAF_E_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString((hipError_t)he));
-            HIP_TRY(hipEventRecord(S.arg_ev[slot], stream));
-            S.arg_pending[slot] = true;
+            zero_deferred = false;
+            arg_slot_used = (int)slot;  // (its event is recorded at the END of the batch: a record between two kernels keeps the second from starting while the first drains)
+        }
+        if (zero_deferred) {  // (nothing to upload: the block is cleared the old way)
+            HIP_TRY(hipMemsetAsync(S.zero_block.p, 0, zero_bytes, stream));
+            zero_deferred = false;
         }
     }
     // ---- 2a. bigram prefilters of every filtered pass in one launch (the arenas as flat byte streams), hit segments -> candidate
@@ -1589,6 +1601,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         }
     }
 #endif
+    if (arg_slot_used >= 0) {
+        HIP_TRY(hipEventRecord(S.arg_ev[arg_slot_used], stream));  // (the copy launch that read the slot ran before everything recorded here)
+        S.arg_pending[arg_slot_used] = true;
+    }
     e->n_timed = ev_i;
     return PWAF_OK;
 }

@@ -244,7 +244,7 @@ struct FilterArgs {
 // 15 KB of descriptors, kernel arguments hold 8). The host builds the descriptors of EVERY launch of a batch before the first one, writes
 // them into a page-locked slot and one copy launch on the batch's stream moves the block (engine.cpp: Scratch::args): stream-ordered,
 // one launch per batch whatever the number of passes.
-int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *stream);
+int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *zero /* nullable: a block to clear in the same launch */, size_t zero_bytes, void *stream);
 struct FilterTable {
     const FilterArgs *f;  // device
     uint32_t count;

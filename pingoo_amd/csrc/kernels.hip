@@ -1203,13 +1203,17 @@ int launch_scan(const ScanArgs &a, void *stream) {
 
 // The batch's launch descriptors, host to device in ONE launch: `src` is page-locked host memory (device-visible: the lanes read it
 // over the link, 16 bytes each), `dst` device memory; both 16-byte aligned, bytes rounded up to 16 by the caller's 256-byte parts.
-__global__ __launch_bounds__(256) void copy_args_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16) {
+// The same launch clears the batch's zeroed block (control words, candidate / visited / walk bitmaps) when the caller hands it over: a memset
+// of its own was one more launch (8 us) in front of every batch.
+__global__ __launch_bounds__(256) void copy_args_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16, uint4 *__restrict__ zero, uint32_t z16) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < z16; i += gridDim.x * 256u) zero[i] = make_uint4(0u, 0u, 0u, 0u);
 }
-int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *stream) {
-    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
-    if (n16 == 0) return 0;
-    hipLaunchKernelGGL(copy_args_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 64u)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)host_pinned, (uint4 *)dev, n16);
+int upload_args_block(const void *host_pinned, void *dev, size_t bytes, void *zero, size_t zero_bytes, void *stream) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16), z16 = (uint32_t)(zero_bytes / 16);  // (the zeroed block is a multiple of 256 bytes)
+    if (n16 == 0 && z16 == 0) return 0;
+    const uint32_t blocks = std::max(std::min<uint32_t>((n16 + 255) / 256, 64u), std::min<uint32_t>((z16 + 2047) / 2048, 1024u));
+    hipLaunchKernelGGL(copy_args_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)host_pinned, (uint4 *)dev, n16, (uint4 *)zero, z16);
     return (int)hipGetLastError();
 }
 
