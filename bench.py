@@ -518,7 +518,7 @@ def main():
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes over this very
         # command (tools/profile_round.sh), committed under profiles/ and only quoted for the workload they were measured on
         traffic, traffic_src = None, None
-        for tname in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json"):
+        for tname in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is not None or not (args.config == 3 and n == 10_000_000 and not args.adversarial and os.path.exists(tpath)):
                 continue

@@ -3,7 +3,7 @@
 # Produces under gpurun_out/<tag>/: the rocprofv3 --kernel-trace --stats summary of a short bench run (kernel_stats.txt), the HBM-traffic
 # counters of the same command (traffic.json: separate --pmc passes, kernel-trace only — never combined with other trace domains) and
 # the issue / LDS counters per product kernel (counters.txt). The bench line itself comes from a plain `python bench.py` run.
-TAG=${1:-r5}; shift
+TAG=${1:-r6}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-extra-modes --no-pcie --no-config5 $@"   # (the driver's step counts: a 4-launch trace caught one box before its clocks settled — 0.624 ms for a kernel the 25-launch trace and the bench's own events put at 0.572 / 0.577)
 export PWAF_COMMIT=$(cat $R/.commit_id 2>/dev/null || echo "?")
