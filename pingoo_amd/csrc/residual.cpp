@@ -6,6 +6,9 @@
 // objects need (http_request / client / lists / http_request.headers are compile-time objects: a member with a literal key becomes
 // the variable's own instruction), jumps for the short circuit of && || ?:. What cannot be lowered is reported (the rule then
 // keeps its PWAF_E_UNSUPPORTED status): see residual.h.
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -56,6 +59,7 @@ struct ResidualBuilder::Impl {
     std::function<int(const std::string &)> header_field;
     const std::vector<std::string> *closed_headers = nullptr;  // every header name of the rule set, in column order (null: not known)
     uint32_t depth = 0, max_depth = 0, heap = 0;
+    bool reorder = getenv("PWAF_RESIDUAL_SOURCE_ORDER") == nullptr;  // (measurement switch: operands of && / || in source order)
     uint32_t heap_items = 0;  // the largest heap bound over the accepted rules (Header::heap_items)
 
     uint32_t str_const(const std::string &s) {
@@ -244,49 +248,56 @@ struct ResidualBuilder::Impl {
     // values are never read (membership tests). A map's entries sit on the stack until R_MKMAP: a rule set that mentions more header
     // names than the stack holds is refused here (stack slots), as is one whose names are not known yet (closed_headers == null).
     void gen_ctx_map(int ctx, bool keys_only, Info &r) {
+        const Val v = ctx_map_const(ctx, keys_only, r);
+        emit(R_CONST, 0, add_const(v));
+        push();
+    }
+    // (round 6) The map is a CONSTANT of the program: its keys are string constants, its value slots name the request value they stand for
+    // (T_REF: read through deref when an index / member / comparison reaches the slot) — one stack slot and no heap item whatever its
+    // size. Until then the entries were pushed and popped by R_MKMAP: a rule set that mentions more than ~10 header names had every rule
+    // that needs the headers map as a value refused ("stack slots").
+    Val ctx_map_const(int ctx, bool keys_only, Info &r) {
         static const char *const kFields[5] = {"host", "url", "path", "method", "user_agent"};
-        uint32_t n = 0;
-        auto key = [&](const std::string &k) { push_str(k); n++; };
+        std::vector<Val> kv;
+        auto key = [&](const std::string &k) { kv.push_back(mk(T_STR, (uint32_t)k.size(), ((uint64_t)S_CONST << 48) | str_const(k))); };
+        auto val = [&](const Val &v) { kv.push_back(keys_only ? mk_bool(true) : v); };
         Info inner;  // (a value that is itself a map: http_request's "headers" entry)
         if (ctx == 1) {
-            for (int f = 0; f < 5; f++) {
-                key(kFields[f]);
-                if (keys_only) push_bool(true);
-                else { emit(R_FIELD, 0, (uint32_t)f); push(); }
-            }
+            Val hm = mk(T_NULL);
+            if (!keys_only) hm = ctx_map_const(4, false, inner);  // (its entries first: a map's entries are contiguous constants)
+            for (int f = 0; f < 5; f++) { key(kFields[f]); val(mk(T_REF, R_FIELD, (uint64_t)f)); }
             key("headers");
-            if (keys_only) push_bool(true);
-            else gen_ctx_map(4, false, inner);
+            val(hm);
         } else if (ctx == 2) {
-            key("ip"); if (keys_only) push_bool(true); else { emit(R_IP); push(); }
-            key("remote_port"); if (keys_only) push_bool(true); else { emit(R_PORT); push(); }
-            key("asn"); if (keys_only) push_bool(true); else { needs_geo = true; emit(R_ASN); push(); }
-            key("country"); if (keys_only) push_bool(true); else { needs_geo = true; emit(R_COUNTRY); push(); }
+            if (!keys_only) needs_geo = true;
+            key("ip"); val(mk(T_REF, R_IP));
+            key("remote_port"); val(mk(T_REF, R_PORT));
+            key("asn"); val(mk(T_REF, R_ASN));
+            key("country"); val(mk(T_REF, R_COUNTRY));
         } else if (ctx == 3) {
             std::set<std::string> seen;  // (names are distinct in the set the host hands over; like select_ctx, the first of a name counts)
             for (size_t k = 0; k < host_lists->size(); k++) {
                 const std::string &name = (*host_lists)[k].name;
                 if (!seen.insert(name).second) continue;
                 key(name);
-                if (keys_only) push_bool(true);
-                else { emit(R_CLIST, 0, list_id(k)); push(); r.clist = true; r.len = std::max(r.len, (uint32_t)(*host_lists)[k].size()); }
+                if (keys_only) val(mk_bool(true));
+                else { val(mk(T_CLIST, list_id(k))); r.clist = true; r.len = std::max(r.len, (uint32_t)(*host_lists)[k].size()); }
             }
         } else {
             if (closed_headers == nullptr) throw Reject{"the headers map with a computed key (it holds the names the whole rule set mentions)"};
             for (const std::string &name : *closed_headers) {
                 key(name);
-                if (keys_only) push_bool(true);
-                else { emit(R_FIELD, 0, (uint32_t)header_field(name)); push(); }
+                val(mk(T_REF, R_FIELD, (uint64_t)header_field(name)));
             }
         }
+        const uint32_t n = (uint32_t)(kv.size() / 2);
         r.nest = std::max(r.nest, inner.nest + 1);
         if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
         r.inner = std::max(std::max(r.inner, inner.inner), inner.len);
         if (ctx != 3) r.len = n;
-        use_heap(2 * n);
-        emit(R_MKMAP, 0, n);
-        pop((int)(2 * n));
-        push();
+        const uint32_t base = (uint32_t)consts.size();
+        for (const Val &v : kv) add_const(v);
+        return mk(T_MAP, n, (uint64_t)base);
     }
 
     // does the node denote a context object? (decided from the syntax alone: nothing is emitted)
@@ -299,6 +310,64 @@ struct ResidualBuilder::Impl {
             if (ix.kind == EX_STR && ix.text == "headers") return 4;
         }
         return 0;
+    }
+
+    // A list / map literal whose items are all constants is a CONSTANT of the program (no stack slot per item, no heap item: a literal of
+    // 40 strings is a value like any other; round 6 — the items used to be pushed and popped like computed ones, 24 at most).
+    bool is_const_node(int ni) const {
+        const Ex &e = syn->nodes[(size_t)ni];
+        switch (e.kind) {
+            case EX_INT: case EX_FLOAT: case EX_STR: case EX_BOOL: case EX_NULL: return true;
+            case EX_LIST: case EX_MAP:
+                for (int k : e.kids) if (!is_const_node(k)) return false;
+                return true;
+            default: return false;
+        }
+    }
+    Val const_value(int ni, Info &r) {
+        const Ex &e = syn->nodes[(size_t)ni];
+        r = Info{};
+        switch (e.kind) {
+            case EX_INT: return mk_int(e.ival);
+            case EX_FLOAT: return mk_flt(e.fval);
+            case EX_STR: return mk(T_STR, (uint32_t)e.text.size(), ((uint64_t)S_CONST << 48) | str_const(e.text));
+            case EX_BOOL: return mk_bool(e.bval);
+            case EX_NULL: return mk(T_NULL);
+            default: break;
+        }
+        std::vector<Val> items;
+        bool err = false;
+        if (e.kind == EX_LIST) {
+            for (int k : e.kids) {
+                Info it;
+                const Val v = const_value(k, it);
+                err = err || v.t == T_ERR;
+                r = merge(r, it);
+                items.push_back(v);
+            }
+        } else {
+            for (size_t k = 0; k + 1 < e.kids.size(); k += 2) {
+                Info ki, vi;
+                const Val key = const_value(e.kids[k], ki), val = const_value(e.kids[k + 1], vi);
+                err = err || key.t != T_STR || val.t == T_ERR;  // (a key that is not a String: the map is an execution error, op_mkmap)
+                r = merge(r, merge(ki, vi));
+                if (err) continue;
+                const std::string &kt = syn->nodes[(size_t)e.kids[k]].text;
+                bool dup = false;
+                for (size_t j = 0; j + 1 < items.size() && !dup; j += 2)
+                    if (strpool.compare((size_t)(items[j].p & 0xFFFFFFFFu), items[j].a, kt) == 0) { items[j + 1] = val; dup = true; }  // later duplicates win
+                if (!dup) { items.push_back(key); items.push_back(val); }
+            }
+        }
+        r.nest += 1;
+        if (r.nest > kMaxNest) throw Reject{"lists / maps nested deeper than " + std::to_string(kMaxNest)};
+        r.inner = std::max(r.inner, r.len);
+        r.len = (uint32_t)(e.kind == EX_LIST ? items.size() : items.size() / 2);
+        r.clist = false;
+        if (err) return mk(T_ERR);
+        const uint32_t base = (uint32_t)consts.size();
+        for (const Val &v : items) add_const(v);
+        return mk(e.kind == EX_LIST ? T_LIST : T_MAP, r.len, (uint64_t)base);
     }
 
     Info gen(int ni) {
@@ -355,6 +424,7 @@ struct ResidualBuilder::Impl {
             case EX_GCALL: push_err(); return r;  // undeclared function
             case EX_MCALL: return call(e);
             case EX_LIST: {
+                if (!e.kids.empty() && is_const_node(ni)) { emit(R_CONST, 0, add_const(const_value(ni, r))); push(); return r; }
                 uint32_t n = 0;
                 for (int k : e.kids) {
                     Info it = gen(k);
@@ -375,6 +445,7 @@ struct ResidualBuilder::Impl {
                 return r;
             }
             case EX_MAP: {
+                if (!e.kids.empty() && is_const_node(ni)) { emit(R_CONST, 0, add_const(const_value(ni, r))); push(); return r; }
                 uint32_t n = 0;
                 for (size_t k = 0; k + 1 < e.kids.size(); k += 2) {
                     Info key = gen(e.kids[k]);
@@ -500,8 +571,152 @@ struct ResidualBuilder::Impl {
         return r;
     }
 
+    // ---- what is statically known about an operand of && / || (round 6: cheapest operand first) --------------------------------------
+    // `A && B` matches iff A is Bool(true) and B is Bool(true); the ORDER only decides which execution error (or non-Bool operand) is
+    // met first, and the per-rule error counters must agree with the reference's evaluation order (pingoo/rules.rs:41-45 logs each).
+    // So a chain of && (or ||) is reordered only when every operand is PURE: statically a Bool whose evaluation cannot fail — then any
+    // order gives the same value and no error either way. Integer arithmetic is pure when interval arithmetic over the operands' ranges
+    // (lengths and client.asn < 2^32, ports < 2^16, constants) shows that it cannot overflow or divide by zero. The cheapest operand
+    // goes first: comparisons of integers and lengths read no string bytes at all, an equality reads them only when the lengths agree,
+    // `contains` / `matches` / orderings walk the text — `(host + ":" + method).matches(..) && path + "x" == "/qx"` evaluated the regex for
+    // every request (0.23 ms per 10M requests) before the equality that nearly always fails.
+    enum { TY_NONE = 0, TY_BOOL, TY_INT, TY_STR };
+    struct Pure {
+        int ty = TY_NONE;  // TY_NONE: not known to be an error-free Bool / Int / String
+        uint32_t cost = 0;
+        __int128 lo = 0, hi = 0;  // TY_INT: every value it can take lies in [lo, hi], inside int64
+    };
+    static Pure mk_pure(int ty, uint32_t cost, __int128 lo = 0, __int128 hi = 0) { Pure p; p.ty = ty; p.cost = cost; p.lo = lo; p.hi = hi; return p; }
+    static bool fits64(__int128 v) { return v >= (__int128)INT64_MIN && v <= (__int128)INT64_MAX; }
+    Pure pure_ctx(int ctx, const std::string &key) const {
+        if (ctx == 1) {
+            for (const char *f : {"host", "url", "path", "method", "user_agent"}) if (key == f) return mk_pure(TY_STR, 0);
+            return Pure{};
+        }
+        if (ctx == 4) {
+            if (closed_headers == nullptr) return Pure{};
+            for (const std::string &n : *closed_headers) if (n == key) return mk_pure(TY_STR, 0);
+            return Pure{};
+        }
+        if (ctx == 2) {
+            if (key == "remote_port") return mk_pure(TY_INT, 0, 0, 65535);
+            if (key == "asn") return mk_pure(TY_INT, 0, 0, 0xFFFFFFFFll);
+            if (key == "country") return mk_pure(TY_STR, 0);
+        }
+        return Pure{};
+    }
+    Pure pure(int ni) const {
+        const Ex &e = syn->nodes[(size_t)ni];
+        switch (e.kind) {
+            case EX_INT: return mk_pure(TY_INT, 0, e.ival, e.ival);
+            case EX_STR: return mk_pure(TY_STR, 0);
+            case EX_BOOL: return mk_pure(TY_BOOL, 0);
+            case EX_MEMBER: { const int c = ctx_of(e.kids[0]); return c ? pure_ctx(c, e.text) : Pure{}; }
+            case EX_INDEX: {
+                const int c = ctx_of(e.kids[0]);
+                const Ex &ix = syn->nodes[(size_t)e.kids[1]];
+                return (c && ix.kind == EX_STR) ? pure_ctx(c, ix.text) : Pure{};
+            }
+            case EX_NOT: { const Pure x = pure(e.kids[0]); return x.ty == TY_BOOL ? x : Pure{}; }
+            case EX_NEG: {
+                const Pure x = pure(e.kids[0]);
+                if (x.ty != TY_INT || !fits64(-x.lo) || !fits64(-x.hi)) return Pure{};
+                return mk_pure(TY_INT, x.cost, -x.hi, -x.lo);
+            }
+            case EX_COND: {
+                const Pure c = pure(e.kids[0]), a = pure(e.kids[1]), b = pure(e.kids[2]);
+                if (c.ty != TY_BOOL || a.ty == TY_NONE || a.ty != b.ty) return Pure{};
+                return mk_pure(a.ty, c.cost + std::max(a.cost, b.cost), std::min(a.lo, b.lo), std::max(a.hi, b.hi));
+            }
+            case EX_MCALL: {
+                if (ctx_of(e.kids[0])) return Pure{};
+                const Pure r = pure(e.kids[0]);
+                if (r.ty != TY_STR) return Pure{};
+                const size_t argc = e.kids.size() - 1;
+                if (e.text == "length" && argc == 0) return mk_pure(TY_INT, r.cost, 0, 0xFFFFFFFFll);
+                if (argc != 1) return Pure{};
+                if (e.text == "matches") {
+                    const Ex &p = syn->nodes[(size_t)e.kids[1]];
+                    if (p.kind != EX_STR) return Pure{};
+                    int status;
+                    std::string err;
+                    regex_parse(p.text, status, err);
+                    return status == 0 ? mk_pure(TY_BOOL, r.cost + 8) : Pure{};
+                }
+                const Pure a = pure(e.kids[1]);
+                if (a.ty != TY_STR) return Pure{};
+                if (e.text == "contains") return mk_pure(TY_BOOL, r.cost + a.cost + 6);
+                if (e.text == "starts_with" || e.text == "ends_with") return mk_pure(TY_BOOL, r.cost + a.cost + 2);
+                return Pure{};
+            }
+            case EX_BIN: {
+                if (e.op == B_IN) return Pure{};
+                const Pure l = pure(e.kids[0]), r = pure(e.kids[1]);
+                if (l.ty == TY_NONE || r.ty == TY_NONE) return Pure{};
+                const uint32_t cost = l.cost + r.cost;
+                switch (e.op) {
+                    case B_OR: case B_AND: return (l.ty == TY_BOOL && r.ty == TY_BOOL) ? mk_pure(TY_BOOL, cost) : Pure{};
+                    case B_EQ: case B_NE: return mk_pure(TY_BOOL, cost + ((l.ty == TY_STR && r.ty == TY_STR) ? 1u : 0u));  // (other types: unequal, not an error — D4)
+                    case B_LT: case B_LE: case B_GT: case B_GE:
+                        if (l.ty == TY_INT && r.ty == TY_INT) return mk_pure(TY_BOOL, cost);
+                        if (l.ty == TY_STR && r.ty == TY_STR) return mk_pure(TY_BOOL, cost + 3);
+                        return Pure{};
+                    case B_ADD:
+                        if (l.ty == TY_STR && r.ty == TY_STR) return mk_pure(TY_STR, cost + 1);  // (a rope: its segments are bounded by the compiler)
+                        [[fallthrough]];
+                    case B_SUB: case B_MUL: {
+                        if (l.ty != TY_INT || r.ty != TY_INT) return Pure{};
+                        __int128 c[4];
+                        if (e.op == B_ADD) { c[0] = c[1] = l.lo + r.lo; c[2] = c[3] = l.hi + r.hi; }
+                        else if (e.op == B_SUB) { c[0] = c[1] = l.lo - r.hi; c[2] = c[3] = l.hi - r.lo; }
+                        else { c[0] = l.lo * r.lo; c[1] = l.lo * r.hi; c[2] = l.hi * r.lo; c[3] = l.hi * r.hi; }
+                        const __int128 lo = std::min(std::min(c[0], c[1]), std::min(c[2], c[3])), hi = std::max(std::max(c[0], c[1]), std::max(c[2], c[3]));
+                        return (fits64(lo) && fits64(hi)) ? mk_pure(TY_INT, cost, lo, hi) : Pure{};
+                    }
+                    case B_DIV: case B_MOD: {
+                        if (l.ty != TY_INT || r.ty != TY_INT || r.lo != r.hi || r.lo == 0 || r.lo == -1) return Pure{};  // a constant divisor other than 0 (and -1: INT64_MIN / -1)
+                        const __int128 d = r.lo < 0 ? -r.lo : r.lo, m = std::max(l.lo < 0 ? -l.lo : l.lo, l.hi < 0 ? -l.hi : l.hi);
+                        return e.op == B_DIV ? mk_pure(TY_INT, cost, -m, m) : mk_pure(TY_INT, cost, l.lo < 0 ? -(d - 1) : 0, d - 1);
+                    }
+                    default: return Pure{};
+                }
+            }
+            default: return Pure{};
+        }
+    }
+    void chain_operands(int ni, BinOp op, std::vector<int> &out) const {
+        const Ex &e = syn->nodes[(size_t)ni];
+        if (e.kind == EX_BIN && e.op == op) { chain_operands(e.kids[0], op, out); chain_operands(e.kids[1], op, out); }
+        else out.push_back(ni);
+    }
+
     Info binary(const Ex &e) {
         Info r;
+        if ((e.op == B_OR || e.op == B_AND) && reorder) {
+            std::vector<int> ops;
+            chain_operands(e.kids[0], e.op, ops);
+            chain_operands(e.kids[1], e.op, ops);
+            std::vector<std::pair<uint32_t, int>> byc;
+            bool all_pure = true;
+            for (int o : ops) {
+                const Pure p = pure(o);
+                all_pure = all_pure && p.ty == TY_BOOL;
+                byc.emplace_back(p.cost, o);
+            }
+            if (all_pure) {
+                std::stable_sort(byc.begin(), byc.end(), [](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) { return a.first < b.first; });
+                gen(byc[0].second);
+                for (size_t k = 1; k < byc.size(); k++) {  // (the left-nested chain `((a && b) && c)`, operand by operand)
+                    const size_t j = code.size();
+                    emit(e.op == B_AND ? R_AND_L : R_OR_L);
+                    pop();
+                    gen(byc[k].second);
+                    emit(R_BOOL_CHK);
+                    code[j].b = (uint16_t)code.size();
+                }
+                return r;
+            }
+        }
         if (e.op == B_OR || e.op == B_AND) {
             Info l = gen(e.kids[0]);
             if (l.ctx) { push_err(); return r; }  // Bool operands required (the right side is not evaluated)

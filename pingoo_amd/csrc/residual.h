@@ -60,7 +60,7 @@ namespace pwaf {
 namespace rvm {
 
 // ---- value model -----------------------------------------------------------------------------------------------------------------
-enum Type : uint32_t { T_ERR = 0, T_NULL, T_BOOL, T_INT, T_FLT, T_STR, T_IP, T_NET, T_LIST, T_CLIST, T_MAP };
+enum Type : uint32_t { T_ERR = 0, T_NULL, T_BOOL, T_INT, T_FLT, T_STR, T_IP, T_NET, T_LIST, T_CLIST, T_MAP, T_REF };
 // T_STR   a = length; p = src << 48 | offset. src: < S_CONST = string column (field id: the request's bytes), S_CONST = the program's
 //         string pool, S_INLINE = up to 6 bytes held in p itself (client.country), S_ROPE = a concatenation: offset = index of its
 //         first segment in the lane's heap | segments << 24 (segments are plain T_STR values)
@@ -68,6 +68,8 @@ enum Type : uint32_t { T_ERR = 0, T_NULL, T_BOOL, T_INT, T_FLT, T_STR, T_IP, T_N
 // T_CLIST a = configured list id (lists["name"]): typed items in the program's list tables
 // T_NET   p = index into the program's network table (an item of an Ip list; there is no literal syntax)
 // T_MAP   like T_LIST with 2 * a values: key (T_STR), value, key, value ...; keys are distinct
+// T_REF   only as a VALUE slot of a CONSTANT map (a context map as a value: residual.cpp gen_ctx_map): a = the instruction that reads the
+//         request (R_FIELD, R_COUNTRY, R_PORT, R_ASN, R_IP), p = its operand; replaced by the value itself when the slot is read (deref)
 struct Val {
     uint32_t t, a;
     uint64_t p;
@@ -273,6 +275,23 @@ PWAF_HD bool net_contains(const NetItem &nt, const uint8_t *ip, uint32_t v6) {  
     return true;
 }
 
+// A value slot of a map, read: a constant map's T_REF slots name a request value (the map itself costs no stack slot and no heap item,
+// whatever its size — a headers map of 64 names as a value; until round 6 its entries were pushed and popped: 2 x 64 stack slots).
+PWAF_HD Val op_field(const Machine &m, uint32_t f);
+PWAF_HD Val op_country(const Machine &m);
+PWAF_HD Val op_port(const Machine &m);
+PWAF_HD Val op_asn(const Machine &m);
+PWAF_HD Val deref(const Machine &m, const Val &v) {
+    if (v.t != T_REF) return v;
+    switch (v.a) {
+        case R_FIELD: return op_field(m, (uint32_t)v.p);
+        case R_COUNTRY: return op_country(m);
+        case R_PORT: return op_port(m);
+        case R_ASN: return op_asn(m);
+        default: return mk(T_IP);
+    }
+}
+
 // val_eq (D4: cross-type equality is false). Lists and maps nest at most kMaxNest deep (the compiler rejects deeper literals), so the
 // recursion is unrolled at compile time through the depth parameter instead of recursing on the device.
 template <int D>
@@ -309,7 +328,7 @@ struct Eq {
                     for (uint32_t j = 0; j < b.a && !found; j++)
                         if (ia[2 * k].a == ib[2 * j].a && str_eq_at(m, ia[2 * k], 0, ib[2 * j])) {
                             found = true;
-                            if (!Eq<D - 1>::eq(m, ia[2 * k + 1], ib[2 * j + 1])) return false;
+                            if (!Eq<D - 1>::eq(m, deref(m, ia[2 * k + 1]), deref(m, ib[2 * j + 1]))) return false;
                         }
                     if (!found) return false;
                 }
@@ -398,7 +417,7 @@ PWAF_HD bool map_has(const Machine &m, const Val &mp, const Val &key, Val *out) 
     const Val *it = items_of(m, mp);
     for (uint32_t k = 0; k < mp.a; k++)
         if (it[2 * k].a == key.a && str_eq_at(m, it[2 * k], 0, key)) {
-            if (out) *out = it[2 * k + 1];
+            if (out) *out = deref(m, it[2 * k + 1]);
             return true;
         }
     return false;

@@ -287,6 +287,77 @@ def test_every_expression_of_the_general_fuzzer_runs_in_the_interpreter(seed):
             assert (got3 == 2) == (want3 == 3), ("execution errors are counted per rule: the interpreter and the oracle must agree on them", seed, e, i, got3, want3)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the cheapest operand of a && / || chain goes first — when, and only when, no order can change an error
+# ---------------------------------------------------------------------------------------------------------------------
+def dchain(rng):
+    """&& / || chains whose operands are mostly PURE in the compiler's sense (statically Bool, cannot fail: comparisons of lengths / ports with
+    in-range arithmetic, equalities of concatenations, starts_with / contains / matches of Strings) with failing or ill-typed ones mixed in:
+    a pure chain is reordered by cost, a chain with one impure operand keeps the source order — either way the value AND the error must
+    be the oracle's, which evaluates left to right."""
+    S = ["http_request.host", "http_request.path", "http_request.method", "http_request.url", "client.country", 'http_request.headers["x-a"]', '"/a"', '"GET"', '""',
+         '(http_request.host + ":" + http_request.method)', '(http_request.path + "x")', '(client.country + http_request.method)']
+    I = ["client.remote_port", "client.asn", "http_request.path.length()", "http_request.url.length()", "(http_request.path.length() + 1)", "(client.remote_port * 2)", "(client.remote_port % 7)",
+         "(client.remote_port / 7)", "(http_request.url.length() - http_request.path.length())", "(client.asn * client.asn)", "(-client.remote_port)", "3", "80", "4242", "0"]
+    IMPURE = ["client.remote_port / (client.remote_port - 80) == 1", "9223372036854775807 + client.remote_port > 0", "client.asn * client.asn * client.asn > 5", 'http_request.host + 1 == "a"',
+              "client.remote_port", '!http_request.path', "client.remote_port % (client.asn - client.asn) == 0", '{"a": 1}.b == 1', 'http_request.path.matches("(")', "[1][client.remote_port] == 1",
+              "client.remote_port < http_request.path", 'http_request.headers["nope"] == ""', "(client.remote_port > 80 ? 1 : true)"]
+
+    def operand(depth):
+        k = rng.randint(0, 11)
+        if k <= 2:
+            return rng.choice(I) + " " + rng.choice(["==", "!=", "<", "<=", ">", ">="]) + " " + rng.choice(I)
+        if k <= 4:
+            return rng.choice(S) + " " + rng.choice(["==", "!=", "<", ">="]) + " " + rng.choice(S)
+        if k <= 6:
+            return rng.choice(S) + "." + rng.choice(["contains", "starts_with", "ends_with"]) + "(" + rng.choice(S) + ")"
+        if k == 7:
+            return rng.choice(S) + ".matches(" + H.q(rng.choice(["^[a-z]+:(GET|POST)$", "^/a", "a.*b", "[0-9]+$", "(?i)get"])) + ")"
+        if k == 8:
+            return "!(" + operand(depth + 1) + ")"
+        if k == 9 and depth < 2:
+            return "(" + operand(depth + 1) + " ? " + operand(depth + 1) + " : " + operand(depth + 1) + ")"
+        if k == 10 and depth < 2:
+            return "(" + chain(depth + 1) + ")"
+        return rng.choice(IMPURE) if rng.random() < 0.5 else rng.choice(["true", "false"])
+
+    def chain(depth):
+        op = rng.choice([" && ", " || "])
+        return op.join(operand(depth) for _ in range(rng.randint(2, 5)))
+
+    return chain(0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_reordered_chains_keep_the_value_and_the_error_of_left_to_right_evaluation(seed):
+    rng = random.Random(626200 + seed)
+    exprs = [dchain(rng) for _ in range(14)]
+    batch = RequestBatch.from_requests(requests(rng, 30))
+    for e in exprs:
+        pyoracle.compile_expression(e)
+        m = HostVM([e], LISTS)
+        orc = pyoracle.Oracle([("r", e, [H.B])], LISTS, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+        m.bind(batch)
+        for i in range(batch.n):
+            want3 = orc.execute_rule(0, batch, i)  # 1 true, 0 false, 2 non-Bool, 3 error
+            got3 = m.eval3(0, i)
+            assert got3 == {1: 1, 0: 0, 2: 0, 3: 2}[want3], (seed, e, i, got3, want3, [batch.field_bytes(f, i) for f in range(5)], int(batch.port[i]), int(batch.asn[i]))
+
+
+def test_the_cheapest_pure_operand_is_evaluated_first():
+    """The program text itself: the regex of `(host + ":" + method).matches(..) && path + "x" == "/qx"` comes AFTER the equality, a chain with
+    an operand that can fail keeps its source order (PWAF_RESIDUAL_SOURCE_ORDER=1 keeps every chain's)."""
+    m = HostVM(['(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && http_request.path + "x" == "/qx"',
+                '(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && client.remote_port / (client.remote_port - 80) == 1',
+                'http_request.url.contains(http_request.host) || client.remote_port % 2 == 0 || http_request.path.length() + 1 > http_request.url.length()'])
+    src = m.specialized_source()
+    r0, r1, r2 = (src[src.index(f"rvm_rule_{k}("):src.index(f"rvm_rule_{k + 1}(") if k < 2 else len(src)] for k in range(3))
+    assert r0.index("op_bin(m, 2u") < r0.index("op_matches")       # == before the walk
+    assert r1.index("op_matches") < r1.index("op_bin(m, 12u")      # a division that can fail: source order
+    assert r2.index("op_bin(m, 13u") < r2.index("op_call(m, 0u")   # % and the length comparison before contains
+    assert r2.index("op_bin(m, 6u") < r2.index("op_call(m, 0u")
+
+
 def test_residual_known_answers():
     cases = [
         ("http_request.path.length() + 1 > http_request.url.length()", [Request(path="/abc", url="/abc"), Request(path="/a", url="/a?x=1")], [True, False]),
@@ -390,12 +461,12 @@ def test_heap_use_of_indexed_nested_literals_is_charged_in_full():
     """`[[1..20]][0] + [[1..20]][0]` — the item an index (or a member access) brings to the top can be LONGER than its
     receiver, and the concatenation copies it: the compiler charged 44 of the 64 heap slots and the interpreter wrote 82. Now the bound
     follows the nested lengths: what fits evaluates like the oracle, what does not is refused at compile time — never overrun."""
-    inner = "[" + ", ".join(str(k) for k in range(1, 21)) + "]"
+    inner = "[" + ", ".join(str(k) for k in range(1, 41)) + "]"  # (round 6: a literal of constants is itself a constant of the program — only what the concatenation copies is charged: 40 + 40 > 64)
     rng = random.Random(77)
     batch = RequestBatch.from_requests([Request(host="h", path="/p", user_agent="ua", remote_port=p) for p in (1, 20, 21, 40)])
     flags = _abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS
     refused = accepted = 0
-    exprs = [f"([{inner}][0] + [{inner}][0]).contains(client.remote_port)",                    # 20 + 20 + 40 copied = 82 > 64: refused
+    exprs = [f"([{inner}][0] + [{inner}][0]).contains(client.remote_port)",                    # 40 + 40 copied = 80 > 64: refused
              f'({{"k": {inner}}}.k + {{"k": {inner}}}.k).contains(client.remote_port)',         # same through a map member
              "([[1, 2, 3, 4, 5, 6]][0] + [[20, 21]][0]).contains(client.remote_port)",          # small: runs
              '({"k": [1, 2, 3]}.k + [[40], [20, 21]][1]).contains(client.remote_port)']
@@ -471,6 +542,56 @@ def test_computed_keys_into_http_request_and_the_headers_map():
     want = orc.evaluate(batch)
     got_v = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
     H.assert_verdicts_equal(got_v, want, batch, "computed keys through the compiled program")
+
+
+def test_a_headers_map_of_64_names_is_a_value():
+    """VERDICT r5 #6 / missing #3: a rule set that mentions 64 header names (BASELINE configs[4]'s width) and needs the headers map AS A VALUE
+    (a computed key). The map's entries used to travel over the interpreter's stack (2 x 64 slots of 24): every such rule was refused by
+    name. Now a context map is a constant of the program whose value slots name the request values (residual.h: T_REF) — one stack slot,
+    no heap item. Interpreter, specialized form and oracle on every rule and request."""
+    import test_residual_jit as J
+
+    names = [f"x-h{k}" for k in range(64)]
+    rules = [f'http_request.headers["{n}"] == "{k}"' for k, n in enumerate(names)]
+    rules += ['http_request.headers[http_request.method] == "v"',                       # the method names a header of the set, or the key is absent (an error)
+              '(http_request.host + "") in http_request.headers',
+              'http_request.headers.contains(http_request.path)',
+              'http_request.headers.length() == 64',
+              'http_request["headers"][http_request.path] == "7"',
+              'http_request[http_request.method == "GET" ? "headers" : "host"] == "x-h3"',  # a Map on one branch (unequal to a String, no error), the host on the other
+              'http_request.headers["x-h" + "63"] == "63"',
+              'http_request.headers[client.country] == ""']
+    rng = random.Random(99)
+    reqs = []
+    for i in range(48):
+        hd = {n: str(k) if rng.random() < 0.5 else H.rstr(rng, 0, 3) for k, n in enumerate(names) if rng.random() < 0.4}
+        reqs.append(Request(host=rng.choice(["x-h3", "x-h40", "a.example", "x-h64"]), path=rng.choice(["x-h7", "/p", "x-h63", "x-h"]), method=rng.choice(["GET", "POST", "x-h12", "x-h7"]),
+                            url="/u", user_agent="ua", country=rng.choice(["US", "FR"]), asn=1, headers=hd))
+    batch = RequestBatch.from_requests(reqs)
+    m = HostVM(rules, LISTS)
+    assert m.header_names == names
+    orc = pyoracle.Oracle([(f"r{k}", e, [H.B]) for k, e in enumerate(rules)], LISTS, flags=_abi.OPT_NO_UA_GATE | _abi.OPT_NO_CAPTCHA_BYPASS)
+    assert orc.header_names == names
+    m.bind(batch)
+    hits = 0
+    for k in range(len(rules)):
+        for i in range(batch.n):
+            want3 = orc.execute_rule(k, batch, i)
+            got3 = m.eval3(k, i)
+            assert got3 == {1: 1, 0: 0, 2: 0, 3: 2}[want3], (rules[k], i, got3, want3)
+            hits += k >= 64 and got3 == 1
+    assert hits >= 20  # (the computed keys do find headers)
+    J.check_rule_set(rules, LISTS, batch, "hdr64")  # the specialized form of the same rule set
+    # through the whole compiler: none refused, and the program names every rule that runs as a residual program
+    from pingoo_amd.engine import CompiledProgram
+    prog = CompiledProgram([(f"r{k}", e, [H.B]) for k, e in enumerate(rules)], LISTS)
+    assert prog.header_names == names and not any("NOT evaluated" in w for w in prog.warnings())
+    import table_walker
+
+    t = table_walker.Tables(prog)
+    want = orc.evaluate(batch)
+    got_v = np.array([t.evaluate(batch, i) for i in range(batch.n)], dtype=[("action", np.uint8), ("rule_idx", np.uint32)])
+    H.assert_verdicts_equal(got_v, want, batch, "64 header names, computed keys")
 
 
 def test_header_keys_that_only_constant_folding_makes_literal():
