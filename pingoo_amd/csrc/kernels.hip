@@ -1877,21 +1877,21 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         }
     }
     {
-    // (software-pipelined: the offsets of the next kAhead x 64 requests are in flight while these are ranked. One step ahead — round 2 to
-    // 6 — left a wave whose slab holds thousands of short fields (a host arena: 6500 requests per 128 KiB slab) with a hundred dependent
-    // round trips, ~45 us of a launch whose other waves had long left: the launch's floor at ANY batch size.)
-    constexpr uint32_t kAhead = 4;
-    uint32_t s_q[kAhead], e_q[kAhead];
-#pragma unroll
-    for (uint32_t k = 0; k < kAhead; k++) {
-        const uint32_t r = lo + 64u * k + lane;
-        s_q[k] = e_q[k] = 0xFFFFFFFFu;
-        if (r < a.n) { s_q[k] = a.off[r]; e_q[k] = a.off[r + 1]; }
+    // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
+    uint32_t s_n = 0xFFFFFFFFu, e_n = 0xFFFFFFFFu;
+    {
+        const uint32_t r = lo + lane;
+        if (r < a.n) { s_n = a.off[r]; e_n = a.off[r + 1]; }
     }
-    // one step of 64 requests; returns "no later request can own a byte of this slab"
-    auto step = [&](const uint32_t rb, const uint32_t s, const uint32_t e) -> bool {
+    for (uint32_t rb = lo; rb < a.n; rb += 64) {
         const uint32_t r = rb + lane;
         const bool live = r < a.n;
+        const uint32_t s = s_n, e = e_n;
+        {
+            const uint32_t r2 = r + 64;
+            s_n = e_n = 0xFFFFFFFFu;
+            if (r2 < a.n) { s_n = a.off[r2]; e_n = a.off[r2 + 1]; }
+        }
         if (a.pairs != nullptr) {
             // A request with a flagged chunk among its own gets its hit record ZEROED here (confirm_kernel merges hits into it; the verdict
             // kernel only reads records whose valid bit a hit or a walk set — which implies a flagged chunk): one store per such request
@@ -1926,7 +1926,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
                     }
                 }
             }
-            return __ballot(live && (uint64_t)s >= b1) != 0;  // (offsets ascend: no later request owns a byte of this slab)
+            if (__ballot(live && (uint64_t)s >= b1) != 0) break;  // (offsets ascend: no later request owns a byte of this slab)
+            continue;
         }
         bool mark = false;
         if (live && (uint64_t)s < b1 + 16) {
@@ -1945,22 +1946,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             const uint32_t parts[3] = {(uint32_t)(m << sh), (uint32_t)(sh ? m >> (32u - sh) : m >> 32), sh ? (uint32_t)(m >> (64u - sh)) : 0u};
             if (lane < 3 && parts[lane] != 0) atomicOr(&a.bitmap[w0 + lane], parts[lane]);
         }
-        return __ballot(live && (uint64_t)s >= b1 + 16) != 0;  // (offsets ascend: nothing further overlaps)
-    };
-    for (uint32_t rb = lo; rb < a.n;) {
-        bool stop = false;
-#pragma unroll
-        for (uint32_t k = 0; k < kAhead; k++) {
-            if (!stop && rb < a.n) {  // (wave-uniform)
-                const uint32_t s = s_q[k], e = e_q[k];
-                const uint32_t r2 = rb + 64u * kAhead + lane;
-                s_q[k] = e_q[k] = 0xFFFFFFFFu;
-                if (r2 < a.n) { s_q[k] = a.off[r2]; e_q[k] = a.off[r2 + 1]; }
-                stop = step(rb, s, e);
-                rb += 64u;
-            }
-        }
-        if (stop) break;
+        if (__ballot(live && (uint64_t)s >= b1 + 16) != 0) break;  // (offsets ascend: nothing further overlaps)
     }
     }
 }

@@ -50,6 +50,8 @@ struct ResidualBuilder::Impl {
     std::vector<NetItem> nets;
     std::vector<RegexDesc> regexes;
     std::vector<std::vector<uint8_t>> regex_tabs;  // trans | classmap | flags per regex, appended to the blob
+    std::vector<RegexSetDesc> rxsets;
+    std::vector<uint32_t> rxitems;
     std::map<std::string, uint32_t> list_ids, regex_ids;
     bool needs_geo = false;
 
@@ -138,7 +140,7 @@ struct ResidualBuilder::Impl {
             DfaGroup g;
             std::string e2;
             if (!build_dfa(one, 8192, 2u << 20, g, e2)) throw Reject{"matches(): the pattern's DFA exceeds the residual interpreter's budget: " + e2};
-            if (regexes.size() >= 0xFFE) throw Reject{"too many regex literals in residual programs"};
+            if (regexes.size() >= 0x7FF) throw Reject{"too many regex literals in residual programs"};
             const std::vector<uint8_t> uimg = scalar_map_image(g.umap);  // (empty: the table reads bytes)
             const size_t uat = (g.trans.size() * 2 + 256 + g.n_states + 3) & ~(size_t)3;
             std::vector<uint8_t> tab(uat + uimg.size());
@@ -502,6 +504,59 @@ struct ResidualBuilder::Impl {
         throw Reject{"internal: unknown node"};
     }
 
+    // The strings a pattern expression can evaluate to, when they are finitely many and known now (a superset is fine: the value picks its
+    // table at run time): literals, conditionals between such, concatenations, items of a configured String list, items of list / map
+    // literals of such. false: not enumerable (a request field, client.country ...), or more than kMaxPatterns candidates.
+    static constexpr size_t kMaxPatterns = 64;
+    const ResidualList *clist_of(int ni) const {  // lists["name"] / lists.name
+        const Ex &e = syn->nodes[(size_t)ni];
+        std::string name;
+        if (e.kind == EX_MEMBER && ctx_of(e.kids[0]) == 3) name = e.text;
+        else if (e.kind == EX_INDEX && ctx_of(e.kids[0]) == 3 && syn->nodes[(size_t)e.kids[1]].kind == EX_STR) name = syn->nodes[(size_t)e.kids[1]].text;
+        else return nullptr;
+        for (auto &l : *host_lists) if (l.name == name) return &l;
+        return nullptr;
+    }
+    bool enum_strings(int ni, std::set<std::string> &out) const {
+        const Ex &e = syn->nodes[(size_t)ni];
+        auto add_all = [&](const std::set<std::string> &more) { out.insert(more.begin(), more.end()); return out.size() <= kMaxPatterns; };
+        switch (e.kind) {
+            case EX_STR: out.insert(e.text); return out.size() <= kMaxPatterns;
+            case EX_INT: case EX_FLOAT: case EX_BOOL: case EX_NULL: return true;  // (never a String: the call is an error whatever the set holds)
+            case EX_COND: return enum_strings(e.kids[1], out) && enum_strings(e.kids[2], out);
+            case EX_BIN: {
+                if (e.op != B_ADD) return false;
+                std::set<std::string> l, r, both;
+                if (!enum_strings(e.kids[0], l) || !enum_strings(e.kids[1], r) || l.size() * r.size() > kMaxPatterns) return false;
+                for (auto &a : l) for (auto &b : r) both.insert(a + b);
+                return add_all(both);
+            }
+            case EX_INDEX: case EX_MEMBER: {
+                if (e.kind == EX_INDEX) {
+                    if (const ResidualList *cl = clist_of(e.kids[0])) {  // any item of the configured list
+                        if (cl->type != PWAF_LIST_STRING) return true;
+                        return add_all(std::set<std::string>(cl->strs.begin(), cl->strs.end()));
+                    }
+                }
+                const Ex &o = syn->nodes[(size_t)e.kids[0]];
+                if (o.kind == EX_LIST && e.kind == EX_INDEX) { for (int k : o.kids) if (!enum_strings(k, out)) return false; return true; }
+                if (o.kind == EX_MAP) { for (size_t k = 1; k < o.kids.size(); k += 2) if (!enum_strings(o.kids[k], out)) return false; return true; }
+                return false;
+            }
+            default: return false;
+        }
+    }
+    uint32_t regex_set_id(const std::set<std::string> &patterns) {
+        if (rxsets.size() >= 0x7FE) throw Reject{"too many computed matches() patterns in residual programs"};
+        RegexSetDesc d{(uint32_t)(rxitems.size() / 4), (uint32_t)patterns.size()};
+        for (const std::string &p : patterns) {
+            const uint32_t id = regex_id(p);
+            rxitems.push_back(str_const(p)); rxitems.push_back((uint32_t)p.size()); rxitems.push_back(id); rxitems.push_back(0);
+        }
+        rxsets.push_back(d);
+        return 0x800u | (uint32_t)(rxsets.size() - 1);
+    }
+
     Info call(const Ex &e) {
         Info r;
         const std::string &f = e.text;
@@ -548,7 +603,11 @@ struct ResidualBuilder::Impl {
             const Ex &p = syn->nodes[(size_t)e.kids[1]];
             if (p.kind != EX_STR) {
                 if (p.kind == EX_INT || p.kind == EX_FLOAT || p.kind == EX_BOOL || p.kind == EX_NULL) aux = 0xFFFu;  // String operands required: an error either way
-                else throw Reject{"matches() with a pattern that is not a String literal"};
+                else {
+                    std::set<std::string> cands;
+                    if (!enum_strings(e.kids[1], cands)) throw Reject{"matches() with a pattern that is not a String literal (nor one of at most 64 strings known when the rule is compiled)"};
+                    aux = regex_set_id(cands);
+                }
             } else {
                 aux = regex_id(p.text);
             }
@@ -809,7 +868,7 @@ int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualL
     Impl &m = *impl;
     m.closed_headers = closed_headers;
     // a failed rule must leave no trace: snapshot the growing tables
-    const size_t c0 = m.code.size(), k0 = m.consts.size(), s0 = m.strpool.size(), l0 = m.lists.size(), ls0 = m.lstr.size(), li0 = m.lints.size(), n0 = m.nets.size(), r0 = m.regexes.size();
+    const size_t c0 = m.code.size(), k0 = m.consts.size(), s0 = m.strpool.size(), l0 = m.lists.size(), ls0 = m.lstr.size(), li0 = m.lints.size(), n0 = m.nets.size(), r0 = m.regexes.size(), xs0 = m.rxsets.size(), xi0 = m.rxitems.size();
     const auto list_ids0 = m.list_ids;
     const auto regex_ids0 = m.regex_ids;
     const bool geo0 = m.needs_geo;
@@ -829,7 +888,7 @@ int ResidualBuilder::compile_rule(const Syntax &syn, const std::vector<ResidualL
         why = rj.why;
     }
     m.code.resize(c0); m.consts.resize(k0); m.strpool.resize(s0); m.lists.resize(l0); m.lstr.resize(ls0); m.lints.resize(li0); m.nets.resize(n0);
-    m.regexes.resize(r0); m.regex_tabs.resize(r0);
+    m.regexes.resize(r0); m.regex_tabs.resize(r0); m.rxsets.resize(xs0); m.rxitems.resize(xi0);
     m.list_ids = list_ids0; m.regex_ids = regex_ids0; m.needs_geo = geo0;
     return -1;
 }
@@ -867,6 +926,8 @@ std::vector<uint8_t> ResidualBuilder::blob() const {
         (void)n_states;
     }
     h.regexes = put(rd.data(), rd.size() * sizeof(RegexDesc), 4);
+    h.rxsets = put(m.rxsets.data(), m.rxsets.size() * sizeof(RegexSetDesc), 4);
+    h.rxitems = put(m.rxitems.data(), m.rxitems.size() * 4, 4);
     h.needs_geo = m.needs_geo ? 1u : 0u;
     h.heap_items = m.heap_items;
     align(16);

@@ -86,7 +86,8 @@ enum Op : uint8_t {
     R_CLIST,    // b = configured list id
     R_INDEX,    // [obj, idx] -> item
     R_SELECT,   // a map value [obj] . const key b (string const index)
-    R_CALL,     // a = function (Fn), b = argc << 12 | aux (matches: regex table id, 0xFFF = invalid pattern)
+    R_CALL,     // a = function (Fn), b = argc << 12 | aux (matches: regex table id, 0xFFF = invalid pattern, 0x800 | k = pattern SET k: the
+                // pattern is computed per request but ranges over a finite set of strings enumerated at compile time — RegexSetDesc)
     R_NOT, R_NEG,
     R_BIN,      // a = BinOp (frontend.h numbering from B_EQ on)
     R_AND_L,    // b = target: pops the left operand of &&; undecided -> falls through to the right operand
@@ -127,6 +128,12 @@ struct RegexDesc {    // one literal `matches` pattern compiled to a DFA (a sing
     uint32_t umap;    // SCALAR MODE (dfa.cpp): byte offset of the scalar-value -> class map ([stage1 u16 x 8704][stage2]: csrc/utf8.h), 0 = the table reads bytes
     uint32_t ill_class;  // ... and the class of a byte that begins no well-formed sequence
 };
+// `s.matches(p)` with a pattern that is not a literal but can only be one of finitely many strings (a conditional between literals, an item of
+// a configured String list, concatenations of such): every candidate is compiled when the engine is created; per request the pattern's
+// VALUE selects the table by string equality (round 6; the reference compiles the pattern per evaluation, pingoo/rules.rs:37-51).
+struct RegexSetDesc {
+    uint32_t first, n;  // entries [first, first + n) of rxitems: {offset into strpool, length, regex id (0xFFF: an invalid pattern), 0}
+};
 // The whole residual program of a rule set is ONE blob (uploaded as is): header, then sections at the header's byte offsets.
 struct Header {
     uint32_t magic;          // 'RVM1'
@@ -143,7 +150,8 @@ struct Header {
     uint32_t needs_geo;      // some rule reads client.asn / client.country
     uint32_t total_bytes;
     uint32_t heap_items;     // no rule puts more values than this on its lane's heap (the compiler's static bound; <= the interpreter's kHeap)
-    uint32_t pad[2];
+    uint32_t rxsets;         // -> RegexSetDesc[]
+    uint32_t rxitems;        // -> uint32 x 4 per candidate pattern
 };
 
 // ---- request view ------------------------------------------------------------------------------------------------------------------
@@ -610,6 +618,16 @@ PWAF_HD Val op_call(const Machine &m, uint32_t fn, uint32_t argc, uint32_t aux, 
             break;
         case FN_MATCHES:
             if (argc != 1 || recv.t != T_STR || arg.t != T_STR || aux == 0xFFFu) break;  // (an invalid pattern is an execution error)
+            if (aux & 0x800u) {  // a computed pattern: which of the set's candidates is it?
+                const RegexSetDesc &sd = section<RegexSetDesc>(m, m.h->rxsets)[aux & 0x7FFu];
+                const uint32_t *it = section<uint32_t>(m, m.h->rxitems) + 4 * (size_t)sd.first;
+                uint32_t id = 0xFFFu;  // (a value outside the enumeration cannot occur: the compiler's set is a superset of the expression's values)
+                for (uint32_t k = 0; k < sd.n; k++)
+                    if (it[4 * k + 1] == arg.a && str_eq_at(m, arg, 0, mk(T_STR, it[4 * k + 1], ((uint64_t)S_CONST << 48) | it[4 * k]))) { id = it[4 * k + 2]; break; }
+                if (id == 0xFFFu) break;
+                v = mk_bool(regex_match(m, id, recv));
+                break;
+            }
             v = mk_bool(regex_match(m, aux, recv));
             break;
         default: break;

@@ -151,7 +151,7 @@ bool translate_rule(const Header &h, const uint8_t *blob, uint32_t rule, std::st
             case R_CALL: {
                 const uint32_t argc = in.b >> 12, aux = in.b & 0xFFFu;
                 const std::string recv = slot(d - 1 - (int)argc);
-                if (in.a == FN_MATCHES && argc == 1 && aux != 0xFFFu) {
+                if (in.a == FN_MATCHES && argc == 1 && aux != 0xFFFu && !(aux & 0x800u)) {
                     // the pattern's table reads bytes or scalar values (dfa.cpp): known now, so the walk is compiled for exactly that
                     const RegexDesc &rd = reinterpret_cast<const RegexDesc *>(blob + h.regexes)[aux];
                     s += "    " + recv + " = op_matches<" + (rd.umap ? "true" : "false") + ">(m, " + u32(aux) + ", " + recv + ", " + slot(d - 1) + ");\n";

@@ -162,3 +162,44 @@ def test_computed_keys_into_http_request_and_headers_on_the_device(how):
     H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "computed keys on the device")
     assert len(set(want["rule_idx"].tolist())) >= 6, set(want["rule_idx"].tolist())
     eng.close()
+
+
+@pytest.mark.parametrize("how", list(JIT))
+def test_wide_header_maps_computed_patterns_and_reordered_chains_on_the_device(how):
+    """Round 6: (a) a rule set that mentions 64 header names and needs the headers map as a value (a constant of the program: one stack
+    slot — such rules were refused by name), (b) `matches` with a pattern computed from finitely many strings (every candidate compiled
+    at creation, the value picks its table), (c) && / || chains of pure operands evaluated cheapest first, one with an operand that can
+    fail kept in source order — error counts included."""
+    names = [f"x-h{k}" for k in range(64)]
+    lists = dict(TR.LISTS, pats=(_abi.LIST_STRING, ["^/adm", "\\.php$", "(", "^[a-z]+$"]))
+    rules = [(f"h{k}", f'http_request.headers["{n}"] == "{k}" && http_request.path == "/h{k}"', [B]) for k, n in enumerate(names)]
+    rules += [("byname", 'http_request.headers[http_request.method] == "v"', [CAP]),
+              ("member", '(http_request.host + "") in http_request.headers && http_request.path == "/m"', [B]),
+              ("via", 'http_request["headers"][http_request.host] == "7"', [CAP]),
+              ("pat_cond", 'http_request.path.matches(http_request.method == "GET" ? "^/adm" : "^/api")', [B]),
+              ("pat_list", 'http_request.path.matches(lists["pats"][client.remote_port % 4])', [CAP]),
+              ("pat_cat", 'http_request.url.matches("^/" + (client.remote_port > 100 ? "a" : "b") + "[a-z]*$")', [B]),
+              ("chain", '(http_request.host + ":" + http_request.method).matches("^[a-z]+:(GET|POST)$") && http_request.path + "x" == "/qx"', [B]),
+              ("chain_err", 'http_request.url.contains(http_request.host) && client.remote_port / (client.remote_port - 80) == 1', [CAP]),
+              ("chain_or", 'http_request.url.contains(http_request.host + "!") || http_request.path.length() * 2 + 1 == http_request.url.length()', [B])]
+    eng = RuleEngine(rules, lists, flags=JIT[how])
+    check_mode(eng, how)
+    assert not eng.partial and eng.header_names == names
+    rng = random.Random(66)
+    reqs = []
+    for _ in range(4000):
+        hd = {n: rng.choice([str(k), "v", "7", ""]) for k, n in enumerate(names) if rng.random() < 0.3}
+        reqs.append(Request(host=rng.choice(["x-h3", "x-h40", "ab", "x-h64", "a.example"]), path=rng.choice(["/h5", "/h40", "/m", "/admin", "/api/x.php", "/q", "/b", "/abc"]),
+                            url=rng.choice(["/ab", "/b", "/abc?ab", "/q/ab!", "/qq1"]), method=rng.choice(["GET", "POST", "x-h12", "x-h7"]), user_agent="ua",
+                            remote_port=rng.choice([0, 1, 2, 3, 80, 101, 443]), headers=hd))
+    batch = RequestBatch.from_requests(reqs)
+    orc = pyoracle.Oracle(rules, lists)
+    want = orc.evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, "64 header names, computed patterns, reordered chains")
+    assert len(set(want["rule_idx"].tolist())) >= 12, set(want["rule_idx"].tolist())
+    n_res = [k for k, r in enumerate(rules) if any(f"rule #{k} " in w and "residual" in w for w in eng.program.warnings())]
+    errs = eng.rule_errors(len(rules))
+    for k in n_res:  # execution errors per residual rule = the oracle's (every residual rule is evaluated for every request)
+        assert errs[k] == sum(orc.execute_rule(k, batch, i) == 3 for i in range(batch.n)), (rules[k][0], errs[k])
+    assert len(n_res) >= 8 and errs[len(names) + 4] > 0 and errs[len(names) + 7] > 0  # (the invalid list pattern for a quarter of the ports; the division by zero at port 80)
+    eng.close()
