@@ -156,6 +156,8 @@ struct Scratch {
     uint64_t pool_entries = 0;  // overflow pool size in use (grown when a batch exhausted it)
     struct View { void *p = nullptr; };  // a part of zero_block / args (not owned)
     View res_cols;  // residual_kernel: the batch's string columns as device arrays of pointers
+    bool retry = false;   // this run repeats a batch that exhausted the overflow pool: its residual rules' execution errors were counted by the first run
+    DevBuf err_sink;      // ... and land here
     DevBuf ipres;  // ipres_kernel -> attr_kernel: (GeoIP class, membership set) of every request
     DevBuf rec, pool, gate_lists, attr;
     DevBuf verdict_spill;     // the sparse column file's per-wave spill arrays (kernels.h: VerdictArgs::spill)
@@ -210,7 +212,7 @@ struct Scratch {
         return PWAF_OK;
     }
     void release() {
-        for (DevBuf *b : {&status, &ipres, &rec, &res_words, &pool, &verdict_spill, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
+        for (DevBuf *b : {&status, &ipres, &rec, &res_words, &err_sink, &pool, &verdict_spill, &zero_block, &gate_lists, &attr, &chunk_bits, &cand_cnt, &need, &pairs, &zero_off, &args, &stage_ip, &stage_v6, &stage_port, &stage_flags,
                           &stage_asn, &stage_country, &stage_out, &stage_counts})
             b->release();
         for (PinBuf &b : arg_slot) b.release();
@@ -1549,6 +1551,10 @@ int run_pipeline(pwaf_engine *e, Scratch &S, const pwaf_batch &db /* device poin
         ra.pool_cap = pool_cap;
         ra.status = status_word;
         ra.rule_errors = (unsigned long long *)e->residual_errors.p;
+        if (S.retry) {  // (pwaf_engine_rule_errors counts REQUESTS: a batch run again for a larger pool must not count its errors twice)
+            if ((rc = S.err_sink.reserve((size_t)P.n_residual * 8))) return rc;
+            ra.rule_errors = (unsigned long long *)S.err_sink.p;
+        }
         if ((rc = mark(nullptr, 0))) return rc;
         if (e->residual_jit.function) {
             // the SPECIALIZED form: the same programs as straight-line device code (compiled at creation); the verdict kernel reads the result words
@@ -2306,7 +2312,9 @@ int pwaf_evaluate_batch(pwaf_engine *e, const pwaf_batch *in, pwaf_verdict *out,
                            bool counts_zero) -> int {
         for (int attempt = 0;; attempt++) {
             if (d_counts && !(counts_zero && attempt == 0)) HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof *d_counts, s));
+            S.retry = attempt > 0;
             int r = run_pipeline(e, S, db, d_out, d_counts, nullptr, nullptr, s, known, begins, true);
+            S.retry = false;
             S.used = true;
             S.last = s;
             S.last_own = true;

@@ -1383,11 +1383,22 @@ __device__ __forceinline__ void filter_rows(const FilterArgs &a, const uint32_t 
     };
     const bool heads = HEADS && a.n_heads != 0;
     if (heads) {
-        uint32_t lo = 0, hi = a.n;  // lower bound of base0 in off[0, n)
+        // lower bound of base0 in off[0, n): a 64-ary search like resolve_kernel's — every lane probes one of 64 evenly spaced offsets, a ballot narrows
+        // the range 64-fold (4 dependent loads for 10M requests where the binary search took 23)
+        uint32_t lo = 0, hi = a.n;  // the answer lies in [lo, hi]
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a.off[mid] < base0) lo = mid + 1;
-            else hi = mid;
+            const uint32_t span = hi - lo, step = (span + 63) / 64;
+            const uint32_t probe = lo + lane * step;
+            const bool ok = probe >= hi || a.off[probe] >= base0;  // monotone in the lane index
+            const unsigned long long m = __ballot(ok);
+            if (m == 0) {  // all 64 probes fail: the answer lies beyond the last one
+                lo += 63u * step + 1u;
+                continue;
+            }
+            const uint32_t f = (uint32_t)__builtin_ctzll(m);
+            const uint32_t nh = min(hi, lo + f * step);  // probe f holds (or is past the range)
+            lo = f == 0 ? lo : lo + (f - 1u) * step + 1u;  // probe f - 1 fails
+            hi = nh;
         }
         rq = lo;
         load_offs(rq);
@@ -1572,6 +1583,7 @@ __global__ __launch_bounds__(kFilterWaves * 64) void filter_kernel(FilterMix M) 
     else filter_rows<HEADS, 2>(a, blk - a.first_block, wave, lane);
 }
 
+template <uint32_t PARTS>
 __global__ void resolve_kernel(FilterTable B);  // (defined below, next to the wave scan it uses)
 
 // bitcount_kernel / compact_kernel: candidate bitmap -> dense ascending request list. Two launches: candidates per workgroup
@@ -1618,11 +1630,20 @@ int launch_filter(const FilterArgs *host1, uint32_t count1, const FilterArgs *de
 
 int launch_resolve(const FilterArgs *host, uint32_t count, const FilterArgs *dev, void *stream) {
     uint32_t max_slabs = 0;
-    for (uint32_t k = 0; k < count; k++) max_slabs = max(max_slabs, (uint32_t)(((uint64_t)host[k].total + kStreamSlab - 1) / kStreamSlab) - host[k].slab0);
+    uint64_t all_slabs = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t slabs = (uint32_t)(((uint64_t)host[k].total + kStreamSlab - 1) / kStreamSlab) - host[k].slab0;
+        max_slabs = max(max_slabs, slabs);
+        all_slabs += slabs;
+    }
     if (count == 0 || max_slabs == 0) return 0;
     FilterTable t{dev, count};
     void *args[] = {&t};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel), dim3((max_slabs + 3) / 4, count), dim3(256), args, 0, (hipStream_t)stream);
+    // four waves per slab when one per slab would leave the chip's wave slots empty (resolve_kernel: PARTS)
+    const char *forced = getenv("PWAF_RESOLVE_PARTS");  // (measurement / test switch, read per launch: 1 or 4)
+    const bool split = forced ? atoi(forced) == 4 : all_slabs < 4096u;  // (measured: 1.25M requests = 2 700 slabs 55 -> 40 us; 2.5M = 5 400 slabs no gain; 10M = 21 600 slabs 123 -> 190 us)
+    hipError_t e = split ? hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel<4>), dim3(max_slabs, count), dim3(256), args, 0, (hipStream_t)stream)
+                         : hipLaunchKernel(reinterpret_cast<const void *>(resolve_kernel<1>), dim3((max_slabs + 3) / 4, count), dim3(256), args, 0, (hipStream_t)stream);
     return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
@@ -1791,15 +1812,22 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
 // by what a window may reach back (three sampled bigrams) and forward (one byte): two rank queries. Slabs without a hit leave at
 // once. (The first version searched the offsets per HIT: 23 dependent loads each and an atomic per marked request — 0.07 ms on
 // benign traffic, 1.4 ms when most segments are flagged.)
+// PARTS: waves per slab (round 6). A slab's wave walks every request that overlaps its 128 KiB — 64 per step, one round trip each; when the batch's
+// slabs do not fill the chip (a 1.25M-request share: 2 700) the launch takes what its longest walk takes, 44 us. With PARTS = 4 every wave ranks the
+// whole slab's bitmap (1 KiB) but walks only the requests of ITS quarter and lists only the flagged chunks of its quarter — their places in the pair
+// list are ranks within the slab, as before.
+template <uint32_t PARTS>
 __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t kChunks = kStreamSlab / 16, kWords = kChunks / 32;  // 8192 chunk bits = 256 words per slab
     __shared__ uint32_t s_bits[4][kWords], s_rank[4][kWords];
     const FilterArgs *pa = &B.f[blockIdx.y];
-    if ((uint64_t)(pa->slab0 + blockIdx.x * 4) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
+    if ((uint64_t)(pa->slab0 + blockIdx.x * 4 / PARTS) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
     const FilterArgs a = load_descriptor(pa);
     if (a.dense_flag != nullptr && *a.dense_flag > a.dense_thresh) return;  // (the pass is walked whole this batch: no pairs, no records to reset)
-    const uint32_t wave = wave_index(), rel = blockIdx.x * 4 + wave, slab = a.slab0 + rel, lane = threadIdx.x & 63;
+    const uint32_t wave = wave_index(), rel = (blockIdx.x * 4 + wave) / PARTS, part = (blockIdx.x * 4 + wave) % PARTS, slab = a.slab0 + rel, lane = threadIdx.x & 63;
+    constexpr uint32_t kPartChunks = kChunks / PARTS;
+    const uint32_t lo_c = part * kPartChunks, hi_c = lo_c + kPartChunks;  // the wave's chunks of the slab, slab-relative
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];
     if (cnt == 0) return;
@@ -1830,8 +1858,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     };
     // 2. the requests overlapping the slab's bytes (extended by the reach of a window), in order
     const uint32_t back = 3u * a.stride;
-    const uint64_t b0 = (uint64_t)slab * kStreamSlab;
-    const uint32_t c_first = (uint32_t)(b0 / 16);  // global index of the slab's first chunk
+    const uint64_t slab_b0 = (uint64_t)slab * kStreamSlab, b0 = slab_b0 + (uint64_t)lo_c * 16u;  // (b0: the first byte of the wave's part)
+    const uint32_t c_first = (uint32_t)(slab_b0 / 16);  // global index of the slab's first chunk
     // first request with off[r + 1] + back > b0: a 64-ary search — every lane probes one of 64 evenly spaced offsets, a ballot
     // narrows the range 64-fold per step (4 dependent loads for 10M requests; the binary search this replaces took 23, about
     // 10 us of every wave's life in a kernel that is nothing but latency)
@@ -1850,7 +1878,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         lo = f == 0 ? lo : lo + (f - 1u) * step + 1u;  // probe f - 1 fails
         hi = nh;
     }
-    const uint64_t b1 = b0 + kStreamSlab;  // requests starting at or beyond b1 + 16 cannot be reached by this slab's chunks
+    const uint64_t b1 = b0 + (uint64_t)kPartChunks * 16u;  // requests starting at or beyond b1 + 16 cannot be reached by this part's chunks
     // A pass with a confirm tier lists its flagged chunks instead of marking candidates: every flagged chunk of the slab becomes ONE pair
     // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — it begins
     // where filter_kernel's atomic on the list's length put it as the slab ended (pair_base; the same atomic taken HERE, ~20k returned
@@ -1862,8 +1890,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     // another view's requests, stale staging bytes — may have flagged chunks that NO request of this batch owns. Their slots of the pair
     // list are filled with "no pair" here (confirm_kernel skips those; left unwritten they would be read as stale {request, chunk}
     // pairs: ADVICE r4). Only the chunks that end at or before off[0]: the chunk that holds off[0] belongs to the first request.
-    if (a.pairs != nullptr && (uint64_t)begin > b0) {
-        const uint32_t n_before = min((uint32_t)(((uint64_t)begin - b0) >> 4), kChunks);  // chunks [0, n_before) of this slab lie wholly before off[0]
+    if (part == 0 && a.pairs != nullptr && (uint64_t)begin > slab_b0) {
+        const uint32_t n_before = min((uint32_t)(((uint64_t)begin - slab_b0) >> 4), kChunks);  // chunks [0, n_before) of this slab lie wholly before off[0]
         for (uint32_t w = lane; w * 32u < n_before; w += 64) {
             uint32_t bw = bits[w];
             if (n_before - w * 32u < 32u) bw &= (1u << (n_before - w * 32u)) - 1u;
@@ -1899,8 +1927,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             // heads keeps the host's memset: its records are written outside the flagged requests too.
             if (a.n_heads == 0 && live && e > s) {
                 const uint32_t g_lo = s >> 4, g_hi = (e - 1u) >> 4;
-                if (g_hi >= c_first && g_lo < c_first + kChunks) {
-                    const uint32_t y0 = g_lo > c_first ? g_lo - c_first : 0u, y1 = min(g_hi - c_first, kChunks - 1u);
+                if (g_hi >= c_first + lo_c && g_lo < c_first + hi_c) {
+                    const uint32_t y0 = g_lo > c_first + lo_c ? g_lo - c_first : lo_c, y1 = min(g_hi - c_first, hi_c - 1u);
                     if (rank_of(y1 + 1u) != rank_of(y0)) a.rec[r] = 0u;
                 }
             }
@@ -1910,8 +1938,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
             // never confirmed).
             if (live && e > s) {
                 const uint32_t f_lo = s == begin ? s >> 4 : (s + 15u) >> 4, f_hi = (e - 1u) >> 4;
-                if (f_lo <= f_hi && f_hi >= c_first && f_lo < c_first + kChunks) {
-                    const uint32_t x0 = f_lo > c_first ? f_lo - c_first : 0u, x1 = min(f_hi - c_first, kChunks - 1u);
+                if (f_lo <= f_hi && f_hi >= c_first + lo_c && f_lo < c_first + hi_c) {
+                    const uint32_t x0 = f_lo > c_first + lo_c ? f_lo - c_first : lo_c, x1 = min(f_hi - c_first, hi_c - 1u);
                     for (uint32_t w = x0 >> 5; w <= (x1 >> 5); w++) {
                         const uint32_t word = bits[w];
                         uint32_t bw = word;
@@ -1933,9 +1961,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         if (live && (uint64_t)s < b1 + 16) {
             // chunks j with 16 j - back < e and 16 j + 16 >= s, clipped to the slab
             const uint32_t j_lo = s == 0 ? 0u : (s - 1u) / 16u, j_hi = (uint32_t)(((uint64_t)e + back - 1u) / 16u);
-            const uint32_t x0 = j_lo > c_first ? j_lo - c_first : 0u;
-            if (j_hi >= c_first && x0 < kChunks) {
-                const uint32_t x1 = min(j_hi - c_first, kChunks - 1u);
+            const uint32_t x0 = j_lo > c_first + lo_c ? j_lo - c_first : lo_c;
+            if (j_hi >= c_first + lo_c && x0 < hi_c) {
+                const uint32_t x1 = min(j_hi - c_first, hi_c - 1u);
                 mark = x0 <= x1 && rank_of(x1 + 1u) != rank_of(x0);
             }
         }

@@ -218,6 +218,23 @@ def test_overflow_pool_exhaustion_is_retried_not_reported():
     eng.close()
 
 
+def test_a_retried_batch_counts_its_execution_errors_once():
+    """pwaf_engine_rule_errors counts REQUESTS whose evaluation of a rule failed (the reference logs each, pingoo/rules.rs:41-45). A batch that
+    exhausts the overflow pool is run again by the synchronous entry point: the second run's errors go to a sink, not to the counters."""
+    toks = ["aa1", "bb2", "cc3", "dd4", "ee5", "ff6", "gg7", "hh8", "ii9", "jj0", "kk1", "ll2"]
+    rules = [(f"r{k}", f'http_request.url.contains("{t}") && http_request.path.length() > 1000', [B]) for k, t in enumerate(toks)]
+    rules.append(("div", "10 / (http_request.path.length() - 2) > 100", [B]))  # path "/p": a division by zero for every request, residual
+    rules.append(("all", " && ".join(f'http_request.url.contains("{t}")' for t in toks), [CAP]))
+    eng = RuleEngine(rules)
+    n = 200_000
+    batch = RequestBatch.from_requests([Request(url="/" + "-".join(toks), path="/p", host="h")]).tile(n)
+    got = eng.evaluate_batch(batch)
+    assert (got["action"] == 2).all() and (got["rule_idx"] == len(rules) - 1).all()
+    errs = eng.rule_errors(len(rules))
+    assert errs[len(toks)] == n and sum(errs) == n, errs[len(toks)]
+    eng.close()
+
+
 def test_field_against_field_predicates_and_per_rule_unsupported():
     """One request field against another on the device (pingoo/rules.rs:37-51 evaluates any expression), and a rule the device compiler
     cannot take (a bounded gap far beyond the DFA budget) failing alone: it is reported by index, never matches, the rest is unaffected."""

@@ -61,6 +61,30 @@ def test_heads_and_candidates_at_slab_and_chunk_boundaries():
     eng.close()
 
 
+@pytest.mark.parametrize("parts", ["1", "4"])
+def test_resolve_with_one_wave_and_four_waves_per_slab(parts, monkeypatch):
+    """resolve_kernel<PARTS>: a slab's flagged chunks resolved by one wave or by four (each its quarter of the slab's chunks; the launch picks by
+    the batch's slab count, PWAF_RESOLVE_PARTS forces it, read per launch). Same pairs, same verdicts: requests of every length around the
+    chunking, requests that straddle quarter and slab boundaries (2 KiB - 40 KiB fields), a batch of several slabs."""
+    monkeypatch.setenv("PWAF_RESOLVE_PARTS", parts)
+    rng = random.Random(4400)
+    rules = [("env", 'http_request.path.contains("/.env")', [B]), ("tail", 'http_request.url.ends_with("x9k2")', [CAP]),
+             ("mid", 'http_request.url.matches("(?i)union\\s+select")', [B]), ("ua", 'http_request.user_agent.contains("sqlmap")', [B])]
+    reqs = []
+    for k in range(3000):
+        pad = "q" * rng.choice([0, 1, 15, 16, 17, 31, 33, 200, 2047, 2048, 2049, 8191, 8192, 8193, 32767, 32768, 40000] if k % 50 == 0 else [0, 3, 16, 40, 90])
+        kind = rng.randrange(6)
+        url = [pad + "x9k2", pad + "x9k", "union select" + pad, pad + "UNION  SELECT", pad + "/index", "x9k2" + pad][kind]
+        reqs.append(Request(url=url, path=["/.env", "/a" + pad[:300] + "/.env", "/.en", pad[:500]][rng.randrange(4)], user_agent=["Mozilla/5.0", "sqlmap/1.7", pad[:100] + "sqlmap"][rng.randrange(3)], host="h"))
+    batch = RequestBatch.from_requests(reqs)
+    eng = RuleEngine(rules)
+    assert eng.stats()["n_filtered_groups"] >= 2
+    want = pyoracle.Oracle(rules).evaluate(batch)
+    H.assert_verdicts_equal(eng.evaluate_batch(batch), want, batch, f"parts {parts}")
+    assert len(set(want["action"].tolist())) == 3
+    eng.close()
+
+
 def test_every_request_a_candidate_and_none():
     rules = [("a", 'http_request.path.contains("/.env")', [B]), ("b", 'http_request.url.contains("zz9")', [CAP])]
     eng = RuleEngine(rules)
