@@ -69,7 +69,7 @@ def test_resolve_with_one_wave_and_four_waves_per_slab(parts, monkeypatch):
     monkeypatch.setenv("PWAF_RESOLVE_PARTS", parts)
     rng = random.Random(4400)
     rules = [("env", 'http_request.path.contains("/.env")', [B]), ("tail", 'http_request.url.ends_with("x9k2")', [CAP]),
-             ("mid", 'http_request.url.matches("(?i)union\\s+select")', [B]), ("ua", 'http_request.user_agent.contains("sqlmap")', [B])]
+             ("mid", 'http_request.url.matches("(?i)union\\\\s+select")', [B]), ("ua", 'http_request.user_agent.contains("sqlmap")', [B])]
     reqs = []
     for k in range(3000):
         pad = "q" * rng.choice([0, 1, 15, 16, 17, 31, 33, 200, 2047, 2048, 2049, 8191, 8192, 8193, 32767, 32768, 40000] if k % 50 == 0 else [0, 3, 16, 40, 90])
