@@ -553,13 +553,28 @@ __device__ __forceinline__ ListOf list_of(const ListScanArgs &a) {
     return l;
 }
 
+// (Round 6: the entries per item also have a floor common to the launch's passes — the power of two with which ALL the passes' entries fit the launch's
+// waves once, 16 at most. A pass's own rule alone let six gap passes that ride one walk list of 16k requests make 4 063 four-entry items EACH: 24k items on
+// 6 144 waves, four nearly empty items one behind the other per wave, every one the whole dependent chain of a walk — 0.084 ms for 97k entries, most of them
+// skipped by their need bit. With the common floor they are 16-entry items, one per wave: lscan_x6 0.084 -> 0.039 ms alone, 0.11 -> 0.05 in the step; the
+// 4096-rule set's gap launch 0.094 -> 0.051, its hostile stream's R-tier launch 0.236 -> 0.107. Measured and dropped: the floor counted against the waves of ONE
+// workgroup per CU — what is resident beside the attribute kernel — with the items packed into the first workgroups: fewer, fuller waves walk in lockstep
+// and are slower — a 1.25M-request share's gap launch 0.033 -> 0.044 ms, nothing gained at 10M.)
 __global__ __launch_bounds__(256) void lscan_plan_kernel(GatedTable b, uint32_t *plan /* [2 count + 1] */, uint32_t n_waves) {
     __shared__ uint32_t part[256];
+    __shared__ unsigned long long all_entries;
     const uint32_t t = threadIdx.x;
     uint32_t items = 0;
+    const uint32_t n_l = t < b.count ? list_of(b.g[t]).n_l : 0u;
+    if (t == 0) all_entries = 0ull;
+    __syncthreads();
+    if (n_l != 0u) atomicAdd(&all_entries, (unsigned long long)n_l);
+    __syncthreads();
     if (t < b.count) {
-        const uint32_t n_l = list_of(b.g[t]).n_l;
+        const uint32_t room = n_waves > b.count ? n_waves - b.count : 1u;  // (every pass may end in a partly filled item)
+        const unsigned long long per_wave = (all_entries + room - 1u) / room;
         uint32_t epi = 1;
+        while (epi < 16u && epi < per_wave) epi <<= 1;
         while (epi < 64u * kListWalks && (n_l + epi - 1) / epi > n_waves) epi <<= 1;
         items = (n_l + epi - 1) / epi;
         plan[b.count + 1 + t] = epi;
