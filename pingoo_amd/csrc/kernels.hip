@@ -1835,6 +1835,7 @@ template <uint32_t PARTS>
 __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t kChunks = kStreamSlab / 16, kWords = kChunks / 32;  // 8192 chunk bits = 256 words per slab
+    constexpr uint32_t kResolveSparse = 128;  // flagged chunks up to which a slab is resolved chunk by chunk (two rounds of 64 lanes)
     __shared__ uint32_t s_bits[4][kWords], s_rank[4][kWords];
     const FilterArgs *pa = &B.f[blockIdx.y];
     if ((uint64_t)(pa->slab0 + blockIdx.x * 4 / PARTS) * kStreamSlab >= pa->total) return;  // (the whole workgroup is past the pass's last slab)
@@ -1918,6 +1919,51 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
                 if (at < a.pair_cap) a.pairs[at] = make_uint2(kNone, 0u);
             }
         }
+    }
+    // CHUNK-DRIVEN (round 6): a slab with few flagged chunks — a benign 10M-request batch of the 1k-rule set leaves 404k pairs in 21 600 slabs, 19 per
+    // slab — does not walk its 1 300 - 2 900 requests, 64 per dependent round trip, to find the owners of 19 chunks: lane k takes the slab's k-th flagged
+    // chunk (the rank table gives the word, the word the bit), finds the request that holds the chunk's first byte by a binary search of the offsets
+    // (within 4096 requests of the slab's first: a dozen dependent loads, all lanes at once), writes the pair at ITS place (pair_base + k) and resets the
+    // records of the requests that overlap the chunk. A slab the bounds do not fit (fields shorter than 32 bytes on average, runs of empty fields) falls
+    // through to the request-driven walk below, which writes the same values.
+    if (PARTS == 1 && a.pairs != nullptr && cnt <= kResolveSparse) {
+        bool redo = false;
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            uint32_t wlo = 0, whi = kWords;  // the last word w with rank[w] <= k holds the k-th flagged chunk
+            while (wlo + 1u < whi) {
+                const uint32_t mid = (wlo + whi) >> 1;
+                if (rank[mid] <= k) wlo = mid;
+                else whi = mid;
+            }
+            uint32_t word = bits[wlo];
+            for (uint32_t skip = k - rank[wlo]; skip != 0u; skip--) word &= word - 1u;
+            const uint32_t chunk = c_first + wlo * 32u + (uint32_t)__builtin_ctz(word), byte0 = chunk * 16u;
+            if (byte0 + 16u <= begin) continue;  // (wholly before off[0]: "no pair", written above)
+            const uint32_t key = max(byte0, begin);  // (the chunk that holds off[0] belongs to the first request that has bytes)
+            uint32_t l = lo, h = min(a.n, lo + 4096u);  // the first request with off[r + 1] > key, in [l, h]
+            const uint32_t h0 = h;
+            while (l < h) {
+                const uint32_t mid = (l + h) >> 1;
+                if (a.off[mid + 1] > key) h = mid;
+                else l = mid + 1u;
+            }
+            if (l == h0) {  // not within the bound (or no request at all holds the byte: cannot be, the filter flags no chunk at or beyond off[n])
+                if (h0 < a.n) { redo = true; continue; }
+                if (pair_base + k < a.pair_cap) a.pairs[pair_base + k] = make_uint2(kNone, 0u);
+                continue;
+            }
+            if (pair_base + k < a.pair_cap) a.pairs[pair_base + k] = make_uint2(l, chunk);
+            if (a.n_heads == 0) {  // the requests with a byte in the chunk (their records are merged into by confirm_kernel: see below)
+                uint32_t r = l, steps = 0;
+                for (; r < a.n && steps < 48u; r++, steps++) {
+                    const uint32_t s = a.off[r];
+                    if (s >= byte0 + 16u) break;
+                    if (a.off[r + 1] > s) a.rec[r] = 0u;
+                }
+                if (steps == 48u) redo = true;  // (a run of empty fields)
+            }
+        }
+        if (__ballot(redo) == 0ull) return;
     }
     {
     // (software-pipelined: the offsets of the next 64 requests are in flight while these are ranked)
