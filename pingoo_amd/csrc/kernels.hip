@@ -1843,10 +1843,13 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     if (a.dense_flag != nullptr && *a.dense_flag > a.dense_thresh) return;  // (the pass is walked whole this batch: no pairs, no records to reset)
     const uint32_t wave = wave_index(), rel = (blockIdx.x * 4 + wave) / PARTS, part = (blockIdx.x * 4 + wave) % PARTS, slab = a.slab0 + rel, lane = threadIdx.x & 63;
     constexpr uint32_t kPartChunks = kChunks / PARTS;
-    const uint32_t lo_c = part * kPartChunks, hi_c = lo_c + kPartChunks;  // the wave's chunks of the slab, slab-relative
     if ((uint64_t)slab * kStreamSlab >= a.total) return;
     const uint32_t cnt = a.sub_count[rel];
     if (cnt == 0) return;
+    // a slab with few flagged chunks is resolved chunk by chunk (below) by ONE wave, whatever PARTS: the others of its four leave
+    const bool sparse = a.pairs != nullptr && cnt <= kResolveSparse;
+    if (sparse && part != 0u) return;
+    const uint32_t lo_c = sparse ? 0u : part * kPartChunks, hi_c = sparse ? kChunks : lo_c + kPartChunks;  // the wave's chunks of the slab, slab-relative
     const uint32_t *slab_bits = a.chunk_bits + (size_t)rel * kWords;
     uint32_t *bits = s_bits[wave], *rank = s_rank[wave];
     // 1. the slab's part of the pass's chunk bitmap (filter_kernel wrote it, one 64-bit word per KiB row), prefix popcounts per word
@@ -1894,7 +1897,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
         lo = f == 0 ? lo : lo + (f - 1u) * step + 1u;  // probe f - 1 fails
         hi = nh;
     }
-    const uint64_t b1 = b0 + (uint64_t)kPartChunks * 16u;  // requests starting at or beyond b1 + 16 cannot be reached by this part's chunks
+    const uint64_t b1 = slab_b0 + (uint64_t)hi_c * 16u;  // requests starting at or beyond b1 + 16 cannot be reached by this part's chunks
     // A pass with a confirm tier lists its flagged chunks instead of marking candidates: every flagged chunk of the slab becomes ONE pair
     // {the request that owns the chunk's first byte, chunk}. The slab's pairs take a contiguous part of the pass's pair list — it begins
     // where filter_kernel's atomic on the list's length put it as the slab ended (pair_base; the same atomic taken HERE, ~20k returned
@@ -1926,7 +1929,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FilterTable B) {
     // (within 4096 requests of the slab's first: a dozen dependent loads, all lanes at once), writes the pair at ITS place (pair_base + k) and resets the
     // records of the requests that overlap the chunk. A slab the bounds do not fit (fields shorter than 32 bytes on average, runs of empty fields) falls
     // through to the request-driven walk below, which writes the same values.
-    if (PARTS == 1 && a.pairs != nullptr && cnt <= kResolveSparse) {
+    if (sparse) {
         bool redo = false;
         for (uint32_t k = lane; k < cnt; k += 64) {
             uint32_t wlo = 0, whi = kWords;  // the last word w with rank[w] <= k holds the k-th flagged chunk
